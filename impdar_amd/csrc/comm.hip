@@ -1,0 +1,78 @@
+// RCCL (xGMI) communicator: one process per GPU.  The only collective on the
+// migration path is the all-gather of the trace-major input image before the
+// Kirchhoff diffraction sum (outputs are disjoint, no reduction is needed).
+#include "common.h"
+#include <rccl/rccl.h>
+
+#define IMPDAR_NCCL_CHECK(expr)                                                        \
+    do {                                                                               \
+        ncclResult_t _r = (expr);                                                      \
+        if (_r != ncclSuccess) {                                                       \
+            impdar_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,             \
+                             ncclGetErrorString(_r));                                  \
+            return IMPDAR_ERR_COMM;                                                    \
+        }                                                                              \
+    } while (0)
+
+static_assert(sizeof(ncclUniqueId) <= IMPDAR_UNIQUE_ID_BYTES, "unique id does not fit the ABI buffer");
+
+extern "C" int impdar_comm_unique_id(char id[IMPDAR_UNIQUE_ID_BYTES])
+{
+    IMPDAR_ARG_CHECK(id, "null id buffer");
+    ncclUniqueId u;
+    IMPDAR_NCCL_CHECK(ncclGetUniqueId(&u));
+    memset(id, 0, IMPDAR_UNIQUE_ID_BYTES);
+    memcpy(id, &u, sizeof(u));
+    return IMPDAR_OK;
+}
+
+extern "C" int impdar_comm_init(impdar_ctx *ctx, const char id[IMPDAR_UNIQUE_ID_BYTES], int rank, int nranks)
+{
+    IMPDAR_ARG_CHECK(ctx && id, "null context/id");
+    IMPDAR_ARG_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d of %d", rank, nranks);
+    IMPDAR_ARG_CHECK(ctx->comm == nullptr, "communicator already initialised");
+    IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ncclComm_t c = nullptr;
+    IMPDAR_NCCL_CHECK(ncclCommInitRank(&c, nranks, u, rank));
+    ctx->comm = reinterpret_cast<ncclComm *>(c);
+    ctx->rank = rank;
+    ctx->nranks = nranks;
+    return IMPDAR_OK;
+}
+
+void impdar_comm_destroy(impdar_ctx *ctx)
+{
+    if (ctx && ctx->comm) {
+        (void)ncclCommDestroy(reinterpret_cast<ncclComm_t>(ctx->comm));
+        ctx->comm = nullptr;
+    }
+}
+
+extern "C" int impdar_comm_rank(const impdar_ctx *ctx) { return ctx ? ctx->rank : IMPDAR_ERR_ARG; }
+extern "C" int impdar_comm_size(const impdar_ctx *ctx) { return ctx ? ctx->nranks : IMPDAR_ERR_ARG; }
+
+// In-place all-gather: rank r owns bytes [r*per, (r+1)*per) of `image`.
+int impdar_allgather_rows(impdar_ctx *ctx, void *image, size_t bytes_per_rank)
+{
+    IMPDAR_ARG_CHECK(ctx && ctx->comm, "communicator not initialised (impdar_comm_init)");
+    char *base = reinterpret_cast<char *>(image);
+    IMPDAR_NCCL_CHECK(ncclAllGather(base + (size_t)ctx->rank * bytes_per_rank, base, bytes_per_rank, ncclChar,
+                                    reinterpret_cast<ncclComm_t>(ctx->comm), ctx->stream));
+    return IMPDAR_OK;
+}
+
+extern "C" int impdar_comm_barrier(impdar_ctx *ctx)
+{
+    IMPDAR_ARG_CHECK(ctx, "null context");
+    IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->comm && ctx->nranks > 1) {
+        static thread_local DevBuf scratch;
+        IMPDAR_HIP_CHECK(scratch.ensure(64));
+        IMPDAR_NCCL_CHECK(ncclAllReduce(scratch.p, scratch.p, 1, ncclInt, ncclSum,
+                                        reinterpret_cast<ncclComm_t>(ctx->comm), ctx->stream));
+    }
+    IMPDAR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return IMPDAR_OK;
+}

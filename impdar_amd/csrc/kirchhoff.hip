@@ -1,0 +1,901 @@
+// Kirchhoff diffraction-summation migration for gfx950 (MI355X).
+//
+// Behaviour restated from the reference (paths relative to the ImpDAR tree):
+//   src/impdar/lib/migrationlib/mig_python.py:35-60   migrationKirchhoffLoop
+//   src/impdar/lib/migrationlib/mig_python.py:63-123  migrationKirchhoff
+//   src/impdar/lib/migrationlib/mig_cython.h:11       mig_kirch_loop (native hook)
+//
+// Three kernels:
+//   kirch_prep_kernel   time gradient (numpy.gradient semantics, :93) fused
+//                       with the (snum,tnum) -> trace-major (tnum,snum)
+//                       transpose, so one input trace is one contiguous run.
+//   kirch_exact_kernel  per-pair fp64 index math in the reference's operation
+//                       order; any dist / travel_time; float or double data.
+//   kirch_fast_kernel   the MI355X hot path: fp32 data, uniform grids.  A
+//                       workgroup owns SC=256 output samples x XB output
+//                       traces; input traces stream through an LDS ring and
+//                       the pick index / obliquity weight of an offset
+//                       n = j - xi is computed once per (sample, n) and reused
+//                       for the XB (xi, xi+n) pairs on that diagonal.
+#include "common.h"
+#include <cmath>
+#include <algorithm>
+
+#define KF_THREADS 256
+#define KF_W 512            // LDS floats per ring slot (circular window)
+
+// ===========================================================================
+// prep: gradient + transpose
+// ===========================================================================
+struct PrepParams {
+    const void *data;       // (snum, ld) row-major, column block [0,nloc)
+    int ld;
+    int snum, nloc, jlo;    // image rows written: jlo .. jlo+nloc-1
+    void *GT;               // (tnum_pad, snum)
+    void *DT;               // same or null
+    int grad_uniform;       // see impdar_hip.h
+    int precomputed;        // data already holds the gradient (mig_kirch_loop)
+    double grad_h;
+    const double *ga, *gb, *gc;
+    int clean;              // map non-finite values to 0 (fast kernel contract)
+};
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void kirch_prep_kernel(PrepParams P)
+{
+    __shared__ double tg[64][65];
+    __shared__ double td[64][65];
+    const TI *f = reinterpret_cast<const TI *>(P.data);
+    const int k0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = P.snum;
+    for (int r = ty; r < 64; r += 4) {
+        const int k = k0 + r, j = j0 + tx;
+        double g = 0.0, d = 0.0;
+        if (k < n && j < P.nloc) {
+            const size_t c = (size_t)j;
+            d = (double)f[(size_t)k * P.ld + c];
+            if (P.precomputed) {
+                g = d;
+            } else if (k == 0) {
+                const double h = P.grad_uniform ? P.grad_h : P.ga[0];
+                g = ((double)f[(size_t)1 * P.ld + c] - d) / h;
+            } else if (k == n - 1) {
+                const double h = P.grad_uniform ? P.grad_h : P.ga[n - 1];
+                g = (d - (double)f[(size_t)(k - 1) * P.ld + c]) / h;
+            } else {
+                const double fm = (double)f[(size_t)(k - 1) * P.ld + c];
+                const double fp = (double)f[(size_t)(k + 1) * P.ld + c];
+                if (P.grad_uniform) {
+                    g = (fp - fm) / (2.0 * P.grad_h);
+                } else {
+                    g = (P.ga[k] * fm + P.gb[k] * d) + P.gc[k] * fp;
+                }
+            }
+            if (sizeof(TI) == 4 && !P.precomputed) g = (double)(float)g;  // numpy keeps f32 gradients in f32
+            if (P.clean) {
+                if (!(fabs(g) <= 1.79e308)) g = 0.0;
+                if (!(fabs(d) <= 1.79e308)) d = 0.0;
+            }
+        }
+        tg[r][tx] = g;
+        td[r][tx] = d;
+    }
+    __syncthreads();
+    TO *GT = reinterpret_cast<TO *>(P.GT);
+    TO *DT = reinterpret_cast<TO *>(P.DT);
+    for (int r = ty; r < 64; r += 4) {
+        const int j = j0 + r, k = k0 + tx;
+        if (j < P.nloc && k < n) {
+            const size_t o = (size_t)(P.jlo + j) * n + k;
+            GT[o] = (TO)tg[tx][r];
+            if (DT) DT[o] = (TO)td[tx][r];
+        }
+    }
+}
+
+// ===========================================================================
+// exact kernel: reference operation order, fp64 index math, any geometry
+// ===========================================================================
+struct ExactParams {
+    const void *GT, *DT;
+    void *out;
+    int ldo;
+    int snum, tnum, xlo, xhi;
+    const double *dist, *zs, *zs2, *tt;
+    double vel, tmax, r2lim, inv_dt, tt0;
+};
+
+template <typename T, bool NEAR>
+__global__ __launch_bounds__(256) void kirch_exact_kernel(ExactParams P)
+{
+    const int ti = blockIdx.x * 256 + threadIdx.x;
+    const int xi = P.xlo + blockIdx.y;
+    if (ti >= P.snum || xi >= P.xhi) return;
+    const T *GT = reinterpret_cast<const T *>(P.GT);
+    const T *DT = reinterpret_cast<const T *>(P.DT);
+    const double dxi = P.dist[xi];
+    const double z = P.zs[ti], z2 = P.zs2[ti];
+    const int n = P.snum;
+    double far = 0.0, near = 0.0;
+    for (int j = 0; j < P.tnum; ++j) {
+        const double dx = P.dist[j] - dxi;
+        const double q = dx * dx + z2;                 // :44 (compiled with -ffp-contract=off)
+        if (q > P.r2lim) continue;                     // far outside the aperture
+        const double rs = sqrt(q);
+        const double cost = z / rs;                    // :47
+        const double t = 2.0 * rs / P.vel;             // :49
+        if (t > P.tmax) continue;                      // :52 -> term is 0 (or NaN, skipped)
+        // nearest sample, ties to the lower index (:49 argmin)
+        int k0 = (int)floor((t - P.tt0) * P.inv_dt);
+        k0 = min(max(k0, 0), n - 1);
+        while (k0 < n - 1 && P.tt[k0 + 1] <= t) ++k0;
+        while (k0 > 0 && P.tt[k0] > t) --k0;
+        const int k1 = min(k0 + 1, n - 1);
+        const int k = (fabs(P.tt[k1] - t) < fabs(P.tt[k0] - t)) ? k1 : k0;
+        const size_t o = (size_t)j * n + k;
+        const double term = (double)GT[o] * cost / P.vel;   // :53
+        if (term == term) far += term;                       // nansum
+        if (NEAR) {
+            const double term2 = (double)DT[o] * cost / (rs * rs);   // :58
+            if (term2 == term2) near += term2;
+        }
+    }
+    const double c = 1.0 / (2.0 * 3.141592653589793);
+    T *out = reinterpret_cast<T *>(P.out);
+    out[(size_t)ti * P.ldo + (xi - P.xlo)] = (T)(c * (far + near));   // :60
+}
+
+// ===========================================================================
+// fast kernel
+// ===========================================================================
+struct FastParams {
+    const float *GT, *DT;
+    float *out;
+    int ldo;
+    int snum, tnum, xlo, xhi;
+    const float *Ahi, *Alo;        // (tt[ti]/dt)^2 split hi+lo           [snum]
+    const float *wc, *wc2;         // far / near weight prefactors         [snum]
+    const float *apexw;            // 1 or 0: n==0 pair kept by the reference's own t>tmax test
+    const float2 *B;               // alpha*n^2 split hi+lo                [nb]
+    const int *hmax;               // per sample-chunk aperture half width [nchunks]
+    const int *klo, *khi;          // per (chunk, |n|) first / last sample a trace at offset n is asked for
+    int nb;                        // entries per chunk in klo/khi (and in B)
+    int zero_row;                  // index of an all-zero image row (out-of-profile traces)
+    float u0h, u0l, umaxh, umaxl;
+    int nchunks, nxt, tiles_per_xcd, G;
+};
+
+template <int XB, int S, bool NEAR>
+__global__ __launch_bounds__(KF_THREADS) void kirch_fast_kernel(FastParams P)
+{
+    constexpr int R = XB + 2 * S;            // ring slots (multiple of S)
+    constexpr int W = KF_W;
+    static_assert(R % S == 0, "ring must be a whole number of step blocks");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *ldsG = lds;
+    float *ldsD = lds + R * W;               // only when NEAR
+
+    // ---- block -> (sample chunk, trace tile), XCD-aware --------------------
+    // blocks b and b+8 share an XCD; give each XCD groups of G adjacent trace
+    // tiles (they re-read the same input traces XB steps apart -> L2 hits) and
+    // every XCD the same mix of shallow (heavy) and deep (light) chunks.
+    const int b = blockIdx.x;
+    const int xcd = b & 7, r = b >> 3;
+    const int chunk = r / P.tiles_per_xcd;
+    const int qx = r - chunk * P.tiles_per_xcd;
+    const int xt = ((qx / P.G) * 8 + xcd) * P.G + (qx % P.G);
+    if (chunk >= P.nchunks || xt >= P.nxt) return;
+
+    const int tid = threadIdx.x;
+    const int s0 = chunk * KF_THREADS;
+    const int x0 = P.xlo + xt * XB;
+    const int snum = P.snum, tnum = P.tnum;
+    const int ti_raw = s0 + tid;
+    const int ti = min(ti_raw, snum - 1);
+
+    // per-lane constants
+    const float Ah = P.Ahi[ti], Al = P.Alo[ti];
+    const float wc = P.wc[ti];
+    const float wc2 = NEAR ? P.wc2[ti] : 0.f;
+    const float apexw = P.apexw[ti];
+    const float u0h = P.u0h, u0l = P.u0l, umh = P.umaxh, uml = P.umaxl;
+
+    // uniform tile geometry
+    const int hmax = P.hmax[chunk];
+    const int *klo = P.klo + (size_t)chunk * P.nb;
+    const int *khi = P.khi + (size_t)chunk * P.nb;
+    const int nlo = max(-hmax, -(x0 + XB - 1));
+    const int nhi = min(hmax, tnum - 1 - x0);
+    const int nsteps = nhi - nlo + 1;
+    const int nblocks = (nsteps + S - 1) / S;
+    const int nsteps_pad = nblocks * S;
+    const int jbase = x0 + nlo;              // ring-relative trace 0
+
+    // window [kmin,kmax] of samples that ring-relative trace q can be asked for
+    // (host tables: pick index of the chunk's first sample at the smallest |n|
+    // the trace is used with, and of its last sample at the largest |n|)
+    auto window = [&](int q, int &kmin, int &kmax) {
+        const int pmin = max(0, q - (XB - 1)), pmax = min(q, nsteps_pad - 1);
+        const int na = nlo + pmin, nb = nlo + pmax;
+        const int lo = (na <= 0 && nb >= 0) ? 0 : min(abs(na), abs(nb));
+        const int hi = max(abs(na), abs(nb));
+        kmin = klo[min(lo, P.nb - 1)];
+        kmax = min(khi[min(hi, P.nb - 1)], kmin + W - 1);
+    };
+
+    // ---- prologue: clear the ring, stage the first XB+S-1 traces -----------
+    for (int e = tid; e < R * W * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
+    __syncthreads();
+    for (int q = 0; q < XB + S - 1; ++q) {
+        int kmin, kmax;
+        window(q, kmin, kmax);
+        const int j = jbase + q;
+        const int jr = (j >= 0 && j < tnum) ? j : P.zero_row;
+        const int slot = q % R;
+        for (int e = kmin + tid; e <= kmax; e += KF_THREADS) {
+            ldsG[slot * W + (e & (W - 1))] = P.GT[(size_t)jr * snum + e];
+            if (NEAR) ldsD[slot * W + (e & (W - 1))] = P.DT[(size_t)jr * snum + e];
+        }
+    }
+    __syncthreads();
+
+    float acc[XB];
+#pragma unroll
+    for (int i = 0; i < XB; ++i) acc[i] = 0.f;
+
+    for (int blk0 = 0; blk0 < nblocks; blk0 += R / S) {
+#pragma unroll
+        for (int bb = 0; bb < R / S; ++bb) {
+            const int blk = blk0 + bb;
+            if (blk >= nblocks) break;
+            // -- issue the global loads of the S traces the next block adds
+            // (unconditional: the element index is clamped into the trace and
+            // out-of-profile traces read the image's all-zero row; anything
+            // landing outside the trace's window is never consumed)
+            float pfG[S][2], pfD[S][2];
+            int pk[S];
+            const bool more = (blk + 1 < nblocks);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                pfG[s][0] = pfG[s][1] = 0.f;
+                pfD[s][0] = pfD[s][1] = 0.f;
+                pk[s] = 0;
+                if (more) {
+                    const int q = (blk + 1) * S + XB - 1 + s;
+                    int kmin, kmax;
+                    window(q, kmin, kmax);
+                    pk[s] = kmin;
+                    const int j = jbase + q;
+                    const int jr = (j >= 0 && j < tnum) ? j : P.zero_row;
+                    const float *src = P.GT + (size_t)jr * snum;
+                    const int e0 = min(kmin + tid, snum - 1), e1 = min(kmin + tid + KF_THREADS, snum - 1);
+                    pfG[s][0] = src[e0];
+                    pfG[s][1] = src[e1];
+                    if (NEAR) {
+                        const float *srd = P.DT + (size_t)jr * snum;
+                        pfD[s][0] = srd[e0];
+                        pfD[s][1] = srd[e1];
+                    }
+                }
+            }
+            // -- S offset steps on the resident ring
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int pm = bb * S + s;                 // step index mod R (compile time)
+                const int n = nlo + blk * S + s;
+                const float2 Bn = P.B[abs(n)];
+                // q = A + B in double-float
+                const float sh = Ah + Bn.x;
+                const float bv = sh - Ah;
+                const float er = (Ah - (sh - bv)) + (Bn.x - bv);
+                const float sl = er + (Al + Bn.y);
+                const float sc = fmaxf(sh, 1e-30f);
+                const float y = __builtin_amdgcn_rsqf(sc);  // 1/u
+                const float r0 = sc * y;                    // u ~ sqrt(q)
+                const float e = fmaf(-r0, r0, sc) + sl;     // q - r0^2
+                const float c = e * (0.5f * y);             // Newton correction, u = r0 + c
+                float kf = rintf(r0 - u0h);
+                const float d = ((r0 - kf) - u0h) + (c - u0l);
+                kf += (d > 0.5f) ? 1.f : 0.f;               // nearest sample, ties -> lower index
+                kf -= (d <= -0.5f) ? 1.f : 0.f;
+                const bool keep = ((r0 - umh) + (c - uml)) <= 0.f;   // t <= max travel time
+                float w = keep ? wc * y : 0.f;
+                float w2 = NEAR ? (w * y) * (y * wc2) : 0.f;
+                if (n == 0) { w *= apexw; w2 *= apexw; }
+                const int kidx = max((int)kf, 0) & (W - 1);
+#pragma unroll
+                for (int i = 0; i < XB; ++i) {
+                    const int slot = (pm + i) % R;
+                    acc[i] = fmaf(w, ldsG[slot * W + kidx], acc[i]);
+                    if (NEAR) acc[i] = fmaf(w2, ldsD[slot * W + kidx], acc[i]);
+                }
+            }
+            // -- publish the prefetched traces for the next block
+            if (more) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const int slot = ((bb + 1) * S + XB - 1 + s) % R;
+                    const int e0 = pk[s] + tid, e1 = e0 + KF_THREADS;
+                    ldsG[slot * W + (e0 & (W - 1))] = pfG[s][0];
+                    ldsG[slot * W + (e1 & (W - 1))] = pfG[s][1];
+                    if (NEAR) {
+                        ldsD[slot * W + (e0 & (W - 1))] = pfD[s][0];
+                        ldsD[slot * W + (e1 & (W - 1))] = pfD[s][1];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    if (ti_raw < snum) {
+        float *o = P.out + (size_t)ti_raw * P.ldo + (x0 - P.xlo);
+#pragma unroll
+        for (int i = 0; i < XB; ++i)
+            if (x0 + i < P.xhi) o[i] = acc[i];
+    }
+}
+
+// ===========================================================================
+// host side
+// ===========================================================================
+struct impdar_kirch_plan {
+    impdar_ctx *ctx = nullptr;
+    int dtype = IMPDAR_F32, snum = 0, tnum = 0, tnum_pad = 0, nranks = 1;
+    int nearfield = 0, mode = IMPDAR_KIRCH_EXACT;
+    int grad_uniform = 0;
+    double grad_h = 1.0, vel = 0, tmax = 0, dt = 1, dx = 1, tt0 = 0, alpha = 1;
+    bool uniform = false;
+    // device tables
+    DevBuf d_dist, d_tt, d_zs, d_zs2, d_ga, d_gb, d_gc;
+    DevBuf GT, DT;
+    DevBuf d_Ahi, d_Alo, d_wc, d_wc2, d_apexw, d_B, d_hmax, d_klo, d_khi;
+    int nb = 0;
+    // host copies for pair counting
+    std::vector<int> h_half;       // exact aperture half-width per sample (uniform grids)
+    float u0h = 0, u0l = 0, umaxh = 0, umaxl = 0;
+    int nchunks = 0;
+    // ring of HIP-event sets so a timed loop can read per-step kernel
+    // durations afterwards without synchronising inside the loop
+    static constexpr int NSLOT = 64;
+    hipEvent_t evs[NSLOT][6] = {};
+    bool haves[NSLOT][3] = {};
+    int slot = 0;
+    int xb = 32;                   // fast-kernel trace tile
+};
+
+static void split2(double v, float &hi, float &lo)
+{
+    hi = (float)v;
+    lo = (float)(v - (double)hi);
+}
+
+static int upload(DevBuf &b, const void *src, size_t bytes)
+{
+    IMPDAR_HIP_CHECK(b.ensure(bytes ? bytes : 8));
+    if (bytes) IMPDAR_HIP_CHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return IMPDAR_OK;
+}
+
+static int fast_xb_from_env()
+{
+    const char *e = getenv("IMPDAR_KIRCH_XB");
+    if (e) {
+        int v = atoi(e);
+        if (v == 16 || v == 32) return v;
+    }
+    return 32;
+}
+
+extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, int tnum,
+                                        const double *dist_m, const double *tt_sec, double vel,
+                                        int nearfield, int grad_uniform, double grad_h,
+                                        const double *ga, const double *gb, const double *gc,
+                                        int mode, int nranks, impdar_kirch_plan **out)
+{
+    IMPDAR_ARG_CHECK(ctx && out, "null context/plan pointer");
+    IMPDAR_ARG_CHECK(dtype == IMPDAR_F32 || dtype == IMPDAR_F64, "dtype must be 0 (f32) or 1 (f64)");
+    IMPDAR_ARG_CHECK(snum >= 2 && tnum >= 1, "need snum >= 2 and tnum >= 1 (got %d, %d)", snum, tnum);
+    IMPDAR_ARG_CHECK(dist_m && tt_sec, "dist/travel_time must not be null");
+    IMPDAR_ARG_CHECK(vel > 0, "vel must be positive");
+    IMPDAR_ARG_CHECK(nranks >= 1, "nranks must be >= 1");
+    IMPDAR_ARG_CHECK(grad_uniform || (ga && gb && gc), "non-uniform gradient needs ga/gb/gc");
+    IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
+
+    impdar_kirch_plan *p = new impdar_kirch_plan();
+    p->ctx = ctx;
+    p->dtype = dtype;
+    p->snum = snum;
+    p->tnum = tnum;
+    p->nranks = nranks;
+    p->tnum_pad = ((tnum + nranks - 1) / nranks) * nranks;
+    p->nearfield = nearfield ? 1 : 0;
+    p->grad_uniform = grad_uniform;
+    p->grad_h = grad_h;
+    p->vel = vel;
+    p->xb = fast_xb_from_env();
+
+    // ---- geometry analysis ------------------------------------------------
+    double tmax = tt_sec[0];
+    bool increasing = true;
+    for (int k = 1; k < snum; ++k) {
+        tmax = std::max(tmax, tt_sec[k]);
+        if (!(tt_sec[k] > tt_sec[k - 1])) increasing = false;
+    }
+    p->tmax = tmax;
+    if (!increasing) {
+        delete p;
+        impdar_set_error("travel_time must be strictly increasing");
+        return IMPDAR_ERR_ARG;
+    }
+    const double dt = (tt_sec[snum - 1] - tt_sec[0]) / (snum - 1);
+    bool uni_t = dt > 0;
+    for (int k = 0; k < snum && uni_t; ++k)
+        if (std::fabs(tt_sec[k] - (tt_sec[0] + k * dt)) > 1e-9 * dt) uni_t = false;
+    double dx = 1.0;
+    bool uni_x = true;
+    if (tnum >= 2) {
+        dx = (dist_m[tnum - 1] - dist_m[0]) / (tnum - 1);
+        uni_x = dx > 0;
+        for (int j = 0; j < tnum && uni_x; ++j)
+            if (std::fabs(dist_m[j] - (dist_m[0] + j * dx)) > 1e-9 * dx) uni_x = false;
+    }
+    p->dt = dt;
+    p->dx = dx;
+    p->tt0 = tt_sec[0];
+    p->uniform = uni_t && uni_x;
+    const double sa = 2.0 * dx / (vel * dt);       // samples of moveout per trace at far offset
+    p->alpha = sa * sa;
+    const bool window_ok = (KF_THREADS + sa * (p->xb - 1) + 8.0) <= (double)KF_W;
+
+    if (mode == IMPDAR_KIRCH_AUTO)
+        mode = (dtype == IMPDAR_F32 && p->uniform && window_ok) ? IMPDAR_KIRCH_FAST : IMPDAR_KIRCH_EXACT;
+    if (mode == IMPDAR_KIRCH_FAST) {
+        if (dtype != IMPDAR_F32 || !p->uniform || !window_ok) {
+            delete p;
+            impdar_set_error("fast Kirchhoff kernel needs float32 data on uniform dist/travel_time grids "
+                             "with moveout 2dx/(v dt) <= %.1f samples per trace",
+                             (KF_W - KF_THREADS - 8.0) / (fast_xb_from_env() - 1));
+            return IMPDAR_ERR_UNSUPPORTED;
+        }
+    }
+    p->mode = mode;
+
+    int rc = IMPDAR_OK;
+    auto fail = [&](int code) {
+        delete p;
+        return code;
+    };
+    const size_t esz = impdar_dtype_size(dtype);
+    const size_t img = (size_t)(p->tnum_pad + 1) * snum * esz;   // + one all-zero row
+    if (p->GT.ensure(img) != hipSuccess) {
+        impdar_set_error("hipMalloc of %zu-byte gradient image failed", img);
+        return fail(IMPDAR_ERR_HIP);
+    }
+    (void)hipMemsetAsync(p->GT.p, 0, img, ctx->stream);
+    if (p->nearfield) {
+        if (p->DT.ensure(img) != hipSuccess) {
+            impdar_set_error("hipMalloc of %zu-byte data image failed", img);
+            return fail(IMPDAR_ERR_HIP);
+        }
+        (void)hipMemsetAsync(p->DT.p, 0, img, ctx->stream);
+    }
+    if (!grad_uniform) {
+        if ((rc = upload(p->d_ga, ga, snum * 8)) || (rc = upload(p->d_gb, gb, snum * 8)) ||
+            (rc = upload(p->d_gc, gc, snum * 8)))
+            return fail(rc);
+    }
+    // exact-kernel tables (also used by count_pairs)
+    {
+        std::vector<double> zs(snum), zs2(snum);
+        for (int k = 0; k < snum; ++k) {
+            zs[k] = vel * tt_sec[k] / 2.0;          // mig_python.py:101
+            zs2[k] = zs[k] * zs[k];                 // :102
+        }
+        if ((rc = upload(p->d_dist, dist_m, (size_t)tnum * 8)) || (rc = upload(p->d_tt, tt_sec, (size_t)snum * 8)) ||
+            (rc = upload(p->d_zs, zs.data(), (size_t)snum * 8)) || (rc = upload(p->d_zs2, zs2.data(), (size_t)snum * 8)))
+            return fail(rc);
+    }
+    // aperture half width per sample (uniform grids): largest n with t <= tmax
+    if (p->uniform) {
+        p->h_half.resize(snum);
+        const double um = tmax / dt;
+        for (int k = 0; k < snum; ++k) {
+            const double a = tt_sec[k] / dt;
+            const double rem = um * um - a * a;
+            p->h_half[k] = rem < 0 ? -1 : (int)std::floor(std::sqrt(rem / p->alpha) + 1e-12);
+        }
+    }
+    if (mode == IMPDAR_KIRCH_FAST) {
+        const int nch = (snum + KF_THREADS - 1) / KF_THREADS;
+        p->nchunks = nch;
+        std::vector<float> Ahi(snum), Alo(snum), wc(snum), wc2(snum), apexw(snum);
+        std::vector<int> hmax(nch, 0);
+        const double half = vel * dt / 2.0;         // metres per sample of two-way time
+        for (int k = 0; k < snum; ++k) {
+            const double a = tt_sec[k] / dt;
+            split2(a * a, Ahi[k], Alo[k]);
+            wc[k] = (float)(a / (2.0 * M_PI * vel));                 // cos(theta)/vel/(2 pi) = a*y*...
+            wc2[k] = (float)(a / (2.0 * M_PI * half * half));        // cos(theta)/rs^2/(2 pi) = a*y^3*...
+            // the reference's own test for the apex pair (n = 0), in its fp64 operation order
+            const double zs = vel * tt_sec[k] / 2.0;
+            const double t0 = 2.0 * std::sqrt(zs * zs) / vel;
+            apexw[k] = (t0 > tmax) ? 0.f : 1.f;
+        }
+        int hglob = 0;
+        std::vector<double> cmin(nch), cmax(nch);
+        for (int c = 0; c < nch; ++c) {
+            double amin = 1e300, amax = 0;
+            int h = 0;
+            for (int k = c * KF_THREADS; k < std::min(snum, (c + 1) * KF_THREADS); ++k) {
+                const double a = tt_sec[k] / dt;
+                amin = std::min(amin, a * a);
+                amax = std::max(amax, a * a);
+                h = std::max(h, p->h_half[k] + 1);
+            }
+            hmax[c] = h;
+            hglob = std::max(hglob, h);
+            cmin[c] = amin;
+            cmax[c] = amax;
+        }
+        const int nb = hglob + 64;
+        p->nb = nb;
+        std::vector<float2> B(nb);
+        for (int n = 0; n < nb; ++n) split2(p->alpha * (double)n * (double)n, B[n].x, B[n].y);
+        // staging windows: smallest / largest sample index any lane of chunk c
+        // can pick at offset |n| (one guard sample each side)
+        std::vector<int> klo((size_t)nch * nb), khi((size_t)nch * nb);
+        const double u0 = tt_sec[0] / dt;
+        for (int c = 0; c < nch; ++c)
+            for (int n = 0; n < nb; ++n) {
+                const double bn = p->alpha * (double)n * (double)n;
+                const double ulo = std::sqrt(cmin[c] + bn) - u0, uhi = std::sqrt(cmax[c] + bn) - u0;
+                klo[(size_t)c * nb + n] = std::max(0, (int)std::floor(ulo) - 1);
+                khi[(size_t)c * nb + n] = std::min(snum - 1, (int)std::ceil(uhi) + 1);
+            }
+        split2(tt_sec[0] / dt, p->u0h, p->u0l);
+        split2(tmax / dt, p->umaxh, p->umaxl);
+        if ((rc = upload(p->d_Ahi, Ahi.data(), snum * 4)) || (rc = upload(p->d_Alo, Alo.data(), snum * 4)) ||
+            (rc = upload(p->d_wc, wc.data(), snum * 4)) || (rc = upload(p->d_wc2, wc2.data(), snum * 4)) ||
+            (rc = upload(p->d_apexw, apexw.data(), snum * 4)) || (rc = upload(p->d_B, B.data(), (size_t)nb * 8)) ||
+            (rc = upload(p->d_hmax, hmax.data(), nch * 4)) || (rc = upload(p->d_klo, klo.data(), klo.size() * 4)) ||
+            (rc = upload(p->d_khi, khi.data(), khi.size() * 4)))
+            return fail(rc);
+    }
+    for (int s = 0; s < impdar_kirch_plan::NSLOT; ++s)
+        for (int i = 0; i < 6; ++i)
+            if (hipEventCreate(&p->evs[s][i]) != hipSuccess) {
+                impdar_set_error("hipEventCreate failed");
+                return fail(IMPDAR_ERR_HIP);
+            }
+    *out = p;
+    return IMPDAR_OK;
+}
+
+extern "C" void impdar_kirch_plan_destroy(impdar_kirch_plan *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    for (int s = 0; s < impdar_kirch_plan::NSLOT; ++s)
+        for (int i = 0; i < 6; ++i)
+            if (p->evs[s][i]) (void)hipEventDestroy(p->evs[s][i]);
+    delete p;
+}
+
+extern "C" int impdar_kirch_plan_mode(const impdar_kirch_plan *p) { return p ? p->mode : IMPDAR_ERR_ARG; }
+extern "C" int impdar_kirch_plan_tnum_pad(const impdar_kirch_plan *p) { return p ? p->tnum_pad : IMPDAR_ERR_ARG; }
+
+static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int jlo, int nloc, int precomputed)
+{
+    IMPDAR_ARG_CHECK(p && d_data, "null plan/data");
+    IMPDAR_ARG_CHECK(jlo >= 0 && nloc >= 0 && jlo + nloc <= p->tnum_pad && ld >= nloc,
+                     "column block [%d,%d) with ld %d does not fit the plan (tnum_pad %d)", jlo, jlo + nloc, ld,
+                     p->tnum_pad);
+    IMPDAR_HIP_CHECK(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    // a prep opens a new step: move to the next event slot
+    p->slot = (p->slot + 1) % impdar_kirch_plan::NSLOT;
+    p->haves[p->slot][0] = p->haves[p->slot][1] = p->haves[p->slot][2] = false;
+    hipEvent_t *ev = p->evs[p->slot];
+    IMPDAR_HIP_CHECK(hipEventRecord(ev[0], st));
+    if (nloc > 0) {
+        PrepParams P;
+        P.data = d_data;
+        P.ld = ld;
+        P.snum = p->snum;
+        P.nloc = nloc;
+        P.jlo = jlo;
+        P.GT = p->GT.p;
+        P.DT = p->nearfield ? p->DT.p : nullptr;
+        P.grad_uniform = p->grad_uniform;
+        P.precomputed = precomputed;
+        P.grad_h = p->grad_h;
+        P.ga = p->d_ga.as<double>();
+        P.gb = p->d_gb.as<double>();
+        P.gc = p->d_gc.as<double>();
+        P.clean = (p->mode == IMPDAR_KIRCH_FAST);
+        dim3 grid((nloc + 63) / 64, (p->snum + 63) / 64);
+        if (p->dtype == IMPDAR_F32)
+            hipLaunchKernelGGL((kirch_prep_kernel<float, float>), grid, dim3(256), 0, st, P);
+        else
+            hipLaunchKernelGGL((kirch_prep_kernel<double, double>), grid, dim3(256), 0, st, P);
+        IMPDAR_HIP_CHECK(hipGetLastError());
+    }
+    IMPDAR_HIP_CHECK(hipEventRecord(ev[1], st));
+    p->haves[p->slot][0] = true;
+    return IMPDAR_OK;
+}
+
+extern "C" int impdar_kirch_prep(impdar_kirch_plan *p, const void *d_data, int ld, int jlo, int nloc)
+{
+    return kirch_prep_impl(p, d_data, ld, jlo, nloc, 0);
+}
+
+int impdar_kirch_prep_precomputed(impdar_kirch_plan *p, const void *d_grad, int ld, int jlo, int nloc)
+{
+    return kirch_prep_impl(p, d_grad, ld, jlo, nloc, 1);
+}
+
+template <int XB, int S>
+static int launch_fast(impdar_kirch_plan *p, const FastParams &P0, int ntiles, hipStream_t st)
+{
+    constexpr int R = XB + 2 * S;
+    FastParams P = P0;
+    P.nxt = ntiles;
+    P.G = 4;
+    const int per = 8 * P.G;
+    const int nxt_pad = ((ntiles + per - 1) / per) * per;
+    P.tiles_per_xcd = nxt_pad / 8;
+    const int nblk = P.nchunks * nxt_pad;
+    const size_t shmem = (size_t)R * KF_W * 4 * (p->nearfield ? 2 : 1);
+    if (p->nearfield) {
+        auto k = kirch_fast_kernel<XB, S, true>;
+        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k, dim3(nblk), dim3(KF_THREADS), shmem, st, P);
+    } else {
+        auto k = kirch_fast_kernel<XB, S, false>;
+        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k, dim3(nblk), dim3(KF_THREADS), shmem, st, P);
+    }
+    IMPDAR_HIP_CHECK(hipGetLastError());
+    return IMPDAR_OK;
+}
+
+extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, int xhi)
+{
+    IMPDAR_ARG_CHECK(p && d_out, "null plan/output");
+    IMPDAR_ARG_CHECK(0 <= xlo && xlo <= xhi && xhi <= p->tnum, "bad output trace range [%d,%d) for tnum %d", xlo,
+                     xhi, p->tnum);
+    IMPDAR_HIP_CHECK(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    hipEvent_t *ev = p->evs[p->slot];
+    IMPDAR_HIP_CHECK(hipEventRecord(ev[4], st));
+    const int nx = xhi - xlo;
+    if (nx > 0 && p->mode == IMPDAR_KIRCH_FAST) {
+        FastParams P;
+        P.GT = p->GT.as<float>();
+        P.DT = p->nearfield ? p->DT.as<float>() : nullptr;
+        P.out = reinterpret_cast<float *>(d_out);
+        P.ldo = nx;
+        P.snum = p->snum;
+        P.tnum = p->tnum;
+        P.xlo = xlo;
+        P.xhi = xhi;
+        P.Ahi = p->d_Ahi.as<float>();
+        P.Alo = p->d_Alo.as<float>();
+        P.wc = p->d_wc.as<float>();
+        P.wc2 = p->d_wc2.as<float>();
+        P.apexw = p->d_apexw.as<float>();
+        P.B = p->d_B.as<float2>();
+        P.hmax = p->d_hmax.as<int>();
+        P.klo = p->d_klo.as<int>();
+        P.khi = p->d_khi.as<int>();
+        P.nb = p->nb;
+        P.zero_row = p->tnum_pad;
+        P.u0h = p->u0h;
+        P.u0l = p->u0l;
+        P.umaxh = p->umaxh;
+        P.umaxl = p->umaxl;
+        P.nchunks = p->nchunks;
+        int rc;
+        if (p->xb == 16)
+            rc = launch_fast<16, 4>(p, P, (nx + 15) / 16, st);
+        else
+            rc = launch_fast<32, 4>(p, P, (nx + 31) / 32, st);
+        if (rc) return rc;
+    } else if (nx > 0) {
+        ExactParams P;
+        P.GT = p->GT.p;
+        P.DT = p->nearfield ? p->DT.p : nullptr;
+        P.out = d_out;
+        P.ldo = nx;
+        P.snum = p->snum;
+        P.tnum = p->tnum;
+        P.xlo = xlo;
+        P.xhi = xhi;
+        P.dist = p->d_dist.as<double>();
+        P.zs = p->d_zs.as<double>();
+        P.zs2 = p->d_zs2.as<double>();
+        P.tt = p->d_tt.as<double>();
+        P.vel = p->vel;
+        P.tmax = p->tmax;
+        const double rlim = p->vel * p->tmax / 2.0;
+        P.r2lim = rlim * rlim * (1.0 + 1e-9);
+        P.inv_dt = 1.0 / p->dt;
+        P.tt0 = p->tt0;
+        dim3 grid((p->snum + 255) / 256, nx);
+        if (p->dtype == IMPDAR_F32) {
+            if (p->nearfield)
+                hipLaunchKernelGGL((kirch_exact_kernel<float, true>), grid, dim3(256), 0, st, P);
+            else
+                hipLaunchKernelGGL((kirch_exact_kernel<float, false>), grid, dim3(256), 0, st, P);
+        } else {
+            if (p->nearfield)
+                hipLaunchKernelGGL((kirch_exact_kernel<double, true>), grid, dim3(256), 0, st, P);
+            else
+                hipLaunchKernelGGL((kirch_exact_kernel<double, false>), grid, dim3(256), 0, st, P);
+        }
+        IMPDAR_HIP_CHECK(hipGetLastError());
+    }
+    IMPDAR_HIP_CHECK(hipEventRecord(ev[5], st));
+    p->haves[p->slot][2] = true;
+    return IMPDAR_OK;
+}
+
+// defined in comm.hip
+int impdar_allgather_rows(impdar_ctx *ctx, void *image, size_t bytes_per_rank);
+
+extern "C" int impdar_kirch_allgather(impdar_kirch_plan *p)
+{
+    IMPDAR_ARG_CHECK(p, "null plan");
+    IMPDAR_ARG_CHECK(p->nranks == p->ctx->nranks, "plan was built for %d ranks but the communicator has %d",
+                     p->nranks, p->ctx->nranks);
+    IMPDAR_HIP_CHECK(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    hipEvent_t *ev = p->evs[p->slot];
+    IMPDAR_HIP_CHECK(hipEventRecord(ev[2], st));
+    if (p->nranks > 1) {
+        const size_t per = (size_t)(p->tnum_pad / p->nranks) * p->snum * impdar_dtype_size(p->dtype);
+        int rc = impdar_allgather_rows(p->ctx, p->GT.p, per);
+        if (rc) return rc;
+        if (p->nearfield && (rc = impdar_allgather_rows(p->ctx, p->DT.p, per))) return rc;
+    }
+    IMPDAR_HIP_CHECK(hipEventRecord(ev[3], st));
+    p->haves[p->slot][1] = true;
+    return IMPDAR_OK;
+}
+
+extern "C" int impdar_kirch_history_ms(impdar_kirch_plan *p, int back, float *prep_ms, float *gather_ms,
+                                       float *migrate_ms)
+{
+    IMPDAR_ARG_CHECK(p, "null plan");
+    IMPDAR_ARG_CHECK(back >= 0 && back < impdar_kirch_plan::NSLOT, "history depth is %d steps",
+                     impdar_kirch_plan::NSLOT);
+    IMPDAR_HIP_CHECK(hipSetDevice(p->ctx->device));
+    const int s = ((p->slot - back) % impdar_kirch_plan::NSLOT + impdar_kirch_plan::NSLOT) % impdar_kirch_plan::NSLOT;
+    float *outs[3] = {prep_ms, gather_ms, migrate_ms};
+    for (int i = 0; i < 3; ++i) {
+        if (!outs[i]) continue;
+        *outs[i] = 0.f;
+        if (!p->haves[s][i]) continue;
+        IMPDAR_HIP_CHECK(hipEventSynchronize(p->evs[s][2 * i + 1]));
+        IMPDAR_HIP_CHECK(hipEventElapsedTime(outs[i], p->evs[s][2 * i], p->evs[s][2 * i + 1]));
+    }
+    return IMPDAR_OK;
+}
+
+extern "C" int impdar_kirch_last_ms(impdar_kirch_plan *p, float *prep_ms, float *gather_ms, float *migrate_ms)
+{
+    return impdar_kirch_history_ms(p, 0, prep_ms, gather_ms, migrate_ms);
+}
+
+extern "C" long long impdar_kirch_count_pairs(const impdar_kirch_plan *p, int xlo, int xhi)
+{
+    if (!p || !p->uniform || xlo < 0 || xhi > p->tnum || xlo > xhi) return -1;
+    long long total = 0;
+    for (int k = 0; k < p->snum; ++k) {
+        const long long h = p->h_half[k];
+        if (h < 0) continue;
+        for (int xi = xlo; xi < xhi; ++xi) {
+            const long long lo = std::max<long long>(xi - h, 0), hi = std::min<long long>(xi + h, p->tnum - 1);
+            total += hi - lo + 1;
+        }
+    }
+    return total;
+}
+
+// ---------------------------------------------------------------------------
+// one-shot host-buffer entry point
+// ---------------------------------------------------------------------------
+extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, int snum, int tnum,
+                                const double *dist_m, const double *tt_sec, double vel, int nearfield,
+                                int grad_uniform, double grad_h, const double *ga, const double *gb,
+                                const double *gc, int mode, double *out)
+{
+    IMPDAR_ARG_CHECK(ctx && data && out, "null context/data/output");
+    impdar_kirch_plan *p = nullptr;
+    int rc = impdar_kirch_plan_create(ctx, dtype, snum, tnum, dist_m, tt_sec, vel, nearfield, grad_uniform, grad_h,
+                                      ga, gb, gc, mode, 1, &p);
+    if (rc) return rc;
+    const size_t esz = impdar_dtype_size(dtype);
+    const size_t bytes = (size_t)snum * tnum * esz;
+    DevBuf din, dout;
+    auto done = [&](int code) {
+        impdar_kirch_plan_destroy(p);
+        return code;
+    };
+    if (din.ensure(bytes) != hipSuccess || dout.ensure(bytes) != hipSuccess) {
+        impdar_set_error("hipMalloc of %zu bytes failed", bytes);
+        return done(IMPDAR_ERR_HIP);
+    }
+    if (hipMemcpyAsync(din.p, data, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        impdar_set_error("H2D copy failed");
+        return done(IMPDAR_ERR_HIP);
+    }
+    if ((rc = impdar_kirch_prep(p, din.p, tnum, 0, tnum))) return done(rc);
+    if ((rc = impdar_kirch_migrate(p, dout.p, 0, tnum))) return done(rc);
+    std::vector<char> tmp;
+    void *host_dst = out;
+    if (dtype == IMPDAR_F32) {
+        tmp.resize(bytes);
+        host_dst = tmp.data();
+    }
+    if (hipMemcpyAsync(host_dst, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        impdar_set_error("D2H copy / synchronize failed: %s", hipGetErrorString(hipGetLastError()));
+        return done(IMPDAR_ERR_HIP);
+    }
+    if (dtype == IMPDAR_F32) {
+        const float *f = reinterpret_cast<const float *>(tmp.data());
+        const size_t n = (size_t)snum * tnum;
+        for (size_t i = 0; i < n; ++i) out[i] = (double)f[i];
+    }
+    return done(IMPDAR_OK);
+}
+
+// ---------------------------------------------------------------------------
+// reference-compatible native hook (mig_cython.h:11)
+// ---------------------------------------------------------------------------
+int impdar_kirch_prep_precomputed(impdar_kirch_plan *p, const void *d_grad, int ld, int jlo, int nloc);
+
+extern "C" void mig_kirch_loop(double *migdata, int tnum, int snum, double *dist, double *zs, double *zs2,
+                               double *tt_sec, double vel, double *gradD, double max_travel_time, int nearfield)
+{
+    static impdar_ctx *ctx = nullptr;
+    if (nearfield) {
+        fprintf(stderr, "impdar mig_kirch_loop: the reference prototype has no data pointer; "
+                        "nearfield needs impdar_kirchhoff()\n");
+        return;
+    }
+    if (!ctx && impdar_ctx_create(0, &ctx) != IMPDAR_OK) {
+        fprintf(stderr, "impdar mig_kirch_loop: %s\n", impdar_last_error());
+        return;
+    }
+    impdar_kirch_plan *p = nullptr;
+    double dummy = 1.0;
+    int rc = impdar_kirch_plan_create(ctx, IMPDAR_F64, snum, tnum, dist, tt_sec, vel, 0, 1, dummy, nullptr, nullptr,
+                                      nullptr, IMPDAR_KIRCH_EXACT, 1, &p);
+    if (rc) {
+        fprintf(stderr, "impdar mig_kirch_loop: %s\n", impdar_last_error());
+        return;
+    }
+    // honour the caller's depth tables and time limit (mig_python.py:98-102 computes them)
+    p->tmax = max_travel_time;
+    const size_t bytes = (size_t)snum * tnum * 8;
+    DevBuf din, dout;
+    if (hipMemcpy(p->d_zs.p, zs, (size_t)snum * 8, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(p->d_zs2.p, zs2, (size_t)snum * 8, hipMemcpyHostToDevice) == hipSuccess &&
+        din.ensure(bytes) == hipSuccess && dout.ensure(bytes) == hipSuccess &&
+        hipMemcpyAsync(din.p, gradD, bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+        impdar_kirch_prep_precomputed(p, din.p, tnum, 0, tnum) == IMPDAR_OK &&
+        impdar_kirch_migrate(p, dout.p, 0, tnum) == IMPDAR_OK &&
+        hipMemcpyAsync(migdata, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+        hipStreamSynchronize(ctx->stream) == hipSuccess) {
+        // done
+    } else {
+        fprintf(stderr, "impdar mig_kirch_loop: %s\n", impdar_last_error());
+    }
+    impdar_kirch_plan_destroy(p);
+}

@@ -1,0 +1,317 @@
+"""Host side of the MI355X migration engine.
+
+Each function keeps the signature, defaults, printed messages, in-place
+mutation of ``dat`` and error types of its reference counterpart in
+``src/impdar/lib/migrationlib/mig_python.py`` (cited per function) and hands
+the arithmetic to hand-written HIP kernels through the C ABI in
+``include/impdar_hip.h``.  The only NumPy work left on the host is O(snum) or
+O(tnum) set-up (frequency axes, gradient coefficients, velocity profile).
+"""
+from __future__ import print_function
+
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+from ... import _hip
+
+_MODES = {None: _hip.KIRCH_AUTO, 'auto': _hip.KIRCH_AUTO, 'exact': _hip.KIRCH_EXACT, 'fast': _hip.KIRCH_FAST}
+
+
+def _check_data_shape(dat):
+    """mig_python.py:646-648."""
+    if np.size(dat.data, 1) != dat.tnum or np.size(dat.data, 0) != dat.snum:
+        raise ValueError('The input array must be of size (snum, tnum)')
+
+
+def _device_data(data):
+    """float32 stays float32; everything else is processed as float64, the
+    dtype the reference's arithmetic promotes to."""
+    data = np.asarray(data)
+    if data.dtype == np.float32:
+        return np.ascontiguousarray(data), _hip.F32
+    return np.ascontiguousarray(data, dtype=np.float64), _hip.F64
+
+
+def gradient_coefficients(x):
+    """Coefficients of ``numpy.gradient(f, x, axis=0)`` (edge_order 1), which the
+    reference applies at mig_python.py:93.  Returns
+    ``(uniform, h, ga, gb, gc)``: NumPy switches to the plain central
+    difference only when every spacing is bit-identical."""
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim != 1 or x.shape[0] < 2:
+        raise ValueError('Shape of array too small to calculate a numerical gradient, '
+                         'at least (edge_order + 1) elements are required.')
+    diffx = np.diff(x)
+    if (diffx == diffx[0]).all():
+        return True, float(diffx[0]), None, None, None
+    n = x.shape[0]
+    ga = np.zeros(n)
+    gb = np.zeros(n)
+    gc = np.zeros(n)
+    dx1 = diffx[:-1]
+    dx2 = diffx[1:]
+    ga[1:-1] = -(dx2) / (dx1 * (dx1 + dx2))
+    gb[1:-1] = (dx2 - dx1) / (dx1 * dx2)
+    gc[1:-1] = dx1 / (dx2 * (dx1 + dx2))
+    ga[0] = diffx[0]
+    ga[-1] = diffx[-1]
+    return False, 1.0, ga, gb, gc
+
+
+def _kx(dat):
+    """Horizontal wavenumbers, mig_python.py:163-168 / :262-267."""
+    if np.mean(dat.trace_int) <= 0:
+        Warning("The trace spacing, variable 'dat.trace_int', should be greater than 0. "
+                "Using gradient(dat.dist) instead.")
+        trace_int = np.gradient(dat.dist)
+    else:
+        trace_int = dat.trace_int
+    return 2. * np.pi * np.fft.fftfreq(dat.tnum, d=np.mean(trace_int))
+
+
+# ---------------------------------------------------------------------------
+# Kirchhoff
+# ---------------------------------------------------------------------------
+def migrationKirchhoff(dat, vel=1.69e8, nearfield=False, mode=None):
+    """Kirchhoff diffraction-summation migration (mig_python.py:63-123).
+
+    ``mode`` (extension): None/'auto' picks the fp32 LDS-ring kernel for
+    float32 data on uniform grids and the fp64 reference-order kernel
+    otherwise; 'exact' / 'fast' force one ($IMPDAR_KIRCH_MODE overrides None).
+    Output is float64 like the reference.
+    """
+    print('Kirchhoff Migration (diffraction summation) of %.0fx%.0f matrix' % (dat.snum, dat.tnum))
+    print('Using the MI355X HIP engine')
+    _check_data_shape(dat)
+    start = time.time()
+    if mode is None:
+        mode = os.environ.get('IMPDAR_KIRCH_MODE') or None
+    if mode not in _MODES:
+        raise ValueError('mode must be one of auto, exact, fast')
+    lib = _hip.load()
+    ctx = _hip.context()
+    data, code = _device_data(dat.data)
+    tt_sec = np.ascontiguousarray(dat.travel_time / 1.0e6, dtype=np.float64)
+    uniform, h, ga, gb, gc = gradient_coefficients(tt_sec)
+    dist = np.ascontiguousarray(dat.dist, dtype=np.float64) * 1.0e3
+    if dist.shape != (dat.tnum,):
+        raise ValueError('dist must have one entry per trace')
+    out = np.empty((dat.snum, dat.tnum), dtype=np.float64)
+    _, p_dist = _hip.as_dp(dist)
+    _, p_tt = _hip.as_dp(tt_sec)
+    ka, p_ga = _hip.as_dp(ga)
+    kb, p_gb = _hip.as_dp(gb)
+    kc, p_gc = _hip.as_dp(gc)
+    rc = lib.impdar_kirchhoff(ctx, data.ctypes.data_as(C.c_void_p), code, dat.snum, dat.tnum, p_dist, p_tt,
+                              float(vel), int(bool(nearfield)), int(uniform), h, p_ga, p_gb, p_gc,
+                              _MODES[mode], out.ctypes.data_as(_hip._dp))
+    _hip.check(rc, 'impdar_kirchhoff')
+    dat.data = out
+    print('')
+    print('Kirchhoff Migration of %.0fx%.0f matrix complete in %.2f seconds'
+          % (dat.snum, dat.tnum, time.time() - start))
+    return dat
+
+
+# ---------------------------------------------------------------------------
+# Stolt
+# ---------------------------------------------------------------------------
+def migrationStolt(dat, vel=1.68e8, htaper=100, vtaper=1000):
+    """Stolt f-k migration (mig_python.py:126-208): taper, rfft2 over
+    (time, trace), Stolt stretch with linear interpolation along omega,
+    obliquity scaling, inverse transform.  float32 data stays float32 (the
+    reference's complex64 path under NumPy >= 2); everything else float64.
+    Integer data is truncated back to its dtype after the taper (:157)."""
+    print('Stolt Migration (f-k migration) of %.0fx%.0f matrix' % (dat.snum, dat.tnum))
+    _check_data_shape(dat)
+    start = time.time()
+    lib = _hip.load()
+    ctx = _hip.context()
+    src = np.asarray(dat.data)
+    pre_tapered = False
+    if not np.issubdtype(src.dtype, np.floating):
+        # integer dtypes: the taper product is truncated to the integer type
+        # before the transform (:157); do that cast on the host so the device
+        # sees exactly the reference's post-taper values
+        it = np.arange(dat.tnum)
+        ks = np.arange(dat.snum)
+        hh = np.minimum(it, it[::-1]) / htaper
+        vv = np.minimum(ks, ks[::-1]) / vtaper
+        hh[hh > 1.] = 1.
+        vv[vv > 1.] = 1.
+        src = (src * hh[None, :] * vv[:, None]).astype(src.dtype)
+        pre_tapered = True
+    data, code = _device_data(src)
+    ws = 2. * np.pi * np.fft.rfftfreq(dat.snum, d=dat.dt)
+    kx = _kx(dat)
+    print(kx.shape, ws.shape, (dat.snum // 2 + 1, dat.tnum))
+    nout = 2 * (dat.snum // 2)
+    out = np.empty((nout, dat.tnum), dtype=data.dtype)
+    _, p_kx = _hip.as_dp(kx)
+    _, p_ws = _hip.as_dp(ws)
+    ht = float('inf') if pre_tapered else float(htaper)
+    vt = float('inf') if pre_tapered else float(vtaper)
+    rc = lib.impdar_stolt(ctx, data.ctypes.data_as(C.c_void_p), code, dat.snum, dat.tnum, p_kx, p_ws,
+                          float(vel), ht, vt, out.ctypes.data_as(C.c_void_p))
+    _hip.check(rc, 'impdar_stolt')
+    dat.data = out
+    print('')
+    print('Stolt Migration of %.0fx%.0f matrix complete in %.2f seconds'
+          % (dat.snum, dat.tnum, time.time() - start))
+    return dat
+
+
+# ---------------------------------------------------------------------------
+# phase shift
+# ---------------------------------------------------------------------------
+def migrationPhaseShift(dat, vel=1.69e8, vel_fn=None, htaper=100, vtaper=1000, **genfromtxt_kwargs):
+    """Phase-shift (Gazdag) migration (mig_python.py:211-287; kernel semantics
+    :361-493).  Constant ``vel`` or a 2-column (v, z) table / ``vel_fn`` file.
+    The 3-column v(x, z) Fourier-finite-difference branch is not implemented
+     and raises NotImplementedError."""
+    print('Phase-Shift Migration of %.0fx%.0f matrix' % (dat.snum, dat.tnum))
+    _check_data_shape(dat)
+    start = time.time()
+    if not np.issubdtype(np.asarray(dat.data).dtype, np.floating):
+        # the reference's in-place ``dat.data *= H*V`` (:258) cannot cast float -> int
+        raise TypeError("Cannot cast ufunc 'multiply' output from dtype('float64') to dtype('%s') "
+                        "with casting rule 'same_kind'" % np.asarray(dat.data).dtype)
+    lib = _hip.load()
+    ctx = _hip.context()
+    data, code = _device_data(dat.data)
+    nt = int(2 ** (np.ceil(np.log(dat.snum) / np.log(2))))
+    kx = _kx(dat)
+    ws = 2. * np.pi * np.fft.fftfreq(nt, d=dat.dt)
+    if vel_fn is not None:
+        try:
+            vel = np.genfromtxt(vel_fn, **genfromtxt_kwargs)
+            print('Velocities loaded from %s.' % vel_fn)
+        except Exception:
+            raise TypeError('File %s was given for input velocity array, but cannot be loaded. '
+                            'Please reformat to txt file.' % vel_fn)
+    vmig = getVelocityProfile(dat, vel)
+    if not hasattr(vmig, '__len__'):
+        print('Constant velocity %s m/usec' % (vmig / 1e6))
+        vconst, vm, vlen, p_vm = float(vmig), None, 0, None
+    else:
+        if not hasattr(vmig, 'shape'):
+            raise ValueError('vmig needs to be an array or float')
+        if len(vmig) != dat.snum:
+            raise ValueError('Interpolated velocity profile is not the length of the number of samples in a trace.')
+        if hasattr(vmig[0], '__len__'):
+            raise NotImplementedError('2-D v(x,z) Fourier finite-difference migration is not implemented')
+        print('1-D velocity structure, Gazdag Migration')
+        vconst = 0.0
+        vm, p_vm = _hip.as_dp(vmig)
+        vlen = dat.snum
+    tt_us, p_tt = _hip.as_dp(dat.travel_time)
+    _, p_kx = _hip.as_dp(kx)
+    _, p_ws = _hip.as_dp(ws)
+    out = np.empty((dat.snum, dat.tnum), dtype=data.dtype)
+    rc = lib.impdar_phaseshift(ctx, data.ctypes.data_as(C.c_void_p), code, dat.snum, dat.tnum, nt, p_kx, p_ws,
+                               float(dat.dt), p_tt, vconst, p_vm, vlen, float(htaper), float(vtaper),
+                               out.ctypes.data_as(C.c_void_p))
+    _hip.check(rc, 'impdar_phaseshift')
+    # the reference returns float64 (ifft(...).real, :282)
+    dat.data = out.astype(np.float64)
+    print('')
+    print('Phase-Shift Migration of %.0fx%.0f matrix complete in %.2f seconds'
+          % (dat.snum, dat.tnum, time.time() - start))
+    return dat
+
+
+def migrationTimeWavenumber(dat, vel=1.69e8, vel_fn=None, htaper=100, vtaper=1000):
+    """The reference's T-K migration is a stub that only tapers the data in
+    place (mig_python.py:290-355, loop body ``continue`` at :346-347); this
+    reproduces exactly that, on the device."""
+    print('Time-Wavenumber Migration of %.0fx%.0f matrix' % (dat.snum, dat.tnum))
+    _check_data_shape(dat)
+    start = time.time()
+    if not np.issubdtype(np.asarray(dat.data).dtype, np.floating):
+        raise TypeError("Cannot cast ufunc 'multiply' output from dtype('float64') to dtype('%s') "
+                        "with casting rule 'same_kind'" % np.asarray(dat.data).dtype)
+    lib = _hip.load()
+    ctx = _hip.context()
+    data = np.array(dat.data, order='C', copy=True)
+    if data.dtype not in (np.float32, np.float64):
+        data = data.astype(np.float64)
+    rc = lib.impdar_taper(ctx, data.ctypes.data_as(C.c_void_p), _hip.dtype_code(data.dtype), dat.snum, dat.tnum,
+                          float(htaper), float(vtaper))
+    _hip.check(rc, 'impdar_taper')
+    dat.data = data
+    _kx(dat)
+    print('')
+    print('Time-Wavenumber Migration of %.0fx%.0f matrix complete in %.2f seconds'
+          % (dat.snum, dat.tnum, time.time() - start))
+    return dat
+
+
+# ---------------------------------------------------------------------------
+# velocity profile (host, O(snum))
+# ---------------------------------------------------------------------------
+def _interp_checked(x, y, xnew):
+    """Linear interpolation with scipy.interpolate.interp1d's default
+    contract: abscissae sorted first, ValueError outside their range."""
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    order = np.argsort(x, kind='mergesort')
+    x, y = x[order], y[order]
+    xnew = np.asarray(xnew, dtype=np.float64)
+    if np.any(xnew < x[0]):
+        raise ValueError('A value in x_new is below the interpolation range.')
+    if np.any(xnew > x[-1]):
+        raise ValueError('A value in x_new is above the interpolation range.')
+    hi = np.clip(np.searchsorted(x, xnew), 1, len(x) - 1)
+    lo = hi - 1
+    with np.errstate(invalid='ignore', divide='ignore'):
+        slope = (y[hi] - y[lo]) / (x[hi] - x[lo])
+    return slope * (xnew - x[lo]) + y[lo]
+
+
+def getVelocityProfile(dat, vels_in):
+    """Map a layered velocity table onto the samples of a trace
+    (mig_python.py:543-643).  Scalar -> returned unchanged; 2-column (v, z)
+    -> 1-D profile of length snum; the error cases of :572-588, :639 raise
+    ValueError as in the reference."""
+    if not hasattr(vels_in, '__len__'):
+        return vels_in
+    start = time.time()
+    print('Interpolating the velocity profile.')
+    if len(np.shape(vels_in)) != 2 or np.shape(vels_in)[1] == 1:
+        raise ValueError('If non-constant vel, inputs needs to be 2d (v, z) or (v, z, x)')
+    nlay, dimension = np.shape(vels_in)
+    vels_in = np.asarray(vels_in, dtype=np.float64)
+    vel_v = vels_in[:, 0]
+    vel_z = vels_in[:, 1]
+    twtt = np.asarray(dat.travel_time, dtype=np.float64).copy() / 1.0e6
+    if nlay == 1:
+        raise ValueError('It does not make sense to only give one layer of velocity--'
+                         'if you want constant velocity just input v')
+    elif dimension == 2:
+        zs = np.max(vel_v) / 2. * twtt
+        zs[0] = twtt[0] * vel_v[0] / 2.
+        zlo, zhi = np.nanmin(zs), np.nanmax(zs)
+        if (vel_z[0] > 1.1 * zlo and vel_z[0] / zhi > 1.0e-3) or vel_z[-1] * 1.1 < zhi:
+            raise ValueError('Your velocity data doesnt come close to covering the depths in the data')
+        if vel_z[0] > zlo:
+            vel_v = np.insert(vel_v, 0, vel_v[np.argmin(vel_z)])
+            vel_z = np.insert(vel_z, 0, zlo)
+        if vel_z[-1] < zhi:
+            vel_v = np.append(vel_v, vel_v[np.argmax(vel_z)])
+            vel_z = np.append(vel_z, zhi)
+        vel_t = 2. * vel_z / vel_v
+        tofz = _interp_checked(vel_z, vel_t, zs)
+        zoft = _interp_checked(tofz, zs, twtt)
+        vmig = 2. * np.gradient(zoft, twtt)
+    elif dimension == 3:
+        if dat.dist is None or np.all(np.asarray(dat.dist) == 0):
+            raise ValueError('The distance vector was never set.')
+        raise NotImplementedError('3-column (v, z, x) velocity tables (2-D Fourier finite-difference '
+                                  'migration) are not implemented')
+    else:
+        raise ValueError('Input must be 2d with 2 or 3 columns')
+    print('Velocity profile finished in %.2f seconds.' % (time.time() - start))
+    return vmig

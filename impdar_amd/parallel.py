@@ -1,0 +1,90 @@
+"""Sharding of a Kirchhoff migration across the GPUs of one node.
+
+Outputs are independent, so each rank owns a contiguous block of output
+traces; the only exchange is an all-gather of the trace-major input image
+(every rank prepares -- gradient + transpose -- only its own equal-width
+block of input traces).  Output blocks are sized by
+in-aperture pair count, not trace count: traces near the ends of the profile
+see roughly half the aperture of interior traces.
+
+Pure NumPy host logic; the collective itself is RCCL inside the C library
+(``impdar_kirch_allgather``).  ``exchange_host`` is the same data movement
+over ``torch.distributed`` (gloo) for CPU-side tests of the partitioning.
+"""
+import numpy as np
+
+
+def aperture_half_widths(tt_sec, dx, vel):
+    """Largest trace offset n with 2*sqrt((n dx)^2 + z^2)/vel <= t_max, per
+    output sample (-1: the sample itself is out of range)."""
+    tt = np.asarray(tt_sec, dtype=np.float64)
+    dt = (tt[-1] - tt[0]) / (len(tt) - 1)
+    alpha = (2.0 * dx / (vel * dt)) ** 2
+    um = np.max(tt) / dt
+    a = tt / dt
+    rem = um * um - a * a
+    h = np.full(len(tt), -1, dtype=np.int64)
+    ok = rem >= 0
+    h[ok] = np.floor(np.sqrt(rem[ok] / alpha) + 1e-12).astype(np.int64)
+    return h
+
+
+def trace_pair_weights(h, tnum):
+    """Number of in-aperture (output sample, input trace) pairs per output trace."""
+    h = np.asarray(h, dtype=np.int64)
+    h = h[h >= 0]
+    xi = np.arange(tnum, dtype=np.int64)
+    w = np.zeros(tnum, dtype=np.int64)
+    hs = np.sort(h)
+    csum = np.concatenate([[0], np.cumsum(hs)])
+    # sum_h min(h, m) for m = xi (left side) and m = tnum-1-xi (right side)
+    for m_arr in (xi, tnum - 1 - xi):
+        idx = np.searchsorted(hs, m_arr, side='right')      # h <= m  -> contributes h, else m
+        w += csum[idx] + (len(hs) - idx) * m_arr
+    return w + len(hs)
+
+
+def balanced_blocks(weights, nranks):
+    """Split [0, tnum) into ``nranks`` contiguous blocks of near-equal weight."""
+    w = np.asarray(weights, dtype=np.float64)
+    tnum = len(w)
+    c = np.concatenate([[0.0], np.cumsum(w)])
+    edges = [0]
+    for r in range(1, nranks):
+        target = c[-1] * r / nranks
+        e = int(np.searchsorted(c, target, side='left'))
+        e = min(max(e, edges[-1]), tnum)
+        edges.append(e)
+    edges.append(tnum)
+    return [(edges[r], edges[r + 1]) for r in range(nranks)]
+
+
+def input_shards(tnum, nranks):
+    """Equal-width input blocks (the all-gather needs equal counts); the last
+    ranks' blocks may be short or empty.  Returns (tnum_pad, [(jlo, jhi), ...])."""
+    per = (tnum + nranks - 1) // nranks
+    shards = [(min(r * per, tnum), min((r + 1) * per, tnum)) for r in range(nranks)]
+    return per * nranks, shards
+
+
+def plan_blocks(tt_sec, dx, vel, tnum, nranks):
+    """(input shards, output blocks, pair counts per output block)."""
+    h = aperture_half_widths(tt_sec, dx, vel)
+    w = trace_pair_weights(h, tnum)
+    tnum_pad, shards = input_shards(tnum, nranks)
+    blocks = balanced_blocks(w, nranks)
+    pairs = [int(w[lo:hi].sum()) for lo, hi in blocks]
+    return tnum_pad, shards, blocks, pairs
+
+
+def exchange_host(local_image, rank, nranks, per):
+    """All-gather of per-rank (per, snum) image blocks over torch.distributed
+    (any backend; used with gloo on CPU in tests).  Returns (per*nranks, snum)."""
+    import torch
+    import torch.distributed as dist
+    block = np.zeros((per, local_image.shape[1]), dtype=local_image.dtype)
+    block[:local_image.shape[0]] = local_image
+    mine = torch.from_numpy(block)
+    parts = [torch.empty_like(mine) for _ in range(nranks)]
+    dist.all_gather(parts, mine)
+    return np.concatenate([p.numpy() for p in parts], axis=0)

@@ -1,0 +1,167 @@
+/*
+ * impdar_hip.h -- C ABI of the MI355X (gfx950) migration engine.
+ *
+ * This is the drop-in boundary for the migration hot path of dlilien/ImpDAR
+ * (reference paths are relative to the ImpDAR source tree):
+ *
+ *   - the reference's only native hook is
+ *       src/impdar/lib/migrationlib/mig_cython.h:11   (mig_kirch_loop)
+ *     bound by src/impdar/lib/migrationlib/_mig_cython.pyx:19-20 and selected
+ *     in src/impdar/lib/migrationlib/__init__.py:16-19.  That exact symbol is
+ *     exported below.
+ *   - Stolt / phase-shift / T-K have no native hook in the reference; their
+ *     boundary is the Python function (mig_python.py:126, :211, :290).  The
+ *     impdar_* entry points below are what a ctypes binding of those
+ *     functions calls.
+ *
+ * Conventions: plain pointers and sizes only.  All host buffers are
+ * caller-owned, C-contiguous, row-major; radargrams have shape (snum, tnum)
+ * (a row is one time sample across all traces).  Every call is blocking
+ * unless documented otherwise, returns 0 on success or a negative
+ * impdar_status, never throws or exits.  impdar_last_error() returns a
+ * thread-local message for the last failing call.
+ */
+#ifndef IMPDAR_HIP_H
+#define IMPDAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum impdar_status {
+    IMPDAR_OK = 0,
+    IMPDAR_ERR_ARG = -1,      /* bad argument (maps to ValueError in Python)  */
+    IMPDAR_ERR_HIP = -2,      /* HIP runtime failure                           */
+    IMPDAR_ERR_FFT = -3,      /* rocFFT failure                                */
+    IMPDAR_ERR_COMM = -4,     /* RCCL failure                                  */
+    IMPDAR_ERR_NODEV = -5,    /* no usable GPU                                 */
+    IMPDAR_ERR_UNSUPPORTED = -6
+} impdar_status;
+
+typedef enum impdar_dtype { IMPDAR_F32 = 0, IMPDAR_F64 = 1 } impdar_dtype;
+
+/* Kirchhoff kernel selection.  AUTO: F64 data -> EXACT, F32 data on a uniform
+ * (dist, travel_time) grid -> FAST, otherwise EXACT. */
+typedef enum impdar_kirch_mode {
+    IMPDAR_KIRCH_AUTO = 0,
+    IMPDAR_KIRCH_EXACT = 1,   /* per-pair fp64 index math, any geometry        */
+    IMPDAR_KIRCH_FAST = 2     /* fp32 LDS-ring kernel, uniform grids only      */
+} impdar_kirch_mode;
+
+typedef struct impdar_ctx impdar_ctx;           /* device + stream + workspaces */
+typedef struct impdar_kirch_plan impdar_kirch_plan;
+
+/* ---- library / device ------------------------------------------------- */
+const char *impdar_last_error(void);
+int impdar_device_count(void);
+int impdar_ctx_create(int device, impdar_ctx **out);
+void impdar_ctx_destroy(impdar_ctx *ctx);
+int impdar_ctx_sync(impdar_ctx *ctx);
+/* raw device-memory plumbing for resident data (bench, multi-GPU) */
+int impdar_dev_alloc(impdar_ctx *ctx, size_t bytes, void **dptr);
+int impdar_dev_free(impdar_ctx *ctx, void *dptr);
+int impdar_dev_upload(impdar_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int impdar_dev_download(impdar_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int impdar_dev_memset(impdar_ctx *ctx, void *dst_dev, int value, size_t bytes);
+
+/* ---- reference-compatible native hook ---------------------------------
+ * Replaces mig_cython.h:11.  Same argument meaning as
+ * mig_python.py:35 migrationKirchhoffLoop: writes migdata (snum x tnum,
+ * row-major, float64) in place.  The reference prototype carries no `data`
+ * pointer, so nearfield != 0 cannot be honoured through it (the reference's
+ * own defect); it is rejected with a message on stderr and
+ * migdata is left untouched.  Uses device 0. */
+void mig_kirch_loop(double *migdata, int tnum, int snum, double *dist,
+                    double *zs, double *zs2, double *tt_sec, double vel,
+                    double *gradD, double max_travel_time, int nearfield);
+
+/* ---- Kirchhoff (mig_python.py:35-123) ---------------------------------
+ * One-shot host-buffer form: data (snum,tnum) of `dtype`; gradient
+ * coefficients come from impdar's host shim (they restate numpy.gradient's
+ * choice of the uniform / non-uniform formula, mig_python.py:93):
+ *   grad_uniform != 0: interior (f[k+1]-f[k-1])/(2*grad_h), ends (f1-f0)/grad_h
+ *   grad_uniform == 0: interior ga[k]*f[k-1]+gb[k]*f[k]+gc[k]*f[k+1],
+ *                      ends (f[1]-f[0])/ga[0], (f[n-1]-f[n-2])/ga[n-1]
+ * out is float64 (snum,tnum) like the reference's dat.data. */
+int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, int snum, int tnum,
+                     const double *dist_m, const double *tt_sec, double vel, int nearfield,
+                     int grad_uniform, double grad_h, const double *ga, const double *gb,
+                     const double *gc, int mode, double *out);
+
+/* Resident / sharded form.  A plan owns the trace-major gradient image
+ * GT[tnum_pad][snum] (and the data image for the near-field term), the
+ * per-sample and per-offset tables and the launch geometry.
+ *   prep     : gradient + transpose of the caller's LOCAL column block
+ *              d_data (snum x nloc, row-major, leading dimension ld) into
+ *              rows [jlo, jlo+nloc) of the image
+ *   allgather: RCCL all-gather of the image rows across the communicator
+ *              (equal blocks of tnum_pad/nranks traces per rank)
+ *   migrate  : diffraction sum for output traces [xlo,xhi) into d_out
+ *              (snum x (xhi-xlo), row-major, element type = plan dtype)
+ * All three are enqueued on the context's stream (asynchronous); call
+ * impdar_ctx_sync to wait. */
+int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, int tnum,
+                             const double *dist_m, const double *tt_sec, double vel,
+                             int nearfield, int grad_uniform, double grad_h,
+                             const double *ga, const double *gb, const double *gc,
+                             int mode, int nranks, impdar_kirch_plan **out);
+void impdar_kirch_plan_destroy(impdar_kirch_plan *plan);
+int impdar_kirch_plan_mode(const impdar_kirch_plan *plan);      /* resolved mode */
+int impdar_kirch_plan_tnum_pad(const impdar_kirch_plan *plan);
+int impdar_kirch_prep(impdar_kirch_plan *plan, const void *d_data, int ld, int jlo, int nloc);
+int impdar_kirch_allgather(impdar_kirch_plan *plan);
+int impdar_kirch_migrate(impdar_kirch_plan *plan, void *d_out, int xlo, int xhi);
+/* HIP-event durations (ms) of the last prep / allgather / migrate enqueued on
+ * the plan's stream; blocks until they have completed. */
+int impdar_kirch_last_ms(impdar_kirch_plan *plan, float *prep_ms, float *gather_ms,
+                         float *migrate_ms);
+/* same for the step `back` steps before the last one (a step starts at each
+ * impdar_kirch_prep; 64 steps of history are kept), so a timed loop can read
+ * its per-step kernel durations after the loop without synchronising in it */
+int impdar_kirch_history_ms(impdar_kirch_plan *plan, int back, float *prep_ms, float *gather_ms,
+                            float *migrate_ms);
+/* exact number of in-aperture (output sample, input trace) pairs for output
+ * traces [xlo,xhi) under the plan's geometry (uniform grids only; -1 else) */
+long long impdar_kirch_count_pairs(const impdar_kirch_plan *plan, int xlo, int xhi);
+
+/* ---- Stolt f-k (mig_python.py:126-208) --------------------------------
+ * data (snum,tnum) of dtype already tapered-cast by the caller? NO: the taper
+ * (mig_python.py:152-157) runs on the device.  kx has tnum entries, ws has
+ * snum/2+1 entries (host shim restates :161-168).  out has 2*(snum/2) rows,
+ * same dtype as data. */
+int impdar_stolt(impdar_ctx *ctx, const void *data, int dtype, int snum, int tnum,
+                 const double *kx, const double *ws, double vel, double htaper,
+                 double vtaper, void *out);
+/* resident form used by bench/tests: d_data and d_out are device pointers */
+int impdar_stolt_dev(impdar_ctx *ctx, const void *d_data, int dtype, int snum, int tnum,
+                     const double *kx, const double *ws, double vel, double htaper,
+                     double vtaper, void *d_out);
+
+/* ---- phase shift / Gazdag (mig_python.py:211-287, :361-493) ------------
+ * vmig_len == 0: constant velocity `vconst`; vmig_len == snum: 1-D v(z).
+ * kx has tnum entries, ws has nt entries (two-sided, :268), tt_us has snum
+ * entries (microseconds).  out float64/float32 (snum,tnum) = dtype. */
+int impdar_phaseshift(impdar_ctx *ctx, const void *data, int dtype, int snum, int tnum,
+                      int nt, const double *kx, const double *ws, double dt,
+                      const double *tt_us, double vconst, const double *vmig, int vmig_len,
+                      double htaper, double vtaper, void *out);
+
+/* ---- taper only (what mtype='tk' does, mig_python.py:330-335) ---------- */
+int impdar_taper(impdar_ctx *ctx, void *data_inout, int dtype, int snum, int tnum,
+                 double htaper, double vtaper);
+
+/* ---- communicator (RCCL over xGMI) ------------------------------------- */
+#define IMPDAR_UNIQUE_ID_BYTES 128
+int impdar_comm_unique_id(char id[IMPDAR_UNIQUE_ID_BYTES]);
+int impdar_comm_init(impdar_ctx *ctx, const char id[IMPDAR_UNIQUE_ID_BYTES], int rank, int nranks);
+int impdar_comm_rank(const impdar_ctx *ctx);
+int impdar_comm_size(const impdar_ctx *ctx);
+int impdar_comm_barrier(impdar_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMPDAR_HIP_H */

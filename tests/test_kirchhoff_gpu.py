@@ -1,0 +1,222 @@
+"""Parity of the HIP Kirchhoff path (through the C ABI) with the golden
+vectors of the reference and with the CPU oracle.
+
+Stated tolerances:
+  exact kernel, float64 data : max |diff| <= 1e-12 * max|ref|
+  fast kernel, float32 data  : relative L2 <= 1e-4 and max |diff| <= 1e-3 * max|ref|
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden, golden_names, make_dat, rel_l2, rel_max
+
+pytestmark = pytest.mark.gpu
+
+EXACT_TOL = 1e-12
+FAST_L2, FAST_MAX = 1e-4, 1e-3
+
+UNIFORM_FASTABLE = ['K1_kirch_farfield_ricker', 'K1n_kirch_farfield_noise', 'K2r_kirch_nearfield_ricker',
+                    'K4_kirch_t0_offset', 'K4n_kirch_pretrigger', 'K5_kirch_config1_256x512',
+                    'K6_kirch_float32']
+
+
+@pytest.mark.parametrize('name', golden_names('K'))
+def test_golden_default_mode(hip, name):
+    """RadarData.migrate('kirch') exactly as a reference user calls it."""
+    g = golden(name)
+    dat = make_dat(g)
+    ret = dat.migrate('kirch', vel=float(g['vel']), nearfield=bool(g['nearfield']))
+    assert ret is None and dat.flags.mig == 'kirch'
+    assert dat.data.dtype == np.float64 and dat.data.shape == g['expected'].shape
+    if g['data'].dtype == np.float32:
+        assert rel_l2(dat.data, g['expected']) < FAST_L2
+        assert rel_max(dat.data, g['expected']) < FAST_MAX
+    else:
+        assert rel_max(dat.data, g['expected']) < EXACT_TOL
+
+
+@pytest.mark.parametrize('name', UNIFORM_FASTABLE)
+def test_golden_fast_kernel(hip, name):
+    from impdar_amd.lib import migrationlib
+    g = golden(name)
+    dat = make_dat(g)
+    dat.data = dat.data.astype(np.float32)
+    migrationlib.migrationKirchhoff(dat, vel=float(g['vel']), nearfield=bool(g['nearfield']), mode='fast')
+    assert rel_l2(dat.data, g['expected']) < FAST_L2, rel_l2(dat.data, g['expected'])
+    assert rel_max(dat.data, g['expected']) < FAST_MAX
+
+
+@pytest.mark.parametrize('name', ['K1n_kirch_farfield_noise', 'K3_kirch_nonuniform_dist', 'K2_kirch_nearfield'])
+def test_golden_exact_kernel_float32_data(hip, name):
+    from impdar_amd.lib import migrationlib
+    g = golden(name)
+    dat = make_dat(g)
+    dat.data = dat.data.astype(np.float32)
+    migrationlib.migrationKirchhoff(dat, vel=float(g['vel']), nearfield=bool(g['nearfield']), mode='exact')
+    assert rel_l2(dat.data, g['expected']) < FAST_L2
+
+
+def test_fast_kernel_rejects_what_it_cannot_do(hip):
+    from impdar_amd.lib import migrationlib
+    g = golden('K3_kirch_nonuniform_dist')          # jittered dist
+    dat = make_dat(g)
+    dat.data = dat.data.astype(np.float32)
+    with pytest.raises(NotImplementedError):
+        migrationlib.migrationKirchhoff(dat, mode='fast')
+    g = golden('K1_kirch_farfield_ricker')           # float64 data
+    dat = make_dat(g)
+    with pytest.raises(NotImplementedError):
+        migrationlib.migrationKirchhoff(dat, mode='fast')
+    g = golden('K2_kirch_nearfield')                 # 23.7 samples of moveout per trace
+    dat = make_dat(g)
+    dat.data = dat.data.astype(np.float32)
+    with pytest.raises(NotImplementedError):
+        migrationlib.migrationKirchhoff(dat, mode='fast')
+
+
+def test_reference_native_hook_mig_kirch_loop(hip):
+    """The symbol the reference's Cython wrapper binds (mig_cython.h:11),
+    driven the way _mig_cython.pyx:50-108 drives it."""
+    g = golden('K1n_kirch_farfield_noise')
+    data = g['data']
+    snum, tnum = data.shape
+    vel = float(g['vel'])
+    tt_sec = g['travel_time'] / 1.0e6
+    gradD = np.ascontiguousarray(np.gradient(np.ascontiguousarray(data, dtype=np.float64), tt_sec, axis=0))
+    mig = np.ascontiguousarray(np.zeros_like(data, dtype=np.float64))
+    zs = np.ascontiguousarray(vel * tt_sec / 2.0)
+    zs2 = np.ascontiguousarray(zs ** 2.)
+    dist = np.ascontiguousarray(g['dist'], dtype=np.float64) * 1.0e3
+    tt = np.ascontiguousarray(tt_sec)
+    dp = C.POINTER(C.c_double)
+    hip.load().mig_kirch_loop(mig.ctypes.data_as(dp), tnum, snum, dist.ctypes.data_as(dp), zs.ctypes.data_as(dp),
+                              zs2.ctypes.data_as(dp), tt.ctypes.data_as(dp), vel, gradD.ctypes.data_as(dp),
+                              float(np.max(tt_sec)), 0)
+    assert rel_max(mig, g['expected']) < EXACT_TOL
+
+
+def test_reference_fixture_all_zeros(hip):
+    """test/test_migrationlib.py:112-114 runs Kirchhoff on 10x20 zeros."""
+    from impdar_amd.lib.NoInitRadarData import NoInitRadarData
+    from impdar_amd.lib import migrationlib
+    data = NoInitRadarData(big=True)
+    data = migrationlib.migrationKirchhoff(data)
+    assert data.data.shape == (10, 20) and not data.data.any()
+
+
+def test_bad_shape_raises_value_error(hip):
+    from impdar_amd.lib.NoInitRadarData import NoInitRadarData
+    from impdar_amd.lib import migrationlib
+    data = NoInitRadarData(big=True)
+    data.data = np.ones((1, 1))
+    with pytest.raises(ValueError):
+        migrationlib.migrationKirchhoff(data)
+
+
+def test_nan_samples_are_skipped_like_nansum(hip):
+    """mig_python.py:53 sums with nansum: a NaN input sample drops its own
+    terms and nothing else."""
+    from oracle import mig_oracle
+    from impdar_amd.lib import migrationlib
+    g = golden('K1n_kirch_farfield_noise')
+    data = g['data'].copy()
+    data[40, 10] = np.nan
+    data[41, 30] = np.nan
+    want = mig_oracle.kirchhoff(data, g['travel_time'], g['dist'], float(g['vel']))
+    assert np.isfinite(want).all()
+    for dtype, tol in ((np.float64, 1e-12), (np.float32, FAST_L2)):
+        dat = make_dat(g)
+        dat.data = data.astype(dtype)
+        migrationlib.migrationKirchhoff(dat, vel=float(g['vel']))
+        assert np.isfinite(dat.data).all()
+        assert rel_l2(dat.data, want) < tol
+
+
+@pytest.mark.parametrize('snum,tnum', [(300, 70), (257, 33), (64, 1), (2, 5), (700, 129)])
+def test_ragged_sizes_vs_oracle(hip, snum, tnum):
+    """Sizes that are not multiples of the 256-sample chunk / 32-trace tile."""
+    from impdar_amd import synth
+    from impdar_amd.kirchhoff import migrate_resident
+    from oracle import c_oracle
+    geo = synth.geometry(snum, tnum)
+    data = synth.noise_radargram(snum, tnum, seed=snum + tnum)
+    want = c_oracle.kirchhoff(data, geo['travel_time'], geo['dist'], 1.69e8)
+    ctx = hip.context()
+    out, mode, _ = migrate_resident(ctx, data, geo['dist'], geo['travel_time'], mode='exact')
+    assert mode == 'exact' and rel_max(out, want) < EXACT_TOL
+    out, mode, _ = migrate_resident(ctx, data.astype(np.float32), geo['dist'], geo['travel_time'], mode='fast')
+    assert mode == 'fast' and rel_l2(out, want) < FAST_L2
+
+
+def test_output_block_and_input_shard_equivalence(hip):
+    """The sharded API (prep per column block, migrate per output block) gives
+    the same image as the one-shot call."""
+    from impdar_amd import synth, _hip
+    from impdar_amd.kirchhoff import KirchhoffPlan, migrate_resident
+    snum, tnum = 512, 300
+    geo = synth.geometry(snum, tnum)
+    data = synth.noise_radargram(snum, tnum, seed=1).astype(np.float32)
+    ctx = hip.context()
+    full, _, _ = migrate_resident(ctx, data, geo['dist'], geo['travel_time'], mode='fast')
+    plan = KirchhoffPlan(ctx, np.float32, snum, tnum, geo['dist'], geo['travel_time'], mode='fast')
+    for jlo, jhi in [(0, 100), (100, 217), (217, 300)]:
+        blk = _hip.DeviceArray.from_host(ctx, np.ascontiguousarray(data[:, jlo:jhi]))
+        plan.prep(blk, jhi - jlo, jlo, jhi - jlo)
+        plan.sync()
+        blk.free()
+    parts = []
+    for xlo, xhi in [(0, 37), (37, 200), (200, 300)]:
+        d_out = _hip.DeviceArray(ctx, (snum, xhi - xlo), np.float32)
+        plan.migrate(d_out, xlo, xhi)
+        plan.sync()
+        parts.append(d_out.to_host())
+        d_out.free()
+    assert plan.count_pairs(0, tnum) == sum(plan.count_pairs(a, b) for a, b in [(0, 37), (37, 200), (200, 300)])
+    plan.destroy()
+    assert np.array_equal(np.concatenate(parts, axis=1), full)
+
+
+def test_full_size_properties_config3(hip):
+    """BASELINE config 3 (10000 x 4096 float32) through the fast kernel:
+    spot traces against the C oracle, linearity, the zero row, and the pair
+    count the roofline is priced in."""
+    from impdar_amd import synth, _hip
+    from impdar_amd.kirchhoff import KirchhoffPlan
+    from oracle import c_oracle
+    snum, tnum, vel = 4096, 10000, 1.69e8
+    geo = synth.geometry(snum, tnum)
+    rng = np.random.default_rng(3)
+    # band-limited noise: smooth white noise along time with a short kernel
+    x = rng.standard_normal((snum, tnum)).astype(np.float32)
+    x[2:-2] = (x[:-4] + 2 * x[1:-3] + 3 * x[2:-2] + 2 * x[3:-1] + x[4:]) / 9
+    y = np.roll(x, 17, axis=1)[::-1].copy()
+    ctx = hip.context()
+    plan = KirchhoffPlan(ctx, np.float32, snum, tnum, geo['dist'], geo['travel_time'], vel, mode='fast')
+    assert plan.count_pairs(0, tnum) == 189920188078          # 1.8992e11
+
+    def run(a):
+        d_in = _hip.DeviceArray.from_host(ctx, a)
+        d_out = _hip.DeviceArray(ctx, (snum, tnum), np.float32)
+        plan.prep(d_in, tnum, 0, tnum)
+        plan.migrate(d_out, 0, tnum)
+        plan.sync()
+        out = d_out.to_host()
+        d_in.free()
+        d_out.free()
+        return out
+
+    mx = run(x)
+    assert np.isfinite(mx).all()
+    assert not mx[0].any()                                   # z = 0 row is exactly zero
+    cols = np.array([0, 1, 4999, 5000, 9998, 9999, 3460, 777], dtype=np.int32)
+    want = c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], vel, traces=cols)
+    got = mx[:, cols]
+    assert rel_l2(got, want) < FAST_L2, rel_l2(got, want)
+    assert rel_max(got, want) < FAST_MAX
+    my = run(y)
+    mz = run((0.5 * x - 2.0 * y).astype(np.float32))
+    lin = 0.5 * mx.astype(np.float64) - 2.0 * my.astype(np.float64)
+    assert rel_l2(mz, lin) < 1e-5
+    plan.destroy()

@@ -1,0 +1,92 @@
+"""The CPU oracle against the golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+from conftest import golden, golden_names, rel_max
+from oracle import mig_oracle as o
+
+TOL = 1e-12     # observed <= 5e-16; stated tolerance for the restatement
+
+
+@pytest.mark.parametrize('name', golden_names('K'))
+def test_kirchhoff(name):
+    g = golden(name)
+    out = o.kirchhoff(g['data'], g['travel_time'], g['dist'], float(g['vel']), bool(g['nearfield']))
+    assert out.dtype == np.float64 and out.shape == g['expected'].shape
+    assert rel_max(out, g['expected']) < TOL
+
+
+@pytest.mark.parametrize('name', ['K4_kirch_t0_offset', 'K4n_kirch_pretrigger'])
+def test_kirchhoff_literal_form(name):
+    g = golden(name)
+    out = o.kirchhoff_literal(g['data'], g['travel_time'], g['dist'], float(g['vel']), bool(g['nearfield']))
+    assert rel_max(out, g['expected']) < TOL
+
+
+@pytest.mark.parametrize('name', golden_names('S'))
+def test_stolt(name):
+    g = golden(name)
+    out = o.stolt(g['data'], float(g['dt']), g['trace_int'], g['dist'], float(g['vel']),
+                  int(g['htaper']), int(g['vtaper']))
+    assert out.shape == g['expected'].shape
+    assert str(out.dtype) == str(g['expected_dtype'])
+    tol = 5e-6 if out.dtype == np.float32 else TOL
+    assert rel_max(out, g['expected']) < tol
+
+
+@pytest.mark.parametrize('name', golden_names('P1') + golden_names('P2'))
+def test_phase_shift(name):
+    g = golden(name)
+    vel = float(g['vel']) if g['vel'].ndim == 0 else g['vel']
+    out = o.phase_shift(g['data'], float(g['dt']), g['trace_int'], g['travel_time'], g['dist'], vel,
+                        int(g['htaper']), int(g['vtaper']))
+    assert rel_max(out, g['expected']) < TOL
+    vm = o.get_velocity_profile(g['travel_time'], vel)
+    assert np.array_equal(np.asarray(vm), g['vmig'])
+
+
+def test_velocity_profile():
+    g = golden('P3_velocity_profile')
+    for c in 'abc':
+        vm = o.get_velocity_profile(g['tt_' + c], g['tab_' + c])
+        assert np.array_equal(vm, g['vmig_' + c])
+    assert o.get_velocity_profile(np.arange(10.), 1.68e8) == 1.68e8
+
+
+def test_velocity_profile_errors():
+    tt = np.arange(10.)
+    bad = 1.68e8 * np.ones((10, 2))
+    bad[:, 1] = 0.
+    with pytest.raises(ValueError):
+        o.get_velocity_profile(tt, bad)
+    for shape in [(8,), (8, 1), (1, 2), (8, 4)]:
+        with pytest.raises(ValueError):
+            o.get_velocity_profile(tt, 1.68e8 * np.ones(shape))
+
+
+def test_tk_is_taper_only():
+    g = golden('T1_tk_taper_only')
+    out = o.time_wavenumber(g['data'], int(g['htaper']), int(g['vtaper']))
+    assert np.array_equal(out, g['expected'])
+
+
+def test_all_zero_fixture_stays_zero():
+    # the reference's own migration tests run on 10x20 zeros (test/test_migrationlib.py:103-135)
+    z = np.zeros((10, 20))
+    tt = np.arange(10.)
+    dist = np.arange(20.)
+    assert not o.kirchhoff(z, tt, dist).any()
+    assert not o.stolt(z, 1, 1, dist).any()
+    assert not o.phase_shift(z, 1, 1, tt, dist).any()
+
+
+def test_shape_check():
+    with pytest.raises(ValueError):
+        o.check_data_shape(np.ones((1, 1)), 10, 20)
+    o.check_data_shape(np.ones((10, 20)), 10, 20)
+
+
+def test_pair_count_matches_survey():
+    # config 1 has 3.2501e7 in-aperture pairs
+    assert o.count_pairs(512, 256, 1e-8, 1.0, 1.69e8) == 32500650
