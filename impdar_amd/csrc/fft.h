@@ -1,0 +1,77 @@
+// Small RAII wrapper over rocFFT plans (used by stolt.hip and phaseshift.hip).
+#pragma once
+#include "common.h"
+#include <rocfft/rocfft.h>
+
+#define IMPDAR_FFT_CHECK(expr)                                                          \
+    do {                                                                                \
+        rocfft_status _s = (expr);                                                      \
+        if (_s != rocfft_status_success) {                                              \
+            impdar_set_error("%s:%d: %s -> rocfft status %d", __FILE__, __LINE__, #expr, (int)_s); \
+            return IMPDAR_ERR_FFT;                                                      \
+        }                                                                               \
+    } while (0)
+
+int impdar_fft_global_setup();   // rocfft_setup once per process
+
+struct FftPlan {
+    rocfft_plan plan = nullptr;
+    rocfft_execution_info info = nullptr;
+    DevBuf work;
+    ~FftPlan() { release(); }
+    void release()
+    {
+        if (info) rocfft_execution_info_destroy(info);
+        if (plan) rocfft_plan_destroy(plan);
+        info = nullptr;
+        plan = nullptr;
+        work.release();
+    }
+    // 1-D batched transform.  stride/dist in elements of the respective type.
+    int create(rocfft_transform_type type, bool dbl, bool inplace, size_t length, size_t batch,
+               rocfft_array_type in_t, rocfft_array_type out_t, size_t in_stride, size_t in_dist,
+               size_t out_stride, size_t out_dist, double scale, hipStream_t stream)
+    {
+        release();
+        int rc = impdar_fft_global_setup();
+        if (rc) return rc;
+        rocfft_plan_description desc = nullptr;
+        IMPDAR_FFT_CHECK(rocfft_plan_description_create(&desc));
+        rocfft_status s = rocfft_plan_description_set_data_layout(desc, in_t, out_t, nullptr, nullptr, 1, &in_stride,
+                                                                  in_dist, 1, &out_stride, out_dist);
+        if (s == rocfft_status_success && scale != 1.0) s = rocfft_plan_description_set_scale_factor(desc, scale);
+        if (s == rocfft_status_success)
+            s = rocfft_plan_create(&plan, inplace ? rocfft_placement_inplace : rocfft_placement_notinplace, type,
+                                   dbl ? rocfft_precision_double : rocfft_precision_single, 1, &length, batch, desc);
+        rocfft_plan_description_destroy(desc);
+        if (s != rocfft_status_success) {
+            impdar_set_error("rocFFT plan creation failed (length %zu, batch %zu, status %d)", length, batch, (int)s);
+            return IMPDAR_ERR_FFT;
+        }
+        IMPDAR_FFT_CHECK(rocfft_execution_info_create(&info));
+        IMPDAR_FFT_CHECK(rocfft_execution_info_set_stream(info, stream));
+        size_t wb = 0;
+        IMPDAR_FFT_CHECK(rocfft_plan_get_work_buffer_size(plan, &wb));
+        if (wb) {
+            IMPDAR_HIP_CHECK(work.ensure(wb));
+            IMPDAR_FFT_CHECK(rocfft_execution_info_set_work_buffer(info, work.p, wb));
+        }
+        return IMPDAR_OK;
+    }
+    int exec(void *in, void *out)
+    {
+        void *ib[1] = {in};
+        void *ob[1] = {out};
+        IMPDAR_FFT_CHECK(rocfft_execute(plan, ib, out ? ob : nullptr, info));
+        return IMPDAR_OK;
+    }
+};
+
+// edge taper weight, reference mig_python.py:152-156: min(i, n-1-i)/taper clipped to 1
+__host__ __device__ static inline double impdar_taper_w(int i, int n, double taper)
+{
+    const int m = i < n - 1 - i ? i : n - 1 - i;
+    double w = (double)m / taper;
+    if (w > 1.0) w = 1.0;
+    return w;
+}

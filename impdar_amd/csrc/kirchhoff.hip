@@ -299,10 +299,15 @@ __global__ __launch_bounds__(KF_THREADS) void kirch_fast_kernel(FastParams P)
                 const float d = ((r0 - kf) - u0h) + (c - u0l);
                 kf += (d > 0.5f) ? 1.f : 0.f;               // nearest sample, ties -> lower index
                 kf -= (d <= -0.5f) ? 1.f : 0.f;
-                const bool keep = ((r0 - umh) + (c - uml)) <= 0.f;   // t <= max travel time
-                float w = keep ? wc * y : 0.f;
-                float w2 = NEAR ? (w * y) * (y * wc2) : 0.f;
-                if (n == 0) { w *= apexw; w2 *= apexw; }
+                bool keep = ((r0 - umh) + (c - uml)) <= 0.f;         // t <= max travel time
+                if (n == 0) {
+                    // apex pair: t is tt[ti] up to the reference's own fp64 rounding, which
+                    // the host evaluated exactly (apexw); the pick is the sample itself
+                    kf = (float)ti;
+                    keep = apexw != 0.f;
+                }
+                const float w = keep ? wc * y : 0.f;
+                const float w2 = NEAR ? (w * y) * (y * wc2) : 0.f;
                 const int kidx = max((int)kf, 0) & (W - 1);
 #pragma unroll
                 for (int i = 0; i < XB; ++i) {

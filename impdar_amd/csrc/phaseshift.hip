@@ -1,6 +1,412 @@
-// placeholder until the phase-shift kernels land (replaced in the next commit)
-#include "common.h"
-extern "C" int impdar_phaseshift(impdar_ctx *, const void *, int, int, int, int, const double *, const double *, double, const double *, double, const double *, int, double, double, void *)
-{ impdar_set_error("phaseshift not built yet"); return IMPDAR_ERR_UNSUPPORTED; }
-extern "C" int impdar_taper(impdar_ctx *, void *, int, int, int, double, double)
-{ impdar_set_error("taper not built yet"); return IMPDAR_ERR_UNSUPPORTED; }
+// Phase-shift (Gazdag) migration on gfx950 and the taper-only "T-K" stub.
+//
+// Behaviour restated from src/impdar/lib/migrationlib/mig_python.py:
+//   :211-287  migrationPhaseShift: taper (in place, d*(H*V)), zero-pad time to
+//             nt = 2^ceil(log2 snum), FK = fft2(data,(nt,tnum)), phaseShift,
+//             image = ifft_k(TK).real
+//   :396-420  constant velocity:  TK[tau,k] = sum_w 1[(v kx/2)^2 < w^2] FK[w,k] e^{i (tau+1) phi},
+//             phi = w dt sqrt(1-(v kx/2w)^2)   (recurrence FFK *= e^{i phi} per tau)
+//   :438-487  1-D v(z): per tau  FK[w,k] *= e^{i w dt Re sqrt(coss)},
+//             coss = 1-(v_tau kx/2w)^2;  FK[w,k] = 0 for good once coss <= thr_tau;
+//             TK[tau,k] = sum_w FK[w,k]
+//   :490-492  TK /= snum
+//   :290-355  migrationTimeWavenumber = taper only
+//
+// Kernel mapping: one workgroup per wavenumber k.  Each lane keeps the
+// complex state of M = nt/BLOCK frequencies in registers and walks tau in
+// tiles of TT; the per-tau sum over frequencies is a wavefront
+// reduce-scatter (DPP/shuffle butterfly, 2*TT values in ~2*TT shuffles)
+// followed by one LDS pass across the waves, so each workgroup emits 128-byte
+// contiguous runs of TK_T[k][tau].
+#include "fft.h"
+#include <mutex>
+
+template <typename T> struct Cp { T x, y; };
+
+#define PS_TT 16          // tau per tile
+
+// (snum,tnum) real -> tapered, zero-padded, transposed complex X[tnum][nt]
+template <typename T>
+__global__ __launch_bounds__(256) void ps_taper_pad_transpose(const T *__restrict__ in, Cp<T> *__restrict__ X, int snum,
+                                                              int tnum, int nt, double htaper, double vtaper)
+{
+    __shared__ T tile[64][65];
+    const int k0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int k = k0 + r, j = j0 + tx;
+        T v = 0;
+        if (k < snum && j < tnum) {
+            const double hv = impdar_taper_w(j, tnum, htaper) * impdar_taper_w(k, snum, vtaper);
+            v = (T)((double)in[(size_t)k * tnum + j] * hv);        // data *= H*V, :258
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int j = j0 + r, k = k0 + tx;
+        if (j < tnum && k < nt) {
+            Cp<T> c;
+            c.x = tile[tx][r];
+            c.y = 0;
+            X[(size_t)j * nt + k] = c;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ps_taper_inplace(T *__restrict__ d, int snum, int tnum, double htaper,
+                                                        double vtaper)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)snum * tnum) return;
+    const int k = (int)(i / tnum), j = (int)(i % tnum);
+    const double hv = impdar_taper_w(j, tnum, htaper) * impdar_taper_w(k, snum, vtaper);
+    d[i] = (T)((double)d[i] * hv);
+}
+
+// Z[tnum][snum] complex -> out (snum,tnum) real part
+template <typename T>
+__global__ __launch_bounds__(256) void ps_real_transpose(const Cp<T> *__restrict__ Z, T *__restrict__ out, int snum,
+                                                         int tnum)
+{
+    __shared__ T tile[64][65];
+    const int k0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int j = j0 + r, k = k0 + tx;
+        tile[r][tx] = (j < tnum && k < snum) ? Z[(size_t)j * snum + k].x : (T)0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int k = k0 + r, j = j0 + tx;
+        if (k < snum && j < tnum) out[(size_t)k * tnum + j] = tile[tx][r];
+    }
+}
+
+template <typename T> __device__ inline void sincos_t(T x, T *s, T *c);
+// |x| <= pi here (x = w dt sqrt(coss), |w dt| <= pi): Cody-Waite reduction by
+// pi/2 and the classic degree-7/8 minimax polynomials; ~1e-7 absolute error,
+// about 20 VALU instructions, no slow path.
+template <> __device__ inline void sincos_t<float>(float x, float *s, float *c)
+{
+    const float q = rintf(x * 0.636619772f);
+    float r = fmaf(q, -1.5707963705062866f, x);
+    r = fmaf(q, 4.37113900018624283e-8f, r);
+    const float r2 = r * r;
+    const float sp = fmaf(r * r2, fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+    const float cp = fmaf(r2 * r2, fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f),
+                                        4.166664568298827e-2f), fmaf(r2, -0.5f, 1.0f));
+    const int qi = (int)q;
+    const float ss = (qi & 1) ? cp : sp;
+    const float cc = (qi & 1) ? sp : cp;
+    *s = (qi & 2) ? -ss : ss;
+    *c = ((qi + 1) & 2) ? -cc : cc;
+}
+template <> __device__ inline void sincos_t<double>(double x, double *s, double *c) { sincos(x, s, c); }
+
+struct PsParams {
+    const void *F;          // [tnum][nt] complex
+    void *TK;               // [tnum][snum] complex
+    const double *kx;       // [tnum]
+    const double *w;        // [nt]   (zero frequency already replaced by 1e-10/dt)
+    const double *vz;       // [snum] (v(z) mode)
+    const double *thr;      // [snum] (v(z) mode): (tau/tt[-1]/1e6)^2
+    double vconst, dt;
+    int snum, tnum, nt, vz_mode;
+};
+
+// wave-level reduce-scatter of NV values: on return lane L holds in v[0] the
+// sum over the 64 lanes of value index (L >> 1) (NV == 32).
+template <typename T, int NV>
+__device__ inline void wave_reduce_scatter(T (&v)[NV], int lane)
+{
+    static_assert(NV == 32, "butterfly below is written for 32 values");
+#pragma unroll
+    for (int step = 0; step < 5; ++step) {
+        const int mask = 32 >> step;          // 32,16,8,4,2
+        const int half = 16 >> step;          // values kept after this step
+        const bool up = (lane & mask) != 0;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+            const T send = up ? v[i] : v[i + half];
+            const T keep = up ? v[i + half] : v[i];
+            v[i] = keep + __shfl_xor(send, mask, 64);
+        }
+    }
+    v[0] += __shfl_xor(v[0], 1, 64);
+}
+
+template <typename T, int BLOCK, int M, bool VZ>
+__global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
+{
+    constexpr int NW = BLOCK / 64;
+    __shared__ T red[2][NW][2 * PS_TT];
+    const int k = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Cp<T> *F = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k * P.nt;
+    Cp<T> *TK = reinterpret_cast<Cp<T> *>(P.TK) + (size_t)k * P.snum;
+    const double kxk = P.kx[k];
+
+    T fr[M], fi[M];          // complex state per owned frequency
+    T pa[M], pb[M];          // const-v: (cos phi, sin phi); v(z): (g = (kx/2w)^2, w*dt)
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int iw = tid + m * BLOCK;
+        fr[m] = fi[m] = pa[m] = pb[m] = 0;
+        if (iw < P.nt) {
+            const Cp<T> f = F[iw];
+            const double w = P.w[iw];
+            if (!VZ) {
+                const double vk = P.vconst * kxk / 2.0;
+                const double vkx2 = vk * vk;                           // :411
+                if (vkx2 < w * w) {                                    // :412 propagating only
+                    const double ph = w * P.dt * sqrt(1.0 - vkx2 / (w * w));   // :415
+                    double s, c;
+                    sincos(ph, &s, &c);
+                    pa[m] = (T)c;
+                    pb[m] = (T)s;
+                    fr[m] = f.x;
+                    fi[m] = f.y;
+                }
+            } else {
+                const double h = 0.5 * kxk / w;                         // coss = 1 - (v h)^2, :458
+                pa[m] = (T)(h * h);
+                pb[m] = (T)(w * P.dt);
+                fr[m] = f.x;
+                fi[m] = f.y;
+            }
+        }
+    }
+
+    const int ntile = (P.snum + PS_TT - 1) / PS_TT;
+    for (int tile = 0; tile < ntile; ++tile) {
+        T acc[2 * PS_TT];
+#pragma unroll
+        for (int i = 0; i < 2 * PS_TT; ++i) acc[i] = 0;
+        const int tau0 = tile * PS_TT;
+        if (!VZ) {
+#pragma unroll
+            for (int t = 0; t < PS_TT; ++t) {
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const T nr = fr[m] * pa[m] - fi[m] * pb[m];         // FFK *= cp, :418
+                    const T ni = fr[m] * pb[m] + fi[m] * pa[m];
+                    fr[m] = nr;
+                    fi[m] = ni;
+                    acc[2 * t] += nr;                                   // TK[itau] += FFK, :420
+                    acc[2 * t + 1] += ni;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < PS_TT; ++t) {
+                const int tau = min(tau0 + t, P.snum - 1);
+                const T v = (T)P.vz[tau];
+                const T thr = (T)P.thr[tau];
+                const bool live_tau = (tau0 + t) < P.snum;
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const T coss = (T)1 - (v * v) * pa[m];              // :458
+                    const T ph = pb[m] * sqrt(coss > 0 ? coss : (T)0);  // :460 (real part of the complex sqrt)
+                    T s, c;
+                    sincos_t<T>(ph, &s, &c);
+                    T nr = fr[m] * c - fi[m] * s;                       // :464
+                    T ni = fr[m] * s + fi[m] * c;
+                    if (coss <= thr) {                                  // :484-485, stays zero afterwards
+                        nr = 0;
+                        ni = 0;
+                    }
+                    if (live_tau) {
+                        fr[m] = nr;
+                        fi[m] = ni;
+                        acc[2 * t] += nr;                               // :487
+                        acc[2 * t + 1] += ni;
+                    }
+                    // keep the M independent sincos chains from being interleaved
+                    // (live temporaries would spill at M >= 8)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // ---- sum over frequencies: wave butterfly, then across waves via LDS
+        wave_reduce_scatter<T, 2 * PS_TT>(acc, lane);
+        T (*buf)[2 * PS_TT] = red[tile & 1];
+        if ((lane & 1) == 0) buf[wave][lane >> 1] = acc[0];
+        __syncthreads();
+        if (tid < 2 * PS_TT) {
+            T s = 0;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) s += buf[q][tid];
+            const int tau = tau0 + (tid >> 1);
+            if (tau < P.snum) {
+                T *dst = reinterpret_cast<T *>(TK + tau) + (tid & 1);
+                *dst = s / (T)P.snum;                                   // TK /= snum, :492
+            }
+        }
+        // red[] is double-buffered: the next tile writes the other buffer and the
+        // barrier of that tile orders it against these reads
+    }
+}
+
+struct PsPlan {
+    int dtype = -1, snum = 0, tnum = 0, nt = 0;
+    FftPlan f_time, f_trace, b_trace;
+    DevBuf X, TK, d_kx, d_w, d_vz, d_thr;
+};
+static std::mutex g_ps_mu;
+static PsPlan *g_ps_plan = nullptr;
+
+template <typename T, int BLOCK, int M>
+static void ps_launch(const PsParams &P, hipStream_t st)
+{
+    if (P.vz_mode)
+        hipLaunchKernelGGL((ps_kernel<T, BLOCK, M, true>), dim3(P.tnum), dim3(BLOCK), 0, st, P);
+    else
+        hipLaunchKernelGGL((ps_kernel<T, BLOCK, M, false>), dim3(P.tnum), dim3(BLOCK), 0, st, P);
+}
+
+template <typename T>
+static int ps_dispatch(const PsParams &P, hipStream_t st)
+{
+    const int nt = P.nt;
+    if (nt <= 64) ps_launch<T, 64, 1>(P, st);
+    else if (nt <= 128) ps_launch<T, 128, 1>(P, st);
+    else if (nt <= 256) ps_launch<T, 256, 1>(P, st);
+    else if (nt <= 512) ps_launch<T, 512, 1>(P, st);
+    else if (nt <= 1024) ps_launch<T, 512, 2>(P, st);
+    else if (nt <= 2048) ps_launch<T, 512, 4>(P, st);
+    else if (nt <= 4096) ps_launch<T, 512, 8>(P, st);
+    else if (nt <= 8192) ps_launch<T, 512, 16>(P, st);
+    else if (nt <= 16384) ps_launch<T, 512, 32>(P, st);
+    else {
+        impdar_set_error("phase-shift kernel supports up to 16384 padded samples (got %d)", nt);
+        return IMPDAR_ERR_UNSUPPORTED;
+    }
+    IMPDAR_HIP_CHECK(hipGetLastError());
+    return IMPDAR_OK;
+}
+
+template <typename T>
+static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int tnum, int nt, const double *kx,
+                  const double *ws, double dt, const double *tt_us, double vconst, const double *vmig, int vlen,
+                  double htaper, double vtaper, void *d_out)
+{
+    hipStream_t st = ctx->stream;
+    const bool dbl = sizeof(T) == 8;
+    if (pl.dtype != (dbl ? IMPDAR_F64 : IMPDAR_F32) || pl.snum != snum || pl.tnum != tnum || pl.nt != nt) {
+        pl.dtype = -1;
+        int rc;
+        const rocfft_array_type ci = rocfft_array_type_complex_interleaved;
+        if ((rc = pl.f_time.create(rocfft_transform_type_complex_forward, dbl, true, nt, tnum, ci, ci, 1, nt, 1, nt, 1.0, st)))
+            return rc;
+        if ((rc = pl.f_trace.create(rocfft_transform_type_complex_forward, dbl, true, tnum, nt, ci, ci, nt, 1, nt, 1, 1.0, st)))
+            return rc;
+        if ((rc = pl.b_trace.create(rocfft_transform_type_complex_inverse, dbl, true, tnum, snum, ci, ci, snum, 1, snum, 1,
+                                    1.0 / tnum, st)))
+            return rc;
+        IMPDAR_HIP_CHECK(pl.X.ensure((size_t)tnum * nt * 2 * sizeof(T)));
+        IMPDAR_HIP_CHECK(pl.TK.ensure((size_t)tnum * snum * 2 * sizeof(T)));
+        IMPDAR_HIP_CHECK(pl.d_kx.ensure((size_t)tnum * 8));
+        IMPDAR_HIP_CHECK(pl.d_w.ensure((size_t)nt * 8));
+        IMPDAR_HIP_CHECK(pl.d_vz.ensure((size_t)snum * 8));
+        IMPDAR_HIP_CHECK(pl.d_thr.ensure((size_t)snum * 8));
+        pl.dtype = dbl ? IMPDAR_F64 : IMPDAR_F32;
+        pl.snum = snum;
+        pl.tnum = tnum;
+        pl.nt = nt;
+    }
+    std::vector<double> w(ws, ws + nt), thr(snum, 0.0);
+    for (int i = 0; i < nt; ++i)
+        if (w[i] == 0.0) w[i] = 1e-10 / dt;                            // :400-402
+    if (vlen)
+        for (int i = 0; i < snum; ++i) {
+            const double tau = tt_us[i] / 1.0e6;                         // :441
+            const double r = tau / tt_us[snum - 1] / 1e6;                // :484
+            thr[i] = r * r;
+        }
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_kx.p, kx, (size_t)tnum * 8, hipMemcpyHostToDevice, st));
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_w.p, w.data(), (size_t)nt * 8, hipMemcpyHostToDevice, st));
+    if (vlen) {
+        IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_vz.p, vmig, (size_t)snum * 8, hipMemcpyHostToDevice, st));
+        IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_thr.p, thr.data(), (size_t)snum * 8, hipMemcpyHostToDevice, st));
+    }
+    dim3 tgrid((tnum + 63) / 64, (nt + 63) / 64);
+    hipLaunchKernelGGL((ps_taper_pad_transpose<T>), tgrid, dim3(256), 0, st, (const T *)d_data, pl.X.as<Cp<T>>(), snum,
+                       tnum, nt, htaper, vtaper);
+    int rc;
+    if ((rc = pl.f_time.exec(pl.X.p, nullptr))) return rc;
+    if ((rc = pl.f_trace.exec(pl.X.p, nullptr))) return rc;
+    PsParams P;
+    P.F = pl.X.p;
+    P.TK = pl.TK.p;
+    P.kx = pl.d_kx.as<double>();
+    P.w = pl.d_w.as<double>();
+    P.vz = pl.d_vz.as<double>();
+    P.thr = pl.d_thr.as<double>();
+    P.vconst = vconst;
+    P.dt = dt;
+    P.snum = snum;
+    P.tnum = tnum;
+    P.nt = nt;
+    P.vz_mode = vlen ? 1 : 0;
+    if ((rc = ps_dispatch<T>(P, st))) return rc;
+    if ((rc = pl.b_trace.exec(pl.TK.p, nullptr))) return rc;
+    dim3 bgrid((tnum + 63) / 64, (snum + 63) / 64);
+    hipLaunchKernelGGL((ps_real_transpose<T>), bgrid, dim3(256), 0, st, pl.TK.as<Cp<T>>(), (T *)d_out, snum, tnum);
+    IMPDAR_HIP_CHECK(hipGetLastError());
+    // host staging vectors (w, thr) must outlive the async copies
+    IMPDAR_HIP_CHECK(hipStreamSynchronize(st));
+    return IMPDAR_OK;
+}
+
+extern "C" int impdar_phaseshift(impdar_ctx *ctx, const void *data, int dtype, int snum, int tnum, int nt,
+                                 const double *kx, const double *ws, double dt, const double *tt_us, double vconst,
+                                 const double *vmig, int vmig_len, double htaper, double vtaper, void *out)
+{
+    IMPDAR_ARG_CHECK(ctx && data && out && kx && ws && tt_us, "null argument");
+    IMPDAR_ARG_CHECK(dtype == IMPDAR_F32 || dtype == IMPDAR_F64, "dtype must be 0 (f32) or 1 (f64)");
+    IMPDAR_ARG_CHECK(snum >= 1 && tnum >= 1 && nt >= snum, "bad sizes snum %d tnum %d nt %d", snum, tnum, nt);
+    IMPDAR_ARG_CHECK(vmig_len == 0 || (vmig_len == snum && vmig),
+                     "Interpolated velocity profile is not the length of the number of samples in a trace.");
+    IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)snum * tnum * impdar_dtype_size(dtype);
+    DevBuf din, dout;
+    IMPDAR_HIP_CHECK(din.ensure(bytes));
+    IMPDAR_HIP_CHECK(dout.ensure(bytes));
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(din.p, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    std::lock_guard<std::mutex> lk(g_ps_mu);
+    if (!g_ps_plan) g_ps_plan = new PsPlan();
+    int rc = dtype == IMPDAR_F32 ? ps_run<float>(ctx, *g_ps_plan, din.p, snum, tnum, nt, kx, ws, dt, tt_us, vconst, vmig,
+                                                 vmig_len, htaper, vtaper, dout.p)
+                                 : ps_run<double>(ctx, *g_ps_plan, din.p, snum, tnum, nt, kx, ws, dt, tt_us, vconst, vmig,
+                                                  vmig_len, htaper, vtaper, dout.p);
+    if (rc) return rc;
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    IMPDAR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return IMPDAR_OK;
+}
+
+extern "C" int impdar_taper(impdar_ctx *ctx, void *data_inout, int dtype, int snum, int tnum, double htaper,
+                            double vtaper)
+{
+    IMPDAR_ARG_CHECK(ctx && data_inout, "null argument");
+    IMPDAR_ARG_CHECK(dtype == IMPDAR_F32 || dtype == IMPDAR_F64, "dtype must be 0 (f32) or 1 (f64)");
+    IMPDAR_ARG_CHECK(snum >= 1 && tnum >= 1, "bad sizes snum %d tnum %d", snum, tnum);
+    IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)snum * tnum, bytes = n * impdar_dtype_size(dtype);
+    DevBuf d;
+    IMPDAR_HIP_CHECK(d.ensure(bytes));
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(d.p, data_inout, bytes, hipMemcpyHostToDevice, ctx->stream));
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (dtype == IMPDAR_F32)
+        hipLaunchKernelGGL((ps_taper_inplace<float>), dim3(grid), dim3(256), 0, ctx->stream, d.as<float>(), snum, tnum,
+                           htaper, vtaper);
+    else
+        hipLaunchKernelGGL((ps_taper_inplace<double>), dim3(grid), dim3(256), 0, ctx->stream, d.as<double>(), snum, tnum,
+                           htaper, vtaper);
+    IMPDAR_HIP_CHECK(hipGetLastError());
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(data_inout, d.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    IMPDAR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return IMPDAR_OK;
+}

@@ -1,0 +1,100 @@
+"""Parity of the HIP phase-shift (Gazdag) path and the taper-only T-K stub
+with the reference's golden vectors and the CPU oracle.
+
+Stated tolerances: float64 data  max|diff| <= 1e-9 * max|ref|  (the reference's
+                   multiplicative recurrence and this kernel's differ by
+                   rounding only)
+                   float32 data  relative L2 <= 2e-4."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden, golden_names, make_dat, rel_l2, rel_max
+
+pytestmark = pytest.mark.gpu
+
+F64_TOL = 1e-9
+F32_L2 = 2e-4
+
+
+@pytest.mark.parametrize('name', golden_names('P1') + golden_names('P2'))
+def test_golden(hip, name):
+    g = golden(name)
+    dat = make_dat(g)
+    vel = float(g['vel']) if g['vel'].ndim == 0 else g['vel']
+    from impdar_amd.lib import migrationlib
+    migrationlib.migrationPhaseShift(dat, vel=vel, htaper=int(g['htaper']), vtaper=int(g['vtaper']))
+    assert dat.data.dtype == np.float64 and dat.data.shape == g['expected'].shape
+    assert rel_max(dat.data, g['expected']) < F64_TOL, rel_max(dat.data, g['expected'])
+
+
+@pytest.mark.parametrize('name', ['P1r_phsh_const_ricker', 'P2_phsh_vz_64x48'])
+def test_golden_float32(hip, name):
+    g = golden(name)
+    dat = make_dat(g)
+    dat.data = dat.data.astype(np.float32)
+    vel = float(g['vel']) if g['vel'].ndim == 0 else g['vel']
+    from impdar_amd.lib import migrationlib
+    migrationlib.migrationPhaseShift(dat, vel=vel, htaper=int(g['htaper']), vtaper=int(g['vtaper']))
+    assert dat.data.dtype == np.float64
+    assert rel_l2(dat.data, g['expected']) < F32_L2, rel_l2(dat.data, g['expected'])
+
+
+def test_velocity_file_and_errors(hip, tmp_path):
+    """test/test_migrationlib.py:120-131: constant, layered from a file,
+    TypeError for an unreadable file."""
+    from impdar_amd.lib.NoInitRadarData import NoInitRadarData
+    from impdar_amd.lib import migrationlib
+    data = NoInitRadarData(big=True)
+    data = migrationlib.migrationPhaseShift(data)
+    assert not data.data.any()
+    fn = tmp_path / 'velocity_layers.txt'
+    fn.write_text('1.677e8  0\n1.677e8  50\n1.2e8  51\n2.2e8  100\n')
+    data = NoInitRadarData(big=True)
+    data.travel_time = data.travel_time / 10.
+    data = migrationlib.migrationPhaseShift(data, vel_fn=str(fn))
+    assert data.data.shape == (10, 20)
+    data = NoInitRadarData(big=True)
+    with pytest.raises(TypeError):
+        migrationlib.migrationPhaseShift(data, vel_fn=str(tmp_path / 'notafile.txt'))
+    data = NoInitRadarData(big=True)
+    data.data = data.data.astype(int)
+    with pytest.raises(TypeError):
+        migrationlib.migrationPhaseShift(data)
+
+
+@pytest.mark.parametrize('snum,tnum,layered', [(200, 96, False), (300, 64, True), (1100, 48, False), (600, 40, True)])
+def test_vs_oracle_sizes(hip, snum, tnum, layered):
+    """nt = 256 .. 2048: every block-size / frequencies-per-lane instantiation
+    up to M = 4."""
+    from impdar_amd import synth
+    from impdar_amd.lib.RadarData import RadarData
+    from oracle import mig_oracle
+    geo = synth.geometry(snum, tnum)
+    data = synth.noise_radargram(snum, tnum, seed=snum)
+    if layered:
+        Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+        vel = np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rp], [1.8e8, 0.5 * Rp], [1.9e8, 1.2 * Rp]])
+    else:
+        vel = 1.69e8
+    want = mig_oracle.phase_shift(data, geo['dt'], geo['trace_int'], geo['travel_time'], geo['dist'], vel, 20, 30)
+    d = RadarData(None)
+    d.data, d.snum, d.tnum = data.copy(), snum, tnum
+    d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
+    from impdar_amd.lib import migrationlib
+    migrationlib.migrationPhaseShift(d, vel=vel, htaper=20, vtaper=30)
+    assert rel_max(d.data, want) < F64_TOL, rel_max(d.data, want)
+
+
+def test_tk_is_taper_only(hip):
+    g = golden('T1_tk_taper_only')
+    dat = make_dat(g)
+    dat.migrate('tk', htaper=int(g['htaper']), vtaper=int(g['vtaper']))
+    assert dat.flags.mig == 'tk'
+    assert np.array_equal(dat.data, g['expected'])
+    from impdar_amd.lib.NoInitRadarData import NoInitRadarData
+    from impdar_amd.lib import migrationlib
+    data = NoInitRadarData(big=True)
+    data = migrationlib.migrationTimeWavenumber(data)
+    assert not data.data.any()
