@@ -1,0 +1,81 @@
+#! /usr/bin/env python
+"""``impproc migrate`` on the MI355X engine.
+
+Mirrors the migrate sub-command of the reference's ``src/impdar/bin/impproc.py``
+(parser ``:295-343``, ``main`` ``:378-415``, ``mig`` ``:508-519``): same
+options, types and defaults, same output naming (``<name minus _raw>_migrated.mat``,
+``-o`` file or folder).  The reference's other 18 processing sub-commands are
+out of scope.
+
+    python -m impdar_amd.bin.impproc migrate --mtype kirch line1_raw.mat
+"""
+import argparse
+import os
+import sys
+
+from ..lib.load import load, FILETYPE_OPTIONS
+
+
+def _get_args():
+    parser = argparse.ArgumentParser()
+    subparsers = parser.add_subparsers(help='Choose a processing step')
+    parser_mig = subparsers.add_parser('migrate', help='Migration')
+    parser_mig.set_defaults(func=mig, name='migrated')
+    parser_mig.add_argument('--mtype', type=str, default='phsh',
+                            choices=['stolt', 'kirch', 'phsh', 'tk', 'sumigtk', 'sustolt', 'sumigffd'],
+                            help='Migration routines.')
+    parser_mig.add_argument('--vel', type=float, default=1.69e8,
+                            help='Speed of light in dielectric medium m/s (default is for ice, 1.69e8)')
+    parser_mig.add_argument('--vel_fn', type=str, default=None,
+                            help='Filename for input velocity array. Column 1: velocities, '
+                                 'Column 2: z locations, Column 3: x locations (optional)')
+    parser_mig.add_argument('--nearfield', action='store_true',
+                            help='Boolean for nearfield operator in Kirchhoff migration.')
+    parser_mig.add_argument('--htaper', type=int, default=100, help='Number of samples for horizontal taper')
+    parser_mig.add_argument('--vtaper', type=int, default=1000, help='Number of samples for vertical taper')
+    parser_mig.add_argument('--nxpad', type=int, default=100, help='Number of traces to pad with zeros for FFT')
+    parser_mig.add_argument('--tmig', type=int, default=0, help='Times for velocity profile')
+    parser_mig.add_argument('--verbose', type=int, default=1, help='Print output from SeisUnix migration')
+    parser_mig.add_argument('fns', type=str, nargs='+', help='The files to process')
+    parser_mig.add_argument('-o', type=str, help='Output to this file (folder if multiple inputs)')
+    parser_mig.add_argument('--ftype', type=str, default='mat', help='Type of file to load (default ImpDAR mat)',
+                            choices=FILETYPE_OPTIONS)
+    return parser
+
+
+def main():
+    parser = _get_args()
+    args = parser.parse_args(sys.argv[1:])
+    if not hasattr(args, 'func'):
+        parser.parse_args(['-h'])
+
+    radar_data = load(args.ftype, args.fns)
+    for dat in radar_data:
+        args.func(dat, **vars(args))
+
+    if args.o is not None:
+        if (len(radar_data) > 1) or (args.o[-1] == '/'):
+            for d, f in zip(radar_data, args.fns):
+                bn = os.path.split(os.path.splitext(f)[0])[1]
+                if bn[-4:] == '_raw':
+                    bn = bn[:-4]
+                d.save(os.path.join(args.o, bn + '_{:s}.mat'.format(args.name)))
+        else:
+            radar_data[0].save(args.o)
+    else:
+        for d, f in zip(radar_data, args.fns):
+            bn = os.path.splitext(f)[0]
+            if bn[-4:] == '_raw':
+                bn = bn[:-4]
+            d.save(bn + '_{:s}.mat'.format(args.name))
+
+
+def mig(dat, mtype='stolt', vel=1.69e8, vtaper=100, htaper=100, tmig=0, verbose=0, vel_fn=None, nxpad=1,
+        nearfield=False, **kwargs):
+    """Migrate data (defaults as the reference's ``impproc.mig``)."""
+    dat.migrate(mtype, vel=vel, vtaper=vtaper, htaper=htaper, tmig=tmig, verbose=verbose, vel_fn=vel_fn,
+                nxpad=nxpad, nearfield=nearfield)
+
+
+if __name__ == '__main__':
+    main()

@@ -157,6 +157,7 @@ struct FastParams {
     const float *Ahi, *Alo;        // (tt[ti]/dt)^2 split hi+lo           [snum]
     const float *wc, *wc2;         // far / near weight prefactors         [snum]
     const float *apexw;            // 1 or 0: n==0 pair kept by the reference's own t>tmax test
+    const int *apexk;              // sample the n==0 pair picks (fp64 reference order; differs from ti for t<0)
     const float2 *B;               // alpha*n^2 split hi+lo                [nb]
     const int *hmax;               // per sample-chunk aperture half width [nchunks]
     const int *klo, *khi;          // per (chunk, |n|) first / last sample a trace at offset n is asked for
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(KF_THREADS) void kirch_fast_kernel(FastParams P)
     const float wc = P.wc[ti];
     const float wc2 = NEAR ? P.wc2[ti] : 0.f;
     const float apexw = P.apexw[ti];
+    const float apexk = (float)P.apexk[ti];
     const float u0h = P.u0h, u0l = P.u0l, umh = P.umaxh, uml = P.umaxl;
 
     // uniform tile geometry
@@ -303,11 +305,11 @@ __global__ __launch_bounds__(KF_THREADS) void kirch_fast_kernel(FastParams P)
                 if (n == 0) {
                     // apex pair: t is tt[ti] up to the reference's own fp64 rounding, which
                     // the host evaluated exactly (apexw); the pick is the sample itself
-                    kf = (float)ti;
+                    kf = apexk;
                     keep = apexw != 0.f;
                 }
                 const float w = keep ? wc * y : 0.f;
-                const float w2 = NEAR ? (w * y) * (y * wc2) : 0.f;
+                const float w2 = (NEAR && keep) ? (wc2 * y) * (y * y) : 0.f;
                 const int kidx = max((int)kf, 0) & (W - 1);
 #pragma unroll
                 for (int i = 0; i < XB; ++i) {
@@ -355,7 +357,7 @@ struct impdar_kirch_plan {
     // device tables
     DevBuf d_dist, d_tt, d_zs, d_zs2, d_ga, d_gb, d_gc;
     DevBuf GT, DT;
-    DevBuf d_Ahi, d_Alo, d_wc, d_wc2, d_apexw, d_B, d_hmax, d_klo, d_khi;
+    DevBuf d_Ahi, d_Alo, d_wc, d_wc2, d_apexw, d_apexk, d_B, d_hmax, d_klo, d_khi;
     int nb = 0;
     // host copies for pair counting
     std::vector<int> h_half;       // exact aperture half-width per sample (uniform grids)
@@ -516,6 +518,7 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         const int nch = (snum + KF_THREADS - 1) / KF_THREADS;
         p->nchunks = nch;
         std::vector<float> Ahi(snum), Alo(snum), wc(snum), wc2(snum), apexw(snum);
+        std::vector<int> apexk(snum);
         std::vector<int> hmax(nch, 0);
         const double half = vel * dt / 2.0;         // metres per sample of two-way time
         for (int k = 0; k < snum; ++k) {
@@ -527,6 +530,13 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
             const double zs = vel * tt_sec[k] / 2.0;
             const double t0 = 2.0 * std::sqrt(zs * zs) / vel;
             apexw[k] = (t0 > tmax) ? 0.f : 1.f;
+            // nearest sample to t0, ties to the lower index (argmin, mig_python.py:49)
+            int k0 = (int)std::floor((t0 - tt_sec[0]) / dt);
+            k0 = std::min(std::max(k0, 0), snum - 1);
+            while (k0 < snum - 1 && tt_sec[k0 + 1] <= t0) ++k0;
+            while (k0 > 0 && tt_sec[k0] > t0) --k0;
+            const int k1 = std::min(k0 + 1, snum - 1);
+            apexk[k] = (std::fabs(tt_sec[k1] - t0) < std::fabs(tt_sec[k0] - t0)) ? k1 : k0;
         }
         int hglob = 0;
         std::vector<double> cmin(nch), cmax(nch);
@@ -563,7 +573,7 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         split2(tmax / dt, p->umaxh, p->umaxl);
         if ((rc = upload(p->d_Ahi, Ahi.data(), snum * 4)) || (rc = upload(p->d_Alo, Alo.data(), snum * 4)) ||
             (rc = upload(p->d_wc, wc.data(), snum * 4)) || (rc = upload(p->d_wc2, wc2.data(), snum * 4)) ||
-            (rc = upload(p->d_apexw, apexw.data(), snum * 4)) || (rc = upload(p->d_B, B.data(), (size_t)nb * 8)) ||
+            (rc = upload(p->d_apexw, apexw.data(), snum * 4)) || (rc = upload(p->d_apexk, apexk.data(), snum * 4)) || (rc = upload(p->d_B, B.data(), (size_t)nb * 8)) ||
             (rc = upload(p->d_hmax, hmax.data(), nch * 4)) || (rc = upload(p->d_klo, klo.data(), klo.size() * 4)) ||
             (rc = upload(p->d_khi, khi.data(), khi.size() * 4)))
             return fail(rc);
@@ -693,6 +703,7 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         P.wc = p->d_wc.as<float>();
         P.wc2 = p->d_wc2.as<float>();
         P.apexw = p->d_apexw.as<float>();
+        P.apexk = p->d_apexk.as<int>();
         P.B = p->d_B.as<float2>();
         P.hmax = p->d_hmax.as<int>();
         P.klo = p->d_klo.as<int>();
@@ -705,8 +716,14 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         P.umaxl = p->umaxl;
         P.nchunks = p->nchunks;
         int rc;
-        if (p->xb == 16)
+        const char *se = getenv("IMPDAR_KIRCH_S");
+        const int sblk = se ? atoi(se) : 4;
+        if (p->xb == 16 && sblk == 8)
+            rc = launch_fast<16, 8>(p, P, (nx + 15) / 16, st);
+        else if (p->xb == 16)
             rc = launch_fast<16, 4>(p, P, (nx + 15) / 16, st);
+        else if (sblk == 8)
+            rc = launch_fast<32, 8>(p, P, (nx + 31) / 32, st);
         else
             rc = launch_fast<32, 4>(p, P, (nx + 31) / 32, st);
         if (rc) return rc;

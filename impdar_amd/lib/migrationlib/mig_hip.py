@@ -152,8 +152,9 @@ def migrationStolt(dat, vel=1.68e8, htaper=100, vtaper=1000):
     out = np.empty((nout, dat.tnum), dtype=data.dtype)
     _, p_kx = _hip.as_dp(kx)
     _, p_ws = _hip.as_dp(ws)
-    ht = float('inf') if pre_tapered else float(htaper)
-    vt = float('inf') if pre_tapered else float(vtaper)
+    # NaN taper lengths tell the device the taper has already been applied
+    ht = float('nan') if pre_tapered else float(htaper)
+    vt = float('nan') if pre_tapered else float(vtaper)
     rc = lib.impdar_stolt(ctx, data.ctypes.data_as(C.c_void_p), code, dat.snum, dat.tnum, p_kx, p_ws,
                           float(vel), ht, vt, out.ctypes.data_as(C.c_void_p))
     _hip.check(rc, 'impdar_stolt')

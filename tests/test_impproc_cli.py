@@ -1,0 +1,116 @@
+"""`impproc migrate` surface (reference test/test_impproc.py:432-561, 603-604)
+and the .mat round trip (reference test/test_RadarDataSaving.py).  CPU-only:
+the migration call is patched; the GPU variant is in test_cli_gpu.py."""
+import os
+import sys
+from unittest.mock import MagicMock, patch
+
+import numpy as np
+import pytest
+
+from impdar_amd.bin import impproc
+from impdar_amd.lib.NoInitRadarData import NoInitRadarData
+from impdar_amd.lib.RadarData import RadarData
+
+
+def run_cli(argv, loaded):
+    with patch.object(sys, 'argv', ['impproc'] + argv), \
+            patch('impdar_amd.bin.impproc.load', return_value=loaded) as ld:
+        impproc.main()
+    return ld
+
+
+@pytest.mark.parametrize('mtype', ['stolt', 'kirch', 'phsh', 'tk', 'sumigtk', 'sustolt', 'sumigffd'])
+def test_migrate_types(mtype):
+    dat = MagicMock()
+    run_cli(['migrate', '--mtype', mtype, 'dummy.mat'], [dat])
+    args, kwargs = dat.migrate.call_args
+    assert args == (mtype,)
+    assert kwargs == dict(vel=1.69e8, vtaper=1000, htaper=100, tmig=0, verbose=1, vel_fn=None, nxpad=100,
+                          nearfield=False)
+    dat.save.assert_called_with('dummy_migrated.mat')
+
+
+def test_migrate_option_types_and_naming(tmp_path):
+    dat = MagicMock()
+    run_cli(['migrate', '--mtype', 'kirch', '--vel', '1.5e8', '--nearfield', '--htaper', '7', '--vtaper', '9',
+             '--nxpad', '3', '--tmig', '2', '--verbose', '0', '--vel_fn', 'v.txt', 'line_raw.mat'], [dat])
+    _, kw = dat.migrate.call_args
+    assert kw['vel'] == 1.5e8 and kw['nearfield'] is True and kw['vel_fn'] == 'v.txt'
+    for k, v in dict(htaper=7, vtaper=9, nxpad=3, tmig=2, verbose=0).items():
+        assert kw[k] == v and isinstance(kw[k], int)
+    dat.save.assert_called_with('line_migrated.mat')          # _raw stripped
+    a, b = MagicMock(), MagicMock()
+    run_cli(['migrate', '-o', str(tmp_path) + '/', 'x_raw.mat', 'y.mat'], [a, b])
+    a.save.assert_called_with(os.path.join(str(tmp_path) + '/', 'x_migrated.mat'))
+    b.save.assert_called_with(os.path.join(str(tmp_path) + '/', 'y_migrated.mat'))
+    c = MagicMock()
+    run_cli(['migrate', '-o', 'out.mat', 'x.mat'], [c])
+    c.save.assert_called_with('out.mat')
+    with pytest.raises(SystemExit):
+        run_cli(['migrate', '--mtype', 'bad', 'x.mat'], [MagicMock()])
+    with pytest.raises(SystemExit):
+        run_cli(['migrate', '--htaper', '1.5', 'x.mat'], [MagicMock()])
+
+
+def test_mig_defaults():
+    dat = MagicMock()
+    impproc.mig(dat)
+    dat.migrate.assert_called_with('stolt', vel=1.69e8, vtaper=100, htaper=100, tmig=0, verbose=0, vel_fn=None,
+                                   nxpad=1, nearfield=False)
+
+
+def make_saveable(dtype=np.float64):
+    d = NoInitRadarData(big=True)
+    rng = np.random.default_rng(0)
+    d.data = (rng.standard_normal((10, 20)) * 100).astype(dtype)
+    d.fn = 'x.mat'
+    return d
+
+
+def test_mat_round_trip(tmp_path):
+    d = make_saveable()
+    d.flags.mig = 'kirch'
+    fn = str(tmp_path / 'a.mat')
+    d.save(fn)
+    r = RadarData(fn)
+    assert np.array_equal(r.data, d.data) and r.data.dtype == np.float64
+    assert (r.snum, r.tnum) == (10, 20)
+    assert np.array_equal(r.travel_time, d.travel_time)
+    assert np.array_equal(r.dist, d.dist)
+    assert r.flags.mig == 'kirch' and r.flags.bpass.shape == (3,)
+    assert r.data_dtype == np.float64
+    r.check_attrs()
+
+
+def test_save_casts_back_to_file_dtype(tmp_path):
+    """_RadarDataSaving.py:60-77: float results are cast back to the dtype the
+    file was loaded with; NaNs in an int16 file force float16."""
+    d = make_saveable(np.int16)
+    fn = str(tmp_path / 'i.mat')
+    d.save(fn)
+    r = RadarData(fn)
+    assert r.data_dtype == np.int16
+    r.data = r.data.astype(np.float64) * 0.5 + 0.25           # "migrated"
+    fn2 = str(tmp_path / 'j.mat')
+    r.save(fn2)
+    r2 = RadarData(fn2)
+    assert r2.data.dtype == np.int16
+    assert np.array_equal(r2.data, (d.data.astype(np.float64) * 0.5 + 0.25).astype(np.int16))
+    r.data[0, 0] = np.nan
+    r.save(fn2)
+    back = RadarData(fn2).data        # scipy stores float16 as double; the values went through float16
+    assert np.isnan(back[0, 0]) and np.array_equal(back[1:], r.data[1:].astype(np.float16).astype(np.float64))
+
+
+def test_load_rejects_other_formats():
+    from impdar_amd.lib.load import load
+    with pytest.raises(ValueError):
+        load('gssi', ['x.DZT'])
+    with pytest.raises(KeyError):
+        from scipy.io import savemat
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            fn = os.path.join(td, 'bad.mat')
+            savemat(fn, {'nothing': np.zeros(3)})
+            RadarData(fn)
