@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libimpdar_hip.so')
 SOURCES = ['api.hip', 'comm.hip', 'kirchhoff.hip', 'stolt.hip', 'phaseshift.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off',
-         '-Wall', '-Wno-unused-function']
+         '-fno-slp-vectorize', '-Wall', '-Wno-unused-function']
 
 
 def _newer(a, b):

@@ -165,6 +165,11 @@ struct FastParams {
     int zero_row;                  // index of an all-zero image row (out-of-profile traces)
     float u0h, u0l, umaxh, umaxl;
     int nchunks, nxt, tiles_per_xcd, G;
+    // pick/weight table of the table-driven kernel: entry (|n|, ti)
+    const unsigned short *TK;      // byte offset of the picked sample inside a ring slot  [ntab][snum]
+    const float *TW, *TW2;         // far / near weights (0 where the reference drops the pair)
+    int ntab;                      // rows; the last row is all zero (|n| beyond every aperture)
+    int dbg;                       // timing experiments only (bit0: all trace loads hit row 0, bit1: all table loads hit row 0)
 };
 
 template <int XB, int S, bool NEAR>
@@ -344,6 +349,671 @@ __global__ __launch_bounds__(KF_THREADS) void kirch_fast_kernel(FastParams P)
     }
 }
 
+// ---------------------------------------------------------------------------
+// pick / weight table.  For a uniform trace spacing the sample picked by the
+// pair (output sample ti, input trace xi+n) and its obliquity weight depend on
+// (ti, |n|) only.  One thread per entry evaluates them in fp64 in the
+// reference's operation order (mig_python.py:44-58), so the diffraction-sum
+// kernel below inherits the reference's picks, its t>tmax test and its NaN
+// skipping exactly; the table is rebuilt by every prep (it is cheap: ~1e7
+// entries) so nothing about it is cached across migrations.
+// ---------------------------------------------------------------------------
+struct TableParams {
+    unsigned short *TK;
+    float *TW, *TW2;
+    const double *zs, *zs2, *tt;
+    double dx, vel, tmax, inv_dt, tt0;
+    int snum, ntab, near;
+    int wmod, kscale;          // slot byte offset of sample k = (k % wmod) * kscale
+};
+
+__global__ __launch_bounds__(256) void kirch_table_kernel(TableParams P)
+{
+    const int ti = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    if (ti >= P.snum) return;
+    const size_t o = (size_t)n * P.snum + ti;
+    unsigned short kb = 0;
+    float w = 0.f, w2 = 0.f;
+    if (n < P.ntab - 1) {
+        const double dx = (double)n * P.dx;
+        const double q = dx * dx + P.zs2[ti];
+        const double rs = sqrt(q);
+        const double cost = P.zs[ti] / rs;
+        const double t = 2.0 * rs / P.vel;
+        if (!(t > P.tmax) && cost == cost) {
+            const int ns = P.snum;
+            int k0 = (int)floor((t - P.tt0) * P.inv_dt);
+            k0 = min(max(k0, 0), ns - 1);
+            while (k0 < ns - 1 && P.tt[k0 + 1] <= t) ++k0;
+            while (k0 > 0 && P.tt[k0] > t) --k0;
+            const int k1 = min(k0 + 1, ns - 1);
+            const int k = (fabs(P.tt[k1] - t) < fabs(P.tt[k0] - t)) ? k1 : k0;
+            kb = (unsigned short)((k % P.wmod) * P.kscale);
+            const double c2pi = 1.0 / (2.0 * 3.141592653589793);
+            w = (float)(c2pi * (cost / P.vel));
+            if (P.near) w2 = (float)(c2pi * (cost / (rs * rs)));
+        }
+    }
+    P.TK[o] = kb;
+    P.TW[o] = w;
+    if (P.near) P.TW2[o] = w2;
+}
+
+// ---------------------------------------------------------------------------
+// table-driven ring kernel: the same tile and LDS ring as kirch_fast_kernel,
+// but the per-(sample, offset) pick and weight come from the table (two
+// coalesced loads per lane per step, prefetched a block ahead) instead of
+// ~40 VALU instructions of double-float index arithmetic.
+// ---------------------------------------------------------------------------
+template <int XB, int S, bool NEAR, int OCC>
+__global__ __launch_bounds__(KF_THREADS, OCC) void kirch_tab_kernel(FastParams P)
+{
+    constexpr int R = XB + 2 * S;
+    constexpr int W = KF_W;
+    static_assert(R % S == 0, "ring must be a whole number of step blocks");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *ldsG = lds;
+    float *ldsD = lds + R * W;
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7, r = b >> 3;
+    const int chunk = r / P.tiles_per_xcd;
+    const int qx = r - chunk * P.tiles_per_xcd;
+    const int xt = ((qx / P.G) * 8 + xcd) * P.G + (qx % P.G);
+    if (chunk >= P.nchunks || xt >= P.nxt) return;
+
+    const int tid = threadIdx.x;
+    const int s0 = chunk * KF_THREADS;
+    const int x0 = P.xlo + xt * XB;
+    const int snum = P.snum, tnum = P.tnum;
+    const int ti_raw = s0 + tid;
+    const int ti = min(ti_raw, snum - 1);
+
+    const int hmax = P.hmax[chunk];
+    const int *klo = P.klo + (size_t)chunk * P.nb;
+    const int *khi = P.khi + (size_t)chunk * P.nb;
+    const int nlo = max(-hmax, -(x0 + XB - 1));
+    const int nhi = min(hmax, tnum - 1 - x0);
+    const int nsteps = nhi - nlo + 1;
+    const int nblocks = (nsteps + S - 1) / S;
+    const int nsteps_pad = nblocks * S;
+    const int jbase = x0 + nlo;
+    const int ntab1 = P.ntab - 1;
+
+    auto window = [&](int q, int &kmin, int &kmax) {
+        const int pmin = max(0, q - (XB - 1)), pmax = min(q, nsteps_pad - 1);
+        const int na = nlo + pmin, nb = nlo + pmax;
+        const int lo = (na <= 0 && nb >= 0) ? 0 : min(abs(na), abs(nb));
+        const int hi = max(abs(na), abs(nb));
+        kmin = klo[min(lo, P.nb - 1)];
+        kmax = min(khi[min(hi, P.nb - 1)], kmin + W - 1);
+    };
+
+    for (int e = tid; e < R * W * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
+    __syncthreads();
+    for (int q = 0; q < XB + S - 1; ++q) {
+        int kmin, kmax;
+        window(q, kmin, kmax);
+        const int j = jbase + q;
+        const int jr = (j >= 0 && j < tnum) ? j : P.zero_row;
+        const int slot = q % R;
+        for (int e = kmin + tid; e <= kmax; e += KF_THREADS) {
+            ldsG[slot * W + (e & (W - 1))] = P.GT[(size_t)jr * snum + e];
+            if (NEAR) ldsD[slot * W + (e & (W - 1))] = P.DT[(size_t)jr * snum + e];
+        }
+    }
+    // table entries of block 0
+    unsigned short tkc[S];
+    float twc[S], tw2c[NEAR ? S : 1];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const size_t o = (size_t)min(abs(nlo + s), ntab1) * snum + ti;
+        tkc[s] = P.TK[o];
+        twc[s] = P.TW[o];
+        if (NEAR) tw2c[s] = P.TW2[o];
+    }
+    __syncthreads();
+
+    float acc[XB];
+#pragma unroll
+    for (int i = 0; i < XB; ++i) acc[i] = 0.f;
+
+    for (int blk0 = 0; blk0 < nblocks; blk0 += R / S) {
+#pragma unroll
+        for (int bb = 0; bb < R / S; ++bb) {
+            const int blk = blk0 + bb;
+            if (blk >= nblocks) break;
+            float pfG[S][2], pfD[S][2];
+            int pk[S];
+            unsigned short tkn[S];
+            float twn[S], tw2n[NEAR ? S : 1];
+            const bool more = (blk + 1 < nblocks);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                pfG[s][0] = pfG[s][1] = 0.f;
+                pfD[s][0] = pfD[s][1] = 0.f;
+                pk[s] = 0;
+                tkn[s] = 0;
+                twn[s] = 0.f;
+                if (NEAR) tw2n[s] = 0.f;
+                if (more) {
+                    const int q = (blk + 1) * S + XB - 1 + s;
+                    int kmin, kmax;
+                    window(q, kmin, kmax);
+                    pk[s] = kmin;
+                    const int j = jbase + q;
+                    const int jr = (j >= 0 && j < tnum) ? j : P.zero_row;
+                    const float *src = P.GT + (size_t)jr * snum;
+                    const int e0 = min(kmin + tid, snum - 1), e1 = min(kmin + tid + KF_THREADS, snum - 1);
+                    pfG[s][0] = src[e0];
+                    pfG[s][1] = src[e1];
+                    if (NEAR) {
+                        const float *srd = P.DT + (size_t)jr * snum;
+                        pfD[s][0] = srd[e0];
+                        pfD[s][1] = srd[e1];
+                    }
+                    const size_t o = (size_t)min(abs(nlo + (blk + 1) * S + s), ntab1) * snum + ti;
+                    tkn[s] = P.TK[o];
+                    twn[s] = P.TW[o];
+                    if (NEAR) tw2n[s] = P.TW2[o];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int pm = bb * S + s;
+                const float w = twc[s];
+                const float w2 = NEAR ? tw2c[s] : 0.f;
+                const char *base = reinterpret_cast<const char *>(ldsG) + tkc[s];
+                const char *based = reinterpret_cast<const char *>(ldsD) + tkc[s];
+#pragma unroll
+                for (int i = 0; i < XB; ++i) {
+                    const int slot = (pm + i) % R;
+                    acc[i] = fmaf(w, *reinterpret_cast<const float *>(base + slot * W * 4), acc[i]);
+                    if (NEAR) acc[i] = fmaf(w2, *reinterpret_cast<const float *>(based + slot * W * 4), acc[i]);
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const int slot = ((bb + 1) * S + XB - 1 + s) % R;
+                    const int e0 = pk[s] + tid, e1 = e0 + KF_THREADS;
+                    ldsG[slot * W + (e0 & (W - 1))] = pfG[s][0];
+                    ldsG[slot * W + (e1 & (W - 1))] = pfG[s][1];
+                    if (NEAR) {
+                        ldsD[slot * W + (e0 & (W - 1))] = pfD[s][0];
+                        ldsD[slot * W + (e1 & (W - 1))] = pfD[s][1];
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                tkc[s] = tkn[s];
+                twc[s] = twn[s];
+                if (NEAR) tw2c[s] = tw2n[s];
+            }
+            __syncthreads();
+        }
+    }
+
+    if (ti_raw < snum) {
+        float *o = P.out + (size_t)ti_raw * P.ldo + (x0 - P.xlo);
+#pragma unroll
+        for (int i = 0; i < XB; ++i)
+            if (x0 + i < P.xhi) o[i] = acc[i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// quad kernel: table-driven ring in SAMPLE-MAJOR LDS layout.
+//   lds[(k mod W) * KQ_STRIDE + slot]      KQ_RING = 40 slots, row stride 44 floats
+// At one step every output i of a lane reads the SAME sample k from XB
+// consecutive ring slots, so in this layout the XB values are contiguous:
+// 6-7 aligned ds_read_b128 per step instead of 24 ds_read_b32.  The row
+// stride is 176 B = 16 B * 11 (odd): 16 lanes holding 16 consecutive samples
+// hit 16 distinct 16-byte bank groups, and the lane->sample permutation below
+// gives every hardware lane group of ds_read_b128 exactly such a run.
+// A step block is S = 8 offsets; the 8 traces the next block needs are two
+// aligned slot quads: each thread loads the same sample of the 8 traces at the
+// start of the block and publishes it with two ds_write_b128 at the end, so
+// the global-load latency has a whole block of LDS/FMA work to hide behind.
+// ---------------------------------------------------------------------------
+#ifndef KQ_PIPE
+#define KQ_PIPE 2
+#endif
+#define KQ_RING 40
+#define KQ_STRIDE 44
+#define KQ_RP KQ_STRIDE
+
+template <int XB, bool NEAR, int OCC>
+__global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams P, int W)
+{
+    constexpr int S = 8;
+    constexpr int RG = KQ_RING;               // ring slots
+    constexpr int ST = KQ_STRIDE;             // row stride (floats)
+    constexpr int NB = RG / S;                // step blocks per ring revolution (unroll length)
+    constexpr int NQ = RG / 4;                // slot quads
+    static_assert(XB + 2 * S - 1 <= RG && RG % S == 0 && XB % 4 == 0, "ring too small");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *ldsG = lds;
+    float *ldsD = lds + W * ST;
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7, r = b >> 3;
+    const int chunk = r / P.tiles_per_xcd;
+    const int qx = r - chunk * P.tiles_per_xcd;
+    const int xt = ((qx / P.G) * 8 + xcd) * P.G + (qx % P.G);
+    if (chunk >= P.nchunks || xt >= P.nxt) return;
+
+    const int tid = threadIdx.x;
+    const int s0 = chunk * KF_THREADS;
+    const int x0 = P.xlo + xt * XB;
+    const int snum = P.snum, tnum = P.tnum;
+    // ds_read_b128 is serviced in four groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31},
+    // {32-35,44-47,52-59}, {36-43,48-51,60-63}).  Give every group 16 CONSECUTIVE samples: their
+    // picks then span < 16 rows and row*11 mod 16 is a bijection, i.e. no bank conflicts.
+    const int lane = tid & 63;
+    const int l32 = lane & 31;
+    const int grp = ((l32 >= 4 && l32 < 12) || (l32 >= 16 && l32 < 20) || l32 >= 28) ? 1 : 0;
+    const int idx = grp ? (l32 < 12 ? l32 - 4 : (l32 < 20 ? l32 - 8 : l32 - 16))
+                        : (l32 < 4 ? l32 : (l32 < 16 ? l32 - 8 : l32 - 12));
+    const int sigma = (lane & 32) + grp * 16 + idx;
+    const int ti_raw = s0 + (tid & ~63) + sigma;
+    const int ti = min(ti_raw, snum - 1);
+
+    const int hmax = P.hmax[chunk];
+    const int *klo = P.klo + (size_t)chunk * P.nb;
+    const int *khi = P.khi + (size_t)chunk * P.nb;
+    const int nlo = max(-hmax, -(x0 + XB - 1));
+    const int nhi = min(hmax, tnum - 1 - x0);
+    const int nsteps = nhi - nlo + 1;
+    const int nblocks = (nsteps + S - 1) / S;
+    // the main loop always runs whole ring revolutions (NB blocks); steps past the
+    // aperture pick the table's all-zero row, so they add nothing
+    const int nrev = (nblocks + NB - 1) / NB;
+    const int nsteps_pad = nrev * NB * S;
+    const int jbase = x0 + nlo;
+    const int ntab1 = P.ntab - 1;
+
+    // samples [kmin,kmax] that ring-relative traces q0..q1 can be asked for
+    auto window = [&](int q0, int q1, int &kmin, int &kmax) {
+        const int pmin = max(0, q0 - (XB - 1)), pmax = min(q1, nsteps_pad - 1);
+        const int na = nlo + pmin, nb = nlo + pmax;
+        const int lo = (na <= 0 && nb >= 0) ? 0 : min(abs(na), abs(nb));
+        const int hi = max(abs(na), abs(nb));
+        kmin = klo[min(lo, P.nb - 1)];
+        kmax = min(khi[min(hi, P.nb - 1)], kmin + W - 1);
+    };
+    auto trace_ptr = [&](const float *img, int q) {
+        const int j = jbase + q;
+        return img + (size_t)((j >= 0 && j < tnum) ? j : P.zero_row) * snum;
+    };
+    auto tab_row = [&](int step) { return (size_t)min(abs(nlo + step), ntab1) * snum; };
+
+    for (int e = tid; e < W * ST * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
+    __syncthreads();
+    // ring position of ring-relative trace q is (q + 1) % RG, which makes the 8
+    // traces every later block adds two aligned slot quads
+    for (int q = 0; q < XB + S - 1; ++q) {
+        int kmin, kmax;
+        window(q, q, kmin, kmax);
+        const float *sg = trace_ptr(P.GT, q);
+        const float *sd = NEAR ? trace_ptr(P.DT, q) : nullptr;
+        const int pos = (q + 1) % RG;
+        for (int e = kmin + tid; e <= kmax; e += KF_THREADS) {
+            ldsG[(e % W) * ST + pos] = sg[e];
+            if (NEAR) ldsD[(e % W) * ST + pos] = sd[e];
+        }
+    }
+    // pick row / weight of the steps of the current block
+    unsigned short tkc[S];
+    float twc[S], tw2c[NEAR ? S : 1];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        tkc[s] = (P.TK + tab_row(s))[ti];
+        twc[s] = (P.TW + tab_row(s))[ti];
+        if (NEAR) tw2c[s] = (P.TW2 + tab_row(s))[ti];
+    }
+    __syncthreads();
+
+    float acc[XB];
+    float sink = 0.f;                            // absorbs the unused components of edge quads
+#pragma unroll
+    for (int i = 0; i < XB; ++i) acc[i] = 0.f;
+
+    for (int rev = 0; rev < nrev; ++rev) {
+#pragma clang loop unroll(full)
+        for (int bb = 0; bb < NB; ++bb) {
+            const int blk = rev * NB + bb;
+            // ---- issue the next block's loads: 8 traces x 2 samples per thread + table entries
+            const int q0 = (blk + 1) * S + XB - 1;
+            int kmin, kmax;
+            window(q0, q0 + S - 1, kmin, kmax);
+            const int e1 = kmin + tid + KF_THREADS;
+            const bool wr1 = e1 <= kmax;
+            const int c0 = min(kmin + tid, snum - 1), c1 = min(e1, snum - 1);
+            int m0 = (kmin % W) + tid;
+            m0 -= (m0 >= W) ? W : 0;
+            int m1 = m0 + KF_THREADS;
+            m1 -= (m1 >= W) ? W : 0;
+            m1 -= (m1 >= W) ? W : 0;
+            float g0[S], g1[S], d0[NEAR ? S : 1], d1[NEAR ? S : 1];
+            unsigned short tkn[S];
+            float twn[S], tw2n[NEAR ? S : 1];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float *src = trace_ptr(P.GT, q0 + s);
+                g0[s] = src[c0];
+                g1[s] = src[c1];
+                if (NEAR) {
+                    const float *srd = trace_ptr(P.DT, q0 + s);
+                    d0[s] = srd[c0];
+                    d1[s] = srd[c1];
+                }
+                const size_t ro = tab_row((blk + 1) * S + s);
+                tkn[s] = (P.TK + ro)[ti];
+                twn[s] = (P.TW + ro)[ti];
+                if (NEAR) tw2n[s] = (P.TW2 + ro)[ti];
+            }
+            // ---- S steps on the resident ring, software pipelined: the reads of step s+1 are
+            // in flight while the FMAs of step s run (two statically indexed quad buffers)
+            float4 va[NQ], vb[NQ], ua[NEAR ? NQ : 1], ub[NEAR ? NQ : 1];
+            auto needed = [](int pm, int qd) {
+                bool any = false;
+                for (int c = 0; c < 4; ++c) any = any || ((4 * qd + c - pm - 1 + 2 * RG) % RG) < XB;
+                return any;
+            };
+            auto load_step = [&](int s, float4 (&v)[NQ], float4 (&u)[NEAR ? NQ : 1]) {
+                const int pm = bb * S + s;                       // step index mod RG (compile time)
+                const float4 *base = reinterpret_cast<const float4 *>(ldsG) + tkc[s];   // row of sample k
+                const float4 *based = reinterpret_cast<const float4 *>(ldsD) + tkc[s];
+#pragma unroll
+                for (int qd = 0; qd < NQ; ++qd)
+                    if (needed(pm, qd)) {
+                        // must stay a whole ds_read_b128 also for the partly used quads at the ends of
+                        // the window (narrowed to b32 pieces they bank-conflict 4-way): fma_step feeds
+                        // the unused components to a sink accumulator so the compiler cannot narrow it
+                        v[qd] = base[qd];
+                        if (NEAR) u[qd] = based[qd];
+                    }
+            };
+            auto fma_step = [&](int s, const float4 (&v)[NQ], const float4 (&u)[NEAR ? NQ : 1]) {
+                const int pm = bb * S + s;
+                const float w = twc[s];
+                const float w2 = NEAR ? tw2c[s] : 0.f;
+#pragma unroll
+                for (int qd = 0; qd < NQ; ++qd) {
+                    // outputs served by slots 4qd .. 4qd+3 at this step
+                    const int i0 = (4 * qd + 0 - pm - 1 + 2 * RG) % RG;
+                    const int i1 = (4 * qd + 1 - pm - 1 + 2 * RG) % RG;
+                    const int i2 = (4 * qd + 2 - pm - 1 + 2 * RG) % RG;
+                    const int i3 = (4 * qd + 3 - pm - 1 + 2 * RG) % RG;
+                    const bool any = i0 < XB || i1 < XB || i2 < XB || i3 < XB;
+                    if (any) {
+                        float &a0 = i0 < XB ? acc[i0 < XB ? i0 : 0] : sink;
+                        float &a1 = i1 < XB ? acc[i1 < XB ? i1 : 0] : sink;
+                        float &a2 = i2 < XB ? acc[i2 < XB ? i2 : 0] : sink;
+                        float &a3 = i3 < XB ? acc[i3 < XB ? i3 : 0] : sink;
+                        a0 = fmaf(w, v[qd].x, a0);
+                        a1 = fmaf(w, v[qd].y, a1);
+                        a2 = fmaf(w, v[qd].z, a2);
+                        a3 = fmaf(w, v[qd].w, a3);
+                        if (NEAR) {
+                            a0 = fmaf(w2, u[qd].x, a0);
+                            a1 = fmaf(w2, u[qd].y, a1);
+                            a2 = fmaf(w2, u[qd].z, a2);
+                            a3 = fmaf(w2, u[qd].w, a3);
+                        }
+                    }
+                }
+            };
+            // The FMAs carry no chain, so instruction selection is free to sink a whole block's
+            // FMAs below all of its LDS reads (which then spill).  Passing the accumulators
+            // through an empty volatile asm after every step pins the order
+            // reads(s+1) -> FMAs(s) without consuming any load result early.
+#define KQ_PIN()                                                                                         \
+    do {                                                                                                 \
+        static_assert(XB == 24, "KQ_PIN lists 24 accumulators");                                         \
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]),         \
+                          "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]),         \
+                          "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]),    \
+                          "+v"(acc[15]), "+v"(acc[16]), "+v"(acc[17]), "+v"(acc[18]), "+v"(acc[19]),    \
+                          "+v"(acc[20]), "+v"(acc[21]), "+v"(acc[22]), "+v"(acc[23]), "+v"(sink)        \
+                     :: "memory");                                                                       \
+    } while (0)
+            load_step(0, va, ua);
+            KQ_PIN();
+            load_step(1, vb, ub); fma_step(0, va, ua); KQ_PIN();
+            load_step(2, va, ua); fma_step(1, vb, ub); KQ_PIN();
+            load_step(3, vb, ub); fma_step(2, va, ua); KQ_PIN();
+            load_step(4, va, ua); fma_step(3, vb, ub); KQ_PIN();
+            load_step(5, vb, ub); fma_step(4, va, ua); KQ_PIN();
+            load_step(6, va, ua); fma_step(5, vb, ub); KQ_PIN();
+            load_step(7, vb, ub); fma_step(6, va, ua); KQ_PIN();
+            fma_step(7, vb, ub);
+            KQ_PIN();
+            // ---- publish the next block's 8 traces: two aligned slot quads per sample
+            const int pos0 = ((bb + 1) * S + XB) % RG;            // (q0 + 1) % RG, multiple of 8
+            float *r0 = &ldsG[m0 * ST + pos0], *r1 = &ldsG[m1 * ST + pos0];
+            reinterpret_cast<float4 *>(r0)[0] = make_float4(g0[0], g0[1], g0[2], g0[3]);
+            reinterpret_cast<float4 *>(r0)[1] = make_float4(g0[4], g0[5], g0[6], g0[7]);
+            if (wr1) {
+                reinterpret_cast<float4 *>(r1)[0] = make_float4(g1[0], g1[1], g1[2], g1[3]);
+                reinterpret_cast<float4 *>(r1)[1] = make_float4(g1[4], g1[5], g1[6], g1[7]);
+            }
+            if (NEAR) {
+                float *t0 = &ldsD[m0 * ST + pos0], *t1 = &ldsD[m1 * ST + pos0];
+                reinterpret_cast<float4 *>(t0)[0] = make_float4(d0[0], d0[1], d0[2], d0[3]);
+                reinterpret_cast<float4 *>(t0)[1] = make_float4(d0[4], d0[5], d0[6], d0[7]);
+                if (wr1) {
+                    reinterpret_cast<float4 *>(t1)[0] = make_float4(d1[0], d1[1], d1[2], d1[3]);
+                    reinterpret_cast<float4 *>(t1)[1] = make_float4(d1[4], d1[5], d1[6], d1[7]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                tkc[s] = tkn[s];
+                twc[s] = twn[s];
+                if (NEAR) tw2c[s] = tw2n[s];
+            }
+            __syncthreads();
+        }
+    }
+
+    if (ti_raw < snum) {
+        float *o = P.out + (size_t)ti_raw * P.ldo + (x0 - P.xlo);
+#pragma unroll
+        for (int i = 0; i < XB; ++i)
+            if (x0 + i < P.xhi) o[i] = acc[i];
+        if (sink == 1.2345e38f) o[0] = sink;     // keeps the sink (and with it whole-quad reads) alive
+    }
+}
+
+// ---------------------------------------------------------------------------
+// trace-stationary variant.  Same tile (256 samples x XB output traces), but a
+// step consumes ONE input trace j for all XB outputs (offsets n_i = j-x0-i),
+// so only the trace being consumed (plus the ones in flight) sits in LDS:
+// 8 slots instead of XB+8.  The pick address / weight of an offset n is
+// computed once when n enters the window and kept in a per-lane register
+// ring for the XB steps that use it.  Per pair: one conflict-free
+// ds_read_b32 + one FMA; per step: one index computation.
+// ---------------------------------------------------------------------------
+template <int XB, int S, bool NEAR, int OCC>
+__global__ __launch_bounds__(KF_THREADS, OCC) void kirch_ts_kernel(FastParams P)
+{
+    constexpr int NS = 2 * S;                 // LDS slots (consume S, stage S)
+    constexpr int W = KF_W;
+    static_assert(XB % NS == 0, "unroll length must be a whole number of slot cycles");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *ldsG = lds;
+    float *ldsD = lds + NS * W;               // only when NEAR
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7, r = b >> 3;
+    const int chunk = r / P.tiles_per_xcd;
+    const int qx = r - chunk * P.tiles_per_xcd;
+    const int xt = ((qx / P.G) * 8 + xcd) * P.G + (qx % P.G);
+    if (chunk >= P.nchunks || xt >= P.nxt) return;
+
+    const int tid = threadIdx.x;
+    const int s0 = chunk * KF_THREADS;
+    const int x0 = P.xlo + xt * XB;
+    const int snum = P.snum, tnum = P.tnum;
+    const int ti_raw = s0 + tid;
+    const int ti = min(ti_raw, snum - 1);
+
+    const float Ah = P.Ahi[ti], Al = P.Alo[ti];
+    const float wc = P.wc[ti];
+    const float wc2 = NEAR ? P.wc2[ti] : 0.f;
+    const float apexw = P.apexw[ti];
+    const float apexk = (float)P.apexk[ti];
+    const float u0h = P.u0h, u0l = P.u0l, umh = P.umaxh, uml = P.umaxl;
+
+    const int hmax = P.hmax[chunk];
+    const int *klo = P.klo + (size_t)chunk * P.nb;
+    const int *khi = P.khi + (size_t)chunk * P.nb;
+    // step index p = 0.. : trace j = x0 + m, m = mlo + p; output i uses offset n = m - i
+    const int mlo = max(-hmax, -(x0 + XB - 1));
+    const int mhi = min(hmax + XB - 1, tnum - 1 - x0);
+    const int nsteps = mhi - mlo + 1;
+    const int nblocks = (nsteps + S - 1) / S;
+
+    auto window = [&](int m, int &kmin, int &kmax) {
+        const int na = m - (XB - 1), nb = m;
+        const int lo = (na <= 0 && nb >= 0) ? 0 : min(abs(na), abs(nb));
+        const int hi = max(abs(na), abs(nb));
+        kmin = klo[min(lo, P.nb - 1)];
+        kmax = min(khi[min(hi, P.nb - 1)], kmin + W - 1);
+    };
+    auto trace_row = [&](int m) {
+        const int j = x0 + m;
+        return (j >= 0 && j < tnum) ? j : P.zero_row;
+    };
+
+    for (int e = tid; e < NS * W * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
+    __syncthreads();
+    for (int q = 0; q < S; ++q) {                       // traces of block 0
+        int kmin, kmax;
+        window(mlo + q, kmin, kmax);
+        const int jr = trace_row(mlo + q);
+        for (int e = kmin + tid; e <= kmax; e += KF_THREADS) {
+            ldsG[q * W + (e & (W - 1))] = P.GT[(size_t)jr * snum + e];
+            if (NEAR) ldsD[q * W + (e & (W - 1))] = P.DT[(size_t)jr * snum + e];
+        }
+    }
+    __syncthreads();
+
+    float acc[XB], wgt[XB], wg2[NEAR ? XB : 1];
+    int kad[XB];
+#pragma unroll
+    for (int i = 0; i < XB; ++i) {
+        acc[i] = 0.f;
+        wgt[i] = 0.f;
+        kad[i] = 0;
+        if (NEAR) wg2[i] = 0.f;
+    }
+
+    for (int blk0 = 0; blk0 < nblocks; blk0 += XB / S) {
+#pragma unroll
+        for (int bb = 0; bb < XB / S; ++bb) {
+            const int blk = blk0 + bb;
+            if (blk >= nblocks) break;
+            float pfG[S][2], pfD[S][2];
+            int pk[S];
+            const bool more = (blk + 1 < nblocks);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                pfG[s][0] = pfG[s][1] = 0.f;
+                pfD[s][0] = pfD[s][1] = 0.f;
+                pk[s] = 0;
+                if (more) {
+                    const int m = mlo + (blk + 1) * S + s;
+                    int kmin, kmax;
+                    window(m, kmin, kmax);
+                    pk[s] = kmin;
+                    const int jr = trace_row(m);
+                    const float *src = P.GT + (size_t)jr * snum;
+                    const int e0 = min(kmin + tid, snum - 1), e1 = min(kmin + tid + KF_THREADS, snum - 1);
+                    pfG[s][0] = src[e0];
+                    pfG[s][1] = src[e1];
+                    if (NEAR) {
+                        const float *srd = P.DT + (size_t)jr * snum;
+                        pfD[s][0] = srd[e0];
+                        pfD[s][1] = srd[e1];
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int pm = bb * S + s;                 // step index mod XB (compile time)
+                const int slot = pm % NS;
+                const int n = mlo + blk * S + s;           // offset entering the window (output 0)
+                // ---- pick / weight of offset n, cached at ring index (XB - pm) % XB ... see below
+                const float2 Bn = P.B[min(abs(n), P.nb - 1)];
+                const float sh = Ah + Bn.x;
+                const float bv = sh - Ah;
+                const float er = (Ah - (sh - bv)) + (Bn.x - bv);
+                const float sl = er + (Al + Bn.y);
+                const float sc = fmaxf(sh, 1e-30f);
+                const float y = __builtin_amdgcn_rsqf(sc);
+                const float r0 = sc * y;
+                const float e = fmaf(-r0, r0, sc) + sl;
+                const float c = e * (0.5f * y);
+                float kf = rintf(r0 - u0h);
+                const float d = ((r0 - kf) - u0h) + (c - u0l);
+                kf += (d > 0.5f) ? 1.f : 0.f;
+                kf -= (d <= -0.5f) ? 1.f : 0.f;
+                bool keep = (((r0 - umh) + (c - uml)) <= 0.f) && (abs(n) <= hmax);
+                if (n == 0) {
+                    kf = apexk;
+                    keep = apexw != 0.f;
+                }
+                // output i at this step uses the entry of offset n - i, which was stored
+                // i steps ago at ring index (pm - i) mod XB
+                // ring index of an offset = (XB - step it entered) mod XB, so that at any
+                // step the entries used by outputs i = 0..XB-1 sit at (i - pm) mod XB:
+                // ascending with i, like acc[]
+                const int rnew = (XB - pm) % XB;
+                wgt[rnew] = keep ? wc * y : 0.f;
+                if (NEAR) wg2[rnew] = keep ? (wc2 * y) * (y * y) : 0.f;
+                kad[rnew] = (max((int)kf, 0) & (W - 1)) << 2;      // byte offset inside a slot
+                const char *sg = reinterpret_cast<const char *>(ldsG + slot * W);
+                const char *sd = reinterpret_cast<const char *>(ldsD + slot * W);
+#pragma unroll
+                for (int i = 0; i < XB; ++i) {
+                    const int ri = (i - pm + XB) % XB;
+                    acc[i] = fmaf(wgt[ri], *reinterpret_cast<const float *>(sg + kad[ri]), acc[i]);
+                    if (NEAR) acc[i] = fmaf(wg2[ri], *reinterpret_cast<const float *>(sd + kad[ri]), acc[i]);
+                }
+                // keep the scheduler from hoisting later steps' reads over this one
+                // (their results would have to stay live: spills at XB = 32)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const int slot = ((bb + 1) * S + s) % NS;
+                    const int e0 = pk[s] + tid, e1 = e0 + KF_THREADS;
+                    ldsG[slot * W + (e0 & (W - 1))] = pfG[s][0];
+                    ldsG[slot * W + (e1 & (W - 1))] = pfG[s][1];
+                    if (NEAR) {
+                        ldsD[slot * W + (e0 & (W - 1))] = pfD[s][0];
+                        ldsD[slot * W + (e1 & (W - 1))] = pfD[s][1];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    if (ti_raw < snum) {
+        float *o = P.out + (size_t)ti_raw * P.ldo + (x0 - P.xlo);
+#pragma unroll
+        for (int i = 0; i < XB; ++i)
+            if (x0 + i < P.xhi) o[i] = acc[i];
+    }
+}
+
 // ===========================================================================
 // host side
 // ===========================================================================
@@ -358,7 +1028,10 @@ struct impdar_kirch_plan {
     DevBuf d_dist, d_tt, d_zs, d_zs2, d_ga, d_gb, d_gc;
     DevBuf GT, DT;
     DevBuf d_Ahi, d_Alo, d_wc, d_wc2, d_apexw, d_apexk, d_B, d_hmax, d_klo, d_khi;
-    int nb = 0;
+    DevBuf d_TK, d_TW, d_TW2;
+    int nb = 0, ntab = 0;
+    bool quad = false;          // sample-major LDS ring (kirch_quad_kernel)
+    int quadW = 0;              // samples per ring slot in that layout
     // host copies for pair counting
     std::vector<int> h_half;       // exact aperture half-width per sample (uniform grids)
     float u0h = 0, u0l = 0, umaxh = 0, umaxl = 0;
@@ -390,7 +1063,7 @@ static int fast_xb_from_env()
     const char *e = getenv("IMPDAR_KIRCH_XB");
     if (e) {
         int v = atoi(e);
-        if (v == 16 || v == 32) return v;
+        if (v == 16 || v == 24 || v == 32) return v;
     }
     return 32;
 }
@@ -468,6 +1141,15 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         }
     }
     p->mode = mode;
+    {
+        // sample-major ring: window of the 4 traces a block adds, rounded up to 4 samples;
+        // must fit 16-bit byte offsets (W*RP*4 <= 65536) and leave room for >= 2 workgroups per CU
+        const char *ie = getenv("IMPDAR_KIRCH_IMPL");
+        const int wq = ((KF_THREADS + (int)std::ceil(sa * (24 + 8 - 2)) + 8 + 3) / 4) * 4;
+        p->quadW = wq;
+        p->quad = (mode == IMPDAR_KIRCH_FAST) && p->xb == 32 && wq * KQ_STRIDE * 4 <= 65536 &&
+                  (!ie || !strcmp(ie, "quad"));
+    }
 
     int rc = IMPDAR_OK;
     auto fail = [&](int code) {
@@ -556,6 +1238,15 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         }
         const int nb = hglob + 64;
         p->nb = nb;
+        p->ntab = hglob + 1;       // offsets 0..hglob-1 (hmax carries a guard) + one all-zero row
+        {
+            const size_t ent = (size_t)p->ntab * snum;
+            if (p->d_TK.ensure(ent * 2) != hipSuccess || p->d_TW.ensure(ent * 4) != hipSuccess ||
+                (p->nearfield && p->d_TW2.ensure(ent * 4) != hipSuccess)) {
+                impdar_set_error("hipMalloc of the %zu-entry pick/weight table failed", ent);
+                return fail(IMPDAR_ERR_HIP);
+            }
+        }
         std::vector<float2> B(nb);
         for (int n = 0; n < nb; ++n) split2(p->alpha * (double)n * (double)n, B[n].x, B[n].y);
         // staging windows: smallest / largest sample index any lane of chunk c
@@ -638,6 +1329,28 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
             hipLaunchKernelGGL((kirch_prep_kernel<double, double>), grid, dim3(256), 0, st, P);
         IMPDAR_HIP_CHECK(hipGetLastError());
     }
+    if (p->mode == IMPDAR_KIRCH_FAST) {
+        // geometry-only pick/weight table, rebuilt with every prep (counted in prep time)
+        TableParams T;
+        T.TK = p->d_TK.as<unsigned short>();
+        T.TW = p->d_TW.as<float>();
+        T.TW2 = p->d_TW2.as<float>();
+        T.zs = p->d_zs.as<double>();
+        T.zs2 = p->d_zs2.as<double>();
+        T.tt = p->d_tt.as<double>();
+        T.dx = p->dx;
+        T.vel = p->vel;
+        T.tmax = p->tmax;
+        T.inv_dt = 1.0 / p->dt;
+        T.tt0 = p->tt0;
+        T.snum = p->snum;
+        T.ntab = p->ntab;
+        T.near = p->nearfield;
+        T.wmod = p->quad ? p->quadW : KF_W;
+        T.kscale = p->quad ? KQ_STRIDE / 4 : 4;  // quad layout: offset in float4 units
+        hipLaunchKernelGGL(kirch_table_kernel, dim3((p->snum + 255) / 256, p->ntab), dim3(256), 0, st, T);
+        IMPDAR_HIP_CHECK(hipGetLastError());
+    }
     IMPDAR_HIP_CHECK(hipEventRecord(ev[1], st));
     p->haves[p->slot][0] = true;
     return IMPDAR_OK;
@@ -674,6 +1387,78 @@ static int launch_fast(impdar_kirch_plan *p, const FastParams &P0, int ntiles, h
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(k, dim3(nblk), dim3(KF_THREADS), shmem, st, P);
     }
+    IMPDAR_HIP_CHECK(hipGetLastError());
+    return IMPDAR_OK;
+}
+
+template <int XB, int OCC>
+static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipStream_t st)
+{
+    FastParams P = P0;
+    const int ntiles = (nx + XB - 1) / XB;
+    P.nxt = ntiles;
+    P.G = 4;
+    const int per = 8 * P.G;
+    const int nxt_pad = ((ntiles + per - 1) / per) * per;
+    P.tiles_per_xcd = nxt_pad / 8;
+    const int nblk = P.nchunks * nxt_pad;
+    const int W = p->quadW;
+    const size_t shmem = (size_t)W * KQ_STRIDE * 4 * (p->nearfield ? 2 : 1);
+    if (p->nearfield) {
+        auto k = kirch_quad_kernel<XB, true, 1>;
+        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k, dim3(nblk), dim3(KF_THREADS), shmem, st, P, W);
+    } else {
+        auto k = kirch_quad_kernel<XB, false, OCC>;
+        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k, dim3(nblk), dim3(KF_THREADS), shmem, st, P, W);
+    }
+    IMPDAR_HIP_CHECK(hipGetLastError());
+    return IMPDAR_OK;
+}
+
+template <int XB, int S, int OCC>
+static int launch_tab(impdar_kirch_plan *p, const FastParams &P0, int nx, hipStream_t st)
+{
+    constexpr int R = XB + 2 * S;
+    FastParams P = P0;
+    const int ntiles = (nx + XB - 1) / XB;
+    P.nxt = ntiles;
+    P.G = 4;
+    const int per = 8 * P.G;
+    const int nxt_pad = ((ntiles + per - 1) / per) * per;
+    P.tiles_per_xcd = nxt_pad / 8;
+    const int nblk = P.nchunks * nxt_pad;
+    const size_t shmem = (size_t)R * KF_W * 4 * (p->nearfield ? 2 : 1);
+    if (p->nearfield) {
+        auto k = kirch_tab_kernel<XB, S, true, 1>;
+        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k, dim3(nblk), dim3(KF_THREADS), shmem, st, P);
+    } else {
+        auto k = kirch_tab_kernel<XB, S, false, OCC>;
+        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k, dim3(nblk), dim3(KF_THREADS), shmem, st, P);
+    }
+    IMPDAR_HIP_CHECK(hipGetLastError());
+    return IMPDAR_OK;
+}
+
+template <int XB, int S, int OCC>
+static int launch_ts(impdar_kirch_plan *p, const FastParams &P0, int nx, hipStream_t st)
+{
+    FastParams P = P0;
+    const int ntiles = (nx + XB - 1) / XB;
+    P.nxt = ntiles;
+    P.G = 4;
+    const int per = 8 * P.G;
+    const int nxt_pad = ((ntiles + per - 1) / per) * per;
+    P.tiles_per_xcd = nxt_pad / 8;
+    const int nblk = P.nchunks * nxt_pad;
+    const size_t shmem = (size_t)(2 * S) * KF_W * 4 * (p->nearfield ? 2 : 1);
+    if (p->nearfield)
+        hipLaunchKernelGGL((kirch_ts_kernel<XB, S, true, (OCC > 2 ? 2 : OCC)>), dim3(nblk), dim3(KF_THREADS), shmem, st, P);
+    else
+        hipLaunchKernelGGL((kirch_ts_kernel<XB, S, false, OCC>), dim3(nblk), dim3(KF_THREADS), shmem, st, P);
     IMPDAR_HIP_CHECK(hipGetLastError());
     return IMPDAR_OK;
 }
@@ -715,10 +1500,42 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         P.umaxh = p->umaxh;
         P.umaxl = p->umaxl;
         P.nchunks = p->nchunks;
+        P.TK = p->d_TK.as<unsigned short>();
+        P.TW = p->d_TW.as<float>();
+        P.TW2 = p->d_TW2.as<float>();
+        P.ntab = p->ntab;
+        {
+            const char *de = getenv("IMPDAR_KIRCH_DBG");
+            P.dbg = de ? atoi(de) : 0;
+        }
         int rc;
         const char *se = getenv("IMPDAR_KIRCH_S");
         const int sblk = se ? atoi(se) : 4;
-        if (p->xb == 16 && sblk == 8)
+        const char *ie = getenv("IMPDAR_KIRCH_IMPL");
+        const bool ring = ie && !strcmp(ie, "ring");
+        const bool ts = ie && !strcmp(ie, "ts");
+        const char *oe0 = getenv("IMPDAR_KIRCH_OCC");
+        const int occ0 = oe0 ? atoi(oe0) : 0;
+        if (p->quad) {
+            rc = (occ0 == 2) ? launch_quad<24, 2>(p, P, nx, st) : launch_quad<24, 3>(p, P, nx, st);
+        } else if (!ring && !ts) {
+            if (p->xb == 16)
+                rc = (occ0 == 3) ? launch_tab<16, 4, 3>(p, P, nx, st) : launch_tab<16, 4, 4>(p, P, nx, st);
+            else if (p->xb == 24)
+                rc = (occ0 == 2) ? launch_tab<24, 4, 2>(p, P, nx, st) : launch_tab<24, 4, 3>(p, P, nx, st);
+            else
+                rc = (occ0 == 3) ? launch_tab<32, 4, 3>(p, P, nx, st) : launch_tab<32, 4, 2>(p, P, nx, st);
+        } else
+        if (!ring) {
+            const char *oe = getenv("IMPDAR_KIRCH_OCC");
+            const int occ = oe ? atoi(oe) : 0;
+            if (p->xb == 16)
+                rc = (occ == 4) ? launch_ts<16, 4, 4>(p, P, nx, st) : launch_ts<16, 4, 3>(p, P, nx, st);
+            else if (p->xb == 24)
+                rc = (occ == 2) ? launch_ts<24, 4, 2>(p, P, nx, st) : launch_ts<24, 4, 3>(p, P, nx, st);
+            else
+                rc = (occ == 3) ? launch_ts<32, 4, 3>(p, P, nx, st) : launch_ts<32, 4, 2>(p, P, nx, st);
+        } else if (p->xb == 16 && sblk == 8)
             rc = launch_fast<16, 8>(p, P, (nx + 15) / 16, st);
         else if (p->xb == 16)
             rc = launch_fast<16, 4>(p, P, (nx + 15) / 16, st);
