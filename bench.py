@@ -191,7 +191,7 @@ def main():
                        "output_finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": "kirch_fast_kernel" if plan.mode == 'fast' else "kirch_exact_kernel",
+                         "kernel": "kirch_quad_kernel" if plan.mode == 'fast' else "kirch_exact_kernel",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo_bytes},
         }
         if world == 1 and not args.no_cpu:

@@ -11,12 +11,14 @@
 //                       transpose, so one input trace is one contiguous run.
 //   kirch_exact_kernel  per-pair fp64 index math in the reference's operation
 //                       order; any dist / travel_time; float or double data.
-//   kirch_fast_kernel   the MI355X hot path: fp32 data, uniform grids.  A
-//                       workgroup owns SC=256 output samples x XB output
-//                       traces; input traces stream through an LDS ring and
-//                       the pick index / obliquity weight of an offset
-//                       n = j - xi is computed once per (sample, n) and reused
-//                       for the XB (xi, xi+n) pairs on that diagonal.
+//   kirch_table_kernel  fp64 pick index + obliquity weight per (sample, |offset|)
+//                       in the reference's operation order (uniform trace spacing).
+//   kirch_quad_kernel   the MI355X hot path: fp32 data, uniform grids.  A
+//                       workgroup owns 256 output samples x 24 output traces;
+//                       input traces stream through a sample-major LDS ring read
+//                       with ds_read_b128; pick/weight come from the table.
+//   kirch_tab_kernel    same idea with a trace-major ring and ds_read_b32, for
+//                       geometries whose moveout does not fit the quad ring.
 #include "common.h"
 #include <cmath>
 #include <algorithm>
@@ -154,200 +156,16 @@ struct FastParams {
     float *out;
     int ldo;
     int snum, tnum, xlo, xhi;
-    const float *Ahi, *Alo;        // (tt[ti]/dt)^2 split hi+lo           [snum]
-    const float *wc, *wc2;         // far / near weight prefactors         [snum]
-    const float *apexw;            // 1 or 0: n==0 pair kept by the reference's own t>tmax test
-    const int *apexk;              // sample the n==0 pair picks (fp64 reference order; differs from ti for t<0)
-    const float2 *B;               // alpha*n^2 split hi+lo                [nb]
-    const int *hmax;               // per sample-chunk aperture half width [nchunks]
+    const int *hmax;               // per sample-chunk aperture half width (+1 guard)     [nchunks]
     const int *klo, *khi;          // per (chunk, |n|) first / last sample a trace at offset n is asked for
-    int nb;                        // entries per chunk in klo/khi (and in B)
+    int nb;                        // entries per chunk in klo/khi
     int zero_row;                  // index of an all-zero image row (out-of-profile traces)
-    float u0h, u0l, umaxh, umaxl;
     int nchunks, nxt, tiles_per_xcd, G;
-    // pick/weight table of the table-driven kernel: entry (|n|, ti)
-    const unsigned short *TK;      // byte offset of the picked sample inside a ring slot  [ntab][snum]
+    // pick/weight table: entry (|n|, ti)
+    const unsigned short *TK;      // offset of the picked sample's row inside a ring slot    [ntab][snum]
     const float *TW, *TW2;         // far / near weights (0 where the reference drops the pair)
     int ntab;                      // rows; the last row is all zero (|n| beyond every aperture)
-    int dbg;                       // timing experiments only (bit0: all trace loads hit row 0, bit1: all table loads hit row 0)
 };
-
-template <int XB, int S, bool NEAR>
-__global__ __launch_bounds__(KF_THREADS) void kirch_fast_kernel(FastParams P)
-{
-    constexpr int R = XB + 2 * S;            // ring slots (multiple of S)
-    constexpr int W = KF_W;
-    static_assert(R % S == 0, "ring must be a whole number of step blocks");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *ldsG = lds;
-    float *ldsD = lds + R * W;               // only when NEAR
-
-    // ---- block -> (sample chunk, trace tile), XCD-aware --------------------
-    // blocks b and b+8 share an XCD; give each XCD groups of G adjacent trace
-    // tiles (they re-read the same input traces XB steps apart -> L2 hits) and
-    // every XCD the same mix of shallow (heavy) and deep (light) chunks.
-    const int b = blockIdx.x;
-    const int xcd = b & 7, r = b >> 3;
-    const int chunk = r / P.tiles_per_xcd;
-    const int qx = r - chunk * P.tiles_per_xcd;
-    const int xt = ((qx / P.G) * 8 + xcd) * P.G + (qx % P.G);
-    if (chunk >= P.nchunks || xt >= P.nxt) return;
-
-    const int tid = threadIdx.x;
-    const int s0 = chunk * KF_THREADS;
-    const int x0 = P.xlo + xt * XB;
-    const int snum = P.snum, tnum = P.tnum;
-    const int ti_raw = s0 + tid;
-    const int ti = min(ti_raw, snum - 1);
-
-    // per-lane constants
-    const float Ah = P.Ahi[ti], Al = P.Alo[ti];
-    const float wc = P.wc[ti];
-    const float wc2 = NEAR ? P.wc2[ti] : 0.f;
-    const float apexw = P.apexw[ti];
-    const float apexk = (float)P.apexk[ti];
-    const float u0h = P.u0h, u0l = P.u0l, umh = P.umaxh, uml = P.umaxl;
-
-    // uniform tile geometry
-    const int hmax = P.hmax[chunk];
-    const int *klo = P.klo + (size_t)chunk * P.nb;
-    const int *khi = P.khi + (size_t)chunk * P.nb;
-    const int nlo = max(-hmax, -(x0 + XB - 1));
-    const int nhi = min(hmax, tnum - 1 - x0);
-    const int nsteps = nhi - nlo + 1;
-    const int nblocks = (nsteps + S - 1) / S;
-    const int nsteps_pad = nblocks * S;
-    const int jbase = x0 + nlo;              // ring-relative trace 0
-
-    // window [kmin,kmax] of samples that ring-relative trace q can be asked for
-    // (host tables: pick index of the chunk's first sample at the smallest |n|
-    // the trace is used with, and of its last sample at the largest |n|)
-    auto window = [&](int q, int &kmin, int &kmax) {
-        const int pmin = max(0, q - (XB - 1)), pmax = min(q, nsteps_pad - 1);
-        const int na = nlo + pmin, nb = nlo + pmax;
-        const int lo = (na <= 0 && nb >= 0) ? 0 : min(abs(na), abs(nb));
-        const int hi = max(abs(na), abs(nb));
-        kmin = klo[min(lo, P.nb - 1)];
-        kmax = min(khi[min(hi, P.nb - 1)], kmin + W - 1);
-    };
-
-    // ---- prologue: clear the ring, stage the first XB+S-1 traces -----------
-    for (int e = tid; e < R * W * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
-    __syncthreads();
-    for (int q = 0; q < XB + S - 1; ++q) {
-        int kmin, kmax;
-        window(q, kmin, kmax);
-        const int j = jbase + q;
-        const int jr = (j >= 0 && j < tnum) ? j : P.zero_row;
-        const int slot = q % R;
-        for (int e = kmin + tid; e <= kmax; e += KF_THREADS) {
-            ldsG[slot * W + (e & (W - 1))] = P.GT[(size_t)jr * snum + e];
-            if (NEAR) ldsD[slot * W + (e & (W - 1))] = P.DT[(size_t)jr * snum + e];
-        }
-    }
-    __syncthreads();
-
-    float acc[XB];
-#pragma unroll
-    for (int i = 0; i < XB; ++i) acc[i] = 0.f;
-
-    for (int blk0 = 0; blk0 < nblocks; blk0 += R / S) {
-#pragma unroll
-        for (int bb = 0; bb < R / S; ++bb) {
-            const int blk = blk0 + bb;
-            if (blk >= nblocks) break;
-            // -- issue the global loads of the S traces the next block adds
-            // (unconditional: the element index is clamped into the trace and
-            // out-of-profile traces read the image's all-zero row; anything
-            // landing outside the trace's window is never consumed)
-            float pfG[S][2], pfD[S][2];
-            int pk[S];
-            const bool more = (blk + 1 < nblocks);
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                pfG[s][0] = pfG[s][1] = 0.f;
-                pfD[s][0] = pfD[s][1] = 0.f;
-                pk[s] = 0;
-                if (more) {
-                    const int q = (blk + 1) * S + XB - 1 + s;
-                    int kmin, kmax;
-                    window(q, kmin, kmax);
-                    pk[s] = kmin;
-                    const int j = jbase + q;
-                    const int jr = (j >= 0 && j < tnum) ? j : P.zero_row;
-                    const float *src = P.GT + (size_t)jr * snum;
-                    const int e0 = min(kmin + tid, snum - 1), e1 = min(kmin + tid + KF_THREADS, snum - 1);
-                    pfG[s][0] = src[e0];
-                    pfG[s][1] = src[e1];
-                    if (NEAR) {
-                        const float *srd = P.DT + (size_t)jr * snum;
-                        pfD[s][0] = srd[e0];
-                        pfD[s][1] = srd[e1];
-                    }
-                }
-            }
-            // -- S offset steps on the resident ring
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const int pm = bb * S + s;                 // step index mod R (compile time)
-                const int n = nlo + blk * S + s;
-                const float2 Bn = P.B[abs(n)];
-                // q = A + B in double-float
-                const float sh = Ah + Bn.x;
-                const float bv = sh - Ah;
-                const float er = (Ah - (sh - bv)) + (Bn.x - bv);
-                const float sl = er + (Al + Bn.y);
-                const float sc = fmaxf(sh, 1e-30f);
-                const float y = __builtin_amdgcn_rsqf(sc);  // 1/u
-                const float r0 = sc * y;                    // u ~ sqrt(q)
-                const float e = fmaf(-r0, r0, sc) + sl;     // q - r0^2
-                const float c = e * (0.5f * y);             // Newton correction, u = r0 + c
-                float kf = rintf(r0 - u0h);
-                const float d = ((r0 - kf) - u0h) + (c - u0l);
-                kf += (d > 0.5f) ? 1.f : 0.f;               // nearest sample, ties -> lower index
-                kf -= (d <= -0.5f) ? 1.f : 0.f;
-                bool keep = ((r0 - umh) + (c - uml)) <= 0.f;         // t <= max travel time
-                if (n == 0) {
-                    // apex pair: t is tt[ti] up to the reference's own fp64 rounding, which
-                    // the host evaluated exactly (apexw); the pick is the sample itself
-                    kf = apexk;
-                    keep = apexw != 0.f;
-                }
-                const float w = keep ? wc * y : 0.f;
-                const float w2 = (NEAR && keep) ? (wc2 * y) * (y * y) : 0.f;
-                const int kidx = max((int)kf, 0) & (W - 1);
-#pragma unroll
-                for (int i = 0; i < XB; ++i) {
-                    const int slot = (pm + i) % R;
-                    acc[i] = fmaf(w, ldsG[slot * W + kidx], acc[i]);
-                    if (NEAR) acc[i] = fmaf(w2, ldsD[slot * W + kidx], acc[i]);
-                }
-            }
-            // -- publish the prefetched traces for the next block
-            if (more) {
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const int slot = ((bb + 1) * S + XB - 1 + s) % R;
-                    const int e0 = pk[s] + tid, e1 = e0 + KF_THREADS;
-                    ldsG[slot * W + (e0 & (W - 1))] = pfG[s][0];
-                    ldsG[slot * W + (e1 & (W - 1))] = pfG[s][1];
-                    if (NEAR) {
-                        ldsD[slot * W + (e0 & (W - 1))] = pfD[s][0];
-                        ldsD[slot * W + (e1 & (W - 1))] = pfD[s][1];
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-
-    if (ti_raw < snum) {
-        float *o = P.out + (size_t)ti_raw * P.ldo + (x0 - P.xlo);
-#pragma unroll
-        for (int i = 0; i < XB; ++i)
-            if (x0 + i < P.xhi) o[i] = acc[i];
-    }
-}
 
 // ---------------------------------------------------------------------------
 // pick / weight table.  For a uniform trace spacing the sample picked by the
@@ -401,10 +219,10 @@ __global__ __launch_bounds__(256) void kirch_table_kernel(TableParams P)
 }
 
 // ---------------------------------------------------------------------------
-// table-driven ring kernel: the same tile and LDS ring as kirch_fast_kernel,
-// but the per-(sample, offset) pick and weight come from the table (two
-// coalesced loads per lane per step, prefetched a block ahead) instead of
-// ~40 VALU instructions of double-float index arithmetic.
+// table-driven ring kernel, trace-major LDS layout: a 256-sample x XB-trace tile walks the
+// trace offset n; the XB+8 input traces in use sit in an LDS ring of 512-sample circular
+// slots, the per-(sample, offset) pick and weight come from the table (two coalesced loads
+// per lane per step, prefetched a block ahead), one conflict-free ds_read_b32 + FMA per pair.
 // ---------------------------------------------------------------------------
 template <int XB, int S, bool NEAR, int OCC>
 __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_tab_kernel(FastParams P)
@@ -829,191 +647,6 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     }
 }
 
-// ---------------------------------------------------------------------------
-// trace-stationary variant.  Same tile (256 samples x XB output traces), but a
-// step consumes ONE input trace j for all XB outputs (offsets n_i = j-x0-i),
-// so only the trace being consumed (plus the ones in flight) sits in LDS:
-// 8 slots instead of XB+8.  The pick address / weight of an offset n is
-// computed once when n enters the window and kept in a per-lane register
-// ring for the XB steps that use it.  Per pair: one conflict-free
-// ds_read_b32 + one FMA; per step: one index computation.
-// ---------------------------------------------------------------------------
-template <int XB, int S, bool NEAR, int OCC>
-__global__ __launch_bounds__(KF_THREADS, OCC) void kirch_ts_kernel(FastParams P)
-{
-    constexpr int NS = 2 * S;                 // LDS slots (consume S, stage S)
-    constexpr int W = KF_W;
-    static_assert(XB % NS == 0, "unroll length must be a whole number of slot cycles");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *ldsG = lds;
-    float *ldsD = lds + NS * W;               // only when NEAR
-
-    const int b = blockIdx.x;
-    const int xcd = b & 7, r = b >> 3;
-    const int chunk = r / P.tiles_per_xcd;
-    const int qx = r - chunk * P.tiles_per_xcd;
-    const int xt = ((qx / P.G) * 8 + xcd) * P.G + (qx % P.G);
-    if (chunk >= P.nchunks || xt >= P.nxt) return;
-
-    const int tid = threadIdx.x;
-    const int s0 = chunk * KF_THREADS;
-    const int x0 = P.xlo + xt * XB;
-    const int snum = P.snum, tnum = P.tnum;
-    const int ti_raw = s0 + tid;
-    const int ti = min(ti_raw, snum - 1);
-
-    const float Ah = P.Ahi[ti], Al = P.Alo[ti];
-    const float wc = P.wc[ti];
-    const float wc2 = NEAR ? P.wc2[ti] : 0.f;
-    const float apexw = P.apexw[ti];
-    const float apexk = (float)P.apexk[ti];
-    const float u0h = P.u0h, u0l = P.u0l, umh = P.umaxh, uml = P.umaxl;
-
-    const int hmax = P.hmax[chunk];
-    const int *klo = P.klo + (size_t)chunk * P.nb;
-    const int *khi = P.khi + (size_t)chunk * P.nb;
-    // step index p = 0.. : trace j = x0 + m, m = mlo + p; output i uses offset n = m - i
-    const int mlo = max(-hmax, -(x0 + XB - 1));
-    const int mhi = min(hmax + XB - 1, tnum - 1 - x0);
-    const int nsteps = mhi - mlo + 1;
-    const int nblocks = (nsteps + S - 1) / S;
-
-    auto window = [&](int m, int &kmin, int &kmax) {
-        const int na = m - (XB - 1), nb = m;
-        const int lo = (na <= 0 && nb >= 0) ? 0 : min(abs(na), abs(nb));
-        const int hi = max(abs(na), abs(nb));
-        kmin = klo[min(lo, P.nb - 1)];
-        kmax = min(khi[min(hi, P.nb - 1)], kmin + W - 1);
-    };
-    auto trace_row = [&](int m) {
-        const int j = x0 + m;
-        return (j >= 0 && j < tnum) ? j : P.zero_row;
-    };
-
-    for (int e = tid; e < NS * W * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
-    __syncthreads();
-    for (int q = 0; q < S; ++q) {                       // traces of block 0
-        int kmin, kmax;
-        window(mlo + q, kmin, kmax);
-        const int jr = trace_row(mlo + q);
-        for (int e = kmin + tid; e <= kmax; e += KF_THREADS) {
-            ldsG[q * W + (e & (W - 1))] = P.GT[(size_t)jr * snum + e];
-            if (NEAR) ldsD[q * W + (e & (W - 1))] = P.DT[(size_t)jr * snum + e];
-        }
-    }
-    __syncthreads();
-
-    float acc[XB], wgt[XB], wg2[NEAR ? XB : 1];
-    int kad[XB];
-#pragma unroll
-    for (int i = 0; i < XB; ++i) {
-        acc[i] = 0.f;
-        wgt[i] = 0.f;
-        kad[i] = 0;
-        if (NEAR) wg2[i] = 0.f;
-    }
-
-    for (int blk0 = 0; blk0 < nblocks; blk0 += XB / S) {
-#pragma unroll
-        for (int bb = 0; bb < XB / S; ++bb) {
-            const int blk = blk0 + bb;
-            if (blk >= nblocks) break;
-            float pfG[S][2], pfD[S][2];
-            int pk[S];
-            const bool more = (blk + 1 < nblocks);
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                pfG[s][0] = pfG[s][1] = 0.f;
-                pfD[s][0] = pfD[s][1] = 0.f;
-                pk[s] = 0;
-                if (more) {
-                    const int m = mlo + (blk + 1) * S + s;
-                    int kmin, kmax;
-                    window(m, kmin, kmax);
-                    pk[s] = kmin;
-                    const int jr = trace_row(m);
-                    const float *src = P.GT + (size_t)jr * snum;
-                    const int e0 = min(kmin + tid, snum - 1), e1 = min(kmin + tid + KF_THREADS, snum - 1);
-                    pfG[s][0] = src[e0];
-                    pfG[s][1] = src[e1];
-                    if (NEAR) {
-                        const float *srd = P.DT + (size_t)jr * snum;
-                        pfD[s][0] = srd[e0];
-                        pfD[s][1] = srd[e1];
-                    }
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const int pm = bb * S + s;                 // step index mod XB (compile time)
-                const int slot = pm % NS;
-                const int n = mlo + blk * S + s;           // offset entering the window (output 0)
-                // ---- pick / weight of offset n, cached at ring index (XB - pm) % XB ... see below
-                const float2 Bn = P.B[min(abs(n), P.nb - 1)];
-                const float sh = Ah + Bn.x;
-                const float bv = sh - Ah;
-                const float er = (Ah - (sh - bv)) + (Bn.x - bv);
-                const float sl = er + (Al + Bn.y);
-                const float sc = fmaxf(sh, 1e-30f);
-                const float y = __builtin_amdgcn_rsqf(sc);
-                const float r0 = sc * y;
-                const float e = fmaf(-r0, r0, sc) + sl;
-                const float c = e * (0.5f * y);
-                float kf = rintf(r0 - u0h);
-                const float d = ((r0 - kf) - u0h) + (c - u0l);
-                kf += (d > 0.5f) ? 1.f : 0.f;
-                kf -= (d <= -0.5f) ? 1.f : 0.f;
-                bool keep = (((r0 - umh) + (c - uml)) <= 0.f) && (abs(n) <= hmax);
-                if (n == 0) {
-                    kf = apexk;
-                    keep = apexw != 0.f;
-                }
-                // output i at this step uses the entry of offset n - i, which was stored
-                // i steps ago at ring index (pm - i) mod XB
-                // ring index of an offset = (XB - step it entered) mod XB, so that at any
-                // step the entries used by outputs i = 0..XB-1 sit at (i - pm) mod XB:
-                // ascending with i, like acc[]
-                const int rnew = (XB - pm) % XB;
-                wgt[rnew] = keep ? wc * y : 0.f;
-                if (NEAR) wg2[rnew] = keep ? (wc2 * y) * (y * y) : 0.f;
-                kad[rnew] = (max((int)kf, 0) & (W - 1)) << 2;      // byte offset inside a slot
-                const char *sg = reinterpret_cast<const char *>(ldsG + slot * W);
-                const char *sd = reinterpret_cast<const char *>(ldsD + slot * W);
-#pragma unroll
-                for (int i = 0; i < XB; ++i) {
-                    const int ri = (i - pm + XB) % XB;
-                    acc[i] = fmaf(wgt[ri], *reinterpret_cast<const float *>(sg + kad[ri]), acc[i]);
-                    if (NEAR) acc[i] = fmaf(wg2[ri], *reinterpret_cast<const float *>(sd + kad[ri]), acc[i]);
-                }
-                // keep the scheduler from hoisting later steps' reads over this one
-                // (their results would have to stay live: spills at XB = 32)
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (more) {
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const int slot = ((bb + 1) * S + s) % NS;
-                    const int e0 = pk[s] + tid, e1 = e0 + KF_THREADS;
-                    ldsG[slot * W + (e0 & (W - 1))] = pfG[s][0];
-                    ldsG[slot * W + (e1 & (W - 1))] = pfG[s][1];
-                    if (NEAR) {
-                        ldsD[slot * W + (e0 & (W - 1))] = pfD[s][0];
-                        ldsD[slot * W + (e1 & (W - 1))] = pfD[s][1];
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-
-    if (ti_raw < snum) {
-        float *o = P.out + (size_t)ti_raw * P.ldo + (x0 - P.xlo);
-#pragma unroll
-        for (int i = 0; i < XB; ++i)
-            if (x0 + i < P.xhi) o[i] = acc[i];
-    }
-}
-
 // ===========================================================================
 // host side
 // ===========================================================================
@@ -1027,14 +660,13 @@ struct impdar_kirch_plan {
     // device tables
     DevBuf d_dist, d_tt, d_zs, d_zs2, d_ga, d_gb, d_gc;
     DevBuf GT, DT;
-    DevBuf d_Ahi, d_Alo, d_wc, d_wc2, d_apexw, d_apexk, d_B, d_hmax, d_klo, d_khi;
+    DevBuf d_hmax, d_klo, d_khi;
     DevBuf d_TK, d_TW, d_TW2;
     int nb = 0, ntab = 0;
     bool quad = false;          // sample-major LDS ring (kirch_quad_kernel)
     int quadW = 0;              // samples per ring slot in that layout
     // host copies for pair counting
     std::vector<int> h_half;       // exact aperture half-width per sample (uniform grids)
-    float u0h = 0, u0l = 0, umaxh = 0, umaxl = 0;
     int nchunks = 0;
     // ring of HIP-event sets so a timed loop can read per-step kernel
     // durations afterwards without synchronising inside the loop
@@ -1045,27 +677,11 @@ struct impdar_kirch_plan {
     int xb = 32;                   // fast-kernel trace tile
 };
 
-static void split2(double v, float &hi, float &lo)
-{
-    hi = (float)v;
-    lo = (float)(v - (double)hi);
-}
-
 static int upload(DevBuf &b, const void *src, size_t bytes)
 {
     IMPDAR_HIP_CHECK(b.ensure(bytes ? bytes : 8));
     if (bytes) IMPDAR_HIP_CHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
     return IMPDAR_OK;
-}
-
-static int fast_xb_from_env()
-{
-    const char *e = getenv("IMPDAR_KIRCH_XB");
-    if (e) {
-        int v = atoi(e);
-        if (v == 16 || v == 24 || v == 32) return v;
-    }
-    return 32;
 }
 
 extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, int tnum,
@@ -1094,7 +710,6 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     p->grad_uniform = grad_uniform;
     p->grad_h = grad_h;
     p->vel = vel;
-    p->xb = fast_xb_from_env();
 
     // ---- geometry analysis ------------------------------------------------
     double tmax = tt_sec[0];
@@ -1127,28 +742,29 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     p->uniform = uni_t && uni_x;
     const double sa = 2.0 * dx / (vel * dt);       // samples of moveout per trace at far offset
     p->alpha = sa * sa;
-    const bool window_ok = (KF_THREADS + sa * (p->xb - 1) + 8.0) <= (double)KF_W;
+    // fast kernels need the moveout 2dx/(v dt) (samples per trace) small enough for their
+    // LDS windows: quad (sample-major ring, 24 traces x 8-step blocks, 16-bit row offsets)
+    // or, for steeper moveout, tab (trace-major ring of 16 traces, 512-sample slots)
+    const int wq = ((KF_THREADS + (int)std::ceil(sa * (24 + 8 - 2)) + 8 + 3) / 4) * 4;
+    const bool quad_ok = (size_t)wq * KQ_STRIDE * 4 <= 65536;
+    const bool tab_ok = (KF_THREADS + sa * (16 - 1) + 8.0) <= (double)KF_W;
+    const bool window_ok = quad_ok || tab_ok;
+    const bool fast_ok = dtype == IMPDAR_F32 && p->uniform && window_ok && snum < 65536;
 
-    if (mode == IMPDAR_KIRCH_AUTO)
-        mode = (dtype == IMPDAR_F32 && p->uniform && window_ok) ? IMPDAR_KIRCH_FAST : IMPDAR_KIRCH_EXACT;
-    if (mode == IMPDAR_KIRCH_FAST) {
-        if (dtype != IMPDAR_F32 || !p->uniform || !window_ok) {
-            delete p;
-            impdar_set_error("fast Kirchhoff kernel needs float32 data on uniform dist/travel_time grids "
-                             "with moveout 2dx/(v dt) <= %.1f samples per trace",
-                             (KF_W - KF_THREADS - 8.0) / (fast_xb_from_env() - 1));
-            return IMPDAR_ERR_UNSUPPORTED;
-        }
+    if (mode == IMPDAR_KIRCH_AUTO) mode = fast_ok ? IMPDAR_KIRCH_FAST : IMPDAR_KIRCH_EXACT;
+    if (mode == IMPDAR_KIRCH_FAST && !fast_ok) {
+        delete p;
+        impdar_set_error("fast Kirchhoff kernel needs float32 data on uniform dist/travel_time grids "
+                         "with moveout 2dx/(v dt) <= %.1f samples per trace (got %.2f)",
+                         (KF_W - KF_THREADS - 8.0) / 15.0, sa);
+        return IMPDAR_ERR_UNSUPPORTED;
     }
     p->mode = mode;
     {
-        // sample-major ring: window of the 4 traces a block adds, rounded up to 4 samples;
-        // must fit 16-bit byte offsets (W*RP*4 <= 65536) and leave room for >= 2 workgroups per CU
-        const char *ie = getenv("IMPDAR_KIRCH_IMPL");
-        const int wq = ((KF_THREADS + (int)std::ceil(sa * (24 + 8 - 2)) + 8 + 3) / 4) * 4;
+        const char *ie = getenv("IMPDAR_KIRCH_IMPL");       // tuning knob: "tab" forces the b32 ring
         p->quadW = wq;
-        p->quad = (mode == IMPDAR_KIRCH_FAST) && p->xb == 32 && wq * KQ_STRIDE * 4 <= 65536 &&
-                  (!ie || !strcmp(ie, "quad"));
+        p->quad = (mode == IMPDAR_KIRCH_FAST) && quad_ok && !(ie && !strcmp(ie, "tab") && tab_ok);
+        p->xb = p->quad ? 24 : 16;
     }
 
     int rc = IMPDAR_OK;
@@ -1199,27 +815,7 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     if (mode == IMPDAR_KIRCH_FAST) {
         const int nch = (snum + KF_THREADS - 1) / KF_THREADS;
         p->nchunks = nch;
-        std::vector<float> Ahi(snum), Alo(snum), wc(snum), wc2(snum), apexw(snum);
-        std::vector<int> apexk(snum);
         std::vector<int> hmax(nch, 0);
-        const double half = vel * dt / 2.0;         // metres per sample of two-way time
-        for (int k = 0; k < snum; ++k) {
-            const double a = tt_sec[k] / dt;
-            split2(a * a, Ahi[k], Alo[k]);
-            wc[k] = (float)(a / (2.0 * M_PI * vel));                 // cos(theta)/vel/(2 pi) = a*y*...
-            wc2[k] = (float)(a / (2.0 * M_PI * half * half));        // cos(theta)/rs^2/(2 pi) = a*y^3*...
-            // the reference's own test for the apex pair (n = 0), in its fp64 operation order
-            const double zs = vel * tt_sec[k] / 2.0;
-            const double t0 = 2.0 * std::sqrt(zs * zs) / vel;
-            apexw[k] = (t0 > tmax) ? 0.f : 1.f;
-            // nearest sample to t0, ties to the lower index (argmin, mig_python.py:49)
-            int k0 = (int)std::floor((t0 - tt_sec[0]) / dt);
-            k0 = std::min(std::max(k0, 0), snum - 1);
-            while (k0 < snum - 1 && tt_sec[k0 + 1] <= t0) ++k0;
-            while (k0 > 0 && tt_sec[k0] > t0) --k0;
-            const int k1 = std::min(k0 + 1, snum - 1);
-            apexk[k] = (std::fabs(tt_sec[k1] - t0) < std::fabs(tt_sec[k0] - t0)) ? k1 : k0;
-        }
         int hglob = 0;
         std::vector<double> cmin(nch), cmax(nch);
         for (int c = 0; c < nch; ++c) {
@@ -1247,8 +843,6 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
                 return fail(IMPDAR_ERR_HIP);
             }
         }
-        std::vector<float2> B(nb);
-        for (int n = 0; n < nb; ++n) split2(p->alpha * (double)n * (double)n, B[n].x, B[n].y);
         // staging windows: smallest / largest sample index any lane of chunk c
         // can pick at offset |n| (one guard sample each side)
         std::vector<int> klo((size_t)nch * nb), khi((size_t)nch * nb);
@@ -1260,12 +854,7 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
                 klo[(size_t)c * nb + n] = std::max(0, (int)std::floor(ulo) - 1);
                 khi[(size_t)c * nb + n] = std::min(snum - 1, (int)std::ceil(uhi) + 1);
             }
-        split2(tt_sec[0] / dt, p->u0h, p->u0l);
-        split2(tmax / dt, p->umaxh, p->umaxl);
-        if ((rc = upload(p->d_Ahi, Ahi.data(), snum * 4)) || (rc = upload(p->d_Alo, Alo.data(), snum * 4)) ||
-            (rc = upload(p->d_wc, wc.data(), snum * 4)) || (rc = upload(p->d_wc2, wc2.data(), snum * 4)) ||
-            (rc = upload(p->d_apexw, apexw.data(), snum * 4)) || (rc = upload(p->d_apexk, apexk.data(), snum * 4)) || (rc = upload(p->d_B, B.data(), (size_t)nb * 8)) ||
-            (rc = upload(p->d_hmax, hmax.data(), nch * 4)) || (rc = upload(p->d_klo, klo.data(), klo.size() * 4)) ||
+        if ((rc = upload(p->d_hmax, hmax.data(), nch * 4)) || (rc = upload(p->d_klo, klo.data(), klo.size() * 4)) ||
             (rc = upload(p->d_khi, khi.data(), khi.size() * 4)))
             return fail(rc);
     }
@@ -1366,31 +955,6 @@ int impdar_kirch_prep_precomputed(impdar_kirch_plan *p, const void *d_grad, int 
     return kirch_prep_impl(p, d_grad, ld, jlo, nloc, 1);
 }
 
-template <int XB, int S>
-static int launch_fast(impdar_kirch_plan *p, const FastParams &P0, int ntiles, hipStream_t st)
-{
-    constexpr int R = XB + 2 * S;
-    FastParams P = P0;
-    P.nxt = ntiles;
-    P.G = 4;
-    const int per = 8 * P.G;
-    const int nxt_pad = ((ntiles + per - 1) / per) * per;
-    P.tiles_per_xcd = nxt_pad / 8;
-    const int nblk = P.nchunks * nxt_pad;
-    const size_t shmem = (size_t)R * KF_W * 4 * (p->nearfield ? 2 : 1);
-    if (p->nearfield) {
-        auto k = kirch_fast_kernel<XB, S, true>;
-        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k, dim3(nblk), dim3(KF_THREADS), shmem, st, P);
-    } else {
-        auto k = kirch_fast_kernel<XB, S, false>;
-        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k, dim3(nblk), dim3(KF_THREADS), shmem, st, P);
-    }
-    IMPDAR_HIP_CHECK(hipGetLastError());
-    return IMPDAR_OK;
-}
-
 template <int XB, int OCC>
 static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipStream_t st)
 {
@@ -1443,26 +1007,6 @@ static int launch_tab(impdar_kirch_plan *p, const FastParams &P0, int nx, hipStr
     return IMPDAR_OK;
 }
 
-template <int XB, int S, int OCC>
-static int launch_ts(impdar_kirch_plan *p, const FastParams &P0, int nx, hipStream_t st)
-{
-    FastParams P = P0;
-    const int ntiles = (nx + XB - 1) / XB;
-    P.nxt = ntiles;
-    P.G = 4;
-    const int per = 8 * P.G;
-    const int nxt_pad = ((ntiles + per - 1) / per) * per;
-    P.tiles_per_xcd = nxt_pad / 8;
-    const int nblk = P.nchunks * nxt_pad;
-    const size_t shmem = (size_t)(2 * S) * KF_W * 4 * (p->nearfield ? 2 : 1);
-    if (p->nearfield)
-        hipLaunchKernelGGL((kirch_ts_kernel<XB, S, true, (OCC > 2 ? 2 : OCC)>), dim3(nblk), dim3(KF_THREADS), shmem, st, P);
-    else
-        hipLaunchKernelGGL((kirch_ts_kernel<XB, S, false, OCC>), dim3(nblk), dim3(KF_THREADS), shmem, st, P);
-    IMPDAR_HIP_CHECK(hipGetLastError());
-    return IMPDAR_OK;
-}
-
 extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, int xhi)
 {
     IMPDAR_ARG_CHECK(p && d_out, "null plan/output");
@@ -1483,66 +1027,23 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         P.tnum = p->tnum;
         P.xlo = xlo;
         P.xhi = xhi;
-        P.Ahi = p->d_Ahi.as<float>();
-        P.Alo = p->d_Alo.as<float>();
-        P.wc = p->d_wc.as<float>();
-        P.wc2 = p->d_wc2.as<float>();
-        P.apexw = p->d_apexw.as<float>();
-        P.apexk = p->d_apexk.as<int>();
-        P.B = p->d_B.as<float2>();
         P.hmax = p->d_hmax.as<int>();
         P.klo = p->d_klo.as<int>();
         P.khi = p->d_khi.as<int>();
         P.nb = p->nb;
         P.zero_row = p->tnum_pad;
-        P.u0h = p->u0h;
-        P.u0l = p->u0l;
-        P.umaxh = p->umaxh;
-        P.umaxl = p->umaxl;
         P.nchunks = p->nchunks;
         P.TK = p->d_TK.as<unsigned short>();
         P.TW = p->d_TW.as<float>();
         P.TW2 = p->d_TW2.as<float>();
         P.ntab = p->ntab;
-        {
-            const char *de = getenv("IMPDAR_KIRCH_DBG");
-            P.dbg = de ? atoi(de) : 0;
-        }
         int rc;
-        const char *se = getenv("IMPDAR_KIRCH_S");
-        const int sblk = se ? atoi(se) : 4;
-        const char *ie = getenv("IMPDAR_KIRCH_IMPL");
-        const bool ring = ie && !strcmp(ie, "ring");
-        const bool ts = ie && !strcmp(ie, "ts");
-        const char *oe0 = getenv("IMPDAR_KIRCH_OCC");
+        const char *oe0 = getenv("IMPDAR_KIRCH_OCC");      // tuning knob: min waves per SIMD to compile for
         const int occ0 = oe0 ? atoi(oe0) : 0;
-        if (p->quad) {
+        if (p->quad)
             rc = (occ0 == 2) ? launch_quad<24, 2>(p, P, nx, st) : launch_quad<24, 3>(p, P, nx, st);
-        } else if (!ring && !ts) {
-            if (p->xb == 16)
-                rc = (occ0 == 3) ? launch_tab<16, 4, 3>(p, P, nx, st) : launch_tab<16, 4, 4>(p, P, nx, st);
-            else if (p->xb == 24)
-                rc = (occ0 == 2) ? launch_tab<24, 4, 2>(p, P, nx, st) : launch_tab<24, 4, 3>(p, P, nx, st);
-            else
-                rc = (occ0 == 3) ? launch_tab<32, 4, 3>(p, P, nx, st) : launch_tab<32, 4, 2>(p, P, nx, st);
-        } else
-        if (!ring) {
-            const char *oe = getenv("IMPDAR_KIRCH_OCC");
-            const int occ = oe ? atoi(oe) : 0;
-            if (p->xb == 16)
-                rc = (occ == 4) ? launch_ts<16, 4, 4>(p, P, nx, st) : launch_ts<16, 4, 3>(p, P, nx, st);
-            else if (p->xb == 24)
-                rc = (occ == 2) ? launch_ts<24, 4, 2>(p, P, nx, st) : launch_ts<24, 4, 3>(p, P, nx, st);
-            else
-                rc = (occ == 3) ? launch_ts<32, 4, 3>(p, P, nx, st) : launch_ts<32, 4, 2>(p, P, nx, st);
-        } else if (p->xb == 16 && sblk == 8)
-            rc = launch_fast<16, 8>(p, P, (nx + 15) / 16, st);
-        else if (p->xb == 16)
-            rc = launch_fast<16, 4>(p, P, (nx + 15) / 16, st);
-        else if (sblk == 8)
-            rc = launch_fast<32, 8>(p, P, (nx + 31) / 32, st);
         else
-            rc = launch_fast<32, 4>(p, P, (nx + 31) / 32, st);
+            rc = launch_tab<16, 4, 4>(p, P, nx, st);
         if (rc) return rc;
     } else if (nx > 0) {
         ExactParams P;

@@ -150,6 +150,41 @@ def test_ragged_sizes_vs_oracle(hip, snum, tnum):
     assert mode == 'fast' and rel_l2(out, want) < FAST_L2
 
 
+@pytest.mark.parametrize('dx,expect', [(1.0, 'quad'), (2.5, 'quad'), (5.0, 'tab'), (12.0, 'tab')])
+def test_fast_kernel_families_by_moveout(hip, dx, expect, monkeypatch):
+    """Moveout 2dx/(v dt) decides which LDS-ring kernel the fast mode uses (sample-major b128
+    'quad' ring up to ~3.6 samples per trace, trace-major b32 'tab' ring up to ~16); both must
+    match the C oracle.  IMPDAR_KIRCH_IMPL=tab also forces the tab kernel at small moveout."""
+    from impdar_amd import synth
+    from impdar_amd.kirchhoff import migrate_resident
+    from oracle import c_oracle
+    snum, tnum = 600, 150
+    geo = synth.geometry(snum, tnum, dx=dx)
+    data = synth.noise_radargram(snum, tnum, seed=int(dx * 10)).astype(np.float32)
+    want = c_oracle.kirchhoff(data, geo['travel_time'], geo['dist'], 1.69e8)
+    ctx = hip.context()
+    out, mode, _ = migrate_resident(ctx, data, geo['dist'], geo['travel_time'], mode='fast')
+    assert mode == 'fast' and rel_l2(out, want) < FAST_L2, (expect, rel_l2(out, want))
+    if expect == 'quad':
+        monkeypatch.setenv('IMPDAR_KIRCH_IMPL', 'tab')
+        out2, _, _ = migrate_resident(ctx, data, geo['dist'], geo['travel_time'], mode='fast')
+        assert rel_l2(out2, want) < FAST_L2
+        assert rel_l2(out2, out) < 1e-6            # same table, same picks; only summation order differs
+
+
+def test_nearfield_fast_vs_oracle(hip):
+    from impdar_amd import synth
+    from impdar_amd.kirchhoff import migrate_resident
+    from oracle import c_oracle
+    snum, tnum = 520, 100
+    geo = synth.geometry(snum, tnum)
+    data = synth.noise_radargram(snum, tnum, seed=9).astype(np.float32)
+    want = c_oracle.kirchhoff(data, geo['travel_time'], geo['dist'], 1.69e8, nearfield=True)
+    out, mode, _ = migrate_resident(hip.context(), data, geo['dist'], geo['travel_time'], nearfield=True,
+                                    mode='fast')
+    assert mode == 'fast' and rel_l2(out, want) < FAST_L2
+
+
 def test_output_block_and_input_shard_equivalence(hip):
     """The sharded API (prep per column block, migrate per output block) gives
     the same image as the one-shot call."""
