@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the driver's bench contract): Stolt f-k at
+BASELINE config 2 (4096x4096 float32) and phase-shift at config 5 (8192x8192,
+constant v and 1-D v(z)), each through the product path on one MI355X.
+Prints one JSON line per path.  Host wall time includes H2D/D2H of the
+radargram (the entry points take host buffers)."""
+import argparse
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--stolt', type=int, default=4096)
+    ap.add_argument('--phsh', type=int, default=8192)
+    ap.add_argument('--reps', type=int, default=3)
+    ap.add_argument('--skip', default='')
+    args = ap.parse_args()
+    from impdar_amd import _hip, synth
+    from impdar_amd.lib.RadarData import RadarData
+    from impdar_amd.lib import migrationlib
+    import contextlib
+    import io
+    _hip.load()
+    assert _hip.device_count() > 0
+
+    def dat_of(data, geo):
+        d = RadarData(None)
+        d.data, (d.snum, d.tnum) = data, data.shape
+        d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
+        return d
+
+    def timed(fn, make):
+        best = None
+        for _ in range(args.reps + 1):           # first call pays rocFFT plan creation
+            d = make()
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                fn(d)
+            el = time.perf_counter() - t0
+            best = el if best is None else min(best, el)
+        return best, d
+
+    rng = np.random.default_rng(0)
+    if 'stolt' not in args.skip:
+        n = args.stolt
+        geo = synth.geometry(n, n)
+        x = rng.standard_normal((n, n)).astype(np.float32)
+        el, d = timed(lambda d: migrationlib.migrationStolt(d, htaper=100, vtaper=1000), lambda: dat_of(x.copy(), geo))
+        print(json.dumps({"path": "stolt", "config": "%dx%d float32 (BASELINE config 2)" % (n, n),
+                          "host_seconds": el, "traces_per_s": n / el, "finite": bool(np.isfinite(d.data).all()),
+                          "reference_seconds_same_size": 100.30}), flush=True)
+    if 'phsh' not in args.skip:
+        n = args.phsh
+        geo = synth.geometry(n, n)
+        x = rng.standard_normal((n, n)).astype(np.float32)
+        el, d = timed(lambda d: migrationlib.migrationPhaseShift(d, vel=1.69e8), lambda: dat_of(x.copy(), geo))
+        print(json.dumps({"path": "phase-shift const v", "config": "%dx%d float32" % (n, n), "host_seconds": el,
+                          "traces_per_s": n / el, "finite": bool(np.isfinite(d.data).all())}), flush=True)
+        Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+        tab = np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rp], [1.8e8, 0.5 * Rp], [1.9e8, 1.2 * Rp]])
+        el, d = timed(lambda d: migrationlib.migrationPhaseShift(d, vel=tab), lambda: dat_of(x.copy(), geo))
+        print(json.dumps({"path": "phase-shift v(z) Gazdag", "config": "%dx%d float32 (BASELINE config 5)" % (n, n),
+                          "host_seconds": el, "traces_per_s": n / el, "finite": bool(np.isfinite(d.data).all()),
+                          "reference_extrapolated_hours": 7.6}), flush=True)
+
+
+if __name__ == '__main__':
+    main()

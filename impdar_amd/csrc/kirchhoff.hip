@@ -25,6 +25,7 @@
 
 #define KF_THREADS 256
 #define KF_W 512            // LDS floats per ring slot (circular window)
+#define KF_PAD_ROWS 128      // zero traces kept on both sides of the image (loops are clipped to the profile)
 
 // ===========================================================================
 // prep: gradient + transpose
@@ -163,7 +164,9 @@ struct FastParams {
     int nchunks, nxt, tiles_per_xcd, G;
     // pick/weight table: entry (|n|, ti)
     const unsigned short *TK;      // offset of the picked sample's row inside a ring slot    [ntab][snum]
-    const float *TW, *TW2;         // far / near weights (0 where the reference drops the pair)
+    const float *TW, *TW2;         // far / near weights (0 where the reference drops the pair); tab kernel only
+    const float *A, *wcf, *wc2f;   // quad kernel: (tt/dt)^2, cos-weight prefactors per sample [snum]
+    float alpha;                   // (2 dx / (v dt))^2
     int ntab;                      // rows; the last row is all zero (|n| beyond every aperture)
 };
 
@@ -183,6 +186,8 @@ struct TableParams {
     double dx, vel, tmax, inv_dt, tt0;
     int snum, ntab, near;
     int wmod, kscale;          // slot byte offset of sample k = (k % wmod) * kscale
+    unsigned short sentinel;   // TK value for dropped pairs (0xFFFF for the quad kernel, 0 for tab: its weight is 0)
+    int write_w;
 };
 
 __global__ __launch_bounds__(256) void kirch_table_kernel(TableParams P)
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256) void kirch_table_kernel(TableParams P)
     const int n = blockIdx.y;
     if (ti >= P.snum) return;
     const size_t o = (size_t)n * P.snum + ti;
-    unsigned short kb = 0;
+    unsigned short kb = P.sentinel;      // pair dropped by the reference
     float w = 0.f, w2 = 0.f;
     if (n < P.ntab - 1) {
         const double dx = (double)n * P.dx;
@@ -214,8 +219,10 @@ __global__ __launch_bounds__(256) void kirch_table_kernel(TableParams P)
         }
     }
     P.TK[o] = kb;
-    P.TW[o] = w;
-    if (P.near) P.TW2[o] = w2;
+    if (P.write_w) {
+        P.TW[o] = w;
+        if (P.near) P.TW2[o] = w2;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -462,11 +469,17 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
         kmin = klo[min(lo, P.nb - 1)];
         kmax = min(khi[min(hi, P.nb - 1)], kmin + W - 1);
     };
-    auto trace_ptr = [&](const float *img, int q) {
-        const int j = jbase + q;
-        return img + (size_t)((j >= 0 && j < tnum) ? j : P.zero_row) * snum;
+    // traces outside the profile are zero rows of the padded image: no range checks
+    auto trace_ptr = [&](const float *img, int q) { return img + (ptrdiff_t)(jbase + q) * snum; };
+    auto tab_row = [&](int step) { return (unsigned)(min(abs(nlo + step), ntab1) * snum); };
+    const unsigned tioff = (unsigned)ti * 2u;
+    auto pick = [&](int step) {
+        return *reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(P.TK + tab_row(step)) + tioff);
     };
-    auto tab_row = [&](int step) { return (size_t)min(abs(nlo + step), ntab1) * snum; };
+    // obliquity weights from the per-sample constants; the table's 0xFFFF marks the pairs
+    // the reference drops (t > t_max, or the 0/0 apex of a t = 0 sample)
+    const float Aq = P.A[ti], wcf = P.wcf[ti], wc2f = NEAR ? P.wc2f[ti] : 0.f;
+    const float alpha = P.alpha;
 
     for (int e = tid; e < W * ST * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
     __syncthreads();
@@ -483,15 +496,10 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
             if (NEAR) ldsD[(e % W) * ST + pos] = sd[e];
         }
     }
-    // pick row / weight of the steps of the current block
+    // pick row of the steps of the current block
     unsigned short tkc[S];
-    float twc[S], tw2c[NEAR ? S : 1];
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-        tkc[s] = (P.TK + tab_row(s))[ti];
-        twc[s] = (P.TW + tab_row(s))[ti];
-        if (NEAR) tw2c[s] = (P.TW2 + tab_row(s))[ti];
-    }
+    for (int s = 0; s < S; ++s) tkc[s] = pick(s);
     __syncthreads();
 
     float acc[XB];
@@ -517,21 +525,30 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
             m1 -= (m1 >= W) ? W : 0;
             float g0[S], g1[S], d0[NEAR ? S : 1], d1[NEAR ? S : 1];
             unsigned short tkn[S];
-            float twn[S], tw2n[NEAR ? S : 1];
+            const unsigned vo0 = (unsigned)c0 * 4u, vo1 = (unsigned)c1 * 4u;
+            const char *tb = reinterpret_cast<const char *>(trace_ptr(P.GT, q0));
+            const char *tbd = NEAR ? reinterpret_cast<const char *>(trace_ptr(P.DT, q0)) : nullptr;
+            const size_t rowb = (size_t)snum * 4;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                const float *src = trace_ptr(P.GT, q0 + s);
-                g0[s] = src[c0];
-                g1[s] = src[c1];
+                g0[s] = *reinterpret_cast<const float *>(tb + s * rowb + vo0);
+                g1[s] = *reinterpret_cast<const float *>(tb + s * rowb + vo1);
                 if (NEAR) {
-                    const float *srd = trace_ptr(P.DT, q0 + s);
-                    d0[s] = srd[c0];
-                    d1[s] = srd[c1];
+                    d0[s] = *reinterpret_cast<const float *>(tbd + s * rowb + vo0);
+                    d1[s] = *reinterpret_cast<const float *>(tbd + s * rowb + vo1);
                 }
-                const size_t ro = tab_row((blk + 1) * S + s);
-                tkn[s] = (P.TK + ro)[ti];
-                twn[s] = (P.TW + ro)[ti];
-                if (NEAR) tw2n[s] = (P.TW2 + ro)[ti];
+                tkn[s] = pick((blk + 1) * S + s);
+            }
+            // weights of this block's steps
+            float twc[S], tw2c[NEAR ? S : 1];
+            const float n0f = (float)(nlo + blk * S);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float nf = n0f + (float)s;
+                const float y = __builtin_amdgcn_rsqf(fmaf(nf, alpha * nf, Aq));
+                const bool keep = tkc[s] != 0xFFFFu;
+                twc[s] = keep ? wcf * y : 0.f;
+                if (NEAR) tw2c[s] = keep ? (wc2f * y) * (y * y) : 0.f;
             }
             // ---- S steps on the resident ring, software pipelined: the reads of step s+1 are
             // in flight while the FMAs of step s run (two statically indexed quad buffers)
@@ -543,8 +560,9 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
             };
             auto load_step = [&](int s, float4 (&v)[NQ], float4 (&u)[NEAR ? NQ : 1]) {
                 const int pm = bb * S + s;                       // step index mod RG (compile time)
-                const float4 *base = reinterpret_cast<const float4 *>(ldsG) + tkc[s];   // row of sample k
-                const float4 *based = reinterpret_cast<const float4 *>(ldsD) + tkc[s];
+                const unsigned kq = tkc[s] == 0xFFFFu ? 0u : tkc[s];
+                const float4 *base = reinterpret_cast<const float4 *>(ldsG) + kq;       // row of sample k
+                const float4 *based = reinterpret_cast<const float4 *>(ldsD) + kq;
 #pragma unroll
                 for (int qd = 0; qd < NQ; ++qd)
                     if (needed(pm, qd)) {
@@ -629,11 +647,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
                 }
             }
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                tkc[s] = tkn[s];
-                twc[s] = twn[s];
-                if (NEAR) tw2c[s] = tw2n[s];
-            }
+            for (int s = 0; s < S; ++s) tkc[s] = tkn[s];
             __syncthreads();
         }
     }
@@ -659,9 +673,9 @@ struct impdar_kirch_plan {
     bool uniform = false;
     // device tables
     DevBuf d_dist, d_tt, d_zs, d_zs2, d_ga, d_gb, d_gc;
-    DevBuf GT, DT;
+    DevBuf GT, DT;                 // images with KF_PAD_ROWS all-zero rows before row 0 and after row tnum_pad-1
     DevBuf d_hmax, d_klo, d_khi;
-    DevBuf d_TK, d_TW, d_TW2;
+    DevBuf d_TK, d_TW, d_TW2, d_A, d_wcf, d_wc2f;
     int nb = 0, ntab = 0;
     bool quad = false;          // sample-major LDS ring (kirch_quad_kernel)
     int quadW = 0;              // samples per ring slot in that layout
@@ -676,6 +690,11 @@ struct impdar_kirch_plan {
     int slot = 0;
     int xb = 32;                   // fast-kernel trace tile
 };
+
+static inline char *img_row0(const impdar_kirch_plan *p, const DevBuf &b)
+{
+    return reinterpret_cast<char *>(b.p) + (size_t)KF_PAD_ROWS * p->snum * impdar_dtype_size(p->dtype);
+}
 
 static int upload(DevBuf &b, const void *src, size_t bytes)
 {
@@ -773,7 +792,7 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         return code;
     };
     const size_t esz = impdar_dtype_size(dtype);
-    const size_t img = (size_t)(p->tnum_pad + 1) * snum * esz;   // + one all-zero row
+    const size_t img = (size_t)(p->tnum_pad + 2 * KF_PAD_ROWS) * snum * esz;   // zero rows on both sides
     if (p->GT.ensure(img) != hipSuccess) {
         impdar_set_error("hipMalloc of %zu-byte gradient image failed", img);
         return fail(IMPDAR_ERR_HIP);
@@ -816,6 +835,19 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         const int nch = (snum + KF_THREADS - 1) / KF_THREADS;
         p->nchunks = nch;
         std::vector<int> hmax(nch, 0);
+        {
+            std::vector<float> A(snum), wcf(snum), wc2f(snum);
+            const double half = vel * dt / 2.0;         // metres per sample of two-way time
+            for (int k = 0; k < snum; ++k) {
+                const double a = tt_sec[k] / dt;
+                A[k] = (float)(a * a);
+                wcf[k] = (float)(a / (2.0 * M_PI * vel));             // cos(theta)/vel/(2 pi) = wcf / u
+                wc2f[k] = (float)(a / (2.0 * M_PI * half * half));    // cos(theta)/rs^2/(2 pi) = wc2f / u^3
+            }
+            if ((rc = upload(p->d_A, A.data(), snum * 4)) || (rc = upload(p->d_wcf, wcf.data(), snum * 4)) ||
+                (rc = upload(p->d_wc2f, wc2f.data(), snum * 4)))
+                return fail(rc);
+        }
         int hglob = 0;
         std::vector<double> cmin(nch), cmax(nch);
         for (int c = 0; c < nch; ++c) {
@@ -902,8 +934,8 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
         P.snum = p->snum;
         P.nloc = nloc;
         P.jlo = jlo;
-        P.GT = p->GT.p;
-        P.DT = p->nearfield ? p->DT.p : nullptr;
+        P.GT = img_row0(p, p->GT);
+        P.DT = p->nearfield ? img_row0(p, p->DT) : nullptr;
         P.grad_uniform = p->grad_uniform;
         P.precomputed = precomputed;
         P.grad_h = p->grad_h;
@@ -937,6 +969,8 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
         T.near = p->nearfield;
         T.wmod = p->quad ? p->quadW : KF_W;
         T.kscale = p->quad ? KQ_STRIDE / 4 : 4;  // quad layout: offset in float4 units
+        T.sentinel = p->quad ? 0xFFFF : 0;
+        T.write_w = p->quad ? 0 : 1;
         hipLaunchKernelGGL(kirch_table_kernel, dim3((p->snum + 255) / 256, p->ntab), dim3(256), 0, st, T);
         IMPDAR_HIP_CHECK(hipGetLastError());
     }
@@ -1019,8 +1053,8 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
     const int nx = xhi - xlo;
     if (nx > 0 && p->mode == IMPDAR_KIRCH_FAST) {
         FastParams P;
-        P.GT = p->GT.as<float>();
-        P.DT = p->nearfield ? p->DT.as<float>() : nullptr;
+        P.GT = reinterpret_cast<const float *>(img_row0(p, p->GT));
+        P.DT = p->nearfield ? reinterpret_cast<const float *>(img_row0(p, p->DT)) : nullptr;
         P.out = reinterpret_cast<float *>(d_out);
         P.ldo = nx;
         P.snum = p->snum;
@@ -1031,12 +1065,16 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         P.klo = p->d_klo.as<int>();
         P.khi = p->d_khi.as<int>();
         P.nb = p->nb;
-        P.zero_row = p->tnum_pad;
+        P.zero_row = p->tnum_pad;          // first zero row after the data rows
         P.nchunks = p->nchunks;
         P.TK = p->d_TK.as<unsigned short>();
         P.TW = p->d_TW.as<float>();
         P.TW2 = p->d_TW2.as<float>();
         P.ntab = p->ntab;
+        P.A = p->d_A.as<float>();
+        P.wcf = p->d_wcf.as<float>();
+        P.wc2f = p->d_wc2f.as<float>();
+        P.alpha = (float)p->alpha;
         int rc;
         const char *oe0 = getenv("IMPDAR_KIRCH_OCC");      // tuning knob: min waves per SIMD to compile for
         const int occ0 = oe0 ? atoi(oe0) : 0;
@@ -1047,8 +1085,8 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         if (rc) return rc;
     } else if (nx > 0) {
         ExactParams P;
-        P.GT = p->GT.p;
-        P.DT = p->nearfield ? p->DT.p : nullptr;
+        P.GT = img_row0(p, p->GT);
+        P.DT = p->nearfield ? img_row0(p, p->DT) : nullptr;
         P.out = d_out;
         P.ldo = nx;
         P.snum = p->snum;
@@ -1096,11 +1134,11 @@ extern "C" int impdar_kirch_allgather(impdar_kirch_plan *p)
     hipStream_t st = p->ctx->stream;
     hipEvent_t *ev = p->evs[p->slot];
     IMPDAR_HIP_CHECK(hipEventRecord(ev[2], st));
-    if (p->nranks > 1) {
+    if (p->nranks > 1 || p->ctx->comm) {        // a 1-rank communicator still runs the (trivial) collective
         const size_t per = (size_t)(p->tnum_pad / p->nranks) * p->snum * impdar_dtype_size(p->dtype);
-        int rc = impdar_allgather_rows(p->ctx, p->GT.p, per);
+        int rc = impdar_allgather_rows(p->ctx, img_row0(p, p->GT), per);
         if (rc) return rc;
-        if (p->nearfield && (rc = impdar_allgather_rows(p->ctx, p->DT.p, per))) return rc;
+        if (p->nearfield && (rc = impdar_allgather_rows(p->ctx, img_row0(p, p->DT), per))) return rc;
     }
     IMPDAR_HIP_CHECK(hipEventRecord(ev[3], st));
     p->haves[p->slot][1] = true;

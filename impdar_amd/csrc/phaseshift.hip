@@ -23,7 +23,6 @@
 
 template <typename T> struct Cp { T x, y; };
 
-#define PS_TT 16          // tau per tile
 
 // (snum,tnum) real -> tapered, zero-padded, transposed complex X[tnum][nt]
 template <typename T>
@@ -116,16 +115,19 @@ struct PsParams {
     int snum, tnum, nt, vz_mode;
 };
 
-// wave-level reduce-scatter of NV values: on return lane L holds in v[0] the
-// sum over the 64 lanes of value index (L >> 1) (NV == 32).
+// wave-level reduce-scatter of NV (power of two <= 32) values over the 64 lanes: each
+// halving step sends half of the remaining values to the partner lane; once one value is
+// left the remaining lane bits are folded with plain butterflies.  On return v[0] of lane
+// L holds the total of value index (L >> (6 - log2 NV)) & (NV - 1).
 template <typename T, int NV>
 __device__ inline void wave_reduce_scatter(T (&v)[NV], int lane)
 {
-    static_assert(NV == 32, "butterfly below is written for 32 values");
+    static_assert(NV == 8 || NV == 32, "instantiated for 8 and 32 values");
+    constexpr int LOG = NV == 32 ? 5 : 3;
 #pragma unroll
-    for (int step = 0; step < 5; ++step) {
-        const int mask = 32 >> step;          // 32,16,8,4,2
-        const int half = 16 >> step;          // values kept after this step
+    for (int step = 0; step < LOG; ++step) {
+        const int mask = 32 >> step;
+        const int half = (NV / 2) >> step;    // values kept after this step
         const bool up = (lane & mask) != 0;
 #pragma unroll
         for (int i = 0; i < half; ++i) {
@@ -134,13 +136,18 @@ __device__ inline void wave_reduce_scatter(T (&v)[NV], int lane)
             v[i] = keep + __shfl_xor(send, mask, 64);
         }
     }
-    v[0] += __shfl_xor(v[0], 1, 64);
+#pragma unroll
+    for (int mask = 32 >> LOG; mask >= 1; mask >>= 1) v[0] += __shfl_xor(v[0], mask, 64);
 }
 
 template <typename T, int BLOCK, int M, bool VZ>
 __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
 {
+    // tau per tile: the v(z) update is ~40 instructions per (tau, frequency) and is fully
+    // unrolled, so its tile is kept short to bound the code size
+    constexpr int PS_TT = VZ ? 4 : 16;
     constexpr int NW = BLOCK / 64;
+    constexpr int SH = VZ ? 3 : 1;            // lane >> SH = value index held after the reduce-scatter
     __shared__ T red[2][NW][2 * PS_TT];
     const int k = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -177,6 +184,8 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
                 fi[m] = f.y;
             }
         }
+        // one frequency's fp64 set-up at a time (interleaved, the M chains spill)
+        asm volatile("" : "+v"(fr[m]), "+v"(fi[m]), "+v"(pa[m]), "+v"(pb[m]));
     }
 
     const int ntile = (P.snum + PS_TT - 1) / PS_TT;
@@ -185,6 +194,9 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
 #pragma unroll
         for (int i = 0; i < 2 * PS_TT; ++i) acc[i] = 0;
         const int tau0 = tile * PS_TT;
+        // The chains carry no memory dependence, so instruction selection is free to interleave
+        // all M x TT of them and the live temporaries spill; threading the state through an empty
+        // volatile asm after every (tau, frequency) update pins the order without adding code.
         if (!VZ) {
 #pragma unroll
             for (int t = 0; t < PS_TT; ++t) {
@@ -196,6 +208,7 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
                     fi[m] = ni;
                     acc[2 * t] += nr;                                   // TK[itau] += FFK, :420
                     acc[2 * t + 1] += ni;
+                    asm volatile("" : "+v"(fr[m]), "+v"(fi[m]), "+v"(acc[2 * t]), "+v"(acc[2 * t + 1]));
                 }
             }
         } else {
@@ -203,11 +216,12 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
             for (int t = 0; t < PS_TT; ++t) {
                 const int tau = min(tau0 + t, P.snum - 1);
                 const T v = (T)P.vz[tau];
+                const T v2 = v * v;
                 const T thr = (T)P.thr[tau];
                 const bool live_tau = (tau0 + t) < P.snum;
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    const T coss = (T)1 - (v * v) * pa[m];              // :458
+                    const T coss = (T)1 - v2 * pa[m];                   // :458
                     const T ph = pb[m] * sqrt(coss > 0 ? coss : (T)0);  // :460 (real part of the complex sqrt)
                     T s, c;
                     sincos_t<T>(ph, &s, &c);
@@ -223,16 +237,14 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
                         acc[2 * t] += nr;                               // :487
                         acc[2 * t + 1] += ni;
                     }
-                    // keep the M independent sincos chains from being interleaved
-                    // (live temporaries would spill at M >= 8)
-                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("" : "+v"(fr[m]), "+v"(fi[m]), "+v"(acc[2 * t]), "+v"(acc[2 * t + 1]));
                 }
             }
         }
         // ---- sum over frequencies: wave butterfly, then across waves via LDS
         wave_reduce_scatter<T, 2 * PS_TT>(acc, lane);
         T (*buf)[2 * PS_TT] = red[tile & 1];
-        if ((lane & 1) == 0) buf[wave][lane >> 1] = acc[0];
+        if ((lane & ((1 << SH) - 1)) == 0) buf[wave][lane >> SH] = acc[0];
         __syncthreads();
         if (tid < 2 * PS_TT) {
             T s = 0;

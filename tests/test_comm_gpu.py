@@ -1,0 +1,61 @@
+"""RCCL plumbing on one GPU: communicator bootstrap from a unique id, the
+in-place all-gather of the image and the barrier (with one rank the
+collectives are trivial, but every RCCL call of the multi-GPU path runs).
+The N > 1 data movement itself is covered on CPU by test_parallel_gloo.py;
+the driver's 8-GPU bench exercises it on hardware."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def test_single_rank_communicator_and_allgather(hip):
+    lib = hip.load()
+    # a private context so the process-wide one stays communicator-free
+    ctx = C.c_void_p()
+    hip.check(lib.impdar_ctx_create(0, C.byref(ctx)), 'ctx')
+    buf = C.create_string_buffer(hip.UNIQUE_ID_BYTES)
+    hip.check(lib.impdar_comm_unique_id(buf), 'unique_id')
+    assert any(b != 0 for b in buf.raw)
+    hip.check(lib.impdar_comm_init(ctx, buf.raw, 0, 1), 'comm_init')
+    assert lib.impdar_comm_rank(ctx) == 0 and lib.impdar_comm_size(ctx) == 1
+    with pytest.raises(ValueError):
+        hip.check(lib.impdar_comm_init(ctx, buf.raw, 0, 1), 'comm_init twice')
+    hip.check(lib.impdar_comm_barrier(ctx), 'barrier')
+
+    from impdar_amd import synth, _hip
+    from impdar_amd.kirchhoff import KirchhoffPlan, migrate_resident
+    snum, tnum = 512, 130
+    geo = synth.geometry(snum, tnum)
+    data = synth.noise_radargram(snum, tnum, seed=2).astype(np.float32)
+    want, _, _ = migrate_resident(hip.context(), data, geo['dist'], geo['travel_time'], mode='fast')
+    plan = KirchhoffPlan(ctx, np.float32, snum, tnum, geo['dist'], geo['travel_time'], mode='fast', nranks=1)
+    d_in = _hip.DeviceArray.from_host(ctx, data)
+    d_out = _hip.DeviceArray(ctx, (snum, tnum), np.float32)
+    plan.prep(d_in, tnum, 0, tnum)
+    plan.allgather()                       # ncclAllGather, in place, one rank
+    plan.migrate(d_out, 0, tnum)
+    plan.sync()
+    got = d_out.to_host()
+    prep_ms, gather_ms, mig_ms = plan.last_ms()
+    assert gather_ms >= 0.0 and mig_ms > 0.0
+    plan.destroy()
+    d_in.free()
+    d_out.free()
+    lib.impdar_ctx_destroy(ctx)
+    assert np.array_equal(got, want)
+
+
+def test_plan_rank_mismatch_is_an_error(hip):
+    from impdar_amd import synth
+    from impdar_amd.kirchhoff import KirchhoffPlan
+    geo = synth.geometry(64, 16)
+    plan = KirchhoffPlan(hip.context(), np.float32, 64, 16, geo['dist'], geo['travel_time'], mode='fast', nranks=2)
+    assert plan.tnum_pad == 16
+    with pytest.raises(ValueError):
+        plan.allgather()                   # context has no 2-rank communicator
+    plan.destroy()
