@@ -67,6 +67,13 @@ def main():
     ap.add_argument('--cpu-budget', type=float, default=15.0)
     args = ap.parse_args()
 
+    # stdout must carry exactly ONE JSON line, but gloo and RCCL print banners on fd 1 (RCCL's
+    # sits in the C stdio buffer until exit): point fd 1 at stderr for the whole run and keep
+    # the real stdout for the result line
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -79,11 +86,15 @@ def main():
     from impdar_amd import _hip, parallel, synth
     from impdar_amd.kirchhoff import KirchhoffPlan
 
+    # IMPDAR_BENCH_FORCE_DIST=1 runs the whole multi-rank code path (gloo group, unique-id
+    # broadcast, RCCL communicator, all-gather) with a single rank, for 1-GPU boxes
+    multi = world > 1 or os.environ.get('IMPDAR_BENCH_FORCE_DIST') == '1'
     dist_pg = None
-    if world > 1:
+    if multi:
         import torch
         import torch.distributed as dist_pg
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist_pg.init_process_group('gloo', rank=rank, world_size=world)
 
     lib = _hip.load()
@@ -92,7 +103,7 @@ def main():
         sys.exit('bench.py: no HIP device visible; the HIP path has no CPU fallback')
     ctx = _hip.context(local % ndev)
 
-    if world > 1:
+    if multi:
         import torch
         ident = torch.zeros(_hip.UNIQUE_ID_BYTES, dtype=torch.uint8)
         if rank == 0:
@@ -126,7 +137,7 @@ def main():
 
     def step():
         plan.prep(d_in, max(nloc, 1), jlo, nloc)
-        if world > 1:
+        if multi:
             plan.allgather()
         plan.migrate(d_out, xlo, xhi)
 
@@ -204,7 +215,7 @@ def main():
             log('[bench] cpu baseline leg took %.1f s' % (time.time() - t0))
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res), flush=True)
+        os.write(result_fd, (json.dumps(res) + '\n').encode())
 
     plan.destroy()
     if dist_pg is not None:

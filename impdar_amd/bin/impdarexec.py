@@ -1,0 +1,34 @@
+#! /usr/bin/env python
+"""``impdar proc -migrate X files`` on the MI355X engine (reference
+``src/impdar/bin/impdarexec.py:47-119,175-182`` -> ``process.process_and_exit``).
+Only the ``proc`` sub-command with the ``-migrate`` step is provided."""
+import argparse
+import sys
+
+from ..lib import process
+
+
+def _get_args():
+    parser = argparse.ArgumentParser()
+    subparsers = parser.add_subparsers(help='Choose a processing step')
+    parser_proc = subparsers.add_parser('proc', help='Process data')
+    parser_proc.set_defaults(func=process.process_and_exit)
+    parser_proc.add_argument('-migrate', type=str, help='Migrate with the indicated routine.')
+    parser_proc.add_argument('fn', type=str, nargs='+', help='File(s) to process')
+    parser_proc.add_argument('-o', type=str, help='Write to this filename')
+    return parser
+
+
+def main():
+    parser = _get_args()
+    args = parser.parse_args(sys.argv[1:])
+    if not hasattr(args, 'func'):
+        parser.parse_args(['-h'])
+        return None
+    kw = vars(args)
+    func = kw.pop('func')
+    return func(**kw)
+
+
+if __name__ == '__main__':
+    main()

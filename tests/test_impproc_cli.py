@@ -114,3 +114,25 @@ def test_load_rejects_other_formats():
             fn = os.path.join(td, 'bad.mat')
             savemat(fn, {'nothing': np.zeros(3)})
             RadarData(fn)
+
+
+def test_process_migrate_hook_always_stolt():
+    """reference test/test_process.py:243-246 and lib/process.py:190-193."""
+    from impdar_amd.lib import process
+    d = MagicMock()
+    assert process.process([d], migrate='kirch') is True
+    d.migrate.assert_called_with(mtype='stolt')
+    assert process.process([MagicMock()]) is False
+    with pytest.raises(NotImplementedError):
+        process.process([d], vbp=(1, 2))
+
+
+def test_impdarexec_proc_migrate(tmp_path):
+    from impdar_amd.bin import impdarexec
+    dat = MagicMock()
+    dat.fn = str(tmp_path / 'line_raw.mat')
+    with patch.object(sys, 'argv', ['impdar', 'proc', '-migrate', 'phsh', dat.fn]), \
+            patch('impdar_amd.lib.process.load', return_value=[dat]):
+        impdarexec.main()
+    dat.migrate.assert_called_with(mtype='stolt')
+    dat.save.assert_called_with(str(tmp_path / 'line_proc.mat'))
