@@ -10,7 +10,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libimpdar_hip.so')
+LIB_PATH = os.environ.get('IMPDAR_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libimpdar_hip.so')
 
 F32, F64 = 0, 1
 KIRCH_AUTO, KIRCH_EXACT, KIRCH_FAST = 0, 1, 2

@@ -46,8 +46,9 @@ struct PrepParams {
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void kirch_prep_kernel(PrepParams P)
 {
-    __shared__ double tg[64][65];
-    __shared__ double td[64][65];
+    // tiles in the image's element type: 2 x 16.6 KB for float32 (9 workgroups per CU)
+    __shared__ TO tg[64][65];
+    __shared__ TO td[64][65];
     const TI *f = reinterpret_cast<const TI *>(P.data);
     const int k0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -81,8 +82,8 @@ __global__ __launch_bounds__(256) void kirch_prep_kernel(PrepParams P)
                 if (!(fabs(d) <= 1.79e308)) d = 0.0;
             }
         }
-        tg[r][tx] = g;
-        td[r][tx] = d;
+        tg[r][tx] = (TO)g;
+        td[r][tx] = (TO)d;
     }
     __syncthreads();
     TO *GT = reinterpret_cast<TO *>(P.GT);
@@ -91,8 +92,8 @@ __global__ __launch_bounds__(256) void kirch_prep_kernel(PrepParams P)
         const int j = j0 + r, k = k0 + tx;
         if (j < P.nloc && k < n) {
             const size_t o = (size_t)(P.jlo + j) * n + k;
-            GT[o] = (TO)tg[tx][r];
-            if (DT) DT[o] = (TO)td[tx][r];
+            GT[o] = tg[tx][r];
+            if (DT) DT[o] = td[tx][r];
         }
     }
 }
@@ -403,8 +404,8 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_tab_kernel(FastParams P
 // start of the block and publishes it with two ds_write_b128 at the end, so
 // the global-load latency has a whole block of LDS/FMA work to hide behind.
 // ---------------------------------------------------------------------------
-#ifndef KQ_PIPE
-#define KQ_PIPE 2
+#ifndef KQ_VARIANT
+#define KQ_VARIANT 0
 #endif
 #define KQ_RING 40
 #define KQ_STRIDE 44
@@ -617,6 +618,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
                           "+v"(acc[20]), "+v"(acc[21]), "+v"(acc[22]), "+v"(acc[23]), "+v"(sink)        \
                      :: "memory");                                                                       \
     } while (0)
+#if KQ_VARIANT == 0
             load_step(0, va, ua);
             KQ_PIN();
             load_step(1, vb, ub); fma_step(0, va, ua); KQ_PIN();
@@ -628,6 +630,26 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
             load_step(7, vb, ub); fma_step(6, va, ua); KQ_PIN();
             fma_step(7, vb, ub);
             KQ_PIN();
+#elif KQ_VARIANT == 1
+            // two steps per pinned group
+            load_step(0, va, ua); load_step(1, vb, ub);
+            KQ_PIN();
+            fma_step(0, va, ua); load_step(2, va, ua); fma_step(1, vb, ub); load_step(3, vb, ub); KQ_PIN();
+            fma_step(2, va, ua); load_step(4, va, ua); fma_step(3, vb, ub); load_step(5, vb, ub); KQ_PIN();
+            fma_step(4, va, ua); load_step(6, va, ua); fma_step(5, vb, ub); load_step(7, vb, ub); KQ_PIN();
+            fma_step(6, va, ua); fma_step(7, vb, ub);
+            KQ_PIN();
+#else
+            // no software pipeline: reads then FMAs of each step, pinned
+            load_step(0, va, ua); KQ_PIN(); fma_step(0, va, ua); KQ_PIN();
+            load_step(1, va, ua); KQ_PIN(); fma_step(1, va, ua); KQ_PIN();
+            load_step(2, va, ua); KQ_PIN(); fma_step(2, va, ua); KQ_PIN();
+            load_step(3, va, ua); KQ_PIN(); fma_step(3, va, ua); KQ_PIN();
+            load_step(4, va, ua); KQ_PIN(); fma_step(4, va, ua); KQ_PIN();
+            load_step(5, va, ua); KQ_PIN(); fma_step(5, va, ua); KQ_PIN();
+            load_step(6, va, ua); KQ_PIN(); fma_step(6, va, ua); KQ_PIN();
+            load_step(7, va, ua); KQ_PIN(); fma_step(7, va, ua); KQ_PIN();
+#endif
             // ---- publish the next block's 8 traces: two aligned slot quads per sample
             const int pos0 = ((bb + 1) * S + XB) % RG;            // (q0 + 1) % RG, multiple of 8
             float *r0 = &ldsG[m0 * ST + pos0], *r1 = &ldsG[m1 * ST + pos0];
@@ -995,7 +1017,11 @@ static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipSt
     FastParams P = P0;
     const int ntiles = (nx + XB - 1) / XB;
     P.nxt = ntiles;
-    P.G = 4;
+    {
+        const char *ge = getenv("IMPDAR_KIRCH_G");        // tuning knob: adjacent trace tiles per XCD group
+        const int g = ge ? atoi(ge) : 1;
+        P.G = (g >= 1 && g <= 64) ? g : 1;
+    }
     const int per = 8 * P.G;
     const int nxt_pad = ((ntiles + per - 1) / per) * per;
     P.tiles_per_xcd = nxt_pad / 8;

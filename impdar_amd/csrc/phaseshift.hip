@@ -119,25 +119,40 @@ struct PsParams {
 // halving step sends half of the remaining values to the partner lane; once one value is
 // left the remaining lane bits are folded with plain butterflies.  On return v[0] of lane
 // L holds the total of value index (L >> (6 - log2 NV)) & (NV - 1).
+template <typename T, int HALF, int MASK, int NV>
+__device__ __forceinline__ void wrs_halve(T (&v)[NV], int lane)
+{
+    // keep HALF of the 2*HALF live values, hand the other half to the lane MASK away
+    const bool up = (lane & MASK) != 0;
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) {
+        const T send = up ? v[i] : v[i + HALF];
+        const T keep = up ? v[i + HALF] : v[i];
+        v[i] = keep + __shfl_xor(send, MASK, 64);
+    }
+}
+
 template <typename T, int NV>
-__device__ inline void wave_reduce_scatter(T (&v)[NV], int lane)
+__device__ __forceinline__ void wave_reduce_scatter(T (&v)[NV], int lane)
 {
     static_assert(NV == 8 || NV == 32, "instantiated for 8 and 32 values");
-    constexpr int LOG = NV == 32 ? 5 : 3;
-#pragma unroll
-    for (int step = 0; step < LOG; ++step) {
-        const int mask = 32 >> step;
-        const int half = (NV / 2) >> step;    // values kept after this step
-        const bool up = (lane & mask) != 0;
-#pragma unroll
-        for (int i = 0; i < half; ++i) {
-            const T send = up ? v[i] : v[i + half];
-            const T keep = up ? v[i + half] : v[i];
-            v[i] = keep + __shfl_xor(send, mask, 64);
-        }
+    // every index below is a compile-time constant (a runtime-indexed register array is
+    // lowered to compare/select chains: ~2000 instructions per call when this was a loop)
+    if constexpr (NV == 32) {
+        wrs_halve<T, 16, 32>(v, lane);
+        wrs_halve<T, 8, 16>(v, lane);
+        wrs_halve<T, 4, 8>(v, lane);
+        wrs_halve<T, 2, 4>(v, lane);
+        wrs_halve<T, 1, 2>(v, lane);
+        v[0] += __shfl_xor(v[0], 1, 64);
+    } else {
+        wrs_halve<T, 4, 32>(v, lane);
+        wrs_halve<T, 2, 16>(v, lane);
+        wrs_halve<T, 1, 8>(v, lane);
+        v[0] += __shfl_xor(v[0], 4, 64);
+        v[0] += __shfl_xor(v[0], 2, 64);
+        v[0] += __shfl_xor(v[0], 1, 64);
     }
-#pragma unroll
-    for (int mask = 32 >> LOG; mask >= 1; mask >>= 1) v[0] += __shfl_xor(v[0], mask, 64);
 }
 
 template <typename T, int BLOCK, int M, bool VZ>
@@ -202,8 +217,8 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
             for (int t = 0; t < PS_TT; ++t) {
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    const T nr = fr[m] * pa[m] - fi[m] * pb[m];         // FFK *= cp, :418
-                    const T ni = fr[m] * pb[m] + fi[m] * pa[m];
+                    const T nr = fma(fr[m], pa[m], -(fi[m] * pb[m]));   // FFK *= cp, :418
+                    const T ni = fma(fr[m], pb[m], fi[m] * pa[m]);
                     fr[m] = nr;
                     fi[m] = ni;
                     acc[2 * t] += nr;                                   // TK[itau] += FFK, :420
@@ -225,8 +240,8 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
                     const T ph = pb[m] * sqrt(coss > 0 ? coss : (T)0);  // :460 (real part of the complex sqrt)
                     T s, c;
                     sincos_t<T>(ph, &s, &c);
-                    T nr = fr[m] * c - fi[m] * s;                       // :464
-                    T ni = fr[m] * s + fi[m] * c;
+                    T nr = fma(fr[m], c, -(fi[m] * s));                 // :464
+                    T ni = fma(fr[m], s, fi[m] * c);
                     if (coss <= thr) {                                  // :484-485, stays zero afterwards
                         nr = 0;
                         ni = 0;
