@@ -35,7 +35,13 @@ extern "C" int impdar_ctx_create(int device, impdar_ctx **out)
     IMPDAR_HIP_CHECK(hipSetDevice(device));
     impdar_ctx *c = new impdar_ctx();
     c->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    // compute stream at the highest priority, producer stream at the lowest: the next
+    // radargram's prep then fills the tail of the current diffraction sum instead of
+    // competing with it for CUs
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio_lo);
     if (e != hipSuccess) {
         delete c;
         impdar_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -51,8 +57,10 @@ extern "C" void impdar_ctx_destroy(impdar_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->aux);
     (void)hipStreamSynchronize(ctx->stream);
     impdar_comm_destroy(ctx);
+    (void)hipStreamDestroy(ctx->aux);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -61,6 +69,7 @@ extern "C" int impdar_ctx_sync(impdar_ctx *ctx)
 {
     IMPDAR_ARG_CHECK(ctx, "null context");
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
+    IMPDAR_HIP_CHECK(hipStreamSynchronize(ctx->aux));
     IMPDAR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return IMPDAR_OK;
 }
@@ -77,6 +86,7 @@ extern "C" int impdar_dev_free(impdar_ctx *ctx, void *dptr)
 {
     IMPDAR_ARG_CHECK(ctx, "null context");
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
+    IMPDAR_HIP_CHECK(hipStreamSynchronize(ctx->aux));
     IMPDAR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     IMPDAR_HIP_CHECK(hipFree(dptr));
     return IMPDAR_OK;

@@ -54,12 +54,12 @@ extern "C" int impdar_comm_rank(const impdar_ctx *ctx) { return ctx ? ctx->rank 
 extern "C" int impdar_comm_size(const impdar_ctx *ctx) { return ctx ? ctx->nranks : IMPDAR_ERR_ARG; }
 
 // In-place all-gather: rank r owns bytes [r*per, (r+1)*per) of `image`.
-int impdar_allgather_rows(impdar_ctx *ctx, void *image, size_t bytes_per_rank)
+int impdar_allgather_rows(impdar_ctx *ctx, void *image, size_t bytes_per_rank, hipStream_t stream)
 {
     IMPDAR_ARG_CHECK(ctx && ctx->comm, "communicator not initialised (impdar_comm_init)");
     char *base = reinterpret_cast<char *>(image);
     IMPDAR_NCCL_CHECK(ncclAllGather(base + (size_t)ctx->rank * bytes_per_rank, base, bytes_per_rank, ncclChar,
-                                    reinterpret_cast<ncclComm_t>(ctx->comm), ctx->stream));
+                                    reinterpret_cast<ncclComm_t>(ctx->comm), stream));
     return IMPDAR_OK;
 }
 

@@ -13,7 +13,8 @@ struct ncclComm;
 
 struct impdar_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // compute stream (migration kernels, copies)
+    hipStream_t aux = nullptr;      // producer stream: prep / table / all-gather of the NEXT radargram
     // RCCL communicator (null until impdar_comm_init)
     ncclComm *comm = nullptr;
     int rank = 0;

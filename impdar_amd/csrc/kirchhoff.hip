@@ -404,9 +404,6 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_tab_kernel(FastParams P
 // start of the block and publishes it with two ds_write_b128 at the end, so
 // the global-load latency has a whole block of LDS/FMA work to hide behind.
 // ---------------------------------------------------------------------------
-#ifndef KQ_VARIANT
-#define KQ_VARIANT 0
-#endif
 #define KQ_RING 40
 #define KQ_STRIDE 44
 #define KQ_RP KQ_STRIDE
@@ -456,7 +453,9 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     const int nblocks = (nsteps + S - 1) / S;
     // the main loop always runs whole ring revolutions (NB blocks); steps past the
     // aperture pick the table's all-zero row, so they add nothing
-    const int nrev = (nblocks + NB - 1) / NB;
+    // (two revolutions are unrolled so that block parity, which selects the staging register
+    // set, is a compile-time constant)
+    const int nrev = 2 * ((nblocks + 2 * NB - 1) / (2 * NB));
     const int nsteps_pad = nrev * NB * S;
     const int jbase = x0 + nlo;
     const int ntab1 = P.ntab - 1;
@@ -508,38 +507,77 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
 #pragma unroll
     for (int i = 0; i < XB; ++i) acc[i] = 0.f;
 
-    for (int rev = 0; rev < nrev; ++rev) {
-#pragma clang loop unroll(full)
-        for (int bb = 0; bb < NB; ++bb) {
-            const int blk = rev * NB + bb;
-            // ---- issue the next block's loads: 8 traces x 2 samples per thread + table entries
-            const int q0 = (blk + 1) * S + XB - 1;
-            int kmin, kmax;
-            window(q0, q0 + S - 1, kmin, kmax);
-            const int e1 = kmin + tid + KF_THREADS;
-            const bool wr1 = e1 <= kmax;
-            const int c0 = min(kmin + tid, snum - 1), c1 = min(e1, snum - 1);
-            int m0 = (kmin % W) + tid;
-            m0 -= (m0 >= W) ? W : 0;
-            int m1 = m0 + KF_THREADS;
-            m1 -= (m1 >= W) ? W : 0;
-            m1 -= (m1 >= W) ? W : 0;
-            float g0[S], g1[S], d0[NEAR ? S : 1], d1[NEAR ? S : 1];
-            unsigned short tkn[S];
-            const unsigned vo0 = (unsigned)c0 * 4u, vo1 = (unsigned)c1 * 4u;
-            const char *tb = reinterpret_cast<const char *>(trace_ptr(P.GT, q0));
-            const char *tbd = NEAR ? reinterpret_cast<const char *>(trace_ptr(P.DT, q0)) : nullptr;
-            const size_t rowb = (size_t)snum * 4;
+    // Staging registers of one block's 8 incoming traces (2 samples per thread each).  Loads are
+    // issued TWO blocks ahead of use: the set filled during block b is published at the end of
+    // block b+1, so the global-load latency has a full block of LDS/FMA work in front of it.
+    struct Stage {
+        float g0[S], g1[S], d0[NEAR ? S : 1], d1[NEAR ? S : 1];
+        int m0, m1;
+        bool wr1;
+    };
+    auto issue = [&](int blk_for, Stage &st) {       // traces that block `blk_for` adds to the ring
+        const int q0 = blk_for * S + XB - 1;
+        int kmin, kmax;
+        window(q0, q0 + S - 1, kmin, kmax);
+        const int e1 = kmin + tid + KF_THREADS;
+        st.wr1 = e1 <= kmax;
+        const int c0 = min(kmin + tid, snum - 1), c1 = min(e1, snum - 1);
+        int m0 = (kmin % W) + tid;
+        m0 -= (m0 >= W) ? W : 0;
+        int m1 = m0 + KF_THREADS;
+        m1 -= (m1 >= W) ? W : 0;
+        m1 -= (m1 >= W) ? W : 0;
+        st.m0 = m0;
+        st.m1 = m1;
+        const unsigned vo0 = (unsigned)c0 * 4u, vo1 = (unsigned)c1 * 4u;
+        const char *tb = reinterpret_cast<const char *>(trace_ptr(P.GT, q0));
+        const char *tbd = NEAR ? reinterpret_cast<const char *>(trace_ptr(P.DT, q0)) : nullptr;
+        const size_t rowb = (size_t)snum * 4;
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                g0[s] = *reinterpret_cast<const float *>(tb + s * rowb + vo0);
-                g1[s] = *reinterpret_cast<const float *>(tb + s * rowb + vo1);
-                if (NEAR) {
-                    d0[s] = *reinterpret_cast<const float *>(tbd + s * rowb + vo0);
-                    d1[s] = *reinterpret_cast<const float *>(tbd + s * rowb + vo1);
-                }
-                tkn[s] = pick((blk + 1) * S + s);
+        for (int s = 0; s < S; ++s) {
+            st.g0[s] = *reinterpret_cast<const float *>(tb + s * rowb + vo0);
+            st.g1[s] = *reinterpret_cast<const float *>(tb + s * rowb + vo1);
+            if (NEAR) {
+                st.d0[s] = *reinterpret_cast<const float *>(tbd + s * rowb + vo0);
+                st.d1[s] = *reinterpret_cast<const float *>(tbd + s * rowb + vo1);
             }
+        }
+    };
+    auto publish = [&](int pos0, const Stage &st) {  // two aligned slot quads per sample
+        float *r0 = &ldsG[st.m0 * ST + pos0], *r1 = &ldsG[st.m1 * ST + pos0];
+        reinterpret_cast<float4 *>(r0)[0] = make_float4(st.g0[0], st.g0[1], st.g0[2], st.g0[3]);
+        reinterpret_cast<float4 *>(r0)[1] = make_float4(st.g0[4], st.g0[5], st.g0[6], st.g0[7]);
+        if (st.wr1) {
+            reinterpret_cast<float4 *>(r1)[0] = make_float4(st.g1[0], st.g1[1], st.g1[2], st.g1[3]);
+            reinterpret_cast<float4 *>(r1)[1] = make_float4(st.g1[4], st.g1[5], st.g1[6], st.g1[7]);
+        }
+        if (NEAR) {
+            float *t0 = &ldsD[st.m0 * ST + pos0], *t1 = &ldsD[st.m1 * ST + pos0];
+            reinterpret_cast<float4 *>(t0)[0] = make_float4(st.d0[0], st.d0[1], st.d0[2], st.d0[3]);
+            reinterpret_cast<float4 *>(t0)[1] = make_float4(st.d0[4], st.d0[5], st.d0[6], st.d0[7]);
+            if (st.wr1) {
+                reinterpret_cast<float4 *>(t1)[0] = make_float4(st.d1[0], st.d1[1], st.d1[2], st.d1[3]);
+                reinterpret_cast<float4 *>(t1)[1] = make_float4(st.d1[4], st.d1[5], st.d1[6], st.d1[7]);
+            }
+        }
+    };
+    Stage stA, stB;                                // stA: filled during even blocks, stB: odd
+    issue(1, stB);                                 // block 1's traces, published at the end of block 0
+
+    for (int rev = 0; rev < nrev; rev += 2) {
+#pragma clang loop unroll(full)
+        for (int bb2 = 0; bb2 < 2 * NB; ++bb2) {
+            const int bb = bb2 % NB;                   // block index within the ring revolution
+            const int blk = rev * NB + bb2;
+            // ---- loads: next block's table entries first (they are waited for first), then the
+            // traces of the block after next
+            unsigned short tkn[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) tkn[s] = pick((blk + 1) * S + s);
+            if ((bb2 & 1) == 0)
+                issue(blk + 2, stA);
+            else
+                issue(blk + 2, stB);
             // weights of this block's steps
             float twc[S], tw2c[NEAR ? S : 1];
             const float n0f = (float)(nlo + blk * S);
@@ -618,7 +656,6 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
                           "+v"(acc[20]), "+v"(acc[21]), "+v"(acc[22]), "+v"(acc[23]), "+v"(sink)        \
                      :: "memory");                                                                       \
     } while (0)
-#if KQ_VARIANT == 0
             load_step(0, va, ua);
             KQ_PIN();
             load_step(1, vb, ub); fma_step(0, va, ua); KQ_PIN();
@@ -630,43 +667,13 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
             load_step(7, vb, ub); fma_step(6, va, ua); KQ_PIN();
             fma_step(7, vb, ub);
             KQ_PIN();
-#elif KQ_VARIANT == 1
-            // two steps per pinned group
-            load_step(0, va, ua); load_step(1, vb, ub);
-            KQ_PIN();
-            fma_step(0, va, ua); load_step(2, va, ua); fma_step(1, vb, ub); load_step(3, vb, ub); KQ_PIN();
-            fma_step(2, va, ua); load_step(4, va, ua); fma_step(3, vb, ub); load_step(5, vb, ub); KQ_PIN();
-            fma_step(4, va, ua); load_step(6, va, ua); fma_step(5, vb, ub); load_step(7, vb, ub); KQ_PIN();
-            fma_step(6, va, ua); fma_step(7, vb, ub);
-            KQ_PIN();
-#else
-            // no software pipeline: reads then FMAs of each step, pinned
-            load_step(0, va, ua); KQ_PIN(); fma_step(0, va, ua); KQ_PIN();
-            load_step(1, va, ua); KQ_PIN(); fma_step(1, va, ua); KQ_PIN();
-            load_step(2, va, ua); KQ_PIN(); fma_step(2, va, ua); KQ_PIN();
-            load_step(3, va, ua); KQ_PIN(); fma_step(3, va, ua); KQ_PIN();
-            load_step(4, va, ua); KQ_PIN(); fma_step(4, va, ua); KQ_PIN();
-            load_step(5, va, ua); KQ_PIN(); fma_step(5, va, ua); KQ_PIN();
-            load_step(6, va, ua); KQ_PIN(); fma_step(6, va, ua); KQ_PIN();
-            load_step(7, va, ua); KQ_PIN(); fma_step(7, va, ua); KQ_PIN();
-#endif
-            // ---- publish the next block's 8 traces: two aligned slot quads per sample
-            const int pos0 = ((bb + 1) * S + XB) % RG;            // (q0 + 1) % RG, multiple of 8
-            float *r0 = &ldsG[m0 * ST + pos0], *r1 = &ldsG[m1 * ST + pos0];
-            reinterpret_cast<float4 *>(r0)[0] = make_float4(g0[0], g0[1], g0[2], g0[3]);
-            reinterpret_cast<float4 *>(r0)[1] = make_float4(g0[4], g0[5], g0[6], g0[7]);
-            if (wr1) {
-                reinterpret_cast<float4 *>(r1)[0] = make_float4(g1[0], g1[1], g1[2], g1[3]);
-                reinterpret_cast<float4 *>(r1)[1] = make_float4(g1[4], g1[5], g1[6], g1[7]);
-            }
-            if (NEAR) {
-                float *t0 = &ldsD[m0 * ST + pos0], *t1 = &ldsD[m1 * ST + pos0];
-                reinterpret_cast<float4 *>(t0)[0] = make_float4(d0[0], d0[1], d0[2], d0[3]);
-                reinterpret_cast<float4 *>(t0)[1] = make_float4(d0[4], d0[5], d0[6], d0[7]);
-                if (wr1) {
-                    reinterpret_cast<float4 *>(t1)[0] = make_float4(d1[0], d1[1], d1[2], d1[3]);
-                    reinterpret_cast<float4 *>(t1)[1] = make_float4(d1[4], d1[5], d1[6], d1[7]);
-                }
+            // ---- publish the next block's 8 traces (loaded during the previous block)
+            {
+                const int pos0 = ((bb + 1) * S + XB) % RG;        // ring position of its first trace, multiple of 8
+                if ((bb2 & 1) == 0)
+                    publish(pos0, stB);
+                else
+                    publish(pos0, stA);
             }
 #pragma unroll
             for (int s = 0; s < S; ++s) tkc[s] = tkn[s];
@@ -695,9 +702,17 @@ struct impdar_kirch_plan {
     bool uniform = false;
     // device tables
     DevBuf d_dist, d_tt, d_zs, d_zs2, d_ga, d_gb, d_gc;
-    DevBuf GT, DT;                 // images with KF_PAD_ROWS all-zero rows before row 0 and after row tnum_pad-1
+    // Everything a prep produces is double-buffered: prep / table / all-gather of radargram
+    // s+1 run on the context's aux stream while the diffraction sum of radargram s runs on
+    // the compute stream.  `buf` flips at the first prep after a migrate.
+    DevBuf GT[2], DT[2];           // images with KF_PAD_ROWS all-zero rows before row 0 and after row tnum_pad-1
+    int buf = 0;
+    bool migrated_since_prep = false;
+    hipEvent_t ev_ready[2] = {nullptr, nullptr};   // image + table of buffer b complete (aux stream)
+    hipEvent_t ev_free[2] = {nullptr, nullptr};    // last migrate reading buffer b done (compute stream)
+    bool free_recorded[2] = {false, false};
     DevBuf d_hmax, d_klo, d_khi;
-    DevBuf d_TK, d_TW, d_TW2, d_A, d_wcf, d_wc2f;
+    DevBuf d_TK[2], d_TW[2], d_TW2[2], d_A, d_wcf, d_wc2f;
     int nb = 0, ntab = 0;
     bool quad = false;          // sample-major LDS ring (kirch_quad_kernel)
     int quadW = 0;              // samples per ring slot in that layout
@@ -713,7 +728,7 @@ struct impdar_kirch_plan {
     int xb = 32;                   // fast-kernel trace tile
 };
 
-static inline char *img_row0(const impdar_kirch_plan *p, const DevBuf &b)
+static inline char *img_row0(const impdar_kirch_plan *p, const DevBuf &b)  // b = GT[buf] / DT[buf]
 {
     return reinterpret_cast<char *>(b.p) + (size_t)KF_PAD_ROWS * p->snum * impdar_dtype_size(p->dtype);
 }
@@ -815,18 +830,15 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     };
     const size_t esz = impdar_dtype_size(dtype);
     const size_t img = (size_t)(p->tnum_pad + 2 * KF_PAD_ROWS) * snum * esz;   // zero rows on both sides
-    if (p->GT.ensure(img) != hipSuccess) {
-        impdar_set_error("hipMalloc of %zu-byte gradient image failed", img);
-        return fail(IMPDAR_ERR_HIP);
-    }
-    (void)hipMemsetAsync(p->GT.p, 0, img, ctx->stream);
-    if (p->nearfield) {
-        if (p->DT.ensure(img) != hipSuccess) {
-            impdar_set_error("hipMalloc of %zu-byte data image failed", img);
+    for (int b = 0; b < 2; ++b) {
+        if (p->GT[b].ensure(img) != hipSuccess || (p->nearfield && p->DT[b].ensure(img) != hipSuccess)) {
+            impdar_set_error("hipMalloc of %zu-byte image failed", img);
             return fail(IMPDAR_ERR_HIP);
         }
-        (void)hipMemsetAsync(p->DT.p, 0, img, ctx->stream);
+        (void)hipMemsetAsync(p->GT[b].p, 0, img, ctx->stream);
+        if (p->nearfield) (void)hipMemsetAsync(p->DT[b].p, 0, img, ctx->stream);
     }
+    (void)hipStreamSynchronize(ctx->stream);
     if (!grad_uniform) {
         if ((rc = upload(p->d_ga, ga, snum * 8)) || (rc = upload(p->d_gb, gb, snum * 8)) ||
             (rc = upload(p->d_gc, gc, snum * 8)))
@@ -891,8 +903,13 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         p->ntab = hglob + 1;       // offsets 0..hglob-1 (hmax carries a guard) + one all-zero row
         {
             const size_t ent = (size_t)p->ntab * snum;
-            if (p->d_TK.ensure(ent * 2) != hipSuccess || p->d_TW.ensure(ent * 4) != hipSuccess ||
-                (p->nearfield && p->d_TW2.ensure(ent * 4) != hipSuccess)) {
+            bool ok = true;
+            for (int b = 0; b < 2; ++b) {
+                ok = ok && p->d_TK[b].ensure(ent * 2) == hipSuccess;
+                if (!p->quad) ok = ok && p->d_TW[b].ensure(ent * 4) == hipSuccess;
+                if (!p->quad && p->nearfield) ok = ok && p->d_TW2[b].ensure(ent * 4) == hipSuccess;
+            }
+            if (!ok) {
                 impdar_set_error("hipMalloc of the %zu-entry pick/weight table failed", ent);
                 return fail(IMPDAR_ERR_HIP);
             }
@@ -918,6 +935,13 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
                 impdar_set_error("hipEventCreate failed");
                 return fail(IMPDAR_ERR_HIP);
             }
+    if (hipEventCreateWithFlags(&p->ev_ready[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_ready[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_free[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_free[1], hipEventDisableTiming) != hipSuccess) {
+        impdar_set_error("hipEventCreate failed");
+        return fail(IMPDAR_ERR_HIP);
+    }
     *out = p;
     return IMPDAR_OK;
 }
@@ -926,7 +950,10 @@ extern "C" void impdar_kirch_plan_destroy(impdar_kirch_plan *p)
 {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->aux);
     (void)hipStreamSynchronize(p->ctx->stream);
+    for (hipEvent_t e : {p->ev_ready[0], p->ev_ready[1], p->ev_free[0], p->ev_free[1]})
+        if (e) (void)hipEventDestroy(e);
     for (int s = 0; s < impdar_kirch_plan::NSLOT; ++s)
         for (int i = 0; i < 6; ++i)
             if (p->evs[s][i]) (void)hipEventDestroy(p->evs[s][i]);
@@ -943,12 +970,21 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
                      "column block [%d,%d) with ld %d does not fit the plan (tnum_pad %d)", jlo, jlo + nloc, ld,
                      p->tnum_pad);
     IMPDAR_HIP_CHECK(hipSetDevice(p->ctx->device));
-    hipStream_t st = p->ctx->stream;
-    // a prep opens a new step: move to the next event slot
-    p->slot = (p->slot + 1) % impdar_kirch_plan::NSLOT;
-    p->haves[p->slot][0] = p->haves[p->slot][1] = p->haves[p->slot][2] = false;
+    hipStream_t st = p->ctx->aux;
+    if (p->migrated_since_prep) {
+        // first prep after a migrate: a new radargram -> other buffer set, next event slot
+        p->migrated_since_prep = false;
+        p->buf ^= 1;
+        p->slot = (p->slot + 1) % impdar_kirch_plan::NSLOT;
+        p->haves[p->slot][0] = p->haves[p->slot][1] = p->haves[p->slot][2] = false;
+    }
+    const int b = p->buf;
+    // the buffer set may still be read by the migrate of the radargram before last.  (The
+    // input itself must already be complete: the upload entry points are blocking, and the
+    // one-shot paths below synchronise their own copy before calling prep.)
+    if (p->free_recorded[b]) IMPDAR_HIP_CHECK(hipStreamWaitEvent(st, p->ev_free[b], 0));
     hipEvent_t *ev = p->evs[p->slot];
-    IMPDAR_HIP_CHECK(hipEventRecord(ev[0], st));
+    if (!p->haves[p->slot][0]) IMPDAR_HIP_CHECK(hipEventRecord(ev[0], st));
     if (nloc > 0) {
         PrepParams P;
         P.data = d_data;
@@ -956,8 +992,8 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
         P.snum = p->snum;
         P.nloc = nloc;
         P.jlo = jlo;
-        P.GT = img_row0(p, p->GT);
-        P.DT = p->nearfield ? img_row0(p, p->DT) : nullptr;
+        P.GT = img_row0(p, p->GT[b]);
+        P.DT = p->nearfield ? img_row0(p, p->DT[b]) : nullptr;
         P.grad_uniform = p->grad_uniform;
         P.precomputed = precomputed;
         P.grad_h = p->grad_h;
@@ -975,9 +1011,9 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
     if (p->mode == IMPDAR_KIRCH_FAST) {
         // geometry-only pick/weight table, rebuilt with every prep (counted in prep time)
         TableParams T;
-        T.TK = p->d_TK.as<unsigned short>();
-        T.TW = p->d_TW.as<float>();
-        T.TW2 = p->d_TW2.as<float>();
+        T.TK = p->d_TK[b].as<unsigned short>();
+        T.TW = p->d_TW[b].as<float>();
+        T.TW2 = p->d_TW2[b].as<float>();
         T.zs = p->d_zs.as<double>();
         T.zs2 = p->d_zs2.as<double>();
         T.tt = p->d_tt.as<double>();
@@ -997,6 +1033,7 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
         IMPDAR_HIP_CHECK(hipGetLastError());
     }
     IMPDAR_HIP_CHECK(hipEventRecord(ev[1], st));
+    IMPDAR_HIP_CHECK(hipEventRecord(p->ev_ready[b], st));
     p->haves[p->slot][0] = true;
     return IMPDAR_OK;
 }
@@ -1075,12 +1112,14 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
     IMPDAR_HIP_CHECK(hipSetDevice(p->ctx->device));
     hipStream_t st = p->ctx->stream;
     hipEvent_t *ev = p->evs[p->slot];
-    IMPDAR_HIP_CHECK(hipEventRecord(ev[4], st));
+    const int b = p->buf;
+    IMPDAR_HIP_CHECK(hipStreamWaitEvent(st, p->ev_ready[b], 0));      // image + table of this radargram
+    if (!p->haves[p->slot][2]) IMPDAR_HIP_CHECK(hipEventRecord(ev[4], st));
     const int nx = xhi - xlo;
     if (nx > 0 && p->mode == IMPDAR_KIRCH_FAST) {
         FastParams P;
-        P.GT = reinterpret_cast<const float *>(img_row0(p, p->GT));
-        P.DT = p->nearfield ? reinterpret_cast<const float *>(img_row0(p, p->DT)) : nullptr;
+        P.GT = reinterpret_cast<const float *>(img_row0(p, p->GT[b]));
+        P.DT = p->nearfield ? reinterpret_cast<const float *>(img_row0(p, p->DT[b])) : nullptr;
         P.out = reinterpret_cast<float *>(d_out);
         P.ldo = nx;
         P.snum = p->snum;
@@ -1093,9 +1132,9 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         P.nb = p->nb;
         P.zero_row = p->tnum_pad;          // first zero row after the data rows
         P.nchunks = p->nchunks;
-        P.TK = p->d_TK.as<unsigned short>();
-        P.TW = p->d_TW.as<float>();
-        P.TW2 = p->d_TW2.as<float>();
+        P.TK = p->d_TK[b].as<unsigned short>();
+        P.TW = p->d_TW[b].as<float>();
+        P.TW2 = p->d_TW2[b].as<float>();
         P.ntab = p->ntab;
         P.A = p->d_A.as<float>();
         P.wcf = p->d_wcf.as<float>();
@@ -1111,8 +1150,8 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         if (rc) return rc;
     } else if (nx > 0) {
         ExactParams P;
-        P.GT = img_row0(p, p->GT);
-        P.DT = p->nearfield ? img_row0(p, p->DT) : nullptr;
+        P.GT = img_row0(p, p->GT[b]);
+        P.DT = p->nearfield ? img_row0(p, p->DT[b]) : nullptr;
         P.out = d_out;
         P.ldo = nx;
         P.snum = p->snum;
@@ -1144,12 +1183,15 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         IMPDAR_HIP_CHECK(hipGetLastError());
     }
     IMPDAR_HIP_CHECK(hipEventRecord(ev[5], st));
+    IMPDAR_HIP_CHECK(hipEventRecord(p->ev_free[b], st));
+    p->free_recorded[b] = true;
+    p->migrated_since_prep = true;
     p->haves[p->slot][2] = true;
     return IMPDAR_OK;
 }
 
 // defined in comm.hip
-int impdar_allgather_rows(impdar_ctx *ctx, void *image, size_t bytes_per_rank);
+int impdar_allgather_rows(impdar_ctx *ctx, void *image, size_t bytes_per_rank, hipStream_t stream);
 
 extern "C" int impdar_kirch_allgather(impdar_kirch_plan *p)
 {
@@ -1157,16 +1199,18 @@ extern "C" int impdar_kirch_allgather(impdar_kirch_plan *p)
     IMPDAR_ARG_CHECK(p->nranks == p->ctx->nranks, "plan was built for %d ranks but the communicator has %d",
                      p->nranks, p->ctx->nranks);
     IMPDAR_HIP_CHECK(hipSetDevice(p->ctx->device));
-    hipStream_t st = p->ctx->stream;
+    hipStream_t st = p->ctx->aux;                       // behind this radargram's prep
     hipEvent_t *ev = p->evs[p->slot];
+    const int b = p->buf;
     IMPDAR_HIP_CHECK(hipEventRecord(ev[2], st));
     if (p->nranks > 1 || p->ctx->comm) {        // a 1-rank communicator still runs the (trivial) collective
         const size_t per = (size_t)(p->tnum_pad / p->nranks) * p->snum * impdar_dtype_size(p->dtype);
-        int rc = impdar_allgather_rows(p->ctx, img_row0(p, p->GT), per);
+        int rc = impdar_allgather_rows(p->ctx, img_row0(p, p->GT[b]), per, st);
         if (rc) return rc;
-        if (p->nearfield && (rc = impdar_allgather_rows(p->ctx, img_row0(p, p->DT), per))) return rc;
+        if (p->nearfield && (rc = impdar_allgather_rows(p->ctx, img_row0(p, p->DT[b]), per, st))) return rc;
     }
     IMPDAR_HIP_CHECK(hipEventRecord(ev[3], st));
+    IMPDAR_HIP_CHECK(hipEventRecord(p->ev_ready[b], st));
     p->haves[p->slot][1] = true;
     return IMPDAR_OK;
 }
@@ -1234,7 +1278,8 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
         impdar_set_error("hipMalloc of %zu bytes failed", bytes);
         return done(IMPDAR_ERR_HIP);
     }
-    if (hipMemcpyAsync(din.p, data, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+    if (hipMemcpyAsync(din.p, data, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {      // prep runs on the aux stream
         impdar_set_error("H2D copy failed");
         return done(IMPDAR_ERR_HIP);
     }
@@ -1293,6 +1338,7 @@ extern "C" void mig_kirch_loop(double *migdata, int tnum, int snum, double *dist
         hipMemcpy(p->d_zs2.p, zs2, (size_t)snum * 8, hipMemcpyHostToDevice) == hipSuccess &&
         din.ensure(bytes) == hipSuccess && dout.ensure(bytes) == hipSuccess &&
         hipMemcpyAsync(din.p, gradD, bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+        hipStreamSynchronize(ctx->stream) == hipSuccess &&
         impdar_kirch_prep_precomputed(p, din.p, tnum, 0, tnum) == IMPDAR_OK &&
         impdar_kirch_migrate(p, dout.p, 0, tnum) == IMPDAR_OK &&
         hipMemcpyAsync(migdata, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&

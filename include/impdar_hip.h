@@ -101,8 +101,11 @@ int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, int snum, int
  *              (equal blocks of tnum_pad/nranks traces per rank)
  *   migrate  : diffraction sum for output traces [xlo,xhi) into d_out
  *              (snum x (xhi-xlo), row-major, element type = plan dtype)
- * All three are enqueued on the context's stream (asynchronous); call
- * impdar_ctx_sync to wait. */
+ * All three are asynchronous; call impdar_ctx_sync to wait.  prep and allgather run on
+ * the context's producer stream into one of two buffer sets, migrate on its compute stream,
+ * so the prep/all-gather of the next radargram overlap the diffraction sum of the current
+ * one; the first prep after a migrate starts a new radargram (switches buffer set).  d_data
+ * must be complete when prep is called (impdar_dev_upload is blocking). */
 int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, int tnum,
                              const double *dist_m, const double *tt_sec, double vel,
                              int nearfield, int grad_uniform, double grad_h,
