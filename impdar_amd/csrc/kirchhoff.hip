@@ -725,7 +725,16 @@ struct impdar_kirch_plan {
     hipEvent_t evs[NSLOT][6] = {};
     bool haves[NSLOT][3] = {};
     int slot = 0;
-    int xb = 32;                   // fast-kernel trace tile
+    int xb = 24;                   // fast-kernel trace tile (24: quad ring, 16: tab ring)
+
+    ~impdar_kirch_plan()
+    {
+        for (hipEvent_t e : {ev_ready[0], ev_ready[1], ev_free[0], ev_free[1]})
+            if (e) (void)hipEventDestroy(e);
+        for (int s = 0; s < NSLOT; ++s)
+            for (int i = 0; i < 6; ++i)
+                if (evs[s][i]) (void)hipEventDestroy(evs[s][i]);
+    }
 };
 
 static inline char *img_row0(const impdar_kirch_plan *p, const DevBuf &b)  // b = GT[buf] / DT[buf]
@@ -898,6 +907,10 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
             cmin[c] = amin;
             cmax[c] = amax;
         }
+        // offsets beyond the profile length can only meet traces outside the profile (zero
+        // rows), so the tables need not extend past tnum even when the aperture does
+        hglob = std::min(hglob, tnum + 128);
+        for (int c = 0; c < nch; ++c) hmax[c] = std::min(hmax[c], hglob);
         const int nb = hglob + 64;
         p->nb = nb;
         p->ntab = hglob + 1;       // offsets 0..hglob-1 (hmax carries a guard) + one all-zero row
@@ -952,11 +965,6 @@ extern "C" void impdar_kirch_plan_destroy(impdar_kirch_plan *p)
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->aux);
     (void)hipStreamSynchronize(p->ctx->stream);
-    for (hipEvent_t e : {p->ev_ready[0], p->ev_ready[1], p->ev_free[0], p->ev_free[1]})
-        if (e) (void)hipEventDestroy(e);
-    for (int s = 0; s < impdar_kirch_plan::NSLOT; ++s)
-        for (int i = 0; i < 6; ++i)
-            if (p->evs[s][i]) (void)hipEventDestroy(p->evs[s][i]);
     delete p;
 }
 
