@@ -87,6 +87,30 @@ def test_vs_oracle_sizes(hip, snum, tnum, layered):
     assert rel_max(d.data, want) < F64_TOL, rel_max(d.data, want)
 
 
+@pytest.mark.parametrize('layered', [False, True])
+def test_float32_larger_size_vs_oracle(hip, layered):
+    """float32 recurrences over ~1000 depth steps (nt = 1024, two frequencies per lane)."""
+    from impdar_amd import synth
+    from impdar_amd.lib.RadarData import RadarData
+    from impdar_amd.lib import migrationlib
+    from oracle import mig_oracle
+    snum, tnum = 1000, 192
+    geo = synth.geometry(snum, tnum)
+    data = synth.diffractor_radargram(snum, tnum, ndiff=16).astype(np.float32)
+    if layered:
+        Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+        vel = np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rp], [1.8e8, 0.5 * Rp], [1.9e8, 1.2 * Rp]])
+    else:
+        vel = 1.69e8
+    want = mig_oracle.phase_shift(data.astype(np.float64), geo['dt'], geo['trace_int'], geo['travel_time'],
+                                  geo['dist'], vel, 20, 30)
+    d = RadarData(None)
+    d.data, d.snum, d.tnum = data.copy(), snum, tnum
+    d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
+    migrationlib.migrationPhaseShift(d, vel=vel, htaper=20, vtaper=30)
+    assert rel_l2(d.data, want) < F32_L2, rel_l2(d.data, want)
+
+
 def test_tk_is_taper_only(hip):
     g = golden('T1_tk_taper_only')
     dat = make_dat(g)
