@@ -22,7 +22,8 @@ import sys
 def counters(d):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
     meta = {}
-    for f in glob.glob(os.path.join(d, '*', '*_counter_collection.csv')):
+    files = sorted(glob.glob(os.path.join(d, '*', '*_counter_collection.csv')), key=os.path.getmtime)
+    for f in files[-1:]:                       # the merged scratch dir may hold older runs too
         for r in csv.DictReader(open(f)):
             out[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
             meta[r['Kernel_Name']] = dict(vgpr=r['VGPR_Count'], sgpr=r['SGPR_Count'], lds=r['LDS_Block_Size'],
@@ -34,8 +35,9 @@ def main():
     src, tag = sys.argv[1], sys.argv[2]
     here = os.path.dirname(os.path.abspath(__file__))
     snum, tnum = 4096, 10000
-    for f in glob.glob(os.path.join(src, 'stats', '*', '*_kernel_stats.csv')):
-        shutil.copy(f, os.path.join(here, '%s_bench_kernel_stats.csv' % tag))
+    stats = sorted(glob.glob(os.path.join(src, 'stats', '*', '*_kernel_stats.csv')), key=os.path.getmtime)
+    if stats:
+        shutil.copy(stats[-1], os.path.join(here, '%s_bench_kernel_stats.csv' % tag))
     rows = []
     allc = {}
     for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
