@@ -89,6 +89,15 @@ template <typename T> __device__ inline void sincos_t(T x, T *s, T *c);
 // about 20 VALU instructions, no slow path.
 template <> __device__ inline void sincos_t<float>(float x, float *s, float *c)
 {
+#ifdef IMPDAR_PS_HWSINCOS
+    // hardware v_sin_f32 / v_cos_f32 (argument in revolutions) + one Newton step back onto the
+    // unit circle, so the amplitude error does not compound over thousands of depth steps
+    const float r = x * 0.15915494309189535f;
+    float ss = __builtin_amdgcn_sinf(r), cc = __builtin_amdgcn_cosf(r);
+    const float k = fmaf(-0.5f, fmaf(cc, cc, ss * ss), 1.5f);
+    *s = ss * k;
+    *c = cc * k;
+#else
     const float q = rintf(x * 0.636619772f);
     float r = fmaf(q, -1.5707963705062866f, x);
     r = fmaf(q, 4.37113900018624283e-8f, r);
@@ -101,6 +110,7 @@ template <> __device__ inline void sincos_t<float>(float x, float *s, float *c)
     const float cc = (qi & 1) ? sp : cp;
     *s = (qi & 2) ? -ss : ss;
     *c = ((qi + 1) & 2) ? -cc : cc;
+#endif
 }
 template <> __device__ inline void sincos_t<double>(double x, double *s, double *c) { sincos(x, s, c); }
 
