@@ -168,6 +168,7 @@ struct FastParams {
     const float *TW, *TW2;         // far / near weights (0 where the reference drops the pair); tab kernel only
     const float *A, *wcf, *wc2f;   // quad kernel: (tt/dt)^2, cos-weight prefactors per sample [snum]
     float alpha;                   // (2 dx / (v dt))^2
+    unsigned long long *stamps;    // diagnostic builds only (-DKQ_STAMP): per-workgroup {start, end, hw id, chunk|steps}
     int ntab;                      // rows; the last row is all zero (|n| beyond every aperture)
 };
 
@@ -427,6 +428,9 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     const int qx = r - chunk * P.tiles_per_xcd;
     const int xt = ((qx / P.G) * 8 + xcd) * P.G + (qx % P.G);
     if (chunk >= P.nchunks || xt >= P.nxt) return;
+#ifdef KQ_STAMP
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const int tid = threadIdx.x;
     const int s0 = chunk * KF_THREADS;
@@ -536,10 +540,15 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             st.g0[s] = *reinterpret_cast<const float *>(tb + s * rowb + vo0);
-            st.g1[s] = *reinterpret_cast<const float *>(tb + s * rowb + vo1);
-            if (NEAR) {
-                st.d0[s] = *reinterpret_cast<const float *>(tbd + s * rowb + vo0);
-                st.d1[s] = *reinterpret_cast<const float *>(tbd + s * rowb + vo1);
+            if (NEAR) st.d0[s] = *reinterpret_cast<const float *>(tbd + s * rowb + vo0);
+        }
+        // the window is ~300 samples: only the first ~44 lanes of the workgroup have a second
+        // sample, so three of the four waves skip these loads altogether
+        if (st.wr1) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                st.g1[s] = *reinterpret_cast<const float *>(tb + s * rowb + vo1);
+                if (NEAR) st.d1[s] = *reinterpret_cast<const float *>(tbd + s * rowb + vo1);
             }
         }
     };
@@ -688,6 +697,19 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
             if (x0 + i < P.xhi) o[i] = acc[i];
         if (sink == 1.2345e38f) o[0] = sink;     // keeps the sink (and with it whole-quad reads) alive
     }
+#ifdef KQ_STAMP
+    // diagnostic build (build/stamp_run.py): workgroup residency timeline, us per step per chunk
+    if (tid == 0 && P.stamps) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *o = P.stamps + (size_t)blockIdx.x * 4;
+        o[0] = t_start;
+        o[1] = __builtin_amdgcn_s_memrealtime();
+        o[2] = ((unsigned long long)xcc << 32) | hwid;
+        o[3] = ((unsigned long long)chunk << 32) | (unsigned)nsteps;
+    }
+#endif
 }
 
 // ===========================================================================
@@ -713,6 +735,7 @@ struct impdar_kirch_plan {
     bool free_recorded[2] = {false, false};
     DevBuf d_hmax, d_klo, d_khi;
     DevBuf d_TK[2], d_TW[2], d_TW2[2], d_A, d_wcf, d_wc2f;
+    DevBuf d_stamps;               // diagnostic builds only
     int nb = 0, ntab = 0;
     bool quad = false;          // sample-major LDS ring (kirch_quad_kernel)
     int quadW = 0;              // samples per ring slot in that layout
@@ -1148,6 +1171,13 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         P.wcf = p->d_wcf.as<float>();
         P.wc2f = p->d_wc2f.as<float>();
         P.alpha = (float)p->alpha;
+        P.stamps = nullptr;
+#ifdef KQ_STAMP
+        if (p->d_stamps.ensure((size_t)1 << 22) == hipSuccess) {
+            (void)hipMemsetAsync(p->d_stamps.p, 0, (size_t)1 << 22, st);
+            P.stamps = p->d_stamps.as<unsigned long long>();
+        }
+#endif
         int rc;
         const char *oe0 = getenv("IMPDAR_KIRCH_OCC");      // tuning knob: min waves per SIMD to compile for
         const int occ0 = oe0 ? atoi(oe0) : 0;
@@ -1246,6 +1276,17 @@ extern "C" int impdar_kirch_last_ms(impdar_kirch_plan *p, float *prep_ms, float 
 {
     return impdar_kirch_history_ms(p, 0, prep_ms, gather_ms, migrate_ms);
 }
+
+#ifdef KQ_STAMP
+extern "C" int impdar_kirch_debug_stamps(impdar_kirch_plan *p, unsigned long long *host, size_t bytes)
+{
+    if (!p || !p->d_stamps.p) return IMPDAR_ERR_ARG;
+    IMPDAR_HIP_CHECK(hipSetDevice(p->ctx->device));
+    IMPDAR_HIP_CHECK(hipDeviceSynchronize());
+    IMPDAR_HIP_CHECK(hipMemcpy(host, p->d_stamps.p, bytes, hipMemcpyDeviceToHost));
+    return IMPDAR_OK;
+}
+#endif
 
 extern "C" long long impdar_kirch_count_pairs(const impdar_kirch_plan *p, int xlo, int xhi)
 {
