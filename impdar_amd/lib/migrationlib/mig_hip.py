@@ -80,7 +80,8 @@ def migrationKirchhoff(dat, vel=1.69e8, nearfield=False, mode=None):
 
     ``mode`` (extension): None/'auto' picks the fp32 LDS-ring kernel for
     float32 data on uniform grids and the fp64 reference-order kernel
-    otherwise; 'exact' / 'fast' force one ($IMPDAR_KIRCH_MODE overrides None).
+    otherwise; 'exact' / 'fast' force one ($IMPDAR_KIRCH_MODE overrides None);
+    'fast' on float64 or integer data converts it to float32 first.
     Output is float64 like the reference.
     """
     print('Kirchhoff Migration (diffraction summation) of %.0fx%.0f matrix' % (dat.snum, dat.tnum))
@@ -93,7 +94,11 @@ def migrationKirchhoff(dat, vel=1.69e8, nearfield=False, mode=None):
         raise ValueError('mode must be one of auto, exact, fast')
     lib = _hip.load()
     ctx = _hip.context()
-    data, code = _device_data(dat.data)
+    src = np.asarray(dat.data)
+    if mode == 'fast' and src.dtype != np.float32:
+        # explicit opt-in to the float32 kernel for float64 / integer data
+        src = src.astype(np.float32)
+    data, code = _device_data(src)
     tt_sec = np.ascontiguousarray(dat.travel_time / 1.0e6, dtype=np.float64)
     uniform, h, ga, gb, gc = gradient_coefficients(tt_sec)
     dist = np.ascontiguousarray(dat.dist, dtype=np.float64) * 1.0e3
