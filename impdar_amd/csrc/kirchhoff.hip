@@ -5,7 +5,7 @@
 //   src/impdar/lib/migrationlib/mig_python.py:63-123  migrationKirchhoff
 //   src/impdar/lib/migrationlib/mig_cython.h:11       mig_kirch_loop (native hook)
 //
-// Three kernels:
+// Kernels:
 //   kirch_prep_kernel   time gradient (numpy.gradient semantics, :93) fused
 //                       with the (snum,tnum) -> trace-major (tnum,snum)
 //                       transpose, so one input trace is one contiguous run.
