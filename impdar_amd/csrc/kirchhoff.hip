@@ -831,10 +831,11 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     const double sa = 2.0 * dx / (vel * dt);       // samples of moveout per trace at far offset
     p->alpha = sa * sa;
     // fast kernels need the moveout 2dx/(v dt) (samples per trace) small enough for their
-    // LDS windows: quad (sample-major ring, 24 traces x 8-step blocks, 16-bit row offsets)
+    // LDS windows: quad (sample-major ring, 24 traces x 8-step blocks, up to ~6.7 samples/trace)
     // or, for steeper moveout, tab (trace-major ring of 16 traces, 512-sample slots)
     const int wq = ((KF_THREADS + (int)std::ceil(sa * (24 + 8 - 2)) + 8 + 3) / 4) * 4;
-    const bool quad_ok = (size_t)wq * KQ_STRIDE * 4 <= 65536;
+    // (two workgroups per CU: 80 KB of LDS each; row offsets in float4 units fit 16 bits easily)
+    const bool quad_ok = (size_t)wq * KQ_STRIDE * 4 <= 80 * 1024 && (size_t)wq * (KQ_STRIDE / 4) < 65535;
     const bool tab_ok = (KF_THREADS + sa * (16 - 1) + 8.0) <= (double)KF_W;
     const bool window_ok = quad_ok || tab_ok;
     const bool fast_ok = dtype == IMPDAR_F32 && p->uniform && window_ok && snum < 65536;

@@ -154,10 +154,10 @@ def test_ragged_sizes_vs_oracle(hip, snum, tnum):
     assert mode == 'fast' and rel_l2(out, want) < FAST_L2
 
 
-@pytest.mark.parametrize('dx,expect', [(0.05, 'quad'), (1.0, 'quad'), (2.5, 'quad'), (5.0, 'tab'), (12.0, 'tab')])
+@pytest.mark.parametrize('dx,expect', [(0.05, 'quad'), (1.0, 'quad'), (2.5, 'quad'), (5.0, 'quad'), (8.0, 'tab'), (12.0, 'tab')])
 def test_fast_kernel_families_by_moveout(hip, dx, expect, monkeypatch):
     """Moveout 2dx/(v dt) decides which LDS-ring kernel the fast mode uses (sample-major b128
-    'quad' ring up to ~3.6 samples per trace, trace-major b32 'tab' ring up to ~16); both must
+    'quad' ring up to ~6.7 samples per trace, trace-major b32 'tab' ring up to ~16); both must
     match the C oracle.  IMPDAR_KIRCH_IMPL=tab also forces the tab kernel at small moveout."""
     from impdar_amd import synth
     from impdar_amd.kirchhoff import migrate_resident
