@@ -41,14 +41,18 @@ struct PrepParams {
     double grad_h;
     const double *ga, *gb, *gc;
     int clean;              // map non-finite values to 0 (fast kernel contract)
+    int i8;                 // image layout: 0 trace-major [row][k]; 1 groups of 8 rows, sample-major
+                            // inside a group: element (row, k) at ((row >> 3) * snum + k) * 8 + (row & 7)
 };
 
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void kirch_prep_kernel(PrepParams P)
 {
-    // tiles in the image's element type: 2 x 16.6 KB for float32 (9 workgroups per CU)
-    __shared__ TO tg[64][65];
-    __shared__ TO td[64][65];
+    // tiles in the image's element type: 2 x 18 KB for float32.  Row stride 65 for the trace-major
+    // store (lanes walk a tile column), 72 for the grouped store (a half wave reads 4 rows x 8 columns)
+    __shared__ TO tg[64 * 72];
+    __shared__ TO td[64 * 72];
+    const int ld = P.i8 ? 72 : 65;
     const TI *f = reinterpret_cast<const TI *>(P.data);
     const int k0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -82,18 +86,34 @@ __global__ __launch_bounds__(256) void kirch_prep_kernel(PrepParams P)
                 if (!(fabs(d) <= 1.79e308)) d = 0.0;
             }
         }
-        tg[r][tx] = (TO)g;
-        td[r][tx] = (TO)d;
+        tg[r * ld + tx] = (TO)g;
+        td[r * ld + tx] = (TO)d;
     }
     __syncthreads();
     TO *GT = reinterpret_cast<TO *>(P.GT);
     TO *DT = reinterpret_cast<TO *>(P.DT);
+    if (P.i8) {
+        // a wave stores 8 samples x 8 rows = 256 contiguous bytes per instruction
+        const int kk = tx >> 3, jj = tx & 7;
+        for (int g8 = 2 * ty; g8 < 2 * ty + 2; ++g8)
+            for (int kb = 0; kb < 8; ++kb) {
+                const int r = kb * 8 + kk, c = g8 * 8 + jj;
+                const int j = j0 + c, k = k0 + r;
+                if (j < P.nloc && k < n) {
+                    const int row = P.jlo + j;
+                    const size_t o = ((size_t)(row >> 3) * n + k) * 8 + (row & 7);
+                    GT[o] = tg[r * ld + c];
+                    if (DT) DT[o] = td[r * ld + c];
+                }
+            }
+        return;
+    }
     for (int r = ty; r < 64; r += 4) {
         const int j = j0 + r, k = k0 + tx;
         if (j < P.nloc && k < n) {
             const size_t o = (size_t)(P.jlo + j) * n + k;
-            GT[o] = tg[tx][r];
-            if (DT) DT[o] = td[tx][r];
+            GT[o] = tg[tx * ld + r];
+            if (DT) DT[o] = td[tx * ld + r];
         }
     }
 }
@@ -166,8 +186,11 @@ struct FastParams {
     // pick/weight table: entry (|n|, ti)
     const unsigned short *TK;      // offset of the picked sample's row inside a ring slot    [ntab][snum]
     const float *TW, *TW2;         // far / near weights (0 where the reference drops the pair); tab kernel only
-    const float *A, *wcf, *wc2f;   // quad kernel: (tt/dt)^2, cos-weight prefactors per sample [snum]
-    float alpha;                   // (2 dx / (v dt))^2
+    // quad kernel: cos(theta) = sign(a) * rsq(1 + c1 n^2) with a = tt/dt, c1 = alpha / a^2; the far-field sum is
+    // scaled by fin = sign(a) / (2 pi v) once at the end, the near-field weight is c2 * cos^3 in those units
+    const float *c1, *c2, *fin;    // per sample [snum]
+    const float *N2;               // float((i - n2off)^2): the n^2 of a step block is one scalar load
+    int n2off;
     unsigned long long *stamps;    // diagnostic builds only (-DKQ_STAMP): per-workgroup {start, end, hw id, chunk|steps}
     int ntab;                      // rows; the last row is all zero (|n| beyond every aperture)
 };
@@ -408,8 +431,9 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_tab_kernel(FastParams P
 #define KQ_RING 40
 #define KQ_STRIDE 44
 #define KQ_RP KQ_STRIDE
+typedef float kq_f4 __attribute__((ext_vector_type(4)));
 
-template <int XB, bool NEAR, int OCC>
+template <int XB, bool NEAR, int OCC, int SH>
 __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams P, int W)
 {
     constexpr int S = 8;
@@ -419,8 +443,8 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     constexpr int NQ = RG / 4;                // slot quads
     static_assert(XB + 2 * S - 1 <= RG && RG % S == 0 && XB % 4 == 0, "ring too small");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *ldsG = lds;
-    float *ldsD = lds + W * ST;
+    float *ldsG = lds;                        // W ring rows + one all-zero row (picked by dropped pairs)
+    float *ldsD = lds + (W + 1) * ST;
 
     const int b = blockIdx.x;
     const int xcd = b & 7, r = b >> 3;
@@ -451,7 +475,12 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     const int hmax = P.hmax[chunk];
     const int *klo = P.klo + (size_t)chunk * P.nb;
     const int *khi = P.khi + (size_t)chunk * P.nb;
-    const int nlo = max(-hmax, -(x0 + XB - 1));
+    // first offset: the 8 traces a step block adds must be one aligned 8-row group of the image
+    // (ring-relative trace q0 = 8 blk + XB - 1  ->  x0 + nlo = 1 mod 8); the up to 7 extra leading
+    // steps lie outside every aperture of the chunk and pick the all-zero row
+    int nlo_ = max(-hmax, -(x0 + XB - 1));
+    nlo_ -= (x0 + nlo_ - 1) & 7;
+    const int nlo = nlo_;
     const int nhi = min(hmax, tnum - 1 - x0);
     const int nsteps = nhi - nlo + 1;
     const int nblocks = (nsteps + S - 1) / S;
@@ -473,54 +502,50 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
         kmin = klo[min(lo, P.nb - 1)];
         kmax = min(khi[min(hi, P.nb - 1)], kmin + W - 1);
     };
-    // traces outside the profile are zero rows of the padded image: no range checks
-    auto trace_ptr = [&](const float *img, int q) { return img + (ptrdiff_t)(jbase + q) * snum; };
+    // The image is stored in groups of 8 traces, sample-major inside a group (see PrepParams::i8):
+    // sample k of the 8 traces of a step block is 32 contiguous bytes.  Raw buffers based at this
+    // workgroup's first group: scalar group offset + per-lane sample offset, no address arithmetic
+    // in vector registers; traces outside the profile are zero rows of the padded image.
+    const unsigned grp_bytes = (unsigned)snum * 32u;
+    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.GT) + (ptrdiff_t)(jbase - 1) * snum, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(NEAR ? P.DT : P.GT) + (ptrdiff_t)(jbase - 1) * snum, 0, 0x7fffffff, 0x00020000);
     auto tab_row = [&](int step) { return (unsigned)(min(abs(nlo + step), ntab1) * snum); };
     const unsigned tioff = (unsigned)ti * 2u;
-    auto pick = [&](int step) {
-        return *reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(P.TK + tab_row(step)) + tioff);
+    // table entry = LDS offset of the picked sample's ring row (bytes >> SH); pairs the reference drops
+    // (t > t_max, or the 0/0 apex of a t = 0 sample) point at the all-zero row, so they need no
+    // compare/select.  `off` is the lane's byte offset into a table row (kept out of the loop-invariant
+    // pointer so the load uses the scalar-base + 32-bit lane-offset form).
+    const __amdgpu_buffer_rsrc_t tkres =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(P.TK), 0, 0x7fffffff, 0x00020000);
+    auto pick = [&](int step, unsigned off) -> unsigned {
+        return __builtin_amdgcn_raw_buffer_load_b16(tkres, off, tab_row(step) * 2u, 0);     // zero-extended
     };
-    // obliquity weights from the per-sample constants; the table's 0xFFFF marks the pairs
-    // the reference drops (t > t_max, or the 0/0 apex of a t = 0 sample)
-    const float Aq = P.A[ti], wcf = P.wcf[ti], wc2f = NEAR ? P.wc2f[ti] : 0.f;
-    const float alpha = P.alpha;
+    const float c1 = P.c1[ti], c2 = NEAR ? P.c2[ti] : 0.f, fin = P.fin[ti];
+    const float *N2 = P.N2 + (P.n2off + nlo);
 
-    for (int e = tid; e < W * ST * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
+    for (int e = tid; e < (W + 1) * ST * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
     __syncthreads();
-    // ring position of ring-relative trace q is (q + 1) % RG, which makes the 8
-    // traces every later block adds two aligned slot quads
-    for (int q = 0; q < XB + S - 1; ++q) {
-        int kmin, kmax;
-        window(q, q, kmin, kmax);
-        const float *sg = trace_ptr(P.GT, q);
-        const float *sd = NEAR ? trace_ptr(P.DT, q) : nullptr;
-        const int pos = (q + 1) % RG;
-        for (int e = kmin + tid; e <= kmax; e += KF_THREADS) {
-            ldsG[(e % W) * ST + pos] = sg[e];
-            if (NEAR) ldsD[(e % W) * ST + pos] = sd[e];
-        }
-    }
     // pick row of the steps of the current block
-    unsigned short tkc[S];
+    unsigned tkc[S];
 #pragma unroll
-    for (int s = 0; s < S; ++s) tkc[s] = pick(s);
-    __syncthreads();
+    for (int s = 0; s < S; ++s) tkc[s] = pick(s, tioff);
 
     float acc[XB];
-    float sink = 0.f;                            // absorbs the unused components of edge quads
 #pragma unroll
     for (int i = 0; i < XB; ++i) acc[i] = 0.f;
 
-    // Staging registers of one block's 8 incoming traces (2 samples per thread each).  Loads are
-    // issued TWO blocks ahead of use: the set filled during block b is published at the end of
-    // block b+1, so the global-load latency has a full block of LDS/FMA work in front of it.
+    // Staging registers of one block's 8 incoming traces (2 samples per thread each, 8 traces = two
+    // 16-byte loads).  Loads are issued TWO blocks ahead of use: the set filled during block b is
+    // published at the end of block b+1, so the load latency has a full block of LDS/FMA work in front of it.
     struct Stage {
-        float g0[S], g1[S], d0[NEAR ? S : 1], d1[NEAR ? S : 1];
+        kq_f4 g0[2], g1[2], d0[NEAR ? 2 : 1], d1[NEAR ? 2 : 1];
         int m0, m1;
         bool wr1;
     };
     auto issue = [&](int blk_for, Stage &st) {       // traces that block `blk_for` adds to the ring
-        const int q0 = blk_for * S + XB - 1;
+        const int q0 = blk_for * S + XB - 1;         // jbase + q0 = 0 mod 8
         int kmin, kmax;
         window(q0, q0 + S - 1, kmin, kmax);
         const int e1 = kmin + tid + KF_THREADS;
@@ -533,43 +558,53 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
         m1 -= (m1 >= W) ? W : 0;
         st.m0 = m0;
         st.m1 = m1;
-        const unsigned vo0 = (unsigned)c0 * 4u, vo1 = (unsigned)c1 * 4u;
-        const char *tb = reinterpret_cast<const char *>(trace_ptr(P.GT, q0));
-        const char *tbd = NEAR ? reinterpret_cast<const char *>(trace_ptr(P.DT, q0)) : nullptr;
-        const size_t rowb = (size_t)snum * 4;
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            st.g0[s] = *reinterpret_cast<const float *>(tb + s * rowb + vo0);
-            if (NEAR) st.d0[s] = *reinterpret_cast<const float *>(tbd + s * rowb + vo0);
+        const unsigned so = (unsigned)(blk_for + 3) * grp_bytes;      // group of trace jbase + q0
+        const unsigned vo0 = (unsigned)c0 * 32u, vo1 = (unsigned)c1 * 32u;
+        st.g0[0] = __builtin_amdgcn_raw_buffer_load_b128(gres, vo0, so, 0);
+        st.g0[1] = __builtin_amdgcn_raw_buffer_load_b128(gres, vo0 + 16u, so, 0);
+        if (NEAR) {
+            st.d0[0] = __builtin_amdgcn_raw_buffer_load_b128(dres, vo0, so, 0);
+            st.d0[1] = __builtin_amdgcn_raw_buffer_load_b128(dres, vo0 + 16u, so, 0);
         }
         // the window is ~300 samples: only the first ~44 lanes of the workgroup have a second
         // sample, so three of the four waves skip these loads altogether
         if (st.wr1) {
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                st.g1[s] = *reinterpret_cast<const float *>(tb + s * rowb + vo1);
-                if (NEAR) st.d1[s] = *reinterpret_cast<const float *>(tbd + s * rowb + vo1);
+            st.g1[0] = __builtin_amdgcn_raw_buffer_load_b128(gres, vo1, so, 0);
+            st.g1[1] = __builtin_amdgcn_raw_buffer_load_b128(gres, vo1 + 16u, so, 0);
+            if (NEAR) {
+                st.d1[0] = __builtin_amdgcn_raw_buffer_load_b128(dres, vo1, so, 0);
+                st.d1[1] = __builtin_amdgcn_raw_buffer_load_b128(dres, vo1 + 16u, so, 0);
             }
         }
     };
     auto publish = [&](int pos0, const Stage &st) {  // two aligned slot quads per sample
-        float *r0 = &ldsG[st.m0 * ST + pos0], *r1 = &ldsG[st.m1 * ST + pos0];
-        reinterpret_cast<float4 *>(r0)[0] = make_float4(st.g0[0], st.g0[1], st.g0[2], st.g0[3]);
-        reinterpret_cast<float4 *>(r0)[1] = make_float4(st.g0[4], st.g0[5], st.g0[6], st.g0[7]);
+        kq_f4 *r0 = reinterpret_cast<kq_f4 *>(&ldsG[st.m0 * ST + pos0]);
+        r0[0] = st.g0[0];
+        r0[1] = st.g0[1];
         if (st.wr1) {
-            reinterpret_cast<float4 *>(r1)[0] = make_float4(st.g1[0], st.g1[1], st.g1[2], st.g1[3]);
-            reinterpret_cast<float4 *>(r1)[1] = make_float4(st.g1[4], st.g1[5], st.g1[6], st.g1[7]);
+            kq_f4 *r1 = reinterpret_cast<kq_f4 *>(&ldsG[st.m1 * ST + pos0]);
+            r1[0] = st.g1[0];
+            r1[1] = st.g1[1];
         }
         if (NEAR) {
-            float *t0 = &ldsD[st.m0 * ST + pos0], *t1 = &ldsD[st.m1 * ST + pos0];
-            reinterpret_cast<float4 *>(t0)[0] = make_float4(st.d0[0], st.d0[1], st.d0[2], st.d0[3]);
-            reinterpret_cast<float4 *>(t0)[1] = make_float4(st.d0[4], st.d0[5], st.d0[6], st.d0[7]);
+            kq_f4 *t0 = reinterpret_cast<kq_f4 *>(&ldsD[st.m0 * ST + pos0]);
+            t0[0] = st.d0[0];
+            t0[1] = st.d0[1];
             if (st.wr1) {
-                reinterpret_cast<float4 *>(t1)[0] = make_float4(st.d1[0], st.d1[1], st.d1[2], st.d1[3]);
-                reinterpret_cast<float4 *>(t1)[1] = make_float4(st.d1[4], st.d1[5], st.d1[6], st.d1[7]);
+                kq_f4 *t1 = reinterpret_cast<kq_f4 *>(&ldsD[st.m1 * ST + pos0]);
+                t1[0] = st.d1[0];
+                t1[1] = st.d1[1];
             }
         }
     };
+    // ring position of ring-relative trace q is (q + 1) % RG, which makes the 8 traces every block
+    // adds two aligned slot quads; the ring starts with the four groups q = -1 .. 30
+    for (int pb = -3; pb <= 0; ++pb) {
+        Stage st;
+        issue(pb, st);
+        publish((pb * S + XB + RG) % RG, st);
+    }
+    __syncthreads();
     Stage stA, stB;                                // stA: filled during even blocks, stB: odd
     issue(1, stB);                                 // block 1's traces, published at the end of block 0
 
@@ -580,23 +615,21 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
             const int blk = rev * NB + bb2;
             // ---- loads: next block's table entries first (they are waited for first), then the
             // traces of the block after next
-            unsigned short tkn[S];
+            unsigned tkn[S];
 #pragma unroll
-            for (int s = 0; s < S; ++s) tkn[s] = pick((blk + 1) * S + s);
+            for (int s = 0; s < S; ++s) tkn[s] = pick((blk + 1) * S + s, tioff);
             if ((bb2 & 1) == 0)
                 issue(blk + 2, stA);
             else
                 issue(blk + 2, stB);
-            // weights of this block's steps
+            // obliquity cos(theta) of this block's steps (n^2 arrives in scalar registers)
             float twc[S], tw2c[NEAR ? S : 1];
-            const float n0f = (float)(nlo + blk * S);
+            const float *n2 = N2 + blk * S;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                const float nf = n0f + (float)s;
-                const float y = __builtin_amdgcn_rsqf(fmaf(nf, alpha * nf, Aq));
-                const bool keep = tkc[s] != 0xFFFFu;
-                twc[s] = keep ? wcf * y : 0.f;
-                if (NEAR) tw2c[s] = keep ? (wc2f * y) * (y * y) : 0.f;
+                const float y = __builtin_amdgcn_rsqf(fmaf(c1, n2[s], 1.0f));
+                twc[s] = y;
+                if (NEAR) tw2c[s] = (y * c2) * (y * y);
             }
             // ---- S steps on the resident ring, software pipelined: the reads of step s+1 are
             // in flight while the FMAs of step s run (two statically indexed quad buffers)
@@ -608,15 +641,14 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
             };
             auto load_step = [&](int s, float4 (&v)[NQ], float4 (&u)[NEAR ? NQ : 1]) {
                 const int pm = bb * S + s;                       // step index mod RG (compile time)
-                const unsigned kq = tkc[s] == 0xFFFFu ? 0u : tkc[s];
-                const float4 *base = reinterpret_cast<const float4 *>(ldsG) + kq;       // row of sample k
-                const float4 *based = reinterpret_cast<const float4 *>(ldsD) + kq;
+                const unsigned kq = tkc[s] << SH;
+                const float4 *base = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(ldsG) + kq);
+                const float4 *based = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(ldsD) + kq);
 #pragma unroll
                 for (int qd = 0; qd < NQ; ++qd)
                     if (needed(pm, qd)) {
                         // must stay a whole ds_read_b128 also for the partly used quads at the ends of
-                        // the window (narrowed to b32 pieces they bank-conflict 4-way): fma_step feeds
-                        // the unused components to a sink accumulator so the compiler cannot narrow it
+                        // the window: fma_step marks the unused components as used (empty asm)
                         v[qd] = base[qd];
                         if (NEAR) u[qd] = based[qd];
                     }
@@ -634,20 +666,22 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
                     const int i3 = (4 * qd + 3 - pm - 1 + 2 * RG) % RG;
                     const bool any = i0 < XB || i1 < XB || i2 < XB || i3 < XB;
                     if (any) {
-                        float &a0 = i0 < XB ? acc[i0 < XB ? i0 : 0] : sink;
-                        float &a1 = i1 < XB ? acc[i1 < XB ? i1 : 0] : sink;
-                        float &a2 = i2 < XB ? acc[i2 < XB ? i2 : 0] : sink;
-                        float &a3 = i3 < XB ? acc[i3 < XB ? i3 : 0] : sink;
-                        a0 = fmaf(w, v[qd].x, a0);
-                        a1 = fmaf(w, v[qd].y, a1);
-                        a2 = fmaf(w, v[qd].z, a2);
-                        a3 = fmaf(w, v[qd].w, a3);
-                        if (NEAR) {
-                            a0 = fmaf(w2, u[qd].x, a0);
-                            a1 = fmaf(w2, u[qd].y, a1);
-                            a2 = fmaf(w2, u[qd].z, a2);
-                            a3 = fmaf(w2, u[qd].w, a3);
-                        }
+                        // components of an edge quad that serve no output are handed to an empty asm: the
+                        // load stays a whole ds_read_b128 (split into b32 pieces it bank-conflicts 4-way)
+                        // at no instruction cost
+#define KQ_COMP(ix, c)                                                          \
+    if (ix < XB) {                                                              \
+        acc[ix < XB ? ix : 0] = fmaf(w, v[qd].c, acc[ix < XB ? ix : 0]);        \
+        if (NEAR) acc[ix < XB ? ix : 0] = fmaf(w2, u[qd].c, acc[ix < XB ? ix : 0]); \
+    } else {                                                                    \
+        asm volatile("" ::"v"(v[qd].c));                                        \
+        if (NEAR) asm volatile("" ::"v"(u[qd].c));                              \
+    }
+                        KQ_COMP(i0, x)
+                        KQ_COMP(i1, y)
+                        KQ_COMP(i2, z)
+                        KQ_COMP(i3, w)
+#undef KQ_COMP
                     }
                 }
             };
@@ -662,7 +696,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
                           "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]),         \
                           "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]),    \
                           "+v"(acc[15]), "+v"(acc[16]), "+v"(acc[17]), "+v"(acc[18]), "+v"(acc[19]),    \
-                          "+v"(acc[20]), "+v"(acc[21]), "+v"(acc[22]), "+v"(acc[23]), "+v"(sink)        \
+                          "+v"(acc[20]), "+v"(acc[21]), "+v"(acc[22]), "+v"(acc[23])                    \
                      :: "memory");                                                                       \
     } while (0)
             load_step(0, va, ua);
@@ -694,8 +728,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
         float *o = P.out + (size_t)ti_raw * P.ldo + (x0 - P.xlo);
 #pragma unroll
         for (int i = 0; i < XB; ++i)
-            if (x0 + i < P.xhi) o[i] = acc[i];
-        if (sink == 1.2345e38f) o[0] = sink;     // keeps the sink (and with it whole-quad reads) alive
+            if (x0 + i < P.xhi) o[i] = acc[i] * fin;
     }
 #ifdef KQ_STAMP
     // diagnostic build (build/stamp_run.py): workgroup residency timeline, us per step per chunk
@@ -734,7 +767,9 @@ struct impdar_kirch_plan {
     hipEvent_t ev_free[2] = {nullptr, nullptr};    // last migrate reading buffer b done (compute stream)
     bool free_recorded[2] = {false, false};
     DevBuf d_hmax, d_klo, d_khi;
-    DevBuf d_TK[2], d_TW[2], d_TW2[2], d_A, d_wcf, d_wc2f;
+    DevBuf d_TK[2], d_TW[2], d_TW2[2], d_c1, d_c2, d_fin, d_N2;
+    int n2off = 0;
+    int quadSH = 0;             // table entries are LDS byte offsets >> quadSH
     DevBuf d_stamps;               // diagnostic builds only
     int nb = 0, ntab = 0;
     bool quad = false;          // sample-major LDS ring (kirch_quad_kernel)
@@ -793,7 +828,8 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     p->snum = snum;
     p->tnum = tnum;
     p->nranks = nranks;
-    p->tnum_pad = ((tnum + nranks - 1) / nranks) * nranks;
+    // equal input shards of whole 8-row groups (the grouped image layout keeps a shard contiguous)
+    p->tnum_pad = ((tnum + 8 * nranks - 1) / (8 * nranks)) * 8 * nranks;
     p->nearfield = nearfield ? 1 : 0;
     p->grad_uniform = grad_uniform;
     p->grad_h = grad_h;
@@ -834,8 +870,9 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     // LDS windows: quad (sample-major ring, 24 traces x 8-step blocks, up to ~6.7 samples/trace)
     // or, for steeper moveout, tab (trace-major ring of 16 traces, 512-sample slots)
     const int wq = ((KF_THREADS + (int)std::ceil(sa * (24 + 8 - 2)) + 8 + 3) / 4) * 4;
-    // (two workgroups per CU: 80 KB of LDS each; row offsets in float4 units fit 16 bits easily)
-    const bool quad_ok = (size_t)wq * KQ_STRIDE * 4 <= 80 * 1024 && (size_t)wq * (KQ_STRIDE / 4) < 65535;
+    // (two workgroups per CU: 80 KB of LDS each, ring rows + the all-zero row; row offsets fit 16 bits as
+    // bytes up to 371 rows, in float4 units beyond)
+    const bool quad_ok = (size_t)(wq + 1) * KQ_STRIDE * 4 <= 80 * 1024;
     const bool tab_ok = (KF_THREADS + sa * (16 - 1) + 8.0) <= (double)KF_W;
     const bool window_ok = quad_ok || tab_ok;
     const bool fast_ok = dtype == IMPDAR_F32 && p->uniform && window_ok && snum < 65536;
@@ -852,6 +889,7 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     {
         const char *ie = getenv("IMPDAR_KIRCH_IMPL");       // tuning knob: "tab" forces the b32 ring
         p->quadW = wq;
+        p->quadSH = ((size_t)(wq + 1) * KQ_STRIDE * 4 <= 65535) ? 0 : 4;
         p->quad = (mode == IMPDAR_KIRCH_FAST) && quad_ok && !(ie && !strcmp(ie, "tab") && tab_ok);
         p->xb = p->quad ? 24 : 16;
     }
@@ -903,16 +941,25 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         p->nchunks = nch;
         std::vector<int> hmax(nch, 0);
         {
-            std::vector<float> A(snum), wcf(snum), wc2f(snum);
+            // with a = tt/dt (samples) and rs = half * sqrt(a^2 + alpha n^2):
+            //   cos(theta)        = a / sqrt(a^2 + alpha n^2) = sign(a) * rsq(1 + c1 n^2),  c1 = alpha / a^2
+            //   far-field weight  = cos / (2 pi v)            = fin * |cos|,                 fin = sign(a) / (2 pi v)
+            //   near-field weight = cos / (2 pi rs^2)         = fin * c2 * |cos|^3,          c2 = v / (half a)^2
+            // a = 0 (a sample at t = 0): cos = 0 for every n != 0 and the apex is 0/0 (dropped) -> fin = 0
+            std::vector<float> c1(snum), c2(snum), fin(snum);
             const double half = vel * dt / 2.0;         // metres per sample of two-way time
             for (int k = 0; k < snum; ++k) {
                 const double a = tt_sec[k] / dt;
-                A[k] = (float)(a * a);
-                wcf[k] = (float)(a / (2.0 * M_PI * vel));             // cos(theta)/vel/(2 pi) = wcf / u
-                wc2f[k] = (float)(a / (2.0 * M_PI * half * half));    // cos(theta)/rs^2/(2 pi) = wc2f / u^3
+                if (a == 0.0) {
+                    c1[k] = c2[k] = fin[k] = 0.f;
+                    continue;
+                }
+                c1[k] = (float)std::min(p->alpha / (a * a), 1e30);
+                c2[k] = (float)std::min(vel / (half * half * a * a), 1e30);
+                fin[k] = (float)((a > 0 ? 1.0 : -1.0) / (2.0 * M_PI * vel));
             }
-            if ((rc = upload(p->d_A, A.data(), snum * 4)) || (rc = upload(p->d_wcf, wcf.data(), snum * 4)) ||
-                (rc = upload(p->d_wc2f, wc2f.data(), snum * 4)))
+            if ((rc = upload(p->d_c1, c1.data(), snum * 4)) || (rc = upload(p->d_c2, c2.data(), snum * 4)) ||
+                (rc = upload(p->d_fin, fin.data(), snum * 4)))
                 return fail(rc);
         }
         int hglob = 0;
@@ -935,9 +982,23 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         // rows), so the tables need not extend past tnum even when the aperture does
         hglob = std::min(hglob, tnum + 128);
         for (int c = 0; c < nch; ++c) hmax[c] = std::min(hmax[c], hglob);
+        {
+            // n^2 as float for offsets n = i - n2off; a step block reads its 8 entries with one scalar load
+            p->n2off = hglob + 16;
+            std::vector<float> n2((size_t)2 * hglob + 512);
+            for (size_t i = 0; i < n2.size(); ++i) {
+                const double n = (double)i - p->n2off;
+                n2[i] = (float)(n * n);
+            }
+            if ((rc = upload(p->d_N2, n2.data(), n2.size() * 4))) return fail(rc);
+        }
         const int nb = hglob + 64;
         p->nb = nb;
         p->ntab = hglob + 1;       // offsets 0..hglob-1 (hmax carries a guard) + one all-zero row
+        if ((size_t)p->ntab * snum * 2 >= ((size_t)1 << 31)) {      // the kernels address it as one raw buffer
+            impdar_set_error("fast Kirchhoff pick table of %d x %d entries exceeds 2 GiB; use the exact mode", p->ntab, snum);
+            return fail(IMPDAR_ERR_UNSUPPORTED);
+        }
         {
             const size_t ent = (size_t)p->ntab * snum;
             bool ok = true;
@@ -1033,6 +1094,7 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
         P.gb = p->d_gb.as<double>();
         P.gc = p->d_gc.as<double>();
         P.clean = (p->mode == IMPDAR_KIRCH_FAST);
+        P.i8 = p->quad ? 1 : 0;
         dim3 grid((nloc + 63) / 64, (p->snum + 63) / 64);
         if (p->dtype == IMPDAR_F32)
             hipLaunchKernelGGL((kirch_prep_kernel<float, float>), grid, dim3(256), 0, st, P);
@@ -1058,8 +1120,8 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
         T.ntab = p->ntab;
         T.near = p->nearfield;
         T.wmod = p->quad ? p->quadW : KF_W;
-        T.kscale = p->quad ? KQ_STRIDE / 4 : 4;  // quad layout: offset in float4 units
-        T.sentinel = p->quad ? 0xFFFF : 0;
+        T.kscale = p->quad ? (KQ_STRIDE * 4) >> p->quadSH : 4;  // quad layout: row offset in bytes >> quadSH
+        T.sentinel = p->quad ? (unsigned short)((p->quadW * KQ_STRIDE * 4) >> p->quadSH) : 0;   // the all-zero row
         T.write_w = p->quad ? 0 : 1;
         hipLaunchKernelGGL(kirch_table_kernel, dim3((p->snum + 255) / 256, p->ntab), dim3(256), 0, st, T);
         IMPDAR_HIP_CHECK(hipGetLastError());
@@ -1080,7 +1142,7 @@ int impdar_kirch_prep_precomputed(impdar_kirch_plan *p, const void *d_grad, int 
     return kirch_prep_impl(p, d_grad, ld, jlo, nloc, 1);
 }
 
-template <int XB, int OCC>
+template <int XB, int OCC, int SH>
 static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipStream_t st)
 {
     FastParams P = P0;
@@ -1096,13 +1158,13 @@ static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipSt
     P.tiles_per_xcd = nxt_pad / 8;
     const int nblk = P.nchunks * nxt_pad;
     const int W = p->quadW;
-    const size_t shmem = (size_t)W * KQ_STRIDE * 4 * (p->nearfield ? 2 : 1);
+    const size_t shmem = (size_t)(W + 1) * KQ_STRIDE * 4 * (p->nearfield ? 2 : 1);
     if (p->nearfield) {
-        auto k = kirch_quad_kernel<XB, true, 1>;
+        auto k = kirch_quad_kernel<XB, true, 1, SH>;
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(k, dim3(nblk), dim3(KF_THREADS), shmem, st, P, W);
     } else {
-        auto k = kirch_quad_kernel<XB, false, OCC>;
+        auto k = kirch_quad_kernel<XB, false, OCC, SH>;
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(k, dim3(nblk), dim3(KF_THREADS), shmem, st, P, W);
     }
@@ -1168,10 +1230,11 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         P.TW = p->d_TW[b].as<float>();
         P.TW2 = p->d_TW2[b].as<float>();
         P.ntab = p->ntab;
-        P.A = p->d_A.as<float>();
-        P.wcf = p->d_wcf.as<float>();
-        P.wc2f = p->d_wc2f.as<float>();
-        P.alpha = (float)p->alpha;
+        P.c1 = p->d_c1.as<float>();
+        P.c2 = p->d_c2.as<float>();
+        P.fin = p->d_fin.as<float>();
+        P.N2 = p->d_N2.as<float>();
+        P.n2off = p->n2off;
         P.stamps = nullptr;
 #ifdef KQ_STAMP
         if (p->d_stamps.ensure((size_t)1 << 22) == hipSuccess) {
@@ -1182,8 +1245,10 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         int rc;
         const char *oe0 = getenv("IMPDAR_KIRCH_OCC");      // tuning knob: min waves per SIMD to compile for
         const int occ0 = oe0 ? atoi(oe0) : 0;
-        if (p->quad)
-            rc = (occ0 == 2) ? launch_quad<24, 2>(p, P, nx, st) : launch_quad<24, 3>(p, P, nx, st);
+        if (p->quad && p->quadSH == 0)
+            rc = (occ0 == 2) ? launch_quad<24, 2, 0>(p, P, nx, st) : launch_quad<24, 3, 0>(p, P, nx, st);
+        else if (p->quad)
+            rc = launch_quad<24, 2, 4>(p, P, nx, st);      // steep moveout: ring > 371 rows, two workgroups per CU
         else
             rc = launch_tab<16, 4, 4>(p, P, nx, st);
         if (rc) return rc;

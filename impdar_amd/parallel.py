@@ -60,9 +60,12 @@ def balanced_blocks(weights, nranks):
 
 
 def input_shards(tnum, nranks):
-    """Equal-width input blocks (the all-gather needs equal counts); the last
-    ranks' blocks may be short or empty.  Returns (tnum_pad, [(jlo, jhi), ...])."""
-    per = (tnum + nranks - 1) // nranks
+    """Equal-width input blocks (the all-gather needs equal counts) of whole
+    8-trace groups (the device image keeps 8 traces interleaved, so a block of
+    whole groups is one contiguous run); the last ranks' blocks may be short or
+    empty.  Returns (tnum_pad, [(jlo, jhi), ...]).  Same rule as
+    ``impdar_kirch_plan_create`` (checked by the tests)."""
+    per = ((tnum + 8 * nranks - 1) // (8 * nranks)) * 8
     shards = [(min(r * per, tnum), min((r + 1) * per, tnum)) for r in range(nranks)]
     return per * nranks, shards
 

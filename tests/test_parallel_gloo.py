@@ -35,7 +35,7 @@ def test_partition_properties():
         assert w[xi] == int((hi - lo + 1).sum())
     for n in (1, 2, 4, 8):
         tnum_pad, shards, blocks, pairs = parallel.plan_blocks(tt, 1.0, 1.69e8, 10000, n)
-        assert tnum_pad % n == 0 and tnum_pad >= 10000
+        assert tnum_pad % (8 * n) == 0 and 10000 <= tnum_pad < 10000 + 8 * n     # whole 8-trace groups per shard
         assert blocks[0][0] == 0 and blocks[-1][1] == 10000
         assert all(blocks[i][1] == blocks[i + 1][0] for i in range(n - 1))
         assert shards[0][0] == 0 and shards[-1][1] == 10000
@@ -43,5 +43,5 @@ def test_partition_properties():
         assert max(pairs) / (sum(pairs) / n) < 1.002        # balanced by pair count
     # ragged: more ranks than traces
     tnum_pad, shards, blocks, pairs = parallel.plan_blocks(np.arange(8) * 1e-8, 1.0, 1.69e8, 3, 4)
-    assert tnum_pad == 4 and sum(b[1] - b[0] for b in blocks) == 3
+    assert tnum_pad == 32 and sum(b[1] - b[0] for b in blocks) == 3
     assert sum(s[1] - s[0] for s in shards) == 3
