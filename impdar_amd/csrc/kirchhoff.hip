@@ -493,14 +493,17 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     const int jbase = x0 + nlo;
     const int ntab1 = P.ntab - 1;
 
-    // samples [kmin,kmax] that ring-relative traces q0..q1 can be asked for
-    auto window = [&](int q0, int q1, int &kmin, int &kmax) {
+    // samples [kmin,kmax] that ring-relative traces q0..q1 can be asked for: two table lookups
+    // (klo entry = kmin | (kmin mod W) << 16).  The lookups of a block's staging are issued ONE BLOCK
+    // EARLIER than their use: s_waitcnt vmcnt counts in order, so waiting for a lookup issued in the
+    // same block would also wait for the pick loads just in front of it (a full miss latency per block).
+    auto window_fetch = [&](int q0, int q1, int &a, int &b) {
         const int pmin = max(0, q0 - (XB - 1)), pmax = min(q1, nsteps_pad - 1);
         const int na = nlo + pmin, nb = nlo + pmax;
         const int lo = (na <= 0 && nb >= 0) ? 0 : min(abs(na), abs(nb));
         const int hi = max(abs(na), abs(nb));
-        kmin = klo[min(lo, P.nb - 1)];
-        kmax = min(khi[min(hi, P.nb - 1)], kmin + W - 1);
+        a = klo[min(lo, P.nb - 1)];
+        b = khi[min(hi, P.nb - 1)];
     };
     // The image is stored in groups of 8 traces, sample-major inside a group (see PrepParams::i8):
     // sample k of the 8 traces of a step block is 32 contiguous bytes.  Raw buffers based at this
@@ -544,14 +547,17 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
         int m0, m1;
         bool wr1;
     };
-    auto issue = [&](int blk_for, Stage &st) {       // traces that block `blk_for` adds to the ring
+    auto fetch_for = [&](int blk_for, int &a, int &b) {
         const int q0 = blk_for * S + XB - 1;         // jbase + q0 = 0 mod 8
-        int kmin, kmax;
-        window(q0, q0 + S - 1, kmin, kmax);
+        window_fetch(q0, q0 + S - 1, a, b);
+    };
+    auto issue = [&](int blk_for, Stage &st, int wa, int wb) {   // traces that block `blk_for` adds to the ring
+        const int kmin = wa & 0xffff, kmod = (int)((unsigned)wa >> 16);
+        const int kmax = min(wb, kmin + W - 1);
         const int e1 = kmin + tid + KF_THREADS;
         st.wr1 = e1 <= kmax;
         const int c0 = min(kmin + tid, snum - 1), c1 = min(e1, snum - 1);
-        int m0 = (kmin % W) + tid;
+        int m0 = kmod + tid;
         m0 -= (m0 >= W) ? W : 0;
         int m1 = m0 + KF_THREADS;
         m1 -= (m1 >= W) ? W : 0;
@@ -599,96 +605,82 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     };
     // ring position of ring-relative trace q is (q + 1) % RG, which makes the 8 traces every block
     // adds two aligned slot quads; the ring starts with the four groups q = -1 .. 30
+    int wa, wb;
     for (int pb = -3; pb <= 0; ++pb) {
         Stage st;
-        issue(pb, st);
+        fetch_for(pb, wa, wb);
+        issue(pb, st, wa, wb);
         publish((pb * S + XB + RG) % RG, st);
     }
     __syncthreads();
     Stage stA, stB;                                // stA: filled during even blocks, stB: odd
-    issue(1, stB);                                 // block 1's traces, published at the end of block 0
+    fetch_for(1, wa, wb);
+    issue(1, stB, wa, wb);                         // block 1's traces, published during block 0
+    fetch_for(2, wa, wb);                          // used by block 0's issue
 
-    for (int rev = 0; rev < nrev; rev += 2) {
-#pragma clang loop unroll(full)
-        for (int bb2 = 0; bb2 < 2 * NB; ++bb2) {
-            const int bb = bb2 % NB;                   // block index within the ring revolution
-            const int blk = rev * NB + bb2;
-            // ---- loads: next block's table entries first (they are waited for first), then the
-            // traces of the block after next
-            unsigned tkn[S];
+    // ---- the resident ring is read software pipelined: the ds_read_b128 of step s+1 are in flight
+    // while the FMAs of step s run (two statically indexed quad buffers), also across block ends
+    float4 va[NQ], vb[NQ], ua[NEAR ? NQ : 1], ub[NEAR ? NQ : 1];
+    auto needed = [](int pm, int qd) {
+        bool any = false;
+        for (int c = 0; c < 4; ++c) any = any || ((4 * qd + c - pm - 1 + 2 * RG) % RG) < XB;
+        return any;
+    };
+    // pm = step index mod RG (a compile-time constant after unrolling), tk = the step's table entry
+    auto load_step = [&](int pm, unsigned tk, float4 (&v)[NQ], float4 (&u)[NEAR ? NQ : 1]) {
+        const unsigned kq = tk << SH;
+        const float4 *base = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(ldsG) + kq);
+        const float4 *based = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(ldsD) + kq);
 #pragma unroll
-            for (int s = 0; s < S; ++s) tkn[s] = pick((blk + 1) * S + s, tioff);
-            if ((bb2 & 1) == 0)
-                issue(blk + 2, stA);
-            else
-                issue(blk + 2, stB);
-            // obliquity cos(theta) of this block's steps (n^2 arrives in scalar registers)
-            float twc[S], tw2c[NEAR ? S : 1];
-            const float *n2 = N2 + blk * S;
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const float y = __builtin_amdgcn_rsqf(fmaf(c1, n2[s], 1.0f));
-                twc[s] = y;
-                if (NEAR) tw2c[s] = (y * c2) * (y * y);
+        for (int qd = 0; qd < NQ; ++qd)
+            if (needed(pm, qd)) {
+                // must stay a whole ds_read_b128 also for the partly used quads at the ends of
+                // the window: fma_step marks the unused components as used (empty asm)
+#ifdef KQ_DIAG_NOLDS        // diagnostic build: no LDS reads (VALU-only time of the loop)
+                asm volatile("" : "=v"(v[qd].x), "=v"(v[qd].y), "=v"(v[qd].z), "=v"(v[qd].w) : "v"(base));
+#else
+                v[qd] = base[qd];
+#endif
+                if (NEAR) u[qd] = based[qd];
             }
-            // ---- S steps on the resident ring, software pipelined: the reads of step s+1 are
-            // in flight while the FMAs of step s run (two statically indexed quad buffers)
-            float4 va[NQ], vb[NQ], ua[NEAR ? NQ : 1], ub[NEAR ? NQ : 1];
-            auto needed = [](int pm, int qd) {
-                bool any = false;
-                for (int c = 0; c < 4; ++c) any = any || ((4 * qd + c - pm - 1 + 2 * RG) % RG) < XB;
-                return any;
-            };
-            auto load_step = [&](int s, float4 (&v)[NQ], float4 (&u)[NEAR ? NQ : 1]) {
-                const int pm = bb * S + s;                       // step index mod RG (compile time)
-                const unsigned kq = tkc[s] << SH;
-                const float4 *base = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(ldsG) + kq);
-                const float4 *based = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(ldsD) + kq);
+    };
+    auto fma_step = [&](int pm, float w, float w2, const float4 (&v)[NQ], const float4 (&u)[NEAR ? NQ : 1]) {
 #pragma unroll
-                for (int qd = 0; qd < NQ; ++qd)
-                    if (needed(pm, qd)) {
-                        // must stay a whole ds_read_b128 also for the partly used quads at the ends of
-                        // the window: fma_step marks the unused components as used (empty asm)
-                        v[qd] = base[qd];
-                        if (NEAR) u[qd] = based[qd];
-                    }
-            };
-            auto fma_step = [&](int s, const float4 (&v)[NQ], const float4 (&u)[NEAR ? NQ : 1]) {
-                const int pm = bb * S + s;
-                const float w = twc[s];
-                const float w2 = NEAR ? tw2c[s] : 0.f;
-#pragma unroll
-                for (int qd = 0; qd < NQ; ++qd) {
-                    // outputs served by slots 4qd .. 4qd+3 at this step
-                    const int i0 = (4 * qd + 0 - pm - 1 + 2 * RG) % RG;
-                    const int i1 = (4 * qd + 1 - pm - 1 + 2 * RG) % RG;
-                    const int i2 = (4 * qd + 2 - pm - 1 + 2 * RG) % RG;
-                    const int i3 = (4 * qd + 3 - pm - 1 + 2 * RG) % RG;
-                    const bool any = i0 < XB || i1 < XB || i2 < XB || i3 < XB;
-                    if (any) {
-                        // components of an edge quad that serve no output are handed to an empty asm: the
-                        // load stays a whole ds_read_b128 (split into b32 pieces it bank-conflicts 4-way)
-                        // at no instruction cost
-#define KQ_COMP(ix, c)                                                          \
-    if (ix < XB) {                                                              \
-        acc[ix < XB ? ix : 0] = fmaf(w, v[qd].c, acc[ix < XB ? ix : 0]);        \
+        for (int qd = 0; qd < NQ; ++qd) {
+            // outputs served by slots 4qd .. 4qd+3 at this step
+            const int i0 = (4 * qd + 0 - pm - 1 + 2 * RG) % RG;
+            const int i1 = (4 * qd + 1 - pm - 1 + 2 * RG) % RG;
+            const int i2 = (4 * qd + 2 - pm - 1 + 2 * RG) % RG;
+            const int i3 = (4 * qd + 3 - pm - 1 + 2 * RG) % RG;
+            const bool any = i0 < XB || i1 < XB || i2 < XB || i3 < XB;
+            if (any) {
+                // components of an edge quad that serve no output are handed to an empty asm: the
+                // load stays a whole ds_read_b128 (split into b32 pieces it bank-conflicts 4-way)
+                // at no instruction cost
+#ifdef KQ_DIAG_NOFMA        // diagnostic build: reads only (LDS-only time of the loop)
+#define KQ_COMP(ix, c) asm volatile("" ::"v"(v[qd].c));
+#else
+#define KQ_COMP(ix, c)                                                              \
+    if (ix < XB) {                                                                  \
+        acc[ix < XB ? ix : 0] = fmaf(w, v[qd].c, acc[ix < XB ? ix : 0]);            \
         if (NEAR) acc[ix < XB ? ix : 0] = fmaf(w2, u[qd].c, acc[ix < XB ? ix : 0]); \
-    } else {                                                                    \
-        asm volatile("" ::"v"(v[qd].c));                                        \
-        if (NEAR) asm volatile("" ::"v"(u[qd].c));                              \
+    } else {                                                                        \
+        asm volatile("" ::"v"(v[qd].c));                                            \
+        if (NEAR) asm volatile("" ::"v"(u[qd].c));                                  \
     }
-                        KQ_COMP(i0, x)
-                        KQ_COMP(i1, y)
-                        KQ_COMP(i2, z)
-                        KQ_COMP(i3, w)
+#endif
+                KQ_COMP(i0, x)
+                KQ_COMP(i1, y)
+                KQ_COMP(i2, z)
+                KQ_COMP(i3, w)
 #undef KQ_COMP
-                    }
-                }
-            };
-            // The FMAs carry no chain, so instruction selection is free to sink a whole block's
-            // FMAs below all of its LDS reads (which then spill).  Passing the accumulators
-            // through an empty volatile asm after every step pins the order
-            // reads(s+1) -> FMAs(s) without consuming any load result early.
+            }
+        }
+    };
+    // The FMAs carry no chain, so instruction selection is free to sink a whole block's
+    // FMAs below all of its LDS reads (which then spill).  Passing the accumulators
+    // through an empty volatile asm (with a memory clobber) after every group of reads and every
+    // step's FMAs pins the order reads(s+1) -> FMAs(s) without consuming any load result early.
 #define KQ_PIN()                                                                                         \
     do {                                                                                                 \
         static_assert(XB == 24, "KQ_PIN lists 24 accumulators");                                         \
@@ -699,18 +691,46 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
                           "+v"(acc[20]), "+v"(acc[21]), "+v"(acc[22]), "+v"(acc[23])                    \
                      :: "memory");                                                                       \
     } while (0)
-            load_step(0, va, ua);
-            KQ_PIN();
-            load_step(1, vb, ub); fma_step(0, va, ua); KQ_PIN();
-            load_step(2, va, ua); fma_step(1, vb, ub); KQ_PIN();
-            load_step(3, vb, ub); fma_step(2, va, ua); KQ_PIN();
-            load_step(4, va, ua); fma_step(3, vb, ub); KQ_PIN();
-            load_step(5, vb, ub); fma_step(4, va, ua); KQ_PIN();
-            load_step(6, va, ua); fma_step(5, vb, ub); KQ_PIN();
-            load_step(7, vb, ub); fma_step(6, va, ua); KQ_PIN();
-            fma_step(7, vb, ub);
-            KQ_PIN();
-            // ---- publish the next block's 8 traces (loaded during the previous block)
+
+    load_step(0, tkc[0], va, ua);                  // step 0 of block 0
+    for (int rev = 0; rev < nrev; rev += 2) {
+#pragma clang loop unroll(full)
+        for (int bb2 = 0; bb2 < 2 * NB; ++bb2) {
+            const int bb = bb2 % NB;                   // block index within the ring revolution
+            const int blk = rev * NB + bb2;
+            const int pm0 = bb * S;                    // step index mod RG of the block's first step
+            // ---- loads: next block's table entries first (they are waited for first), then the
+            // traces of the block after next
+            unsigned tkn[S];
+#pragma unroll
+#ifdef KQ_DIAG_NOPICK
+            for (int s = 0; s < S; ++s) tkn[s] = tkc[s];
+#else
+            for (int s = 0; s < S; ++s) tkn[s] = pick((blk + 1) * S + s, tioff);
+#endif
+#ifndef KQ_DIAG_NOSTAGE
+            if ((bb2 & 1) == 0)
+                issue(blk + 2, stA, wa, wb);
+            else
+                issue(blk + 2, stB, wa, wb);
+            fetch_for(blk + 3, wa, wb);                // the next block's staging window
+#endif
+            // obliquity cos(theta) of this block's steps
+            float twc[S], tw2c[NEAR ? S : 1];
+            const float *n2 = N2 + blk * S;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float y = __builtin_amdgcn_rsqf(fmaf(c1, n2[s], 1.0f));
+                twc[s] = y;
+                if (NEAR) tw2c[s] = (y * c2) * (y * y);
+            }
+#define KQ_W2(s) (NEAR ? tw2c[NEAR ? (s) : 0] : 0.f)
+            load_step(pm0 + 1, tkc[1], vb, ub); KQ_PIN(); fma_step(pm0 + 0, twc[0], KQ_W2(0), va, ua); KQ_PIN();
+            load_step(pm0 + 2, tkc[2], va, ua); KQ_PIN(); fma_step(pm0 + 1, twc[1], KQ_W2(1), vb, ub); KQ_PIN();
+            // ---- publish the next block's 8 traces (loaded during the previous block).  Their ring
+            // slots held traces last read at step 6 of the previous block, and every wave is past that
+            // block's barrier, which sits after step 6: no wave can still be reading them.
+#ifndef KQ_DIAG_NOSTAGE
             {
                 const int pos0 = ((bb + 1) * S + XB) % RG;        // ring position of its first trace, multiple of 8
                 if ((bb2 & 1) == 0)
@@ -718,11 +738,27 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
                 else
                     publish(pos0, stA);
             }
+#endif
+            load_step(pm0 + 3, tkc[3], vb, ub); KQ_PIN(); fma_step(pm0 + 2, twc[2], KQ_W2(2), va, ua); KQ_PIN();
+            load_step(pm0 + 4, tkc[4], va, ua); KQ_PIN(); fma_step(pm0 + 3, twc[3], KQ_W2(3), vb, ub); KQ_PIN();
+            load_step(pm0 + 5, tkc[5], vb, ub); KQ_PIN(); fma_step(pm0 + 4, twc[4], KQ_W2(4), va, ua); KQ_PIN();
+            load_step(pm0 + 6, tkc[6], va, ua); KQ_PIN(); fma_step(pm0 + 5, twc[5], KQ_W2(5), vb, ub); KQ_PIN();
+            load_step(pm0 + 7, tkc[7], vb, ub); KQ_PIN(); fma_step(pm0 + 6, twc[6], KQ_W2(6), va, ua); KQ_PIN();
+            // ---- barrier after step 6.  The published traces are first read by step 0 of the next
+            // block, whose reads are issued below.  This wave's publish stores are already complete:
+            // LDS operations finish in order and the FMAs above waited for younger reads.  The reads
+            // of step 7 stay in flight across the barrier, so the read pipeline never drains.
+#ifndef KQ_DIAG_NOBAR
+            asm volatile("s_barrier" ::: "memory");
+#endif
+            load_step((pm0 + 8) % RG, tkn[0], va, ua); KQ_PIN(); fma_step(pm0 + 7, twc[7], KQ_W2(7), vb, ub); KQ_PIN();
+#undef KQ_W2
 #pragma unroll
             for (int s = 0; s < S; ++s) tkc[s] = tkn[s];
-            __syncthreads();
         }
     }
+#undef KQ_PIN
+    asm volatile("" ::"v"(va[0].x), "v"(va[NQ - 1].w));   // the look-ahead reads of the step after the last
 
     if (ti_raw < snum) {
         float *o = P.out + (size_t)ti_raw * P.ldo + (x0 - P.xlo);
@@ -1020,7 +1056,9 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
             for (int n = 0; n < nb; ++n) {
                 const double bn = p->alpha * (double)n * (double)n;
                 const double ulo = std::sqrt(cmin[c] + bn) - u0, uhi = std::sqrt(cmax[c] + bn) - u0;
-                klo[(size_t)c * nb + n] = std::max(0, (int)std::floor(ulo) - 1);
+                const int kmin = std::max(0, (int)std::floor(ulo) - 1);
+                // quad kernel: ring row of kmin in the upper half (saves a division by the runtime W)
+                klo[(size_t)c * nb + n] = p->quad ? (kmin | ((kmin % p->quadW) << 16)) : kmin;
                 khi[(size_t)c * nb + n] = std::min(snum - 1, (int)std::ceil(uhi) + 1);
             }
         if ((rc = upload(p->d_hmax, hmax.data(), nch * 4)) || (rc = upload(p->d_klo, klo.data(), klo.size() * 4)) ||
