@@ -566,6 +566,10 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
         st.m1 = m1;
         const unsigned so = (unsigned)(blk_for + 3) * grp_bytes;      // group of trace jbase + q0
         const unsigned vo0 = (unsigned)c0 * 32u, vo1 = (unsigned)c1 * 32u;
+#ifdef KQ_DIAG_NOISSUE      // diagnostic: publish register contents, no global loads
+        asm volatile("" : "=v"(st.g0[0]), "=v"(st.g0[1]), "=v"(st.g1[0]), "=v"(st.g1[1]) : "v"(vo0), "v"(vo1), "s"(so));
+        return;
+#endif
         st.g0[0] = __builtin_amdgcn_raw_buffer_load_b128(gres, vo0, so, 0);
         st.g0[1] = __builtin_amdgcn_raw_buffer_load_b128(gres, vo0 + 16u, so, 0);
         if (NEAR) {
@@ -584,6 +588,11 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
         }
     };
     auto publish = [&](int pos0, const Stage &st) {  // two aligned slot quads per sample
+#ifdef KQ_DIAG_NOPUB        // diagnostic: wait for the staged data but do not write it to LDS
+        asm volatile("" ::"v"(st.g0[0]), "v"(st.g0[1]), "v"(st.m0));
+        if (st.wr1) asm volatile("" ::"v"(st.g1[0]), "v"(st.g1[1]), "v"(st.m1));
+        return;
+#endif
         kq_f4 *r0 = reinterpret_cast<kq_f4 *>(&ldsG[st.m0 * ST + pos0]);
         r0[0] = st.g0[0];
         r0[1] = st.g0[1];
@@ -692,6 +701,9 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
                      :: "memory");                                                                       \
     } while (0)
 
+    float n2c[S];                                  // n^2 of the current block's steps
+#pragma unroll
+    for (int s = 0; s < S; ++s) n2c[s] = N2[s];
     load_step(0, tkc[0], va, ua);                  // step 0 of block 0
     for (int rev = 0; rev < nrev; rev += 2) {
 #pragma clang loop unroll(full)
@@ -708,21 +720,27 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
 #else
             for (int s = 0; s < S; ++s) tkn[s] = pick((blk + 1) * S + s, tioff);
 #endif
-#ifndef KQ_DIAG_NOSTAGE
+#if !defined(KQ_DIAG_NOSTAGE)
             if ((bb2 & 1) == 0)
                 issue(blk + 2, stA, wa, wb);
             else
                 issue(blk + 2, stB, wa, wb);
             fetch_for(blk + 3, wa, wb);                // the next block's staging window
 #endif
-            // obliquity cos(theta) of this block's steps
+            // obliquity cos(theta) of this block's steps; the n^2 were loaded during the previous block
+            // (vmcnt waits are in order: a value loaded and used in the same block would drain the
+            // pick and staging loads in front of it)
             float twc[S], tw2c[NEAR ? S : 1];
-            const float *n2 = N2 + blk * S;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                const float y = __builtin_amdgcn_rsqf(fmaf(c1, n2[s], 1.0f));
+                const float y = __builtin_amdgcn_rsqf(fmaf(c1, n2c[s], 1.0f));
                 twc[s] = y;
                 if (NEAR) tw2c[s] = (y * c2) * (y * y);
+            }
+            {
+                const float *n2 = N2 + (blk + 1) * S;
+#pragma unroll
+                for (int s = 0; s < S; ++s) n2c[s] = n2[s];
             }
 #define KQ_W2(s) (NEAR ? tw2c[NEAR ? (s) : 0] : 0.f)
             load_step(pm0 + 1, tkc[1], vb, ub); KQ_PIN(); fma_step(pm0 + 0, twc[0], KQ_W2(0), va, ua); KQ_PIN();
@@ -730,7 +748,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
             // ---- publish the next block's 8 traces (loaded during the previous block).  Their ring
             // slots held traces last read at step 6 of the previous block, and every wave is past that
             // block's barrier, which sits after step 6: no wave can still be reading them.
-#ifndef KQ_DIAG_NOSTAGE
+#if !defined(KQ_DIAG_NOSTAGE)
             {
                 const int pos0 = ((bb + 1) * S + XB) % RG;        // ring position of its first trace, multiple of 8
                 if ((bb2 & 1) == 0)
