@@ -189,8 +189,14 @@ struct FastParams {
     // quad kernel: cos(theta) = sign(a) * rsq(1 + c1 n^2) with a = tt/dt, c1 = alpha / a^2; the far-field sum is
     // scaled by fin = sign(a) / (2 pi v) once at the end, the near-field weight is c2 * cos^3 in those units
     const float *c1, *c2, *fin;    // per sample [snum]
-    const float *N2;               // float((i - n2off)^2): the n^2 of a step block is one scalar load
-    int n2off;
+    // quad kernel, step-block tables.  Every workgroup walks the trace offset n in blocks of 8 steps
+    // n = 8 m + 1 .. 8 m + 8 (tiles start at multiples of 8, so the alignment is the same for all);
+    // table row = m + mrow0:
+    const void *TKB;               // [nrows][snum] x 8 picks of 16 bits: one 16-byte load per lane per block
+    const int2 *WIN;               // [nchunks][nrows] staging window of the 8 traces a block adds:
+                                   //   x = kmin | (kmin mod W) << 16, y = kmax
+    const float *N2;               // [nrows][8] float(n^2)
+    int nrows, mrow0;
     unsigned long long *stamps;    // diagnostic builds only (-DKQ_STAMP): per-workgroup {start, end, hw id, chunk|steps}
     int ntab;                      // rows; the last row is all zero (|n| beyond every aperture)
 };
@@ -248,6 +254,51 @@ __global__ __launch_bounds__(256) void kirch_table_kernel(TableParams P)
         P.TW[o] = w;
         if (P.near) P.TW2[o] = w2;
     }
+}
+
+// Same picks for the quad kernel, laid out by step block: row r holds, per sample, the 8 picks of the
+// offsets n = 8 (r - mrow0) + 1 + s, s = 0..7 (|n| decides the pick; blocks left of the apex are stored
+// mirrored, so the kernel never computes |n|).  One thread per (row, sample), one 16-byte store.
+struct TableQParams {
+    uint4 *TKB;
+    const double *zs, *zs2, *tt;
+    double dx, vel, tmax, inv_dt, tt0;
+    int snum, nrows, mrow0, nmax;   // offsets |n| >= nmax are outside every aperture
+    int wmod, kscale;
+    unsigned sentinel;
+};
+
+__global__ __launch_bounds__(256) void kirch_tableq_kernel(TableQParams P)
+{
+    const int ti = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (ti >= P.snum) return;
+    unsigned pk[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int n = abs(8 * (r - P.mrow0) + 1 + s);
+        unsigned kb = P.sentinel;
+        if (n < P.nmax) {
+            const double dx = (double)n * P.dx;
+            const double q = dx * dx + P.zs2[ti];
+            const double rs = sqrt(q);
+            const double cost = P.zs[ti] / rs;
+            const double t = 2.0 * rs / P.vel;
+            if (!(t > P.tmax) && cost == cost) {
+                const int ns = P.snum;
+                int k0 = (int)floor((t - P.tt0) * P.inv_dt);
+                k0 = min(max(k0, 0), ns - 1);
+                while (k0 < ns - 1 && P.tt[k0 + 1] <= t) ++k0;
+                while (k0 > 0 && P.tt[k0] > t) --k0;
+                const int k1 = min(k0 + 1, ns - 1);
+                const int k = (fabs(P.tt[k1] - t) < fabs(P.tt[k0] - t)) ? k1 : k0;
+                kb = (unsigned)((k % P.wmod) * P.kscale);
+            }
+        }
+        pk[s] = kb;
+    }
+    P.TKB[(size_t)r * P.snum + ti] =
+        make_uint4(pk[0] | (pk[1] << 16), pk[2] | (pk[3] << 16), pk[4] | (pk[5] << 16), pk[6] | (pk[7] << 16));
 }
 
 // ---------------------------------------------------------------------------
@@ -432,6 +483,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_tab_kernel(FastParams P
 #define KQ_STRIDE 44
 #define KQ_RP KQ_STRIDE
 typedef float kq_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned kq_u4 __attribute__((ext_vector_type(4)));
 
 template <int XB, bool NEAR, int OCC, int SH>
 __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams P, int W)
@@ -458,7 +510,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
 
     const int tid = threadIdx.x;
     const int s0 = chunk * KF_THREADS;
-    const int x0 = P.xlo + xt * XB;
+    const int x0 = (P.xlo & ~7) + xt * XB;       // tiles start at a multiple of 8 (outputs left of xlo are not stored)
     const int snum = P.snum, tnum = P.tnum;
     // ds_read_b128 is serviced in four groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31},
     // {32-35,44-47,52-59}, {36-43,48-51,60-63}).  Give every group 16 CONSECUTIVE samples: their
@@ -473,13 +525,11 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     const int ti = min(ti_raw, snum - 1);
 
     const int hmax = P.hmax[chunk];
-    const int *klo = P.klo + (size_t)chunk * P.nb;
-    const int *khi = P.khi + (size_t)chunk * P.nb;
     // first offset: the 8 traces a step block adds must be one aligned 8-row group of the image
-    // (ring-relative trace q0 = 8 blk + XB - 1  ->  x0 + nlo = 1 mod 8); the up to 7 extra leading
-    // steps lie outside every aperture of the chunk and pick the all-zero row
+    // (ring-relative trace q0 = 8 blk + XB - 1  ->  x0 + nlo = 1 mod 8, i.e. nlo = 1 mod 8); the up to
+    // 7 extra leading steps lie outside every aperture of the chunk and pick the all-zero row
     int nlo_ = max(-hmax, -(x0 + XB - 1));
-    nlo_ -= (x0 + nlo_ - 1) & 7;
+    nlo_ -= (nlo_ - 1) & 7;
     const int nlo = nlo_;
     const int nhi = min(hmax, tnum - 1 - x0);
     const int nsteps = nhi - nlo + 1;
@@ -489,21 +539,20 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     // (two revolutions are unrolled so that block parity, which selects the staging register
     // set, is a compile-time constant)
     const int nrev = 2 * ((nblocks + 2 * NB - 1) / (2 * NB));
-    const int nsteps_pad = nrev * NB * S;
     const int jbase = x0 + nlo;
-    const int ntab1 = P.ntab - 1;
+    // table row of block 0 (block b covers n = nlo + 8 b .. + 7); rows past the tables' end (only the
+    // padding blocks of the last revolution can get there) are clamped to the last, all-dropped row
+    const int mrow = ((nlo - 1) >> 3) + P.mrow0;
+    auto row_of = [&](int blk) { return min(mrow + blk, P.nrows - 1); };
 
-    // samples [kmin,kmax] that ring-relative traces q0..q1 can be asked for: two table lookups
-    // (klo entry = kmin | (kmin mod W) << 16).  The lookups of a block's staging are issued ONE BLOCK
-    // EARLIER than their use: s_waitcnt vmcnt counts in order, so waiting for a lookup issued in the
-    // same block would also wait for the pick loads just in front of it (a full miss latency per block).
-    auto window_fetch = [&](int q0, int q1, int &a, int &b) {
-        const int pmin = max(0, q0 - (XB - 1)), pmax = min(q1, nsteps_pad - 1);
-        const int na = nlo + pmin, nb = nlo + pmax;
-        const int lo = (na <= 0 && nb >= 0) ? 0 : min(abs(na), abs(nb));
-        const int hi = max(abs(na), abs(nb));
-        a = klo[min(lo, P.nb - 1)];
-        b = khi[min(hi, P.nb - 1)];
+    // Staging window of the 8 traces block `blk_for` adds: one 8-byte lookup, issued ONE BLOCK EARLIER
+    // than its use: s_waitcnt vmcnt counts in order, so waiting for a lookup issued in the same block
+    // would also wait for the pick loads just in front of it (a full miss latency per block).
+    const int2 *WIN = P.WIN + (size_t)chunk * P.nrows;
+    auto fetch_for = [&](int blk_for, int &a, int &b) {
+        const int2 w = WIN[max(row_of(blk_for), 0)];
+        a = w.x;
+        b = w.y;
     };
     // The image is stored in groups of 8 traces, sample-major inside a group (see PrepParams::i8):
     // sample k of the 8 traces of a step block is 32 contiguous bytes.  Raw buffers based at this
@@ -514,26 +563,24 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
         const_cast<float *>(P.GT) + (ptrdiff_t)(jbase - 1) * snum, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(NEAR ? P.DT : P.GT) + (ptrdiff_t)(jbase - 1) * snum, 0, 0x7fffffff, 0x00020000);
-    auto tab_row = [&](int step) { return (unsigned)(min(abs(nlo + step), ntab1) * snum); };
-    const unsigned tioff = (unsigned)ti * 2u;
-    // table entry = LDS offset of the picked sample's ring row (bytes >> SH); pairs the reference drops
-    // (t > t_max, or the 0/0 apex of a t = 0 sample) point at the all-zero row, so they need no
-    // compare/select.  `off` is the lane's byte offset into a table row (kept out of the loop-invariant
-    // pointer so the load uses the scalar-base + 32-bit lane-offset form).
+    // Pick table entry = LDS offset of the picked sample's ring row (bytes >> SH); pairs the reference
+    // drops (t > t_max, or the 0/0 apex of a t = 0 sample) point at the all-zero row, so they need no
+    // compare/select.  The 8 picks of a step block are 16 contiguous bytes per lane: one raw-buffer load
+    // (scalar row offset + lane offset) per block.
     const __amdgpu_buffer_rsrc_t tkres =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(P.TK), 0, 0x7fffffff, 0x00020000);
-    auto pick = [&](int step, unsigned off) -> unsigned {
-        return __builtin_amdgcn_raw_buffer_load_b16(tkres, off, tab_row(step) * 2u, 0);     // zero-extended
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(P.TKB), 0, 0x7fffffff, 0x00020000);
+    const unsigned tioff = (unsigned)ti * 16u;
+    const unsigned rowbytes = (unsigned)snum * 16u;
+    auto picks = [&](int blk) -> kq_u4 {
+        return __builtin_amdgcn_raw_buffer_load_b128(tkres, tioff, (unsigned)row_of(blk) * rowbytes, 0);
     };
+#define KQ_TK(q, s) (((q)[(s) >> 1] >> (16 * ((s) & 1))) & 0xffffu)
     const float c1 = P.c1[ti], c2 = NEAR ? P.c2[ti] : 0.f, fin = P.fin[ti];
-    const float *N2 = P.N2 + (P.n2off + nlo);
+    auto n2_of = [&](int blk) { return P.N2 + (size_t)row_of(blk) * 8; };
 
     for (int e = tid; e < (W + 1) * ST * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
     __syncthreads();
-    // pick row of the steps of the current block
-    unsigned tkc[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) tkc[s] = pick(s, tioff);
+    kq_u4 tkc = picks(0);                          // picks of the current block
 
     float acc[XB];
 #pragma unroll
@@ -546,10 +593,6 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
         kq_f4 g0[2], g1[2], d0[NEAR ? 2 : 1], d1[NEAR ? 2 : 1];
         int m0, m1;
         bool wr1;
-    };
-    auto fetch_for = [&](int blk_for, int &a, int &b) {
-        const int q0 = blk_for * S + XB - 1;         // jbase + q0 = 0 mod 8
-        window_fetch(q0, q0 + S - 1, a, b);
     };
     auto issue = [&](int blk_for, Stage &st, int wa, int wb) {   // traces that block `blk_for` adds to the ring
         const int kmin = wa & 0xffff, kmod = (int)((unsigned)wa >> 16);
@@ -702,9 +745,12 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     } while (0)
 
     float n2c[S];                                  // n^2 of the current block's steps
+    {
+        const float *n2 = n2_of(0);
 #pragma unroll
-    for (int s = 0; s < S; ++s) n2c[s] = N2[s];
-    load_step(0, tkc[0], va, ua);                  // step 0 of block 0
+        for (int s = 0; s < S; ++s) n2c[s] = n2[s];
+    }
+    load_step(0, KQ_TK(tkc, 0), va, ua);           // step 0 of block 0
     for (int rev = 0; rev < nrev; rev += 2) {
 #pragma clang loop unroll(full)
         for (int bb2 = 0; bb2 < 2 * NB; ++bb2) {
@@ -713,12 +759,10 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
             const int pm0 = bb * S;                    // step index mod RG of the block's first step
             // ---- loads: next block's table entries first (they are waited for first), then the
             // traces of the block after next
-            unsigned tkn[S];
-#pragma unroll
 #ifdef KQ_DIAG_NOPICK
-            for (int s = 0; s < S; ++s) tkn[s] = tkc[s];
+            const kq_u4 tkn = tkc;
 #else
-            for (int s = 0; s < S; ++s) tkn[s] = pick((blk + 1) * S + s, tioff);
+            const kq_u4 tkn = picks(blk + 1);
 #endif
 #if !defined(KQ_DIAG_NOSTAGE)
             if ((bb2 & 1) == 0)
@@ -738,13 +782,13 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
                 if (NEAR) tw2c[s] = (y * c2) * (y * y);
             }
             {
-                const float *n2 = N2 + (blk + 1) * S;
+                const float *n2 = n2_of(blk + 1);
 #pragma unroll
                 for (int s = 0; s < S; ++s) n2c[s] = n2[s];
             }
 #define KQ_W2(s) (NEAR ? tw2c[NEAR ? (s) : 0] : 0.f)
-            load_step(pm0 + 1, tkc[1], vb, ub); KQ_PIN(); fma_step(pm0 + 0, twc[0], KQ_W2(0), va, ua); KQ_PIN();
-            load_step(pm0 + 2, tkc[2], va, ua); KQ_PIN(); fma_step(pm0 + 1, twc[1], KQ_W2(1), vb, ub); KQ_PIN();
+            load_step(pm0 + 1, KQ_TK(tkc, 1), vb, ub); KQ_PIN(); fma_step(pm0 + 0, twc[0], KQ_W2(0), va, ua); KQ_PIN();
+            load_step(pm0 + 2, KQ_TK(tkc, 2), va, ua); KQ_PIN(); fma_step(pm0 + 1, twc[1], KQ_W2(1), vb, ub); KQ_PIN();
             // ---- publish the next block's 8 traces (loaded during the previous block).  Their ring
             // slots held traces last read at step 6 of the previous block, and every wave is past that
             // block's barrier, which sits after step 6: no wave can still be reading them.
@@ -757,11 +801,11 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
                     publish(pos0, stA);
             }
 #endif
-            load_step(pm0 + 3, tkc[3], vb, ub); KQ_PIN(); fma_step(pm0 + 2, twc[2], KQ_W2(2), va, ua); KQ_PIN();
-            load_step(pm0 + 4, tkc[4], va, ua); KQ_PIN(); fma_step(pm0 + 3, twc[3], KQ_W2(3), vb, ub); KQ_PIN();
-            load_step(pm0 + 5, tkc[5], vb, ub); KQ_PIN(); fma_step(pm0 + 4, twc[4], KQ_W2(4), va, ua); KQ_PIN();
-            load_step(pm0 + 6, tkc[6], va, ua); KQ_PIN(); fma_step(pm0 + 5, twc[5], KQ_W2(5), vb, ub); KQ_PIN();
-            load_step(pm0 + 7, tkc[7], vb, ub); KQ_PIN(); fma_step(pm0 + 6, twc[6], KQ_W2(6), va, ua); KQ_PIN();
+            load_step(pm0 + 3, KQ_TK(tkc, 3), vb, ub); KQ_PIN(); fma_step(pm0 + 2, twc[2], KQ_W2(2), va, ua); KQ_PIN();
+            load_step(pm0 + 4, KQ_TK(tkc, 4), va, ua); KQ_PIN(); fma_step(pm0 + 3, twc[3], KQ_W2(3), vb, ub); KQ_PIN();
+            load_step(pm0 + 5, KQ_TK(tkc, 5), vb, ub); KQ_PIN(); fma_step(pm0 + 4, twc[4], KQ_W2(4), va, ua); KQ_PIN();
+            load_step(pm0 + 6, KQ_TK(tkc, 6), va, ua); KQ_PIN(); fma_step(pm0 + 5, twc[5], KQ_W2(5), vb, ub); KQ_PIN();
+            load_step(pm0 + 7, KQ_TK(tkc, 7), vb, ub); KQ_PIN(); fma_step(pm0 + 6, twc[6], KQ_W2(6), va, ua); KQ_PIN();
             // ---- barrier after step 6.  The published traces are first read by step 0 of the next
             // block, whose reads are issued below.  This wave's publish stores are already complete:
             // LDS operations finish in order and the FMAs above waited for younger reads.  The reads
@@ -769,20 +813,20 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
 #ifndef KQ_DIAG_NOBAR
             asm volatile("s_barrier" ::: "memory");
 #endif
-            load_step((pm0 + 8) % RG, tkn[0], va, ua); KQ_PIN(); fma_step(pm0 + 7, twc[7], KQ_W2(7), vb, ub); KQ_PIN();
+            load_step((pm0 + 8) % RG, KQ_TK(tkn, 0), va, ua); KQ_PIN(); fma_step(pm0 + 7, twc[7], KQ_W2(7), vb, ub); KQ_PIN();
 #undef KQ_W2
-#pragma unroll
-            for (int s = 0; s < S; ++s) tkc[s] = tkn[s];
+            tkc = tkn;
         }
     }
 #undef KQ_PIN
+#undef KQ_TK
     asm volatile("" ::"v"(va[0].x), "v"(va[NQ - 1].w));   // the look-ahead reads of the step after the last
 
     if (ti_raw < snum) {
         float *o = P.out + (size_t)ti_raw * P.ldo + (x0 - P.xlo);
 #pragma unroll
         for (int i = 0; i < XB; ++i)
-            if (x0 + i < P.xhi) o[i] = acc[i] * fin;
+            if (x0 + i >= P.xlo && x0 + i < P.xhi) o[i] = acc[i] * fin;
     }
 #ifdef KQ_STAMP
     // diagnostic build (build/stamp_run.py): workgroup residency timeline, us per step per chunk
@@ -821,8 +865,8 @@ struct impdar_kirch_plan {
     hipEvent_t ev_free[2] = {nullptr, nullptr};    // last migrate reading buffer b done (compute stream)
     bool free_recorded[2] = {false, false};
     DevBuf d_hmax, d_klo, d_khi;
-    DevBuf d_TK[2], d_TW[2], d_TW2[2], d_c1, d_c2, d_fin, d_N2;
-    int n2off = 0;
+    DevBuf d_TK[2], d_TW[2], d_TW2[2], d_c1, d_c2, d_fin, d_N2, d_WIN;
+    int nrows = 0, mrow0 = 0;   // quad kernel: step-block table rows (see FastParams)
     int quadSH = 0;             // table entries are LDS byte offsets >> quadSH
     DevBuf d_stamps;               // diagnostic builds only
     int nb = 0, ntab = 0;
@@ -1036,33 +1080,27 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         // rows), so the tables need not extend past tnum even when the aperture does
         hglob = std::min(hglob, tnum + 128);
         for (int c = 0; c < nch; ++c) hmax[c] = std::min(hmax[c], hglob);
-        {
-            // n^2 as float for offsets n = i - n2off; a step block reads its 8 entries with one scalar load
-            p->n2off = hglob + 16;
-            std::vector<float> n2((size_t)2 * hglob + 512);
-            for (size_t i = 0; i < n2.size(); ++i) {
-                const double n = (double)i - p->n2off;
-                n2[i] = (float)(n * n);
-            }
-            if ((rc = upload(p->d_N2, n2.data(), n2.size() * 4))) return fail(rc);
-        }
         const int nb = hglob + 64;
         p->nb = nb;
         p->ntab = hglob + 1;       // offsets 0..hglob-1 (hmax carries a guard) + one all-zero row
-        if ((size_t)p->ntab * snum * 2 >= ((size_t)1 << 31)) {      // the kernels address it as one raw buffer
-            impdar_set_error("fast Kirchhoff pick table of %d x %d entries exceeds 2 GiB; use the exact mode", p->ntab, snum);
-            return fail(IMPDAR_ERR_UNSUPPORTED);
-        }
+        // quad kernel: tables by step block, row r <-> offsets n = 8 (r - mrow0) + 1 .. + 8
+        p->mrow0 = hglob / 8 + 8;
+        p->nrows = 2 * (hglob / 8) + 64;
         {
+            const size_t tkbytes = p->quad ? (size_t)p->nrows * snum * 16 : (size_t)p->ntab * snum * 2;
+            if (tkbytes >= ((size_t)1 << 31)) {      // the kernels address it as one raw buffer
+                impdar_set_error("fast Kirchhoff pick table of %zu bytes exceeds 2 GiB; use the exact mode", tkbytes);
+                return fail(IMPDAR_ERR_UNSUPPORTED);
+            }
             const size_t ent = (size_t)p->ntab * snum;
             bool ok = true;
             for (int b = 0; b < 2; ++b) {
-                ok = ok && p->d_TK[b].ensure(ent * 2) == hipSuccess;
+                ok = ok && p->d_TK[b].ensure(tkbytes) == hipSuccess;
                 if (!p->quad) ok = ok && p->d_TW[b].ensure(ent * 4) == hipSuccess;
                 if (!p->quad && p->nearfield) ok = ok && p->d_TW2[b].ensure(ent * 4) == hipSuccess;
             }
             if (!ok) {
-                impdar_set_error("hipMalloc of the %zu-entry pick/weight table failed", ent);
+                impdar_set_error("hipMalloc of the %zu-byte pick table failed", tkbytes);
                 return fail(IMPDAR_ERR_HIP);
             }
         }
@@ -1074,11 +1112,32 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
             for (int n = 0; n < nb; ++n) {
                 const double bn = p->alpha * (double)n * (double)n;
                 const double ulo = std::sqrt(cmin[c] + bn) - u0, uhi = std::sqrt(cmax[c] + bn) - u0;
-                const int kmin = std::max(0, (int)std::floor(ulo) - 1);
-                // quad kernel: ring row of kmin in the upper half (saves a division by the runtime W)
-                klo[(size_t)c * nb + n] = p->quad ? (kmin | ((kmin % p->quadW) << 16)) : kmin;
+                klo[(size_t)c * nb + n] = std::max(0, (int)std::floor(ulo) - 1);
                 khi[(size_t)c * nb + n] = std::min(snum - 1, (int)std::ceil(uhi) + 1);
             }
+        if (p->quad) {
+            // the 8 traces block r adds are read by the steps n = 8 (r - mrow0) + 1 .. + 31 (they enter
+            // the 24-trace window of a lane at its last slot and leave it 23 steps later)
+            std::vector<int> win((size_t)nch * p->nrows * 2);
+            std::vector<float> n2((size_t)p->nrows * 8);
+            for (int r = 0; r < p->nrows; ++r) {
+                const long long na = 8LL * (r - p->mrow0) + 1, nz = na + 30;
+                const long long lo = (na <= 0 && nz >= 0) ? 0 : std::min(std::llabs(na), std::llabs(nz));
+                const long long hi = std::max(std::llabs(na), std::llabs(nz));
+                for (int c = 0; c < nch; ++c) {
+                    const int kmin = klo[(size_t)c * nb + std::min<long long>(lo, nb - 1)];
+                    const int kmax = khi[(size_t)c * nb + std::min<long long>(hi, nb - 1)];
+                    win[((size_t)c * p->nrows + r) * 2 + 0] = kmin | ((kmin % p->quadW) << 16);
+                    win[((size_t)c * p->nrows + r) * 2 + 1] = kmax;
+                }
+                for (int s8 = 0; s8 < 8; ++s8) {
+                    const double n = (double)(8LL * (r - p->mrow0) + 1 + s8);
+                    n2[(size_t)r * 8 + s8] = (float)(n * n);
+                }
+            }
+            if ((rc = upload(p->d_WIN, win.data(), win.size() * 4)) || (rc = upload(p->d_N2, n2.data(), n2.size() * 4)))
+                return fail(rc);
+        }
         if ((rc = upload(p->d_hmax, hmax.data(), nch * 4)) || (rc = upload(p->d_klo, klo.data(), klo.size() * 4)) ||
             (rc = upload(p->d_khi, khi.data(), khi.size() * 4)))
             return fail(rc);
@@ -1158,7 +1217,28 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
             hipLaunchKernelGGL((kirch_prep_kernel<double, double>), grid, dim3(256), 0, st, P);
         IMPDAR_HIP_CHECK(hipGetLastError());
     }
-    if (p->mode == IMPDAR_KIRCH_FAST) {
+    if (p->mode == IMPDAR_KIRCH_FAST && p->quad) {
+        // geometry-only pick table, rebuilt with every prep (counted in prep time)
+        TableQParams T;
+        T.TKB = p->d_TK[b].as<uint4>();
+        T.zs = p->d_zs.as<double>();
+        T.zs2 = p->d_zs2.as<double>();
+        T.tt = p->d_tt.as<double>();
+        T.dx = p->dx;
+        T.vel = p->vel;
+        T.tmax = p->tmax;
+        T.inv_dt = 1.0 / p->dt;
+        T.tt0 = p->tt0;
+        T.snum = p->snum;
+        T.nrows = p->nrows;
+        T.mrow0 = p->mrow0;
+        T.nmax = p->ntab - 1;
+        T.wmod = p->quadW;
+        T.kscale = (KQ_STRIDE * 4) >> p->quadSH;                                   // row offset in bytes >> quadSH
+        T.sentinel = (unsigned)((p->quadW * KQ_STRIDE * 4) >> p->quadSH);         // the all-zero row
+        hipLaunchKernelGGL(kirch_tableq_kernel, dim3((p->snum + 255) / 256, p->nrows), dim3(256), 0, st, T);
+        IMPDAR_HIP_CHECK(hipGetLastError());
+    } else if (p->mode == IMPDAR_KIRCH_FAST) {
         // geometry-only pick/weight table, rebuilt with every prep (counted in prep time)
         TableParams T;
         T.TK = p->d_TK[b].as<unsigned short>();
@@ -1175,10 +1255,10 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
         T.snum = p->snum;
         T.ntab = p->ntab;
         T.near = p->nearfield;
-        T.wmod = p->quad ? p->quadW : KF_W;
-        T.kscale = p->quad ? (KQ_STRIDE * 4) >> p->quadSH : 4;  // quad layout: row offset in bytes >> quadSH
-        T.sentinel = p->quad ? (unsigned short)((p->quadW * KQ_STRIDE * 4) >> p->quadSH) : 0;   // the all-zero row
-        T.write_w = p->quad ? 0 : 1;
+        T.wmod = KF_W;
+        T.kscale = 4;
+        T.sentinel = 0;
+        T.write_w = 1;
         hipLaunchKernelGGL(kirch_table_kernel, dim3((p->snum + 255) / 256, p->ntab), dim3(256), 0, st, T);
         IMPDAR_HIP_CHECK(hipGetLastError());
     }
@@ -1202,7 +1282,7 @@ template <int XB, int OCC, int SH>
 static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipStream_t st)
 {
     FastParams P = P0;
-    const int ntiles = (nx + XB - 1) / XB;
+    const int ntiles = (P.xhi - (P.xlo & ~7) + XB - 1) / XB;      // tiles start at a multiple of 8
     P.nxt = ntiles;
     {
         const char *ge = getenv("IMPDAR_KIRCH_G");        // tuning knob: adjacent trace tiles per XCD group
@@ -1290,7 +1370,10 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         P.c2 = p->d_c2.as<float>();
         P.fin = p->d_fin.as<float>();
         P.N2 = p->d_N2.as<float>();
-        P.n2off = p->n2off;
+        P.TKB = p->d_TK[b].p;
+        P.WIN = p->d_WIN.as<int2>();
+        P.nrows = p->nrows;
+        P.mrow0 = p->mrow0;
         P.stamps = nullptr;
 #ifdef KQ_STAMP
         if (p->d_stamps.ensure((size_t)1 << 22) == hipSuccess) {
