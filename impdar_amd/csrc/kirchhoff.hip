@@ -195,7 +195,6 @@ struct FastParams {
     const void *TKB;               // [nrows][snum] x 8 picks of 16 bits: one 16-byte load per lane per block
     const int2 *WIN;               // [nchunks][nrows] staging window of the 8 traces a block adds:
                                    //   x = kmin | (kmin mod W) << 16, y = kmax
-    const float *N2;               // [nrows][8] float(n^2)
     int nrows, mrow0;
     unsigned long long *stamps;    // diagnostic builds only (-DKQ_STAMP): per-workgroup {start, end, hw id, chunk|steps}
     int ntab;                      // rows; the last row is all zero (|n| beyond every aperture)
@@ -576,7 +575,12 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     };
 #define KQ_TK(q, s) (((q)[(s) >> 1] >> (16 * ((s) & 1))) & 0xffffu)
     const float c1 = P.c1[ti], c2 = NEAR ? P.c2[ti] : 0.f, fin = P.fin[ti];
-    auto n2_of = [&](int blk) { return P.N2 + (size_t)row_of(blk) * 8; };
+    // n^2 of a step: scalar multiply + one conversion (in-aperture offsets are < 65536, so the product
+    // fits 32 bits; padding steps may wrap, they only ever meet the all-zero row)
+    auto n2_of = [&](int step) {
+        const int n = nlo + step;
+        return (float)((unsigned)n * (unsigned)n);
+    };
 
     for (int e = tid; e < (W + 1) * ST * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
     __syncthreads();
@@ -745,11 +749,8 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     } while (0)
 
     float n2c[S];                                  // n^2 of the current block's steps
-    {
-        const float *n2 = n2_of(0);
 #pragma unroll
-        for (int s = 0; s < S; ++s) n2c[s] = n2[s];
-    }
+    for (int s = 0; s < S; ++s) n2c[s] = n2_of(s);
     load_step(0, KQ_TK(tkc, 0), va, ua);           // step 0 of block 0
     for (int rev = 0; rev < nrev; rev += 2) {
 #pragma clang loop unroll(full)
@@ -782,9 +783,8 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
                 if (NEAR) tw2c[s] = (y * c2) * (y * y);
             }
             {
-                const float *n2 = n2_of(blk + 1);
 #pragma unroll
-                for (int s = 0; s < S; ++s) n2c[s] = n2[s];
+                for (int s = 0; s < S; ++s) n2c[s] = n2_of((blk + 1) * S + s);
             }
 #define KQ_W2(s) (NEAR ? tw2c[NEAR ? (s) : 0] : 0.f)
             load_step(pm0 + 1, KQ_TK(tkc, 1), vb, ub); KQ_PIN(); fma_step(pm0 + 0, twc[0], KQ_W2(0), va, ua); KQ_PIN();
@@ -865,7 +865,7 @@ struct impdar_kirch_plan {
     hipEvent_t ev_free[2] = {nullptr, nullptr};    // last migrate reading buffer b done (compute stream)
     bool free_recorded[2] = {false, false};
     DevBuf d_hmax, d_klo, d_khi;
-    DevBuf d_TK[2], d_TW[2], d_TW2[2], d_c1, d_c2, d_fin, d_N2, d_WIN;
+    DevBuf d_TK[2], d_TW[2], d_TW2[2], d_c1, d_c2, d_fin, d_WIN;
     int nrows = 0, mrow0 = 0;   // quad kernel: step-block table rows (see FastParams)
     int quadSH = 0;             // table entries are LDS byte offsets >> quadSH
     DevBuf d_stamps;               // diagnostic builds only
@@ -973,7 +973,9 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     const bool quad_ok = (size_t)(wq + 1) * KQ_STRIDE * 4 <= 80 * 1024;
     const bool tab_ok = (KF_THREADS + sa * (16 - 1) + 8.0) <= (double)KF_W;
     const bool window_ok = quad_ok || tab_ok;
-    const bool fast_ok = dtype == IMPDAR_F32 && p->uniform && window_ok && snum < 65536;
+    // (aperture half width below 65536 traces: the kernel squares trace offsets in 32 bits)
+    const bool fast_ok = dtype == IMPDAR_F32 && p->uniform && window_ok && snum < 65536 &&
+                         std::fabs(tmax / dt) / sa < 65000.0;
 
     if (mode == IMPDAR_KIRCH_AUTO) mode = fast_ok ? IMPDAR_KIRCH_FAST : IMPDAR_KIRCH_EXACT;
     if (mode == IMPDAR_KIRCH_FAST && !fast_ok) {
@@ -1119,7 +1121,6 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
             // the 8 traces block r adds are read by the steps n = 8 (r - mrow0) + 1 .. + 31 (they enter
             // the 24-trace window of a lane at its last slot and leave it 23 steps later)
             std::vector<int> win((size_t)nch * p->nrows * 2);
-            std::vector<float> n2((size_t)p->nrows * 8);
             for (int r = 0; r < p->nrows; ++r) {
                 const long long na = 8LL * (r - p->mrow0) + 1, nz = na + 30;
                 const long long lo = (na <= 0 && nz >= 0) ? 0 : std::min(std::llabs(na), std::llabs(nz));
@@ -1130,13 +1131,8 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
                     win[((size_t)c * p->nrows + r) * 2 + 0] = kmin | ((kmin % p->quadW) << 16);
                     win[((size_t)c * p->nrows + r) * 2 + 1] = kmax;
                 }
-                for (int s8 = 0; s8 < 8; ++s8) {
-                    const double n = (double)(8LL * (r - p->mrow0) + 1 + s8);
-                    n2[(size_t)r * 8 + s8] = (float)(n * n);
-                }
             }
-            if ((rc = upload(p->d_WIN, win.data(), win.size() * 4)) || (rc = upload(p->d_N2, n2.data(), n2.size() * 4)))
-                return fail(rc);
+            if ((rc = upload(p->d_WIN, win.data(), win.size() * 4))) return fail(rc);
         }
         if ((rc = upload(p->d_hmax, hmax.data(), nch * 4)) || (rc = upload(p->d_klo, klo.data(), klo.size() * 4)) ||
             (rc = upload(p->d_khi, khi.data(), khi.size() * 4)))
@@ -1369,7 +1365,6 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         P.c1 = p->d_c1.as<float>();
         P.c2 = p->d_c2.as<float>();
         P.fin = p->d_fin.as<float>();
-        P.N2 = p->d_N2.as<float>();
         P.TKB = p->d_TK[b].p;
         P.WIN = p->d_WIN.as<int2>();
         P.nrows = p->nrows;
