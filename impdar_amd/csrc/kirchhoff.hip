@@ -263,9 +263,14 @@ struct TableQParams {
     const double *zs, *zs2, *tt;
     double dx, vel, tmax, inv_dt, tt0;
     int snum, nrows, mrow0, nmax;   // offsets |n| >= nmax are outside every aperture
-    int wmod, kscale;
-    unsigned sentinel;
+    int wmod, sh;                   // ring rows; entries are LDS byte offsets >> sh
 };
+
+// byte offset of half 0 of ring row r in the quad kernel's LDS image (layout: see kirch_quad_kernel)
+__host__ __device__ static inline unsigned kq_row_offset(int r)
+{
+    return (unsigned)(r >> 5) * 5376u + (unsigned)(r & 31) * 32u + (((unsigned)(r >> 3) & 1u) << 4);
+}
 
 __global__ __launch_bounds__(256) void kirch_tableq_kernel(TableQParams P)
 {
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(256) void kirch_tableq_kernel(TableQParams P)
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int n = abs(8 * (r - P.mrow0) + 1 + s);
-        unsigned kb = P.sentinel;
+        unsigned kb = 1024u >> P.sh;             // the all-zero row (KQ_ZERO)
         if (n < P.nmax) {
             const double dx = (double)n * P.dx;
             const double q = dx * dx + P.zs2[ti];
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(256) void kirch_tableq_kernel(TableQParams P)
                 while (k0 > 0 && P.tt[k0] > t) --k0;
                 const int k1 = min(k0 + 1, ns - 1);
                 const int k = (fabs(P.tt[k1] - t) < fabs(P.tt[k0] - t)) ? k1 : k0;
-                kb = (unsigned)((k % P.wmod) * P.kscale);
+                kb = kq_row_offset(k % P.wmod) >> P.sh;
             }
         }
         pk[s] = kb;
@@ -465,22 +470,27 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_tab_kernel(FastParams P
 }
 
 // ---------------------------------------------------------------------------
-// quad kernel: table-driven ring in SAMPLE-MAJOR LDS layout.
-//   lds[(k mod W) * KQ_STRIDE + slot]      KQ_RING = 40 slots, row stride 44 floats
-// At one step every output i of a lane reads the SAME sample k from XB
-// consecutive ring slots, so in this layout the XB values are contiguous:
-// 6-7 aligned ds_read_b128 per step instead of 24 ds_read_b32.  The row
-// stride is 176 B = 16 B * 11 (odd): 16 lanes holding 16 consecutive samples
-// hit 16 distinct 16-byte bank groups, and the lane->sample permutation below
-// gives every hardware lane group of ds_read_b128 exactly such a run.
-// A step block is S = 8 offsets; the 8 traces the next block needs are two
-// aligned slot quads: each thread loads the same sample of the 8 traces at the
-// start of the block and publishes it with two ds_write_b128 at the end, so
-// the global-load latency has a whole block of LDS/FMA work to hide behind.
+// quad kernel: table-driven ring of 40 trace slots (5 groups of 8 traces) in LDS.
+// At one step every output i of a lane reads the SAME sample k from XB consecutive ring slots:
+// 6-7 aligned ds_read_b128 per step instead of 24 ds_read_b32.
+//
+// LDS image (filled by LDS-DMA, which writes 1 KiB contiguously per wave instruction):
+//   piece  = 32 consecutive ring rows (row = sample mod W, W a multiple of 32)
+//   byte(row, group g, half h) = (row >> 5) * KQ_PS + g * KQ_GS + (row & 31) * 32 + 16 * (h ^ ((row >> 3) & 1))
+// i.e. per (piece, group) a contiguous [32 rows][8 traces] block of 1 KiB plus one spare 32-byte row; KQ_PS is a
+// multiple of 256 B, which keeps rows of neighbouring pieces on distinct banks (15 % conflict cycles otherwise)
+// (the spare row of piece 0 stays zero: it is what dropped pairs pick).  The two 16-byte halves of a
+// row are swapped in rows with bit 3 set: the 16 lanes a ds_read_b128 services together hold 16
+// consecutive samples (lane permutation below), whose rows r and r+8 would otherwise share banks.
+// The DMA keeps the image linear and applies the swap on its per-lane SOURCE address; the pick table
+// holds the byte offset of half 0 of the picked row, half 1 is that offset ^ 16.
 // ---------------------------------------------------------------------------
 #define KQ_RING 40
-#define KQ_STRIDE 44
-#define KQ_RP KQ_STRIDE
+#define KQ_GS 1056          // bytes between the 5 trace groups inside a piece (32 rows x 32 B + spare row)
+#define KQ_PS 5376          // bytes per piece: 5 groups + pad to a multiple of 256 B (rows of neighbouring
+                            // pieces then keep distinct banks inside one ds_read_b128 lane group)
+#define KQ_ZERO 1024        // byte offset of the all-zero row (spare row of piece 0, group 0; + g * KQ_GS)
+static_assert(KQ_PS == 5376 && KQ_PS >= 5 * KQ_GS && KQ_ZERO == 1024, "kq_row_offset / kirch_tableq_kernel use these literally");
 typedef float kq_f4 __attribute__((ext_vector_type(4)));
 typedef unsigned kq_u4 __attribute__((ext_vector_type(4)));
 
@@ -489,13 +499,12 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
 {
     constexpr int S = 8;
     constexpr int RG = KQ_RING;               // ring slots
-    constexpr int ST = KQ_STRIDE;             // row stride (floats)
     constexpr int NB = RG / S;                // step blocks per ring revolution (unroll length)
     constexpr int NQ = RG / 4;                // slot quads
     static_assert(XB + 2 * S - 1 <= RG && RG % S == 0 && XB % 4 == 0, "ring too small");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *ldsG = lds;                        // W ring rows + one all-zero row (picked by dropped pairs)
-    float *ldsD = lds + (W + 1) * ST;
+    const int npieces = W >> 5;               // W is a multiple of 32
+    const unsigned img_bytes = (unsigned)npieces * KQ_PS;      // one image (gradient; data image behind it)
 
     const int b = blockIdx.x;
     const int xcd = b & 7, r = b >> 3;
@@ -535,9 +544,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     const int nblocks = (nsteps + S - 1) / S;
     // the main loop always runs whole ring revolutions (NB blocks); steps past the
     // aperture pick the table's all-zero row, so they add nothing
-    // (two revolutions are unrolled so that block parity, which selects the staging register
-    // set, is a compile-time constant)
-    const int nrev = 2 * ((nblocks + 2 * NB - 1) / (2 * NB));
+    const int nrev = (nblocks + NB - 1) / NB;
     const int jbase = x0 + nlo;
     // table row of block 0 (block b covers n = nlo + 8 b .. + 7); rows past the tables' end (only the
     // padding blocks of the last revolution can get there) are clamped to the last, all-dropped row
@@ -558,10 +565,18 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     // workgroup's first group: scalar group offset + per-lane sample offset, no address arithmetic
     // in vector registers; traces outside the profile are zero rows of the padded image.
     const unsigned grp_bytes = (unsigned)snum * 32u;
-    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(P.GT) + (ptrdiff_t)(jbase - 1) * snum, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(NEAR ? P.DT : P.GT) + (ptrdiff_t)(jbase - 1) * snum, 0, 0x7fffffff, 0x00020000);
+    // buffer descriptors as four scalar words (the DMA below is inline asm): base, no stride, 2 GiB range, raw dword format
+    auto make_desc = [&](const float *img) {
+        const unsigned long long a = (unsigned long long)(img + (ptrdiff_t)(jbase - 1) * snum);
+        kq_u4 d;
+        d.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+        d.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+        d.z = 0x7fffffffu;
+        d.w = 0x00020000u;
+        return d;
+    };
+    const kq_u4 gdesc = make_desc(P.GT);
+    const kq_u4 ddesc = make_desc(NEAR ? P.DT : P.GT);
     // Pick table entry = LDS offset of the picked sample's ring row (bytes >> SH); pairs the reference
     // drops (t > t_max, or the 0/0 apex of a t = 0 sample) point at the all-zero row, so they need no
     // compare/select.  The 8 picks of a step block are 16 contiguous bytes per lane: one raw-buffer load
@@ -582,7 +597,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
         return (float)((unsigned)n * (unsigned)n);
     };
 
-    for (int e = tid; e < (W + 1) * ST * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
+    for (int e = tid; e < (int)(img_bytes / 4) * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
     __syncthreads();
     kq_u4 tkc = picks(0);                          // picks of the current block
 
@@ -590,89 +605,52 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
 #pragma unroll
     for (int i = 0; i < XB; ++i) acc[i] = 0.f;
 
-    // Staging registers of one block's 8 incoming traces (2 samples per thread each, 8 traces = two
-    // 16-byte loads).  Loads are issued TWO blocks ahead of use: the set filled during block b is
-    // published at the end of block b+1, so the load latency has a full block of LDS/FMA work in front of it.
-    struct Stage {
-        kq_f4 g0[2], g1[2], d0[NEAR ? 2 : 1], d1[NEAR ? 2 : 1];
-        int m0, m1;
-        bool wr1;
+    // ---- staging by LDS-DMA: the 8 traces a block adds (one 8-row group of the image) go straight from
+    // memory into their ring group, 1 KiB (32 rows) per wave instruction, no staging registers and no
+    // ds_write.  Lane l of a piece writes bytes [16 l, 16 l + 16) of the piece: row 32 piece + l/2,
+    // half (l & 1); its SOURCE is the sample congruent to that row in [kmin, kmin + W) and the half
+    // the row's swap puts there.  Pieces are dealt to the four waves round robin.
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave index, in a scalar register
+    const int rl = lane >> 1;                                  // row of this lane inside a piece
+    const unsigned hsel = ((unsigned)(lane & 1) ^ ((unsigned)(rl >> 3) & 1u)) * 16u;
+    // The DMA is inline asm on purpose: hipcc treats its own LDS-DMA as a pending LDS write and drains it
+    // (s_waitcnt vmcnt) in front of the next ds_read, which would expose the whole load latency in
+    // every block.  Here the order is ours: each wave retires its DMA with the vmcnt(0) in front of the
+    // block's barrier, and the new traces are only read after that barrier.  M0 (the LDS destination)
+    // is saved and restored inside the statement.
+    auto dma16 = [&](unsigned lds_dst, unsigned vo, kq_u4 desc, unsigned so) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(lds_dst), "v"(vo), "s"(desc), "s"(so)
+                     : "memory");
     };
-    auto issue = [&](int blk_for, Stage &st, int wa, int wb) {   // traces that block `blk_for` adds to the ring
+    auto dma_issue = [&](int blk_for, int wa) {     // traces that block `blk_for` adds to the ring
         const int kmin = wa & 0xffff, kmod = (int)((unsigned)wa >> 16);
-        const int kmax = min(wb, kmin + W - 1);
-        const int e1 = kmin + tid + KF_THREADS;
-        st.wr1 = e1 <= kmax;
-        const int c0 = min(kmin + tid, snum - 1), c1 = min(e1, snum - 1);
-        int m0 = kmod + tid;
-        m0 -= (m0 >= W) ? W : 0;
-        int m1 = m0 + KF_THREADS;
-        m1 -= (m1 >= W) ? W : 0;
-        m1 -= (m1 >= W) ? W : 0;
-        st.m0 = m0;
-        st.m1 = m1;
-        const unsigned so = (unsigned)(blk_for + 3) * grp_bytes;      // group of trace jbase + q0
-        const unsigned vo0 = (unsigned)c0 * 32u, vo1 = (unsigned)c1 * 32u;
-#ifdef KQ_DIAG_NOISSUE      // diagnostic: publish register contents, no global loads
-        asm volatile("" : "=v"(st.g0[0]), "=v"(st.g0[1]), "=v"(st.g1[0]), "=v"(st.g1[1]) : "v"(vo0), "v"(vo1), "s"(so));
-        return;
-#endif
-        st.g0[0] = __builtin_amdgcn_raw_buffer_load_b128(gres, vo0, so, 0);
-        st.g0[1] = __builtin_amdgcn_raw_buffer_load_b128(gres, vo0 + 16u, so, 0);
-        if (NEAR) {
-            st.d0[0] = __builtin_amdgcn_raw_buffer_load_b128(dres, vo0, so, 0);
-            st.d0[1] = __builtin_amdgcn_raw_buffer_load_b128(dres, vo0 + 16u, so, 0);
-        }
-        // the window is ~300 samples: only the first ~44 lanes of the workgroup have a second
-        // sample, so three of the four waves skip these loads altogether
-        if (st.wr1) {
-            st.g1[0] = __builtin_amdgcn_raw_buffer_load_b128(gres, vo1, so, 0);
-            st.g1[1] = __builtin_amdgcn_raw_buffer_load_b128(gres, vo1 + 16u, so, 0);
-            if (NEAR) {
-                st.d1[0] = __builtin_amdgcn_raw_buffer_load_b128(dres, vo1, so, 0);
-                st.d1[1] = __builtin_amdgcn_raw_buffer_load_b128(dres, vo1 + 16u, so, 0);
-            }
+        const int gidx = ((blk_for + 3) % NB + NB) % NB;       // ring group of these traces
+        const unsigned so = (unsigned)(blk_for + 3) * grp_bytes;      // image group of trace jbase + q0
+        for (int pc = wv; pc < npieces; pc += 4) {
+            int t = pc * 32 + rl - kmod;
+            t += (t < 0) ? W : 0;
+            const int c = min(kmin + t, snum - 1);
+            const unsigned vo = (unsigned)c * 32u + hsel;
+            dma16((unsigned)(pc * KQ_PS + gidx * KQ_GS), vo, gdesc, so);
+            if (NEAR) dma16(img_bytes + (unsigned)(pc * KQ_PS + gidx * KQ_GS), vo, ddesc, so);
         }
     };
-    auto publish = [&](int pos0, const Stage &st) {  // two aligned slot quads per sample
-#ifdef KQ_DIAG_NOPUB        // diagnostic: wait for the staged data but do not write it to LDS
-        asm volatile("" ::"v"(st.g0[0]), "v"(st.g0[1]), "v"(st.m0));
-        if (st.wr1) asm volatile("" ::"v"(st.g1[0]), "v"(st.g1[1]), "v"(st.m1));
-        return;
-#endif
-        kq_f4 *r0 = reinterpret_cast<kq_f4 *>(&ldsG[st.m0 * ST + pos0]);
-        r0[0] = st.g0[0];
-        r0[1] = st.g0[1];
-        if (st.wr1) {
-            kq_f4 *r1 = reinterpret_cast<kq_f4 *>(&ldsG[st.m1 * ST + pos0]);
-            r1[0] = st.g1[0];
-            r1[1] = st.g1[1];
-        }
-        if (NEAR) {
-            kq_f4 *t0 = reinterpret_cast<kq_f4 *>(&ldsD[st.m0 * ST + pos0]);
-            t0[0] = st.d0[0];
-            t0[1] = st.d0[1];
-            if (st.wr1) {
-                kq_f4 *t1 = reinterpret_cast<kq_f4 *>(&ldsD[st.m1 * ST + pos0]);
-                t1[0] = st.d1[0];
-                t1[1] = st.d1[1];
-            }
-        }
-    };
-    // ring position of ring-relative trace q is (q + 1) % RG, which makes the 8 traces every block
-    // adds two aligned slot quads; the ring starts with the four groups q = -1 .. 30
-    int wa, wb;
+    // ring position of ring-relative trace q is (q + 1) % RG: the 8 traces a block adds are one ring
+    // group; the ring starts with the four groups q = -1 .. 30
+    int wa, wb, wn = 0;
     for (int pb = -3; pb <= 0; ++pb) {
-        Stage st;
         fetch_for(pb, wa, wb);
-        issue(pb, st, wa, wb);
-        publish((pb * S + XB + RG) % RG, st);
+        dma_issue(pb, wa);
     }
-    __syncthreads();
-    Stage stA, stB;                                // stA: filled during even blocks, stB: odd
     fetch_for(1, wa, wb);
-    issue(1, stB, wa, wb);                         // block 1's traces, published during block 0
-    fetch_for(2, wa, wb);                          // used by block 0's issue
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+    __syncthreads();
+    dma_issue(1, wa);                              // block 1's traces land during block 0
+    fetch_for(2, wa, wb);                          // used by the DMA issued at the end of block 0
 
     // ---- the resident ring is read software pipelined: the ds_read_b128 of step s+1 are in flight
     // while the FMAs of step s run (two statically indexed quad buffers), also across block ends
@@ -682,22 +660,24 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
         for (int c = 0; c < 4; ++c) any = any || ((4 * qd + c - pm - 1 + 2 * RG) % RG) < XB;
         return any;
     };
-    // pm = step index mod RG (a compile-time constant after unrolling), tk = the step's table entry
+    // pm = step index mod RG (a compile-time constant after unrolling), tk = the step's table entry =
+    // byte offset of half 0 of the picked row; quad qd = ring slots 4 qd .. 4 qd + 3 = half qd & 1 of group qd >> 1
     auto load_step = [&](int pm, unsigned tk, float4 (&v)[NQ], float4 (&u)[NEAR ? NQ : 1]) {
-        const unsigned kq = tk << SH;
-        const float4 *base = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(ldsG) + kq);
-        const float4 *based = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(ldsD) + kq);
+        const unsigned a0 = tk << SH, a1 = a0 ^ 16u;
+        const char *h0 = reinterpret_cast<const char *>(lds) + a0;
+        const char *h1 = reinterpret_cast<const char *>(lds) + a1;
 #pragma unroll
         for (int qd = 0; qd < NQ; ++qd)
             if (needed(pm, qd)) {
                 // must stay a whole ds_read_b128 also for the partly used quads at the ends of
                 // the window: fma_step marks the unused components as used (empty asm)
+                const char *src = ((qd & 1) ? h1 : h0) + (qd >> 1) * KQ_GS;
 #ifdef KQ_DIAG_NOLDS        // diagnostic build: no LDS reads (VALU-only time of the loop)
-                asm volatile("" : "=v"(v[qd].x), "=v"(v[qd].y), "=v"(v[qd].z), "=v"(v[qd].w) : "v"(base));
+                asm volatile("" : "=v"(v[qd].x), "=v"(v[qd].y), "=v"(v[qd].z), "=v"(v[qd].w) : "v"(src));
 #else
-                v[qd] = base[qd];
+                v[qd] = *reinterpret_cast<const float4 *>(src);
 #endif
-                if (NEAR) u[qd] = based[qd];
+                if (NEAR) u[qd] = *reinterpret_cast<const float4 *>(src + img_bytes);
             }
     };
     auto fma_step = [&](int pm, float w, float w2, const float4 (&v)[NQ], const float4 (&u)[NEAR ? NQ : 1]) {
@@ -752,29 +732,23 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
 #pragma unroll
     for (int s = 0; s < S; ++s) n2c[s] = n2_of(s);
     load_step(0, KQ_TK(tkc, 0), va, ua);           // step 0 of block 0
-    for (int rev = 0; rev < nrev; rev += 2) {
+    for (int rev = 0; rev < nrev; ++rev) {
 #pragma clang loop unroll(full)
-        for (int bb2 = 0; bb2 < 2 * NB; ++bb2) {
-            const int bb = bb2 % NB;                   // block index within the ring revolution
-            const int blk = rev * NB + bb2;
+        for (int bb = 0; bb < NB; ++bb) {              // block index within the ring revolution
+            const int blk = rev * NB + bb;
             const int pm0 = bb * S;                    // step index mod RG of the block's first step
-            // ---- loads: next block's table entries first (they are waited for first), then the
-            // traces of the block after next
+            // ---- loads: the next block's table entries and, by DMA, its 8 new traces.  Their ring group
+            // held traces last read at step 6 of the previous block, and every wave is past that block's
+            // barrier, which sits after step 6: no wave can still be reading them.
 #ifdef KQ_DIAG_NOPICK
             const kq_u4 tkn = tkc;
 #else
             const kq_u4 tkn = picks(blk + 1);
 #endif
 #if !defined(KQ_DIAG_NOSTAGE)
-            if ((bb2 & 1) == 0)
-                issue(blk + 2, stA, wa, wb);
-            else
-                issue(blk + 2, stB, wa, wb);
-            fetch_for(blk + 3, wa, wb);                // the next block's staging window
+            fetch_for(blk + 3, wn, wb);                // staging window of the DMA after the next one
 #endif
-            // obliquity cos(theta) of this block's steps; the n^2 were loaded during the previous block
-            // (vmcnt waits are in order: a value loaded and used in the same block would drain the
-            // pick and staging loads in front of it)
+            // obliquity cos(theta) of this block's steps
             float twc[S], tw2c[NEAR ? S : 1];
 #pragma unroll
             for (int s = 0; s < S; ++s) {
@@ -789,31 +763,25 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
 #define KQ_W2(s) (NEAR ? tw2c[NEAR ? (s) : 0] : 0.f)
             load_step(pm0 + 1, KQ_TK(tkc, 1), vb, ub); KQ_PIN(); fma_step(pm0 + 0, twc[0], KQ_W2(0), va, ua); KQ_PIN();
             load_step(pm0 + 2, KQ_TK(tkc, 2), va, ua); KQ_PIN(); fma_step(pm0 + 1, twc[1], KQ_W2(1), vb, ub); KQ_PIN();
-            // ---- publish the next block's 8 traces (loaded during the previous block).  Their ring
-            // slots held traces last read at step 6 of the previous block, and every wave is past that
-            // block's barrier, which sits after step 6: no wave can still be reading them.
-#if !defined(KQ_DIAG_NOSTAGE)
-            {
-                const int pos0 = ((bb + 1) * S + XB) % RG;        // ring position of its first trace, multiple of 8
-                if ((bb2 & 1) == 0)
-                    publish(pos0, stB);
-                else
-                    publish(pos0, stA);
-            }
-#endif
             load_step(pm0 + 3, KQ_TK(tkc, 3), vb, ub); KQ_PIN(); fma_step(pm0 + 2, twc[2], KQ_W2(2), va, ua); KQ_PIN();
             load_step(pm0 + 4, KQ_TK(tkc, 4), va, ua); KQ_PIN(); fma_step(pm0 + 3, twc[3], KQ_W2(3), vb, ub); KQ_PIN();
             load_step(pm0 + 5, KQ_TK(tkc, 5), vb, ub); KQ_PIN(); fma_step(pm0 + 4, twc[4], KQ_W2(4), va, ua); KQ_PIN();
             load_step(pm0 + 6, KQ_TK(tkc, 6), va, ua); KQ_PIN(); fma_step(pm0 + 5, twc[5], KQ_W2(5), vb, ub); KQ_PIN();
             load_step(pm0 + 7, KQ_TK(tkc, 7), vb, ub); KQ_PIN(); fma_step(pm0 + 6, twc[6], KQ_W2(6), va, ua); KQ_PIN();
-            // ---- barrier after step 6.  The published traces are first read by step 0 of the next
-            // block, whose reads are issued below.  This wave's publish stores are already complete:
-            // LDS operations finish in order and the FMAs above waited for younger reads.  The reads
-            // of step 7 stay in flight across the barrier, so the read pipeline never drains.
+            // ---- barrier after step 6.  The new traces are first read by step 0 of the next block, whose
+            // reads are issued below; each wave retires its own DMA (and the pick load) first.  The LDS
+            // reads of step 7 stay in flight across the barrier, so the read pipeline never drains.
+            __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) only; a builtin so that hipcc's own wait counting sees it
 #ifndef KQ_DIAG_NOBAR
             asm volatile("s_barrier" ::: "memory");
 #endif
-            load_step((pm0 + 8) % RG, KQ_TK(tkn, 0), va, ua); KQ_PIN(); fma_step(pm0 + 7, twc[7], KQ_W2(7), vb, ub); KQ_PIN();
+            load_step((pm0 + 8) % RG, KQ_TK(tkn, 0), va, ua); KQ_PIN();
+#if !defined(KQ_DIAG_NOSTAGE)
+            // every wave is past step 6 of this block: the ring group of the traces last read there is free
+            dma_issue(blk + 2, wa);
+            wa = wn;
+#endif
+            fma_step(pm0 + 7, twc[7], KQ_W2(7), vb, ub); KQ_PIN();
 #undef KQ_W2
             tkc = tkn;
         }
@@ -821,6 +789,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
 #undef KQ_PIN
 #undef KQ_TK
     asm volatile("" ::"v"(va[0].x), "v"(va[NQ - 1].w));   // the look-ahead reads of the step after the last
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // the look-ahead DMA must land before the LDS is released
 
     if (ti_raw < snum) {
         float *o = P.out + (size_t)ti_raw * P.ldo + (x0 - P.xlo);
@@ -967,10 +936,10 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     // fast kernels need the moveout 2dx/(v dt) (samples per trace) small enough for their
     // LDS windows: quad (sample-major ring, 24 traces x 8-step blocks, up to ~6.7 samples/trace)
     // or, for steeper moveout, tab (trace-major ring of 16 traces, 512-sample slots)
-    const int wq = ((KF_THREADS + (int)std::ceil(sa * (24 + 8 - 2)) + 8 + 3) / 4) * 4;
-    // (two workgroups per CU: 80 KB of LDS each, ring rows + the all-zero row; row offsets fit 16 bits as
-    // bytes up to 371 rows, in float4 units beyond)
-    const bool quad_ok = (size_t)(wq + 1) * KQ_STRIDE * 4 <= 80 * 1024;
+    const int wq = ((KF_THREADS + (int)std::ceil(sa * (24 + 8 - 2)) + 8 + 31) / 32) * 32;   // whole 32-row pieces
+    // (two workgroups per CU: 80 KB of LDS each; table entries are 16-bit byte offsets up to 12 pieces,
+    // 16-byte units beyond)
+    const bool quad_ok = (size_t)(wq / 32) * KQ_PS <= 80 * 1024;
     const bool tab_ok = (KF_THREADS + sa * (16 - 1) + 8.0) <= (double)KF_W;
     const bool window_ok = quad_ok || tab_ok;
     // (aperture half width below 65536 traces: the kernel squares trace offsets in 32 bits)
@@ -989,7 +958,7 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     {
         const char *ie = getenv("IMPDAR_KIRCH_IMPL");       // tuning knob: "tab" forces the b32 ring
         p->quadW = wq;
-        p->quadSH = ((size_t)(wq + 1) * KQ_STRIDE * 4 <= 65535) ? 0 : 4;
+        p->quadSH = ((size_t)(wq / 32) * KQ_PS <= 65535) ? 0 : 4;
         p->quad = (mode == IMPDAR_KIRCH_FAST) && quad_ok && !(ie && !strcmp(ie, "tab") && tab_ok);
         p->xb = p->quad ? 24 : 16;
     }
@@ -1230,8 +1199,7 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
         T.mrow0 = p->mrow0;
         T.nmax = p->ntab - 1;
         T.wmod = p->quadW;
-        T.kscale = (KQ_STRIDE * 4) >> p->quadSH;                                   // row offset in bytes >> quadSH
-        T.sentinel = (unsigned)((p->quadW * KQ_STRIDE * 4) >> p->quadSH);         // the all-zero row
+        T.sh = p->quadSH;
         hipLaunchKernelGGL(kirch_tableq_kernel, dim3((p->snum + 255) / 256, p->nrows), dim3(256), 0, st, T);
         IMPDAR_HIP_CHECK(hipGetLastError());
     } else if (p->mode == IMPDAR_KIRCH_FAST) {
@@ -1290,7 +1258,7 @@ static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipSt
     P.tiles_per_xcd = nxt_pad / 8;
     const int nblk = P.nchunks * nxt_pad;
     const int W = p->quadW;
-    const size_t shmem = (size_t)(W + 1) * KQ_STRIDE * 4 * (p->nearfield ? 2 : 1);
+    const size_t shmem = (size_t)(W / 32) * KQ_PS * (p->nearfield ? 2 : 1);
     if (p->nearfield) {
         auto k = kirch_quad_kernel<XB, true, 1, SH>;
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
