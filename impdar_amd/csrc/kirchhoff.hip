@@ -597,6 +597,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
         return (float)((unsigned)n * (unsigned)n);
     };
 
+    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds != 0u) __builtin_trap();
     for (int e = tid; e < (int)(img_bytes / 4) * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
     __syncthreads();
     kq_u4 tkc = picks(0);                          // picks of the current block
@@ -654,7 +655,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
 
     // ---- the resident ring is read software pipelined: the ds_read_b128 of step s+1 are in flight
     // while the FMAs of step s run (two statically indexed quad buffers), also across block ends
-    float4 va[NQ], vb[NQ], ua[NEAR ? NQ : 1], ub[NEAR ? NQ : 1];
+    kq_f4 va[NQ], vb[NQ], ua[NEAR ? NQ : 1], ub[NEAR ? NQ : 1];
     auto needed = [](int pm, int qd) {
         bool any = false;
         for (int c = 0; c < 4; ++c) any = any || ((4 * qd + c - pm - 1 + 2 * RG) % RG) < XB;
@@ -662,25 +663,26 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     };
     // pm = step index mod RG (a compile-time constant after unrolling), tk = the step's table entry =
     // byte offset of half 0 of the picked row; quad qd = ring slots 4 qd .. 4 qd + 3 = half qd & 1 of group qd >> 1
-    auto load_step = [&](int pm, unsigned tk, float4 (&v)[NQ], float4 (&u)[NEAR ? NQ : 1]) {
+    auto load_step = [&](int pm, unsigned tk, kq_f4 (&v)[NQ], kq_f4 (&u)[NEAR ? NQ : 1]) {
+        // LDS pointers built from the table's byte offsets directly: the dynamic LDS block of this kernel
+        // starts at LDS address 0 (no static __shared__; checked once in the prologue), so no base is added
+        typedef const __attribute__((address_space(3))) kq_f4 *lds_f4p;
         const unsigned a0 = tk << SH, a1 = a0 ^ 16u;
-        const char *h0 = reinterpret_cast<const char *>(lds) + a0;
-        const char *h1 = reinterpret_cast<const char *>(lds) + a1;
 #pragma unroll
         for (int qd = 0; qd < NQ; ++qd)
             if (needed(pm, qd)) {
                 // must stay a whole ds_read_b128 also for the partly used quads at the ends of
                 // the window: fma_step marks the unused components as used (empty asm)
-                const char *src = ((qd & 1) ? h1 : h0) + (qd >> 1) * KQ_GS;
+                const unsigned src = ((qd & 1) ? a1 : a0) + (qd >> 1) * KQ_GS;
 #ifdef KQ_DIAG_NOLDS        // diagnostic build: no LDS reads (VALU-only time of the loop)
                 asm volatile("" : "=v"(v[qd].x), "=v"(v[qd].y), "=v"(v[qd].z), "=v"(v[qd].w) : "v"(src));
 #else
-                v[qd] = *reinterpret_cast<const float4 *>(src);
+                v[qd] = *(lds_f4p)(uintptr_t)src;
 #endif
-                if (NEAR) u[qd] = *reinterpret_cast<const float4 *>(src + img_bytes);
+                if (NEAR) u[qd] = *(lds_f4p)(uintptr_t)(src + img_bytes);
             }
     };
-    auto fma_step = [&](int pm, float w, float w2, const float4 (&v)[NQ], const float4 (&u)[NEAR ? NQ : 1]) {
+    auto fma_step = [&](int pm, float w, float w2, const kq_f4 (&v)[NQ], const kq_f4 (&u)[NEAR ? NQ : 1]) {
 #pragma unroll
         for (int qd = 0; qd < NQ; ++qd) {
             // outputs served by slots 4qd .. 4qd+3 at this step
@@ -771,7 +773,9 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
             // ---- barrier after step 6.  The new traces are first read by step 0 of the next block, whose
             // reads are issued below; each wave retires its own DMA (and the pick load) first.  The LDS
             // reads of step 7 stay in flight across the barrier, so the read pipeline never drains.
+#ifndef KQ_DIAG_NODMAWAIT
             __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) only; a builtin so that hipcc's own wait counting sees it
+#endif
 #ifndef KQ_DIAG_NOBAR
             asm volatile("s_barrier" ::: "memory");
 #endif
