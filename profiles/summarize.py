@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 output directories (gpurun_out/<run>/{stats,pmc_fetch,pmc_write,pmc_sq})
-into the small CSV/JSON files committed next to this script.
+"""Condense rocprofv3 output directories (gpurun_out/<run>/{stats,pmc_fetch,pmc_write,pmc_sq,pmc_sq2},
+written by profiles/tools/profile_bench.sh) into the small CSV/JSON files committed next to this script.
 
-    python profiles/summarize.py gpurun_out/prof12 r01
+    python profiles/summarize.py gpurun_out/prof_r01b r01
 
-FETCH_SIZE calibration: MI355X_MICROARCH.md (HBM section) says gfx950 under-reports read bytes
-(exactly 1/2 for 16 B/lane streams) and that other access widths must be calibrated on a known
-byte count in the same access pattern.  kirch_prep_kernel reads the (snum, tnum) float32 input
-exactly once with the same dword-per-lane coalesced loads the migration kernel's staging uses,
-so known_bytes / FETCH_SIZE(prep) is used as the read correction for the migration kernel.
+FETCH_SIZE correction: MI355X_MICROARCH.md (HBM section) says gfx950 reports exactly 1/2 of the bytes
+of wide coalesced 16 B/lane reads and that other access widths must be calibrated on a known byte
+count in the same pattern.  The migration kernel's memory reads are all 16 B/lane (LDS-DMA staging of
+the image, pick-table rows), so its FETCH_SIZE is doubled.  kirch_prep_kernel reads the (snum, tnum)
+float32 input exactly once with dword-per-lane loads; its known byte count is kept in the output as a
+cross-check of the counter (ratio known/counted, 1.545 on this part).
 """
 import collections
 import csv
@@ -40,7 +41,7 @@ def main():
         shutil.copy(stats[-1], os.path.join(here, '%s_bench_kernel_stats.csv' % tag))
     rows = []
     allc = {}
-    for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
+    for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_sq2'):
         c, meta = counters(os.path.join(src, sub))
         for k, cs in c.items():
             for name, v in cs.items():
@@ -55,16 +56,17 @@ def main():
     prep = [k for k in allc if 'kirch_prep' in k][0]
     known = snum * tnum * 4
     cal = known / (allc[prep]['FETCH_SIZE'] * 1024)
-    traffic = (allc[mig]['FETCH_SIZE'] * cal + allc[mig]['WRITE_SIZE']) * 1024
+    traffic = (allc[mig]['FETCH_SIZE'] * 2 + allc[mig]['WRITE_SIZE']) * 1024
     out = dict(kernel=mig, fetch_size_kb_raw=allc[mig]['FETCH_SIZE'], write_size_kb_raw=allc[mig]['WRITE_SIZE'],
-               fetch_calibration=cal,
-               calibration_note='kirch_prep_kernel FETCH_SIZE %.1f KB for a known %.1f KB read (same dword-per-lane '
-                                'coalesced loads); see profiles/summarize.py' % (allc[prep]['FETCH_SIZE'], known / 1024),
+               fetch_correction=2.0,
+               correction_note='all reads of the kernel are 16 B/lane (LDS-DMA staging, pick rows): gfx950 FETCH_SIZE '
+                               'counts half of those bytes (MI355X_MICROARCH.md, HBM section)',
+               prep_cross_check='kirch_prep_kernel (4 B/lane reads): FETCH_SIZE %.1f KB for a known %.1f KB read, '
+                                'ratio %.3f' % (allc[prep]['FETCH_SIZE'], known / 1024, cal),
                hbm_bytes_per_launch=traffic,
-               hbm_bytes_per_launch_if_x2=(allc[mig]['FETCH_SIZE'] * 2 + allc[mig]['WRITE_SIZE']) * 1024,
-               sq={k: v for k, v in allc[mig].items() if k.startswith('SQ_')},
+               other={k: v for k, v in allc[mig].items() if not k.endswith('_SIZE')},
                source='profiles/%s_bench_pmc.csv (rocprofv3 --pmc, separate passes per counter group, '
-                      'bench.py --steps 3 --warmup 1 --no-cpu)' % tag)
+                      'bench.py --steps 3 --warmup 1 --no-cpu; profiles/tools/profile_bench.sh)' % tag)
     json.dump(out, open(os.path.join(here, 'kirch_fast_hbm_traffic.json'), 'w'), indent=1)
     print(json.dumps(out, indent=1))
 

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Run on the GPU box (gpurun): rocprofv3 passes over the default bench workload.
+#   profiles/tools/profile_bench.sh <outdir under gpurun_out>
+# kernel-trace --stats, then separate --pmc passes (FETCH_SIZE / WRITE_SIZE cannot share a pass; SQ has 8 slots).
+# Summarise afterwards with: python profiles/summarize.py gpurun_out/<outdir> r01
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/$1
+mkdir -p $O
+cd $R
+B="python3 bench.py --steps 3 --warmup 1 --no-cpu"
+rocprofv3 --kernel-trace --stats -d $O/stats/run -o x --output-format csv -- $B > $O/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch/run -o x --output-format csv -- $B > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write/run -o x --output-format csv -- $B > $O/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/pmc_sq/run -o x --output-format csv -- $B > $O/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum -d $O/pmc_sq2/run -o x --output-format csv -- $B > $O/pmc_sq2.log 2>&1
+ls -R $O | head -40
