@@ -60,6 +60,7 @@ SIGNATURES = {
     'impdar_stolt': (_i, [_p, _p, _i, _i, _i, _dp, _dp, _d, _d, _d, _p]),
     'impdar_stolt_dev': (_i, [_p, _p, _i, _i, _i, _dp, _dp, _d, _d, _d, _p]),
     'impdar_phaseshift': (_i, [_p, _p, _i, _i, _i, _i, _dp, _dp, _d, _dp, _d, _dp, _i, _d, _d, _p]),
+    'impdar_phaseshift_ffd': (_i, [_p, _dp, _i, _i, _i, _dp, _dp, _d, _dp, _dp, _d, _d, _d, _dp]),
     'impdar_taper': (_i, [_p, _p, _i, _i, _i, _d, _d]),
     'impdar_comm_unique_id': (_i, [C.c_char_p]),
     'impdar_comm_init': (_i, [_p, C.c_char_p, _i, _i]),

@@ -424,6 +424,290 @@ extern "C" int impdar_phaseshift(impdar_ctx *ctx, const void *data, int dtype, i
     return IMPDAR_OK;
 }
 
+// ===========================================================================
+// 2-D v(x,z): Fourier finite-difference branch of phaseShift
+// (mig_python.py:428-432, 448-487; fourierFiniteDiff :496-525; Sp_Matr :528-540)
+//
+// The reference keeps ONE FFX_last for the whole (tau, omega) nest (:478): the update of
+// frequency iw uses the field of frequency iw-1 (and of the last frequency of the previous tau
+// at iw = 0), so the nest is a single serial chain of snum*nt steps, each with a length-tnum
+// inverse and forward FFT over the traces.  That order is reproduced literally: per step
+//   [post of the previous step + retardation phase of this row]  ->  rocFFT inverse (row, in place)
+//   ->  [thin-lens phase + finite-difference update, one workgroup]  ->  rocFFT forward (into the row).
+// float64 throughout, operation order of the reference (the file is compiled with
+// -ffp-contract=off).  Arrays are (row = frequency, column = trace), traces contiguous.
+// ===========================================================================
+typedef Cp<double> Cd;
+
+__device__ inline Cd cmul(Cd a, Cd b) { return Cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+
+// (snum,tnum) real -> tapered (:253-258), zero padded to nt rows, complex
+__global__ __launch_bounds__(256) void ffd_load(const double *__restrict__ in, Cd *__restrict__ X, int snum, int tnum,
+                                                int nt, double htaper, double vtaper)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)nt * tnum) return;
+    const int k = (int)(i / tnum), j = (int)(i % tnum);
+    double v = 0.0;
+    if (k < snum) v = in[i] * (impdar_taper_w(j, tnum, htaper) * impdar_taper_w(k, snum, vtaper));
+    X[i] = Cd{v, 0.0};
+}
+
+struct FfdStep {
+    Cd *FK;              // (nt, tnum)
+    Cd *TK;              // (snum, tnum)
+    const double *kx;    // (tnum)
+    const double *vmig;  // (snum, tnum)
+    const double *vbg;   // (snum) min over traces
+    const double *thr;   // (snum) (tau / tt[-1] / 1e6)^2, :484
+    int tnum;
+    // "post" half: row post_iw of step (post_itau): zero evanescent columns, accumulate into TK
+    int post_itau, post_iw;
+    double post_w;
+    // "pre" half: retardation phase of row pre_iw at depth step pre_itau
+    int pre_itau, pre_iw;
+    double pre_w;
+    double dt;
+};
+
+__device__ inline double ffd_coss(double vbg, double kx, double w)
+{
+    const double a = 0.5 * vbg * kx / w;          // :456
+    return 1.0 - a * a;
+}
+
+__global__ __launch_bounds__(256) void ffd_post_pre(FfdStep P)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= P.tnum) return;
+    if (P.post_iw >= 0) {
+        Cd *row = P.FK + (size_t)P.post_iw * P.tnum;
+        const double coss = ffd_coss(P.vbg[P.post_itau], P.kx[k], P.post_w);
+        Cd v = row[k];
+        if (coss <= P.thr[P.post_itau]) {          // :484-485 (sticky: written back)
+            v = Cd{0.0, 0.0};
+            row[k] = v;
+        }
+        Cd *t = P.TK + (size_t)P.post_itau * P.tnum + k;   // :487
+        t->x += v.x;
+        t->y += v.y;
+    }
+    if (P.pre_iw >= 0) {
+        Cd *row = P.FK + (size_t)P.pre_iw * P.tnum;
+        const double coss = ffd_coss(P.vbg[P.pre_itau], P.kx[k], P.pre_w);
+        // phase = (-w dt sqrt(coss)).real with a complex sqrt: 0 for coss < 0 (:458-460)
+        const double root = coss >= 0.0 ? sqrt(coss) : 0.0;
+        const double phase = -P.pre_w * P.dt * root;
+        double sn, cs;
+        sincos(phase, &sn, &cs);
+        row[k] = cmul(row[k], Cd{cs, -sn});        // conj(cos + i sin), :461-464
+    }
+}
+
+struct FfdMid {
+    const Cd *row;       // ifft of FK[iw] (tnum)
+    const Cd *last;      // FFX_last (tnum)
+    Cd *next;            // FFX of this step (tnum): becomes FFX_last and the forward FFT's input
+    const double *vmig;  // row itau of (snum, tnum)
+    double vbg, w, dt, dx;
+    int tnum, first;     // first: itau == 0 (no finite-difference term, :475)
+};
+
+// one workgroup: the last stencil row is a sum over all traces
+__global__ __launch_bounds__(256) void ffd_mid(FfdMid P)
+{
+    extern __shared__ Cd sm[];          // thin-lensed field (tnum) + 2 x 256 partial sums
+    Cd *fx = sm;
+    Cd *part = sm + P.tnum;
+    const int tid = threadIdx.x, n = P.tnum;
+    Cd sf = {0.0, 0.0}, sl = {0.0, 0.0};
+    for (int x = tid; x < n; x += 256) {
+        const double v = P.vmig[x];
+        const double ufg = 1. / v - 1. / P.vbg;                            // :453
+        const double phase2 = 2. * ufg * P.w * P.dt + 1. * P.vbg * P.w * P.dt;   // :471
+        double sn, cs;
+        sincos(phase2, &sn, &cs);
+        const Cd f = cmul(P.row[x], Cd{cs, sn});                           // :472-473
+        fx[x] = f;
+        sf.x += f.x;
+        sf.y += f.y;
+        if (!P.first) {
+            sl.x += P.last[x].x;
+            sl.y += P.last[x].y;
+        }
+    }
+    part[tid] = sf;
+    part[256 + tid] = sl;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            part[tid].x += part[tid + s].x;
+            part[tid].y += part[tid + s].y;
+            part[256 + tid].x += part[256 + tid + s].x;
+            part[256 + tid].y += part[256 + tid + s].y;
+        }
+        __syncthreads();
+    }
+    const Cd sumf = part[0], suml = part[256];
+    for (int x = tid; x < n; x += 256) {
+        Cd out = fx[x];
+        if (!P.first) {
+            // stencil = Sp_Matr(N,-2,1,1) as built: zero main diagonal (:533 overwrites it), row 0 = e0,
+            // last row all ones (:536-539)
+            Cd a, b;
+            if (x == 0) {
+                a = fx[0];
+                b = P.last[0];
+            } else if (x == n - 1) {
+                a = sumf;
+                b = suml;
+            } else {
+                a = Cd{fx[x - 1].x + fx[x + 1].x, fx[x - 1].y + fx[x + 1].y};
+                b = Cd{P.last[x - 1].x + P.last[x + 1].x, P.last[x - 1].y + P.last[x + 1].y};
+            }
+            const double vs = P.vmig[x] - P.vbg;                           // :452
+            const double num = P.dt * 0.5 * (vs * vs);                     // dt*alpha*vs**2, alpha = 0.5
+            const double den = 4. * P.w * (P.dx * P.dx);                   // imaginary part of 1j*4.*w*dx**2
+            // real / (0 + i den) the way NumPy divides complex numbers (Smith: scale by 1/den), :517
+            const double scl = 1.0 / den;
+            const Cd c1 = {0.0, (0.0 - num) * scl};
+            const double c2 = (-0.25 * (vs * vs)) / (4. * (P.w * P.w) * (P.dx * P.dx));   // :518
+            const Cd t1 = cmul(c1, a);
+            const Cd d = {a.x - b.x, a.y - b.y};
+            const Cd l = P.last[x];
+            out = Cd{(l.x + t1.x) + c2 * d.x, (l.y + t1.y) + c2 * d.y};   // :521
+        }
+        P.next[x] = out;
+    }
+}
+
+// TK (snum,tnum) complex -> out (snum,tnum) real: ifft over the traces done by rocFFT, /snum here (:491)
+__global__ __launch_bounds__(256) void ffd_real_out(const Cd *__restrict__ Z, double *__restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = Z[i].x;
+}
+
+__global__ __launch_bounds__(256) void ffd_scale(Cd *__restrict__ Z, size_t n, double div)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        Z[i].x /= div;
+        Z[i].y /= div;
+    }
+}
+
+extern "C" int impdar_phaseshift_ffd(impdar_ctx *ctx, const double *data, int snum, int tnum, int nt, const double *kx,
+                                     const double *ws, double dt, const double *tt_us, const double *vmig2d,
+                                     double dx_mean, double htaper, double vtaper, double *out)
+{
+    IMPDAR_ARG_CHECK(ctx && data && out && kx && ws && tt_us && vmig2d, "null argument");
+    IMPDAR_ARG_CHECK(snum >= 1 && tnum >= 2 && nt >= snum, "bad sizes snum %d tnum %d nt %d", snum, tnum, nt);
+    IMPDAR_ARG_CHECK((size_t)tnum * 16 + 2 * 256 * 16 <= 150 * 1024, "the finite-difference step keeps a trace row in LDS: "
+                     "tnum %d is above its 9000-trace limit", tnum);
+    IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t nreal = (size_t)snum * tnum;
+    DevBuf din, dout, X, TK, L, N, d_kx, d_vm, d_vbg, d_thr;
+    IMPDAR_HIP_CHECK(din.ensure(nreal * 8));
+    IMPDAR_HIP_CHECK(dout.ensure(nreal * 8));
+    IMPDAR_HIP_CHECK(X.ensure((size_t)nt * tnum * 16));
+    IMPDAR_HIP_CHECK(TK.ensure(nreal * 16));
+    IMPDAR_HIP_CHECK(L.ensure((size_t)tnum * 16));
+    IMPDAR_HIP_CHECK(N.ensure((size_t)tnum * 16));
+    IMPDAR_HIP_CHECK(d_kx.ensure((size_t)tnum * 8));
+    IMPDAR_HIP_CHECK(d_vm.ensure(nreal * 8));
+    IMPDAR_HIP_CHECK(d_vbg.ensure((size_t)snum * 8));
+    IMPDAR_HIP_CHECK(d_thr.ensure((size_t)snum * 8));
+    std::vector<double> w(ws, ws + nt), thr(snum), vbg(snum);
+    for (int i = 0; i < nt; ++i)
+        if (w[i] == 0.0) w[i] = 1.0e-10 / dt;                            // :445-447
+    for (int i = 0; i < snum; ++i) {
+        const double tau = tt_us[i] / 1.0e6;
+        const double r = tau / tt_us[snum - 1] / 1e6;                    // :484
+        thr[i] = r * r;
+        double m = vmig2d[(size_t)i * tnum];
+        for (int j = 1; j < tnum; ++j) m = std::min(m, vmig2d[(size_t)i * tnum + j]);   // :450
+        vbg[i] = m;
+    }
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(din.p, data, nreal * 8, hipMemcpyHostToDevice, st));
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(d_kx.p, kx, (size_t)tnum * 8, hipMemcpyHostToDevice, st));
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(d_vm.p, vmig2d, nreal * 8, hipMemcpyHostToDevice, st));
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(d_vbg.p, vbg.data(), (size_t)snum * 8, hipMemcpyHostToDevice, st));
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(d_thr.p, thr.data(), (size_t)snum * 8, hipMemcpyHostToDevice, st));
+    IMPDAR_HIP_CHECK(hipMemsetAsync(TK.p, 0, nreal * 16, st));
+    IMPDAR_HIP_CHECK(hipMemsetAsync(L.p, 0, (size_t)tnum * 16, st));
+
+    const rocfft_array_type ci = rocfft_array_type_complex_interleaved;
+    FftPlan f_x, f_t, row_inv, row_fwd, tk_inv;
+    int rc;
+    // fft2(data, (nt, tnum)) (:270): over the traces (contiguous), then over time (stride tnum)
+    if ((rc = f_x.create(rocfft_transform_type_complex_forward, true, true, tnum, nt, ci, ci, 1, tnum, 1, tnum, 1.0, st))) return rc;
+    if ((rc = f_t.create(rocfft_transform_type_complex_forward, true, true, nt, tnum, ci, ci, tnum, 1, tnum, 1, 1.0, st))) return rc;
+    if ((rc = row_inv.create(rocfft_transform_type_complex_inverse, true, true, tnum, 1, ci, ci, 1, tnum, 1, tnum, 1.0 / tnum, st))) return rc;
+    if ((rc = row_fwd.create(rocfft_transform_type_complex_forward, true, false, tnum, 1, ci, ci, 1, tnum, 1, tnum, 1.0, st))) return rc;
+    if ((rc = tk_inv.create(rocfft_transform_type_complex_inverse, true, true, tnum, snum, ci, ci, 1, tnum, 1, tnum, 1.0 / tnum, st))) return rc;
+
+    const unsigned gall = (unsigned)(((size_t)nt * tnum + 255) / 256);
+    hipLaunchKernelGGL(ffd_load, dim3(gall), dim3(256), 0, st, din.as<double>(), X.as<Cd>(), snum, tnum, nt, htaper, vtaper);
+    if ((rc = f_x.exec(X.p, nullptr))) return rc;
+    if ((rc = f_t.exec(X.p, nullptr))) return rc;
+
+    FfdStep S;
+    S.FK = X.as<Cd>();
+    S.TK = TK.as<Cd>();
+    S.kx = d_kx.as<double>();
+    S.vmig = d_vm.as<double>();
+    S.vbg = d_vbg.as<double>();
+    S.thr = d_thr.as<double>();
+    S.tnum = tnum;
+    S.dt = dt;
+    S.post_iw = -1;
+    S.post_itau = 0;
+    S.post_w = 1.0;
+    const unsigned grow = (unsigned)((tnum + 255) / 256);
+    const size_t mid_lds = ((size_t)tnum + 512) * 16;
+    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ffd_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_lds));
+    Cd *last = L.as<Cd>(), *next = N.as<Cd>();
+    for (int itau = 0; itau < snum; ++itau)
+        for (int iw = 0; iw < nt; ++iw) {
+            S.pre_itau = itau;
+            S.pre_iw = iw;
+            S.pre_w = w[iw];
+            hipLaunchKernelGGL(ffd_post_pre, dim3(grow), dim3(256), 0, st, S);
+            Cd *row = X.as<Cd>() + (size_t)iw * tnum;
+            if ((rc = row_inv.exec(row, nullptr))) return rc;                       // :467
+            FfdMid M;
+            M.row = row;
+            M.last = last;
+            M.next = next;
+            M.vmig = d_vm.as<double>() + (size_t)itau * tnum;
+            M.vbg = vbg[itau];
+            M.w = w[iw];
+            M.dt = dt;
+            M.dx = dx_mean;
+            M.tnum = tnum;
+            M.first = itau == 0;
+            hipLaunchKernelGGL(ffd_mid, dim3(1), dim3(256), mid_lds, st, M);
+            if ((rc = row_fwd.exec(next, row))) return rc;                          // :481
+            std::swap(last, next);                                                   // FFX_last = FFX, :478
+            S.post_itau = itau;
+            S.post_iw = iw;
+            S.post_w = w[iw];
+        }
+    S.pre_iw = -1;
+    hipLaunchKernelGGL(ffd_post_pre, dim3(grow), dim3(256), 0, st, S);
+    IMPDAR_HIP_CHECK(hipGetLastError());
+    const unsigned gtk = (unsigned)((nreal + 255) / 256);
+    hipLaunchKernelGGL(ffd_scale, dim3(gtk), dim3(256), 0, st, TK.as<Cd>(), nreal, (double)snum);     // :491
+    if ((rc = tk_inv.exec(TK.p, nullptr))) return rc;                                                  // :282
+    hipLaunchKernelGGL(ffd_real_out, dim3(gtk), dim3(256), 0, st, TK.as<Cd>(), dout.as<double>(), nreal);
+    IMPDAR_HIP_CHECK(hipGetLastError());
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(out, dout.p, nreal * 8, hipMemcpyDeviceToHost, st));
+    IMPDAR_HIP_CHECK(hipStreamSynchronize(st));
+    return IMPDAR_OK;
+}
+
 extern "C" int impdar_taper(impdar_ctx *ctx, void *data_inout, int dtype, int snum, int tnum, double htaper,
                             double vtaper)
 {

@@ -175,9 +175,9 @@ def migrationStolt(dat, vel=1.68e8, htaper=100, vtaper=1000):
 # ---------------------------------------------------------------------------
 def migrationPhaseShift(dat, vel=1.69e8, vel_fn=None, htaper=100, vtaper=1000, **genfromtxt_kwargs):
     """Phase-shift (Gazdag) migration (mig_python.py:211-287; kernel semantics
-    :361-493).  Constant ``vel`` or a 2-column (v, z) table / ``vel_fn`` file.
-    The 3-column v(x, z) Fourier-finite-difference branch is not implemented
-     and raises NotImplementedError."""
+    :361-493).  Constant ``vel``, a 2-column (v, z) table or a 3-column
+    (v, z, x) table / ``vel_fn`` file; the last runs the 2-D v(x, z) Fourier
+    finite-difference branch (:428-432, 448-487, 496-540) in float64."""
     print('Phase-Shift Migration of %.0fx%.0f matrix' % (dat.snum, dat.tnum))
     _check_data_shape(dat)
     start = time.time()
@@ -208,7 +208,24 @@ def migrationPhaseShift(dat, vel=1.69e8, vel_fn=None, htaper=100, vtaper=1000, *
         if len(vmig) != dat.snum:
             raise ValueError('Interpolated velocity profile is not the length of the number of samples in a trace.')
         if hasattr(vmig[0], '__len__'):
-            raise NotImplementedError('2-D v(x,z) Fourier finite-difference migration is not implemented')
+            print('2-D velocity structure, Fourier Finite-Difference Migration')
+            vm2 = np.ascontiguousarray(vmig, dtype=np.float64)
+            if vm2.shape != (dat.snum, dat.tnum):
+                raise ValueError('2-D velocity array must have shape (snum, tnum)')
+            d64 = np.ascontiguousarray(dat.data, dtype=np.float64)
+            out = np.empty((dat.snum, dat.tnum), dtype=np.float64)
+            tt_us, p_tt = _hip.as_dp(dat.travel_time)
+            _, p_kx = _hip.as_dp(kx)
+            _, p_ws = _hip.as_dp(ws)
+            rc = lib.impdar_phaseshift_ffd(ctx, _hip.as_dp(d64)[1], dat.snum, dat.tnum, nt, p_kx, p_ws, float(dat.dt),
+                                           p_tt, _hip.as_dp(vm2)[1], float(np.mean(dat.trace_int)), float(htaper),
+                                           float(vtaper), _hip.as_dp(out)[1])
+            _hip.check(rc, 'impdar_phaseshift_ffd')
+            dat.data = out
+            print('')
+            print('Phase-Shift Migration of %.0fx%.0f matrix complete in %.2f seconds'
+                  % (dat.snum, dat.tnum, time.time() - start))
+            return dat
         print('1-D velocity structure, Gazdag Migration')
         vconst = 0.0
         vm, p_vm = _hip.as_dp(vmig)
@@ -270,18 +287,17 @@ def _interp_checked(x, y, xnew):
         raise ValueError('A value in x_new is below the interpolation range.')
     if np.any(xnew > x[-1]):
         raise ValueError('A value in x_new is above the interpolation range.')
-    hi = np.clip(np.searchsorted(x, xnew), 1, len(x) - 1)
-    lo = hi - 1
-    with np.errstate(invalid='ignore', divide='ignore'):
-        slope = (y[hi] - y[lo]) / (x[hi] - x[lo])
-    return slope * (xnew - x[lo]) + y[lo]
+    # numpy.interp is what SciPy's 1-D linear interp1d evaluates with (same slope formula; repeated
+    # abscissae resolve to the last of the equal knots instead of 0/0)
+    return np.interp(xnew, x, y)
 
 
 def getVelocityProfile(dat, vels_in):
-    """Map a layered velocity table onto the samples of a trace
+    """Map a velocity table onto the samples of the traces
     (mig_python.py:543-643).  Scalar -> returned unchanged; 2-column (v, z)
-    -> 1-D profile of length snum; the error cases of :572-588, :639 raise
-    ValueError as in the reference."""
+    -> 1-D profile of length snum; 3-column (v, z, x) -> (snum, tnum) array
+    (nearest-neighbour gridding, then t(z) per trace); the error cases of
+    :572-588, :614, :632, :639 raise ValueError as in the reference."""
     if not hasattr(vels_in, '__len__'):
         return vels_in
     start = time.time()
@@ -313,10 +329,26 @@ def getVelocityProfile(dat, vels_in):
         zoft = _interp_checked(tofz, zs, twtt)
         vmig = 2. * np.gradient(zoft, twtt)
     elif dimension == 3:
+        vel_x = vels_in[:, 2]
+        # depth axis for the largest penetration range (:610-612)
+        zs = np.linspace(np.min(vel_v) * twtt[0], np.max(vel_v) * twtt[-1], dat.snum) / 2.
         if dat.dist is None or np.all(np.asarray(dat.dist) == 0):
             raise ValueError('The distance vector was never set.')
-        raise NotImplementedError('3-column (v, z, x) velocity tables (2-D Fourier finite-difference '
-                                  'migration) are not implemented')
+        dist = np.asarray(dat.dist, dtype=np.float64)
+        # nearest-neighbour gridding of the table onto the (dist, zs) mesh (:616-618), one trace at a time
+        vmig = np.zeros((dat.snum, dat.tnum))
+        dz = np.diff(zs)
+        for i in range(dat.tnum):
+            d2 = (dist[i] - vel_x[None, :]) ** 2 + (zs[:, None] - vel_z[None, :]) ** 2
+            v = vel_v[np.argmin(d2, axis=1)]
+            # t(z) = 2 * integral of dz / v over the samples ABOVE z (:626: trapz over the first j points)
+            cum = np.concatenate([[0.], np.cumsum(dz * (1. / v[1:] + 1. / v[:-1]) / 2.)])
+            vel_t = 2. * np.concatenate([[0.], cum[:-1]])
+            tofz = _interp_checked(zs, vel_t, zs)
+            if twtt[-1] > tofz[-1]:
+                raise ValueError('Two-way travel time array extends outside of interpolation range')
+            zoft = _interp_checked(tofz, zs, twtt)
+            vmig[:, i] = 2. * np.gradient(zoft, twtt)
     else:
         raise ValueError('Input must be 2d with 2 or 3 columns')
     print('Velocity profile finished in %.2f seconds.' % (time.time() - start))

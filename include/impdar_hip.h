@@ -152,6 +152,20 @@ int impdar_phaseshift(impdar_ctx *ctx, const void *data, int dtype, int snum, in
                       const double *tt_us, double vconst, const double *vmig, int vmig_len,
                       double htaper, double vtaper, void *out);
 
+/* ---- phase shift, 2-D v(x,z): Fourier finite-difference branch ----------
+ * Replaces the `hasattr(vmig[itau], "__len__")` path of phaseShift
+ * (mig_python.py:428-432, 448-487) with fourierFiniteDiff (:496-525) and the
+ * stencil of Sp_Matr (:528-540), behind migrationPhaseShift (:211-287).
+ * float64 only.  data/out: host (snum, tnum) row-major; vmig2d: host
+ * (snum, tnum) migration velocities (getVelocityProfile's 3-column output);
+ * kx (tnum), ws (nt) as for impdar_phaseshift; dx_mean = mean(trace_int).
+ * The (tau, omega) nest is one serial chain in the reference (a single
+ * FFX_last); it is executed in that order. */
+int impdar_phaseshift_ffd(impdar_ctx *ctx, const double *data, int snum, int tnum, int nt,
+                          const double *kx, const double *ws, double dt, const double *tt_us,
+                          const double *vmig2d, double dx_mean, double htaper, double vtaper,
+                          double *out);
+
 /* ---- taper only (what mtype='tk' does, mig_python.py:330-335) ---------- */
 int impdar_taper(impdar_ctx *ctx, void *data_inout, int dtype, int snum, int tnum,
                  double htaper, double vtaper);

@@ -22,7 +22,7 @@ import numpy as np
 __all__ = [
     "check_data_shape", "taper", "kirchhoff", "kirchhoff_literal",
     "kirchhoff_pick", "stolt", "phase_shift", "phase_shift_tk",
-    "time_wavenumber", "get_velocity_profile", "count_pairs",
+    "time_wavenumber", "get_velocity_profile", "count_pairs", "phase_shift_ffd_tk",
 ]
 
 
@@ -220,11 +220,64 @@ def stolt(data, dt, trace_int, dist_km=None, vel=1.68e8, htaper=100, vtaper=1000
 # --------------------------------------------------------------------------
 # Phase shift (Gazdag)
 # --------------------------------------------------------------------------
-def phase_shift_tk(FK, vmig, kx, ws, dt, travel_time_us, snum, tnum):
+def _ffd_stencil_apply(x):
+    """stencil * x for stencil = Sp_Matr(N, -2, 1, 1) (mig_python.py:528-540) as the
+    reference actually builds it: the k3 = 0 ``setdiag(..., k=0)`` at :533 overwrites
+    the main diagonal with zeros, row 0 is e_0 and the last row is all ones."""
+    y = np.empty_like(x)
+    y[1:-1] = x[:-2] + x[2:]
+    y[0] = x[0]
+    y[-1] = np.sum(x)
+    return y
+
+
+def phase_shift_ffd_tk(FK, vmig, kx, ws, dt, travel_time_us, trace_int_mean, snum, tnum,
+                       alpha=0.5, beta=0.25):
+    """2-D v(x,z) branch of phaseShift (mig_python.py:428-432,448-487) with
+    fourierFiniteDiff (:496-525).  Literal loops (small cases only): the update of
+    one frequency uses the previous frequency's field (``FFX_last`` is a single
+    variable, :478), so the whole (tau, omega) nest is one serial chain."""
+    FK = np.array(FK, dtype=np.complex128)
+    vmig = np.asarray(vmig, dtype=np.float64)
+    tt = np.asarray(travel_time_us, dtype=np.float64)
+    TK = np.zeros((snum, len(kx)), dtype=np.complex128)
+    dx = trace_int_mean
+    FFX_last = 0.
+    for itau in range(snum):
+        tau = tt[itau] / 1.0e6
+        vbg = np.min(vmig[itau])
+        vfg = vmig[itau] - vbg
+        ufg = 1. / vmig[itau] - 1. / vbg
+        for iw in range(len(ws)):
+            w = ws[iw]
+            if w == 0.0:
+                w = 1.0e-10 / dt
+            coss = 1.0 + 0j - (0.5 * vbg * kx / w) ** 2.
+            phase = (-w * dt * np.sqrt(coss)).real
+            FK[iw] *= np.conj(np.cos(phase) + 1j * np.sin(phase))
+            FFX = np.fft.ifft(FK[iw])
+            phase2 = 2. * ufg * w * dt + 1. * vbg * w * dt
+            FFX = FFX * (np.cos(phase2) + 1j * np.sin(phase2))
+            if itau > 0:
+                coeff1 = dt * alpha * vfg ** 2. / (1j * 4. * w * dx ** 2.)
+                coeff2 = -beta * vfg ** 2. / (4. * w ** 2. * dx ** 2.)
+                sf = _ffd_stencil_apply(FFX)
+                sl = _ffd_stencil_apply(FFX_last)
+                FFX = FFX_last + coeff1 * sf + coeff2 * (sf - sl)
+            FFX_last = FFX
+            FK[iw] = np.fft.fft(FFX)
+            FK[iw, coss <= (tau / tt[-1] / 1e6) ** 2.] = 0.0 + 0j
+            TK[itau] += FK[iw]
+    TK = TK[:, :tnum]
+    return TK / snum
+
+
+def phase_shift_tk(FK, vmig, kx, ws, dt, travel_time_us, snum, tnum, trace_int_mean=None):
     """phaseShift (mig_python.py:361-493): FK (nt, tnum) -> TK (snum, tnum).
 
     ``vmig`` scalar -> constant-velocity branch (:396-420);
-    1-D array of length snum -> Gazdag v(z) branch (:438-487).
+    1-D array of length snum -> Gazdag v(z) branch (:438-487);
+    2-D (snum, tnum) -> Fourier finite-difference branch (phase_shift_ffd_tk).
     FK is not modified (the reference mutates it in the v(z) branch).
     """
     FK = np.array(FK, dtype=np.complex128)
@@ -246,7 +299,7 @@ def phase_shift_tk(FK, vmig, kx, ws, dt, travel_time_us, snum, tnum):
         if len(vmig) != snum:
             raise ValueError('Interpolated velocity profile is not the length of the number of samples in a trace.')
         if vmig.ndim != 1:
-            raise NotImplementedError('2-D v(x,z) Fourier finite-difference branch (SURVEY 8f-4)')
+            return phase_shift_ffd_tk(FK, vmig, kx, ws, dt, travel_time_us, trace_int_mean, snum, tnum)
         tt = np.asarray(travel_time_us, dtype=np.float64)
         F = FK
         for itau in range(snum):
@@ -262,8 +315,8 @@ def phase_shift_tk(FK, vmig, kx, ws, dt, travel_time_us, snum, tnum):
 
 def phase_shift(data, dt, trace_int, travel_time_us, dist_km=None, vel=1.69e8,
                 htaper=100, vtaper=1000):
-    """migrationPhaseShift (mig_python.py:211-287) for scalar or (v,z)-table
-    ``vel``.  Returns float64 (snum, tnum)."""
+    """migrationPhaseShift (mig_python.py:211-287) for scalar, (v,z)-table or
+    (v,z,x)-table ``vel``.  Returns float64 (snum, tnum)."""
     data = np.asarray(data)
     if not np.issubdtype(data.dtype, np.floating):
         # :258 in-place multiply of an integer array by floats raises
@@ -274,8 +327,9 @@ def phase_shift(data, dt, trace_int, travel_time_us, dist_km=None, vel=1.69e8,
     kx = _kx(tnum, trace_int, dist_km)
     ws = 2. * np.pi * np.fft.fftfreq(nt, d=dt)
     FK = np.fft.fft2(tap, (nt, tnum))
-    vmig = get_velocity_profile(travel_time_us, vel)
-    TK = phase_shift_tk(FK, vmig, kx, ws, dt, travel_time_us, snum, tnum)
+    vmig = get_velocity_profile(travel_time_us, vel, dist_km)
+    TK = phase_shift_tk(FK, vmig, kx, ws, dt, travel_time_us, snum, tnum,
+                        trace_int_mean=np.mean(trace_int))
     return np.fft.ifft(TK).real
 
 
@@ -304,17 +358,22 @@ def _interp1d_strict(x, y, xnew):
         raise ValueError('A value in x_new is below the interpolation range.')
     if np.any(xnew > x[-1]):
         raise ValueError('A value in x_new is above the interpolation range.')
-    # interp1d's linear rule: hi = searchsorted(x, xnew) clipped to [1, n-1]
-    hi = np.clip(np.searchsorted(x, xnew), 1, len(x) - 1)
-    lo = hi - 1
-    with np.errstate(invalid='ignore', divide='ignore'):
-        slope = (y[hi] - y[lo]) / (x[hi] - x[lo])
-    return slope * (xnew - x[lo]) + y[lo]
+    # SciPy (1.15 here) evaluates a 1-D linear interp1d with numpy.interp: same slope formula as the
+    # classic searchsorted rule, but repeated abscissae pick the LAST of the equal knots instead of
+    # dividing by zero (this matters for the 3-column branch, whose t(z) starts with two zeros)
+    return np.interp(xnew, x, y)
 
 
-def get_velocity_profile(travel_time_us, vels_in):
-    """getVelocityProfile (mig_python.py:543-643), scalar and 2-column (v, z)
-    branches.  The 3-column (v, z, x) branch is SURVEY 8f-4 ("next")."""
+def _nearest_values(px, pz, pv, qx, qz):
+    """griddata(..., method='nearest') (mig_python.py:617): value of the table
+    point closest (Euclidean, in the raw (x, z) coordinates) to each query."""
+    d2 = (qx[:, None] - px[None, :]) ** 2 + (qz[:, None] - pz[None, :]) ** 2
+    return pv[np.argmin(d2, axis=1)]
+
+
+def get_velocity_profile(travel_time_us, vels_in, dist_km=None):
+    """getVelocityProfile (mig_python.py:543-643): scalar, 2-column (v, z) and
+    3-column (v, z, x) tables (the last needs ``dist_km``; returns (snum, tnum))."""
     if not hasattr(vels_in, '__len__'):
         return vels_in
     if len(np.shape(vels_in)) != 2 or np.shape(vels_in)[1] == 1:
@@ -343,5 +402,28 @@ def get_velocity_profile(travel_time_us, vels_in):
         zoft = _interp1d_strict(tofz, zs, twtt)
         return 2. * np.gradient(zoft, twtt)
     if dimension == 3:
-        raise NotImplementedError('3-column (v, z, x) velocity tables: SURVEY 8f-4')
+        vel_x = vels_in[:, 2]
+        snum = len(twtt)
+        zs = np.linspace(np.min(vel_v) * twtt[0], np.max(vel_v) * twtt[-1], snum) / 2.       # :610-612
+        if dist_km is None or np.all(np.asarray(dist_km) == 0):
+            raise ValueError('The distance vector was never set.')                           # :614-615
+        dist = np.asarray(dist_km, dtype=np.float64)
+        tnum = len(dist)
+        # nearest-neighbour gridding onto the (dist, zs) mesh (:616-618); note the table's x is
+        # compared with dat.dist as is (the reference mixes km and m here)
+        XS, ZS = np.meshgrid(dist, zs)
+        VS = _nearest_values(vel_x, vel_z, vel_v, XS.ravel(), ZS.ravel()).reshape(XS.shape)
+        vmig = np.zeros_like(VS)
+        for i in range(tnum):                                                                # :622-636
+            v = VS[:, i]
+            # vel_t[j] = 2 * trapz(1/v[:j], zs[:j]): integral over the first j points
+            seg = np.diff(zs) * (1. / v[1:] + 1. / v[:-1]) / 2.
+            cum = np.concatenate([[0.], np.cumsum(seg)])          # cum[m] = integral over points 0..m
+            vel_t = 2. * np.concatenate([[0.], cum[:-1]])         # j points -> cum[j-1]; j = 0 -> 0
+            tofz = _interp1d_strict(zs, vel_t, zs)
+            if twtt[-1] > tofz[-1]:
+                raise ValueError('Two-way travel time array extends outside of interpolation range')
+            zoft = _interp1d_strict(tofz, zs, twtt)
+            vmig[:, i] = 2. * np.gradient(zoft, twtt)
+        return vmig
     raise ValueError('Input must be 2d with 2 or 3 columns')

@@ -5,7 +5,7 @@ synthetic inputs.  Only runs in the build container; the committed ``*.npz``
 files are what travels.  Each fixture stores inputs, expected outputs and the
 NumPy/SciPy versions that produced them.
 
-Usage:  python tests/golden/make_golden.py [--skip-slow]
+Usage:  python tests/golden/make_golden.py [--skip-slow] [--only PREFIX[,PREFIX...]]
 """
 import contextlib
 import io
@@ -44,7 +44,15 @@ def quiet(fn, *a, **k):
         return fn(*a, **k)
 
 
+ONLY = None
+for _i, _a in enumerate(sys.argv):
+    if _a == '--only':
+        ONLY = sys.argv[_i + 1].split(',')
+
+
 def save(name, **arrs):
+    if ONLY is not None and not any(name.startswith(p) for p in ONLY):
+        return
     path = os.path.join(HERE, name + '.npz')
     np.savez_compressed(path, **arrs, **VERS)
     print('wrote', path, os.path.getsize(path), 'bytes')
@@ -134,7 +142,40 @@ def velprof_cases():
     out['tt_c'] = geo['travel_time']
     out['tab_c'] = tab
     out['vmig_c'] = quiet(ref.getVelocityProfile, d, tab)
+    # 3-column (v, z, x) table: the reference's own fixture on its own test geometry
+    # (test/test_migrationlib.py:69-70; t(z) starts with two equal knots there) ...
+    lateral = np.genfromtxt('/root/reference/test/input_data/velocity_lateral.txt')
+    d = NoInitRadarData(big=True)
+    out['tt_lat'] = np.asarray(d.travel_time, dtype=np.float64)
+    out['dist_lat'] = np.asarray(d.dist, dtype=np.float64)
+    out['tab_lat'] = lateral
+    out['vmig_lat'] = quiet(ref.getVelocityProfile, d, lateral)
+    # ... and on a physical geometry (the one the FFD fixtures use)
+    geo = ffd_geometry(32, 16)
+    d = make_dat(np.zeros((32, 16)), geo)
+    out['tt_lat2'] = geo['travel_time']
+    out['dist_lat2'] = geo['dist']
+    out['vmig_lat2'] = quiet(ref.getVelocityProfile, d, lateral)
     save('P3_velocity_profile', **out)
+
+
+def ffd_geometry(snum, tnum, dt=1e-8, dx=5.0):
+    """Geometry on which the reference's 2-D v(x,z) branch accepts its own velocity_lateral.txt
+    (depths 16-124 m, x 9-77 compared with dist as is) and stays finite: first sample at dt."""
+    return dict(travel_time=(np.arange(snum) * dt + dt) * 1e6, dist=np.arange(tnum) * dx / 1e3,
+                trace_int=np.ones(tnum) * dx, dt=dt)
+
+
+def ffd_case(name, snum, tnum, htaper, vtaper, seed):
+    lateral = np.genfromtxt('/root/reference/test/input_data/velocity_lateral.txt')
+    geo = ffd_geometry(snum, tnum)
+    data = np.random.default_rng(seed).standard_normal((snum, tnum))
+    dat = make_dat(data, geo)
+    vmig = quiet(ref.getVelocityProfile, dat, lateral)
+    quiet(ref.migrationPhaseShift, dat, vel=lateral, htaper=htaper, vtaper=vtaper)
+    assert np.isfinite(dat.data).all() and np.abs(dat.data).max() < 1e3
+    save(name, data=data, travel_time=geo['travel_time'], dist=geo['dist'], trace_int=geo['trace_int'],
+         dt=geo['dt'], vel=lateral, htaper=htaper, vtaper=vtaper, expected=dat.data, vmig=np.asarray(vmig))
 
 
 def tk_case():
@@ -182,6 +223,9 @@ def main():
     tab = [[1.69e8, 0.], [1.5e8, 0.3 * Rp], [1.9e8, 0.6 * Rp], [1.9e8, 1.2 * Rp]]
     phsh_case('P2b_phsh_vz_50x70', 50, 70, 1e-8, 2.0, tab, 8, 6)
     velprof_cases()
+    # 2-D v(x,z) Fourier finite-difference branch (mig_python.py:428-432,448-487,496-540)
+    ffd_case('P4_phsh_ffd_32x16', 32, 16, 3, 4, 0)
+    ffd_case('P4b_phsh_ffd_32x21', 32, 21, 2, 2, 1)
     tk_case()
 
 

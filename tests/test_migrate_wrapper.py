@@ -83,8 +83,20 @@ def test_velocity_profile_host_logic():
     bad[:, 1] = 0.
     with pytest.raises(ValueError):
         getVelocityProfile(d, bad)
-    with pytest.raises(NotImplementedError):                      # 3-column v(x,z): SURVEY 8f-4, not built yet
-        getVelocityProfile(d, 1.68e8 * np.ones((10, 3)))
+    # 3-column (v, z, x) table: the reference's fixture on its own test geometry and on a physical one
+    # (test/test_migrationlib.py:69-75)
+    for c in ('lat', 'lat2'):
+        d = NoInitRadarData(big=True)
+        d.travel_time = g['tt_' + c]
+        d.dist = g['dist_' + c]
+        d.snum, d.tnum = len(d.travel_time), len(d.dist)
+        vm = getVelocityProfile(d, g['tab_lat'])
+        assert vm.shape == (d.snum, d.tnum)
+        assert np.allclose(vm, g['vmig_' + c], rtol=1e-12, atol=0)
+    d = NoInitRadarData(big=True)
+    d.dist = None
+    with pytest.raises(ValueError):
+        getVelocityProfile(d, g['tab_lat'])
     d.dist = None
     with pytest.raises(ValueError):
         getVelocityProfile(d, 1.68e8 * np.ones((10, 3)))

@@ -46,12 +46,34 @@ def test_phase_shift(name):
     assert np.array_equal(np.asarray(vm), g['vmig'])
 
 
+@pytest.mark.parametrize('name', golden_names('P4'))
+def test_phase_shift_ffd(name):
+    # 2-D v(x,z) Fourier finite-difference branch (mig_python.py:428-432,448-487,496-540)
+    g = golden(name)
+    out = o.phase_shift(g['data'], float(g['dt']), g['trace_int'], g['travel_time'], g['dist'], g['vel'],
+                        int(g['htaper']), int(g['vtaper']))
+    assert rel_max(out, g['expected']) < TOL
+    vm = o.get_velocity_profile(g['travel_time'], g['vel'], g['dist'])
+    assert vm.shape == g['vmig'].shape == g['data'].shape
+    assert rel_max(vm, g['vmig']) < TOL
+
+
 def test_velocity_profile():
     g = golden('P3_velocity_profile')
     for c in 'abc':
         vm = o.get_velocity_profile(g['tt_' + c], g['tab_' + c])
         assert np.array_equal(vm, g['vmig_' + c])
     assert o.get_velocity_profile(np.arange(10.), 1.68e8) == 1.68e8
+    # 3-column (v, z, x) table (mig_python.py:606-636); cumulative trapezoid instead of the reference's
+    # O(snum^2) per-prefix np.trapz: equal to rounding
+    for c in ('lat', 'lat2'):
+        vm = o.get_velocity_profile(g['tt_' + c], g['tab_lat'], g['dist_' + c])
+        assert vm.shape == g['vmig_' + c].shape
+        assert np.isfinite(vm).all() and rel_max(vm, g['vmig_' + c]) < TOL
+    with pytest.raises(ValueError):            # test/test_migrationlib.py:72-75
+        o.get_velocity_profile(g['tt_lat'], g['tab_lat'], None)
+    with pytest.raises(ValueError):
+        o.get_velocity_profile(g['tt_lat'], g['tab_lat'], np.zeros(20))
 
 
 def test_velocity_profile_errors():

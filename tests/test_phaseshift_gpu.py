@@ -41,6 +41,42 @@ def test_golden_float32(hip, name):
     assert rel_l2(dat.data, g['expected']) < F32_L2, rel_l2(dat.data, g['expected'])
 
 
+@pytest.mark.parametrize('name', golden_names('P4'))
+def test_golden_ffd(hip, name):
+    """2-D v(x,z) Fourier finite-difference branch (mig_python.py:428-432,448-487,496-540) with the
+    reference's own 3-column table (test/input_data/velocity_lateral.txt, stored in the fixture)."""
+    g = golden(name)
+    dat = make_dat(g)
+    from impdar_amd.lib import migrationlib
+    migrationlib.migrationPhaseShift(dat, vel=g['vel'], htaper=int(g['htaper']), vtaper=int(g['vtaper']))
+    assert dat.data.dtype == np.float64 and dat.data.shape == g['expected'].shape
+    assert rel_max(dat.data, g['expected']) < F64_TOL, rel_max(dat.data, g['expected'])
+
+
+def test_ffd_vs_oracle_and_float32(hip, tmp_path):
+    """A second geometry against the oracle, the table read from a file (test_PhaseShiftLateral,
+    test/test_migrationlib.py:133-135), and float32 data (computed in float64 here)."""
+    from oracle import mig_oracle
+    from impdar_amd.lib import migrationlib
+    g = golden('P4_phsh_ffd_32x16')
+    rng = np.random.default_rng(11)
+    snum, tnum = 32, 19
+    data = rng.standard_normal((snum, tnum))
+    gg = dict(data=data, travel_time=g['travel_time'], dist=np.arange(tnum) * 5.0 / 1e3,
+              trace_int=np.ones(tnum) * 5.0, dt=g['dt'])
+    want = mig_oracle.phase_shift(data, float(g['dt']), gg['trace_int'], gg['travel_time'], gg['dist'], g['vel'], 4, 3)
+    fn = tmp_path / 'velocity_lateral.txt'
+    np.savetxt(fn, g['vel'])
+    dat = make_dat(gg)
+    migrationlib.migrationPhaseShift(dat, vel_fn=str(fn), htaper=4, vtaper=3)
+    assert rel_max(dat.data, want) < F64_TOL, rel_max(dat.data, want)
+    dat = make_dat(gg)
+    dat.data = dat.data.astype(np.float32)
+    migrationlib.migrationPhaseShift(dat, vel=g['vel'], htaper=4, vtaper=3)
+    assert dat.data.dtype == np.float64
+    assert rel_l2(dat.data, want) < F32_L2, rel_l2(dat.data, want)
+
+
 def test_velocity_file_and_errors(hip, tmp_path):
     """test/test_migrationlib.py:120-131: constant, layered from a file,
     TypeError for an unreadable file."""
