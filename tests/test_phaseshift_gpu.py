@@ -94,6 +94,12 @@ def test_velocity_file_and_errors(hip, tmp_path):
     data = NoInitRadarData(big=True)
     with pytest.raises(TypeError):
         migrationlib.migrationPhaseShift(data, vel_fn=str(tmp_path / 'notafile.txt'))
+    # test_PhaseShiftLateral (test/test_migrationlib.py:133-135): 3-column table, all-zero data
+    fn = tmp_path / 'velocity_lateral.txt'
+    np.savetxt(fn, golden('P3_velocity_profile')['tab_lat'])
+    data = NoInitRadarData(big=True)
+    data = migrationlib.migrationPhaseShift(data, vel_fn=str(fn))
+    assert data.data.shape == (10, 20) and not data.data.any()
     data = NoInitRadarData(big=True)
     data.data = data.data.astype(int)
     with pytest.raises(TypeError):
