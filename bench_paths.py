@@ -3,7 +3,11 @@
 BASELINE config 2 (4096x4096 float32) and phase-shift at config 5 (8192x8192,
 constant v and 1-D v(z)), each through the product path on one MI355X.
 Prints one JSON line per path.  Host wall time includes H2D/D2H of the
-radargram (the entry points take host buffers)."""
+radargram (the entry points take host buffers).  Each line carries a
+``cpu_baseline``: the NumPy oracle (a port of the reference's algorithm in
+closed form, far faster than the reference's Python loops) timed on the host
+cores of the same box on a bounded sample, with the sample stated.  Kernel
+times: run under ``rocprofv3 --kernel-trace --stats`` (profiles/r01_paths_*)."""
 import argparse
 import json
 import sys
@@ -20,6 +24,7 @@ def main():
     ap.add_argument('--phsh', type=int, default=8192)
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--skip', default='')
+    ap.add_argument('--no-cpu', action='store_true')
     args = ap.parse_args()
     from impdar_amd import _hip, synth
     from impdar_amd.lib.RadarData import RadarData
@@ -46,28 +51,56 @@ def main():
             best = el if best is None else min(best, el)
         return best, d
 
+    def cpu(fn, label):
+        if args.no_cpu:
+            return None
+        from oracle import mig_oracle                      # the checker, timed as the CPU baseline
+        t0 = time.perf_counter()
+        fn(mig_oracle)
+        el = time.perf_counter() - t0
+        return {"seconds": el, "kind": "port", "cores": 1, "sample": label}
+
     rng = np.random.default_rng(0)
     if 'stolt' not in args.skip:
         n = args.stolt
         geo = synth.geometry(n, n)
         x = rng.standard_normal((n, n)).astype(np.float32)
         el, d = timed(lambda d: migrationlib.migrationStolt(d, htaper=100, vtaper=1000), lambda: dat_of(x.copy(), geo))
+        cb = cpu(lambda o: o.stolt(x, geo['dt'], geo['trace_int'], geo['dist'], 1.68e8, 100, 1000),
+                 "NumPy oracle, same %dx%d float32 radargram, one process" % (n, n))
         print(json.dumps({"path": "stolt", "config": "%dx%d float32 (BASELINE config 2)" % (n, n),
                           "host_seconds": el, "traces_per_s": n / el, "finite": bool(np.isfinite(d.data).all()),
-                          "reference_seconds_same_size": 100.30}), flush=True)
+                          "algorithmic_bytes": 40 * n * n, "reference_seconds_same_size": 100.30,
+                          "cpu_baseline": cb}), flush=True)
     if 'phsh' not in args.skip:
         n = args.phsh
         geo = synth.geometry(n, n)
         x = rng.standard_normal((n, n)).astype(np.float32)
         el, d = timed(lambda d: migrationlib.migrationPhaseShift(d, vel=1.69e8), lambda: dat_of(x.copy(), geo))
+        m = min(n, 1024)
+        gs = synth.geometry(m, m)
+        xs = x[:m, :m].astype(np.float64)
+        cb = cpu(lambda o: o.phase_shift(xs, gs['dt'], gs['trace_int'], gs['travel_time'], gs['dist'], 1.69e8),
+                 "NumPy oracle on a %dx%d corner (work scales with snum*nt*tnum: x%d for the full size)"
+                 % (m, m, (n // m) ** 3))
         print(json.dumps({"path": "phase-shift const v", "config": "%dx%d float32" % (n, n), "host_seconds": el,
-                          "traces_per_s": n / el, "finite": bool(np.isfinite(d.data).all())}), flush=True)
+                          "traces_per_s": n / el, "finite": bool(np.isfinite(d.data).all()),
+                          "rotate_accumulate_steps": float(n) ** 3, "cpu_baseline": cb}), flush=True)
         Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
         tab = np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rp], [1.8e8, 0.5 * Rp], [1.9e8, 1.2 * Rp]])
         el, d = timed(lambda d: migrationlib.migrationPhaseShift(d, vel=tab), lambda: dat_of(x.copy(), geo))
+        m = min(n, 512)
+        gs = synth.geometry(m, m)
+        xs = x[:m, :m].astype(np.float64)
+        Rs = 1.9e8 * gs['travel_time'][-1] * 1e-6 / 2.
+        tabs = np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rs], [1.8e8, 0.5 * Rs], [1.9e8, 1.2 * Rs]])
+        cb = cpu(lambda o: o.phase_shift(xs, gs['dt'], gs['trace_int'], gs['travel_time'], gs['dist'], tabs),
+                 "NumPy oracle on a %dx%d radargram (work scales with snum*nt*tnum: x%d for the full size)"
+                 % (m, m, (n // m) ** 3))
         print(json.dumps({"path": "phase-shift v(z) Gazdag", "config": "%dx%d float32 (BASELINE config 5)" % (n, n),
                           "host_seconds": el, "traces_per_s": n / el, "finite": bool(np.isfinite(d.data).all()),
-                          "reference_extrapolated_hours": 7.6}), flush=True)
+                          "rotate_accumulate_steps": float(n) ** 3, "reference_extrapolated_hours": 7.6,
+                          "cpu_baseline": cb}), flush=True)
 
 
 if __name__ == '__main__':
