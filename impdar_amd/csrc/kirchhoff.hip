@@ -6,19 +6,19 @@
 //   src/impdar/lib/migrationlib/mig_cython.h:11       mig_kirch_loop (native hook)
 //
 // Kernels:
-//   kirch_prep_kernel   time gradient (numpy.gradient semantics, :93) fused
-//                       with the (snum,tnum) -> trace-major (tnum,snum)
-//                       transpose, so one input trace is one contiguous run.
-//   kirch_exact_kernel  per-pair fp64 index math in the reference's operation
-//                       order; any dist / travel_time; float or double data.
-//   kirch_table_kernel  fp64 pick index + obliquity weight per (sample, |offset|)
-//                       in the reference's operation order (uniform trace spacing).
-//   kirch_quad_kernel   the MI355X hot path: fp32 data, uniform grids.  A
-//                       workgroup owns 256 output samples x 24 output traces;
-//                       input traces stream through a sample-major LDS ring read
-//                       with ds_read_b128; pick/weight come from the table.
-//   kirch_tab_kernel    same idea with a trace-major ring and ds_read_b32, for
-//                       geometries whose moveout does not fit the quad ring.
+//   kirch_prep_kernel    time gradient (numpy.gradient semantics, :93) fused with the
+//                        (snum,tnum) -> trace-major (tnum,snum) transpose, or into groups of 8
+//                        traces that are sample-major inside (the quad kernel's image).
+//   kirch_exact_kernel   per-pair fp64 index math in the reference's operation
+//                        order; any dist / travel_time; float or double data.
+//   kirch_tableq_kernel  fp64 pick per (sample, trace offset) in the reference's operation order
+//                        (uniform grids), stored by step block as the LDS offset of the picked row.
+//   kirch_quad_kernel    the MI355X hot path: fp32 data, uniform grids.  A workgroup owns 256
+//                        output samples x 24 output traces; input traces stream by LDS-DMA through
+//                        a 40-trace LDS ring read with ds_read_b128; picks come from the table.
+//   kirch_table_kernel / kirch_tab_kernel
+//                        same idea with a trace-major ring, ds_read_b32 and an fp32 weight table,
+//                        for geometries whose moveout does not fit the quad ring.
 #include "common.h"
 #include <cmath>
 #include <algorithm>
@@ -179,13 +179,13 @@ struct FastParams {
     int ldo;
     int snum, tnum, xlo, xhi;
     const int *hmax;               // per sample-chunk aperture half width (+1 guard)     [nchunks]
+    int nchunks, nxt, tiles_per_xcd, G;
+    // tab kernel only:
     const int *klo, *khi;          // per (chunk, |n|) first / last sample a trace at offset n is asked for
     int nb;                        // entries per chunk in klo/khi
     int zero_row;                  // index of an all-zero image row (out-of-profile traces)
-    int nchunks, nxt, tiles_per_xcd, G;
-    // pick/weight table: entry (|n|, ti)
-    const unsigned short *TK;      // offset of the picked sample's row inside a ring slot    [ntab][snum]
-    const float *TW, *TW2;         // far / near weights (0 where the reference drops the pair); tab kernel only
+    const unsigned short *TK;      // pick table (|n|, ti): offset of the picked sample inside a ring slot [ntab][snum]
+    const float *TW, *TW2;         // far / near weights (0 where the reference drops the pair)
     // quad kernel: cos(theta) = sign(a) * rsq(1 + c1 n^2) with a = tt/dt, c1 = alpha / a^2; the far-field sum is
     // scaled by fin = sign(a) / (2 pi v) once at the end, the near-field weight is c2 * cos^3 in those units
     const float *c1, *c2, *fin;    // per sample [snum]
@@ -197,7 +197,7 @@ struct FastParams {
                                    //   x = kmin | (kmin mod W) << 16, y = kmax
     int nrows, mrow0;
     unsigned long long *stamps;    // diagnostic builds only (-DKQ_STAMP): per-workgroup {start, end, hw id, chunk|steps}
-    int ntab;                      // rows; the last row is all zero (|n| beyond every aperture)
+    int ntab;                      // tab kernel: table rows; the last row is all zero (|n| beyond every aperture)
 };
 
 // ---------------------------------------------------------------------------
