@@ -128,6 +128,7 @@ struct ExactParams {
     int snum, tnum, xlo, xhi;
     const double *dist, *zs, *zs2, *tt;
     double vel, tmax, r2lim, inv_dt, tt0;
+    int dist_sorted;     // dist is non-decreasing: the traces inside the aperture are one index range
 };
 
 template <typename T, bool NEAR>
@@ -142,7 +143,31 @@ __global__ __launch_bounds__(256) void kirch_exact_kernel(ExactParams P)
     const double z = P.zs[ti], z2 = P.zs2[ti];
     const int n = P.snum;
     double far = 0.0, near = 0.0;
-    for (int j = 0; j < P.tnum; ++j) {
+    int jlo = 0, jhi = P.tnum;
+    if (P.dist_sorted) {
+        // traces with (dist - dist[xi])^2 + z^2 <= r2lim form one index range: bisect its ends (a guard
+        // trace on both sides; the per-pair test below still decides)
+        const double rad2 = P.r2lim - z2;
+        if (rad2 < 0.0) {
+            jhi = 0;
+        } else {
+            const double rad = sqrt(rad2) * (1.0 + 1e-12);
+            int a = 0, b = xi;                       // first j with dist[j] >= dxi - rad
+            while (a < b) {
+                const int m = (a + b) >> 1;
+                if (P.dist[m] < dxi - rad) a = m + 1; else b = m;
+            }
+            jlo = max(a - 1, 0);
+            a = xi;
+            b = P.tnum;                              // first j with dist[j] > dxi + rad
+            while (a < b) {
+                const int m = (a + b) >> 1;
+                if (P.dist[m] <= dxi + rad) a = m + 1; else b = m;
+            }
+            jhi = min(a + 1, P.tnum);
+        }
+    }
+    for (int j = jlo; j < jhi; ++j) {
         const double dx = P.dist[j] - dxi;
         const double q = dx * dx + z2;                 // :44 (compiled with -ffp-contract=off)
         if (q > P.r2lim) continue;                     // far outside the aperture
@@ -491,6 +516,10 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_tab_kernel(FastParams P
                             // pieces then keep distinct banks inside one ds_read_b128 lane group)
 #define KQ_ZERO 1024        // byte offset of the all-zero row (spare row of piece 0, group 0; + g * KQ_GS)
 static_assert(KQ_PS == 5376 && KQ_PS >= 5 * KQ_GS && KQ_ZERO == 1024, "kq_row_offset / kirch_tableq_kernel use these literally");
+#ifndef KQ_PER
+#define KQ_PER 4            // quads per interleave slice (1..7 all measure within 2 %; 4 keeps 97 VGPRs)
+#endif
+#define KQ_PARTS ((7 + KQ_PER - 1) / KQ_PER)
 typedef float kq_f4 __attribute__((ext_vector_type(4)));
 typedef unsigned kq_u4 __attribute__((ext_vector_type(4)));
 
@@ -663,14 +692,18 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     };
     // pm = step index mod RG (a compile-time constant after unrolling), tk = the step's table entry =
     // byte offset of half 0 of the picked row; quad qd = ring slots 4 qd .. 4 qd + 3 = half qd & 1 of group qd >> 1
-    auto load_step = [&](int pm, unsigned tk, kq_f4 (&v)[NQ], kq_f4 (&u)[NEAR ? NQ : 1]) {
+    // position of quad qd in the step's run of 6-7 needed quads (they are consecutive, cyclically)
+    auto run_pos = [](int pm, int qd) { return (qd - ((pm + 1) % RG) / 4 + NQ) % NQ; };
+    // `part` selects a slice of the run (KQ_PARTS slices; -1 = all): reads and FMAs are interleaved slice
+    // by slice so that a wave's ds_read_b128 do not arrive at the LDS queue as one burst of 7
+    auto load_step = [&](int pm, unsigned tk, kq_f4 (&v)[NQ], kq_f4 (&u)[NEAR ? NQ : 1], int part) {
         // LDS pointers built from the table's byte offsets directly: the dynamic LDS block of this kernel
         // starts at LDS address 0 (no static __shared__; checked once in the prologue), so no base is added
         typedef const __attribute__((address_space(3))) kq_f4 *lds_f4p;
         const unsigned a0 = tk << SH, a1 = a0 ^ 16u;
 #pragma unroll
         for (int qd = 0; qd < NQ; ++qd)
-            if (needed(pm, qd)) {
+            if (needed(pm, qd) && (part < 0 || run_pos(pm, qd) / KQ_PER == part)) {
                 // must stay a whole ds_read_b128 also for the partly used quads at the ends of
                 // the window: fma_step marks the unused components as used (empty asm)
                 const unsigned src = ((qd & 1) ? a1 : a0) + (qd >> 1) * KQ_GS;
@@ -682,9 +715,10 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
                 if (NEAR) u[qd] = *(lds_f4p)(uintptr_t)(src + img_bytes);
             }
     };
-    auto fma_step = [&](int pm, float w, float w2, const kq_f4 (&v)[NQ], const kq_f4 (&u)[NEAR ? NQ : 1]) {
+    auto fma_step = [&](int pm, float w, float w2, const kq_f4 (&v)[NQ], const kq_f4 (&u)[NEAR ? NQ : 1], int part) {
 #pragma unroll
         for (int qd = 0; qd < NQ; ++qd) {
+            if (part >= 0 && run_pos(pm, qd) / KQ_PER != part) continue;
             // outputs served by slots 4qd .. 4qd+3 at this step
             const int i0 = (4 * qd + 0 - pm - 1 + 2 * RG) % RG;
             const int i1 = (4 * qd + 1 - pm - 1 + 2 * RG) % RG;
@@ -733,7 +767,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     float n2c[S];                                  // n^2 of the current block's steps
 #pragma unroll
     for (int s = 0; s < S; ++s) n2c[s] = n2_of(s);
-    load_step(0, KQ_TK(tkc, 0), va, ua);           // step 0 of block 0
+    load_step(0, KQ_TK(tkc, 0), va, ua, -1);       // step 0 of block 0
     for (int rev = 0; rev < nrev; ++rev) {
 #pragma clang loop unroll(full)
         for (int bb = 0; bb < NB; ++bb) {              // block index within the ring revolution
@@ -763,13 +797,21 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
                 for (int s = 0; s < S; ++s) n2c[s] = n2_of((blk + 1) * S + s);
             }
 #define KQ_W2(s) (NEAR ? tw2c[NEAR ? (s) : 0] : 0.f)
-            load_step(pm0 + 1, KQ_TK(tkc, 1), vb, ub); KQ_PIN(); fma_step(pm0 + 0, twc[0], KQ_W2(0), va, ua); KQ_PIN();
-            load_step(pm0 + 2, KQ_TK(tkc, 2), va, ua); KQ_PIN(); fma_step(pm0 + 1, twc[1], KQ_W2(1), vb, ub); KQ_PIN();
-            load_step(pm0 + 3, KQ_TK(tkc, 3), vb, ub); KQ_PIN(); fma_step(pm0 + 2, twc[2], KQ_W2(2), va, ua); KQ_PIN();
-            load_step(pm0 + 4, KQ_TK(tkc, 4), va, ua); KQ_PIN(); fma_step(pm0 + 3, twc[3], KQ_W2(3), vb, ub); KQ_PIN();
-            load_step(pm0 + 5, KQ_TK(tkc, 5), vb, ub); KQ_PIN(); fma_step(pm0 + 4, twc[4], KQ_W2(4), va, ua); KQ_PIN();
-            load_step(pm0 + 6, KQ_TK(tkc, 6), va, ua); KQ_PIN(); fma_step(pm0 + 5, twc[5], KQ_W2(5), vb, ub); KQ_PIN();
-            load_step(pm0 + 7, KQ_TK(tkc, 7), vb, ub); KQ_PIN(); fma_step(pm0 + 6, twc[6], KQ_W2(6), va, ua); KQ_PIN();
+#define KQ_UNPACK(...) __VA_ARGS__
+#define KQ_STEP(L, F)                                                                          \
+    do {                                                                                       \
+        _Pragma("unroll") for (int part = 0; part < KQ_PARTS; ++part) {                      \
+            load_step(KQ_UNPACK L, part); KQ_PIN();                                            \
+            fma_step(KQ_UNPACK F, part); KQ_PIN();                                             \
+        }                                                                                      \
+    } while (0)
+            KQ_STEP((pm0 + 1, KQ_TK(tkc, 1), vb, ub), (pm0 + 0, twc[0], KQ_W2(0), va, ua));
+            KQ_STEP((pm0 + 2, KQ_TK(tkc, 2), va, ua), (pm0 + 1, twc[1], KQ_W2(1), vb, ub));
+            KQ_STEP((pm0 + 3, KQ_TK(tkc, 3), vb, ub), (pm0 + 2, twc[2], KQ_W2(2), va, ua));
+            KQ_STEP((pm0 + 4, KQ_TK(tkc, 4), va, ua), (pm0 + 3, twc[3], KQ_W2(3), vb, ub));
+            KQ_STEP((pm0 + 5, KQ_TK(tkc, 5), vb, ub), (pm0 + 4, twc[4], KQ_W2(4), va, ua));
+            KQ_STEP((pm0 + 6, KQ_TK(tkc, 6), va, ua), (pm0 + 5, twc[5], KQ_W2(5), vb, ub));
+            KQ_STEP((pm0 + 7, KQ_TK(tkc, 7), vb, ub), (pm0 + 6, twc[6], KQ_W2(6), va, ua));
             // ---- barrier after step 6.  The new traces are first read by step 0 of the next block, whose
             // reads are issued below; each wave retires its own DMA (and the pick load) first.  The LDS
             // reads of step 7 stay in flight across the barrier, so the read pipeline never drains.
@@ -779,14 +821,15 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
 #ifndef KQ_DIAG_NOBAR
             asm volatile("s_barrier" ::: "memory");
 #endif
-            load_step((pm0 + 8) % RG, KQ_TK(tkn, 0), va, ua); KQ_PIN();
 #if !defined(KQ_DIAG_NOSTAGE)
             // every wave is past step 6 of this block: the ring group of the traces last read there is free
             dma_issue(blk + 2, wa);
             wa = wn;
 #endif
-            fma_step(pm0 + 7, twc[7], KQ_W2(7), vb, ub); KQ_PIN();
+            KQ_STEP(((pm0 + 8) % RG, KQ_TK(tkn, 0), va, ua), (pm0 + 7, twc[7], KQ_W2(7), vb, ub));
 #undef KQ_W2
+#undef KQ_STEP
+#undef KQ_UNPACK
             tkc = tkn;
         }
     }
@@ -826,6 +869,7 @@ struct impdar_kirch_plan {
     int grad_uniform = 0;
     double grad_h = 1.0, vel = 0, tmax = 0, dt = 1, dx = 1, tt0 = 0, alpha = 1;
     bool uniform = false;
+    bool dist_sorted = false;
     // device tables
     DevBuf d_dist, d_tt, d_zs, d_zs2, d_ga, d_gb, d_gc;
     // Everything a prep produces is double-buffered: prep / table / all-gather of radargram
@@ -931,6 +975,9 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         for (int j = 0; j < tnum && uni_x; ++j)
             if (std::fabs(dist_m[j] - (dist_m[0] + j * dx)) > 1e-9 * dx) uni_x = false;
     }
+    p->dist_sorted = true;
+    for (int j = 1; j < tnum; ++j)
+        if (!(dist_m[j] >= dist_m[j - 1])) p->dist_sorted = false;
     p->dt = dt;
     p->dx = dx;
     p->tt0 = tt_sec[0];
@@ -1378,6 +1425,7 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         P.r2lim = rlim * rlim * (1.0 + 1e-9);
         P.inv_dt = 1.0 / p->dt;
         P.tt0 = p->tt0;
+        P.dist_sorted = p->dist_sorted ? 1 : 0;
         dim3 grid((p->snum + 255) / 256, nx);
         if (p->dtype == IMPDAR_F32) {
             if (p->nearfield)
