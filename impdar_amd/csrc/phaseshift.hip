@@ -122,6 +122,7 @@ struct PsParams {
     const double *vz;       // [snum] (v(z) mode)
     const double *thr;      // [snum] (v(z) mode): (tau/tt[-1]/1e6)^2
     double vconst, dt;
+    double vtol;            // float32 v(z): relative velocity change below which the phase increments are reused
     int snum, tnum, nt, vz_mode;
 };
 
@@ -180,12 +181,26 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
     Cp<T> *TK = reinterpret_cast<Cp<T> *>(P.TK) + (size_t)k * P.snum;
     const double kxk = P.kx[k];
 
-    T fr[M], fi[M];          // complex state per owned frequency
-    T pa[M], pb[M];          // const-v: (cos phi, sin phi); v(z): (g = (kx/2w)^2, w*dt)
+    // float32 data: a multiplicative recurrence in fp32 drifts systematically (the rounded rotation is the
+    // same at every depth step of a constant-velocity run: 8192 steps x 6e-8 = 5e-4 .. 2e-3 at config 5),
+    // so the accumulated phase is kept in fp64 and the spectrum is rotated from its ORIGINAL value:
+    //   constant v: recurrence, re-anchored to FK0 * exp(i tau phi) every 64 depth steps
+    //   v(z):       Phi += w dt sqrt(coss) in fp64 (the increment is recomputed in fp64 only when the
+    //               velocity changes), F = FK0 * exp(i Phi) every step
+    // float64 data keeps the reference's recurrence (rounding 1e-16 per step).
+    constexpr bool F32 = sizeof(T) == 4;
+    T fr[M], fi[M];          // complex state per owned frequency (F32 v(z): the original spectrum FK0)
+    T pa[M], pb[M];          // const-v: (cos phi, sin phi); v(z) fp64: (g = (kx/2w)^2, w*dt); v(z) fp32: (coss, -)
+    double phd[F32 ? M : 1]; // F32: phase increment per depth step (const v: phi; v(z): w dt sqrt(coss))
+    double Phi[F32 && VZ ? M : 1];   // F32 v(z): accumulated phase, kept in [-pi, pi]
+    T f0r[F32 && !VZ ? M : 1], f0i[F32 && !VZ ? M : 1];   // F32 const v: original spectrum for re-anchoring
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const int iw = tid + m * BLOCK;
         fr[m] = fi[m] = pa[m] = pb[m] = 0;
+        if (F32) phd[F32 ? m : 0] = 0.0;
+        if (F32 && VZ) Phi[F32 && VZ ? m : 0] = 0.0;
+        if (F32 && !VZ) f0r[F32 && !VZ ? m : 0] = f0i[F32 && !VZ ? m : 0] = 0;
         if (iw < P.nt) {
             const Cp<T> f = F[iw];
             const double w = P.w[iw];
@@ -200,6 +215,11 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
                     pb[m] = (T)s;
                     fr[m] = f.x;
                     fi[m] = f.y;
+                    if (F32) {
+                        phd[F32 ? m : 0] = ph;
+                        f0r[F32 && !VZ ? m : 0] = f.x;
+                        f0i[F32 && !VZ ? m : 0] = f.y;
+                    }
                 }
             } else {
                 const double h = 0.5 * kxk / w;                         // coss = 1 - (v h)^2, :458
@@ -212,6 +232,10 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
         // one frequency's fp64 set-up at a time (interleaved, the M chains spill)
         asm volatile("" : "+v"(fr[m]), "+v"(fi[m]), "+v"(pa[m]), "+v"(pb[m]));
     }
+    // float32 helpers: exp(i x) for a phase kept in fp64, |x| <= pi after the wrap
+    auto rot32 = [](double ph, T *s, T *c) { sincos_t<T>((T)ph, s, c); };
+    double v_prev = -1.0;    // F32 v(z): velocity the increments phd[] were computed for
+    unsigned edge = 0;       // F32 v(z): bit m = frequency m sits on the evanescent boundary (|coss| < 1e-8)
 
     const int ntile = (P.snum + PS_TT - 1) / PS_TT;
     for (int tile = 0; tile < ntile; ++tile) {
@@ -223,6 +247,20 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
         // all M x TT of them and the live temporaries spill; threading the state through an empty
         // volatile asm after every (tau, frequency) update pins the order without adding code.
         if (!VZ) {
+            if (F32 && tile > 0 && (tile & 3) == 0) {
+                // re-anchor: state after tau0 steps = FK0 * exp(i tau0 phi), phase reduced in fp64
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const double x = (double)tau0 * phd[F32 ? m : 0];
+                    const double r = x - 6.283185307179586 * rint(x * 0.15915494309189535);
+                    T sn, cs;
+                    rot32(r, &sn, &cs);
+                    const T a = f0r[F32 && !VZ ? m : 0], b = f0i[F32 && !VZ ? m : 0];
+                    fr[m] = fma(a, cs, -(b * sn));
+                    fi[m] = fma(a, sn, b * cs);
+                    asm volatile("" : "+v"(fr[m]), "+v"(fi[m]));
+                }
+            }
 #pragma unroll
             for (int t = 0; t < PS_TT; ++t) {
 #pragma unroll
@@ -233,6 +271,76 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
                     fi[m] = ni;
                     acc[2 * t] += nr;                                   // TK[itau] += FFK, :420
                     acc[2 * t + 1] += ni;
+                    asm volatile("" : "+v"(fr[m]), "+v"(fi[m]), "+v"(acc[2 * t]), "+v"(acc[2 * t + 1]));
+                }
+            }
+        } else if (F32) {
+#pragma unroll
+            for (int t = 0; t < PS_TT; ++t) {
+                const int tau = min(tau0 + t, P.snum - 1);
+                const double vd = P.vz[tau];
+                const T thr = (T)P.thr[tau];
+                const bool live_tau = (tau0 + t) < P.snum;
+                if (fabs(vd - v_prev) > P.vtol * fabs(vd)) {
+                    // new velocity (a wave-uniform branch; layered profiles take it a few times): the phase
+                    // increment of every owned frequency in fp64, from the fp64 frequency axis.  Velocities
+                    // within 1e-10 of the last one reuse its increments: 2*gradient(z(t)) of a layered
+                    // table is constant inside a layer up to ~4e-13 of rounding noise, and a 1e-10 velocity
+                    // error moves the phase by < 3e-6 rad over 8192 steps (float32 path only).
+                    v_prev = vd;
+                    edge = 0;
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        const int iw = tid + m * BLOCK;
+                        double inc = 0.0, cs = 1.0;
+                        if (iw < P.nt) {
+                            const double w = P.w[iw];
+                            const double a = 0.5 * vd * kxk / w;        // :456
+                            cs = 1.0 - a * a;
+                            inc = w * P.dt * (cs > 0.0 ? sqrt(cs) : 0.0);   // :458-460
+                        }
+                        phd[F32 ? m : 0] = inc;
+                        pa[m] = (T)cs;
+                        edge |= (fabs(cs) < 1e-8 ? 1u : 0u) << m;
+                        asm volatile("" : "+v"(pa[m]));
+                    }
+                } else if (edge) {
+                    // A frequency on the evanescent boundary (coss = 0 to rounding; with round-number
+                    // geometries whole families of (kx, w) sit exactly there) is kept or dropped for good
+                    // by the sign of coss, which the reference re-evaluates with every step's velocity:
+                    // do exactly that for those lanes (a handful per radargram), in fp64.
+#pragma unroll
+                    for (int m = 0; m < M; ++m)
+                        if ((edge >> m) & 1u) {
+                            const double w = P.w[tid + m * BLOCK];
+                            const double a = 0.5 * vd * kxk / w;
+                            const double cs = 1.0 - a * a;
+                            phd[F32 ? m : 0] = w * P.dt * (cs > 0.0 ? sqrt(cs) : 0.0);
+                            pa[m] = (T)cs;
+                        }
+                }
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    double ph = Phi[F32 && VZ ? m : 0] + phd[F32 ? m : 0];
+                    // negative frequencies rotate the other way: wrap on both sides
+                    ph -= ph > 3.141592653589793 ? 6.283185307179586 : 0.0;
+                    ph += ph < -3.141592653589793 ? 6.283185307179586 : 0.0;
+                    T s, c;
+                    rot32(ph, &s, &c);
+                    T nr = fma(fr[m], c, -(fi[m] * s));                 // FK0 * exp(i Phi), :464 cumulated
+                    T ni = fma(fr[m], s, fi[m] * c);
+                    const bool dead = pa[m] <= thr;                     // :484-485, stays zero afterwards
+                    if (live_tau) {
+                        Phi[F32 && VZ ? m : 0] = ph;
+                        if (dead) {
+                            fr[m] = 0;
+                            fi[m] = 0;
+                            nr = 0;
+                            ni = 0;
+                        }
+                        acc[2 * t] += nr;                               // :487
+                        acc[2 * t + 1] += ni;
+                    }
                     asm volatile("" : "+v"(fr[m]), "+v"(fi[m]), "+v"(acc[2 * t]), "+v"(acc[2 * t + 1]));
                 }
             }
@@ -387,6 +495,10 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     P.tnum = tnum;
     P.nt = nt;
     P.vz_mode = vlen ? 1 : 0;
+    {
+        const char *e = getenv("IMPDAR_PS_VTOL");     // diagnostic knob
+        P.vtol = e ? atof(e) : 1e-10;
+    }
     if ((rc = ps_dispatch<T>(P, st))) return rc;
     if ((rc = pl.b_trace.exec(pl.TK.p, nullptr))) return rc;
     dim3 bgrid((tnum + 63) / 64, (snum + 63) / 64);

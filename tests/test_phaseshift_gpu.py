@@ -77,6 +77,52 @@ def test_ffd_vs_oracle_and_float32(hip, tmp_path):
     assert rel_l2(dat.data, want) < F32_L2, rel_l2(dat.data, want)
 
 
+@pytest.mark.parametrize('kind', ['vz', 'const'])
+def test_config5_size_spot_wavenumbers_and_linearity(hip, kind):
+    """BASELINE config 5 (8192 x 8192 float32, 1-D v(z) table; also constant v) at full size.  Wavenumbers are independent
+    in phaseShift (mig_python.py:438-487), so the oracle is run on a few (k, -k) column pairs of the 2-D
+    spectrum and compared with the same columns of the GPU image transformed back over x:
+    fft_x(Re ifft_k TK)[k] = (TK[k] + conj(TK[-k])) / 2.  Plus linearity of the whole image."""
+    from impdar_amd import synth
+    from impdar_amd.lib.RadarData import RadarData
+    from oracle import mig_oracle
+    n = 8192
+    geo = synth.geometry(n, n)
+    Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+    tab = np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rp], [1.8e8, 0.5 * Rp], [1.9e8, 1.2 * Rp]]) if kind == 'vz' else 1.69e8
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((n, n)).astype(np.float32)
+    y = rng.standard_normal((n, n)).astype(np.float32)
+
+    def run(a):
+        d = RadarData(None)
+        d.data, d.snum, d.tnum = a, n, n
+        d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
+        d.migrate('phsh', vel=tab, htaper=100, vtaper=1000)
+        return d.data
+
+    mx = run(x.copy())
+    assert mx.dtype == np.float64 and mx.shape == (n, n) and np.isfinite(mx).all()
+    if kind == 'vz':
+        my = run(y.copy())
+        mz = run((2 * x - 3 * y).astype(np.float32))
+        assert rel_l2(mz, 2.0 * mx - 3.0 * my) < F32_L2
+        del my, mz
+    # oracle on spot wavenumbers (the taper and the 2-D FFT restated with NumPy, float32 data as given)
+    tap = mig_oracle._apply_taper(x, 100, 1000, inplace_form=True).astype(np.float32)
+    ks = np.array([0, 1, 37, 1000, 4095])
+    cols = np.concatenate([ks, (n - ks) % n])
+    FKc = np.fft.fft(np.fft.fft(tap.astype(np.float64), axis=1)[:, cols], n=n, axis=0)     # (nt = n, len(cols))
+    kx = mig_oracle._kx(n, geo['trace_int'], geo['dist'])[cols]
+    ws = 2. * np.pi * np.fft.fftfreq(n, d=geo['dt'])
+    vmig = mig_oracle.get_velocity_profile(geo['travel_time'], tab)
+    TK = mig_oracle.phase_shift_tk(FKc, vmig, kx, ws, geo['dt'], geo['travel_time'], n, len(cols))
+    want = 0.5 * (TK[:, :len(ks)] + np.conj(TK[:, len(ks):]))
+    got = np.fft.fft(mx, axis=1)[:, ks]
+    err = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert err < F32_L2, err
+
+
 def test_velocity_file_and_errors(hip, tmp_path):
     """test/test_migrationlib.py:120-131: constant, layered from a file,
     TypeError for an unreadable file."""
