@@ -259,3 +259,21 @@ def test_full_size_properties_config3(hip):
     lin = 0.5 * mx.astype(np.float64) - 2.0 * my.astype(np.float64)
     assert rel_l2(mz, lin) < 1e-5
     plan.destroy()
+
+
+def test_full_size_exact_kernel_config3(hip):
+    """BASELINE config 3 geometry (10000 x 4096) with float64 data through the product default (exact kernel,
+    the path the reference's own hook mig_kirch_loop binds): spot traces against the C oracle at the
+    float64 bar, the exactly-zero z = 0 row."""
+    from impdar_amd import synth
+    from impdar_amd.kirchhoff import migrate_resident
+    from oracle import c_oracle
+    snum, tnum, vel = 4096, 10000, 1.69e8
+    geo = synth.geometry(snum, tnum)
+    x = np.random.default_rng(4).standard_normal((snum, tnum))
+    out, mode, ms = migrate_resident(hip.context(), x, geo['dist'], geo['travel_time'], vel, mode='auto')
+    assert mode == 'exact' and out.dtype == np.float64 and np.isfinite(out).all()
+    assert not out[0].any()
+    cols = np.array([0, 2, 5000, 9999, 6543], dtype=np.int32)
+    want = c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], vel, traces=cols)
+    assert rel_max(out[:, cols], want) < EXACT_TOL, rel_max(out[:, cols], want)
