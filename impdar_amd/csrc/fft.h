@@ -58,6 +58,38 @@ struct FftPlan {
         }
         return IMPDAR_OK;
     }
+    // 2-D transform of one array: len0 along the contiguous axis, len1 rows `in_row` / `out_row` elements apart.
+    int create2d(rocfft_transform_type type, bool dbl, bool inplace, size_t len0, size_t len1, rocfft_array_type in_t,
+                 rocfft_array_type out_t, size_t in_row, size_t out_row, double scale, hipStream_t stream)
+    {
+        release();
+        int rc = impdar_fft_global_setup();
+        if (rc) return rc;
+        rocfft_plan_description desc = nullptr;
+        IMPDAR_FFT_CHECK(rocfft_plan_description_create(&desc));
+        size_t is[2] = {1, in_row}, os[2] = {1, out_row};
+        rocfft_status s = rocfft_plan_description_set_data_layout(desc, in_t, out_t, nullptr, nullptr, 2, is, in_row * len1,
+                                                                  2, os, out_row * len1);
+        if (s == rocfft_status_success && scale != 1.0) s = rocfft_plan_description_set_scale_factor(desc, scale);
+        size_t lengths[2] = {len0, len1};
+        if (s == rocfft_status_success)
+            s = rocfft_plan_create(&plan, inplace ? rocfft_placement_inplace : rocfft_placement_notinplace, type,
+                                   dbl ? rocfft_precision_double : rocfft_precision_single, 2, lengths, 1, desc);
+        rocfft_plan_description_destroy(desc);
+        if (s != rocfft_status_success) {
+            impdar_set_error("rocFFT 2-D plan creation failed (%zu x %zu, status %d)", len0, len1, (int)s);
+            return IMPDAR_ERR_FFT;
+        }
+        IMPDAR_FFT_CHECK(rocfft_execution_info_create(&info));
+        IMPDAR_FFT_CHECK(rocfft_execution_info_set_stream(info, stream));
+        size_t wb = 0;
+        IMPDAR_FFT_CHECK(rocfft_plan_get_work_buffer_size(plan, &wb));
+        if (wb) {
+            IMPDAR_HIP_CHECK(work.ensure(wb));
+            IMPDAR_FFT_CHECK(rocfft_execution_info_set_work_buffer(info, work.p, wb));
+        }
+        return IMPDAR_OK;
+    }
     int exec(void *in, void *out)
     {
         void *ib[1] = {in};

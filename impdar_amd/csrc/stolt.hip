@@ -132,7 +132,9 @@ __global__ void stolt_fix_hermitian(Cx<T> *K, int m, int tnum)
 
 struct StoltPlan {
     int dtype = -1, snum = 0, tnum = 0;
-    FftPlan r2c, c2c_f, c2c_b, c2r;
+    FftPlan r2c, c2c_f, c2c_b, c2r;     // separate passes (IMPDAR_STOLT_FFT=1d)
+    FftPlan fwd2d, inv2d;               // the same two pairs as 2-D real transforms (default)
+    bool use2d = true;
     DevBuf X, F, K, Y, d_kx, d_ws;
 };
 
@@ -149,6 +151,22 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
     if (pl.dtype != (dbl ? IMPDAR_F64 : IMPDAR_F32) || pl.snum != snum || pl.tnum != tnum) {
         pl.dtype = -1;
         int rc;
+        {
+            const char *e = getenv("IMPDAR_STOLT_FFT");          // tuning knob: "1d" = four 1-D passes
+            pl.use2d = !(e && !strcmp(e, "1d"));
+        }
+        // rfft2(axes=(1,0)) (:159) = real transform over time (contiguous here), complex over the traces (rows);
+        // irfft2 (:202) = complex inverse over the traces, then C2R over time.  rocFFT's 2-D real plans do
+        // exactly these two passes each, with its own blocked column kernels instead of a strided batch.
+        if (pl.use2d) {
+            if ((rc = pl.fwd2d.create2d(rocfft_transform_type_real_forward, dbl, false, snum, tnum, rocfft_array_type_real,
+                                        rocfft_array_type_hermitian_interleaved, snum, m, 1.0, st)))
+                return rc;
+            if ((rc = pl.inv2d.create2d(rocfft_transform_type_real_inverse, dbl, false, nout, tnum,
+                                        rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, m, nout,
+                                        1.0 / ((double)nout * tnum), st)))
+                return rc;
+        }
         if ((rc = pl.r2c.create(rocfft_transform_type_real_forward, dbl, false, snum, tnum, rocfft_array_type_real,
                                 rocfft_array_type_hermitian_interleaved, 1, snum, 1, m, 1.0, st)))
             return rc;
@@ -181,13 +199,21 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
     hipLaunchKernelGGL((stolt_taper_transpose<T>), tgrid, dim3(256), 0, st, (const T *)d_data, pl.X.as<T>(), snum, tnum,
                        htaper, vtaper, do_taper);
     int rc;
-    if ((rc = pl.r2c.exec(pl.X.p, pl.F.p))) return rc;
-    if ((rc = pl.c2c_f.exec(pl.F.p, nullptr))) return rc;
+    if (pl.use2d) {
+        if ((rc = pl.fwd2d.exec(pl.X.p, pl.F.p))) return rc;
+    } else {
+        if ((rc = pl.r2c.exec(pl.X.p, pl.F.p))) return rc;
+        if ((rc = pl.c2c_f.exec(pl.F.p, nullptr))) return rc;
+    }
     hipLaunchKernelGGL((stolt_stretch<T>), dim3((m + 255) / 256, tnum), dim3(256), 0, st, pl.F.as<Cx<T>>(),
                        pl.K.as<Cx<T>>(), pl.d_kx.as<double>(), pl.d_ws.as<double>(), m, nz, tnum, vel);
-    if ((rc = pl.c2c_b.exec(pl.K.p, nullptr))) return rc;
-    hipLaunchKernelGGL((stolt_fix_hermitian<T>), dim3((tnum + 255) / 256), dim3(256), 0, st, pl.K.as<Cx<T>>(), m, tnum);
-    if ((rc = pl.c2r.exec(pl.K.p, pl.Y.p))) return rc;
+    if (pl.use2d) {
+        if ((rc = pl.inv2d.exec(pl.K.p, pl.Y.p))) return rc;
+    } else {
+        if ((rc = pl.c2c_b.exec(pl.K.p, nullptr))) return rc;
+        hipLaunchKernelGGL((stolt_fix_hermitian<T>), dim3((tnum + 255) / 256), dim3(256), 0, st, pl.K.as<Cx<T>>(), m, tnum);
+        if ((rc = pl.c2r.exec(pl.K.p, pl.Y.p))) return rc;
+    }
     dim3 bgrid((tnum + 63) / 64, (nout + 63) / 64);
     hipLaunchKernelGGL((stolt_transpose_back<T>), bgrid, dim3(256), 0, st, pl.Y.as<T>(), (T *)d_out, nout, tnum);
     IMPDAR_HIP_CHECK(hipGetLastError());
