@@ -11,6 +11,9 @@
 //                        traces that are sample-major inside (the quad kernel's image).
 //   kirch_exact_kernel   per-pair fp64 index math in the reference's operation
 //                        order; any dist / travel_time; float or double data.
+//   kirch_tablex_kernel / kirch_exact_tab_kernel
+//                        the same fp64 picks and weights tabulated per (sample, |offset|) on uniform
+//                        grids: one gather + one fp64 FMA per pair (the float64 parity path).
 //   kirch_tableq_kernel  fp64 pick per (sample, trace offset) in the reference's operation order
 //                        (uniform grids), stored by step block as the LDS offset of the picked row.
 //   kirch_quad_kernel    the MI355X hot path: fp32 data, uniform grids.  A workgroup owns 256
@@ -193,6 +196,102 @@ __global__ __launch_bounds__(256) void kirch_exact_kernel(ExactParams P)
     const double c = 1.0 / (2.0 * 3.141592653589793);
     T *out = reinterpret_cast<T *>(P.out);
     out[(size_t)ti * P.ldo + (xi - P.xlo)] = (T)(c * (far + near));   // :60
+}
+
+// ---------------------------------------------------------------------------
+// exact path on uniform grids: the pick and the obliquity factor of a pair depend on (sample, |trace
+// offset|) only, so they are tabulated once per geometry -- in fp64, in the reference's operation order
+// (mig_python.py:44-58) -- and the diffraction sum becomes one gather + one fp64 FMA per pair.  Same
+// picks as kirch_exact_kernel; the weight cos/vel is rounded once more than the reference's
+// (g*cos)/vel (1 ulp, far inside the 1e-12 bar).
+// ---------------------------------------------------------------------------
+struct TableXParams {
+    int *XK;                 // [ntab][snum] picked sample (0 where the pair is dropped)
+    double *XW, *XW2;        // cos/vel and cos/rs^2 (0 where dropped: t > t_max or the 0/0 apex)
+    const double *zs, *zs2, *tt;
+    double dx, vel, tmax, inv_dt, tt0;
+    int snum, ntab, near;
+};
+
+__global__ __launch_bounds__(256) void kirch_tablex_kernel(TableXParams P)
+{
+    const int ti = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    if (ti >= P.snum) return;
+    const size_t o = (size_t)n * P.snum + ti;
+    int kk = 0;
+    double w = 0.0, w2 = 0.0;
+    const double dx = (double)n * P.dx;
+    const double q = dx * dx + P.zs2[ti];
+    const double rs = sqrt(q);
+    const double cost = P.zs[ti] / rs;
+    const double t = 2.0 * rs / P.vel;
+    if (!(t > P.tmax) && cost == cost) {
+        const int ns = P.snum;
+        int k0 = (int)floor((t - P.tt0) * P.inv_dt);
+        k0 = min(max(k0, 0), ns - 1);
+        while (k0 < ns - 1 && P.tt[k0 + 1] <= t) ++k0;
+        while (k0 > 0 && P.tt[k0] > t) --k0;
+        const int k1 = min(k0 + 1, ns - 1);
+        kk = (fabs(P.tt[k1] - t) < fabs(P.tt[k0] - t)) ? k1 : k0;
+        w = cost / P.vel;
+        w2 = cost / (rs * rs);
+    }
+    P.XK[o] = kk;
+    P.XW[o] = w;
+    if (P.near) P.XW2[o] = w2;
+}
+
+struct ExactTabParams {
+    const void *GT, *DT;
+    void *out;
+    int ldo, snum, tnum, xlo, xhi;
+    const int *XK;
+    const double *XW, *XW2;
+    const int *hmax;         // per 256-sample chunk: largest aperture half width of its samples
+    int ntab;
+};
+
+template <typename T, bool NEAR, int XE>
+__global__ __launch_bounds__(256) void kirch_exact_tab_kernel(ExactTabParams P)
+{
+    const int ti_raw = blockIdx.x * 256 + threadIdx.x;
+    const int ti = min(ti_raw, P.snum - 1);
+    const int x0 = P.xlo + blockIdx.y * XE;
+    const T *GT = reinterpret_cast<const T *>(P.GT);
+    const T *DT = reinterpret_cast<const T *>(P.DT);
+    const int hm = min(P.hmax[blockIdx.x], P.ntab - 1);
+    const int nlo = max(-hm, -(x0 + XE - 1)), nhi = min(hm, P.tnum - 1 - x0);
+    double far[XE], near[XE];
+#pragma unroll
+    for (int e = 0; e < XE; ++e) far[e] = near[e] = 0.0;
+    const size_t sn = (size_t)P.snum;
+    for (int n = nlo; n <= nhi; ++n) {
+        const size_t o = (size_t)abs(n) * sn + ti;
+        const int k = P.XK[o];
+        const double w = P.XW[o];
+        const double w2 = NEAR ? P.XW2[o] : 0.0;
+#pragma unroll
+        for (int e = 0; e < XE; ++e) {
+            const int j = x0 + e + n;
+            if (j >= 0 && j < P.tnum) {
+                const size_t g = (size_t)j * sn + k;
+                const double term = (double)GT[g] * w;            // :53
+                if (term == term) far[e] += term;                 // nansum
+                if (NEAR) {
+                    const double term2 = (double)DT[g] * w2;      // :58
+                    if (term2 == term2) near[e] += term2;
+                }
+            }
+        }
+    }
+    if (ti_raw < P.snum) {
+        const double c = 1.0 / (2.0 * 3.141592653589793);
+        T *out = reinterpret_cast<T *>(P.out);
+#pragma unroll
+        for (int e = 0; e < XE; ++e)
+            if (x0 + e < P.xhi) out[(size_t)ti_raw * P.ldo + (x0 + e - P.xlo)] = (T)(c * (far[e] + near[e]));   // :60
+    }
 }
 
 // ===========================================================================
@@ -870,6 +969,10 @@ struct impdar_kirch_plan {
     double grad_h = 1.0, vel = 0, tmax = 0, dt = 1, dx = 1, tt0 = 0, alpha = 1;
     bool uniform = false;
     bool dist_sorted = false;
+    // exact path on uniform grids: fp64 pick / weight tables (built at the first migrate)
+    DevBuf d_XK, d_XW, d_XW2, d_xhmax;
+    int xntab = 0;
+    bool xtab_ready = false, xtab_off = false;
     // device tables
     DevBuf d_dist, d_tt, d_zs, d_zs2, d_ga, d_gb, d_gc;
     // Everything a prep produces is double-buffered: prep / table / all-gather of radargram
@@ -1405,6 +1508,74 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         else
             rc = launch_tab<16, 4, 4>(p, P, nx, st);
         if (rc) return rc;
+    } else if (nx > 0 && p->uniform && !p->xtab_off && !(getenv("IMPDAR_KIRCH_EXACT_IMPL") &&
+                                                          !strcmp(getenv("IMPDAR_KIRCH_EXACT_IMPL"), "pair"))) {
+        // exact arithmetic on uniform grids: tabulated fp64 picks / weights, one gather + FMA per pair
+        const int nch = (p->snum + 255) / 256;
+        if (!p->xtab_ready) {
+            int hg = 0;
+            std::vector<int> hm(nch, 0);
+            for (int k = 0; k < p->snum; ++k) {
+                hm[k / 256] = std::max(hm[k / 256], p->h_half[k] + 1);
+                hg = std::max(hg, p->h_half[k] + 1);
+            }
+            hg = std::min(hg, p->tnum) + 1;
+            const size_t ent = (size_t)hg * p->snum;
+            if (p->d_XK.ensure(ent * 4) != hipSuccess || p->d_XW.ensure(ent * 8) != hipSuccess ||
+                (p->nearfield && p->d_XW2.ensure(ent * 8) != hipSuccess) || p->d_xhmax.ensure((size_t)nch * 4) != hipSuccess) {
+                impdar_set_error("hipMalloc of the %zu-entry exact pick/weight table failed", ent);
+                return IMPDAR_ERR_HIP;
+            }
+            IMPDAR_HIP_CHECK(hipMemcpyAsync(p->d_xhmax.p, hm.data(), (size_t)nch * 4, hipMemcpyHostToDevice, st));
+            IMPDAR_HIP_CHECK(hipStreamSynchronize(st));          // hm is a stack vector
+            TableXParams T;
+            T.XK = p->d_XK.as<int>();
+            T.XW = p->d_XW.as<double>();
+            T.XW2 = p->d_XW2.as<double>();
+            T.zs = p->d_zs.as<double>();
+            T.zs2 = p->d_zs2.as<double>();
+            T.tt = p->d_tt.as<double>();
+            T.dx = p->dx;
+            T.vel = p->vel;
+            T.tmax = p->tmax;
+            T.inv_dt = 1.0 / p->dt;
+            T.tt0 = p->tt0;
+            T.snum = p->snum;
+            T.ntab = hg;
+            T.near = p->nearfield;
+            hipLaunchKernelGGL(kirch_tablex_kernel, dim3(nch, hg), dim3(256), 0, st, T);
+            IMPDAR_HIP_CHECK(hipGetLastError());
+            p->xntab = hg;
+            p->xtab_ready = true;
+        }
+        ExactTabParams P;
+        P.GT = img_row0(p, p->GT[b]);
+        P.DT = p->nearfield ? img_row0(p, p->DT[b]) : nullptr;
+        P.out = d_out;
+        P.ldo = nx;
+        P.snum = p->snum;
+        P.tnum = p->tnum;
+        P.xlo = xlo;
+        P.xhi = xhi;
+        P.XK = p->d_XK.as<int>();
+        P.XW = p->d_XW.as<double>();
+        P.XW2 = p->d_XW2.as<double>();
+        P.hmax = p->d_xhmax.as<int>();
+        P.ntab = p->xntab;
+        constexpr int XE = 8;
+        dim3 grid(nch, (nx + XE - 1) / XE);
+        if (p->dtype == IMPDAR_F32) {
+            if (p->nearfield)
+                hipLaunchKernelGGL((kirch_exact_tab_kernel<float, true, XE>), grid, dim3(256), 0, st, P);
+            else
+                hipLaunchKernelGGL((kirch_exact_tab_kernel<float, false, XE>), grid, dim3(256), 0, st, P);
+        } else {
+            if (p->nearfield)
+                hipLaunchKernelGGL((kirch_exact_tab_kernel<double, true, XE>), grid, dim3(256), 0, st, P);
+            else
+                hipLaunchKernelGGL((kirch_exact_tab_kernel<double, false, XE>), grid, dim3(256), 0, st, P);
+        }
+        IMPDAR_HIP_CHECK(hipGetLastError());
     } else if (nx > 0) {
         ExactParams P;
         P.GT = img_row0(p, p->GT[b]);
@@ -1599,8 +1770,10 @@ extern "C" void mig_kirch_loop(double *migdata, int tnum, int snum, double *dist
         fprintf(stderr, "impdar mig_kirch_loop: %s\n", impdar_last_error());
         return;
     }
-    // honour the caller's depth tables and time limit (mig_python.py:98-102 computes them)
+    // honour the caller's depth tables and time limit (mig_python.py:98-102 computes them): the tabulated
+    // exact kernel derives its aperture from the plan's own tmax, so the hook keeps the per-pair kernel
     p->tmax = max_travel_time;
+    p->xtab_off = true;
     const size_t bytes = (size_t)snum * tnum * 8;
     DevBuf din, dout;
     if (hipMemcpy(p->d_zs.p, zs, (size_t)snum * 8, hipMemcpyHostToDevice) == hipSuccess &&
