@@ -1,5 +1,7 @@
 // Context, error channel and raw device-memory plumbing of the C ABI.
 #include "common.h"
+#include <algorithm>
+#include <thread>
 
 static thread_local char g_err[1024] = "";
 
@@ -53,12 +55,64 @@ extern "C" int impdar_ctx_create(int device, impdar_ctx **out)
 
 void impdar_comm_destroy(impdar_ctx *ctx);   // comm.hip
 
+void *impdar_ctx_pinned(impdar_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->pinned_bytes) return ctx->pinned;
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned = nullptr;
+    ctx->pinned_bytes = 0;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    ctx->pinned = p;
+    ctx->pinned_bytes = bytes;
+    return p;
+}
+
+void impdar_host_copy_f64(double *dst, const void *src, size_t n, bool src_is_f32)
+{
+    const unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nthr; ++t)
+        pool.emplace_back([=] {
+            const size_t a = n * t / nthr, b = n * (t + 1) / nthr;
+            if (src_is_f32) {
+                const float *f = reinterpret_cast<const float *>(src);
+                for (size_t i = a; i < b; ++i) dst[i] = (double)f[i];
+            } else {
+                memcpy(dst + a, reinterpret_cast<const double *>(src) + a, (b - a) * sizeof(double));
+            }
+        });
+    for (auto &th : pool) th.join();
+}
+
+int impdar_download(impdar_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes, hipStream_t st)
+{
+    void *stage = bytes >= (1u << 20) ? impdar_ctx_pinned(ctx, bytes) : nullptr;
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(stage ? stage : host_dst, dev_src, bytes, hipMemcpyDeviceToHost, st));
+    IMPDAR_HIP_CHECK(hipStreamSynchronize(st));
+    if (stage) {
+        const unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nthr; ++t)
+            pool.emplace_back([=] {
+                const size_t a = (bytes * t / nthr) & ~(size_t)63, b = t + 1 == nthr ? bytes : ((bytes * (t + 1) / nthr) & ~(size_t)63);
+                memcpy(reinterpret_cast<char *>(host_dst) + a, reinterpret_cast<const char *>(stage) + a, b - a);
+            });
+        for (auto &th : pool) th.join();
+    }
+    return IMPDAR_OK;
+}
+
 extern "C" void impdar_ctx_destroy(impdar_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->aux);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     impdar_comm_destroy(ctx);
     (void)hipStreamDestroy(ctx->aux);
     (void)hipStreamDestroy(ctx->stream);

@@ -19,7 +19,20 @@ struct impdar_ctx {
     ncclComm *comm = nullptr;
     int rank = 0;
     int nranks = 1;
+    // pinned host staging for the one-shot (host-buffer) entry points: device -> pinned at PCIe speed,
+    // then pinned -> the caller's pageable buffer on several threads (first touch of a fresh result
+    // array is a page fault per 4 KiB; the faults parallelise, a single D2H into it does not)
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
 };
+
+// grow-only pinned staging buffer of the context; nullptr when the allocation fails (callers fall back to a
+// direct pageable copy)
+void *impdar_ctx_pinned(impdar_ctx *ctx, size_t bytes);
+// copy (or convert float -> double) `n` elements from pinned staging into pageable memory on a few threads
+void impdar_host_copy_f64(double *dst, const void *src, size_t n, bool src_is_f32);
+// device -> host through the pinned staging buffer and a threaded copy (falls back to a plain D2H); synchronises `st`
+int impdar_download(impdar_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes, hipStream_t st);
 
 void impdar_set_error(const char *fmt, ...);
 

@@ -25,6 +25,8 @@
 #include "common.h"
 #include <cmath>
 #include <algorithm>
+#include <chrono>
+#include <thread>
 
 #define KF_THREADS 256
 #define KF_W 512            // LDS floats per ring slot (circular window)
@@ -1703,6 +1705,12 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
                                 const double *gc, int mode, double *out)
 {
     IMPDAR_ARG_CHECK(ctx && data && out, "null context/data/output");
+    const bool timing = getenv("IMPDAR_TIMING") != nullptr;      // diagnostic: phase times of the one-shot call on stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
     impdar_kirch_plan *p = nullptr;
     int rc = impdar_kirch_plan_create(ctx, dtype, snum, tnum, dist_m, tt_sec, vel, nearfield, grad_uniform, grad_h,
                                       ga, gb, gc, mode, 1, &p);
@@ -1723,25 +1731,33 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
         impdar_set_error("H2D copy failed");
         return done(IMPDAR_ERR_HIP);
     }
+    const auto t1 = now();
     if ((rc = impdar_kirch_prep(p, din.p, tnum, 0, tnum))) return done(rc);
     if ((rc = impdar_kirch_migrate(p, dout.p, 0, tnum))) return done(rc);
+    // device -> pinned staging -> the caller's float64 array (mig_python.py:118 returns float64)
+    void *stage = impdar_ctx_pinned(ctx, bytes);
     std::vector<char> tmp;
-    void *host_dst = out;
-    if (dtype == IMPDAR_F32) {
-        tmp.resize(bytes);
-        host_dst = tmp.data();
+    void *host_dst = stage;
+    if (!stage) {
+        host_dst = out;
+        if (dtype == IMPDAR_F32) {
+            tmp.resize(bytes);
+            host_dst = tmp.data();
+        }
     }
     if (hipMemcpyAsync(host_dst, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) {
         impdar_set_error("D2H copy / synchronize failed: %s", hipGetErrorString(hipGetLastError()));
         return done(IMPDAR_ERR_HIP);
     }
-    if (dtype == IMPDAR_F32) {
-        const float *f = reinterpret_cast<const float *>(tmp.data());
-        const size_t n = (size_t)snum * tnum;
-        for (size_t i = 0; i < n; ++i) out[i] = (double)f[i];
-    }
-    return done(IMPDAR_OK);
+    const auto t2 = now();
+    if (host_dst != out) impdar_host_copy_f64(out, host_dst, (size_t)snum * tnum, dtype == IMPDAR_F32);
+    const auto t3 = now();
+    rc = done(IMPDAR_OK);
+    if (timing)
+        fprintf(stderr, "impdar_kirchhoff: plan+alloc+H2D %.1f ms, prep+migrate+D2H %.1f ms, convert %.1f ms, destroy %.1f ms\n",
+                ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
+    return rc;
 }
 
 // ---------------------------------------------------------------------------

@@ -531,9 +531,7 @@ extern "C" int impdar_phaseshift(impdar_ctx *ctx, const void *data, int dtype, i
                                  : ps_run<double>(ctx, *g_ps_plan, din.p, snum, tnum, nt, kx, ws, dt, tt_us, vconst, vmig,
                                                   vmig_len, htaper, vtaper, dout.p);
     if (rc) return rc;
-    IMPDAR_HIP_CHECK(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    IMPDAR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    return IMPDAR_OK;
+    return impdar_download(ctx, out, dout.p, bytes, ctx->stream);
 }
 
 // ===========================================================================

@@ -254,7 +254,5 @@ extern "C" int impdar_stolt(impdar_ctx *ctx, const void *data, int dtype, int sn
     IMPDAR_HIP_CHECK(hipMemcpyAsync(din.p, data, inb, hipMemcpyHostToDevice, ctx->stream));
     int rc = impdar_stolt_dev(ctx, din.p, dtype, snum, tnum, kx, ws, vel, htaper, vtaper, dout.p);
     if (rc) return rc;
-    IMPDAR_HIP_CHECK(hipMemcpyAsync(out, dout.p, outb, hipMemcpyDeviceToHost, ctx->stream));
-    IMPDAR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    return IMPDAR_OK;
+    return impdar_download(ctx, out, dout.p, outb, ctx->stream);
 }
