@@ -1564,7 +1564,10 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         P.XW2 = p->d_XW2.as<double>();
         P.hmax = p->d_xhmax.as<int>();
         P.ntab = p->xntab;
-        constexpr int XE = 8;
+#ifndef KX_XE
+#define KX_XE 16
+#endif
+        constexpr int XE = KX_XE;
         dim3 grid(nch, (nx + XE - 1) / XE);
         if (p->dtype == IMPDAR_F32) {
             if (p->nearfield)
