@@ -277,3 +277,32 @@ def test_full_size_exact_kernel_config3(hip):
     cols = np.array([0, 2, 5000, 9999, 6543], dtype=np.int32)
     want = c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], vel, traces=cols)
     assert rel_max(out[:, cols], want) < EXACT_TOL, rel_max(out[:, cols], want)
+
+
+def test_fast_kernels_random_geometries(hip):
+    """Seeded sweep over sizes, sample/trace spacing, velocity, first-sample time and near field: the fast
+    path (whichever LDS-ring kernel the moveout selects) against the C oracle.  Moveouts the fast kernels do
+    not cover must be refused, not mis-migrated."""
+    from impdar_amd import synth
+    from impdar_amd.kirchhoff import migrate_resident
+    from oracle import c_oracle
+    rng = np.random.default_rng(20260101)
+    ctx = hip.context()
+    ran = 0
+    for _ in range(24):
+        snum, tnum = int(rng.integers(2, 1200)), int(rng.integers(1, 500))
+        dt, dx = float(10 ** rng.uniform(-9.3, -7.5)), float(10 ** rng.uniform(-1.3, 0.9))
+        vel = float(rng.uniform(0.6e8, 3e8))
+        t0 = float(rng.choice([0.0, dt * 1e6, -3 * dt * 1e6, 17.3 * dt * 1e6]))
+        near = bool(rng.integers(0, 2))
+        geo = synth.geometry(snum, tnum, dt=dt, dx=dx, t0_us=t0)
+        data = rng.standard_normal((snum, tnum)).astype(np.float32)
+        try:
+            out, mode, _ = migrate_resident(ctx, data, geo['dist'], geo['travel_time'], vel, nearfield=near, mode='fast')
+        except NotImplementedError:
+            assert 2 * dx / (vel * dt) > 15.0          # only steep moveout is out of reach
+            continue
+        want = c_oracle.kirchhoff(data, geo['travel_time'], geo['dist'], vel, near)
+        assert mode == 'fast' and rel_l2(out, want) < FAST_L2, (snum, tnum, dt, dx, vel, t0, near, rel_l2(out, want))
+        ran += 1
+    assert ran >= 12
