@@ -396,6 +396,7 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
 
 struct PsPlan {
     int dtype = -1, snum = 0, tnum = 0, nt = 0;
+    const impdar_ctx *owner = nullptr;   // plans and buffers live on this context's device and stream
     FftPlan f_time, f_trace, b_trace;
     DevBuf X, TK, d_kx, d_w, d_vz, d_thr;
 };
@@ -439,8 +440,12 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
 {
     hipStream_t st = ctx->stream;
     const bool dbl = sizeof(T) == 8;
-    if (pl.dtype != (dbl ? IMPDAR_F64 : IMPDAR_F32) || pl.snum != snum || pl.tnum != tnum || pl.nt != nt) {
+    if (pl.owner != ctx || pl.dtype != (dbl ? IMPDAR_F64 : IMPDAR_F32) || pl.snum != snum || pl.tnum != tnum || pl.nt != nt) {
         pl.dtype = -1;
+        if (pl.owner != ctx) {               // another device / stream: drop everything bound to the old one
+            pl.X.release(); pl.TK.release(); pl.d_kx.release(); pl.d_w.release(); pl.d_vz.release(); pl.d_thr.release();
+            pl.owner = ctx;
+        }
         int rc;
         const rocfft_array_type ci = rocfft_array_type_complex_interleaved;
         if ((rc = pl.f_time.create(rocfft_transform_type_complex_forward, dbl, true, nt, tnum, ci, ci, 1, nt, 1, nt, 1.0, st)))

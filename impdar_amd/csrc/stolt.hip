@@ -132,6 +132,7 @@ __global__ void stolt_fix_hermitian(Cx<T> *K, int m, int tnum)
 
 struct StoltPlan {
     int dtype = -1, snum = 0, tnum = 0;
+    const impdar_ctx *owner = nullptr;   // plans and buffers live on this context's device and stream
     FftPlan r2c, c2c_f, c2c_b, c2r;     // separate passes (IMPDAR_STOLT_FFT=1d)
     FftPlan fwd2d, inv2d;               // the same two pairs as 2-D real transforms (default)
     bool use2d = true;
@@ -148,8 +149,12 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
     const int m = snum / 2 + 1, nz = snum / 2, nout = 2 * (snum / 2);
     hipStream_t st = ctx->stream;
     const bool dbl = sizeof(T) == 8;
-    if (pl.dtype != (dbl ? IMPDAR_F64 : IMPDAR_F32) || pl.snum != snum || pl.tnum != tnum) {
+    if (pl.owner != ctx || pl.dtype != (dbl ? IMPDAR_F64 : IMPDAR_F32) || pl.snum != snum || pl.tnum != tnum) {
         pl.dtype = -1;
+        if (pl.owner != ctx) {               // another device / stream: drop everything bound to the old one
+            pl.X.release(); pl.F.release(); pl.K.release(); pl.Y.release(); pl.d_kx.release(); pl.d_ws.release();
+            pl.owner = ctx;
+        }
         int rc;
         {
             const char *e = getenv("IMPDAR_STOLT_FFT");          // tuning knob: "1d" = four 1-D passes
