@@ -55,6 +55,9 @@ extern "C" int impdar_ctx_create(int device, impdar_ctx **out)
 
 void impdar_comm_destroy(impdar_ctx *ctx);   // comm.hip
 
+void impdar_stolt_forget(const impdar_ctx *ctx);   // stolt.hip
+void impdar_ps_forget(const impdar_ctx *ctx);      // phaseshift.hip
+
 void *impdar_ctx_pinned(impdar_ctx *ctx, size_t bytes)
 {
     if (bytes <= ctx->pinned_bytes) return ctx->pinned;
@@ -112,6 +115,8 @@ extern "C" void impdar_ctx_destroy(impdar_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->aux);
     (void)hipStreamSynchronize(ctx->stream);
+    impdar_stolt_forget(ctx);
+    impdar_ps_forget(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     impdar_comm_destroy(ctx);
     (void)hipStreamDestroy(ctx->aux);

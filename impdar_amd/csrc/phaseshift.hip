@@ -403,6 +403,16 @@ struct PsPlan {
 static std::mutex g_ps_mu;
 static PsPlan *g_ps_plan = nullptr;
 
+// called by impdar_ctx_destroy: a cached plan must not outlive the stream it was created on
+void impdar_ps_forget(const impdar_ctx *ctx)
+{
+    std::lock_guard<std::mutex> lk(g_ps_mu);
+    if (g_ps_plan && g_ps_plan->owner == ctx) {
+        delete g_ps_plan;
+        g_ps_plan = nullptr;
+    }
+}
+
 template <typename T, int BLOCK, int M>
 static void ps_launch(const PsParams &P, hipStream_t st)
 {

@@ -142,6 +142,16 @@ struct StoltPlan {
 static std::mutex g_stolt_mu;
 static StoltPlan *g_stolt_plan = nullptr;     // last-used plan (sizes repeat across calls)
 
+// called by impdar_ctx_destroy: a cached plan must not outlive the stream it was created on
+void impdar_stolt_forget(const impdar_ctx *ctx)
+{
+    std::lock_guard<std::mutex> lk(g_stolt_mu);
+    if (g_stolt_plan && g_stolt_plan->owner == ctx) {
+        delete g_stolt_plan;
+        g_stolt_plan = nullptr;
+    }
+}
+
 template <typename T>
 static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snum, int tnum, const double *kx,
                      const double *ws, double vel, double htaper, double vtaper, void *d_out)
