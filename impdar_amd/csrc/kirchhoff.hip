@@ -1098,9 +1098,12 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     const bool quad_ok = (size_t)(wq / 32) * KQ_PS <= 80 * 1024;
     const bool tab_ok = (KF_THREADS + sa * (16 - 1) + 8.0) <= (double)KF_W;
     const bool window_ok = quad_ok || tab_ok;
-    // (aperture half width below 65536 traces: the kernel squares trace offsets in 32 bits)
+    // aperture half width in traces (upper bound): below 65536 (the kernel squares trace offsets in 32
+    // bits), and the span of image groups one workgroup walks must stay inside its 2 GiB raw buffer
+    const double hest = std::min(std::fabs(tmax / dt) / sa + 2.0, (double)tnum + 128.0);
+    const bool span_ok = (2.0 * hest + 400.0) / 8.0 * (double)snum * 32.0 < 2147483648.0;
     const bool fast_ok = dtype == IMPDAR_F32 && p->uniform && window_ok && snum < 65536 &&
-                         std::fabs(tmax / dt) / sa < 65000.0;
+                         std::fabs(tmax / dt) / sa < 65000.0 && span_ok;
 
     if (mode == IMPDAR_KIRCH_AUTO) mode = fast_ok ? IMPDAR_KIRCH_FAST : IMPDAR_KIRCH_EXACT;
     if (mode == IMPDAR_KIRCH_FAST && !fast_ok) {
