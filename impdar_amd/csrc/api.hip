@@ -43,7 +43,11 @@ extern "C" int impdar_ctx_create(int device, impdar_ctx **out)
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio_lo);
+    {
+        const char *pe = getenv("IMPDAR_AUX_PRIO");   // tuning knob: lo (default) / hi
+        const int pa = (pe && !strcmp(pe, "hi")) ? prio_hi : prio_lo;
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, pa);
+    }
     if (e != hipSuccess) {
         delete c;
         impdar_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));

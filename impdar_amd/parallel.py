@@ -83,17 +83,14 @@ def input_shards(tnum, nranks):
     return per * nranks, shards
 
 
-# Fixed cost of one output trace in the fast Kirchhoff kernel, in in-aperture pairs: measured on one
-# MI355X by timing the eight blocks of the 10000 x 4096 radargram separately (block time = a * pairs +
-# b * traces, b / a = 4.4e6): a workgroup's prologue (LDS image, first four trace groups) and the
-# table/picks of its 16 sample chunks do not shrink with the aperture, so the half-aperture traces at the
-# ends of the profile cost more per pair than interior ones.
-TRACE_COST_PAIRS = 4.4e6
-# The fast kernel tiles an output block into 24-trace tiles, dealt to the 8 XCDs in groups of 8: a block
-# whose width is a multiple of 192 traces launches no padding tiles, and 6 x 192 = 1152 traces x 16 sample
-# chunks fill the 768 resident workgroup slots of an MI355X exactly once.  Interior blocks are rounded to
-# that quantum (measured: kernel-only strong-scaling efficiency at 8 ranks 84 % -> 92 %).
-BLOCK_QUANTUM = 192
+# Optional refinements of the pair-count balance (both off by default).  Timing each rank's block in
+# isolation suggested a fixed cost per output trace (4.4e6 pairs) and interior widths rounded to 192 traces
+# (8 tiles of 24: no padding tiles, 6 x 192 traces x 16 chunks = the 768 resident workgroups); in the
+# pipelined steady state of bench.py (prep of the next radargram under the current diffraction sum,
+# profiles/tools/rank_steps.py) plain pair balance is the better of the two: 93 % vs 88 % at 4 ranks,
+# 80 % vs 76 % at 8 (kernel side, all-gather not emulated).
+TRACE_COST_PAIRS = 0.0
+BLOCK_QUANTUM = 1
 
 
 def plan_blocks(tt_sec, dx, vel, tnum, nranks, trace_cost=TRACE_COST_PAIRS, quantum=BLOCK_QUANTUM):
@@ -103,7 +100,7 @@ def plan_blocks(tt_sec, dx, vel, tnum, nranks, trace_cost=TRACE_COST_PAIRS, quan
     h = aperture_half_widths(tt_sec, dx, vel)
     w = trace_pair_weights(h, tnum)
     tnum_pad, shards = input_shards(tnum, nranks)
-    blocks = balanced_blocks(w + trace_cost, nranks, quantum if tnum >= 4 * quantum * nranks else 1)
+    blocks = balanced_blocks(w + trace_cost, nranks, quantum if (quantum > 1 and tnum >= 4 * quantum * nranks) else 1)
     pairs = [int(w[lo:hi].sum()) for lo, hi in blocks]
     return tnum_pad, shards, blocks, pairs
 

@@ -40,9 +40,11 @@ def test_partition_properties():
         assert all(blocks[i][1] == blocks[i + 1][0] for i in range(n - 1))
         assert shards[0][0] == 0 and shards[-1][1] == 10000
         assert sum(pairs) == 189920188078
-        assert max(pairs) / (sum(pairs) / n) < 1.12         # pair count + a fixed cost per trace, rounded widths
+        assert max(pairs) / (sum(pairs) / n) < 1.002        # balanced by pair count
+        _, _, qb, qp = parallel.plan_blocks(tt, 1.0, 1.69e8, 10000, n, trace_cost=4.4e6, quantum=192)
+        assert sum(qp) == sum(pairs) and qb[0][0] == 0 and qb[-1][1] == 10000
         if n >= 4:
-            assert all((b[1] - b[0]) % parallel.BLOCK_QUANTUM == 0 for b in blocks[1:-1])
+            assert all((b[1] - b[0]) % 192 == 0 for b in qb[1:-1])      # optional rounded widths
         _, _, _, pure = parallel.plan_blocks(tt, 1.0, 1.69e8, 10000, n, trace_cost=0, quantum=1)
         assert max(pure) / (sum(pure) / n) < 1.002 and sum(pure) == sum(pairs)
     # ragged: more ranks than traces
