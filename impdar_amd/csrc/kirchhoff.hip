@@ -123,6 +123,45 @@ __global__ __launch_bounds__(256) void kirch_prep_kernel(PrepParams P)
     }
 }
 
+// LDS-free variant for the grouped layout, float32: used for a rank's input shard in multi-GPU runs.
+// The diffraction sum of the previous radargram keeps all of a CU's LDS, so a producer kernel that
+// needs LDS cannot start before that kernel drains; this one can run on the CUs' spare wave slots.
+// One thread per (sample k, trace j): reads are coalesced along j, writes are 32-byte runs per group.
+__global__ __launch_bounds__(256) void kirch_prep_direct_kernel(PrepParams P)
+{
+    const float *f = reinterpret_cast<const float *>(P.data);
+    const int j = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    const int n = P.snum;
+    if (j >= P.nloc) return;
+    const size_t c = (size_t)j;
+    double d = (double)f[(size_t)k * P.ld + c], g;
+    if (P.precomputed) {
+        g = d;
+    } else if (k == 0) {
+        const double h = P.grad_uniform ? P.grad_h : P.ga[0];
+        g = ((double)f[(size_t)1 * P.ld + c] - d) / h;
+    } else if (k == n - 1) {
+        const double h = P.grad_uniform ? P.grad_h : P.ga[n - 1];
+        g = (d - (double)f[(size_t)(k - 1) * P.ld + c]) / h;
+    } else {
+        const double fm = (double)f[(size_t)(k - 1) * P.ld + c];
+        const double fp = (double)f[(size_t)(k + 1) * P.ld + c];
+        if (P.grad_uniform)
+            g = (fp - fm) / (2.0 * P.grad_h);
+        else
+            g = (P.ga[k] * fm + P.gb[k] * d) + P.gc[k] * fp;
+    }
+    if (!P.precomputed) g = (double)(float)g;                  // numpy keeps f32 gradients in f32
+    if (P.clean) {
+        if (!(fabs(g) <= 1.79e308)) g = 0.0;
+        if (!(fabs(d) <= 1.79e308)) d = 0.0;
+    }
+    const int row = P.jlo + j;
+    const size_t o = ((size_t)(row >> 3) * n + k) * 8 + (row & 7);
+    reinterpret_cast<float *>(P.GT)[o] = (float)g;
+    if (P.DT) reinterpret_cast<float *>(P.DT)[o] = (float)d;
+}
+
 // ===========================================================================
 // exact kernel: reference operation order, fp64 index math, any geometry
 // ===========================================================================
@@ -1336,7 +1375,9 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
         P.clean = (p->mode == IMPDAR_KIRCH_FAST);
         P.i8 = p->quad ? 1 : 0;
         dim3 grid((nloc + 63) / 64, (p->snum + 63) / 64);
-        if (p->dtype == IMPDAR_F32)
+        if (p->dtype == IMPDAR_F32 && P.i8 && p->nranks > 1)
+            hipLaunchKernelGGL(kirch_prep_direct_kernel, dim3((nloc + 255) / 256, p->snum), dim3(256), 0, st, P);
+        else if (p->dtype == IMPDAR_F32)
             hipLaunchKernelGGL((kirch_prep_kernel<float, float>), grid, dim3(256), 0, st, P);
         else
             hipLaunchKernelGGL((kirch_prep_kernel<double, double>), grid, dim3(256), 0, st, P);

@@ -87,8 +87,8 @@ def input_shards(tnum, nranks):
 # isolation suggested a fixed cost per output trace (4.4e6 pairs) and interior widths rounded to 192 traces
 # (8 tiles of 24: no padding tiles, 6 x 192 traces x 16 chunks = the 768 resident workgroups); in the
 # pipelined steady state of bench.py (prep of the next radargram under the current diffraction sum,
-# profiles/tools/rank_steps.py) plain pair balance is the better of the two: 93 % vs 88 % at 4 ranks,
-# 80 % vs 76 % at 8 (kernel side, all-gather not emulated).
+# profiles/tools/rank_steps.py) plain pair balance is the better of the two: 96 % vs 88 % at 4 ranks,
+# 83 % vs 82 % at 8 (kernel side, all-gather not emulated).
 TRACE_COST_PAIRS = 0.0
 BLOCK_QUANTUM = 1
 

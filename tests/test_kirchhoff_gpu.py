@@ -306,3 +306,33 @@ def test_fast_kernels_random_geometries(hip):
         assert mode == 'fast' and rel_l2(out, want) < FAST_L2, (snum, tnum, dt, dx, vel, t0, near, rel_l2(out, want))
         ran += 1
     assert ran >= 12
+
+
+def test_multirank_plan_shard_prep_matches_one_shot(hip):
+    """A plan built for several ranks preps its input shards with the LDS-free gradient kernel (the one a
+    rank runs underneath the previous diffraction sum).  Prepping every shard locally, without the
+    all-gather, must give the one-shot image: near and far field."""
+    from impdar_amd import synth, _hip, parallel
+    from impdar_amd.kirchhoff import KirchhoffPlan, migrate_resident
+    snum, tnum = 300, 211
+    geo = synth.geometry(snum, tnum)
+    data = synth.noise_radargram(snum, tnum, seed=12).astype(np.float32)
+    ctx = hip.context()
+    for near in (False, True):
+        full, _, _ = migrate_resident(ctx, data, geo['dist'], geo['travel_time'], nearfield=near, mode='fast')
+        plan = KirchhoffPlan(ctx, np.float32, snum, tnum, geo['dist'], geo['travel_time'], nearfield=near,
+                             mode='fast', nranks=4)
+        tnum_pad, shards = parallel.input_shards(tnum, 4)
+        assert plan.tnum_pad == tnum_pad
+        for jlo, jhi in shards:
+            blk = _hip.DeviceArray.from_host(ctx, np.ascontiguousarray(data[:, jlo:jhi]))
+            plan.prep(blk, max(jhi - jlo, 1), jlo, jhi - jlo)
+            plan.sync()
+            blk.free()
+        d_out = _hip.DeviceArray(ctx, (snum, tnum), np.float32)
+        plan.migrate(d_out, 0, tnum)
+        plan.sync()
+        got = d_out.to_host()
+        d_out.free()
+        plan.destroy()
+        assert np.array_equal(got, full)
