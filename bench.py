@@ -214,7 +214,7 @@ def main():
                          "on_chip": {"bound": "lds", "achieved": achieved, "peak": LDS_PEAK_GBS, "unit": "GB/s",
                                      "frac": (achieved / LDS_PEAK_GBS) if achieved else None,
                                      "note": "peak at the 2.4 GHz spec clock; the kernel holds ~1.9 GHz, where "
-                                             "rocprof counts 82% of the LDS cycles busy"}},
+                                             "rocprof counts 86% of the LDS cycles busy"}},
         }
         if world == 1 and not args.no_cpu:
             t0 = time.time()
