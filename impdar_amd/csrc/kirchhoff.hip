@@ -441,21 +441,31 @@ __host__ __device__ static inline unsigned kq_row_offset(int r)
 
 __global__ __launch_bounds__(256) void kirch_tableq_kernel(TableQParams P)
 {
+    // One thread evaluates the 9 picks |n| = 8a .. 8a+8 of one sample and fills TWO rows with them: the
+    // block right of the apex n = 8a+1 .. 8a+8 (row a + mrow0) and its mirror n = -8a-7 .. -8a
+    // (row mrow0 - a - 1, picks in reverse order): 9 evaluations instead of 16.  A pick beyond the
+    // sample's own aperture (t > t_max) is the all-zero row; so is everything once t exceeded t_max
+    // (t grows with |n|), which skips the fp64 work for the outer part of the table.
     const int ti = blockIdx.x * 256 + threadIdx.x;
-    const int r = blockIdx.y;
+    const int a = blockIdx.y;
     if (ti >= P.snum) return;
-    unsigned pk[8];
+    const unsigned zero_row = 1024u >> P.sh;         // KQ_ZERO
+    unsigned pk[9];
+    bool out = false;                                // t already beyond t_max at a smaller offset
+    const double zs = P.zs[ti], zs2 = P.zs2[ti];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int n = abs(8 * (r - P.mrow0) + 1 + s);
-        unsigned kb = 1024u >> P.sh;             // the all-zero row (KQ_ZERO)
-        if (n < P.nmax) {
+    for (int s = 0; s < 9; ++s) {
+        const int n = 8 * a + s;
+        unsigned kb = zero_row;
+        if (n < P.nmax && !out) {
             const double dx = (double)n * P.dx;
-            const double q = dx * dx + P.zs2[ti];
+            const double q = dx * dx + zs2;
             const double rs = sqrt(q);
-            const double cost = P.zs[ti] / rs;
+            const double cost = zs / rs;
             const double t = 2.0 * rs / P.vel;
-            if (!(t > P.tmax) && cost == cost) {
+            if (t > P.tmax) {
+                out = true;
+            } else if (cost == cost) {
                 const int ns = P.snum;
                 int k0 = (int)floor((t - P.tt0) * P.inv_dt);
                 k0 = min(max(k0, 0), ns - 1);
@@ -468,8 +478,13 @@ __global__ __launch_bounds__(256) void kirch_tableq_kernel(TableQParams P)
         }
         pk[s] = kb;
     }
-    P.TKB[(size_t)r * P.snum + ti] =
-        make_uint4(pk[0] | (pk[1] << 16), pk[2] | (pk[3] << 16), pk[4] | (pk[5] << 16), pk[6] | (pk[7] << 16));
+    const int rp = a + P.mrow0, rn = P.mrow0 - a - 1;
+    if (rp < P.nrows)
+        P.TKB[(size_t)rp * P.snum + ti] =
+            make_uint4(pk[1] | (pk[2] << 16), pk[3] | (pk[4] << 16), pk[5] | (pk[6] << 16), pk[7] | (pk[8] << 16));
+    if (rn >= 0)
+        P.TKB[(size_t)rn * P.snum + ti] =
+            make_uint4(pk[7] | (pk[6] << 16), pk[5] | (pk[4] << 16), pk[3] | (pk[2] << 16), pk[1] | (pk[0] << 16));
 }
 
 // ---------------------------------------------------------------------------
@@ -1408,7 +1423,9 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
         T.nmax = p->ntab - 1;
         T.wmod = p->quadW;
         T.sh = p->quadSH;
-        hipLaunchKernelGGL(kirch_tableq_kernel, dim3((p->snum + 255) / 256, p->nrows), dim3(256), 0, st, T);
+        // rows a + mrow0 (a >= 0) and mrow0 - a - 1: a runs over the larger of the two sides
+        const int na = std::max(p->nrows - p->mrow0, p->mrow0);
+        hipLaunchKernelGGL(kirch_tableq_kernel, dim3((p->snum + 255) / 256, na), dim3(256), 0, st, T);
         IMPDAR_HIP_CHECK(hipGetLastError());
     } else if (p->mode == IMPDAR_KIRCH_FAST) {
         // geometry-only pick/weight table, rebuilt with every prep (counted in prep time)
