@@ -1475,7 +1475,10 @@ static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipSt
     P.nxt = ntiles;
     {
         const char *ge = getenv("IMPDAR_KIRCH_G");        // tuning knob: adjacent trace tiles per XCD group
-        const int g = ge ? atoi(ge) : 4;      // same-box A/B at config 3: G = 4 is 1.2 % faster than 1, 2.5 % than 6
+        // groups of 4 adjacent tiles per XCD share staging lines in L2 (same-box A/B at config 3: 1.2-1.6 %
+        // faster than 1, L2 misses -36 %), but the XCDs only stay balanced when each gets many groups: with
+        // the 45-70 tiles of an 8-rank block G = 4 leaves half of the XCDs with twice the work (-16 %).
+        const int g = ge ? atoi(ge) : (ntiles >= 256 ? 4 : 1);
         P.G = (g >= 1 && g <= 64) ? g : 1;
     }
     const int per = 8 * P.G;
