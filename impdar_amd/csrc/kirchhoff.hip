@@ -431,12 +431,13 @@ struct TableQParams {
     double dx, vel, tmax, inv_dt, tt0;
     int snum, nrows, mrow0, nmax;   // offsets |n| >= nmax are outside every aperture
     int wmod, sh;                   // ring rows; entries are LDS byte offsets >> sh
+    int ps;                         // bytes per 32-row piece of the LDS image (kq_piece_bytes)
 };
 
 // byte offset of half 0 of ring row r in the quad kernel's LDS image (layout: see kirch_quad_kernel)
-__host__ __device__ static inline unsigned kq_row_offset(int r)
+__host__ __device__ static inline unsigned kq_row_offset(int r, int ps)
 {
-    return (unsigned)(r >> 5) * 5376u + (unsigned)(r & 31) * 32u + (((unsigned)(r >> 3) & 1u) << 4);
+    return (unsigned)(r >> 5) * (unsigned)ps + (unsigned)(r & 31) * 32u + (((unsigned)(r >> 3) & 1u) << 4);
 }
 
 __global__ __launch_bounds__(256) void kirch_tableq_kernel(TableQParams P)
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(256) void kirch_tableq_kernel(TableQParams P)
                 while (k0 > 0 && P.tt[k0] > t) --k0;
                 const int k1 = min(k0 + 1, ns - 1);
                 const int k = (fabs(P.tt[k1] - t) < fabs(P.tt[k0] - t)) ? k1 : k0;
-                kb = kq_row_offset(k % P.wmod) >> P.sh;
+                kb = kq_row_offset(k % P.wmod, P.ps) >> P.sh;
             }
         }
         pk[s] = kb;
@@ -667,16 +668,18 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_tab_kernel(FastParams P
 // The DMA keeps the image linear and applies the swap on its per-lane SOURCE address; the pick table
 // holds the byte offset of half 0 of the picked row, half 1 is that offset ^ 16.
 // ---------------------------------------------------------------------------
-#define KQ_RING 40
-#define KQ_GS 1056          // bytes between the 5 trace groups inside a piece (32 rows x 32 B + spare row)
-#define KQ_PS 5376          // bytes per piece: 5 groups + pad to a multiple of 256 B (rows of neighbouring
-                            // pieces then keep distinct banks inside one ds_read_b128 lane group)
+#define KQ_GS 1056          // bytes between the trace groups inside a piece (32 rows x 32 B + spare row)
 #define KQ_ZERO 1024        // byte offset of the all-zero row (spare row of piece 0, group 0; + g * KQ_GS)
-static_assert(KQ_PS == 5376 && KQ_PS >= 5 * KQ_GS && KQ_ZERO == 1024, "kq_row_offset / kirch_tableq_kernel use these literally");
+// ring slots for an XB-trace output tile (XB + 15 traces are live, in whole 8-trace groups) and bytes per
+// 32-row piece: the groups + pad to a multiple of 256 B (rows of neighbouring pieces then keep distinct
+// banks inside one ds_read_b128 lane group)
+__host__ __device__ constexpr int kq_ring_slots(int xb) { return ((xb + 15 + 7) / 8) * 8; }
+__host__ __device__ constexpr int kq_piece_bytes(int xb) { return ((kq_ring_slots(xb) / 8 * KQ_GS + 255) / 256) * 256; }
+static_assert(kq_ring_slots(24) == 40 && kq_piece_bytes(24) == 5376 && kq_ring_slots(32) == 48 && kq_piece_bytes(32) == 6400 &&
+              kq_ring_slots(40) == 56 && kq_piece_bytes(40) == 7424, "");
 #ifndef KQ_PER
 #define KQ_PER 4            // quads per interleave slice (1..7 all measure within 2 %; 4 keeps 97 VGPRs)
 #endif
-#define KQ_PARTS ((7 + KQ_PER - 1) / KQ_PER)
 typedef float kq_f4 __attribute__((ext_vector_type(4)));
 typedef unsigned kq_u4 __attribute__((ext_vector_type(4)));
 
@@ -684,7 +687,10 @@ template <int XB, bool NEAR, int OCC, int SH>
 __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams P, int W)
 {
     constexpr int S = 8;
-    constexpr int RG = KQ_RING;               // ring slots
+    constexpr int RG = kq_ring_slots(XB);     // ring slots
+    constexpr int KQ_PS = kq_piece_bytes(XB);
+    constexpr int G0 = XB / 8;                // a block's new traces belong to image / ring group blk + G0
+    constexpr int KQ_PARTS = (XB / 4 + 1 + KQ_PER - 1) / KQ_PER;   // interleave slices per step
     constexpr int NB = RG / S;                // step blocks per ring revolution (unroll length)
     constexpr int NQ = RG / 4;                // slot quads
     static_assert(XB + 2 * S - 1 <= RG && RG % S == 0 && XB % 4 == 0, "ring too small");
@@ -788,9 +794,11 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     __syncthreads();
     kq_u4 tkc = picks(0);                          // picks of the current block
 
-    float acc[XB];
+    // accumulators in quads: the ordering pin below takes them as XB/4 operands of ONE asm statement
+    kq_f4 acc4[XB / 4];
 #pragma unroll
-    for (int i = 0; i < XB; ++i) acc[i] = 0.f;
+    for (int i = 0; i < XB / 4; ++i) acc4[i] = kq_f4{0.f, 0.f, 0.f, 0.f};
+#define KQ_ACC(i) acc4[(i) >> 2][(i) & 3]
 
     // ---- staging by LDS-DMA: the 8 traces a block adds (one 8-row group of the image) go straight from
     // memory into their ring group, 1 KiB (32 rows) per wave instruction, no staging registers and no
@@ -815,8 +823,8 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     };
     auto dma_issue = [&](int blk_for, int wa) {     // traces that block `blk_for` adds to the ring
         const int kmin = wa & 0xffff, kmod = (int)((unsigned)wa >> 16);
-        const int gidx = ((blk_for + 3) % NB + NB) % NB;       // ring group of these traces
-        const unsigned so = (unsigned)(blk_for + 3) * grp_bytes;      // image group of trace jbase + q0
+        const int gidx = ((blk_for + G0) % NB + NB) % NB;      // ring group of these traces
+        const unsigned so = (unsigned)(blk_for + G0) * grp_bytes;     // image group of trace jbase + q0
         for (int pc = wv; pc < npieces; pc += 4) {
             int t = pc * 32 + rl - kmod;
             t += (t < 0) ? W : 0;
@@ -829,7 +837,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     // ring position of ring-relative trace q is (q + 1) % RG: the 8 traces a block adds are one ring
     // group; the ring starts with the four groups q = -1 .. 30
     int wa, wb, wn = 0;
-    for (int pb = -3; pb <= 0; ++pb) {
+    for (int pb = -G0; pb <= 0; ++pb) {
         fetch_for(pb, wa, wb);
         dma_issue(pb, wa);
     }
@@ -891,8 +899,8 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
 #else
 #define KQ_COMP(ix, c)                                                              \
     if (ix < XB) {                                                                  \
-        acc[ix < XB ? ix : 0] = fmaf(w, v[qd].c, acc[ix < XB ? ix : 0]);            \
-        if (NEAR) acc[ix < XB ? ix : 0] = fmaf(w2, u[qd].c, acc[ix < XB ? ix : 0]); \
+        KQ_ACC(ix < XB ? ix : 0) = fmaf(w, v[qd].c, KQ_ACC(ix < XB ? ix : 0));            \
+        if (NEAR) KQ_ACC(ix < XB ? ix : 0) = fmaf(w2, u[qd].c, KQ_ACC(ix < XB ? ix : 0)); \
     } else {                                                                        \
         asm volatile("" ::"v"(v[qd].c));                                            \
         if (NEAR) asm volatile("" ::"v"(u[qd].c));                                  \
@@ -910,15 +918,20 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     // FMAs below all of its LDS reads (which then spill).  Passing the accumulators
     // through an empty volatile asm (with a memory clobber) after every group of reads and every
     // step's FMAs pins the order reads(s+1) -> FMAs(s) without consuming any load result early.
-#define KQ_PIN()                                                                                         \
-    do {                                                                                                 \
-        static_assert(XB == 24, "KQ_PIN lists 24 accumulators");                                         \
-        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]),         \
-                          "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]),         \
-                          "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]),    \
-                          "+v"(acc[15]), "+v"(acc[16]), "+v"(acc[17]), "+v"(acc[18]), "+v"(acc[19]),    \
-                          "+v"(acc[20]), "+v"(acc[21]), "+v"(acc[22]), "+v"(acc[23])                    \
-                     :: "memory");                                                                       \
+#define KQ_PIN()                                                                                          \
+    do {                                                                                                  \
+        static_assert(XB == 24 || XB == 32 || XB == 40, "KQ_PIN lists XB/4 accumulator quads");           \
+        if (XB == 24)                                                                                     \
+            asm volatile("" : "+v"(acc4[0]), "+v"(acc4[1]), "+v"(acc4[2]), "+v"(acc4[3]), "+v"(acc4[4]), \
+                              "+v"(acc4[5]) :: "memory");                                                 \
+        else if (XB == 32)                                                                                \
+            asm volatile("" : "+v"(acc4[0]), "+v"(acc4[1]), "+v"(acc4[2]), "+v"(acc4[3]), "+v"(acc4[4]), \
+                              "+v"(acc4[5]), "+v"(acc4[XB >= 32 ? 6 : 0]), "+v"(acc4[XB >= 32 ? 7 : 0])   \
+                         :: "memory");                                                                    \
+        else                                                                                              \
+            asm volatile("" : "+v"(acc4[0]), "+v"(acc4[1]), "+v"(acc4[2]), "+v"(acc4[3]), "+v"(acc4[4]), \
+                              "+v"(acc4[5]), "+v"(acc4[XB >= 32 ? 6 : 0]), "+v"(acc4[XB >= 32 ? 7 : 0]),  \
+                              "+v"(acc4[XB >= 40 ? 8 : 0]), "+v"(acc4[XB >= 40 ? 9 : 0]) :: "memory");    \
     } while (0)
 
     float n2c[S];                                  // n^2 of the current block's steps
@@ -999,8 +1012,9 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
         float *o = P.out + (size_t)ti_raw * P.ldo + (x0 - P.xlo);
 #pragma unroll
         for (int i = 0; i < XB; ++i)
-            if (x0 + i >= P.xlo && x0 + i < P.xhi) o[i] = acc[i] * fin;
+            if (x0 + i >= P.xlo && x0 + i < P.xhi) o[i] = KQ_ACC(i) * fin;
     }
+#undef KQ_ACC
 #ifdef KQ_STAMP
     // diagnostic build (build/stamp_run.py): workgroup residency timeline, us per step per chunk
     if (tid == 0 && P.stamps) {
@@ -1149,10 +1163,25 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     // fast kernels need the moveout 2dx/(v dt) (samples per trace) small enough for their
     // LDS windows: quad (sample-major ring, 24 traces x 8-step blocks, up to ~6.7 samples/trace)
     // or, for steeper moveout, tab (trace-major ring of 16 traces, 512-sample slots)
-    const int wq = ((KF_THREADS + (int)std::ceil(sa * (24 + 8 - 2)) + 8 + 31) / 32) * 32;   // whole 32-row pieces
+    // quad kernel's output-trace tile: 24 traces (40-slot ring, three workgroups per CU) or 40 traces
+    // (56-slot ring, two workgroups per CU).  The wider tile stages and picks 40 % less per pair and is
+    // 2.5-5 % faster on a whole radargram (same-box A/B at config 3; 32 traces: 1.3 %); with the short
+    // launches of a many-rank run (under ~2000 output traces per rank) its fewer, longer workgroups
+    // balance worse (-7 % at 8 ranks), so those keep 24.  IMPDAR_KIRCH_XB = 24 / 32 / 40 overrides.
+    int xbq = 24;
+    {
+        auto rows_for = [&](int xb) { return ((KF_THREADS + (int)std::ceil(sa * (xb + 8 - 2)) + 8 + 31) / 32) * 32; };
+        const char *xe = getenv("IMPDAR_KIRCH_XB");
+        if (xe && (atoi(xe) == 24 || atoi(xe) == 32 || atoi(xe) == 40))
+            xbq = atoi(xe);
+        else if ((size_t)(rows_for(40) / 32) * kq_piece_bytes(40) <= 80 * 1024 && (long long)tnum >= 2000LL * nranks)
+            xbq = 40;
+    }
+    const int kq_ps = kq_piece_bytes(xbq);
+    const int wq = ((KF_THREADS + (int)std::ceil(sa * (xbq + 8 - 2)) + 8 + 31) / 32) * 32;   // whole 32-row pieces
     // (two workgroups per CU: 80 KB of LDS each; table entries are 16-bit byte offsets up to 12 pieces,
     // 16-byte units beyond)
-    const bool quad_ok = (size_t)(wq / 32) * KQ_PS <= 80 * 1024;
+    const bool quad_ok = (size_t)(wq / 32) * kq_ps <= 80 * 1024;
     const bool tab_ok = (KF_THREADS + sa * (16 - 1) + 8.0) <= (double)KF_W;
     const bool window_ok = quad_ok || tab_ok;
     // aperture half width in traces (upper bound): below 65536 (the kernel squares trace offsets in 32
@@ -1174,9 +1203,9 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     {
         const char *ie = getenv("IMPDAR_KIRCH_IMPL");       // tuning knob: "tab" forces the b32 ring
         p->quadW = wq;
-        p->quadSH = ((size_t)(wq / 32) * KQ_PS <= 65535) ? 0 : 4;
+        p->quadSH = ((size_t)(wq / 32) * kq_ps <= 65535) ? 0 : 4;
         p->quad = (mode == IMPDAR_KIRCH_FAST) && quad_ok && !(ie && !strcmp(ie, "tab") && tab_ok);
-        p->xb = p->quad ? 24 : 16;
+        p->xb = p->quad ? xbq : 16;
     }
 
     int rc = IMPDAR_OK;
@@ -1307,7 +1336,7 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
             // the 24-trace window of a lane at its last slot and leave it 23 steps later)
             std::vector<int> win((size_t)nch * p->nrows * 2);
             for (int r = 0; r < p->nrows; ++r) {
-                const long long na = 8LL * (r - p->mrow0) + 1, nz = na + 30;
+                const long long na = 8LL * (r - p->mrow0) + 1, nz = na + p->xb + 6;
                 const long long lo = (na <= 0 && nz >= 0) ? 0 : std::min(std::llabs(na), std::llabs(nz));
                 const long long hi = std::max(std::llabs(na), std::llabs(nz));
                 for (int c = 0; c < nch; ++c) {
@@ -1423,6 +1452,7 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
         T.nmax = p->ntab - 1;
         T.wmod = p->quadW;
         T.sh = p->quadSH;
+        T.ps = kq_piece_bytes(p->xb);
         // rows a + mrow0 (a >= 0) and mrow0 - a - 1: a runs over the larger of the two sides
         const int na = std::max(p->nrows - p->mrow0, p->mrow0);
         hipLaunchKernelGGL(kirch_tableq_kernel, dim3((p->snum + 255) / 256, na), dim3(256), 0, st, T);
@@ -1486,7 +1516,7 @@ static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipSt
     P.tiles_per_xcd = nxt_pad / 8;
     const int nblk = P.nchunks * nxt_pad;
     const int W = p->quadW;
-    const size_t shmem = (size_t)(W / 32) * KQ_PS * (p->nearfield ? 2 : 1);
+    const size_t shmem = (size_t)(W / 32) * kq_piece_bytes(XB) * (p->nearfield ? 2 : 1);
     if (p->nearfield) {
         auto k = kirch_quad_kernel<XB, true, 1, SH>;
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -1576,9 +1606,13 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         const char *oe0 = getenv("IMPDAR_KIRCH_OCC");      // tuning knob: min waves per SIMD to compile for
         const int occ0 = oe0 ? atoi(oe0) : 0;
         if (p->quad && p->quadSH == 0)
-            rc = (occ0 == 2) ? launch_quad<24, 2, 0>(p, P, nx, st) : launch_quad<24, 3, 0>(p, P, nx, st);
+            rc = p->xb == 40 ? launch_quad<40, 2, 0>(p, P, nx, st)
+                 : p->xb == 32 ? launch_quad<32, 2, 0>(p, P, nx, st)
+                 : (occ0 == 2) ? launch_quad<24, 2, 0>(p, P, nx, st) : launch_quad<24, 3, 0>(p, P, nx, st);
         else if (p->quad)
-            rc = launch_quad<24, 2, 4>(p, P, nx, st);      // steep moveout: ring > 371 rows, two workgroups per CU
+            rc = p->xb == 40 ? launch_quad<40, 2, 4>(p, P, nx, st)
+                 : p->xb == 32 ? launch_quad<32, 2, 4>(p, P, nx, st)
+                             : launch_quad<24, 2, 4>(p, P, nx, st);      // steep moveout: two workgroups per CU
         else
             rc = launch_tab<16, 4, 4>(p, P, nx, st);
         if (rc) return rc;

@@ -337,3 +337,36 @@ def test_multirank_plan_shard_prep_matches_one_shot(hip):
         d_out.free()
         plan.destroy()
         assert np.array_equal(got, full)
+
+
+@pytest.mark.parametrize('xb', ['32', '40'])
+def test_wide_output_tiles(hip, xb, monkeypatch):
+    """The quad kernel with 32- and 40-trace output tiles (40 is what whole radargrams of >= 2000 traces per
+    rank use; small ones default to 24): sizes, moveouts, near field and an output block against the C oracle."""
+    from impdar_amd import synth, _hip
+    from impdar_amd.kirchhoff import KirchhoffPlan, migrate_resident
+    from oracle import c_oracle
+    monkeypatch.setenv('IMPDAR_KIRCH_XB', xb)
+    ctx = hip.context()
+    for snum, tnum, dx, near in [(300, 211, 1.0, False), (700, 129, 2.5, True), (257, 33, 0.3, False), (64, 1, 1.0, False)]:
+        geo = synth.geometry(snum, tnum, dx=dx)
+        data = synth.noise_radargram(snum, tnum, seed=snum).astype(np.float32)
+        want = c_oracle.kirchhoff(data, geo['travel_time'], geo['dist'], 1.69e8, near)
+        out, mode, _ = migrate_resident(ctx, data, geo['dist'], geo['travel_time'], nearfield=near, mode='fast')
+        assert mode == 'fast' and rel_l2(out, want) < FAST_L2, (xb, snum, tnum, rel_l2(out, want))
+    # an output block that does not start at a multiple of 8
+    snum, tnum = 300, 211
+    geo = synth.geometry(snum, tnum)
+    data = synth.noise_radargram(snum, tnum, seed=1).astype(np.float32)
+    full, _, _ = migrate_resident(ctx, data, geo['dist'], geo['travel_time'], mode='fast')
+    plan = KirchhoffPlan(ctx, np.float32, snum, tnum, geo['dist'], geo['travel_time'], mode='fast')
+    d_in = _hip.DeviceArray.from_host(ctx, data)
+    d_out = _hip.DeviceArray(ctx, (snum, 150 - 37), np.float32)
+    plan.prep(d_in, tnum, 0, tnum)
+    plan.migrate(d_out, 37, 150)
+    plan.sync()
+    got = d_out.to_host()
+    plan.destroy()
+    d_in.free()
+    d_out.free()
+    assert np.array_equal(got, full[:, 37:150])
