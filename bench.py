@@ -213,8 +213,8 @@ def main():
                          # port (one 4-byte ds_read lane per pair)
                          "on_chip": {"bound": "lds", "achieved": achieved, "peak": LDS_PEAK_GBS, "unit": "GB/s",
                                      "frac": (achieved / LDS_PEAK_GBS) if achieved else None,
-                                     "note": "peak at the 2.4 GHz spec clock; the kernel holds ~1.9 GHz, where "
-                                             "rocprof counts 86% of the LDS cycles busy"}},
+                                     "note": "peak at the 2.4 GHz spec clock; the kernel holds ~1.9-2.1 GHz, where "
+                                             "rocprof counts 78% of the LDS cycles busy (40-trace tiles)"}},
         }
         if world == 1 and not args.no_cpu:
             t0 = time.time()
