@@ -31,6 +31,7 @@ _p = C.c_void_p
 _dp = C.POINTER(C.c_double)
 _i = C.c_int
 _d = C.c_double
+_ip = C.POINTER(C.c_int)
 
 # name -> (restype, argtypes); must list every symbol of include/impdar_hip.h
 SIGNATURES = {
@@ -62,6 +63,12 @@ SIGNATURES = {
     'impdar_phaseshift': (_i, [_p, _p, _i, _i, _i, _i, _dp, _dp, _d, _dp, _d, _dp, _i, _d, _d, _p]),
     'impdar_phaseshift_ffd': (_i, [_p, _dp, _i, _i, _i, _dp, _dp, _d, _dp, _dp, _d, _d, _d, _dp]),
     'impdar_taper': (_i, [_p, _p, _i, _i, _i, _d, _d]),
+    'impdar_filtfilt': (_i, [_p, _p, _i, _i, _i, _dp, _dp, _i, _dp]),
+    'impdar_filtfilt_dev': (_i, [_p, _p, _i, _i, _i, _dp, _dp, _i, _dp]),
+    'impdar_fir_shift': (_i, [_p, _p, _i, _i, _i, _dp, _i]),
+    'impdar_fir_shift_dev': (_i, [_p, _p, _i, _i, _i, _dp, _i]),
+    'impdar_trace_lerp': (_i, [_p, _p, _i, _i, _i, _ip, _ip, _dp, _dp, _i, _p]),
+    'impdar_trace_lerp_dev': (_i, [_p, _p, _i, _i, _i, _ip, _ip, _dp, _dp, _i, _p]),
     'impdar_comm_unique_id': (_i, [C.c_char_p]),
     'impdar_comm_init': (_i, [_p, C.c_char_p, _i, _i]),
     'impdar_comm_rank': (_i, [_p]),

@@ -1,11 +1,12 @@
 #! /usr/bin/env python
-"""``impproc migrate`` on the MI355X engine.
+"""``impproc migrate`` (and the two steps usually run in front of it, ``vbp`` and ``interp``) on the MI355X
+engine.
 
-Mirrors the migrate sub-command of the reference's ``src/impdar/bin/impproc.py``
-(parser ``:295-343``, ``main`` ``:378-415``, ``mig`` ``:508-519``): same
-options, types and defaults, same output naming (``<name minus _raw>_migrated.mat``,
-``-o`` file or folder).  The reference's other 18 processing sub-commands are
-out of scope.
+Mirrors these sub-commands of the reference's ``src/impdar/bin/impproc.py`` (migrate parser ``:295-343``,
+vbp ``:113-125``, interp ``:222-251``, ``main`` ``:378-415``, ``mig`` ``:508-519``, ``vbp`` ``:438-440``,
+``interp`` ``:483-491``): same options, types and defaults, same output naming
+(``<name minus _raw>_<migrated|bandpassed|interp>.mat``, ``-o`` file or folder).  The reference's other
+processing sub-commands are out of scope.
 
     python -m impdar_amd.bin.impproc migrate --mtype kirch line1_raw.mat
 """
@@ -36,11 +37,32 @@ def _get_args():
     parser_mig.add_argument('--nxpad', type=int, default=100, help='Number of traces to pad with zeros for FFT')
     parser_mig.add_argument('--tmig', type=int, default=0, help='Times for velocity profile')
     parser_mig.add_argument('--verbose', type=int, default=1, help='Print output from SeisUnix migration')
-    parser_mig.add_argument('fns', type=str, nargs='+', help='The files to process')
-    parser_mig.add_argument('-o', type=str, help='Output to this file (folder if multiple inputs)')
-    parser_mig.add_argument('--ftype', type=str, default='mat', help='Type of file to load (default ImpDAR mat)',
-                            choices=FILETYPE_OPTIONS)
+    _add_def_args(parser_mig)
+
+    parser_vbp = subparsers.add_parser('vbp', help='Vertically bandpass the data')
+    parser_vbp.set_defaults(func=vbp, name='bandpassed')
+    parser_vbp.add_argument('low_MHz', type=float, help='Lowest frequency passed (in MHz)')
+    parser_vbp.add_argument('high_MHz', type=float, help='Highest frequency passed (in MHz)')
+    _add_def_args(parser_vbp)
+
+    parser_interp = subparsers.add_parser('interp', help='Reinterpolate GPS')
+    parser_interp.set_defaults(func=interp, name='interp')
+    parser_interp.add_argument('spacing', type=float, help='New spacing of radar traces, in meters')
+    parser_interp.add_argument('--gps_fn', type=str, default=None,
+                               help='File with precision GPS (kinematic GPS control is not part of this engine; '
+                                    'only the default, the GPS already in the file, is accepted)')
+    parser_interp.add_argument('--offset', type=float, default=0.0, help='Offset from GPS time to radar time')
+    parser_interp.add_argument('--minmove', type=float, default=1.0e-2, help='Minimum movement to not be stationary')
+    parser_interp.add_argument('--extrapolate', action='store_true', help='Extrapolate GPS data beyond bounds')
+    _add_def_args(parser_interp)
     return parser
+
+
+def _add_def_args(parser):
+    parser.add_argument('fns', type=str, nargs='+', help='The files to process')
+    parser.add_argument('-o', type=str, help='Output to this file (folder if multiple inputs)')
+    parser.add_argument('--ftype', type=str, default='mat', help='Type of file to load (default ImpDAR mat)',
+                        choices=FILETYPE_OPTIONS)
 
 
 def main():
@@ -50,8 +72,11 @@ def main():
         parser.parse_args(['-h'])
 
     radar_data = load(args.ftype, args.fns)
-    for dat in radar_data:
-        args.func(dat, **vars(args))
+    if args.name == 'interp':
+        interp(radar_data, **vars(args))
+    else:
+        for dat in radar_data:
+            args.func(dat, **vars(args))
 
     if args.o is not None:
         if (len(radar_data) > 1) or (args.o[-1] == '/'):
@@ -75,6 +100,19 @@ def mig(dat, mtype='stolt', vel=1.69e8, vtaper=100, htaper=100, tmig=0, verbose=
     """Migrate data (defaults as the reference's ``impproc.mig``)."""
     dat.migrate(mtype, vel=vel, vtaper=vtaper, htaper=htaper, tmig=tmig, verbose=verbose, vel_fn=vel_fn,
                 nxpad=nxpad, nearfield=nearfield)
+
+
+def vbp(dat, low_MHz=1, high_MHz=10000, **kwargs):
+    """Vertically bandpass the data."""
+    dat.vertical_band_pass(low_MHz, high_MHz)
+
+
+def interp(dats, spacing, gps_fn=None, offset=0.0, minmove=1.0e-2, extrapolate=False, **kwargs):
+    """Move data to constant spacing (the reference's ``gpslib.interp`` without external GPS control)."""
+    if gps_fn is not None:
+        raise NotImplementedError('kinematic GPS control (--gps_fn) is not part of the MI355X migration engine')
+    for dat in dats:
+        dat.constant_space(spacing, min_movement=minmove)
 
 
 if __name__ == '__main__':

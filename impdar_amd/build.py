@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libimpdar_hip.so')
-SOURCES = ['api.hip', 'comm.hip', 'kirchhoff.hip', 'stolt.hip', 'phaseshift.hip']
+SOURCES = ['api.hip', 'comm.hip', 'kirchhoff.hip', 'stolt.hip', 'phaseshift.hip', 'preproc.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off',
          '-fno-slp-vectorize', '-Wall', '-Wno-unused-function']
 

@@ -6,14 +6,19 @@ Mirrors (re-implemented, not copied) the reference's
 ``src/impdar/lib/RadarData/__init__.py:36-61`` (attribute lists), ``:124-244``
 (None-initialisation and ``.mat`` load), ``:270-331`` (``check_attrs``),
 ``_RadarDataSaving.py:32-78`` (``save`` incl. the cast back to the file's
-dtype) and ``_RadarDataFiltering.py:590-637`` (``migrate``).  Everything else
-in the reference's class (filters, picks, GPS, plotting) is out of scope.
+dtype), ``_RadarDataFiltering.py:590-637`` (``migrate``) and the two steps an
+impproc chain runs in front of a migration: ``vertical_band_pass``
+(``_RadarDataFiltering.py:469-549``) and ``constant_space``
+(``_RadarDataProcessing.py:499-583``).  Everything else in the reference's
+class (other filters, picks, GPS, plotting) is out of scope.
 """
 import numpy as np
 
 from ..ImpdarError import ImpdarError
 from ..RadarFlags import RadarFlags
-from ._RadarDataFiltering import migrate as _migrate
+from ._RadarDataFiltering import migrate as _migrate, vertical_band_pass as _vertical_band_pass
+from ._RadarDataProcessing import constant_space as _constant_space
+from ... import resident as _resident
 
 STODEEP_ATTRS = ['data', 'migdata', 'interp_data', 'nmo_data', 'filtdata', 'hfilt_data']
 
@@ -25,6 +30,10 @@ class RadarData(object):
     stodeep_attrs = STODEEP_ATTRS
 
     migrate = _migrate
+    vertical_band_pass = _vertical_band_pass
+    constant_space = _constant_space
+    to_device = _resident.to_device
+    from_device = _resident.from_device
 
     def __init__(self, fn_mat):
         for attr in self.attrs_guaranteed + self.attrs_optional:
@@ -33,6 +42,7 @@ class RadarData(object):
         self.picks = None
         self.data_dtype = None
         self._picks_struct = None
+        self._dev = None
         self.fn = fn_mat
         if fn_mat is None:
             return
@@ -111,6 +121,8 @@ class RadarData(object):
         """Write a StoDeep/ImpDAR ``.mat``; ``data`` is cast back to the dtype
         it was loaded with (NaN-aware for integer files)."""
         from scipy.io import savemat
+        if getattr(self, '_dev', None) is not None:
+            self.from_device()
         mat = {}
         for attr in self.attrs_guaranteed:
             val = getattr(self, attr)

@@ -1,32 +1,60 @@
-"""The migrate hook of ImpDAR's multi-step driver.
+"""The band-pass / re-spacing / migration chain of ImpDAR's multi-step driver.
 
-Mirrors the part of the reference's ``src/impdar/lib/process.py`` that touches
-migration: ``process(..., migrate=X)`` calls ``dat.migrate(mtype='stolt')`` for
-every RadarData whatever ``X`` is (``process.py:190-193`` -- the string given
-on the command line is ignored by the reference, and so it is here),
-``process_and_exit`` loads, processes and saves with the reference's file
-naming (``:30-70``, ``:274-295``).  The other processing steps of that driver
-(crop, nmo, filters, restack, interp, denoise) are out of scope and rejected.
+Mirrors the part of the reference's ``src/impdar/lib/process.py`` that leads up to a migration, in the
+reference's order (``:72-197``): ``vbp=(low, high)`` -> ``dat.vertical_band_pass`` (``:151-154``),
+``interp=(spacing, gps_fn)`` -> ``gpslib.interp`` = ``dat.constant_space`` when no GPS file is given
+(``:178-180``), ``migrate=X`` -> ``dat.migrate(mtype='stolt')`` whatever ``X`` is (``:190-193`` -- the string
+given on the command line is ignored by the reference, and so it is here).  When more than one of the steps
+is requested on a float radargram it is uploaded once and stays in HBM until the last step is done.
+``process_and_exit`` loads, processes and saves with the reference's file naming (``:30-70``, ``:274-295``).
+The other steps of that driver (crop, nmo, horizontal filters, restack, denoise, reverse) are out of scope
+and rejected.
 """
 import os
 
+import numpy as np
+
 from .load import load
 
-_OUT_OF_SCOPE = ('interp', 'rev', 'vbp', 'hfilt', 'ahfilt', 'nmo', 'crop', 'hcrop', 'restack', 'denoise')
+_OUT_OF_SCOPE = ('rev', 'hfilt', 'ahfilt', 'nmo', 'crop', 'hcrop', 'restack', 'denoise')
 
 
-def process(RadarDataList, migrate=None, **kwargs):
+def process(RadarDataList, interp=None, vbp=None, migrate=None, **kwargs):
     """Returns True if something was done (reference ``process.py:72-197``)."""
     for name in _OUT_OF_SCOPE:
         if kwargs.get(name) not in (None, False):
             raise NotImplementedError('processing step %r is not part of the MI355X migration engine; '
                                       'run it with the reference ImpDAR first' % name)
-    done_stuff = False
-    if migrate is not None:
-        for dat in RadarDataList:
-            dat.migrate(mtype='stolt')
-        done_stuff = True
-    return done_stuff
+    if vbp is not None:
+        if not hasattr(vbp, '__iter__'):
+            raise TypeError('vbp must be a tuple with first two elements [low] [high] MHz')
+    if interp is not None:
+        try:
+            float(interp[0])
+            interp[1]
+        except (ValueError, TypeError, IndexError):
+            raise ValueError('interp must be a target spacing (float) then a gps filename')
+        if interp[1] is not None:
+            raise NotImplementedError('kinematic GPS control (a gps filename for interp) is not part of the '
+                                      'MI355X migration engine')
+    steps = sum(x is not None for x in (vbp, interp, migrate))
+    if steps == 0:
+        return False
+    for dat in RadarDataList:
+        resident = steps > 1 and np.asarray(dat.data).dtype in (np.float32, np.float64)
+        if resident:
+            dat.to_device()
+        try:
+            if vbp is not None:
+                dat.vertical_band_pass(*vbp)
+            if interp is not None:
+                dat.constant_space(float(interp[0]))
+            if migrate is not None:
+                dat.migrate(mtype='stolt')
+        finally:
+            if resident:
+                dat.from_device()
+    return True
 
 
 def _save(rd_list, outpath=None, cat=False):

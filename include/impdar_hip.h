@@ -170,6 +170,38 @@ int impdar_phaseshift_ffd(impdar_ctx *ctx, const double *data, int snum, int tnu
 int impdar_taper(impdar_ctx *ctx, void *data_inout, int dtype, int snum, int tnum,
                  double htaper, double vtaper);
 
+/* ---- processing steps in front of a migration ----------
+ * The `_dev` forms take device pointers and run on the context's compute
+ * stream without synchronising it, so a radargram can stay resident from the
+ * first filter to the migrated image; the plain forms take host buffers.
+ *
+ * impdar_filtfilt: RadarData.vertical_band_pass with an IIR design
+ * (_RadarDataFiltering.py:527-535) = scipy.signal.filtfilt(b, a, data, axis=0)
+ * cast back to the data's dtype, in place.  b, a: `ncoef` (2..33)
+ * coefficients each; zi: ncoef-1 steady-state initial conditions
+ * (scipy.signal.lfilter_zi).  Fails with scipy's message when
+ * snum <= 3*ncoef.
+ * impdar_fir_shift: the FIR branch (:536-540): rows [0, snum-order) become
+ * lfilter(taps, 1, data)[order:], the last `order` = ntaps-1 rows are left.
+ * impdar_trace_lerp: the data part of RadarData.constant_space
+ * (_RadarDataProcessing.py:549-553): out[k, m] = (data[k, hi[m]] -
+ * data[k, lo[m]]) / den[m] * t[m] + data[k, lo[m]] (scipy interp1d's slope
+ * form), out float64 (snum, n_new); lo/hi/den/t are host arrays. */
+int impdar_filtfilt(impdar_ctx *ctx, void *data_inout, int dtype, int snum, int tnum,
+                    const double *b, const double *a, int ncoef, const double *zi);
+int impdar_filtfilt_dev(impdar_ctx *ctx, void *d_data_inout, int dtype, int snum, int tnum,
+                        const double *b, const double *a, int ncoef, const double *zi);
+int impdar_fir_shift(impdar_ctx *ctx, void *data_inout, int dtype, int snum, int tnum,
+                     const double *taps, int ntaps);
+int impdar_fir_shift_dev(impdar_ctx *ctx, void *d_data_inout, int dtype, int snum, int tnum,
+                         const double *taps, int ntaps);
+int impdar_trace_lerp(impdar_ctx *ctx, const void *data, int dtype, int snum, int tnum,
+                      const int *lo, const int *hi, const double *den, const double *t,
+                      int n_new, double *out);
+int impdar_trace_lerp_dev(impdar_ctx *ctx, const void *d_data, int dtype, int snum, int tnum,
+                          const int *lo, const int *hi, const double *den, const double *t,
+                          int n_new, double *d_out);
+
 /* ---- communicator (RCCL over xGMI) ------------------------------------- */
 #define IMPDAR_UNIQUE_ID_BYTES 128
 int impdar_comm_unique_id(char id[IMPDAR_UNIQUE_ID_BYTES]);

@@ -187,6 +187,58 @@ def tk_case():
          trace_int=geo['trace_int'], dt=geo['dt'], htaper=7, vtaper=5, expected=dat.data)
 
 
+def vbp_case(name, snum, tnum, dtype, dt, low, high, seed, **kw):
+    """RadarData.vertical_band_pass of the reference (_RadarDataFiltering.py:469-549) on noise."""
+    from impdar.lib.NoInitRadarData import NoInitRadarDataFiltering
+    rng = np.random.default_rng(seed)
+    raw = rng.standard_normal((snum, tnum))
+    data = (raw * 1000.).astype(dtype) if np.issubdtype(dtype, np.integer) else raw.astype(dtype)
+    d = NoInitRadarDataFiltering()
+    d.data = data.copy()
+    d.snum, d.tnum = data.shape
+    d.dt = dt
+    quiet(d.vertical_band_pass, low, high, **kw)
+    save(name, data=data, dt=dt, low=low, high=high, order=kw.get('order', 5),
+         filttype=kw.get('filttype', 'butter'), cheb_rp=kw.get('cheb_rp', 5), expected=d.data,
+         bpass=np.asarray(d.flags.bpass, dtype=float))
+
+
+def cspace_case(name, snum, tnum, dtype, spacing, min_movement, seed, stationary=()):
+    """RadarData.constant_space of the reference (_RadarDataProcessing.py:499-583): uneven trace spacing,
+    optionally with runs of stationary shots."""
+    from impdar.lib.NoInitRadarData import NoInitRadarDataFiltering
+    rng = np.random.default_rng(seed)
+    raw = rng.standard_normal((snum, tnum))
+    if dtype == np.complex128:
+        data = raw + 1.j * rng.standard_normal((snum, tnum))
+    elif np.issubdtype(dtype, np.integer):
+        data = (raw * 1000.).astype(dtype)
+    else:
+        data = raw.astype(dtype)
+    steps = 0.8 + 0.9 * rng.random(tnum - 1)            # metres between shots
+    for lo, hi in stationary:
+        steps[lo:hi] = 1.0e-3 * rng.random(hi - lo)
+    dist = np.hstack(([0.0], np.cumsum(steps))) / 1000. + 0.25
+    d = NoInitRadarDataFiltering()
+    d.data = data.copy()
+    d.snum, d.tnum = data.shape
+    d.dist = dist.copy()
+    d.trace_num = np.arange(tnum) + 1.
+    d.trace_int = np.hstack(([steps[0]], steps))
+    for i, attr in enumerate(['lat', 'long', 'x_coord', 'y_coord', 'decday', 'pressure', 'elev']):
+        setattr(d, attr, np.cumsum(rng.random(tnum)) + i)
+    d.trig = rng.integers(0, 5, tnum)
+    d.picks = None
+    attrs_in = {a + '_in': np.array(getattr(d, a)) for a in
+                ['lat', 'long', 'x_coord', 'y_coord', 'decday', 'pressure', 'elev', 'trig']}
+    quiet(d.constant_space, spacing, min_movement=min_movement)
+    attrs_out = {a + '_out': np.array(getattr(d, a)) for a in
+                 ['lat', 'long', 'x_coord', 'y_coord', 'decday', 'pressure', 'elev', 'trig', 'dist', 'trace_int',
+                  'trace_num']}
+    save(name, data=data, dist=dist, spacing=spacing, min_movement=min_movement, expected=d.data,
+         tnum_out=d.tnum, interp_flag=np.asarray(d.flags.interp, dtype=float), **attrs_in, **attrs_out)
+
+
 def main():
     slow = '--skip-slow' not in sys.argv
     # ---- Kirchhoff -------------------------------------------------------
@@ -227,6 +279,18 @@ def main():
     ffd_case('P4_phsh_ffd_32x16', 32, 16, 3, 4, 0)
     ffd_case('P4b_phsh_ffd_32x21', 32, 21, 2, 2, 1)
     tk_case()
+    # ---- processing steps in front of a migration --------
+    vbp_case('V1_vbp_butter_f64', 120, 9, np.float64, 1e-8, 2., 10., 0)
+    vbp_case('V2_vbp_cheb_f32', 150, 7, np.float32, 1e-8, 1., 20., 1, filttype='cheb')
+    vbp_case('V3_vbp_bessel_int16', 101, 5, np.int16, 1e-8, 2., 10., 2, filttype='bessel')
+    vbp_case('V4_vbp_fir_f64', 90, 6, np.float64, 1e-8, 2., 10., 3, filttype='fir', order=20)
+    vbp_case('V5_vbp_butter2_f32', 77, 65, np.float32, 2e-9, 5., 50., 4, order=2)
+    vbp_case('V6_vbp_butter8_f64', 200, 4, np.float64, 1e-8, 2., 10., 5, order=8)
+    vbp_case('V7_vbp_fir_int16', 64, 5, np.int16, 1e-8, 2., 10., 6, filttype='fir', order=10)
+    cspace_case('C1_cspace_f64', 24, 60, np.float64, 2.0, 1.0e-2, 0)
+    cspace_case('C2_cspace_f32_stationary', 20, 80, np.float32, 1.5, 1.0e-2, 1, stationary=((10, 14), (40, 41)))
+    cspace_case('C3_cspace_complex', 12, 40, np.complex128, 3.0, 1.0e-2, 2)
+    cspace_case('C4_cspace_int16_upsample', 16, 30, np.int16, 0.4, 1.0e-2, 3, stationary=((5, 8),))
 
 
 if __name__ == '__main__':
