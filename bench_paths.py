@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Secondary measurements (not the driver's bench contract): Stolt f-k at
-BASELINE config 2 (4096x4096 float32) and phase-shift at config 5 (8192x8192,
-constant v and 1-D v(z)), each through the product path on one MI355X.
+BASELINE config 2 (4096x4096 float32), phase-shift at config 5 (8192x8192,
+constant v and 1-D v(z)) and the band-pass / re-spacing steps in front of a
+migration at config-3 size (4096x10000 float32, resident in HBM, plus the
+three-step chain with and without residency), each through the product path on
+one MI355X.
 Prints one JSON line per path.  Host wall time includes H2D/D2H of the
 radargram (the entry points take host buffers).  Each line carries a
 ``cpu_baseline``: the NumPy oracle (a port of the reference's algorithm in
@@ -22,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--stolt', type=int, default=4096)
     ap.add_argument('--phsh', type=int, default=8192)
+    ap.add_argument('--chain', type=str, default='4096x10000', help='snum x tnum of the band-pass / re-spacing lines')
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--skip', default='')
     ap.add_argument('--no-cpu', action='store_true')
@@ -101,6 +105,91 @@ def main():
                           "host_seconds": el, "traces_per_s": n / el, "finite": bool(np.isfinite(d.data).all()),
                           "rotate_accumulate_steps": float(n) ** 3, "reference_extrapolated_hours": 7.6,
                           "cpu_baseline": cb}), flush=True)
+    if 'chain' not in args.skip:
+        from impdar_amd import preproc
+        from impdar_amd.lib.NoInitRadarData import NoInitRadarDataFiltering
+        snum, tnum = (int(v) for v in args.chain.split('x'))
+        ctx, lib = _hip.context(), _hip.load()
+        x = rng.standard_normal((snum, tnum)).astype(np.float32)
+        dist = np.hstack(([0.], np.cumsum(0.6 + 0.8 * rng.random(tnum - 1)))) / 1000.
+
+        def dev_ms(fn, reps=10):
+            fn()
+            lib.impdar_ctx_sync(ctx)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            lib.impdar_ctx_sync(ctx)
+            return (time.perf_counter() - t0) / reps * 1e3
+
+        def sample_cpu(fn, label):
+            if args.no_cpu:
+                return None
+            t0 = time.perf_counter()
+            fn()
+            return {"seconds": time.perf_counter() - t0, "kind": "reference", "cores": 1, "sample": label}
+
+        d_x = _hip.DeviceArray.from_host(ctx, x)
+        spec = preproc.design_filter(1e-8, 2., 10.)
+        ms = dev_ms(lambda: preproc.filter_dev(d_x, spec))
+        L = snum + 6 * len(spec[1])
+        algo = 2 * snum * tnum * 4 + 2 * L * tnum * 8        # read x, write/read the fp64 forward pass, write out
+        m = min(tnum, 1000)
+        from scipy import signal
+        cb = sample_cpu(lambda: signal.filtfilt(spec[1], spec[2], x[:, :m], axis=0).astype(np.float32),
+                        "scipy.signal.filtfilt (what the reference calls) on %d of %d traces" % (m, tnum))
+        print(json.dumps({"path": "vertical_band_pass butter order 5 (filtfilt), resident", "config": "%dx%d float32" % (snum, tnum),
+                          "device_ms": ms, "traces_per_s": tnum / ms * 1e3, "algorithmic_bytes": algo,
+                          "roofline": {"bound": "hbm", "achieved": algo / ms / 1e6, "peak": 8000.0, "unit": "GB/s",
+                                       "frac": algo / ms / 1e6 / 8000.0,
+                                       "note": "serial fp64 recurrence along time, 21 non-fused operations per sample: "
+                                               "issue-bound at 625 wavefronts, not HBM-bound"},
+                          "cpu_baseline": cb}), flush=True)
+        d_x.free()
+        d_x = _hip.DeviceArray.from_host(ctx, x)
+        plan = preproc.SpacingPlan(dist.copy(), 1.0)
+
+        def lerp():
+            o = plan.apply_dev(d_x)
+            lib.impdar_ctx_sync(ctx)
+            o.free()
+        ms = dev_ms(lerp)
+        algo = snum * tnum * 4 + snum * plan.n_new * 8
+        from scipy.interpolate import interp1d
+        ms_rows = min(snum, 256)
+        cb = sample_cpu(lambda: interp1d(dist, x[:ms_rows])(plan.new_dists),
+                        "scipy.interpolate.interp1d (what the reference calls) on %d of %d sample rows" % (ms_rows, snum))
+        print(json.dumps({"path": "constant_space (linear re-spacing), resident", "config": "%dx%d float32 -> %d traces float64" % (snum, tnum, plan.n_new),
+                          "device_ms": ms, "traces_per_s": tnum / ms * 1e3, "algorithmic_bytes": algo,
+                          "roofline": {"bound": "hbm", "achieved": algo / ms / 1e6, "peak": 8000.0, "unit": "GB/s",
+                                       "frac": algo / ms / 1e6 / 8000.0,
+                                       "note": "includes the output allocation and the upload of the gather tables"},
+                          "cpu_baseline": cb}), flush=True)
+        d_x.free()
+
+        def chain(resident):
+            d = NoInitRadarDataFiltering()
+            d.data, (d.snum, d.tnum) = x.copy(), x.shape
+            d.dt, d.dist = 1e-8, dist.copy()
+            d.travel_time = np.arange(snum) * 1e-2
+            for a in ['lat', 'long', 'x_coord', 'y_coord', 'decday', 'pressure', 'elev']:
+                setattr(d, a, np.arange(tnum, dtype=float))
+            d.trig = np.zeros(tnum)
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                if resident:
+                    d.to_device()
+                d.vertical_band_pass(2., 10.)
+                d.constant_space(1.0)
+                d.migrate('stolt', htaper=100, vtaper=1000)
+                if resident:
+                    d.from_device()
+            return time.perf_counter() - t0, d
+        for resident in (False, True):
+            best = min(chain(resident)[0] for _ in range(args.reps + 1))
+            print(json.dumps({"path": "chain vbp -> constant_space -> stolt, %s" % ("resident in HBM" if resident else "host buffers between steps"),
+                              "config": "%dx%d float32 in, float64 out" % (snum, tnum), "host_seconds": best,
+                              "traces_per_s": tnum / best}), flush=True)
 
 
 if __name__ == '__main__':

@@ -9,9 +9,9 @@
 //       linear interpolation of every sample row onto equally spaced distances (scipy interp1d, slope form).
 //
 // All three are HBM-streaming kernels; the arithmetic is fp64 in SciPy's operation order whatever the data
-// type (the file is compiled with -ffp-contract=off).  The IIR recurrence is a serial chain along time, so it
-// runs one trace per lane (rows of the (snum, tnum) array are contiguous across traces: every access is a
-// coalesced row segment) with the loads of the next 8 samples in flight while 8 are filtered.
+// type (the file is compiled with -ffp-contract=off).  The IIR recurrence is a serial chain along time: a
+// wavefront runs 16 traces, four lanes each (rows of the (snum, tnum) array are contiguous across traces, so
+// every access is a coalesced row segment), with the loads of the next 16 samples in flight while 16 are filtered.
 #include "common.h"
 
 #define FF_MAX_COEF 33
@@ -38,105 +38,300 @@ __device__ __forceinline__ double ff_ext(const T *__restrict__ x, int i, int j, 
     return (double)(T)((T)2 * e - v);
 }
 
-// one step of the transposed direct-form II recurrence, in the order of SciPy's C loop (_lfilter.c.in):
-//   y = z[0] + b[0]*x;  z[n] = z[n+1] + x*b[n+1] - y*a[n+1];  z[last] = x*b[last] - y*a[last]
-template <int NC> __device__ __forceinline__ double ff_step(double (&z)[NC - 1], const FiltCoefs &c, double xn)
+// The recurrence of one trace is spread over the four lanes of a quad: lane q keeps the K delays
+// z[qK .. qK+K-1] (K = ceil((NC-1)/4), padded with zero coefficients) and their coefficients in registers.
+// fp64 issues at half rate and a trace-per-lane mapping leaves 85 % of the SIMDs idle at 10000 traces (157
+// wavefronts for 1024 SIMDs), so the ~4(NC-1) fp64 operations of a step are the whole cost: split four ways
+// they take a third of the issue slots per wavefront on four times as many SIMDs.  Every delay is still
+// updated by exactly SciPy's expression (_lfilter.c.in),
+//   y = z[0] + b[0]*x;  z[n] = z[n+1] + x*b[n+1] - y*a[n+1];  z[last] = x*b[last] - y*a[last],
+// from the old value of its neighbour, fetched across lanes with quad DPP moves before anything is updated.
+__device__ __forceinline__ double ff_quad_bcast0(double v)
 {
-    const double y = z[0] + c.b[0] * xn;
+#ifdef FF_DIAG_NODPP   // timing ablation only
+    return v;
+#endif
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x00, 0xf, 0xf, true);   // quad_perm [0,0,0,0]
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x00, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ff_quad_next(double v)
+{
+#ifdef FF_DIAG_NODPP
+    return v * 0.5;
+#endif
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xF9, 0xf, 0xf, true);   // quad_perm [1,2,3,3]
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xF9, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int K> struct FfLane {
+    double z[K], B[K], A[K];
+    double b0;
+    bool last;   // lane 3 of the quad: nothing follows its last delay
+    __device__ __forceinline__ void init(const FiltCoefs &c, int q, int nc, double x0)
+    {
+        b0 = c.b[0];
+        last = q == 3;
 #pragma unroll
-    for (int n = 0; n < NC - 2; ++n) z[n] = z[n + 1] + xn * c.b[n + 1] - y * c.a[n + 1];
-    z[NC - 2] = xn * c.b[NC - 1] - y * c.a[NC - 1];
-    return y;
+        for (int k = 0; k < K; ++k) {
+            const int n = q * K + k;   // delay index; its coefficients are b[n+1], a[n+1]
+            const bool real = n + 1 < nc;
+            B[k] = real ? c.b[n + 1] : 0.0;
+            A[k] = real ? c.a[n + 1] : 0.0;
+            z[k] = (n < nc - 1) ? c.zi[n] * x0 : 0.0;
+        }
+    }
+    __device__ __forceinline__ double step(double xn)
+    {
+        const double y = ff_quad_bcast0(z[0]) + b0 * xn;
+        double zn = ff_quad_next(z[0]);
+        if (last) zn = 0.0;
+#pragma unroll
+        for (int k = 0; k < K - 1; ++k) z[k] = z[k + 1] + xn * B[k] - y * A[k];
+        z[K - 1] = zn + xn * B[K - 1] - y * A[K - 1];
+        return y;
+    }
+};
+
+#define FF_TRACES 16   // traces per 64-lane wavefront
+#define FF_CH 16       // samples per chunk: the loads of chunk c+1 are in flight while chunk c is filtered.
+                       // 32 would hide more latency but needs more than the 256 architectural VGPRs: the
+                       // compiler then parks live values in AccVGPRs, and a copy of a register whose asm
+                       // load has not landed yet copies garbage (seen as 1e-8 errors).  Keep vgpr_count <= 256.
+
+// With plain loads hipcc waits for the prefetched chunk before the first step of the current one (it treats
+// loads and stores pending on vmcnt as completing out of order and drains: s_waitcnt vmcnt(7) .. vmcnt(0) in
+// the ISA), which exposes the memory latency of every chunk (1.2 ms per band pass at config-3 size).  The
+// prefetch is therefore issued from inline asm, invisible to that bookkeeping, and retired by one explicit
+// s_waitcnt vmcnt(0) at the END of the chunk, tied to the loaded registers.  Nothing is assumed about the
+// relative completion order of loads and stores: the outputs of a chunk are kept in registers and stored at
+// the top of the next chunk, in front of the next prefetch, so that by the time of the wait everything
+// outstanding was issued a whole chunk (~1.3 us) earlier.
+__device__ __forceinline__ void ff_load_async(float &dst, const float *p)
+{
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void ff_load_async(double &dst, const double *p)
+{
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+#define FF_TIE16(r, o)                                                                                              \
+    "+v"(r[o + 0]), "+v"(r[o + 1]), "+v"(r[o + 2]), "+v"(r[o + 3]), "+v"(r[o + 4]), "+v"(r[o + 5]), "+v"(r[o + 6]),     \
+        "+v"(r[o + 7]), "+v"(r[o + 8]), "+v"(r[o + 9]), "+v"(r[o + 10]), "+v"(r[o + 11]), "+v"(r[o + 12]),              \
+        "+v"(r[o + 13]), "+v"(r[o + 14]), "+v"(r[o + 15])
+template <typename T> __device__ __forceinline__ void ff_wait_chunk(T (&r)[FF_CH])
+{
+    static_assert(FF_CH == 16, "operand list below");
+    asm volatile("s_waitcnt vmcnt(0)" : FF_TIE16(r, 0) : : "memory");
 }
 
 // forward pass over the extended trace; Y is (snum + 2*edge, tnum) fp64
 template <typename T, int NC>
 __global__ __launch_bounds__(64) void ff_forward_kernel(const T *__restrict__ x, double *__restrict__ Y, int snum,
-                                                        int tnum, int edge, FiltCoefs c)
+                                                        int tnum, int edge, int nc, FiltCoefs c)
 {
-    const int j = blockIdx.x * 64 + threadIdx.x;
-    if (j >= tnum) return;
+    constexpr int K = (NC - 1 + 3) / 4;
+    const int j = blockIdx.x * FF_TRACES + (threadIdx.x >> 2), q = threadIdx.x & 3;
+    if (j >= tnum) return;   // whole quads leave together
     const int L = snum + 2 * edge;
-    double z[NC - 1];
-    const double x0 = ff_ext(x, 0, j, snum, tnum, edge);
+    FfLane<K> f;
+    f.init(c, q, nc, ff_ext(x, 0, j, snum, tnum, edge));
+    double cur[FF_CH], held[FF_CH];
+    double *held_row = nullptr;   // outputs of the previous chunk still in registers (uniform)
 #pragma unroll
-    for (int n = 0; n < NC - 1; ++n) z[n] = c.zi[n] * x0;
-    int i = 0;
-    for (; i + 8 <= L; i += 8) {
-        double xv[8];
+    for (int u = 0; u < FF_CH; ++u) cur[u] = ff_ext(x, u < L ? u : L - 1, j, snum, tnum, edge);
+    for (int i = 0; i < L; i += FF_CH) {
+        if (held_row) {
+            // all four lanes of the quad store the same value: no divergent branch around the stores
 #pragma unroll
-        for (int u = 0; u < 8; ++u) xv[u] = ff_ext(x, i + u, j, snum, tnum, edge);
+            for (int u = 0; u < FF_CH; ++u) held_row[(size_t)u * tnum] = held[u];
+            held_row = nullptr;
+        }
+        const int r0 = i + FF_CH;                                      // first row of the next chunk
+        const bool inside = r0 >= edge && r0 + FF_CH <= edge + snum;   // uniform: plain rows of the data
+        T raw[FF_CH];
+        double nxt[FF_CH];
+        if (inside) {
+            const T *row = x + (size_t)(r0 - edge) * tnum + j;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) Y[(size_t)(i + u) * tnum + j] = ff_step<NC>(z, c, xv[u]);
+            for (int u = 0; u < FF_CH; ++u) {
+#ifdef FF_DIAG_NOLOAD   // timing ablation only
+                raw[u] = (T)(u + threadIdx.x) + (T)(size_t)row;
+#else
+                ff_load_async(raw[u], row + (size_t)u * tnum);
+#endif
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < FF_CH; ++u) nxt[u] = ff_ext(x, r0 + u < L ? r0 + u : L - 1, j, snum, tnum, edge);
+        }
+        double *yrow = Y + (size_t)i * tnum + j;
+        if (i + FF_CH <= L) {
+#pragma unroll
+            for (int u = 0; u < FF_CH; ++u) held[u] = f.step(cur[u]);
+            held_row = yrow;
+        } else {
+#pragma unroll
+            for (int u = 0; u < FF_CH; ++u) {
+                if (i + u < L) {   // uniform
+                    const double y = f.step(cur[u]);
+                    if (q == 0) yrow[(size_t)u * tnum] = y;
+                }
+            }
+        }
+        if (inside) {
+#ifndef FF_DIAG_NOLOAD
+            ff_wait_chunk(raw);
+#endif
+#pragma unroll
+            for (int u = 0; u < FF_CH; ++u) nxt[u] = (double)raw[u];
+        }
+#pragma unroll
+        for (int u = 0; u < FF_CH; ++u) cur[u] = nxt[u];
     }
-    for (; i < L; ++i) Y[(size_t)i * tnum + j] = ff_step<NC>(z, c, ff_ext(x, i, j, snum, tnum, edge));
+    if (held_row) {
+#pragma unroll
+        for (int u = 0; u < FF_CH; ++u) held_row[(size_t)u * tnum] = held[u];
+    }
 }
 
 // backward pass: filters Y from its last row to its first and writes rows [edge, edge+snum) back into the
 // data array in its own dtype (the rows in front of `edge` are never needed)
 template <typename T, int NC>
 __global__ __launch_bounds__(64) void ff_backward_kernel(const double *__restrict__ Y, T *__restrict__ out, int snum,
-                                                         int tnum, int edge, FiltCoefs c)
+                                                         int tnum, int edge, int nc, FiltCoefs c)
 {
-    const int j = blockIdx.x * 64 + threadIdx.x;
+    constexpr int K = (NC - 1 + 3) / 4;
+    const int j = blockIdx.x * FF_TRACES + (threadIdx.x >> 2), q = threadIdx.x & 3;
     if (j >= tnum) return;
     const int L = snum + 2 * edge;
-    double z[NC - 1];
-    const double y0 = Y[(size_t)(L - 1) * tnum + j];
+    FfLane<K> f;
+    f.init(c, q, nc, Y[(size_t)(L - 1) * tnum + j]);
+    double cur[FF_CH];
+    T held[FF_CH];
+    T *held_row = nullptr;
 #pragma unroll
-    for (int n = 0; n < NC - 1; ++n) z[n] = c.zi[n] * y0;
-    int p = L - 1;   // position in the extended trace
-    for (; p - 7 >= edge; p -= 8) {
-        double yv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) yv[u] = Y[(size_t)(p - u) * tnum + j];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const double v = ff_step<NC>(z, c, yv[u]);
-            const int r = p - u - edge;
-            if (r < snum) out[(size_t)r * tnum + j] = (T)v;
-        }
+    for (int u = 0; u < FF_CH; ++u) {
+        const int r = L - 1 - u;
+        cur[u] = Y[(size_t)(r > 0 ? r : 0) * tnum + j];
     }
-    for (; p >= edge; --p) {
-        const double v = ff_step<NC>(z, c, Y[(size_t)p * tnum + j]);
-        if (p - edge < snum) out[(size_t)(p - edge) * tnum + j] = (T)v;
+    for (int p = L - 1; p >= edge; p -= FF_CH) {   // p: position of cur[0] in the extended trace
+        if (held_row) {
+#pragma unroll
+            for (int u = 0; u < FF_CH; ++u) *(held_row - (size_t)u * tnum) = held[u];
+            held_row = nullptr;
+        }
+        const bool inside = p - 2 * FF_CH + 1 >= 0;   // uniform: the next chunk's rows all exist
+        double nxt[FF_CH];
+        if (inside) {
+            const double *row = Y + (size_t)(p - FF_CH) * tnum + j;
+#pragma unroll
+            for (int u = 0; u < FF_CH; ++u) {
+#ifdef FF_DIAG_NOLOAD
+                nxt[u] = (double)(u + threadIdx.x) + (double)(size_t)row;
+#else
+                ff_load_async(nxt[u], row - (size_t)u * tnum);
+#endif
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < FF_CH; ++u) {
+                const int r = p - FF_CH - u;
+                nxt[u] = Y[(size_t)(r > 0 ? r : 0) * tnum + j];
+            }
+        }
+        const int r0 = p - edge;   // output row of cur[0]
+        if (r0 < snum && r0 - (FF_CH - 1) >= 0) {
+#pragma unroll
+            for (int u = 0; u < FF_CH; ++u) held[u] = (T)f.step(cur[u]);
+            held_row = out + (size_t)r0 * tnum + j;
+        } else {
+#pragma unroll
+            for (int u = 0; u < FF_CH; ++u) {
+                const int r = r0 - u;
+                if (r >= 0) {   // uniform
+                    const double v = f.step(cur[u]);
+                    if (q == 0 && r < snum) out[(size_t)r * tnum + j] = (T)v;
+                }
+            }
+        }
+#ifndef FF_DIAG_NOLOAD
+        if (inside) ff_wait_chunk(nxt);
+#endif
+#pragma unroll
+        for (int u = 0; u < FF_CH; ++u) cur[u] = nxt[u];
+    }
+    if (held_row) {
+#pragma unroll
+        for (int u = 0; u < FF_CH; ++u) *(held_row - (size_t)u * tnum) = held[u];
     }
 }
 
+#define FIR_ROWS 8   // consecutive output rows per thread
+
 struct FirTaps {
-    double t[256];
+    double t[256 + 2 * FIR_ROWS];   // taps[i] at t[FIR_ROWS + i], zeros on both sides
 };
 
 // out[k, j] = sum_i taps[i] * x[k + order - i, j] for k < snum - order (lfilter delayed by `order` rows and
-// shifted back, _RadarDataFiltering.py:536-540); `out` is a separate array
+// shifted back, _RadarDataFiltering.py:536-540); `out` is a separate array.  A thread owns FIR_ROWS
+// consecutive rows of one trace and walks the order + FIR_ROWS input rows they touch once: one coalesced row
+// load and one scalar load of FIR_ROWS consecutive taps per input row, FIR_ROWS fp64 FMAs.
 template <typename T>
 __global__ __launch_bounds__(256) void fir_shift_kernel(const T *__restrict__ x, T *__restrict__ out, int snum, int tnum,
                                                         int ntaps, FirTaps taps)
 {
-    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int order = ntaps - 1;
-    const size_t n = (size_t)(snum - order) * tnum;
-    if (id >= n) return;
-    const int k = (int)(id / tnum), j = (int)(id % tnum);
-    double s = 0.0;
-    for (int i = 0; i < ntaps; ++i) s += taps.t[i] * (double)x[(size_t)(k + order - i) * tnum + j];
-    out[id] = (T)s;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int k0 = blockIdx.y * FIR_ROWS;
+    const int order = ntaps - 1, nout = snum - order;
+    if (j >= tnum) return;
+    double acc[FIR_ROWS];
+#pragma unroll
+    for (int u = 0; u < FIR_ROWS; ++u) acc[u] = 0.0;
+    // input row k0 + s contributes to output row k0 + u through tap i = u + order - s
+#pragma unroll 4
+    for (int s = 0; s < order + FIR_ROWS; ++s) {
+        const int r = k0 + s;
+        const double xv = r < snum ? (double)x[(size_t)r * tnum + j] : 0.0;
+        const double *tp = &taps.t[FIR_ROWS + order - s];
+#pragma unroll
+        for (int u = 0; u < FIR_ROWS; ++u) acc[u] = __builtin_fma(tp[u], xv, acc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < FIR_ROWS; ++u)
+        if (k0 + u < nout) out[(size_t)(k0 + u) * tnum + j] = (T)acc[u];
 }
 
 // out[k, m] = (y_hi - y_lo) / den[m] * t[m] + y_lo   (scipy interp1d._call_linear: the difference is taken in
 // the data's own arithmetic, everything after it in fp64)
+#define LERP_ROWS 8   // sample rows per thread: the four table entries of a column are loaded once for all of them
+
 template <typename T>
 __global__ __launch_bounds__(256) void trace_lerp_kernel(const T *__restrict__ x, double *__restrict__ out, int snum,
                                                          int tnum, int n_new, const int *__restrict__ lo,
                                                          const int *__restrict__ hi, const double *__restrict__ den,
                                                          const double *__restrict__ t)
 {
-    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (id >= (size_t)snum * n_new) return;
-    const int k = (int)(id / n_new), m = (int)(id % n_new);
-    const T ylo = x[(size_t)k * tnum + lo[m]], yhi = x[(size_t)k * tnum + hi[m]];
-    const double slope = (double)(T)(yhi - ylo) / den[m];
-    out[id] = slope * t[m] + (double)ylo;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= n_new) return;
+    const int k0 = blockIdx.y * LERP_ROWS;
+    const int jl = lo[m], jh = hi[m];
+    const double dm = den[m], tm = t[m];
+    T ylo[LERP_ROWS], yhi[LERP_ROWS];
+#pragma unroll
+    for (int u = 0; u < LERP_ROWS; ++u) {
+        const int k = k0 + u < snum ? k0 + u : snum - 1;
+        ylo[u] = x[(size_t)k * tnum + jl];
+        yhi[u] = x[(size_t)k * tnum + jh];
+    }
+#pragma unroll
+    for (int u = 0; u < LERP_ROWS; ++u) {
+        if (k0 + u < snum) {
+            const double slope = (double)(T)(yhi[u] - ylo[u]) / dm;
+            out[(size_t)(k0 + u) * n_new + m] = slope * tm + (double)ylo[u];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -170,11 +365,11 @@ void impdar_preproc_forget(impdar_ctx *ctx)
 }
 
 template <typename T, int NC>
-static int filtfilt_launch(impdar_ctx *ctx, T *d, double *Y, int snum, int tnum, int edge, const FiltCoefs &c)
+static int filtfilt_launch(impdar_ctx *ctx, T *d, double *Y, int snum, int tnum, int edge, int nc, const FiltCoefs &c)
 {
-    const int nb = (tnum + 63) / 64;
-    hipLaunchKernelGGL((ff_forward_kernel<T, NC>), dim3(nb), dim3(64), 0, ctx->stream, d, Y, snum, tnum, edge, c);
-    hipLaunchKernelGGL((ff_backward_kernel<T, NC>), dim3(nb), dim3(64), 0, ctx->stream, Y, d, snum, tnum, edge, c);
+    const int nb = (tnum + FF_TRACES - 1) / FF_TRACES;
+    hipLaunchKernelGGL((ff_forward_kernel<T, NC>), dim3(nb), dim3(64), 0, ctx->stream, d, Y, snum, tnum, edge, nc, c);
+    hipLaunchKernelGGL((ff_backward_kernel<T, NC>), dim3(nb), dim3(64), 0, ctx->stream, Y, d, snum, tnum, edge, nc, c);
     IMPDAR_HIP_CHECK(hipGetLastError());
     return IMPDAR_OK;
 }
@@ -182,10 +377,10 @@ static int filtfilt_launch(impdar_ctx *ctx, T *d, double *Y, int snum, int tnum,
 template <typename T>
 static int filtfilt_dispatch(impdar_ctx *ctx, T *d, double *Y, int snum, int tnum, int edge, int ncoef, const FiltCoefs &c)
 {
-    if (ncoef <= 5) return filtfilt_launch<T, 5>(ctx, d, Y, snum, tnum, edge, c);
-    if (ncoef <= 11) return filtfilt_launch<T, 11>(ctx, d, Y, snum, tnum, edge, c);
-    if (ncoef <= 21) return filtfilt_launch<T, 21>(ctx, d, Y, snum, tnum, edge, c);
-    return filtfilt_launch<T, FF_MAX_COEF>(ctx, d, Y, snum, tnum, edge, c);
+    if (ncoef <= 5) return filtfilt_launch<T, 5>(ctx, d, Y, snum, tnum, edge, ncoef, c);
+    if (ncoef <= 11) return filtfilt_launch<T, 11>(ctx, d, Y, snum, tnum, edge, ncoef, c);
+    if (ncoef <= 21) return filtfilt_launch<T, 21>(ctx, d, Y, snum, tnum, edge, ncoef, c);
+    return filtfilt_launch<T, FF_MAX_COEF>(ctx, d, Y, snum, tnum, edge, ncoef, c);
 }
 
 extern "C" int impdar_filtfilt_dev(impdar_ctx *ctx, void *d_data, int dtype, int snum, int tnum, const double *b,
@@ -226,16 +421,16 @@ extern "C" int impdar_fir_shift_dev(impdar_ctx *ctx, void *d_data, int dtype, in
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
     FirTaps t;
     memset(&t, 0, sizeof(t));
-    for (int i = 0; i < ntaps; ++i) t.t[i] = taps[i];
+    for (int i = 0; i < ntaps; ++i) t.t[FIR_ROWS + i] = taps[i];
     const size_t es = impdar_dtype_size(dtype), n = (size_t)(snum - order) * tnum;
     scratch_bind(ctx);
     IMPDAR_HIP_CHECK(g_scr.aux.ensure(n * es));
-    const unsigned nb = (unsigned)((n + 255) / 256);
+    const dim3 grid((tnum + 255) / 256, (snum - order + FIR_ROWS - 1) / FIR_ROWS);
     if (dtype == IMPDAR_F32)
-        hipLaunchKernelGGL(fir_shift_kernel<float>, dim3(nb), dim3(256), 0, ctx->stream, (const float *)d_data,
+        hipLaunchKernelGGL(fir_shift_kernel<float>, grid, dim3(256), 0, ctx->stream, (const float *)d_data,
                            g_scr.aux.as<float>(), snum, tnum, ntaps, t);
     else
-        hipLaunchKernelGGL(fir_shift_kernel<double>, dim3(nb), dim3(256), 0, ctx->stream, (const double *)d_data,
+        hipLaunchKernelGGL(fir_shift_kernel<double>, grid, dim3(256), 0, ctx->stream, (const double *)d_data,
                            g_scr.aux.as<double>(), snum, tnum, ntaps, t);
     IMPDAR_HIP_CHECK(hipGetLastError());
     IMPDAR_HIP_CHECK(hipMemcpyAsync(d_data, g_scr.aux.p, n * es, hipMemcpyDeviceToDevice, ctx->stream));
@@ -259,19 +454,21 @@ extern "C" int impdar_trace_lerp_dev(impdar_ctx *ctx, const void *d_data, int dt
     char *base = g_scr.idx.as<char>();
     double *d_den = (double *)base, *d_t = (double *)(base + db);
     int *d_lo = (int *)(base + 2 * db), *d_hi = (int *)(base + 2 * db + ib);
-    // the tables are small; synchronous copies keep the caller's host arrays free to go away
+    // the tables are small: one packed synchronous copy keeps the caller's host arrays free to go away (the
+    // stream is drained first because the previous launch may still read the table buffer)
+    std::vector<char> pack(2 * ib + 2 * db);
+    memcpy(pack.data(), den, db);
+    memcpy(pack.data() + db, t, db);
+    memcpy(pack.data() + 2 * db, lo, ib);
+    memcpy(pack.data() + 2 * db + ib, hi, ib);
     IMPDAR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    IMPDAR_HIP_CHECK(hipMemcpy(d_den, den, db, hipMemcpyHostToDevice));
-    IMPDAR_HIP_CHECK(hipMemcpy(d_t, t, db, hipMemcpyHostToDevice));
-    IMPDAR_HIP_CHECK(hipMemcpy(d_lo, lo, ib, hipMemcpyHostToDevice));
-    IMPDAR_HIP_CHECK(hipMemcpy(d_hi, hi, ib, hipMemcpyHostToDevice));
-    const size_t n = (size_t)snum * n_new;
-    const unsigned nb = (unsigned)((n + 255) / 256);
+    IMPDAR_HIP_CHECK(hipMemcpy(base, pack.data(), pack.size(), hipMemcpyHostToDevice));
+    const dim3 grid((n_new + 255) / 256, (snum + LERP_ROWS - 1) / LERP_ROWS);
     if (dtype == IMPDAR_F32)
-        hipLaunchKernelGGL(trace_lerp_kernel<float>, dim3(nb), dim3(256), 0, ctx->stream, (const float *)d_data, d_out, snum,
+        hipLaunchKernelGGL(trace_lerp_kernel<float>, grid, dim3(256), 0, ctx->stream, (const float *)d_data, d_out, snum,
                            tnum, n_new, d_lo, d_hi, d_den, d_t);
     else
-        hipLaunchKernelGGL(trace_lerp_kernel<double>, dim3(nb), dim3(256), 0, ctx->stream, (const double *)d_data, d_out, snum,
+        hipLaunchKernelGGL(trace_lerp_kernel<double>, grid, dim3(256), 0, ctx->stream, (const double *)d_data, d_out, snum,
                            tnum, n_new, d_lo, d_hi, d_den, d_t);
     IMPDAR_HIP_CHECK(hipGetLastError());
     return IMPDAR_OK;
