@@ -11,7 +11,7 @@
 // All three are HBM-streaming kernels; the arithmetic is fp64 in SciPy's operation order whatever the data
 // type (the file is compiled with -ffp-contract=off).  The IIR recurrence is a serial chain along time: a
 // wavefront runs 16 traces, four lanes each (rows of the (snum, tnum) array are contiguous across traces, so
-// every access is a coalesced row segment), with the loads of the next 16 samples in flight while 16 are filtered.
+// every access is a coalesced row segment), with the loads of the next 32 samples in flight while 32 are filtered.
 #include "common.h"
 
 #define FF_MAX_COEF 33
@@ -95,19 +95,25 @@ template <int K> struct FfLane {
 };
 
 #define FF_TRACES 16   // traces per 64-lane wavefront
-#define FF_CH 16       // samples per chunk: the loads of chunk c+1 are in flight while chunk c is filtered.
-                       // 32 would hide more latency but needs more than the 256 architectural VGPRs: the
-                       // compiler then parks live values in AccVGPRs, and a copy of a register whose asm
-                       // load has not landed yet copies garbage (seen as 1e-8 errors).  Keep vgpr_count <= 256.
+#define FF_CH 32       // samples per chunk (64 needs more than 256 VGPRs for the 21- and 33-coefficient kernels)
+#define FF_PK (FF_CH / 4)
 
+// Memory side.  625 wavefronts with a 64-byte row segment each cannot keep HBM busy unless many rows are in
+// flight per wavefront (16 rows in flight = 640 KB on the whole chip = 0.6 TB/s at ~1 us latency), so input
+// and output are quad-packed: the four lanes of a quad hold four consecutive samples of their trace (lane q of
+// register k holds sample 4k+q of the chunk), one load / store instruction moves four rows, and a 32-sample
+// chunk is 8 instructions.  A step takes its sample from lane u&3 of register u>>2 with a quad-broadcast DPP
+// move, and lane u&3 keeps the step's output.
+//
 // With plain loads hipcc waits for the prefetched chunk before the first step of the current one (it treats
-// loads and stores pending on vmcnt as completing out of order and drains: s_waitcnt vmcnt(7) .. vmcnt(0) in
-// the ISA), which exposes the memory latency of every chunk (1.2 ms per band pass at config-3 size).  The
-// prefetch is therefore issued from inline asm, invisible to that bookkeeping, and retired by one explicit
-// s_waitcnt vmcnt(0) at the END of the chunk, tied to the loaded registers.  Nothing is assumed about the
-// relative completion order of loads and stores: the outputs of a chunk are kept in registers and stored at
-// the top of the next chunk, in front of the next prefetch, so that by the time of the wait everything
-// outstanding was issued a whole chunk (~1.3 us) earlier.
+// loads and stores pending on vmcnt as completing out of order and drains), which exposes the memory latency
+// of every chunk.  The prefetch of the next chunk is therefore issued from inline asm, invisible to that
+// bookkeeping, and retired by one explicit s_waitcnt vmcnt(0) at the END of the chunk, tied to the loaded
+// registers.  Nothing is assumed about the relative completion order of loads and stores: the outputs of a
+// chunk stay in registers and are stored at the top of the next chunk, in front of the next prefetch, so that
+// by the time of the wait everything outstanding was issued a whole chunk (~2.5 us) earlier.
+// The kernels must stay within the 256 architectural VGPRs: beyond that the compiler parks live values in
+// AccVGPRs, and a copy of a register whose asm load has not landed yet copies garbage.
 __device__ __forceinline__ void ff_load_async(float &dst, const float *p)
 {
     asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
@@ -116,14 +122,50 @@ __device__ __forceinline__ void ff_load_async(double &dst, const double *p)
 {
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
-#define FF_TIE16(r, o)                                                                                              \
-    "+v"(r[o + 0]), "+v"(r[o + 1]), "+v"(r[o + 2]), "+v"(r[o + 3]), "+v"(r[o + 4]), "+v"(r[o + 5]), "+v"(r[o + 6]),     \
-        "+v"(r[o + 7]), "+v"(r[o + 8]), "+v"(r[o + 9]), "+v"(r[o + 10]), "+v"(r[o + 11]), "+v"(r[o + 12]),              \
-        "+v"(r[o + 13]), "+v"(r[o + 14]), "+v"(r[o + 15])
-template <typename T> __device__ __forceinline__ void ff_wait_chunk(T (&r)[FF_CH])
+#define FF_TIE8(r) "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+template <typename T> __device__ __forceinline__ void ff_wait_chunk(T (&r)[FF_PK])
 {
-    static_assert(FF_CH == 16, "operand list below");
-    asm volatile("s_waitcnt vmcnt(0)" : FF_TIE16(r, 0) : : "memory");
+    static_assert(FF_PK == 8, "operand list above");
+    asm volatile("s_waitcnt vmcnt(0)" : FF_TIE8(r) : : "memory");
+}
+
+// value of lane L (0..3) of the quad
+template <int L> __device__ __forceinline__ float ff_quad_pick(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), L * 0x55, 0xf, 0xf, true));
+}
+template <int L> __device__ __forceinline__ double ff_quad_pick(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), L * 0x55, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), L * 0x55, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// sample i of the odd extension in the data's own type (see ff_ext); i may lie past the end (clamped)
+template <typename T> __device__ __forceinline__ T ff_ext_t(const T *__restrict__ x, int i, int j, int snum, int ld, int edge)
+{
+    const int L = snum + 2 * edge;
+    i = i < L ? i : L - 1;
+    if (i < edge) return (T)((T)2 * x[j] - x[(size_t)(edge - i) * ld + j]);
+    i -= edge;
+    if (i < snum) return x[(size_t)i * ld + j];
+    i -= snum;
+    return (T)((T)2 * x[(size_t)(snum - 1) * ld + j] - x[(size_t)(snum - 2 - i) * ld + j]);
+}
+
+// FF_CH steps on the packed samples in `cur`; the packed outputs go to `held` (converted to TO)
+template <typename TI, typename TO, int K>
+__device__ __forceinline__ void ff_chunk_steps(FfLane<K> &f, const TI (&cur)[FF_PK], TO (&held)[FF_PK], int q)
+{
+#pragma unroll
+    for (int k = 0; k < FF_PK; ++k) {
+        const double y0 = f.step((double)ff_quad_pick<0>(cur[k]));
+        const double y1 = f.step((double)ff_quad_pick<1>(cur[k]));
+        const double y2 = f.step((double)ff_quad_pick<2>(cur[k]));
+        const double y3 = f.step((double)ff_quad_pick<3>(cur[k]));
+        const double lo = (q & 1) ? y1 : y0, hi = (q & 1) ? y3 : y2;
+        held[k] = (TO)((q & 2) ? hi : lo);
+    }
 }
 
 // forward pass over the extended trace; Y is (snum + 2*edge, tnum) fp64
@@ -136,63 +178,48 @@ __global__ __launch_bounds__(64) void ff_forward_kernel(const T *__restrict__ x,
     if (j >= tnum) return;   // whole quads leave together
     const int L = snum + 2 * edge;
     FfLane<K> f;
-    f.init(c, q, nc, ff_ext(x, 0, j, snum, tnum, edge));
-    double cur[FF_CH], held[FF_CH];
-    double *held_row = nullptr;   // outputs of the previous chunk still in registers (uniform)
+    f.init(c, q, nc, (double)ff_ext_t(x, 0, j, snum, tnum, edge));
+    T cur[FF_PK], nxt[FF_PK];
+    double held[FF_PK];
+    int held_i = -1;   // first sample of the chunk whose outputs are still in registers (uniform)
 #pragma unroll
-    for (int u = 0; u < FF_CH; ++u) cur[u] = ff_ext(x, u < L ? u : L - 1, j, snum, tnum, edge);
+    for (int k = 0; k < FF_PK; ++k) cur[k] = ff_ext_t(x, 4 * k + q, j, snum, tnum, edge);
     for (int i = 0; i < L; i += FF_CH) {
-        if (held_row) {
-            // all four lanes of the quad store the same value: no divergent branch around the stores
+        if (held_i >= 0) {
 #pragma unroll
-            for (int u = 0; u < FF_CH; ++u) held_row[(size_t)u * tnum] = held[u];
-            held_row = nullptr;
+            for (int k = 0; k < FF_PK; ++k) {
+                const int r = held_i + 4 * k + q;
+                if (r < L) Y[(size_t)r * tnum + j] = held[k];
+            }
         }
-        const int r0 = i + FF_CH;                                      // first row of the next chunk
+        const int r0 = i + FF_CH;                                      // first sample of the next chunk
         const bool inside = r0 >= edge && r0 + FF_CH <= edge + snum;   // uniform: plain rows of the data
-        T raw[FF_CH];
-        double nxt[FF_CH];
         if (inside) {
-            const T *row = x + (size_t)(r0 - edge) * tnum + j;
+            const T *row = x + (size_t)(r0 - edge + q) * tnum + j;
 #pragma unroll
-            for (int u = 0; u < FF_CH; ++u) {
+            for (int k = 0; k < FF_PK; ++k) {
 #ifdef FF_DIAG_NOLOAD   // timing ablation only
-                raw[u] = (T)(u + threadIdx.x) + (T)(size_t)row;
+                nxt[k] = (T)(k + threadIdx.x) + (T)(size_t)row;
 #else
-                ff_load_async(raw[u], row + (size_t)u * tnum);
+                ff_load_async(nxt[k], row + (size_t)(4 * k) * tnum);
 #endif
             }
-        } else {
+        } else if (r0 < L) {
 #pragma unroll
-            for (int u = 0; u < FF_CH; ++u) nxt[u] = ff_ext(x, r0 + u < L ? r0 + u : L - 1, j, snum, tnum, edge);
+            for (int k = 0; k < FF_PK; ++k) nxt[k] = ff_ext_t(x, r0 + 4 * k + q, j, snum, tnum, edge);
         }
-        double *yrow = Y + (size_t)i * tnum + j;
-        if (i + FF_CH <= L) {
-#pragma unroll
-            for (int u = 0; u < FF_CH; ++u) held[u] = f.step(cur[u]);
-            held_row = yrow;
-        } else {
-#pragma unroll
-            for (int u = 0; u < FF_CH; ++u) {
-                if (i + u < L) {   // uniform
-                    const double y = f.step(cur[u]);
-                    if (q == 0) yrow[(size_t)u * tnum] = y;
-                }
-            }
-        }
-        if (inside) {
+        ff_chunk_steps(f, cur, held, q);   // samples past L-1 are filtered too; their outputs are never stored
+        held_i = i;
 #ifndef FF_DIAG_NOLOAD
-            ff_wait_chunk(raw);
+        if (inside) ff_wait_chunk(nxt);
 #endif
 #pragma unroll
-            for (int u = 0; u < FF_CH; ++u) nxt[u] = (double)raw[u];
-        }
-#pragma unroll
-        for (int u = 0; u < FF_CH; ++u) cur[u] = nxt[u];
+        for (int k = 0; k < FF_PK; ++k) cur[k] = nxt[k];
     }
-    if (held_row) {
 #pragma unroll
-        for (int u = 0; u < FF_CH; ++u) held_row[(size_t)u * tnum] = held[u];
+    for (int k = 0; k < FF_PK; ++k) {
+        const int r = held_i + 4 * k + q;
+        if (r < L) Y[(size_t)r * tnum + j] = held[k];
     }
 }
 
@@ -208,63 +235,52 @@ __global__ __launch_bounds__(64) void ff_backward_kernel(const double *__restric
     const int L = snum + 2 * edge;
     FfLane<K> f;
     f.init(c, q, nc, Y[(size_t)(L - 1) * tnum + j]);
-    double cur[FF_CH];
-    T held[FF_CH];
-    T *held_row = nullptr;
+    double cur[FF_PK], nxt[FF_PK];
+    T held[FF_PK];
+    int held_p = -1;   // position (in the extended trace) of the first sample of the chunk held in registers
 #pragma unroll
-    for (int u = 0; u < FF_CH; ++u) {
-        const int r = L - 1 - u;
-        cur[u] = Y[(size_t)(r > 0 ? r : 0) * tnum + j];
+    for (int k = 0; k < FF_PK; ++k) {
+        const int r = L - 1 - (4 * k + q);
+        cur[k] = Y[(size_t)(r > 0 ? r : 0) * tnum + j];
     }
-    for (int p = L - 1; p >= edge; p -= FF_CH) {   // p: position of cur[0] in the extended trace
-        if (held_row) {
+    for (int p = L - 1; p >= edge; p -= FF_CH) {   // p: position of the chunk's first sample
+        if (held_p >= 0) {
 #pragma unroll
-            for (int u = 0; u < FF_CH; ++u) *(held_row - (size_t)u * tnum) = held[u];
-            held_row = nullptr;
+            for (int k = 0; k < FF_PK; ++k) {
+                const int r = held_p - (4 * k + q) - edge;
+                if (r >= 0 && r < snum) out[(size_t)r * tnum + j] = held[k];
+            }
         }
         const bool inside = p - 2 * FF_CH + 1 >= 0;   // uniform: the next chunk's rows all exist
-        double nxt[FF_CH];
         if (inside) {
-            const double *row = Y + (size_t)(p - FF_CH) * tnum + j;
+            const double *row = Y + (size_t)(p - FF_CH - q) * tnum + j;
 #pragma unroll
-            for (int u = 0; u < FF_CH; ++u) {
+            for (int k = 0; k < FF_PK; ++k) {
 #ifdef FF_DIAG_NOLOAD
-                nxt[u] = (double)(u + threadIdx.x) + (double)(size_t)row;
+                nxt[k] = (double)(k + threadIdx.x) + (double)(size_t)row;
 #else
-                ff_load_async(nxt[u], row - (size_t)u * tnum);
+                ff_load_async(nxt[k], row - (size_t)(4 * k) * tnum);
 #endif
             }
         } else {
 #pragma unroll
-            for (int u = 0; u < FF_CH; ++u) {
-                const int r = p - FF_CH - u;
-                nxt[u] = Y[(size_t)(r > 0 ? r : 0) * tnum + j];
+            for (int k = 0; k < FF_PK; ++k) {
+                const int r = p - FF_CH - (4 * k + q);
+                nxt[k] = Y[(size_t)(r > 0 ? r : 0) * tnum + j];
             }
         }
-        const int r0 = p - edge;   // output row of cur[0]
-        if (r0 < snum && r0 - (FF_CH - 1) >= 0) {
-#pragma unroll
-            for (int u = 0; u < FF_CH; ++u) held[u] = (T)f.step(cur[u]);
-            held_row = out + (size_t)r0 * tnum + j;
-        } else {
-#pragma unroll
-            for (int u = 0; u < FF_CH; ++u) {
-                const int r = r0 - u;
-                if (r >= 0) {   // uniform
-                    const double v = f.step(cur[u]);
-                    if (q == 0 && r < snum) out[(size_t)r * tnum + j] = (T)v;
-                }
-            }
-        }
+        ff_chunk_steps(f, cur, held, q);
+        held_p = p;
 #ifndef FF_DIAG_NOLOAD
         if (inside) ff_wait_chunk(nxt);
 #endif
 #pragma unroll
-        for (int u = 0; u < FF_CH; ++u) cur[u] = nxt[u];
+        for (int k = 0; k < FF_PK; ++k) cur[k] = nxt[k];
     }
-    if (held_row) {
 #pragma unroll
-        for (int u = 0; u < FF_CH; ++u) *(held_row - (size_t)u * tnum) = held[u];
+    for (int k = 0; k < FF_PK; ++k) {
+        const int r = held_p - (4 * k + q) - edge;
+        if (r >= 0 && r < snum) out[(size_t)r * tnum + j] = held[k];
     }
 }
 
