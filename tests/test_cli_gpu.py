@@ -48,3 +48,63 @@ def test_impproc_migrate_on_mat_file(hip, tmp_path, mtype):
         want = o.time_wavenumber(d.data, 8, 6)
     assert r.data.shape == want.shape
     assert rel_max(r.data, want) < 1e-9
+
+
+def _line_file(tmp_path, snum=160, tnum=90, seed=4):
+    from impdar_amd import synth
+    from impdar_amd.lib.NoInitRadarData import NoInitRadarData
+    geo = synth.geometry(snum, tnum)
+    rng = np.random.default_rng(seed)
+    d = NoInitRadarData(big=True)
+    d.data = synth.noise_radargram(snum, tnum, seed=seed)
+    d.snum, d.tnum = snum, tnum
+    for k in ('lat', 'long', 'decday', 'pressure', 'x_coord', 'y_coord', 'elev'):
+        setattr(d, k, np.cumsum(rng.random(tnum)))
+    d.trig = np.zeros(tnum)
+    d.trace_num = np.arange(tnum) + 1.
+    d.travel_time, d.dt = geo['travel_time'], geo['dt']
+    d.dist = np.hstack(([0.], np.cumsum(0.7 + 0.6 * rng.random(tnum - 1)))) / 1000.
+    d.trace_int = np.hstack(([1.], np.diff(d.dist) * 1000.))
+    fn = str(tmp_path / 'line_raw.mat')
+    d.save(fn)
+    return d, fn
+
+
+def test_impproc_vbp_and_interp_on_mat_file(hip, tmp_path):
+    """`impproc vbp` then `impproc interp` on real files: load, process through the C ABI, save with the
+    reference's naming; contents against the oracle."""
+    from impdar_amd.bin import impproc
+    from impdar_amd.lib.RadarData import RadarData
+    from oracle import preproc_oracle as po
+    d, fn = _line_file(tmp_path)
+    with patch.object(sys, 'argv', ['impproc', 'vbp', '2', '12', fn]):
+        impproc.main()
+    r = RadarData(str(tmp_path / 'line_bandpassed.mat'))
+    want = po.vertical_band_pass(d.data, d.dt, 2., 12.)
+    assert rel_max(r.data, want) < 1e-12
+    assert list(np.asarray(r.flags.bpass, dtype=float)) == [1., 2., 12.]
+    with patch.object(sys, 'argv', ['impproc', 'interp', '1.5', '-o', str(tmp_path / 'even.mat'), fn]):
+        impproc.main()
+    r = RadarData(str(tmp_path / 'even.mat'))
+    want, new_dists, _, _ = po.constant_space(d.data, d.dist, 1.5)
+    assert r.data.shape == want.shape and r.tnum == want.shape[1]
+    assert rel_max(r.data, want) < 1e-12
+    assert np.allclose(r.dist, new_dists, rtol=0, atol=0)
+    assert r.lat.shape == (r.tnum,) and list(np.asarray(r.flags.interp, dtype=float)) == [1., 1.5]
+
+
+def test_impdar_proc_resident_chain_on_mat_file(hip, tmp_path):
+    """`impdar proc -vbp 2 12 -migrate stolt file`: the two steps run as one resident chain (process.py) and give
+    what the oracle gives for band pass followed by the reference's hard-wired Stolt defaults."""
+    from impdar_amd.bin import impdarexec
+    from impdar_amd.lib.RadarData import RadarData
+    from oracle import mig_oracle as o, preproc_oracle as po
+    d, fn = _line_file(tmp_path, seed=9)
+    with patch.object(sys, 'argv', ['impdar', 'proc', '-vbp', '2', '12', '-migrate', 'kirch', fn]):
+        impdarexec.main()
+    r = RadarData(str(tmp_path / 'line_proc.mat'))
+    filt = po.vertical_band_pass(d.data, d.dt, 2., 12.)
+    want = o.stolt(filt, d.dt, d.trace_int, d.dist, 1.68e8, 10, 10)     # RadarData.migrate defaults (:590)
+    assert r.flags.mig == 'stolt' and r.data.shape == want.shape
+    assert rel_max(r.data, want) < 1e-9
+    assert getattr(r, '_dev', None) is None
