@@ -175,6 +175,10 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
     constexpr int NW = BLOCK / 64;
     constexpr int SH = VZ ? 3 : 1;            // lane >> SH = value index held after the reduce-scatter
     __shared__ T red[2][NW][2 * PS_TT];
+    // float32 v(z): the fp64 phase increment of every owned frequency at the current velocity lives in LDS
+    // ([m][thread], each thread reads only what it wrote): 2M registers too many, and recomputing it (fp64
+    // divide + square root) at every anchor cost as much as the 64 steps in between
+    __shared__ double phd_lds[(VZ && sizeof(T) == 4) ? M * BLOCK : 1];
     const int k = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Cp<T> *F = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k * P.nt;
@@ -186,20 +190,27 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
     // so the accumulated phase is kept in fp64 and the spectrum is rotated from its ORIGINAL value:
     //   constant v: recurrence, re-anchored to FK0 * exp(i tau phi) every 64 depth steps
     //   v(z):       Phi += w dt sqrt(coss) in fp64 (the increment is recomputed in fp64 only when the
-    //               velocity changes), F = FK0 * exp(i Phi) every step
+    //               velocity changes); F = FK0 * exp(i Phi) at every velocity change and every 64th step,
+    //               a fixed fp32 rotation per step in between (as for constant v)
     // float64 data keeps the reference's recurrence (rounding 1e-16 per step).
     constexpr bool F32 = sizeof(T) == 4;
     T fr[M], fi[M];          // complex state per owned frequency (F32 v(z): the original spectrum FK0)
     T pa[M], pb[M];          // const-v: (cos phi, sin phi); v(z) fp64: (g = (kx/2w)^2, w*dt); v(z) fp32: (coss, -)
-    double phd[F32 ? M : 1]; // F32: phase increment per depth step (const v: phi; v(z): w dt sqrt(coss))
-    double Phi[F32 && VZ ? M : 1];   // F32 v(z): accumulated phase, kept in [-pi, pi]
+    double phd[F32 && !VZ ? M : 1]; // F32 const v: phase increment per depth step
+    constexpr bool FZ = F32 && VZ;
+    double Phi[FZ ? M : 1];          // F32 v(z): accumulated phase at the last anchor, kept in [-pi, pi]
+    T gr[FZ ? M : 1], gi[FZ ? M : 1];   // F32 v(z): rotated state FK0 * exp(i Phi_tau)
+    T pc[FZ ? M : 1], ps[FZ ? M : 1];   // F32 v(z): exp(i increment) of the current velocity
     T f0r[F32 && !VZ ? M : 1], f0i[F32 && !VZ ? M : 1];   // F32 const v: original spectrum for re-anchoring
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const int iw = tid + m * BLOCK;
         fr[m] = fi[m] = pa[m] = pb[m] = 0;
-        if (F32) phd[F32 ? m : 0] = 0.0;
-        if (F32 && VZ) Phi[F32 && VZ ? m : 0] = 0.0;
+        if (F32 && !VZ) phd[F32 && !VZ ? m : 0] = 0.0;
+        if (FZ) {
+            Phi[FZ ? m : 0] = 0.0;
+            gr[FZ ? m : 0] = gi[FZ ? m : 0] = pc[FZ ? m : 0] = ps[FZ ? m : 0] = 0;
+        }
         if (F32 && !VZ) f0r[F32 && !VZ ? m : 0] = f0i[F32 && !VZ ? m : 0] = 0;
         if (iw < P.nt) {
             const Cp<T> f = F[iw];
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
                     fr[m] = f.x;
                     fi[m] = f.y;
                     if (F32) {
-                        phd[F32 ? m : 0] = ph;
+                        phd[F32 && !VZ ? m : 0] = ph;
                         f0r[F32 && !VZ ? m : 0] = f.x;
                         f0i[F32 && !VZ ? m : 0] = f.y;
                     }
@@ -234,8 +245,23 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
     }
     // float32 helpers: exp(i x) for a phase kept in fp64, |x| <= pi after the wrap
     auto rot32 = [](double ph, T *s, T *c) { sincos_t<T>((T)ph, s, c); };
-    double v_prev = -1.0;    // F32 v(z): velocity the increments phd[] were computed for
+    // F32 v(z): fp64 phase increment w dt sqrt(coss) of owned frequency m at velocity v (0 past the end of the axis)
+    auto incr = [&](int m, double v, double *cs_out) -> double {
+        const int iw = tid + m * BLOCK;
+        double inc = 0.0, cs = 1.0;
+        if (iw < P.nt) {
+            const double w = P.w[iw];
+            const double a = 0.5 * v * kxk / w;                 // :456
+            cs = 1.0 - a * a;
+            inc = w * P.dt * (cs > 0.0 ? sqrt(cs) : 0.0);       // :458-460
+        }
+        *cs_out = cs;
+        return inc;
+    };
+    double v_prev = -1.0;    // F32 v(z): velocity of the last depth step
     unsigned edge = 0;       // F32 v(z): bit m = frequency m sits on the evanescent boundary (|coss| < 1e-8)
+    int nrec = 0;            // F32 v(z): depth steps since the last anchor (uniform)
+    bool rot_valid = false;  // F32 v(z): pc/ps hold exp(i phd) of the current velocity (uniform)
 
     const int ntile = (P.snum + PS_TT - 1) / PS_TT;
     for (int tile = 0; tile < ntile; ++tile) {
@@ -251,7 +277,7 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
                 // re-anchor: state after tau0 steps = FK0 * exp(i tau0 phi), phase reduced in fp64
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    const double x = (double)tau0 * phd[F32 ? m : 0];
+                    const double x = (double)tau0 * phd[F32 && !VZ ? m : 0];
                     const double r = x - 6.283185307179586 * rint(x * 0.15915494309189535);
                     T sn, cs;
                     rot32(r, &sn, &cs);
@@ -275,73 +301,127 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
                 }
             }
         } else if (F32) {
-#pragma unroll
+            // not unrolled: the rare blocks (velocity change, anchor, boundary frequencies) appear once in the
+            // code and the per-step sums are filed into acc[] by a uniform index (unrolled four times the body
+            // exceeded the unroller's budget and acc[2t] turned into select chains: 2x slower than before)
+#pragma unroll 1
             for (int t = 0; t < PS_TT; ++t) {
-                const int tau = min(tau0 + t, P.snum - 1);
-                const double vd = P.vz[tau];
-                const T thr = (T)P.thr[tau];
-                const bool live_tau = (tau0 + t) < P.snum;
-                if (fabs(vd - v_prev) > P.vtol * fabs(vd)) {
-                    // new velocity (a wave-uniform branch; layered profiles take it a few times): the phase
-                    // increment of every owned frequency in fp64, from the fp64 frequency axis.  Velocities
-                    // within 1e-10 of the last one reuse its increments: 2*gradient(z(t)) of a layered
-                    // table is constant inside a layer up to ~4e-13 of rounding noise, and a 1e-10 velocity
-                    // error moves the phase by < 3e-6 rad over 8192 steps (float32 path only).
-                    v_prev = vd;
-                    edge = 0;
+                const int tau = tau0 + t;
+                if (tau < P.snum) {   // uniform
+                    const double vd = P.vz[tau];
+                    const T thr = (T)P.thr[tau];
+                    const bool changed = fabs(vd - v_prev) > P.vtol * fabs(vd);   // uniform
+                    if (changed) {
+                        // new velocity (layered profiles get here a few times).  Velocities within 1e-10 of
+                        // the last one count as the same: 2*gradient(z(t)) of a layered table is constant
+                        // inside a layer up to ~4e-13 of rounding noise, and a 1e-10 velocity error moves the
+                        // phase by < 3e-6 rad over 8192 steps (float32 path only).
+                        unsigned new_edge = 0;
+#pragma unroll
+                        for (int m = 0; m < M; ++m) {
+                            if (nrec > 0) {   // uniform: the steps since the last anchor turned by the OLD increment
+                                const double ph = Phi[FZ ? m : 0] + (double)nrec * phd_lds[FZ ? m * BLOCK + tid : 0];
+                                Phi[FZ ? m : 0] = ph - 6.283185307179586 * rint(ph * 0.15915494309189535);
+                            }
+                            // A frequency on the evanescent boundary (coss = 0 to rounding; with round-number
+                            // geometries whole families of (kx, w) sit exactly there) is kept or dropped for
+                            // good by the sign of coss, which the reference re-evaluates with every step's
+                            // velocity: those (a handful per radargram) are advanced step by step below, in
+                            // fp64, and take no part in the shared-increment scheme (increment 0 for them).
+                            double cs;
+                            const double inc = incr(m, vd, &cs);
+                            const bool on_edge = fabs(cs) < 1e-8;
+                            phd_lds[FZ ? m * BLOCK + tid : 0] = on_edge ? 0.0 : inc;
+                            new_edge |= (on_edge ? 1u : 0u) << m;
+                            pa[m] = (T)cs;
+                            // evanescent at this velocity: zero from here on (:484-485).  The threshold the
+                            // reference compares coss with is (tau/tt_end/1e6)^2 <= 1e-12, so away from the
+                            // boundary the test is the sign of coss and is settled once per velocity; the
+                            // boundary frequencies are tested step by step below.
+                            if (!on_edge && cs <= 0.0) {
+                                fr[m] = 0;
+                                fi[m] = 0;
+                            }
+                            asm volatile("" : "+v"(pa[m]), "+v"(fr[m]), "+v"(fi[m]));
+                        }
+                        v_prev = vd;
+                        edge = new_edge;
+                        rot_valid = false;
+                        nrec = 0;
+                    }
+                    nrec += 1;
+                    if (changed || nrec == 64) {
+                        // anchor: the state from the ORIGINAL spectrum and the fp64 phase
+#pragma unroll
+                        for (int m = 0; m < M; ++m) {
+                            double ph = Phi[FZ ? m : 0] + (double)nrec * phd_lds[FZ ? m * BLOCK + tid : 0];
+                            ph -= 6.283185307179586 * rint(ph * 0.15915494309189535);
+                            Phi[FZ ? m : 0] = ph;
+                            T sn, cs;
+                            rot32(ph, &sn, &cs);
+                            gr[FZ ? m : 0] = fma(fr[m], cs, -(fi[m] * sn));     // FK0 * exp(i Phi), :464 cumulated
+                            gi[FZ ? m : 0] = fma(fr[m], sn, fi[m] * cs);
+                            asm volatile("" : "+v"(gr[FZ ? m : 0]), "+v"(gi[FZ ? m : 0]));
+                        }
+                        nrec = 0;
+                    } else {
+                        // same velocity as the last step: every frequency turns by its fixed increment; the
+                        // fp32 recurrence runs for at most 63 steps between anchors (4e-6 rad of drift)
+                        if (!rot_valid) {
+#pragma unroll
+                            for (int m = 0; m < M; ++m) {
+                                T sn, cs;
+                                rot32(phd_lds[FZ ? m * BLOCK + tid : 0], &sn, &cs);   // |increment| <= |w| dt <= pi
+                                pc[FZ ? m : 0] = cs;
+                                ps[FZ ? m : 0] = sn;
+                                asm volatile("" : "+v"(pc[FZ ? m : 0]), "+v"(ps[FZ ? m : 0]));
+                            }
+                            rot_valid = true;
+                        }
+#pragma unroll
+                        for (int m = 0; m < M; ++m) {
+                            const T a = gr[FZ ? m : 0], b = gi[FZ ? m : 0];
+                            gr[FZ ? m : 0] = fma(a, pc[FZ ? m : 0], -(b * ps[FZ ? m : 0]));
+                            gi[FZ ? m : 0] = fma(a, ps[FZ ? m : 0], b * pc[FZ ? m : 0]);
+                        }
+                    }
+                    if (edge) {
+                        // boundary frequencies: this step's increment from this step's velocity, in fp64
+#pragma unroll
+                        for (int m = 0; m < M; ++m)
+                            if ((edge >> m) & 1u) {
+                                const double w = P.w[tid + m * BLOCK];
+                                const double a = 0.5 * vd * kxk / w;
+                                const double cs = 1.0 - a * a;
+                                pa[m] = (T)cs;
+                                double ph = Phi[FZ ? m : 0] + w * P.dt * (cs > 0.0 ? sqrt(cs) : 0.0);
+                                ph -= 6.283185307179586 * rint(ph * 0.15915494309189535);
+                                Phi[FZ ? m : 0] = ph;
+                                T sn, c2;
+                                rot32(ph, &sn, &c2);
+                                gr[FZ ? m : 0] = fma(fr[m], c2, -(fi[m] * sn));
+                                gi[FZ ? m : 0] = fma(fr[m], sn, fi[m] * c2);
+                                if (pa[m] <= thr) {                         // :484-485, stays zero afterwards
+                                    fr[m] = 0;
+                                    fi[m] = 0;
+                                    gr[FZ ? m : 0] = 0;
+                                    gi[FZ ? m : 0] = 0;
+                                }
+                            }
+                    }
+                    T sr = 0, si = 0;
 #pragma unroll
                     for (int m = 0; m < M; ++m) {
-                        const int iw = tid + m * BLOCK;
-                        double inc = 0.0, cs = 1.0;
-                        if (iw < P.nt) {
-                            const double w = P.w[iw];
-                            const double a = 0.5 * vd * kxk / w;        // :456
-                            cs = 1.0 - a * a;
-                            inc = w * P.dt * (cs > 0.0 ? sqrt(cs) : 0.0);   // :458-460
-                        }
-                        phd[F32 ? m : 0] = inc;
-                        pa[m] = (T)cs;
-                        edge |= (fabs(cs) < 1e-8 ? 1u : 0u) << m;
-                        asm volatile("" : "+v"(pa[m]));
+                        sr += gr[FZ ? m : 0];                                // :487
+                        si += gi[FZ ? m : 0];
+                        asm volatile("" : "+v"(gr[FZ ? m : 0]), "+v"(gi[FZ ? m : 0]), "+v"(sr), "+v"(si));
                     }
-                } else if (edge) {
-                    // A frequency on the evanescent boundary (coss = 0 to rounding; with round-number
-                    // geometries whole families of (kx, w) sit exactly there) is kept or dropped for good
-                    // by the sign of coss, which the reference re-evaluates with every step's velocity:
-                    // do exactly that for those lanes (a handful per radargram), in fp64.
 #pragma unroll
-                    for (int m = 0; m < M; ++m)
-                        if ((edge >> m) & 1u) {
-                            const double w = P.w[tid + m * BLOCK];
-                            const double a = 0.5 * vd * kxk / w;
-                            const double cs = 1.0 - a * a;
-                            phd[F32 ? m : 0] = w * P.dt * (cs > 0.0 ? sqrt(cs) : 0.0);
-                            pa[m] = (T)cs;
+                    for (int u = 0; u < PS_TT; ++u)
+                        if (t == u) {   // uniform
+                            acc[2 * u] = sr;
+                            acc[2 * u + 1] = si;
                         }
-                }
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    double ph = Phi[F32 && VZ ? m : 0] + phd[F32 ? m : 0];
-                    // negative frequencies rotate the other way: wrap on both sides
-                    ph -= ph > 3.141592653589793 ? 6.283185307179586 : 0.0;
-                    ph += ph < -3.141592653589793 ? 6.283185307179586 : 0.0;
-                    T s, c;
-                    rot32(ph, &s, &c);
-                    T nr = fma(fr[m], c, -(fi[m] * s));                 // FK0 * exp(i Phi), :464 cumulated
-                    T ni = fma(fr[m], s, fi[m] * c);
-                    const bool dead = pa[m] <= thr;                     // :484-485, stays zero afterwards
-                    if (live_tau) {
-                        Phi[F32 && VZ ? m : 0] = ph;
-                        if (dead) {
-                            fr[m] = 0;
-                            fi[m] = 0;
-                            nr = 0;
-                            ni = 0;
-                        }
-                        acc[2 * t] += nr;                               // :487
-                        acc[2 * t + 1] += ni;
-                    }
-                    asm volatile("" : "+v"(fr[m]), "+v"(fi[m]), "+v"(acc[2 * t]), "+v"(acc[2 * t + 1]));
                 }
             }
         } else {
