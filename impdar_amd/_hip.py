@@ -61,6 +61,7 @@ SIGNATURES = {
     'impdar_stolt': (_i, [_p, _p, _i, _i, _i, _dp, _dp, _d, _d, _d, _p]),
     'impdar_stolt_dev': (_i, [_p, _p, _i, _i, _i, _dp, _dp, _d, _d, _d, _p]),
     'impdar_phaseshift': (_i, [_p, _p, _i, _i, _i, _i, _dp, _dp, _d, _dp, _d, _dp, _i, _d, _d, _p]),
+    'impdar_phaseshift_dev': (_i, [_p, _p, _i, _i, _i, _i, _dp, _dp, _d, _dp, _d, _dp, _i, _d, _d, _p]),
     'impdar_phaseshift_ffd': (_i, [_p, _dp, _i, _i, _i, _dp, _dp, _d, _dp, _dp, _d, _d, _d, _dp]),
     'impdar_taper': (_i, [_p, _p, _i, _i, _i, _d, _d]),
     'impdar_filtfilt': (_i, [_p, _p, _i, _i, _i, _dp, _dp, _i, _dp]),

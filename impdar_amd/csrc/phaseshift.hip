@@ -629,6 +629,25 @@ extern "C" int impdar_phaseshift(impdar_ctx *ctx, const void *data, int dtype, i
     return impdar_download(ctx, out, dout.p, bytes, ctx->stream);
 }
 
+// resident form: d_data and d_out are device arrays of `dtype` (snum, tnum); runs on the context's compute stream
+extern "C" int impdar_phaseshift_dev(impdar_ctx *ctx, const void *d_data, int dtype, int snum, int tnum, int nt,
+                                     const double *kx, const double *ws, double dt, const double *tt_us, double vconst,
+                                     const double *vmig, int vmig_len, double htaper, double vtaper, void *d_out)
+{
+    IMPDAR_ARG_CHECK(ctx && d_data && d_out && kx && ws && tt_us, "null argument");
+    IMPDAR_ARG_CHECK(dtype == IMPDAR_F32 || dtype == IMPDAR_F64, "dtype must be 0 (f32) or 1 (f64)");
+    IMPDAR_ARG_CHECK(snum >= 1 && tnum >= 1 && nt >= snum, "bad sizes snum %d tnum %d nt %d", snum, tnum, nt);
+    IMPDAR_ARG_CHECK(vmig_len == 0 || (vmig_len == snum && vmig),
+                     "Interpolated velocity profile is not the length of the number of samples in a trace.");
+    IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> lk(g_ps_mu);
+    if (!g_ps_plan) g_ps_plan = new PsPlan();
+    return dtype == IMPDAR_F32 ? ps_run<float>(ctx, *g_ps_plan, d_data, snum, tnum, nt, kx, ws, dt, tt_us, vconst, vmig,
+                                               vmig_len, htaper, vtaper, d_out)
+                               : ps_run<double>(ctx, *g_ps_plan, d_data, snum, tnum, nt, kx, ws, dt, tt_us, vconst, vmig,
+                                                vmig_len, htaper, vtaper, d_out);
+}
+
 // ===========================================================================
 // 2-D v(x,z): Fourier finite-difference branch of phaseShift
 // (mig_python.py:428-432, 448-487; fourierFiniteDiff :496-525; Sp_Matr :528-540)

@@ -35,6 +35,8 @@ def migrate(self, mtype='stolt', vtaper=10, htaper=10, tmig=0, vel_fn=None, vel=
             resident.kirchhoff_resident(self, vel=vel, nearfield=nearfield)
         elif mtype == 'stolt':
             resident.stolt_resident(self, vel=vel, htaper=htaper, vtaper=vtaper)
+        elif mtype == 'phsh':
+            migrationlib.mig_hip._phase_shift(self, vel, vel_fn, htaper, vtaper, {}, self._dev)
         else:
             self.from_device()
             migrate(self, mtype=mtype, vtaper=vtaper, htaper=htaper, tmig=tmig, vel_fn=vel_fn, vel=vel,

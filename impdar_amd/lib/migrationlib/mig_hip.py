@@ -178,16 +178,31 @@ def migrationPhaseShift(dat, vel=1.69e8, vel_fn=None, htaper=100, vtaper=1000, *
     :361-493).  Constant ``vel``, a 2-column (v, z) table or a 3-column
     (v, z, x) table / ``vel_fn`` file; the last runs the 2-D v(x, z) Fourier
     finite-difference branch (:428-432, 448-487, 496-540) in float64."""
+    return _phase_shift(dat, vel, vel_fn, htaper, vtaper, genfromtxt_kwargs, None)
+
+
+def _phase_shift(dat, vel, vel_fn, htaper, vtaper, genfromtxt_kwargs, dev):
+    """``dev``: None -> ``dat.data`` (host); a resident DeviceArray -> migrated where it is, the result
+    replaces ``dat._dev`` (constant v and 1-D v(z); the 2-D branch goes through the host)."""
     print('Phase-Shift Migration of %.0fx%.0f matrix' % (dat.snum, dat.tnum))
-    _check_data_shape(dat)
+    if dev is None:
+        _check_data_shape(dat)
+        src_dtype = np.asarray(dat.data).dtype
+    else:
+        if dev.shape != (dat.snum, dat.tnum):
+            raise ValueError('The input array must be of size (snum, tnum)')
+        src_dtype = dev.dtype
     start = time.time()
-    if not np.issubdtype(np.asarray(dat.data).dtype, np.floating):
+    if not np.issubdtype(src_dtype, np.floating):
         # the reference's in-place ``dat.data *= H*V`` (:258) cannot cast float -> int
         raise TypeError("Cannot cast ufunc 'multiply' output from dtype('float64') to dtype('%s') "
-                        "with casting rule 'same_kind'" % np.asarray(dat.data).dtype)
+                        "with casting rule 'same_kind'" % src_dtype)
     lib = _hip.load()
-    ctx = _hip.context()
-    data, code = _device_data(dat.data)
+    ctx = _hip.context() if dev is None else dev.ctx
+    if dev is None:
+        data, code = _device_data(dat.data)
+    else:
+        data, code = None, _hip.dtype_code(dev.dtype)
     nt = int(2 ** (np.ceil(np.log(dat.snum) / np.log(2))))
     kx = _kx(dat)
     ws = 2. * np.pi * np.fft.fftfreq(nt, d=dat.dt)
@@ -212,6 +227,8 @@ def migrationPhaseShift(dat, vel=1.69e8, vel_fn=None, htaper=100, vtaper=1000, *
             vm2 = np.ascontiguousarray(vmig, dtype=np.float64)
             if vm2.shape != (dat.snum, dat.tnum):
                 raise ValueError('2-D velocity array must have shape (snum, tnum)')
+            if dev is not None:
+                dat.from_device()
             d64 = np.ascontiguousarray(dat.data, dtype=np.float64)
             out = np.empty((dat.snum, dat.tnum), dtype=np.float64)
             tt_us, p_tt = _hip.as_dp(dat.travel_time)
@@ -222,6 +239,8 @@ def migrationPhaseShift(dat, vel=1.69e8, vel_fn=None, htaper=100, vtaper=1000, *
                                            float(vtaper), _hip.as_dp(out)[1])
             _hip.check(rc, 'impdar_phaseshift_ffd')
             dat.data = out
+            if dev is not None:
+                dat.to_device()
             print('')
             print('Phase-Shift Migration of %.0fx%.0f matrix complete in %.2f seconds'
                   % (dat.snum, dat.tnum, time.time() - start))
@@ -233,13 +252,25 @@ def migrationPhaseShift(dat, vel=1.69e8, vel_fn=None, htaper=100, vtaper=1000, *
     tt_us, p_tt = _hip.as_dp(dat.travel_time)
     _, p_kx = _hip.as_dp(kx)
     _, p_ws = _hip.as_dp(ws)
-    out = np.empty((dat.snum, dat.tnum), dtype=data.dtype)
-    rc = lib.impdar_phaseshift(ctx, data.ctypes.data_as(C.c_void_p), code, dat.snum, dat.tnum, nt, p_kx, p_ws,
-                               float(dat.dt), p_tt, vconst, p_vm, vlen, float(htaper), float(vtaper),
-                               out.ctypes.data_as(C.c_void_p))
-    _hip.check(rc, 'impdar_phaseshift')
-    # the reference returns float64 (ifft(...).real, :282)
-    dat.data = out.astype(np.float64)
+    if dev is None:
+        out = np.empty((dat.snum, dat.tnum), dtype=data.dtype)
+        rc = lib.impdar_phaseshift(ctx, data.ctypes.data_as(C.c_void_p), code, dat.snum, dat.tnum, nt, p_kx, p_ws,
+                                   float(dat.dt), p_tt, vconst, p_vm, vlen, float(htaper), float(vtaper),
+                                   out.ctypes.data_as(C.c_void_p))
+        _hip.check(rc, 'impdar_phaseshift')
+        # the reference returns float64 (ifft(...).real, :282)
+        dat.data = out.astype(np.float64)
+    else:
+        d_out = _hip.DeviceArray(ctx, dev.shape, dev.dtype)
+        rc = lib.impdar_phaseshift_dev(ctx, dev.ptr, code, dat.snum, dat.tnum, nt, p_kx, p_ws, float(dat.dt), p_tt,
+                                       vconst, p_vm, vlen, float(htaper), float(vtaper), d_out.ptr)
+        if rc:
+            d_out.free()
+        _hip.check(rc, 'impdar_phaseshift')
+        _hip.check(lib.impdar_ctx_sync(ctx), 'impdar_ctx_sync')
+        dev.free()
+        dat._dev = d_out
+        dat._dev_widen = True          # float64 on the way back, as the host path
     print('')
     print('Phase-Shift Migration of %.0fx%.0f matrix complete in %.2f seconds'
           % (dat.snum, dat.tnum, time.time() - start))

@@ -1,9 +1,10 @@
 """Keeping a radargram in HBM across the steps of a processing chain.
 
 ``dat.to_device()`` uploads ``dat.data`` once; ``vertical_band_pass``, ``constant_space`` and
-``migrate('kirch' | 'stolt')`` then work on the resident array through the ``*_dev`` entry points of the C ABI
-(no PCIe traffic between steps), and ``dat.from_device()`` brings the result back.  While resident,
-``dat.data`` is None.  Migrations without a resident form ('phsh', 'tk') round-trip through the host.
+``migrate('kirch' | 'stolt' | 'phsh')`` then work on the resident array through the ``*_dev`` entry points of
+the C ABI (no PCIe traffic between steps), and ``dat.from_device()`` brings the result back.  While resident,
+``dat.data`` is None.  What has no resident form ('tk', the 2-D v(x, z) branch of 'phsh', SeisUnix)
+round-trips through the host.
 """
 import numpy as np
 

@@ -152,6 +152,12 @@ int impdar_phaseshift(impdar_ctx *ctx, const void *data, int dtype, int snum, in
                       const double *tt_us, double vconst, const double *vmig, int vmig_len,
                       double htaper, double vtaper, void *out);
 
+/* resident form: d_data and d_out are device arrays of `dtype` (snum, tnum) */
+int impdar_phaseshift_dev(impdar_ctx *ctx, const void *d_data, int dtype, int snum, int tnum,
+                          int nt, const double *kx, const double *ws, double dt,
+                          const double *tt_us, double vconst, const double *vmig, int vmig_len,
+                          double htaper, double vtaper, void *d_out);
+
 /* ---- phase shift, 2-D v(x,z): Fourier finite-difference branch ----------
  * Replaces the `hasattr(vmig[itau], "__len__")` path of phaseShift
  * (mig_python.py:428-432, 448-487) with fourierFiniteDiff (:496-525) and the

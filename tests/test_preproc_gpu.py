@@ -168,7 +168,7 @@ def test_reference_constant_space_fixture(hip):
 
 
 @pytest.mark.parametrize('dtype', [np.float32, np.float64])
-@pytest.mark.parametrize('mtype', ['stolt', 'kirch'])
+@pytest.mark.parametrize('mtype', ['stolt', 'kirch', 'phsh', 'tk'])
 def test_resident_chain_equals_host_chain(hip, dtype, mtype):
     """band pass -> constant spacing -> migration with the radargram held in HBM gives exactly what the same
     three calls give through host buffers (same kernels, no PCIe round trips in between)."""
@@ -234,3 +234,26 @@ def test_full_size_properties(hip):
     n = d.data.shape[1]
     near = np.abs(d.data - x[:, :n].astype(np.float64))
     assert np.max(near) < 1e-6 * np.max(np.abs(x))
+
+
+def test_resident_phase_shift_with_velocity_table(hip):
+    """migrate('phsh') with a layered (v, z) table on a radargram held in HBM = the host-buffer call."""
+    rng = np.random.default_rng(5)
+    snum, tnum = 200, 90
+    data = rng.standard_normal((snum, tnum)).astype(np.float32)
+    tt_end = (snum - 1) * 1e-8
+    Rp = 1.9e8 * tt_end / 2.
+    tab = np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rp], [1.8e8, 0.5 * Rp], [1.9e8, 1.2 * Rp]])
+    import impdar_amd.lib.migrationlib.mig_hip as mh
+
+    def run(resident):
+        d = filt_dat(data)
+        if resident:
+            d.to_device()
+            mh._phase_shift(d, tab, None, 10, 10, {}, d._dev)
+            d.from_device()
+        else:
+            mh.migrationPhaseShift(d, vel=tab, htaper=10, vtaper=10)
+        return d.data
+    a, b = run(False), run(True)
+    assert a.dtype == np.float64 and b.dtype == np.float64 and np.array_equal(a, b)
