@@ -260,6 +260,7 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
     };
     double v_prev = -1.0;    // F32 v(z): velocity of the last depth step
     unsigned edge = 0;       // F32 v(z): bit m = frequency m sits on the evanescent boundary (|coss| < 1e-8)
+    double vz_next = (FZ && P.vz) ? P.vz[0] : 0.0, thr_next = (FZ && P.thr) ? P.thr[0] : 0.0;   // F32 v(z): prefetched
     int nrec = 0;            // F32 v(z): depth steps since the last anchor (uniform)
     bool rot_valid = false;  // F32 v(z): pc/ps hold exp(i phd) of the current velocity (uniform)
 
@@ -308,8 +309,13 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
             for (int t = 0; t < PS_TT; ++t) {
                 const int tau = tau0 + t;
                 if (tau < P.snum) {   // uniform
-                    const double vd = P.vz[tau];
-                    const T thr = (T)P.thr[tau];
+                    // this step's velocity and threshold were requested a step ago (a load-and-wait per step
+                    // cost as much as the step)
+                    const double vd = vz_next;
+                    const T thr = (T)thr_next;
+                    const int tn = tau + 1 < P.snum ? tau + 1 : tau;
+                    vz_next = P.vz[tn];
+                    thr_next = P.thr[tn];
                     const bool changed = fabs(vd - v_prev) > P.vtol * fabs(vd);   // uniform
                     if (changed) {
                         // new velocity (layered profiles get here a few times).  Velocities within 1e-10 of
@@ -409,13 +415,15 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
                                 }
                             }
                     }
-                    T sr = 0, si = 0;
+                    // :487, four partial sums per component (one 16-deep dependent chain of adds stalls a
+                    // lone wavefront)
+                    T pr[4] = {0, 0, 0, 0}, pi[4] = {0, 0, 0, 0};
 #pragma unroll
                     for (int m = 0; m < M; ++m) {
-                        sr += gr[FZ ? m : 0];                                // :487
-                        si += gi[FZ ? m : 0];
-                        asm volatile("" : "+v"(gr[FZ ? m : 0]), "+v"(gi[FZ ? m : 0]), "+v"(sr), "+v"(si));
+                        pr[m & 3] += gr[FZ ? m : 0];
+                        pi[m & 3] += gi[FZ ? m : 0];
                     }
+                    const T sr = (pr[0] + pr[1]) + (pr[2] + pr[3]), si = (pi[0] + pi[1]) + (pi[2] + pi[3]);
 #pragma unroll
                     for (int u = 0; u < PS_TT; ++u)
                         if (t == u) {   // uniform
