@@ -52,3 +52,27 @@ def test_product_never_imports_the_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(base, f)).read()
                 assert 'oracle' not in src.replace('the oracle', ''), os.path.join(base, f)
+
+
+def test_band_pass_kernels_stay_in_architectural_vgprs(tmp_path):
+    """The band-pass kernels prefetch with inline-asm loads that the compiler cannot see (csrc/preproc.hip): if a
+    kernel needed more than the 256 architectural VGPRs the compiler would park live values in AccVGPRs, and a
+    copy of a register whose load has not landed copies garbage.  Guard the register budget at build level."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip('hipcc not available')
+    from impdar_amd import build
+    out = str(tmp_path / 'preproc.s')
+    flags = [f for f in build.FLAGS if f != '-fPIC']
+    subprocess.check_call([hipcc] + flags + ['--cuda-device-only', '-S', os.path.join(build.CSRC, 'preproc.hip'), '-o', out],
+                          stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    rows = re.findall(r'\.agpr_count:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)',
+                      text, flags=re.S)
+    ff = [(name, int(agpr), int(scratch), int(vgpr)) for agpr, name, scratch, vgpr in rows if 'ff_' in name]
+    assert len(ff) == 16, [r[0] for r in ff]
+    for name, agpr, scratch, vgpr in ff:
+        assert agpr == 0 and scratch == 0 and vgpr <= 256, (name, agpr, scratch, vgpr)
