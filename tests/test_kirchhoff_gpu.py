@@ -370,3 +370,45 @@ def test_wide_output_tiles(hip, xb, monkeypatch):
     d_in.free()
     d_out.free()
     assert np.array_equal(got, full[:, 37:150])
+
+
+def test_config4_size_on_one_gpu(hip):
+    """BASELINE config 4's radargram (40000 x 4096 float32; quoted on 8 GPUs) fits one MI355X: the pair count
+    SURVEY 8(d) prices it at, spot traces against the C oracle, and one rank's output block of an 8-way split
+    equal to the same columns of the whole-radargram run."""
+    from impdar_amd import synth, _hip, parallel
+    from impdar_amd.kirchhoff import KirchhoffPlan
+    from oracle import c_oracle
+    snum, tnum, vel = 4096, 40000, 1.69e8
+    geo = synth.geometry(snum, tnum)
+    x = np.random.default_rng(11).standard_normal((snum, tnum)).astype(np.float32)
+    ctx = hip.context()
+    plan = KirchhoffPlan(ctx, np.float32, snum, tnum, geo['dist'], geo['travel_time'], vel, mode='fast')
+    pairs = plan.count_pairs(0, tnum)
+    assert abs(pairs - 8.5776e11) < 5e7, pairs                # SURVEY 8(d): 8.5776e11
+    d_in = _hip.DeviceArray.from_host(ctx, x)
+    d_out = _hip.DeviceArray(ctx, (snum, tnum), np.float32)
+    plan.prep(d_in, tnum, 0, tnum)
+    plan.migrate(d_out, 0, tnum)
+    plan.sync()
+    ms = plan.last_ms()[2]
+    out = d_out.to_host()
+    print('config-4 radargram on one GPU: %.1f ms, %.0f traces/s' % (ms, tnum / ms * 1e3))
+    assert np.isfinite(out).all() and not out[0].any()
+    cols = np.array([0, 3459, 20000, 39999, 31234], dtype=np.int32)
+    want = c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], vel, traces=cols)
+    assert rel_l2(out[:, cols], want) < FAST_L2
+    # rank 3 of 8: its block through a plan built for 8 ranks (24-trace tiles) is the same image
+    _, _, blocks, _ = parallel.plan_blocks(geo['travel_time'] / 1e6, 1.0, vel, tnum, 8)
+    lo, hi = blocks[3]
+    plan8 = KirchhoffPlan(ctx, np.float32, snum, tnum, geo['dist'], geo['travel_time'], vel, mode='fast', nranks=8)
+    d_blk = _hip.DeviceArray(ctx, (snum, hi - lo), np.float32)
+    plan8.prep(d_in, tnum, 0, tnum)
+    plan8.migrate(d_blk, lo, hi)
+    plan8.sync()
+    blk = d_blk.to_host()
+    assert rel_l2(blk, out[:, lo:hi]) < 1e-6
+    for d in (d_in, d_out, d_blk):
+        d.free()
+    plan.destroy()
+    plan8.destroy()
