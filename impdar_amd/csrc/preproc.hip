@@ -13,6 +13,7 @@
 // wavefront runs 16 traces, four lanes each (rows of the (snum, tnum) array are contiguous across traces, so
 // every access is a coalesced row segment), with the loads of the next 32 samples in flight while 32 are filtered.
 #include "common.h"
+#include <mutex>
 
 #define FF_MAX_COEF 33
 
@@ -357,6 +358,10 @@ struct PreprocScratch {
     DevBuf y, data, aux, idx;
 };
 static PreprocScratch g_scr;
+// one scratch set per process: entry points of different contexts / threads take turns (re-entrant because the
+// host-buffer forms call the resident ones)
+static std::recursive_mutex g_scr_mu;
+#define PREPROC_LOCK() std::lock_guard<std::recursive_mutex> preproc_lock_(g_scr_mu)
 
 static void scratch_bind(impdar_ctx *ctx)
 {
@@ -371,6 +376,7 @@ static void scratch_bind(impdar_ctx *ctx)
 
 void impdar_preproc_forget(impdar_ctx *ctx)
 {
+    PREPROC_LOCK();
     if (g_scr.owner == ctx) {
         g_scr.y.release();
         g_scr.data.release();
@@ -402,6 +408,7 @@ static int filtfilt_dispatch(impdar_ctx *ctx, T *d, double *Y, int snum, int tnu
 extern "C" int impdar_filtfilt_dev(impdar_ctx *ctx, void *d_data, int dtype, int snum, int tnum, const double *b,
                                    const double *a, int ncoef, const double *zi)
 {
+    PREPROC_LOCK();
     IMPDAR_ARG_CHECK(ctx && d_data && b && a && zi, "impdar_filtfilt: null argument");
     IMPDAR_ARG_CHECK(dtype == IMPDAR_F32 || dtype == IMPDAR_F64, "impdar_filtfilt: dtype must be float32 or float64");
     IMPDAR_ARG_CHECK(ncoef >= 2 && ncoef <= FF_MAX_COEF, "impdar_filtfilt: %d filter coefficients (2..%d supported)", ncoef,
@@ -428,6 +435,7 @@ extern "C" int impdar_filtfilt_dev(impdar_ctx *ctx, void *d_data, int dtype, int
 extern "C" int impdar_fir_shift_dev(impdar_ctx *ctx, void *d_data, int dtype, int snum, int tnum, const double *taps,
                                     int ntaps)
 {
+    PREPROC_LOCK();
     IMPDAR_ARG_CHECK(ctx && d_data && taps, "impdar_fir_shift: null argument");
     IMPDAR_ARG_CHECK(dtype == IMPDAR_F32 || dtype == IMPDAR_F64, "impdar_fir_shift: dtype must be float32 or float64");
     IMPDAR_ARG_CHECK(ntaps >= 1 && ntaps <= 256, "impdar_fir_shift: %d taps (1..256 supported)", ntaps);
@@ -456,6 +464,7 @@ extern "C" int impdar_fir_shift_dev(impdar_ctx *ctx, void *d_data, int dtype, in
 extern "C" int impdar_trace_lerp_dev(impdar_ctx *ctx, const void *d_data, int dtype, int snum, int tnum, const int *lo,
                                      const int *hi, const double *den, const double *t, int n_new, double *d_out)
 {
+    PREPROC_LOCK();
     IMPDAR_ARG_CHECK(ctx && d_data && lo && hi && den && t && d_out, "impdar_trace_lerp: null argument");
     IMPDAR_ARG_CHECK(dtype == IMPDAR_F32 || dtype == IMPDAR_F64, "impdar_trace_lerp: dtype must be float32 or float64");
     IMPDAR_ARG_CHECK(snum >= 1 && tnum >= 2 && n_new >= 0, "impdar_trace_lerp: bad shape %d x %d -> %d", snum, tnum, n_new);
@@ -504,6 +513,7 @@ static int stage_in(impdar_ctx *ctx, const void *host, size_t bytes)
 extern "C" int impdar_filtfilt(impdar_ctx *ctx, void *data, int dtype, int snum, int tnum, const double *b,
                                const double *a, int ncoef, const double *zi)
 {
+    PREPROC_LOCK();
     IMPDAR_ARG_CHECK(ctx && data, "impdar_filtfilt: null argument");
     IMPDAR_ARG_CHECK(snum >= 1 && tnum >= 1, "impdar_filtfilt: empty radargram");
     const size_t bytes = (size_t)snum * tnum * impdar_dtype_size(dtype);
@@ -516,6 +526,7 @@ extern "C" int impdar_filtfilt(impdar_ctx *ctx, void *data, int dtype, int snum,
 
 extern "C" int impdar_fir_shift(impdar_ctx *ctx, void *data, int dtype, int snum, int tnum, const double *taps, int ntaps)
 {
+    PREPROC_LOCK();
     IMPDAR_ARG_CHECK(ctx && data, "impdar_fir_shift: null argument");
     IMPDAR_ARG_CHECK(snum >= 1 && tnum >= 1, "impdar_fir_shift: empty radargram");
     const size_t bytes = (size_t)snum * tnum * impdar_dtype_size(dtype);
@@ -529,6 +540,7 @@ extern "C" int impdar_fir_shift(impdar_ctx *ctx, void *data, int dtype, int snum
 extern "C" int impdar_trace_lerp(impdar_ctx *ctx, const void *data, int dtype, int snum, int tnum, const int *lo,
                                  const int *hi, const double *den, const double *t, int n_new, double *out)
 {
+    PREPROC_LOCK();
     IMPDAR_ARG_CHECK(ctx && data && out, "impdar_trace_lerp: null argument");
     IMPDAR_ARG_CHECK(snum >= 1 && tnum >= 2 && n_new >= 0, "impdar_trace_lerp: bad shape %d x %d -> %d", snum, tnum, n_new);
     if (n_new == 0) return IMPDAR_OK;
