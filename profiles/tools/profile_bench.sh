@@ -9,9 +9,11 @@ O=$R/gpurun_out/$1
 mkdir -p $O
 cd $R
 B="python3 bench.py --steps 3 --warmup 1 --no-cpu"
-# the stats pass runs the default bench command (20 steps, 3 warm-up) so that its average kernel duration is
-# the one bench.py reports from HIP events; the counter passes only need a few launches
-rocprofv3 --kernel-trace --stats -d $O/stats/run -o x --output-format csv -- python3 bench.py --no-cpu > $O/stats.log 2>&1
+# the stats pass runs the default bench command (python3 bench.py: 20 steps, 3 warm-up, CPU baseline leg) so that
+# its average kernel duration is the one bench.py reports from HIP events in the JSON line of the same process
+# (kept as bench_under_rocprof.json); the counter passes only need a few launches
+rocprofv3 --kernel-trace --stats -d $O/stats/run -o x --output-format csv -- python3 bench.py > $O/stats.log 2>&1
+grep '^{"metric"' $O/stats.log > $O/bench_under_rocprof.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch/run -o x --output-format csv -- $B > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write/run -o x --output-format csv -- $B > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/pmc_sq/run -o x --output-format csv -- $B > $O/pmc_sq.log 2>&1
