@@ -45,6 +45,7 @@ SIGNATURES = {
     'impdar_dev_upload': (_i, [_p, _p, _p, C.c_size_t]),
     'impdar_dev_download': (_i, [_p, _p, _p, C.c_size_t]),
     'impdar_dev_memset': (_i, [_p, _p, _i, C.c_size_t]),
+    'impdar_dev_download_f64': (_i, [_p, _dp, _p, _i, C.c_size_t]),
     'mig_kirch_loop': (None, [_dp, _i, _i, _dp, _dp, _dp, _dp, _d, _dp, _d, _i]),
     'impdar_kirchhoff': (_i, [_p, _p, _i, _i, _i, _dp, _dp, _d, _i, _i, _d, _dp, _dp, _dp, _i, _dp]),
     'impdar_kirch_plan_create': (_i, [_p, _i, _i, _i, _dp, _dp, _d, _i, _i, _d, _dp, _dp, _dp, _i, _i,
@@ -179,6 +180,14 @@ class DeviceArray(object):
         out = np.empty(self.shape, dtype=self.dtype)
         check(load().impdar_dev_download(self.ctx, out.ctypes.data_as(_p), self.ptr, self.nbytes),
               'impdar_dev_download')
+        return out
+
+    def to_host_f64(self):
+        """float64 host copy (widened on several host threads when the array is float32)."""
+        out = np.empty(self.shape, dtype=np.float64)
+        n = int(np.prod(self.shape))
+        check(load().impdar_dev_download_f64(self.ctx, out.ctypes.data_as(_dp), self.ptr, dtype_code(self.dtype), n),
+              'impdar_dev_download_f64')
         return out
 
     def free(self):

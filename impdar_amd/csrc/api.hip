@@ -114,6 +114,26 @@ int impdar_download(impdar_ctx *ctx, void *host_dst, const void *dev_src, size_t
     return IMPDAR_OK;
 }
 
+extern "C" int impdar_dev_download_f64(impdar_ctx *ctx, double *dst_host, const void *src_dev, int dtype, size_t n)
+{
+    IMPDAR_ARG_CHECK(ctx && dst_host && src_dev, "impdar_dev_download_f64: null argument");
+    IMPDAR_ARG_CHECK(dtype == IMPDAR_F32 || dtype == IMPDAR_F64, "impdar_dev_download_f64: dtype must be float32 or float64");
+    if (n == 0) return IMPDAR_OK;
+    IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t bytes = n * impdar_dtype_size(dtype);
+    void *stage = impdar_ctx_pinned(ctx, bytes);
+    std::vector<char> fallback;
+    if (!stage) {
+        if (dtype == IMPDAR_F64) return impdar_download(ctx, dst_host, src_dev, bytes, ctx->stream);
+        fallback.resize(bytes);
+        stage = fallback.data();
+    }
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(stage, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    IMPDAR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    impdar_host_copy_f64(dst_host, stage, n, dtype == IMPDAR_F32);
+    return IMPDAR_OK;
+}
+
 extern "C" void impdar_ctx_destroy(impdar_ctx *ctx)
 {
     if (!ctx) return;

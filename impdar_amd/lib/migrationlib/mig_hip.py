@@ -253,13 +253,18 @@ def _phase_shift(dat, vel, vel_fn, htaper, vtaper, genfromtxt_kwargs, dev):
     _, p_kx = _hip.as_dp(kx)
     _, p_ws = _hip.as_dp(ws)
     if dev is None:
-        out = np.empty((dat.snum, dat.tnum), dtype=data.dtype)
-        rc = lib.impdar_phaseshift(ctx, data.ctypes.data_as(C.c_void_p), code, dat.snum, dat.tnum, nt, p_kx, p_ws,
-                                   float(dat.dt), p_tt, vconst, p_vm, vlen, float(htaper), float(vtaper),
-                                   out.ctypes.data_as(C.c_void_p))
-        _hip.check(rc, 'impdar_phaseshift')
-        # the reference returns float64 (ifft(...).real, :282)
-        dat.data = out.astype(np.float64)
+        # upload, migrate on the device, and bring the result back as float64 (the reference returns
+        # ifft(...).real, :282) through the threaded widening download
+        d_in = _hip.DeviceArray.from_host(ctx, data)
+        d_out = _hip.DeviceArray(ctx, d_in.shape, d_in.dtype)
+        try:
+            rc = lib.impdar_phaseshift_dev(ctx, d_in.ptr, code, dat.snum, dat.tnum, nt, p_kx, p_ws, float(dat.dt), p_tt,
+                                           vconst, p_vm, vlen, float(htaper), float(vtaper), d_out.ptr)
+            _hip.check(rc, 'impdar_phaseshift')
+            dat.data = d_out.to_host_f64()
+        finally:
+            d_in.free()
+            d_out.free()
     else:
         d_out = _hip.DeviceArray(ctx, dev.shape, dev.dtype)
         rc = lib.impdar_phaseshift_dev(ctx, dev.ptr, code, dat.snum, dat.tnum, nt, p_kx, p_ws, float(dat.dt), p_tt,

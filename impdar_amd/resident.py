@@ -32,9 +32,10 @@ def from_device(self):
     dev = getattr(self, '_dev', None)
     if dev is None:
         return self
-    out = dev.to_host()
-    if getattr(self, '_dev_widen', False) and out.dtype != np.float64:
-        out = out.astype(np.float64)       # migrationKirchhoff always hands back float64 (mig_python.py:118)
+    if getattr(self, '_dev_widen', False):
+        out = dev.to_host_f64()            # migrationKirchhoff / PhaseShift always hand back float64 (mig_python.py:118, :282)
+    else:
+        out = dev.to_host()
     dev.free()
     self._dev = None
     self._dev_widen = False

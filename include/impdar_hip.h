@@ -66,6 +66,11 @@ int impdar_dev_free(impdar_ctx *ctx, void *dptr);
 int impdar_dev_upload(impdar_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int impdar_dev_download(impdar_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int impdar_dev_memset(impdar_ctx *ctx, void *dst_dev, int value, size_t bytes);
+/* device (float32 or float64, `n` elements) -> a float64 host array: what the reference's migrations hand back
+ * whatever the input type (mig_python.py:118, :282).  Goes through the context's pinned staging buffer and
+ * converts on several host threads (a single-threaded astype of a fresh 512 MB array costs more than the
+ * phase-shift kernel that produced it). */
+int impdar_dev_download_f64(impdar_ctx *ctx, double *dst_host, const void *src_dev, int dtype, size_t n);
 
 /* ---- reference-compatible native hook ---------------------------------
  * Replaces mig_cython.h:11.  Same argument meaning as
