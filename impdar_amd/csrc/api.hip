@@ -190,9 +190,8 @@ extern "C" int impdar_dev_download(impdar_ctx *ctx, void *dst_host, const void *
 {
     IMPDAR_ARG_CHECK(ctx && dst_host && src_dev, "null context/pointer");
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
-    IMPDAR_HIP_CHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    IMPDAR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    return IMPDAR_OK;
+    // through the pinned staging buffer and a threaded copy: the destination is usually a fresh pageable array
+    return impdar_download(ctx, dst_host, src_dev, bytes, ctx->stream);
 }
 
 extern "C" int impdar_dev_memset(impdar_ctx *ctx, void *dst_dev, int value, size_t bytes)
