@@ -70,6 +70,7 @@ SIGNATURES = {
     'impdar_fir_shift': (_i, [_p, _p, _i, _i, _i, _dp, _i]),
     'impdar_fir_shift_dev': (_i, [_p, _p, _i, _i, _i, _dp, _i]),
     'impdar_trace_lerp': (_i, [_p, _p, _i, _i, _i, _ip, _ip, _dp, _dp, _i, _p]),
+    'impdar_cast_dev': (_i, [_p, _p, _i, _p, _i, C.c_size_t]),
     'impdar_trace_lerp_dev': (_i, [_p, _p, _i, _i, _i, _ip, _ip, _dp, _dp, _i, _p]),
     'impdar_comm_unique_id': (_i, [C.c_char_p]),
     'impdar_comm_init': (_i, [_p, C.c_char_p, _i, _i]),

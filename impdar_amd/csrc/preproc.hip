@@ -499,6 +499,34 @@ extern "C" int impdar_trace_lerp_dev(impdar_ctx *ctx, const void *d_data, int dt
     return IMPDAR_OK;
 }
 
+// element-wise float32 <-> float64 conversion of a resident array (what NumPy's astype does on the host)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI *__restrict__ in, TO *__restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (TO)in[i];
+}
+
+extern "C" int impdar_cast_dev(impdar_ctx *ctx, const void *d_src, int src_dtype, void *d_dst, int dst_dtype, size_t n)
+{
+    IMPDAR_ARG_CHECK(ctx && d_src && d_dst, "impdar_cast_dev: null argument");
+    IMPDAR_ARG_CHECK((src_dtype == IMPDAR_F32 || src_dtype == IMPDAR_F64) && (dst_dtype == IMPDAR_F32 || dst_dtype == IMPDAR_F64),
+                     "impdar_cast_dev: dtypes must be float32 or float64");
+    if (n == 0) return IMPDAR_OK;
+    IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
+    if (src_dtype == dst_dtype) {
+        IMPDAR_HIP_CHECK(hipMemcpyAsync(d_dst, d_src, n * impdar_dtype_size(src_dtype), hipMemcpyDeviceToDevice, ctx->stream));
+        return IMPDAR_OK;
+    }
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (src_dtype == IMPDAR_F64)
+        hipLaunchKernelGGL((cast_kernel<double, float>), dim3(nb), dim3(256), 0, ctx->stream, (const double *)d_src, (float *)d_dst, n);
+    else
+        hipLaunchKernelGGL((cast_kernel<float, double>), dim3(nb), dim3(256), 0, ctx->stream, (const float *)d_src, (double *)d_dst, n);
+    IMPDAR_HIP_CHECK(hipGetLastError());
+    return IMPDAR_OK;
+}
+
 // ---- host-buffer forms: upload, run, download ------------------------------------------------------------
 
 static int stage_in(impdar_ctx *ctx, const void *host, size_t bytes)

@@ -6,6 +6,8 @@ the C ABI (no PCIe traffic between steps), and ``dat.from_device()`` brings the 
 ``dat.data`` is None.  What has no resident form ('tk', the 2-D v(x, z) branch of 'phsh', SeisUnix)
 round-trips through the host.
 """
+import os
+
 import numpy as np
 
 from . import _hip
@@ -51,7 +53,18 @@ def kirchhoff_resident(dat, vel=1.69e8, nearfield=False):
         raise ValueError('The input array must be of size (snum, tnum)')
     print('Kirchhoff Migration (diffraction summation) of %.0fx%.0f matrix' % (dat.snum, dat.tnum))
     print('Using the MI355X HIP engine (resident)')
-    plan = KirchhoffPlan(dev.ctx, dev.dtype, dat.snum, dat.tnum, dat.dist, dat.travel_time, vel, nearfield, 'auto')
+    mode = os.environ.get('IMPDAR_KIRCH_MODE') or 'auto'
+    if mode not in ('auto', 'exact', 'fast'):
+        raise ValueError('mode must be one of auto, exact, fast')
+    if mode == 'fast' and dev.dtype != np.float32:
+        # explicit opt-in to the float32 kernel for float64 data (as migrationKirchhoff(mode='fast') on the host)
+        d32 = _hip.DeviceArray(dev.ctx, dev.shape, np.float32)
+        _hip.check(_hip.load().impdar_cast_dev(dev.ctx, dev.ptr, _hip.dtype_code(dev.dtype), d32.ptr, _hip.F32,
+                                               int(np.prod(dev.shape))), 'impdar_cast_dev')
+        _hip.check(_hip.load().impdar_ctx_sync(dev.ctx), 'impdar_ctx_sync')
+        dev.free()
+        dev = dat._dev = d32
+    plan = KirchhoffPlan(dev.ctx, dev.dtype, dat.snum, dat.tnum, dat.dist, dat.travel_time, vel, nearfield, mode)
     d_out = _hip.DeviceArray(dev.ctx, dev.shape, dev.dtype)
     try:
         plan.prep(dev, dat.tnum, 0, dat.tnum)

@@ -213,6 +213,9 @@ int impdar_trace_lerp_dev(impdar_ctx *ctx, const void *d_data, int dtype, int sn
                           const int *lo, const int *hi, const double *den, const double *t,
                           int n_new, double *d_out);
 
+/* float32 <-> float64 conversion of a resident array of `n` elements (NumPy's astype, on the device) */
+int impdar_cast_dev(impdar_ctx *ctx, const void *d_src, int src_dtype, void *d_dst, int dst_dtype, size_t n);
+
 /* ---- communicator (RCCL over xGMI) ------------------------------------- */
 #define IMPDAR_UNIQUE_ID_BYTES 128
 int impdar_comm_unique_id(char id[IMPDAR_UNIQUE_ID_BYTES]);

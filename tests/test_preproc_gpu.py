@@ -257,3 +257,24 @@ def test_resident_phase_shift_with_velocity_table(hip):
         return d.data
     a, b = run(False), run(True)
     assert a.dtype == np.float64 and b.dtype == np.float64 and np.array_equal(a, b)
+
+
+def test_resident_kirchhoff_fast_mode_opt_in(hip, monkeypatch):
+    """IMPDAR_KIRCH_MODE=fast on a float64 radargram held in HBM (what constant_space leaves behind): converted
+    to float32 on the device and migrated by the LDS-ring kernel, exactly as the host-buffer call with the same
+    setting; the result comes back float64."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(8)
+    snum, tnum = 300, 180
+    data = rng.standard_normal((snum, tnum))
+    monkeypatch.setenv('IMPDAR_KIRCH_MODE', 'fast')
+    h = filt_dat(data)
+    h.migrate('kirch', vel=1.69e8)
+    r = filt_dat(data)
+    r.to_device()
+    r.migrate('kirch', vel=1.69e8)
+    r.from_device()
+    assert r.data.dtype == np.float64 and np.array_equal(r.data, h.data)
+    want = c_oracle.kirchhoff(data, h.travel_time, h.dist, 1.69e8, False)
+    err = np.linalg.norm(r.data - want) / np.linalg.norm(want)
+    assert 1e-9 < err < 1e-4, err          # the float32 kernel's error, not the exact kernel's
