@@ -40,6 +40,7 @@ SIGNATURES = {
     'impdar_ctx_create': (_i, [_i, C.POINTER(_p)]),
     'impdar_ctx_destroy': (None, [_p]),
     'impdar_ctx_sync': (_i, [_p]),
+    'impdar_ctx_last_ms': (_i, [_p, C.POINTER(C.c_float)]),
     'impdar_dev_alloc': (_i, [_p, C.c_size_t, C.POINTER(_p)]),
     'impdar_dev_free': (_i, [_p, _p]),
     'impdar_dev_upload': (_i, [_p, _p, _p, C.c_size_t]),
@@ -55,6 +56,7 @@ SIGNATURES = {
     'impdar_kirch_plan_tnum_pad': (_i, [_p]),
     'impdar_kirch_prep': (_i, [_p, _p, _i, _i, _i]),
     'impdar_kirch_allgather': (_i, [_p]),
+    'impdar_kirch_exchange': (_i, [_p, _i, _ip, _ip, _ip, _i, _ip, _ip, _ip]),
     'impdar_kirch_migrate': (_i, [_p, _p, _i, _i]),
     'impdar_kirch_last_ms': (_i, [_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     'impdar_kirch_history_ms': (_i, [_p, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
@@ -100,6 +102,32 @@ def load():
             fn.argtypes = args
         _lib = lib
         return lib
+
+
+def mapped_rccl():
+    """Paths of every librccl mapped into this process (there must be one, and it must be the ROCm install's:
+    a torch wheel ships its own older librccl.so under the same SONAME, and whichever is loaded first serves
+    both)."""
+    paths = set()
+    try:
+        with open('/proc/self/maps') as fi:
+            for line in fi:
+                if 'librccl' in line:
+                    paths.add(line.split()[-1])
+    except OSError:
+        pass
+    return sorted(paths)
+
+
+def require_system_rccl():
+    load()
+    foreign = [p for p in mapped_rccl() if not os.path.realpath(p).startswith(os.path.realpath('/opt/rocm') + os.sep)
+               and '/opt/rocm' not in p]
+    if foreign and os.environ.get('IMPDAR_ALLOW_FOREIGN_RCCL') != '1':
+        raise HipUnavailableError(
+            'librccl was already mapped from %s before libimpdar_hip.so was loaded (import torch after '
+            'impdar_amd._hip.load(), or not at all): the library is linked against /opt/rocm\'s RCCL; set '
+            'IMPDAR_ALLOW_FOREIGN_RCCL=1 to run anyway' % ', '.join(foreign))
 
 
 def last_error():

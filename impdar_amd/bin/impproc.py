@@ -37,6 +37,9 @@ def _get_args():
     parser_mig.add_argument('--nxpad', type=int, default=100, help='Number of traces to pad with zeros for FFT')
     parser_mig.add_argument('--tmig', type=int, default=0, help='Times for velocity profile')
     parser_mig.add_argument('--verbose', type=int, default=1, help='Print output from SeisUnix migration')
+    parser_mig.add_argument('--gpus', type=int, default=0,
+                            help='(extension) shard a Kirchhoff migration over this many MI355X of the node '
+                                 '(default: $IMPDAR_NGPUS, else one)')
     _add_def_args(parser_mig)
 
     parser_vbp = subparsers.add_parser('vbp', help='Vertically bandpass the data')
@@ -96,8 +99,10 @@ def main():
 
 
 def mig(dat, mtype='stolt', vel=1.69e8, vtaper=100, htaper=100, tmig=0, verbose=0, vel_fn=None, nxpad=1,
-        nearfield=False, **kwargs):
+        nearfield=False, gpus=0, **kwargs):
     """Migrate data (defaults as the reference's ``impproc.mig``)."""
+    if gpus and gpus > 1:
+        os.environ['IMPDAR_NGPUS'] = str(gpus)
     dat.migrate(mtype, vel=vel, vtaper=vtaper, htaper=htaper, tmig=tmig, verbose=verbose, vel_fn=vel_fn,
                 nxpad=nxpad, nearfield=nearfield)
 

@@ -57,6 +57,40 @@ extern "C" int impdar_ctx_create(int device, impdar_ctx **out)
     return IMPDAR_OK;
 }
 
+int impdar_ctx_mark_produced(impdar_ctx *ctx)
+{
+    if (!ctx->ev_produced) IMPDAR_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_produced, hipEventDisableTiming));
+    IMPDAR_HIP_CHECK(hipEventRecord(ctx->ev_produced, ctx->stream));
+    ctx->produced = true;
+    return IMPDAR_OK;
+}
+
+int impdar_ctx_tic(impdar_ctx *ctx)
+{
+    if (!ctx->ev_tic) IMPDAR_HIP_CHECK(hipEventCreate(&ctx->ev_tic));
+    if (!ctx->ev_toc) IMPDAR_HIP_CHECK(hipEventCreate(&ctx->ev_toc));
+    ctx->timed = false;
+    IMPDAR_HIP_CHECK(hipEventRecord(ctx->ev_tic, ctx->stream));
+    return IMPDAR_OK;
+}
+
+int impdar_ctx_toc(impdar_ctx *ctx)
+{
+    IMPDAR_HIP_CHECK(hipEventRecord(ctx->ev_toc, ctx->stream));
+    ctx->timed = true;
+    return IMPDAR_OK;
+}
+
+extern "C" int impdar_ctx_last_ms(impdar_ctx *ctx, float *ms)
+{
+    IMPDAR_ARG_CHECK(ctx && ms, "null context/pointer");
+    IMPDAR_ARG_CHECK(ctx->timed, "no timed call (impdar_stolt_dev / impdar_phaseshift_dev) has run on this context");
+    IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
+    IMPDAR_HIP_CHECK(hipEventSynchronize(ctx->ev_toc));
+    IMPDAR_HIP_CHECK(hipEventElapsedTime(ms, ctx->ev_tic, ctx->ev_toc));
+    return IMPDAR_OK;
+}
+
 void impdar_comm_destroy(impdar_ctx *ctx);   // comm.hip
 
 void impdar_stolt_forget(const impdar_ctx *ctx);   // stolt.hip
@@ -115,6 +149,9 @@ static int impdar_download_piped(impdar_ctx *ctx, void *host_dst, const void *de
                                  bool widen, hipStream_t st)
 {
     const size_t bytes = n * elem_in;
+    // one staged download per context at a time: the staging buffer is shared (and may be re-allocated) and
+    // ctypes callers run without the GIL
+    std::lock_guard<std::mutex> lock(ctx->pinned_mu);
     void *stage = bytes >= (1u << 20) ? impdar_ctx_pinned(ctx, bytes) : nullptr;
     std::vector<char> fallback;
     if (!stage) {
@@ -128,17 +165,30 @@ static int impdar_download_piped(impdar_ctx *ctx, void *host_dst, const void *de
     }
     // pieces of >= 48 MB: below that the host-thread start-up of every piece costs more than the overlap gains
     const int npiece = (int)std::min<size_t>(8, std::max<size_t>(1, bytes / (48u << 20)));
-    hipEvent_t ev[8];
+    hipEvent_t ev[8] = {};
     size_t lo[9];
     for (int c = 0; c <= npiece; ++c) lo[c] = (n * c / npiece) / 16 * 16;
     lo[npiece] = n;
-    for (int c = 0; c < npiece; ++c) {
-        IMPDAR_HIP_CHECK(hipEventCreateWithFlags(&ev[c], hipEventDisableTiming));
-        IMPDAR_HIP_CHECK(hipMemcpyAsync((char *)stage + lo[c] * elem_in, (const char *)dev_src + lo[c] * elem_in,
-                                        (lo[c + 1] - lo[c]) * elem_in, hipMemcpyDeviceToHost, st));
-        IMPDAR_HIP_CHECK(hipEventRecord(ev[c], st));
+    int rc = IMPDAR_OK, issued = 0;
+    for (int c = 0; c < npiece && rc == IMPDAR_OK; ++c) {
+        if (hipEventCreateWithFlags(&ev[c], hipEventDisableTiming) != hipSuccess) {
+            ev[c] = nullptr;
+            rc = IMPDAR_ERR_HIP;
+            break;
+        }
+        ++issued;
+        if (hipMemcpyAsync((char *)stage + lo[c] * elem_in, (const char *)dev_src + lo[c] * elem_in,
+                           (lo[c + 1] - lo[c]) * elem_in, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipEventRecord(ev[c], st) != hipSuccess)
+            rc = IMPDAR_ERR_HIP;
     }
-    int rc = IMPDAR_OK;
+    if (rc) {
+        // no DMA into the staging buffer may still be in flight when it is handed to the next caller
+        (void)hipStreamSynchronize(st);
+        for (int c = 0; c < issued; ++c) (void)hipEventDestroy(ev[c]);
+        impdar_set_error("device -> host copy failed: %s", hipGetErrorString(hipGetLastError()));
+        return rc;
+    }
     for (int c = 0; c < npiece; ++c) {
         if (hipEventSynchronize(ev[c]) != hipSuccess) rc = IMPDAR_ERR_HIP;
         (void)hipEventDestroy(ev[c]);
@@ -154,7 +204,17 @@ static int impdar_download_piped(impdar_ctx *ctx, void *host_dst, const void *de
             impdar_parallel_for(cnt * elem_in, 64, [=](size_t a, size_t b) { memcpy(dp + a, sp + a, b - a); });
         }
     }
-    if (rc) impdar_set_error("device -> host copy failed");
+    if (rc) {
+        (void)hipStreamSynchronize(st);
+        impdar_set_error("device -> host copy failed");
+    }
+    // a staging buffer above 1 GiB is not kept pinned for the life of the process (re-pinning costs ~0.2 ms per MB,
+    // so the common radargram sizes keep theirs)
+    if (ctx->pinned_bytes > ((size_t)1 << 30)) {
+        (void)hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+    }
     return rc;
 }
 
@@ -183,6 +243,9 @@ extern "C" void impdar_ctx_destroy(impdar_ctx *ctx)
     impdar_ps_forget(ctx);
     impdar_preproc_forget(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->ev_produced) (void)hipEventDestroy(ctx->ev_produced);
+    if (ctx->ev_tic) (void)hipEventDestroy(ctx->ev_tic);
+    if (ctx->ev_toc) (void)hipEventDestroy(ctx->ev_toc);
     impdar_comm_destroy(ctx);
     (void)hipStreamDestroy(ctx->aux);
     (void)hipStreamDestroy(ctx->stream);
@@ -240,5 +303,5 @@ extern "C" int impdar_dev_memset(impdar_ctx *ctx, void *dst_dev, int value, size
     IMPDAR_ARG_CHECK(ctx && dst_dev, "null context/pointer");
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
     IMPDAR_HIP_CHECK(hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
-    return IMPDAR_OK;
+    return impdar_ctx_mark_produced(ctx);
 }

@@ -63,6 +63,35 @@ int impdar_allgather_rows(impdar_ctx *ctx, void *image, size_t bytes_per_rank, h
     return IMPDAR_OK;
 }
 
+// Grouped point-to-point exchange on one buffer: this rank sends bytes [soff[i], soff[i] + slen[i]) of `image` to
+// rank speer[i] and receives bytes [roff[i], roff[i] + rlen[i]) from rank rpeer[i] (the halo exchange of the
+// sharded Kirchhoff migration: every byte range is a run of whole image rows).  One ncclGroup, so the
+// transfers of all peers proceed concurrently over their own xGMI links.
+int impdar_exchange_ranges(impdar_ctx *ctx, void *image, int nsend, const int *speer, const size_t *soff,
+                           const size_t *slen, int nrecv, const int *rpeer, const size_t *roff, const size_t *rlen,
+                           hipStream_t stream)
+{
+    IMPDAR_ARG_CHECK(ctx && ctx->comm, "communicator not initialised (impdar_comm_init)");
+    char *base = reinterpret_cast<char *>(image);
+    ncclComm_t comm = reinterpret_cast<ncclComm_t>(ctx->comm);
+    for (int i = 0; i < nsend; ++i)
+        IMPDAR_ARG_CHECK(speer[i] >= 0 && speer[i] < ctx->nranks, "send peer %d outside the communicator", speer[i]);
+    for (int i = 0; i < nrecv; ++i)
+        IMPDAR_ARG_CHECK(rpeer[i] >= 0 && rpeer[i] < ctx->nranks, "receive peer %d outside the communicator", rpeer[i]);
+    IMPDAR_NCCL_CHECK(ncclGroupStart());
+    ncclResult_t bad = ncclSuccess;
+    for (int i = 0; i < nsend && bad == ncclSuccess; ++i)
+        if (slen[i]) bad = ncclSend(base + soff[i], slen[i], ncclChar, speer[i], comm, stream);
+    for (int i = 0; i < nrecv && bad == ncclSuccess; ++i)
+        if (rlen[i]) bad = ncclRecv(base + roff[i], rlen[i], ncclChar, rpeer[i], comm, stream);
+    ncclResult_t end = ncclGroupEnd();
+    if (bad != ncclSuccess || end != ncclSuccess) {
+        impdar_set_error("grouped ncclSend/ncclRecv failed: %s", ncclGetErrorString(bad != ncclSuccess ? bad : end));
+        return IMPDAR_ERR_COMM;
+    }
+    return IMPDAR_OK;
+}
+
 extern "C" int impdar_comm_barrier(impdar_ctx *ctx)
 {
     IMPDAR_ARG_CHECK(ctx, "null context");

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/impdar_hip.h"
@@ -24,7 +25,22 @@ struct impdar_ctx {
     // array is a page fault per 4 KiB; the faults parallelise, a single D2H into it does not)
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
+    std::mutex pinned_mu;           // held for a whole staged download (the buffer may be re-allocated by the next one)
+    // last work enqueued on `stream` by a *_dev entry point that WRITES a caller-visible device array; consumers
+    // on the producer stream (impdar_kirch_prep) wait for it
+    hipEvent_t ev_produced = nullptr;
+    bool produced = false;
+    // device-side duration of the last Stolt / phase-shift call enqueued on `stream` (impdar_ctx_last_ms)
+    hipEvent_t ev_tic = nullptr, ev_toc = nullptr;
+    bool timed = false;
 };
+
+// bracket the device work of one call on ctx->stream (read back by impdar_ctx_last_ms)
+int impdar_ctx_tic(impdar_ctx *ctx);
+int impdar_ctx_toc(impdar_ctx *ctx);
+
+// record "everything enqueued on ctx->stream so far produces data a later call may read" (see impdar_kirch_prep)
+int impdar_ctx_mark_produced(impdar_ctx *ctx);
 
 // grow-only pinned staging buffer of the context; nullptr when the allocation fails (callers fall back to a
 // direct pageable copy)

@@ -1054,6 +1054,8 @@ struct impdar_kirch_plan {
     DevBuf GT[2], DT[2];           // images with KF_PAD_ROWS all-zero rows before row 0 and after row tnum_pad-1
     int buf = 0;
     bool migrated_since_prep = false;
+    const void *last_out = nullptr;   // output of the last migrate (a prep that reads it must wait for that kernel)
+    int last_out_buf = 0;
     hipEvent_t ev_ready[2] = {nullptr, nullptr};   // image + table of buffer b complete (aux stream)
     hipEvent_t ev_free[2] = {nullptr, nullptr};    // last migrate reading buffer b done (compute stream)
     bool free_recorded[2] = {false, false};
@@ -1401,6 +1403,14 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
     // input itself must already be complete: the upload entry points are blocking, and the
     // one-shot paths below synchronise their own copy before calling prep.)
     if (p->free_recorded[b]) IMPDAR_HIP_CHECK(hipStreamWaitEvent(st, p->ev_free[b], 0));
+    // d_data may have been produced by a *_dev step (band pass, re-spacing, cast, another migration).  Those only
+    // enqueue on the compute stream and mark the context (impdar_ctx_mark_produced): the producer stream waits
+    // for the last such mark.  The mark sits in FRONT of any diffraction sum enqueued since, so the prep of
+    // radargram s+1 still overlaps the migrate of radargram s; only when the input IS the previous migrate's
+    // output does prep wait for that kernel.
+    if (p->ctx->produced) IMPDAR_HIP_CHECK(hipStreamWaitEvent(st, p->ctx->ev_produced, 0));
+    if (p->last_out && d_data == p->last_out && p->free_recorded[p->last_out_buf])
+        IMPDAR_HIP_CHECK(hipStreamWaitEvent(st, p->ev_free[p->last_out_buf], 0));
     hipEvent_t *ev = p->evs[p->slot];
     if (!p->haves[p->slot][0]) IMPDAR_HIP_CHECK(hipEventRecord(ev[0], st));
     if (nloc > 0) {
@@ -1725,6 +1735,8 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
     IMPDAR_HIP_CHECK(hipEventRecord(ev[5], st));
     IMPDAR_HIP_CHECK(hipEventRecord(p->ev_free[b], st));
     p->free_recorded[b] = true;
+    p->last_out = d_out;
+    p->last_out_buf = b;
     p->migrated_since_prep = true;
     p->haves[p->slot][2] = true;
     return IMPDAR_OK;
@@ -1749,6 +1761,52 @@ extern "C" int impdar_kirch_allgather(impdar_kirch_plan *p)
         if (rc) return rc;
         if (p->nearfield && (rc = impdar_allgather_rows(p->ctx, img_row0(p, p->DT[b]), per, st))) return rc;
     }
+    IMPDAR_HIP_CHECK(hipEventRecord(ev[3], st));
+    IMPDAR_HIP_CHECK(hipEventRecord(p->ev_ready[b], st));
+    p->haves[p->slot][1] = true;
+    return IMPDAR_OK;
+}
+
+// defined in comm.hip
+int impdar_exchange_ranges(impdar_ctx *ctx, void *image, int nsend, const int *speer, const size_t *soff,
+                           const size_t *slen, int nrecv, const int *rpeer, const size_t *roff, const size_t *rlen,
+                           hipStream_t stream);
+
+// Halo exchange: grouped ncclSend/ncclRecv of image-row ranges instead of the all-gather, for shards whose
+// aperture halo is narrower than the rest of the profile.  Row ranges are whole 8-trace groups
+// (contiguous in both image layouts); rows nobody sends stay whatever the buffer set held -- the kernels never
+// pick from rows beyond their block's aperture.
+extern "C" int impdar_kirch_exchange(impdar_kirch_plan *p, int nsend, const int *speer, const int *slo, const int *shi,
+                                     int nrecv, const int *rpeer, const int *rlo, const int *rhi)
+{
+    IMPDAR_ARG_CHECK(p, "null plan");
+    IMPDAR_ARG_CHECK(nsend >= 0 && nrecv >= 0 && nsend <= 4096 && nrecv <= 4096, "bad range counts %d / %d", nsend, nrecv);
+    IMPDAR_ARG_CHECK((nsend == 0 || (speer && slo && shi)) && (nrecv == 0 || (rpeer && rlo && rhi)), "null range arrays");
+    IMPDAR_ARG_CHECK(p->nranks == p->ctx->nranks, "plan was built for %d ranks but the communicator has %d",
+                     p->nranks, p->ctx->nranks);
+    const size_t rowb = (size_t)p->snum * impdar_dtype_size(p->dtype);
+    std::vector<size_t> soff(nsend), slen(nsend), roff(nrecv), rlen(nrecv);
+    auto conv = [&](int lo, int hi, size_t &off, size_t &len) {
+        if (lo < 0 || hi < lo || hi > p->tnum_pad || (lo & 7) || (hi & 7)) return false;
+        off = (size_t)lo * rowb;
+        len = (size_t)(hi - lo) * rowb;
+        return true;
+    };
+    for (int i = 0; i < nsend; ++i)
+        IMPDAR_ARG_CHECK(conv(slo[i], shi[i], soff[i], slen[i]), "send rows [%d,%d) are not whole 8-trace groups of the image", slo[i], shi[i]);
+    for (int i = 0; i < nrecv; ++i)
+        IMPDAR_ARG_CHECK(conv(rlo[i], rhi[i], roff[i], rlen[i]), "receive rows [%d,%d) are not whole 8-trace groups of the image", rlo[i], rhi[i]);
+    IMPDAR_HIP_CHECK(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->aux;                       // behind this radargram's prep
+    hipEvent_t *ev = p->evs[p->slot];
+    const int b = p->buf;
+    IMPDAR_HIP_CHECK(hipEventRecord(ev[2], st));
+    int rc = impdar_exchange_ranges(p->ctx, img_row0(p, p->GT[b]), nsend, speer, soff.data(), slen.data(), nrecv, rpeer,
+                                    roff.data(), rlen.data(), st);
+    if (rc) return rc;
+    if (p->nearfield && (rc = impdar_exchange_ranges(p->ctx, img_row0(p, p->DT[b]), nsend, speer, soff.data(), slen.data(),
+                                                     nrecv, rpeer, roff.data(), rlen.data(), st)))
+        return rc;
     IMPDAR_HIP_CHECK(hipEventRecord(ev[3], st));
     IMPDAR_HIP_CHECK(hipEventRecord(p->ev_ready[b], st));
     p->haves[p->slot][1] = true;
@@ -1843,29 +1901,15 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
     const auto t1 = now();
     if ((rc = impdar_kirch_prep(p, din.p, tnum, 0, tnum))) return done(rc);
     if ((rc = impdar_kirch_migrate(p, dout.p, 0, tnum))) return done(rc);
-    // device -> pinned staging -> the caller's float64 array (mig_python.py:118 returns float64)
-    void *stage = impdar_ctx_pinned(ctx, bytes);
-    std::vector<char> tmp;
-    void *host_dst = stage;
-    if (!stage) {
-        host_dst = out;
-        if (dtype == IMPDAR_F32) {
-            tmp.resize(bytes);
-            host_dst = tmp.data();
-        }
-    }
-    if (hipMemcpyAsync(host_dst, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) {
-        impdar_set_error("D2H copy / synchronize failed: %s", hipGetErrorString(hipGetLastError()));
-        return done(IMPDAR_ERR_HIP);
-    }
+    // device -> pinned staging (in pieces) -> the caller's float64 array on several host threads
+    // (mig_python.py:118 returns float64); waits for the diffraction sum on the compute stream
+    if ((rc = impdar_dev_download_f64(ctx, out, dout.p, dtype, (size_t)snum * tnum))) return done(rc);
     const auto t2 = now();
-    if (host_dst != out) impdar_host_copy_f64(out, host_dst, (size_t)snum * tnum, dtype == IMPDAR_F32);
     const auto t3 = now();
     rc = done(IMPDAR_OK);
     if (timing)
-        fprintf(stderr, "impdar_kirchhoff: plan+alloc+H2D %.1f ms, prep+migrate+D2H %.1f ms, convert %.1f ms, destroy %.1f ms\n",
-                ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
+        fprintf(stderr, "impdar_kirchhoff: plan+alloc+H2D %.1f ms, prep+migrate+D2H+convert %.1f ms, destroy %.1f ms\n",
+                ms(t0, t1), ms(t1, t2), ms(t3, now()));
     return rc;
 }
 

@@ -580,9 +580,10 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_thr.p, thr.data(), (size_t)snum * 8, hipMemcpyHostToDevice, st));
     }
     dim3 tgrid((tnum + 63) / 64, (nt + 63) / 64);
+    int rc;
+    if ((rc = impdar_ctx_tic(ctx))) return rc;
     hipLaunchKernelGGL((ps_taper_pad_transpose<T>), tgrid, dim3(256), 0, st, (const T *)d_data, pl.X.as<Cp<T>>(), snum,
                        tnum, nt, htaper, vtaper);
-    int rc;
     if ((rc = pl.f_time.exec(pl.X.p, nullptr))) return rc;
     if ((rc = pl.f_trace.exec(pl.X.p, nullptr))) return rc;
     PsParams P;
@@ -607,6 +608,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     dim3 bgrid((tnum + 63) / 64, (snum + 63) / 64);
     hipLaunchKernelGGL((ps_real_transpose<T>), bgrid, dim3(256), 0, st, pl.TK.as<Cp<T>>(), (T *)d_out, snum, tnum);
     IMPDAR_HIP_CHECK(hipGetLastError());
+    if ((rc = impdar_ctx_toc(ctx))) return rc;
     // host staging vectors (w, thr) must outlive the async copies
     IMPDAR_HIP_CHECK(hipStreamSynchronize(st));
     return IMPDAR_OK;
@@ -650,10 +652,11 @@ extern "C" int impdar_phaseshift_dev(impdar_ctx *ctx, const void *d_data, int dt
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
     std::lock_guard<std::mutex> lk(g_ps_mu);
     if (!g_ps_plan) g_ps_plan = new PsPlan();
-    return dtype == IMPDAR_F32 ? ps_run<float>(ctx, *g_ps_plan, d_data, snum, tnum, nt, kx, ws, dt, tt_us, vconst, vmig,
-                                               vmig_len, htaper, vtaper, d_out)
-                               : ps_run<double>(ctx, *g_ps_plan, d_data, snum, tnum, nt, kx, ws, dt, tt_us, vconst, vmig,
-                                                vmig_len, htaper, vtaper, d_out);
+    const int rc = dtype == IMPDAR_F32 ? ps_run<float>(ctx, *g_ps_plan, d_data, snum, tnum, nt, kx, ws, dt, tt_us, vconst, vmig,
+                                                       vmig_len, htaper, vtaper, d_out)
+                                       : ps_run<double>(ctx, *g_ps_plan, d_data, snum, tnum, nt, kx, ws, dt, tt_us, vconst, vmig,
+                                                        vmig_len, htaper, vtaper, d_out);
+    return rc ? rc : impdar_ctx_mark_produced(ctx);
 }
 
 // ===========================================================================

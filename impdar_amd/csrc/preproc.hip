@@ -428,8 +428,10 @@ extern "C" int impdar_filtfilt_dev(impdar_ctx *ctx, void *d_data, int dtype, int
     for (int n = 0; n < ncoef - 1; ++n) c.zi[n] = zi[n];
     scratch_bind(ctx);
     IMPDAR_HIP_CHECK(g_scr.y.ensure((size_t)(snum + 2 * edge) * tnum * sizeof(double)));
-    if (dtype == IMPDAR_F32) return filtfilt_dispatch<float>(ctx, (float *)d_data, g_scr.y.as<double>(), snum, tnum, edge, ncoef, c);
-    return filtfilt_dispatch<double>(ctx, (double *)d_data, g_scr.y.as<double>(), snum, tnum, edge, ncoef, c);
+    const int rc = dtype == IMPDAR_F32
+                       ? filtfilt_dispatch<float>(ctx, (float *)d_data, g_scr.y.as<double>(), snum, tnum, edge, ncoef, c)
+                       : filtfilt_dispatch<double>(ctx, (double *)d_data, g_scr.y.as<double>(), snum, tnum, edge, ncoef, c);
+    return rc ? rc : impdar_ctx_mark_produced(ctx);
 }
 
 extern "C" int impdar_fir_shift_dev(impdar_ctx *ctx, void *d_data, int dtype, int snum, int tnum, const double *taps,
@@ -458,7 +460,7 @@ extern "C" int impdar_fir_shift_dev(impdar_ctx *ctx, void *d_data, int dtype, in
                            g_scr.aux.as<double>(), snum, tnum, ntaps, t);
     IMPDAR_HIP_CHECK(hipGetLastError());
     IMPDAR_HIP_CHECK(hipMemcpyAsync(d_data, g_scr.aux.p, n * es, hipMemcpyDeviceToDevice, ctx->stream));
-    return IMPDAR_OK;
+    return impdar_ctx_mark_produced(ctx);
 }
 
 extern "C" int impdar_trace_lerp_dev(impdar_ctx *ctx, const void *d_data, int dtype, int snum, int tnum, const int *lo,
@@ -496,7 +498,7 @@ extern "C" int impdar_trace_lerp_dev(impdar_ctx *ctx, const void *d_data, int dt
         hipLaunchKernelGGL(trace_lerp_kernel<double>, grid, dim3(256), 0, ctx->stream, (const double *)d_data, d_out, snum,
                            tnum, n_new, d_lo, d_hi, d_den, d_t);
     IMPDAR_HIP_CHECK(hipGetLastError());
-    return IMPDAR_OK;
+    return impdar_ctx_mark_produced(ctx);
 }
 
 // element-wise float32 <-> float64 conversion of a resident array (what NumPy's astype does on the host)
@@ -516,7 +518,7 @@ extern "C" int impdar_cast_dev(impdar_ctx *ctx, const void *d_src, int src_dtype
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
     if (src_dtype == dst_dtype) {
         IMPDAR_HIP_CHECK(hipMemcpyAsync(d_dst, d_src, n * impdar_dtype_size(src_dtype), hipMemcpyDeviceToDevice, ctx->stream));
-        return IMPDAR_OK;
+        return impdar_ctx_mark_produced(ctx);
     }
     const unsigned nb = (unsigned)((n + 255) / 256);
     if (src_dtype == IMPDAR_F64)
@@ -524,7 +526,7 @@ extern "C" int impdar_cast_dev(impdar_ctx *ctx, const void *d_src, int src_dtype
     else
         hipLaunchKernelGGL((cast_kernel<float, double>), dim3(nb), dim3(256), 0, ctx->stream, (const float *)d_src, (double *)d_dst, n);
     IMPDAR_HIP_CHECK(hipGetLastError());
-    return IMPDAR_OK;
+    return impdar_ctx_mark_produced(ctx);
 }
 
 // ---- host-buffer forms: upload, run, download ------------------------------------------------------------

@@ -209,6 +209,10 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
     }
     IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_kx.p, kx, (size_t)tnum * 8, hipMemcpyHostToDevice, st));
     IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_ws.p, ws, (size_t)m * 8, hipMemcpyHostToDevice, st));
+    {
+        int trc = impdar_ctx_tic(ctx);
+        if (trc) return trc;
+    }
     const int do_taper = !(htaper != htaper);     // NaN = caller already tapered (integer dtypes)
     dim3 tgrid((tnum + 63) / 64, (snum + 63) / 64);
     hipLaunchKernelGGL((stolt_taper_transpose<T>), tgrid, dim3(256), 0, st, (const T *)d_data, pl.X.as<T>(), snum, tnum,
@@ -232,7 +236,7 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
     dim3 bgrid((tnum + 63) / 64, (nout + 63) / 64);
     hipLaunchKernelGGL((stolt_transpose_back<T>), bgrid, dim3(256), 0, st, pl.Y.as<T>(), (T *)d_out, nout, tnum);
     IMPDAR_HIP_CHECK(hipGetLastError());
-    return IMPDAR_OK;
+    return impdar_ctx_toc(ctx);
 }
 
 extern "C" int impdar_stolt_dev(impdar_ctx *ctx, const void *d_data, int dtype, int snum, int tnum, const double *kx,
@@ -251,7 +255,7 @@ extern "C" int impdar_stolt_dev(impdar_ctx *ctx, const void *d_data, int dtype, 
     if (rc) return rc;
     // kx/ws were staged from caller memory: complete before returning
     IMPDAR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    return IMPDAR_OK;
+    return impdar_ctx_mark_produced(ctx);
 }
 
 extern "C" int impdar_stolt(impdar_ctx *ctx, const void *data, int dtype, int snum, int tnum, const double *kx,

@@ -39,6 +39,16 @@ class KirchhoffPlan(object):
     def allgather(self):
         _hip.check(self.lib.impdar_kirch_allgather(self.h), 'impdar_kirch_allgather')
 
+    def exchange(self, send, recv):
+        """Halo exchange: ``send`` / ``recv`` are lists of (peer, row_lo, row_hi) (``parallel.plan_exchange``)."""
+        def cols(lst):
+            a = np.ascontiguousarray(np.asarray(lst, dtype=np.int32).reshape(-1, 3).T)
+            ip = C.POINTER(C.c_int)
+            return a, len(lst), a[0].ctypes.data_as(ip), a[1].ctypes.data_as(ip), a[2].ctypes.data_as(ip)
+        sa, ns, sp, sl, sh = cols(send)
+        ra, nr, rp, rl, rh = cols(recv)
+        _hip.check(self.lib.impdar_kirch_exchange(self.h, ns, sp, sl, sh, nr, rp, rl, rh), 'impdar_kirch_exchange')
+
     def migrate(self, d_out, xlo, xhi):
         ptr = d_out.ptr if hasattr(d_out, 'ptr') else d_out
         _hip.check(self.lib.impdar_kirch_migrate(self.h, ptr, int(xlo), int(xhi)), 'impdar_kirch_migrate')

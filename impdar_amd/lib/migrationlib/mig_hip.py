@@ -75,8 +75,11 @@ def _kx(dat):
 # ---------------------------------------------------------------------------
 # Kirchhoff
 # ---------------------------------------------------------------------------
-def migrationKirchhoff(dat, vel=1.69e8, nearfield=False, mode=None):
+def migrationKirchhoff(dat, vel=1.69e8, nearfield=False, mode=None, ngpus=None):
     """Kirchhoff diffraction-summation migration (mig_python.py:63-123).
+
+    ``ngpus`` (extension; default ``$IMPDAR_NGPUS``): above 1 the radargram is sharded by output-trace blocks
+    over that many GPUs of the node, one worker process per GPU (``impdar_amd.parallel.run_sharded``).
 
     ``mode`` (extension): None/'auto' picks the fp32 LDS-ring kernel for
     float32 data on uniform grids and the fp64 reference-order kernel
@@ -92,12 +95,24 @@ def migrationKirchhoff(dat, vel=1.69e8, nearfield=False, mode=None):
         mode = os.environ.get('IMPDAR_KIRCH_MODE') or None
     if mode not in _MODES:
         raise ValueError('mode must be one of auto, exact, fast')
-    lib = _hip.load()
-    ctx = _hip.context()
     src = np.asarray(dat.data)
     if mode == 'fast' and src.dtype != np.float32:
         # explicit opt-in to the float32 kernel for float64 / integer data
         src = src.astype(np.float32)
+    from ... import parallel
+    ngpus = parallel.ngpus_requested() if ngpus is None else int(ngpus)
+    if ngpus > 1:
+        # before this process touches the GPU: the ranks are child processes, one per device
+        if np.shape(dat.dist) != (dat.tnum,):
+            raise ValueError('dist must have one entry per trace')
+        dat.data = parallel.run_sharded(src, dat.dist, dat.travel_time, vel=vel, nearfield=nearfield, ngpus=ngpus,
+                                        mode=mode or 'auto')
+        print('')
+        print('Kirchhoff Migration of %.0fx%.0f matrix complete in %.2f seconds on %d GPUs'
+              % (dat.snum, dat.tnum, time.time() - start, ngpus))
+        return dat
+    lib = _hip.load()
+    ctx = _hip.context()
     data, code = _device_data(src)
     tt_sec = np.ascontiguousarray(dat.travel_time / 1.0e6, dtype=np.float64)
     uniform, h, ga, gb, gc = gradient_coefficients(tt_sec)

@@ -1,16 +1,39 @@
 """Sharding of a Kirchhoff migration across the GPUs of one node.
 
 Outputs are independent, so each rank owns a contiguous block of output
-traces; the only exchange is an all-gather of the trace-major input image
-(every rank prepares -- gradient + transpose -- only its own equal-width
-block of input traces).  Output blocks are sized by
-in-aperture pair count, not trace count: traces near the ends of the profile
-see roughly half the aperture of interior traces.
+traces; the only exchange moves rows of the trace-major input image (every
+rank prepares -- gradient + transpose -- only its own equal-width block of
+input traces): an all-gather, or, when a block's
+aperture halo is narrower than the rest of the profile, grouped
+point-to-point sends of just the rows each block's aperture reaches
+(``plan_exchange``).  Output blocks are sized by in-aperture pair count, not
+trace count: traces near the ends of the profile see roughly half the
+aperture of interior traces.
 
-Pure NumPy host logic; the collective itself is RCCL inside the C library
-(``impdar_kirch_allgather``).  ``exchange_host`` is the same data movement
-over ``torch.distributed`` (gloo) for CPU-side tests of the partitioning.
+Layers, bottom up:
+
+* partition arithmetic (``plan_blocks``, ``plan_exchange``): pure NumPy;
+* ``Rendezvous``: the control plane of one job -- a TCP star on rank 0 found
+  through a file in /tmp, carrying the 128-byte RCCL unique id, barriers and
+  small reductions.  No torch, no MPI;
+* ``migrate_kirchhoff_sharded``: what one rank does for one radargram
+  (prep of its shard -> exchange -> diffraction sum of its block) through an
+  *engine*: ``HipEngine`` is the C library (RCCL inside), the tests plug in a
+  CPU stand-in to run the same orchestration over gloo;
+* ``run_sharded``: the single-process front door (``RadarData.migrate`` with
+  ``IMPDAR_NGPUS`` / ``impproc migrate --gpus N``): spawns one worker per GPU
+  (``impdar_amd._shard_worker``) around shared-memory copies of the
+  radargram and collects the output blocks.
 """
+import os
+import pickle
+import socket
+import struct
+import subprocess
+import sys
+import tempfile
+import time
+
 import numpy as np
 
 
@@ -103,6 +126,368 @@ def plan_blocks(tt_sec, dx, vel, tnum, nranks, trace_cost=TRACE_COST_PAIRS, quan
     blocks = balanced_blocks(w + trace_cost, nranks, quantum if (quantum > 1 and tnum >= 4 * quantum * nranks) else 1)
     pairs = [int(w[lo:hi].sum()) for lo, hi in blocks]
     return tnum_pad, shards, blocks, pairs
+
+
+def plan_exchange(blocks, tnum_pad, nranks, halo, threshold=0.75):
+    """Which image rows every rank must receive, and from whom.
+
+    Rank r's output block [xlo, xhi) reads input traces [xlo - halo, xhi + halo) (whole 8-trace groups, clipped
+    to the padded profile); rank s owns rows [s*per, (s+1)*per).  Returns a dict with ``mode``: ``'halo'`` when
+    the busiest rank receives at most ``threshold`` of what the all-gather would hand it, else ``'allgather'``;
+    ``need[r]`` = (lo, hi); ``recv[r]`` / ``send[r]`` = lists of (peer, row_lo, row_hi).  Deterministic in its
+    arguments, so every rank derives the same plan without talking."""
+    per = tnum_pad // nranks
+    need, recv, send = [], [[] for _ in range(nranks)], [[] for _ in range(nranks)]
+    for r, (xlo, xhi) in enumerate(blocks):
+        if xhi <= xlo:
+            need.append((0, 0))
+            continue
+        lo = max(0, ((xlo - halo) // 8) * 8)
+        hi = min(tnum_pad, -((-(xhi + halo)) // 8) * 8)
+        need.append((lo, hi))
+        for s_ in range(nranks):
+            a, b = max(lo, s_ * per), min(hi, (s_ + 1) * per)
+            if s_ != r and b > a:
+                recv[r].append((s_, a, b))
+                send[s_].append((r, a, b))
+    got = [sum(b - a for _, a, b in rv) for rv in recv]
+    full = (nranks - 1) * per
+    mode = 'halo' if nranks > 1 and full > 0 and max(got) <= threshold * full else 'allgather'
+    return dict(mode=mode, need=need, recv=recv, send=send, rows_received=got, rows_allgather=full)
+
+
+def halo_traces(tt_sec, dx, vel):
+    """Aperture half width in traces (+ one 8-trace group of margin for the kernels' staging look-ahead)."""
+    h = aperture_half_widths(tt_sec, dx, vel)
+    return int(max(int(h.max()), 0)) + 1 + 8
+
+
+# ---------------------------------------------------------------------------------------------------------
+# control plane
+# ---------------------------------------------------------------------------------------------------------
+def _send_msg(sock, obj):
+    blob = pickle.dumps(obj, protocol=4)
+    sock.sendall(struct.pack('<Q', len(blob)) + blob)
+
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError('rendezvous peer closed the connection')
+        buf += chunk
+    return bytes(buf)
+
+
+def _recv_msg(sock):
+    (n,) = struct.unpack('<Q', _recv_exact(sock, 8))
+    return pickle.loads(_recv_exact(sock, n))
+
+
+class Rendezvous(object):
+    """Control plane of one multi-process job on one node: rank 0 listens on an ephemeral TCP port of
+    127.0.0.1 and publishes it in ``/tmp/impdar_rdv_<job>``; the other ranks connect.  ``job`` defaults to
+    ``$MASTER_PORT`` + the launcher's pid (the same for every rank under ``torch.distributed.run`` and under
+    ``bench.py``'s own spawner), so concurrent jobs do not meet.  Collectives are tiny (a unique id, a
+    float, a barrier) and go through rank 0.  Ranks must call the same collectives in the same order."""
+
+    def __init__(self, rank=None, world=None, job=None, timeout=120.0):
+        self.rank = int(os.environ.get('RANK', '0')) if rank is None else int(rank)
+        self.world = int(os.environ.get('WORLD_SIZE', '1')) if world is None else int(world)
+        self.timeout = timeout
+        self.peers = {}
+        self.sock = None
+        self.path = None
+        if self.world == 1:
+            return
+        if job is None:
+            job = os.environ.get('IMPDAR_RDV_JOB') or '%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getppid())
+        self.path = os.path.join(tempfile.gettempdir(), 'impdar_rdv_%s' % job)
+        token = 'impdar-rdv %s world=%d' % (job, self.world)
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind(('127.0.0.1', 0))
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            tmp = self.path + '.%d' % os.getpid()
+            with open(tmp, 'w') as fo:
+                fo.write('%d\n' % srv.getsockname()[1])
+            os.replace(tmp, self.path)
+            try:
+                while len(self.peers) < self.world - 1:
+                    c, _ = srv.accept()
+                    c.settimeout(timeout)
+                    hello = _recv_msg(c)
+                    if hello.get('token') != token or hello.get('rank') in self.peers:
+                        c.close()
+                        continue
+                    c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    self.peers[hello['rank']] = c
+                for c in self.peers.values():
+                    _send_msg(c, 'go')
+            finally:
+                srv.close()
+                try:
+                    os.unlink(self.path)
+                except OSError:
+                    pass
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    port = int(open(self.path).read().split()[0])
+                    c = socket.create_connection(('127.0.0.1', port), timeout=5.0)
+                    c.settimeout(timeout)
+                    c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    _send_msg(c, dict(token=token, rank=self.rank))
+                    if _recv_msg(c) == 'go':
+                        self.sock = c
+                        break
+                    c.close()
+                except (OSError, ValueError, IndexError, ConnectionError, EOFError):
+                    pass                    # no file yet, a stale file of an earlier job, or a refused token
+                if time.time() > deadline:
+                    raise TimeoutError('rank %d found no rendezvous at %s within %.0f s' % (self.rank, self.path, timeout))
+                time.sleep(0.05)
+
+    # every collective is a gather to rank 0 followed by a broadcast of the reduced value
+    def _collect(self, value, reduce_fn):
+        if self.world == 1:
+            return reduce_fn([value])
+        if self.rank == 0:
+            vals = [None] * self.world
+            vals[0] = value
+            for r, c in self.peers.items():
+                vals[r] = _recv_msg(c)
+            out = reduce_fn(vals)
+            for c in self.peers.values():
+                _send_msg(c, out)
+            return out
+        _send_msg(self.sock, value)
+        return _recv_msg(self.sock)
+
+    def broadcast(self, value, root=0):
+        return self._collect(value, lambda vals: vals[root])
+
+    def barrier(self):
+        self._collect(None, lambda vals: None)
+
+    def allreduce_max(self, x):
+        return self._collect(float(x), max)
+
+    def allgather(self, obj):
+        return self._collect(obj, list)
+
+    def close(self):
+        for c in list(self.peers.values()) + ([self.sock] if self.sock else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+        self.peers, self.sock = {}, None
+
+
+def init_communicator(ctx, rdv):
+    """RCCL communicator of the job on ``ctx``: rank 0's unique id travels over the rendezvous."""
+    import ctypes as C
+    from . import _hip
+    lib = _hip.load()
+    _hip.require_system_rccl()
+    ident = None
+    if rdv.rank == 0:
+        buf = C.create_string_buffer(_hip.UNIQUE_ID_BYTES)
+        _hip.check(lib.impdar_comm_unique_id(buf), 'impdar_comm_unique_id')
+        ident = bytes(buf.raw)
+    ident = rdv.broadcast(ident, 0)
+    _hip.check(lib.impdar_comm_init(ctx, ident, rdv.rank, rdv.world), 'impdar_comm_init')
+
+
+# ---------------------------------------------------------------------------------------------------------
+# one rank's share of one radargram
+# ---------------------------------------------------------------------------------------------------------
+class ShardedKirchhoff(object):
+    """One rank's plan for migrating radargrams of a fixed geometry on ``world`` GPUs: partition, exchange
+    schedule, the device plan and buffers.  ``step()`` enqueues prep -> exchange -> diffraction sum for the
+    rank's resident input shard; consecutive steps pipeline (the C plan double-buffers)."""
+
+    def __init__(self, ctx, snum, tnum, dist_km, travel_time_us, vel, rank, world, dtype=np.float32,
+                 nearfield=False, mode='auto', exchange='auto', engine=None):
+        self.rank, self.world = int(rank), int(world)
+        self.snum, self.tnum, self.dtype = int(snum), int(tnum), np.dtype(dtype)
+        tt_sec = np.asarray(travel_time_us, dtype=np.float64) / 1.0e6
+        dist_m = np.asarray(dist_km, dtype=np.float64) * 1.0e3
+        dx = float((dist_m[-1] - dist_m[0]) / (tnum - 1)) if tnum > 1 else 1.0
+        uniform_x = tnum < 2 or (dx > 0 and np.allclose(np.diff(dist_m), dx, rtol=1e-9, atol=0))
+        if uniform_x:
+            self.tnum_pad, self.shards, self.blocks, self.pairs = plan_blocks(tt_sec, dx, vel, tnum, world)
+            halo = halo_traces(tt_sec, dx, vel)
+        else:
+            # irregular spacing: equal-width output blocks, whole-image exchange
+            self.tnum_pad, self.shards = input_shards(tnum, world)
+            e = [tnum * r // world for r in range(world + 1)]
+            self.blocks = [(e[r], e[r + 1]) for r in range(world)]
+            self.pairs = [None] * world
+            halo = tnum
+        self.xplan = plan_exchange(self.blocks, self.tnum_pad, world, halo)
+        if exchange in ('halo', 'allgather'):
+            self.xplan['mode'] = exchange if world > 1 else 'allgather'
+        self.jlo, self.jhi = self.shards[self.rank]
+        self.xlo, self.xhi = self.blocks[self.rank]
+        self.engine = engine if engine is not None else HipEngine(ctx)
+        self.engine.setup(self, dist_km, travel_time_us, vel, nearfield, mode)
+
+    @property
+    def nloc(self):
+        return self.jhi - self.jlo
+
+    def step(self, d_in, d_out, multi=None):
+        multi = self.world > 1 if multi is None else multi
+        self.engine.prep(d_in, max(self.nloc, 1), self.jlo, self.nloc)
+        if multi:
+            if self.xplan['mode'] == 'halo':
+                self.engine.exchange(self.xplan['send'][self.rank], self.xplan['recv'][self.rank])
+            else:
+                self.engine.allgather()
+        self.engine.migrate(d_out, self.xlo, self.xhi)
+
+
+class HipEngine(object):
+    """The device side of ``ShardedKirchhoff``: ``impdar_kirch_*`` of the C ABI (RCCL inside the library)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.plan = None
+
+    def setup(self, sk, dist_km, travel_time_us, vel, nearfield, mode):
+        from .kirchhoff import KirchhoffPlan
+        self.plan = KirchhoffPlan(self.ctx, sk.dtype, sk.snum, sk.tnum, dist_km, travel_time_us, vel, nearfield,
+                                  mode, nranks=sk.world)
+        assert self.plan.tnum_pad == sk.tnum_pad, (self.plan.tnum_pad, sk.tnum_pad)
+
+    def prep(self, d_in, ld, jlo, nloc):
+        self.plan.prep(d_in, ld, jlo, nloc)
+
+    def allgather(self):
+        self.plan.allgather()
+
+    def exchange(self, send, recv):
+        self.plan.exchange(send, recv)
+
+    def migrate(self, d_out, xlo, xhi):
+        self.plan.migrate(d_out, xlo, xhi)
+
+
+def migrate_kirchhoff_sharded(local_data, geometry, vel=1.69e8, nearfield=False, mode='auto', rdv=None, ctx=None,
+                              exchange='auto', engine=None):
+    """Collective: every rank of the job calls this with ITS input shard ``local_data`` =
+    ``data[:, jlo:jhi]`` (``parallel.input_shards``) of a (snum, tnum) radargram and gets back
+    ``(xlo, xhi, block)``: the migrated output traces it owns, in ``local_data``'s dtype.
+
+    ``geometry``: dict(snum, tnum, dist [km], travel_time [us]).  ``rdv``: the job's ``Rendezvous`` (made from the
+    environment when None).  Reference semantics per block: mig_python.py:63-123."""
+    from . import _hip
+    own_rdv = rdv is None
+    rdv = Rendezvous() if rdv is None else rdv
+    if engine is None:
+        _hip.load()
+        ctx = _hip.context() if ctx is None else ctx
+        if rdv.world > 1 and not _hip.load().impdar_comm_size(ctx) == rdv.world:
+            init_communicator(ctx, rdv)
+    snum, tnum = int(geometry['snum']), int(geometry['tnum'])
+    local_data = np.ascontiguousarray(local_data)
+    sk = ShardedKirchhoff(ctx, snum, tnum, geometry['dist'], geometry['travel_time'], vel, rdv.rank, rdv.world,
+                          local_data.dtype, nearfield, mode, exchange, engine)
+    if local_data.shape != (snum, sk.nloc):
+        raise ValueError('rank %d owns input traces [%d, %d): expected a (%d, %d) shard, got %s'
+                         % (rdv.rank, sk.jlo, sk.jhi, snum, sk.nloc, local_data.shape))
+    block = sk.engine.run_once(sk, local_data)
+    rdv.barrier()
+    if own_rdv:
+        rdv.close()
+    return sk.xlo, sk.xhi, block
+
+
+def _hip_run_once(self, sk, local_data):
+    from . import _hip
+    d_in = _hip.DeviceArray.from_host(self.ctx, local_data if sk.nloc else np.zeros((sk.snum, 1), local_data.dtype))
+    d_out = _hip.DeviceArray(self.ctx, (sk.snum, max(sk.xhi - sk.xlo, 1)), sk.dtype)
+    try:
+        sk.step(d_in, d_out)
+        self.plan.sync()
+        out = d_out.to_host()[:, :sk.xhi - sk.xlo]
+    finally:
+        self.plan.destroy()
+        d_in.free()
+        d_out.free()
+    return out
+
+
+HipEngine.run_once = _hip_run_once
+
+
+# ---------------------------------------------------------------------------------------------------------
+# single-process front door: one worker per GPU
+# ---------------------------------------------------------------------------------------------------------
+def ngpus_requested():
+    """``$IMPDAR_NGPUS`` (0 / unset: the ordinary one-GPU path)."""
+    try:
+        return max(int(os.environ.get('IMPDAR_NGPUS', '0')), 0)
+    except ValueError:
+        return 0
+
+
+def spawn_ranks(argv, world, env_extra=None, timeout=None):
+    """Start ``world`` copies of ``argv`` (one per GPU: RANK / LOCAL_RANK / WORLD_SIZE set, a job name for the
+    rendezvous) and wait.  The parent must not have touched the GPU.  Returns the list of return codes."""
+    job = 'spawn_%d_%d' % (os.getpid(), int(time.time() * 1e3) % 1000000)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), IMPDAR_RDV_JOB=job)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen(argv, env=env))
+    codes = []
+    deadline = None if timeout is None else time.time() + timeout
+    for p in procs:
+        try:
+            codes.append(p.wait(None if deadline is None else max(deadline - time.time(), 0.1)))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            codes.append(p.wait())
+    return codes
+
+
+def run_sharded(data, dist_km, travel_time_us, vel=1.69e8, nearfield=False, ngpus=2, mode='auto'):
+    """Migrate a host radargram on ``ngpus`` GPUs from a single process: the radargram and the result live in
+    /dev/shm, one worker process per GPU (``impdar_amd._shard_worker``) runs ``migrate_kirchhoff_sharded`` on its
+    shard.  Returns the float64 migrated array like migrationKirchhoff (mig_python.py:118)."""
+    data = np.ascontiguousarray(data)
+    if data.dtype not in (np.float32, np.float64):
+        data = data.astype(np.float64)
+    snum, tnum = data.shape
+    shm = '/dev/shm' if os.path.isdir('/dev/shm') else tempfile.gettempdir()
+    base = os.path.join(shm, 'impdar_shard_%d_%d' % (os.getpid(), int(time.time() * 1e6) % 10 ** 9))
+    f_in, f_out, f_meta = base + '_in.npy', base + '_out.npy', base + '_meta.pkl'
+    try:
+        np.save(f_in, data)
+        out = np.lib.format.open_memmap(f_out, mode='w+', dtype=np.float64, shape=(snum, tnum))
+        del out
+        with open(f_meta, 'wb') as fo:
+            pickle.dump(dict(snum=snum, tnum=tnum, dist=np.asarray(dist_km, dtype=np.float64),
+                             travel_time=np.asarray(travel_time_us, dtype=np.float64), vel=float(vel),
+                             nearfield=bool(nearfield), mode=mode, f_in=f_in, f_out=f_out), fo)
+        codes = spawn_ranks([sys.executable, '-m', 'impdar_amd._shard_worker', f_meta], ngpus)
+        if any(codes):
+            raise RuntimeError('sharded Kirchhoff migration failed: worker exit codes %s' % codes)
+        return np.array(np.load(f_out, mmap_mode='r'))
+    finally:
+        for f in (f_in, f_out, f_meta):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
 
 
 def exchange_host(local_image, rank, nranks, per):

@@ -22,12 +22,14 @@ def geometry(snum, tnum, dt=1.0e-8, dx=1.0, t0_us=0.0):
 
 def diffractor_radargram(snum, tnum, vel=1.69e8, dt=1.0e-8, dx=1.0, fc=5.0e6,
                          ndiff=64, dtype=np.float64, t0_us=0.0, trace_lo=0,
-                         trace_hi=None, chunk=512):
+                         trace_hi=None, chunk=512, threads=1):
     """``ndiff`` point diffractors imaged with a Ricker wavelet of centre
     frequency ``fc``: data[k, j] = sum_m A_m ricker(t_k - 2 r_mj / vel).
 
     ``trace_lo:trace_hi`` selects a column block of the full ``tnum``-trace
     radargram (used by multi-GPU ranks to build only their own shard).
+    ``threads`` > 1 builds column chunks on a thread pool (NumPy releases the
+    GIL inside the ufuncs); the values do not depend on it.
     """
     if trace_hi is None:
         trace_hi = tnum
@@ -39,7 +41,7 @@ def diffractor_radargram(snum, tnum, vel=1.69e8, dt=1.0e-8, dx=1.0, fc=5.0e6,
     zm = (0.05 + 0.9 * np.mod(m * _SQ2, 1.0)) * R
     out = np.empty((snum, trace_hi - trace_lo), dtype=dtype)
     a = (np.pi * fc) ** 2
-    for c0 in range(trace_lo, trace_hi, chunk):
+    def build(c0):
         c1 = min(c0 + chunk, trace_hi)
         xj = np.arange(c0, c1) * dx
         acc = np.zeros((snum, c1 - c0), dtype=np.float64)
@@ -50,6 +52,15 @@ def diffractor_radargram(snum, tnum, vel=1.69e8, dt=1.0e-8, dx=1.0, fc=5.0e6,
             au2 = a * u * u
             acc += amp[None, :] * (1.0 - 2.0 * au2) * np.exp(-au2)
         out[:, c0 - trace_lo:c1 - trace_lo] = acc.astype(dtype)
+
+    starts = list(range(trace_lo, trace_hi, chunk))
+    if threads > 1 and len(starts) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(threads, len(starts))) as pool:
+            list(pool.map(build, starts))
+    else:
+        for c0 in starts:
+            build(c0)
     return out
 
 

@@ -16,8 +16,10 @@
  *
  * Conventions: plain pointers and sizes only.  All host buffers are
  * caller-owned, C-contiguous, row-major; radargrams have shape (snum, tnum)
- * (a row is one time sample across all traces).  Every call is blocking
- * unless documented otherwise, returns 0 on success or a negative
+ * (a row is one time sample across all traces).  Calls that take HOST buffers
+ * are blocking.  Calls that take DEVICE pointers (the *_dev forms, impdar_dev_memset and the
+ * impdar_kirch_prep / _allgather / _exchange / _migrate family) only enqueue work: they are ordered
+ * among themselves on the device, and impdar_ctx_sync / any download waits for them.  Every call returns 0 on success or a negative
  * impdar_status, never throws or exits.  impdar_last_error() returns a
  * thread-local message for the last failing call.
  */
@@ -60,6 +62,9 @@ int impdar_device_count(void);
 int impdar_ctx_create(int device, impdar_ctx **out);
 void impdar_ctx_destroy(impdar_ctx *ctx);
 int impdar_ctx_sync(impdar_ctx *ctx);
+/* device-side duration (HIP events on the compute stream, ms) of the kernels of the last impdar_stolt[_dev] /
+ * impdar_phaseshift[_dev] call on this context; blocks until they have completed */
+int impdar_ctx_last_ms(impdar_ctx *ctx, float *ms);
 /* raw device-memory plumbing for resident data (bench, multi-GPU) */
 int impdar_dev_alloc(impdar_ctx *ctx, size_t bytes, void **dptr);
 int impdar_dev_free(impdar_ctx *ctx, void *dptr);
@@ -106,11 +111,13 @@ int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, int snum, int
  *              (equal blocks of tnum_pad/nranks traces per rank)
  *   migrate  : diffraction sum for output traces [xlo,xhi) into d_out
  *              (snum x (xhi-xlo), row-major, element type = plan dtype)
- * All three are asynchronous; call impdar_ctx_sync to wait.  prep and allgather run on
+ * All of them are asynchronous; call impdar_ctx_sync to wait.  prep and allgather run on
  * the context's producer stream into one of two buffer sets, migrate on its compute stream,
  * so the prep/all-gather of the next radargram overlap the diffraction sum of the current
- * one; the first prep after a migrate starts a new radargram (switches buffer set).  d_data
- * must be complete when prep is called (impdar_dev_upload is blocking). */
+ * one; the first prep after a migrate starts a new radargram (switches buffer set).  prep waits
+ * (on the device) for whatever the *_dev entry points and impdar_dev_memset have enqueued on the
+ * compute stream before it, so a resident chain filter -> prep needs no host synchronisation;
+ * impdar_dev_upload is blocking. */
 int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, int tnum,
                              const double *dist_m, const double *tt_sec, double vel,
                              int nearfield, int grad_uniform, double grad_h,
@@ -121,6 +128,12 @@ int impdar_kirch_plan_mode(const impdar_kirch_plan *plan);      /* resolved mode
 int impdar_kirch_plan_tnum_pad(const impdar_kirch_plan *plan);
 int impdar_kirch_prep(impdar_kirch_plan *plan, const void *d_data, int ld, int jlo, int nloc);
 int impdar_kirch_allgather(impdar_kirch_plan *plan);
+/* Halo form of the exchange ("grouped ncclSend/ncclRecv of halos when H < shard"): this rank sends
+ * image rows [slo[i], shi[i]) to rank speer[i] and receives rows [rlo[i], rhi[i]) from rank rpeer[i], all in one
+ * RCCL group on the producer stream.  Ranges are whole 8-trace groups (multiples of 8 inside [0, tnum_pad)).
+ * impdar_amd/parallel.py (plan_exchange) derives them from the output blocks and the aperture half width. */
+int impdar_kirch_exchange(impdar_kirch_plan *plan, int nsend, const int *speer, const int *slo, const int *shi,
+                          int nrecv, const int *rpeer, const int *rlo, const int *rhi);
 int impdar_kirch_migrate(impdar_kirch_plan *plan, void *d_out, int xlo, int xhi);
 /* HIP-event durations (ms) of the last prep / allgather / migrate enqueued on
  * the plan's stream; blocks until they have completed. */

@@ -34,6 +34,26 @@ def threads():
     return int(_load().kirch_oracle_threads())
 
 
+def kirchhoff_from_gradient(grad, data, travel_time_us, dist_km, vel=1.69e8, nearfield=False, traces=None):
+    """The diffraction sum alone (mig_python.py:35-60) on a given time-gradient array ``grad`` (snum, tnum)
+    (and ``data`` for the near-field term): what a rank of the sharded migration runs on its exchanged image."""
+    lib = _load()
+    grad = np.ascontiguousarray(grad, dtype=np.float64)
+    snum, tnum = grad.shape
+    d64 = np.ascontiguousarray(data if data is not None else grad, dtype=np.float64)
+    tt = np.ascontiguousarray(np.asarray(travel_time_us) / 1.0e6, dtype=np.float64)
+    dist = np.ascontiguousarray(dist_km, dtype=np.float64) * 1.0e3
+    if traces is None:
+        traces = np.arange(tnum)
+    traces = np.ascontiguousarray(traces, dtype=np.int32)
+    out = np.zeros((snum, len(traces)), dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    lib.kirch_oracle(grad.ctypes.data_as(dp), d64.ctypes.data_as(dp), snum, tnum, dist.ctypes.data_as(dp),
+                     tt.ctypes.data_as(dp), float(vel), int(bool(nearfield)),
+                     traces.ctypes.data_as(C.POINTER(C.c_int)), len(traces), out.ctypes.data_as(dp))
+    return out
+
+
 def kirchhoff(data, travel_time_us, dist_km, vel=1.69e8, nearfield=False, traces=None):
     """Same contract as mig_oracle.kirchhoff but returns only the requested
     output traces: array (snum, len(traces))."""

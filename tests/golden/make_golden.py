@@ -239,8 +239,48 @@ def cspace_case(name, snum, tnum, dtype, spacing, min_movement, seed, stationary
          tnum_out=d.tnum, interp_flag=np.asarray(d.flags.interp, dtype=float), **attrs_in, **attrs_out)
 
 
+def mat_cases():
+    """`.mat` files written by the REFERENCE's RadarData.save() (_RadarDataSaving.py:32-78): a float64 and an
+    int16 radargram with a migration recorded in the flags, the first straight from a constructed object (no
+    `picks` key), the second after a load -> save round trip through the reference's loader
+    (RadarData/__init__.py:207-244), which adds the empty `picks` struct every re-saved file carries.  The files
+    are data (arrays + struct layout), generated here and committed."""
+    from impdar.lib.RadarData import RadarData as RefRadarData
+    import tempfile
+    for name, dtype in (('M1_ref_saved_f64', np.float64), ('M2_ref_resaved_int16', np.int16)):
+        if ONLY is not None and not any(name.startswith(p) for p in ONLY):
+            continue
+        snum, tnum = 24, 18
+        geo = synth.geometry(snum, tnum, dx=1.5)
+        data = synth.diffractor_radargram(snum, tnum, ndiff=3, dx=1.5)
+        data = np.round(data * 1000).astype(dtype) if np.issubdtype(dtype, np.integer) else data.astype(dtype)
+        d = make_dat(data, geo)
+        d.trace_int = np.array(geo['trace_int'])
+        d.chan = 1
+        d.trig_level = 0.
+        d.lat, d.long = np.arange(tnum) * 2., np.arange(tnum) * 3.
+        d.decday, d.trace_num = np.arange(tnum).astype(float), np.arange(tnum) + 1.
+        d.trig, d.pressure = np.zeros(tnum), np.zeros(tnum)
+        d.x_coord = np.arange(tnum) * 1.5
+        d.y_coord = np.zeros(tnum)
+        d.elev = 100. + 0.01 * np.arange(tnum)
+        d.data_dtype = data.dtype
+        d.flags.mig = 'kirch'
+        d.flags.bpass = np.array([1., 2., 10.])
+        path = os.path.join(HERE, name + '.mat')
+        if name.startswith('M2'):
+            with tempfile.TemporaryDirectory() as td:
+                first = os.path.join(td, 'first.mat')
+                d.save(first)
+                quiet(RefRadarData(first).save, path)
+        else:
+            d.save(path)
+        print('wrote', path, os.path.getsize(path), 'bytes')
+
+
 def main():
     slow = '--skip-slow' not in sys.argv
+    mat_cases()
     # ---- Kirchhoff -------------------------------------------------------
     kirch_case('K1_kirch_farfield_ricker', 128, 64, 1e-8, 1.0, 1.69e8, False)
     kirch_case('K1n_kirch_farfield_noise', 128, 64, 1e-8, 1.0, 1.69e8, False, kind='noise')

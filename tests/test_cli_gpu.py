@@ -108,3 +108,32 @@ def test_impdar_proc_resident_chain_on_mat_file(hip, tmp_path):
     assert r.flags.mig == 'stolt' and r.data.shape == want.shape
     assert rel_max(r.data, want) < 1e-9
     assert getattr(r, '_dev', None) is None
+
+
+def test_interp_then_migrate_on_a_file_the_reference_resaved(hip, tmp_path):
+    """`impproc interp` + `impproc migrate` on tests/golden/M2_ref_resaved_int16.mat: written by the reference's
+    save() after a load, so it carries the empty `picks` struct every processed file has (the interp step once
+    refused all of those).  The picks struct must survive into the output file."""
+    import shutil
+    from scipy.io import loadmat
+    from conftest import GOLDEN
+    from impdar_amd.bin import impproc
+    from impdar_amd.lib.RadarData import RadarData
+    from oracle import mig_oracle as o, preproc_oracle as po
+    fn = str(tmp_path / 'ref_raw.mat')
+    shutil.copy(os.path.join(GOLDEN, 'M2_ref_resaved_int16.mat'), fn)
+    src = RadarData(fn)
+    with patch.object(sys, 'argv', ['impproc', 'interp', '3.0', fn]):
+        impproc.main()
+    mid = str(tmp_path / 'ref_interp.mat')
+    r = RadarData(mid)
+    want = po.constant_space(src.data, src.dist, 3.0)[0]
+    assert r.tnum == want.shape[1] and r.data.dtype == np.int16           # cast back to the file's dtype
+    assert np.array_equal(r.data, want.astype(np.int16))
+    assert 'picks' in loadmat(mid) and r.flags.interp[0] == 1 and r.flags.interp[1] == 3.0
+    with patch.object(sys, 'argv', ['impproc', 'migrate', '--mtype', 'kirch', mid]):
+        impproc.main()
+    out = RadarData(str(tmp_path / 'ref_interp_migrated.mat'))
+    ref = o.kirchhoff(r.data, r.travel_time, r.dist, 1.69e8)
+    assert out.flags.mig == 'kirch' and out.data.dtype == np.int16
+    assert np.array_equal(out.data, ref.astype(np.int16)) or rel_max(out.data, ref.astype(np.int16)) < 1e-3

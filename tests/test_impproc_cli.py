@@ -8,6 +8,7 @@ from unittest.mock import MagicMock, patch
 import numpy as np
 import pytest
 
+from conftest import GOLDEN
 from impdar_amd.bin import impproc
 from impdar_amd.lib.NoInitRadarData import NoInitRadarData
 from impdar_amd.lib.RadarData import RadarData
@@ -183,3 +184,71 @@ def test_impdarexec_proc_migrate(tmp_path):
         impdarexec.main()
     dat.migrate.assert_called_with(mtype='stolt')
     dat.save.assert_called_with(str(tmp_path / 'line_proc.mat'))
+
+
+# ---- .mat interop pinned to files the REFERENCE wrote (tests/golden/M*.mat, generated by make_golden.py from the
+# reference's RadarData.save(), _RadarDataSaving.py:32-78; loader RadarData/__init__.py:207-244, flags
+# RadarFlags.py:64-98)
+def _mat_keys(path):
+    from scipy.io import loadmat
+    m = loadmat(path)
+    return {k: v for k, v in m.items() if not k.startswith('__')}
+
+
+@pytest.mark.parametrize('name,dtype,has_picks', [('M1_ref_saved_f64', np.float64, False),
+                                                  ('M2_ref_resaved_int16', np.int16, True)])
+def test_loads_files_written_by_the_reference(name, dtype, has_picks, tmp_path):
+    from impdar_amd import synth
+    src = os.path.join(GOLDEN, name + '.mat')
+    r = RadarData(src)
+    snum, tnum = 24, 18
+    geo = synth.geometry(snum, tnum, dx=1.5)
+    data = synth.diffractor_radargram(snum, tnum, ndiff=3, dx=1.5)
+    data = np.round(data * 1000).astype(dtype) if np.issubdtype(dtype, np.integer) else data.astype(dtype)
+    assert r.data.dtype == dtype and r.data_dtype == dtype and np.array_equal(r.data, data)
+    assert (r.snum, r.tnum) == (snum, tnum) and r.dt == geo['dt'] and r.chan == 1 and r.trig_level == 0
+    for attr, want in (('travel_time', geo['travel_time']), ('dist', geo['dist']), ('trace_int', geo['trace_int']),
+                       ('lat', np.arange(tnum) * 2.), ('long', np.arange(tnum) * 3.),
+                       ('x_coord', np.arange(tnum) * 1.5), ('y_coord', None), ('elev', 100. + 0.01 * np.arange(tnum)),
+                       ('decday', np.arange(tnum, dtype=float)), ('trace_num', np.arange(tnum) + 1.),
+                       ('trig', None), ('pressure', None)):
+        got = getattr(r, attr)
+        if want is None:
+            # all-zero vectors are vectors in the file; check_attrs keeps them (only a SCALAR 0 means None)
+            assert got is not None and np.array_equal(got, np.zeros(tnum))
+        else:
+            assert np.array_equal(got, want), attr
+    assert r.flags.mig == 'kirch' and np.array_equal(r.flags.bpass, [1., 2., 10.])
+    assert not r.flags.batch and not r.flags.reverse and r.flags.crop.shape == (3,)
+    assert (r._picks_struct is not None) == has_picks
+    # written back by this repo: same keys, same dtypes and shapes as the reference's file
+    out = str(tmp_path / 'again.mat')
+    r.save(out)
+    a, b = _mat_keys(src), _mat_keys(out)
+    assert sorted(a) == sorted(b)
+    for k in a:
+        if k == 'fn':               # the path the object was loaded from (the reference's loader sets it too)
+            continue
+        assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape, k
+        if a[k].dtype.names is None and a[k].dtype != object:
+            assert np.array_equal(a[k], b[k]), k
+    assert a['flags'].dtype.names == b['flags'].dtype.names
+    for f in a['flags'].dtype.names:
+        assert np.array_equal(a['flags'][f][0][0], b['flags'][f][0][0]), f
+    if has_picks:
+        assert a['picks'].dtype.names == b['picks'].dtype.names
+
+
+def test_constant_space_accepts_the_empty_picks_struct_of_resaved_files(tmp_path):
+    """Every file the reference loaded and saved again carries an (empty) picks struct; interp must not refuse
+    it, and it must still be in the file written afterwards.  Real picks stay refused."""
+    from impdar_amd.lib.RadarData._RadarDataProcessing import picks_struct_holds_picks
+    r = RadarData(os.path.join(GOLDEN, 'M2_ref_resaved_int16.mat'))
+    assert r._picks_struct is not None and not picks_struct_holds_picks(r._picks_struct)
+    picked = r._picks_struct.copy()
+    picked['samp1'][0][0] = np.arange(36.).reshape(2, 18)
+    assert picks_struct_holds_picks(picked)
+    r2 = RadarData(os.path.join(GOLDEN, 'M2_ref_resaved_int16.mat'))
+    r2._picks_struct = picked
+    with pytest.raises(NotImplementedError):
+        r2.constant_space(3.0)

@@ -278,3 +278,38 @@ def test_resident_kirchhoff_fast_mode_opt_in(hip, monkeypatch):
     want = c_oracle.kirchhoff(data, h.travel_time, h.dist, 1.69e8, False)
     err = np.linalg.norm(r.data - want) / np.linalg.norm(want)
     assert 1e-9 < err < 1e-4, err          # the float32 kernel's error, not the exact kernel's
+
+
+def test_plan_reused_after_a_device_filter_sees_the_filtered_radargram(hip):
+    """Streaming use of the C ABI: a Kirchhoff plan is re-used on a resident radargram
+    right after impdar_filtfilt_dev, with no host synchronisation in between.  prep runs on the producer stream
+    and must wait for the band pass enqueued on the compute stream (it once read a half-written radargram)."""
+    from impdar_amd import _hip, preproc, synth
+    from impdar_amd.kirchhoff import KirchhoffPlan
+    ctx = hip.context()
+    snum, tnum = 2048, 3000                       # the band pass takes long enough to lose a race
+    geo = synth.geometry(snum, tnum)
+    x = synth.noise_radargram(snum, tnum, seed=8).astype(np.float32)
+    spec = preproc.design_filter(geo['dt'], 2., 10.)
+    filtered = preproc.filter_host(x.copy(), spec)
+    plan = KirchhoffPlan(ctx, np.float32, snum, tnum, geo['dist'], geo['travel_time'], mode='fast')
+    d_in = _hip.DeviceArray.from_host(ctx, filtered)
+    d_ref = _hip.DeviceArray(ctx, (snum, tnum), np.float32)
+    plan.prep(d_in, tnum, 0, tnum)
+    plan.migrate(d_ref, 0, tnum)
+    plan.sync()
+    want = d_ref.to_host()
+    for _ in range(3):
+        d_x = _hip.DeviceArray.from_host(ctx, x)
+        d_out = _hip.DeviceArray(ctx, (snum, tnum), np.float32)
+        preproc.filter_dev(d_x, spec)             # enqueued only
+        plan.prep(d_x, tnum, 0, tnum)             # same plan, straight after
+        plan.migrate(d_out, 0, tnum)
+        plan.sync()
+        got = d_out.to_host()
+        d_x.free()
+        d_out.free()
+        assert np.array_equal(got, want)
+    plan.destroy()
+    d_in.free()
+    d_ref.free()
