@@ -45,9 +45,10 @@ struct PrepParams {
     int precomputed;        // data already holds the gradient (mig_kirch_loop)
     double grad_h;
     const double *ga, *gb, *gc;
-    int clean;              // map non-finite values to 0 (fast kernel contract)
-    int i8;                 // image layout: 0 trace-major [row][k]; 1 groups of 8 rows, sample-major
-                            // inside a group: element (row, k) at ((row >> 3) * snum + k) * 8 + (row & 7)
+    int clean;              // 1: map non-finite values to 0 (fp32 ring kernels); 2: NaN only (fp64 ring kernel)
+    int i8;                 // image layout: 0 trace-major [row][k]; 1 groups of 8 rows (4 for float64: 32 bytes per
+                            // sample either way), sample-major inside a group: element (row, k) at
+                            // ((row / G) * snum + k) * G + (row % G)
 };
 
 template <typename TI, typename TO>
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void kirch_prep_kernel(PrepParams P)
                 }
             }
             if (sizeof(TI) == 4 && !P.precomputed) g = (double)(float)g;  // numpy keeps f32 gradients in f32
-            if (P.clean) {
+            if (P.clean == 1) {
                 if (!(fabs(g) <= 1.79e308)) g = 0.0;
                 if (!(fabs(d) <= 1.79e308)) d = 0.0;
             }
@@ -129,9 +130,10 @@ __global__ __launch_bounds__(256) void kirch_prep_kernel(PrepParams P)
 // runs on the CUs' spare wave slots underneath it: 8.58 -> 8.30 ms per step at config 3, and the
 // difference between a working and a counter-productive overlap for the short kernels of an 8-rank run.
 // One thread per (sample k, trace j): reads are coalesced along j, writes are 32-byte runs per group.
+template <typename T, int GRP>
 __global__ __launch_bounds__(256) void kirch_prep_direct_kernel(PrepParams P)
 {
-    const float *f = reinterpret_cast<const float *>(P.data);
+    const T *f = reinterpret_cast<const T *>(P.data);
     const int j = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
     const int n = P.snum;
     if (j >= P.nloc) return;
@@ -153,15 +155,18 @@ __global__ __launch_bounds__(256) void kirch_prep_direct_kernel(PrepParams P)
         else
             g = (P.ga[k] * fm + P.gb[k] * d) + P.gc[k] * fp;
     }
-    if (!P.precomputed) g = (double)(float)g;                  // numpy keeps f32 gradients in f32
-    if (P.clean) {
+    if (sizeof(T) == 4 && !P.precomputed) g = (double)(float)g;                  // numpy keeps f32 gradients in f32
+    if (P.clean == 1) {                                        // fp32 ring kernels: every non-finite value
         if (!(fabs(g) <= 1.79e308)) g = 0.0;
         if (!(fabs(d) <= 1.79e308)) d = 0.0;
+    } else if (P.clean == 2) {                                 // fp64 ring kernel: NaN terms are what nansum skips
+        if (g != g) g = 0.0;                                   // (mig_python.py:53); infinities stay and propagate
+        if (d != d) d = 0.0;
     }
     const int row = P.jlo + j;
-    const size_t o = ((size_t)(row >> 3) * n + k) * 8 + (row & 7);
-    reinterpret_cast<float *>(P.GT)[o] = (float)g;
-    if (P.DT) reinterpret_cast<float *>(P.DT)[o] = (float)d;
+    const size_t o = ((size_t)(row / GRP) * n + k) * GRP + (row % GRP);
+    reinterpret_cast<T *>(P.GT)[o] = (T)g;
+    if (P.DT) reinterpret_cast<T *>(P.DT)[o] = (T)d;
 }
 
 // ===========================================================================
@@ -356,6 +361,7 @@ struct FastParams {
     // quad kernel: cos(theta) = sign(a) * rsq(1 + c1 n^2) with a = tt/dt, c1 = alpha / a^2; the far-field sum is
     // scaled by fin = sign(a) / (2 pi v) once at the end, the near-field weight is c2 * cos^3 in those units
     const float *c1, *c2, *fin;    // per sample [snum]
+    const double *c1d, *c2d, *find;   // the same in float64 (dquad kernel): c1 = (dx/zs)^2, fin = 1/(2 pi v), c2: see kirch_dquad_kernel
     // quad kernel, step-block tables.  Every workgroup walks the trace offset n in blocks of 8 steps
     // n = 8 m + 1 .. 8 m + 8 (tiles start at multiples of 8, so the alignment is the same for all);
     // table row = m + mrow0:
@@ -434,6 +440,14 @@ struct TableQParams {
     int ps;                         // bytes per 32-row piece of the LDS image (kq_piece_bytes)
 };
 
+// Row stride of the step-block pick table in 16-byte entries.  Not snum: with snum a power of two a chunk's
+// slice of consecutive rows (256 entries out of every snum) lands on 1/16 of the L2's sets (and of whatever else
+// indexes by address bits); the odd number of 256-byte lines of padding walks the slice over all of them.
+#ifndef KQ_TKB_PAD
+#define KQ_TKB_PAD 272       // entries (4352 bytes)
+#endif
+__host__ __device__ static inline size_t kq_tkb_stride(int snum) { return (size_t)snum + KQ_TKB_PAD; }
+
 // byte offset of half 0 of ring row r in the quad kernel's LDS image (layout: see kirch_quad_kernel)
 __host__ __device__ static inline unsigned kq_row_offset(int r, int ps)
 {
@@ -481,10 +495,10 @@ __global__ __launch_bounds__(256) void kirch_tableq_kernel(TableQParams P)
     }
     const int rp = a + P.mrow0, rn = P.mrow0 - a - 1;
     if (rp < P.nrows)
-        P.TKB[(size_t)rp * P.snum + ti] =
+        P.TKB[(size_t)rp * kq_tkb_stride(P.snum) + ti] =
             make_uint4(pk[1] | (pk[2] << 16), pk[3] | (pk[4] << 16), pk[5] | (pk[6] << 16), pk[7] | (pk[8] << 16));
     if (rn >= 0)
-        P.TKB[(size_t)rn * P.snum + ti] =
+        P.TKB[(size_t)rn * kq_tkb_stride(P.snum) + ti] =
             make_uint4(pk[7] | (pk[6] << 16), pk[5] | (pk[4] << 16), pk[3] | (pk[2] << 16), pk[1] | (pk[0] << 16));
 }
 
@@ -742,6 +756,11 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     // padding blocks of the last revolution can get there) are clamped to the last, all-dropped row
     const int mrow = ((nlo - 1) >> 3) + P.mrow0;
     auto row_of = [&](int blk) { return min(mrow + blk, P.nrows - 1); };
+#ifdef KQ_DIAG_PICKHOT      // diagnostic build: every pick load hits the same 16 table rows (L2-hot); results invalid
+    auto prow_of = [&](int blk) { return (mrow + blk) & 15; };
+#else
+    auto prow_of = row_of;
+#endif
 
     // Staging window of the 8 traces block `blk_for` adds: one 8-byte lookup, issued ONE BLOCK EARLIER
     // than its use: s_waitcnt vmcnt counts in order, so waiting for a lookup issued in the same block
@@ -776,9 +795,9 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     const __amdgpu_buffer_rsrc_t tkres =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(P.TKB), 0, 0x7fffffff, 0x00020000);
     const unsigned tioff = (unsigned)ti * 16u;
-    const unsigned rowbytes = (unsigned)snum * 16u;
+    const unsigned rowbytes = (unsigned)kq_tkb_stride(snum) * 16u;
     auto picks = [&](int blk) -> kq_u4 {
-        return __builtin_amdgcn_raw_buffer_load_b128(tkres, tioff, (unsigned)row_of(blk) * rowbytes, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(tkres, tioff, (unsigned)prow_of(blk) * rowbytes, 0);
     };
 #define KQ_TK(q, s) (((q)[(s) >> 1] >> (16 * ((s) & 1))) & 0xffffu)
     const float c1 = P.c1[ti], c2 = NEAR ? P.c2[ti] : 0.f, fin = P.fin[ti];
@@ -792,7 +811,19 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds != 0u) __builtin_trap();
     for (int e = tid; e < (int)(img_bytes / 4) * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
     __syncthreads();
+    // Pick rows are requested TWO blocks ahead (KQ_PICK_AHEAD = 2): a row that misses the XCD's L2 (the table is
+    // 61 MB, a chunk's slice 3.8 MB) takes longer than one block (~1.3 us) to arrive, and with one block of
+    // lookahead that latency sat in front of every barrier (a build whose pick rows were always L2-hot ran
+    // 0.74 ms faster at config 3).  The wait in front of the barrier then leaves the two youngest loads (the
+    // pick row and the staging window issued at the top of the block) in flight: s_waitcnt vmcnt counts in
+    // order, so vmcnt(2) still retires the staging DMA issued behind the previous barrier.
+#ifndef KQ_PICK_AHEAD
+#define KQ_PICK_AHEAD 2
+#endif
     kq_u4 tkc = picks(0);                          // picks of the current block
+#if KQ_PICK_AHEAD == 2
+    kq_u4 tkn = picks(1);                          // ... and of the next one
+#endif
 
     // accumulators in quads: the ordering pin below takes them as XB/4 operands of ONE asm statement
     kq_f4 acc4[XB / 4];
@@ -824,11 +855,19 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     auto dma_issue = [&](int blk_for, int wa) {     // traces that block `blk_for` adds to the ring
         const int kmin = wa & 0xffff, kmod = (int)((unsigned)wa >> 16);
         const int gidx = ((blk_for + G0) % NB + NB) % NB;      // ring group of these traces
+#ifdef KQ_DIAG_STAGEHOT     // diagnostic build: the staging DMA re-reads the same 8 image groups (L2-hot)
+        const unsigned so = (unsigned)((blk_for + G0) & 7) * grp_bytes;
+#else
         const unsigned so = (unsigned)(blk_for + G0) * grp_bytes;     // image group of trace jbase + q0
+#endif
         for (int pc = wv; pc < npieces; pc += 4) {
             int t = pc * 32 + rl - kmod;
             t += (t < 0) ? W : 0;
+#ifdef KQ_DIAG_STAGEONE     // diagnostic build: every DMA lane reads the same 32 bytes of its image group
+            const int c = 0;
+#else
             const int c = min(kmin + t, snum - 1);
+#endif
             const unsigned vo = (unsigned)c * 32u + hsel;
             dma16((unsigned)(pc * KQ_PS + gidx * KQ_GS), vo, gdesc, so);
             if (NEAR) dma16(img_bytes + (unsigned)(pc * KQ_PS + gidx * KQ_GS), vo, ddesc, so);
@@ -947,7 +986,9 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
             // held traces last read at step 6 of the previous block, and every wave is past that block's
             // barrier, which sits after step 6: no wave can still be reading them.
 #ifdef KQ_DIAG_NOPICK
-            const kq_u4 tkn = tkc;
+            const kq_u4 tkf = tkc;
+#elif KQ_PICK_AHEAD == 2
+            const kq_u4 tkf = picks(blk + 2);
 #else
             const kq_u4 tkn = picks(blk + 1);
 #endif
@@ -986,7 +1027,12 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
             // reads are issued below; each wave retires its own DMA (and the pick load) first.  The LDS
             // reads of step 7 stay in flight across the barrier, so the read pipeline never drains.
 #ifndef KQ_DIAG_NODMAWAIT
-            __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) only; a builtin so that hipcc's own wait counting sees it
+            // a builtin so that hipcc's own wait counting sees it
+#if KQ_PICK_AHEAD == 2 && !defined(KQ_DIAG_NOSTAGE) && !defined(KQ_DIAG_NOPICK)
+            __builtin_amdgcn_s_waitcnt(0x0F72);        // vmcnt(2): all but this block's pick row + window lookup
+#else
+            __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) only
+#endif
 #endif
 #ifndef KQ_DIAG_NOBAR
             asm volatile("s_barrier" ::: "memory");
@@ -1001,6 +1047,9 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
 #undef KQ_STEP
 #undef KQ_UNPACK
             tkc = tkn;
+#if KQ_PICK_AHEAD == 2 || defined(KQ_DIAG_NOPICK)
+            tkn = tkf;
+#endif
         }
     }
 #undef KQ_PIN
@@ -1028,6 +1077,319 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
         o[3] = ((unsigned long long)chunk << 32) | (unsigned)nsteps;
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// dquad kernel: the quad kernel's ring in float64 -- the float64 parity path on uniform grids (what
+// RadarData.migrate('kirch') runs on a float64 radargram, mig_python.py:35-60,118).
+//
+// Same LDS image byte for byte (a ring row is 32 bytes: here 4 traces x 8 bytes, so the image is kept in groups
+// of FOUR traces and a step block is 4 steps), same LDS-DMA staging, same fp64 pick table (the reference's
+// picks, t > t_max test and 0/0 skip, kirch_tabled_kernel below); a ds_read_b128 now carries the samples of two
+// traces.  What differs from the float32 kernel:
+//   * XB = 20 (or 16) outputs per lane in float64 accumulators (XB/2 register quads, as many as the 40 floats);
+//   * the obliquity factor cos(theta) = zs/rs = rsqrt(1 + (n dx / zs)^2) is evaluated in float64 per (lane,
+//     step): a float32 v_rsq seed and ONE third-order correction y0 (1 + r/2 + 3 r^2/8), r = 1 - x y0^2, which
+//     leaves < 1e-20 of truncation on top of float64 rounding -- far inside the 1e-12 bar, without the 113 MB
+//     float64 weight table of kirch_exact_tab_kernel or an IEEE sqrt + divide per step;
+//   * the factor sign(zs)/(2 pi v) is applied once at the end, in float64 (the near-field weight cos/rs^2 is
+//     carried in those units: y^3 v / zs^2);
+//   * non-finite input: only NaNs are zeroed by prep (they are what nansum drops, :53,:58); infinities travel
+//     through the sum as in the reference.  Rows with zs = 0 are written as exact zeros (:60 with cos = 0).
+// The kernel is bound by the float64 vector rate (20 v_fma_f64 + ~10 for the weight per lane and step against
+// 11 ds_read_b128), not by the LDS port.
+// ---------------------------------------------------------------------------
+__host__ __device__ constexpr int kd_ring_slots(int xb) { return ((xb + 7 + 3) / 4) * 4; }     // XB + 2 S - 1 live traces, whole groups
+__host__ __device__ constexpr int kd_piece_bytes(int xb) { return ((kd_ring_slots(xb) / 4 * KQ_GS + 255) / 256) * 256; }
+static_assert(kd_ring_slots(20) == 28 && kd_piece_bytes(20) == 7424 && kd_ring_slots(16) == 24 && kd_piece_bytes(16) == 6400, "");
+typedef double kd_d2 __attribute__((ext_vector_type(2)));
+
+// picks for the dquad kernel: rows of FOUR offsets, n = 4 (r - mrow0) + 1 + s, 16 bits each (see kirch_tableq_kernel)
+__global__ __launch_bounds__(256) void kirch_tabled_kernel(TableQParams P)
+{
+    const int ti = blockIdx.x * 256 + threadIdx.x;
+    const int a = blockIdx.y;
+    if (ti >= P.snum) return;
+    const unsigned zero_row = 1024u >> P.sh;         // KQ_ZERO
+    unsigned pk[5];
+    bool out = false;
+    const double zs = P.zs[ti], zs2 = P.zs2[ti];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int n = 4 * a + s;
+        unsigned kb = zero_row;
+        if (n < P.nmax && !out) {
+            const double dx = (double)n * P.dx;
+            const double q = dx * dx + zs2;                       // mig_python.py:44
+            const double rs = sqrt(q);
+            const double cost = zs / rs;                          // :47
+            const double t = 2.0 * rs / P.vel;                    // :49
+            if (t > P.tmax) {                                     // :52
+                out = true;
+            } else if (cost == cost) {
+                const int ns = P.snum;
+                int k0 = (int)floor((t - P.tt0) * P.inv_dt);
+                k0 = min(max(k0, 0), ns - 1);
+                while (k0 < ns - 1 && P.tt[k0 + 1] <= t) ++k0;
+                while (k0 > 0 && P.tt[k0] > t) --k0;
+                const int k1 = min(k0 + 1, ns - 1);
+                const int k = (fabs(P.tt[k1] - t) < fabs(P.tt[k0] - t)) ? k1 : k0;
+                kb = kq_row_offset(k % P.wmod, P.ps) >> P.sh;
+            }
+        }
+        pk[s] = kb;
+    }
+    uint2 *T = reinterpret_cast<uint2 *>(P.TKB);
+    const int rp = a + P.mrow0, rn = P.mrow0 - a - 1;
+    if (rp < P.nrows) T[(size_t)rp * kq_tkb_stride(P.snum) + ti] = make_uint2(pk[1] | (pk[2] << 16), pk[3] | (pk[4] << 16));
+    if (rn >= 0) T[(size_t)rn * kq_tkb_stride(P.snum) + ti] = make_uint2(pk[3] | (pk[2] << 16), pk[1] | (pk[0] << 16));
+}
+
+template <int XB, bool NEAR, int OCC, int SH>
+__global__ __launch_bounds__(KF_THREADS, OCC) void kirch_dquad_kernel(FastParams P, int W)
+{
+    constexpr int S = 4;
+    constexpr int RG = kd_ring_slots(XB);     // ring slots (traces)
+    constexpr int KQ_PS = kd_piece_bytes(XB);
+    constexpr int G0 = XB / 4;                // a block's new traces belong to image / ring group blk + G0
+    constexpr int KQ_PARTS = (XB / 2 + 1 + KQ_PER - 1) / KQ_PER;   // interleave slices per step
+    constexpr int NB = RG / S;                // step blocks per ring revolution (unroll length)
+    constexpr int NQ = RG / 2;                // 16-byte slot pairs
+    static_assert(XB + 2 * S - 1 <= RG && RG % S == 0 && XB % 4 == 0, "ring too small");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int npieces = W >> 5;
+    const unsigned img_bytes = (unsigned)npieces * KQ_PS;
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7, r = b >> 3;
+    const int chunk = r / P.tiles_per_xcd;
+    const int qx = r - chunk * P.tiles_per_xcd;
+    const int xt = ((qx / P.G) * 8 + xcd) * P.G + (qx % P.G);
+    if (chunk >= P.nchunks || xt >= P.nxt) return;
+
+    const int tid = threadIdx.x;
+    const int s0 = chunk * KF_THREADS;
+    const int x0 = (P.xlo & ~3) + xt * XB;       // tiles start at a multiple of 4 (outputs left of xlo are not stored)
+    const int snum = P.snum, tnum = P.tnum;
+    // lane -> sample permutation: the 16 lanes a ds_read_b128 services together hold 16 consecutive samples
+    // (see kirch_quad_kernel)
+    const int lane = tid & 63;
+    const int l32 = lane & 31;
+    const int grp = ((l32 >= 4 && l32 < 12) || (l32 >= 16 && l32 < 20) || l32 >= 28) ? 1 : 0;
+    const int idx = grp ? (l32 < 12 ? l32 - 4 : (l32 < 20 ? l32 - 8 : l32 - 16))
+                        : (l32 < 4 ? l32 : (l32 < 16 ? l32 - 8 : l32 - 12));
+    const int sigma = (lane & 32) + grp * 16 + idx;
+    const int ti_raw = s0 + (tid & ~63) + sigma;
+    const int ti = min(ti_raw, snum - 1);
+
+    const int hmax = P.hmax[chunk];
+    int nlo_ = max(-hmax, -(x0 + XB - 1));
+    nlo_ -= (nlo_ - 1) & 3;                      // x0 + nlo = 1 mod 4: a block's 4 new traces are one image group
+    const int nlo = nlo_;
+    const int nhi = min(hmax, tnum - 1 - x0);
+    const int nsteps = nhi - nlo + 1;
+    const int nblocks = (nsteps + S - 1) / S;
+    const int nrev = (nblocks + NB - 1) / NB;
+    const int jbase = x0 + nlo;
+    const int mrow = ((nlo - 1) >> 2) + P.mrow0;
+    auto row_of = [&](int blk) { return min(mrow + blk, P.nrows - 1); };
+
+    const int2 *WIN = P.WIN + (size_t)chunk * P.nrows;
+    auto fetch_for = [&](int blk_for, int &a, int &b) {
+        const int2 w = WIN[max(row_of(blk_for), 0)];
+        a = w.x;
+        b = w.y;
+    };
+    const unsigned grp_bytes = (unsigned)snum * 32u;
+    auto make_desc = [&](const double *img) {
+        const unsigned long long a = (unsigned long long)(img + (ptrdiff_t)(jbase - 1) * snum);
+        kq_u4 d;
+        d.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+        d.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+        d.z = 0x7fffffffu;
+        d.w = 0x00020000u;
+        return d;
+    };
+    const kq_u4 gdesc = make_desc(reinterpret_cast<const double *>(P.GT));
+    const kq_u4 ddesc = make_desc(reinterpret_cast<const double *>(NEAR ? P.DT : P.GT));
+    const __amdgpu_buffer_rsrc_t tkres =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(P.TKB), 0, 0x7fffffff, 0x00020000);
+    const unsigned tioff = (unsigned)ti * 8u;
+    const unsigned rowbytes = (unsigned)kq_tkb_stride(snum) * 8u;
+    typedef unsigned kd_u2 __attribute__((ext_vector_type(2)));
+    auto picks = [&](int blk) -> kd_u2 {
+        return __builtin_amdgcn_raw_buffer_load_b64(tkres, tioff, (unsigned)row_of(blk) * rowbytes, 0);
+    };
+#define KD_TK(q, s) (((q)[(s) >> 1] >> (16 * ((s) & 1))) & 0xffffu)
+    const double c1 = P.c1d[ti], c2 = NEAR ? P.c2d[ti] : 0.0, fin = P.find[ti];
+    auto n2_of = [&](int step) {
+        const int n = nlo + step;
+        return (double)((unsigned)n * (unsigned)n);
+    };
+    // cos(theta) = rsqrt(1 + c1 n^2) in float64: float32 seed + one third-order correction (see the header)
+    auto cosine = [&](double n2) {
+        const double x = fma(c1, n2, 1.0);
+        const double y0 = (double)__builtin_amdgcn_rsqf((float)x);
+        const double h = x * y0;
+        const double rr = fma(-h, y0, 1.0);
+        const double pp = fma(rr, 0.375, 0.5) * rr;
+        return fma(y0, pp, y0);
+    };
+
+    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds != 0u) __builtin_trap();
+    for (int e = tid; e < (int)(img_bytes / 4) * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
+    __syncthreads();
+    kd_u2 tkc = picks(0);
+
+    kd_d2 acc2[XB / 2];
+#pragma unroll
+    for (int i = 0; i < XB / 2; ++i) acc2[i] = kd_d2{0.0, 0.0};
+#define KD_ACC(i) acc2[(i) >> 1][(i) & 1]
+
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rl = lane >> 1;
+    const unsigned hsel = ((unsigned)(lane & 1) ^ ((unsigned)(rl >> 3) & 1u)) * 16u;
+    auto dma16 = [&](unsigned lds_dst, unsigned vo, kq_u4 desc, unsigned so) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(lds_dst), "v"(vo), "s"(desc), "s"(so)
+                     : "memory");
+    };
+    auto dma_issue = [&](int blk_for, int wa) {     // the 4 traces that block `blk_for` adds to the ring
+        const int kmin = wa & 0xffff, kmod = (int)((unsigned)wa >> 16);
+        const int gidx = ((blk_for + G0) % NB + NB) % NB;
+        const unsigned so = (unsigned)(blk_for + G0) * grp_bytes;
+        for (int pc = wv; pc < npieces; pc += 4) {
+            int t = pc * 32 + rl - kmod;
+            t += (t < 0) ? W : 0;
+            const int c = min(kmin + t, snum - 1);
+            const unsigned vo = (unsigned)c * 32u + hsel;
+            dma16((unsigned)(pc * KQ_PS + gidx * KQ_GS), vo, gdesc, so);
+            if (NEAR) dma16(img_bytes + (unsigned)(pc * KQ_PS + gidx * KQ_GS), vo, ddesc, so);
+        }
+    };
+    int wa, wb, wn = 0;
+    for (int pb = -G0; pb <= 0; ++pb) {
+        fetch_for(pb, wa, wb);
+        dma_issue(pb, wa);
+    }
+    fetch_for(1, wa, wb);
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+    __syncthreads();
+    dma_issue(1, wa);
+    fetch_for(2, wa, wb);
+
+    kq_f4 va[NQ], vb[NQ], ua[NEAR ? NQ : 1], ub[NEAR ? NQ : 1];
+    auto needed = [](int pm, int qd) {
+        bool any = false;
+        for (int c = 0; c < 2; ++c) any = any || ((2 * qd + c - pm - 1 + 2 * RG) % RG) < XB;
+        return any;
+    };
+    auto run_pos = [](int pm, int qd) { return (qd - ((pm + 1) % RG) / 2 + NQ) % NQ; };
+    auto load_step = [&](int pm, unsigned tk, kq_f4 (&v)[NQ], kq_f4 (&u)[NEAR ? NQ : 1], int part) {
+        typedef const __attribute__((address_space(3))) kq_f4 *lds_f4p;
+        const unsigned a0 = tk << SH, a1 = a0 ^ 16u;
+#pragma unroll
+        for (int qd = 0; qd < NQ; ++qd)
+            if (needed(pm, qd) && (part < 0 || run_pos(pm, qd) / KQ_PER == part)) {
+                const unsigned src = ((qd & 1) ? a1 : a0) + (qd >> 1) * KQ_GS;
+                v[qd] = *(lds_f4p)(uintptr_t)src;
+                if (NEAR) u[qd] = *(lds_f4p)(uintptr_t)(src + img_bytes);
+            }
+    };
+    auto fma_step = [&](int pm, double w, double w2, const kq_f4 (&v)[NQ], const kq_f4 (&u)[NEAR ? NQ : 1], int part) {
+#pragma unroll
+        for (int qd = 0; qd < NQ; ++qd) {
+            if (part >= 0 && run_pos(pm, qd) / KQ_PER != part) continue;
+            const int i0 = (2 * qd + 0 - pm - 1 + 2 * RG) % RG;
+            const int i1 = (2 * qd + 1 - pm - 1 + 2 * RG) % RG;
+            if (i0 < XB || i1 < XB) {
+                const kd_d2 dv = __builtin_bit_cast(kd_d2, v[qd]);
+                const kd_d2 du = __builtin_bit_cast(kd_d2, u[NEAR ? qd : 0]);
+#define KD_COMP(ix, c)                                                              \
+    if (ix < XB) {                                                                  \
+        KD_ACC(ix < XB ? ix : 0) = fma(w, dv[c], KD_ACC(ix < XB ? ix : 0));            \
+        if (NEAR) KD_ACC(ix < XB ? ix : 0) = fma(w2, du[c], KD_ACC(ix < XB ? ix : 0)); \
+    } else {                                                                        \
+        asm volatile("" ::"v"(dv[c]));                                              \
+        if (NEAR) asm volatile("" ::"v"(du[c]));                                    \
+    }
+                KD_COMP(i0, 0)
+                KD_COMP(i1, 1)
+#undef KD_COMP
+            }
+        }
+    };
+#define KD_PIN()                                                                                          \
+    do {                                                                                                  \
+        static_assert(XB == 16 || XB == 20, "KD_PIN lists XB/2 accumulator pairs");                       \
+        if (XB == 16)                                                                                     \
+            asm volatile("" : "+v"(acc2[0]), "+v"(acc2[1]), "+v"(acc2[2]), "+v"(acc2[3]), "+v"(acc2[4]), \
+                              "+v"(acc2[5]), "+v"(acc2[6]), "+v"(acc2[7]) :: "memory");                   \
+        else                                                                                              \
+            asm volatile("" : "+v"(acc2[0]), "+v"(acc2[1]), "+v"(acc2[2]), "+v"(acc2[3]), "+v"(acc2[4]), \
+                              "+v"(acc2[5]), "+v"(acc2[6]), "+v"(acc2[7]), "+v"(acc2[XB >= 20 ? 8 : 0]),  \
+                              "+v"(acc2[XB >= 20 ? 9 : 0]) :: "memory");                                  \
+    } while (0)
+
+    double n2c[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) n2c[s] = n2_of(s);
+    load_step(0, KD_TK(tkc, 0), va, ua, -1);
+    for (int rev = 0; rev < nrev; ++rev) {
+#pragma clang loop unroll(full)
+        for (int bb = 0; bb < NB; ++bb) {
+            const int blk = rev * NB + bb;
+            const int pm0 = bb * S;
+            const kd_u2 tkn = picks(blk + 1);
+            fetch_for(blk + 3, wn, wb);
+            double twc[S], tw2c[NEAR ? S : 1];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const double y = cosine(n2c[s]);
+                twc[s] = y;
+                if (NEAR) tw2c[s] = (y * c2) * (y * y);        // near-field weight in units of fin: c2 = v / zs^2
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s) n2c[s] = n2_of((blk + 1) * S + s);
+#define KD_W2(s) (NEAR ? tw2c[NEAR ? (s) : 0] : 0.0)
+#define KD_UNPACK(...) __VA_ARGS__
+#define KD_STEP(L, F)                                                                          \
+    do {                                                                                       \
+        _Pragma("unroll") for (int part = 0; part < KQ_PARTS; ++part) {                      \
+            load_step(KD_UNPACK L, part); KD_PIN();                                            \
+            fma_step(KD_UNPACK F, part); KD_PIN();                                             \
+        }                                                                                      \
+    } while (0)
+            KD_STEP((pm0 + 1, KD_TK(tkc, 1), vb, ub), (pm0 + 0, twc[0], KD_W2(0), va, ua));
+            KD_STEP((pm0 + 2, KD_TK(tkc, 2), va, ua), (pm0 + 1, twc[1], KD_W2(1), vb, ub));
+            KD_STEP((pm0 + 3, KD_TK(tkc, 3), vb, ub), (pm0 + 2, twc[2], KD_W2(2), va, ua));
+            // barrier after step S - 2: the ring group the next DMA overwrites was last read there
+            __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
+            asm volatile("s_barrier" ::: "memory");
+            dma_issue(blk + 2, wa);
+            wa = wn;
+            KD_STEP(((pm0 + 4) % RG, KD_TK(tkn, 0), va, ua), (pm0 + 3, twc[3], KD_W2(3), vb, ub));
+#undef KD_W2
+#undef KD_STEP
+#undef KD_UNPACK
+            tkc = tkn;
+        }
+    }
+#undef KD_PIN
+#undef KD_TK
+    asm volatile("" ::"v"(va[0].x), "v"(va[NQ - 1].w));
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    if (ti_raw < snum) {
+        double *o = reinterpret_cast<double *>(P.out) + (size_t)ti_raw * P.ldo + (x0 - P.xlo);
+#pragma unroll
+        for (int i = 0; i < XB; ++i)
+            if (x0 + i >= P.xlo && x0 + i < P.xhi) o[i] = (fin == 0.0) ? 0.0 : KD_ACC(i) * fin;
+    }
+#undef KD_ACC
 }
 
 // ===========================================================================
@@ -1066,6 +1428,8 @@ struct impdar_kirch_plan {
     DevBuf d_stamps;               // diagnostic builds only
     int nb = 0, ntab = 0;
     bool quad = false;          // sample-major LDS ring (kirch_quad_kernel)
+    bool dquad = false;         // the same ring in float64 (kirch_dquad_kernel): exact mode, float64 data, uniform grids
+    DevBuf d_c1d, d_c2d, d_find;
     int quadW = 0;              // samples per ring slot in that layout
     // host copies for pair counting
     std::vector<int> h_half;       // exact aperture half-width per sample (uniform grids)
@@ -1113,8 +1477,9 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     IMPDAR_ARG_CHECK(vel > 0, "vel must be positive");
     IMPDAR_ARG_CHECK(nranks >= 1, "nranks must be >= 1");
     IMPDAR_ARG_CHECK(grad_uniform || (ga && gb && gc), "non-uniform gradient needs ga/gb/gc");
-    IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
 
+    // (the geometry analysis and the kernel choice below are pure host code and run before the first HIP call,
+    // so their argument errors do not need a device: tests/test_sanitizer.py drives them under ASan/UBSan)
     impdar_kirch_plan *p = new impdar_kirch_plan();
     p->ctx = ctx;
     p->dtype = dtype;
@@ -1209,12 +1574,33 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         p->quad = (mode == IMPDAR_KIRCH_FAST) && quad_ok && !(ie && !strcmp(ie, "tab") && tab_ok);
         p->xb = p->quad ? xbq : 16;
     }
+    // float64 data in exact mode on uniform grids: the same ring in float64 (20 or 16 output traces per lane,
+    // step blocks of 4) when its window fits; otherwise (and for IMPDAR_KIRCH_EXACT_IMPL = tab | pair) the
+    // global-memory kernels
+    if (mode == IMPDAR_KIRCH_EXACT && dtype == IMPDAR_F64 && p->uniform && snum < 65536 &&
+        std::fabs(tmax / dt) / sa < 65000.0 && (2.0 * hest + 400.0) / 4.0 * (double)snum * 32.0 < 2147483648.0 &&
+        !getenv("IMPDAR_KIRCH_EXACT_IMPL")) {
+        auto rows_for = [&](int xb) { return ((KF_THREADS + (int)std::ceil(sa * (xb + 4 - 2)) + 8 + 31) / 32) * 32; };
+        const char *xe = getenv("IMPDAR_KIRCH_XBD");        // tuning knob: 16 | 20
+        int xbd = (xe && atoi(xe) == 16) ? 16 : 20;
+        if ((size_t)(rows_for(xbd) / 32) * kd_piece_bytes(xbd) > 80 * 1024) xbd = 16;
+        if ((size_t)(rows_for(xbd) / 32) * kd_piece_bytes(xbd) <= 80 * 1024) {
+            p->dquad = true;
+            p->xb = xbd;
+            p->quadW = rows_for(xbd);
+            p->quadSH = ((size_t)(p->quadW / 32) * kd_piece_bytes(xbd) <= 65535) ? 0 : 4;
+        }
+    }
 
     int rc = IMPDAR_OK;
     auto fail = [&](int code) {
         delete p;
         return code;
     };
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        impdar_set_error("hipSetDevice(%d) failed: %s", ctx->device, hipGetErrorString(hipGetLastError()));
+        return fail(IMPDAR_ERR_HIP);
+    }
     const size_t esz = impdar_dtype_size(dtype);
     const size_t img = (size_t)(p->tnum_pad + 2 * KF_PAD_ROWS) * snum * esz;   // zero rows on both sides
     for (int b = 0; b < 2; ++b) {
@@ -1252,11 +1638,32 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
             p->h_half[k] = rem < 0 ? -1 : (int)std::floor(std::sqrt(rem / p->alpha) + 1e-12);
         }
     }
-    if (mode == IMPDAR_KIRCH_FAST) {
+    const int ringS = p->dquad ? 4 : 8;            // steps per block of the ring kernels (traces per 32-byte row)
+    if (mode == IMPDAR_KIRCH_FAST || p->dquad) {
         const int nch = (snum + KF_THREADS - 1) / KF_THREADS;
         p->nchunks = nch;
         std::vector<int> hmax(nch, 0);
-        {
+        if (p->dquad) {
+            // float64 per-sample factors, from the reference's own zs = v t / 2 (mig_python.py:101):
+            //   cos(theta) = zs / sqrt(zs^2 + (n dx)^2) = sign(zs) * rsqrt(1 + c1 n^2),   c1 = (dx / zs)^2
+            //   far field  : cos / (2 pi v)     = fin * |cos|,           fin = sign(zs) / (2 pi v)
+            //   near field : cos / (2 pi rs^2)  = fin * c2 * |cos|^3,    c2 = v / zs^2
+            // zs = 0: the whole output row is 0 (cos = 0 off the apex, the apex is 0/0 and dropped): fin = 0
+            std::vector<double> c1(snum), c2(snum), fin(snum);
+            for (int k = 0; k < snum; ++k) {
+                const double zs = vel * tt_sec[k] / 2.0;
+                if (zs == 0.0) {
+                    c1[k] = c2[k] = fin[k] = 0.0;
+                    continue;
+                }
+                c1[k] = std::min((dx / zs) * (dx / zs), 1e300);
+                c2[k] = std::min(vel / (zs * zs), 1e300);
+                fin[k] = (zs > 0 ? 1.0 : -1.0) / (2.0 * M_PI * vel);
+            }
+            if ((rc = upload(p->d_c1d, c1.data(), snum * 8)) || (rc = upload(p->d_c2d, c2.data(), snum * 8)) ||
+                (rc = upload(p->d_find, fin.data(), snum * 8)))
+                return fail(rc);
+        } else {
             // with a = tt/dt (samples) and rs = half * sqrt(a^2 + alpha n^2):
             //   cos(theta)        = a / sqrt(a^2 + alpha n^2) = sign(a) * rsq(1 + c1 n^2),  c1 = alpha / a^2
             //   far-field weight  = cos / (2 pi v)            = fin * |cos|,                 fin = sign(a) / (2 pi v)
@@ -1301,11 +1708,12 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         const int nb = hglob + 64;
         p->nb = nb;
         p->ntab = hglob + 1;       // offsets 0..hglob-1 (hmax carries a guard) + one all-zero row
-        // quad kernel: tables by step block, row r <-> offsets n = 8 (r - mrow0) + 1 .. + 8
-        p->mrow0 = hglob / 8 + 8;
-        p->nrows = 2 * (hglob / 8) + 64;
+        // ring kernels: tables by step block, row r <-> offsets n = S (r - mrow0) + 1 .. + S
+        p->mrow0 = hglob / ringS + 8;
+        p->nrows = 2 * (hglob / ringS) + 64;
         {
-            const size_t tkbytes = p->quad ? (size_t)p->nrows * snum * 16 : (size_t)p->ntab * snum * 2;
+            const size_t tkbytes = (p->quad || p->dquad) ? (size_t)p->nrows * kq_tkb_stride(snum) * 2 * ringS
+                                                         : (size_t)p->ntab * snum * 2;
             if (tkbytes >= ((size_t)1 << 31)) {      // the kernels address it as one raw buffer
                 impdar_set_error("fast Kirchhoff pick table of %zu bytes exceeds 2 GiB; use the exact mode", tkbytes);
                 return fail(IMPDAR_ERR_UNSUPPORTED);
@@ -1314,8 +1722,8 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
             bool ok = true;
             for (int b = 0; b < 2; ++b) {
                 ok = ok && p->d_TK[b].ensure(tkbytes) == hipSuccess;
-                if (!p->quad) ok = ok && p->d_TW[b].ensure(ent * 4) == hipSuccess;
-                if (!p->quad && p->nearfield) ok = ok && p->d_TW2[b].ensure(ent * 4) == hipSuccess;
+                if (!p->quad && !p->dquad) ok = ok && p->d_TW[b].ensure(ent * 4) == hipSuccess;
+                if (!p->quad && !p->dquad && p->nearfield) ok = ok && p->d_TW2[b].ensure(ent * 4) == hipSuccess;
             }
             if (!ok) {
                 impdar_set_error("hipMalloc of the %zu-byte pick table failed", tkbytes);
@@ -1333,12 +1741,12 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
                 klo[(size_t)c * nb + n] = std::max(0, (int)std::floor(ulo) - 1);
                 khi[(size_t)c * nb + n] = std::min(snum - 1, (int)std::ceil(uhi) + 1);
             }
-        if (p->quad) {
-            // the 8 traces block r adds are read by the steps n = 8 (r - mrow0) + 1 .. + 31 (they enter
-            // the 24-trace window of a lane at its last slot and leave it 23 steps later)
+        if (p->quad || p->dquad) {
+            // the S traces block r adds are read by the steps n = S (r - mrow0) + 1 .. + XB + S - 2 (they enter
+            // the XB-trace window of a lane at its last slot and leave it XB - 1 steps later)
             std::vector<int> win((size_t)nch * p->nrows * 2);
             for (int r = 0; r < p->nrows; ++r) {
-                const long long na = 8LL * (r - p->mrow0) + 1, nz = na + p->xb + 6;
+                const long long na = (long long)ringS * (r - p->mrow0) + 1, nz = na + p->xb + ringS - 2;
                 const long long lo = (na <= 0 && nz >= 0) ? 0 : std::min(std::llabs(na), std::llabs(nz));
                 const long long hi = std::max(std::llabs(na), std::llabs(nz));
                 for (int c = 0; c < nch; ++c) {
@@ -1428,12 +1836,14 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
         P.ga = p->d_ga.as<double>();
         P.gb = p->d_gb.as<double>();
         P.gc = p->d_gc.as<double>();
-        P.clean = (p->mode == IMPDAR_KIRCH_FAST);
-        P.i8 = p->quad ? 1 : 0;
+        P.clean = (p->mode == IMPDAR_KIRCH_FAST) ? 1 : (p->dquad ? 2 : 0);
+        P.i8 = (p->quad || p->dquad) ? 1 : 0;
         dim3 grid((nloc + 63) / 64, (p->snum + 63) / 64);
         static const bool force_tile = getenv("IMPDAR_KIRCH_PREP_TILE") != nullptr;   // tuning knob: LDS-tile transpose
         if (p->dtype == IMPDAR_F32 && P.i8 && !force_tile)
-            hipLaunchKernelGGL(kirch_prep_direct_kernel, dim3((nloc + 255) / 256, p->snum), dim3(256), 0, st, P);
+            hipLaunchKernelGGL((kirch_prep_direct_kernel<float, 8>), dim3((nloc + 255) / 256, p->snum), dim3(256), 0, st, P);
+        else if (p->dquad)
+            hipLaunchKernelGGL((kirch_prep_direct_kernel<double, 4>), dim3((nloc + 255) / 256, p->snum), dim3(256), 0, st, P);
         else if (p->dtype == IMPDAR_F32)
             hipLaunchKernelGGL((kirch_prep_kernel<float, float>), grid, dim3(256), 0, st, P);
         else
@@ -1443,7 +1853,7 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
     static const bool diag_table_once = getenv("IMPDAR_DIAG_TABLE_ONCE") != nullptr;   // timing diagnostic only
     if (p->mode == IMPDAR_KIRCH_FAST && p->quad && diag_table_once && p->diag_tables_built >= 2) {
         // timing diagnostic: both table buffers are built, leave them
-    } else if (p->mode == IMPDAR_KIRCH_FAST && p->quad) {
+    } else if ((p->mode == IMPDAR_KIRCH_FAST && p->quad) || p->dquad) {
         // geometry-only pick table, rebuilt with every prep (counted in prep time)
         ++p->diag_tables_built;
         TableQParams T;
@@ -1462,10 +1872,13 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
         T.nmax = p->ntab - 1;
         T.wmod = p->quadW;
         T.sh = p->quadSH;
-        T.ps = kq_piece_bytes(p->xb);
+        T.ps = p->dquad ? kd_piece_bytes(p->xb) : kq_piece_bytes(p->xb);
         // rows a + mrow0 (a >= 0) and mrow0 - a - 1: a runs over the larger of the two sides
         const int na = std::max(p->nrows - p->mrow0, p->mrow0);
-        hipLaunchKernelGGL(kirch_tableq_kernel, dim3((p->snum + 255) / 256, na), dim3(256), 0, st, T);
+        if (p->dquad)
+            hipLaunchKernelGGL(kirch_tabled_kernel, dim3((p->snum + 255) / 256, na), dim3(256), 0, st, T);
+        else
+            hipLaunchKernelGGL(kirch_tableq_kernel, dim3((p->snum + 255) / 256, na), dim3(256), 0, st, T);
         IMPDAR_HIP_CHECK(hipGetLastError());
     } else if (p->mode == IMPDAR_KIRCH_FAST) {
         // geometry-only pick/weight table, rebuilt with every prep (counted in prep time)
@@ -1540,6 +1953,36 @@ static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipSt
     return IMPDAR_OK;
 }
 
+template <int XB, int SH>
+static int launch_dquad(impdar_kirch_plan *p, const FastParams &P0, hipStream_t st)
+{
+    FastParams P = P0;
+    const int ntiles = (P.xhi - (P.xlo & ~3) + XB - 1) / XB;      // tiles start at a multiple of 4
+    P.nxt = ntiles;
+    {
+        const char *ge = getenv("IMPDAR_KIRCH_G");
+        const int g = ge ? atoi(ge) : (ntiles >= 256 ? 4 : 1);
+        P.G = (g >= 1 && g <= 64) ? g : 1;
+    }
+    const int per = 8 * P.G;
+    const int nxt_pad = ((ntiles + per - 1) / per) * per;
+    P.tiles_per_xcd = nxt_pad / 8;
+    const int nblk = P.nchunks * nxt_pad;
+    const int W = p->quadW;
+    const size_t shmem = (size_t)(W / 32) * kd_piece_bytes(XB) * (p->nearfield ? 2 : 1);
+    if (p->nearfield) {
+        auto k = kirch_dquad_kernel<XB, true, 1, SH>;
+        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k, dim3(nblk), dim3(KF_THREADS), shmem, st, P, W);
+    } else {
+        auto k = kirch_dquad_kernel<XB, false, 2, SH>;
+        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k, dim3(nblk), dim3(KF_THREADS), shmem, st, P, W);
+    }
+    IMPDAR_HIP_CHECK(hipGetLastError());
+    return IMPDAR_OK;
+}
+
 template <int XB, int S, int OCC>
 static int launch_tab(impdar_kirch_plan *p, const FastParams &P0, int nx, hipStream_t st)
 {
@@ -1578,7 +2021,7 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
     IMPDAR_HIP_CHECK(hipStreamWaitEvent(st, p->ev_ready[b], 0));      // image + table of this radargram
     if (!p->haves[p->slot][2]) IMPDAR_HIP_CHECK(hipEventRecord(ev[4], st));
     const int nx = xhi - xlo;
-    if (nx > 0 && p->mode == IMPDAR_KIRCH_FAST) {
+    if (nx > 0 && (p->mode == IMPDAR_KIRCH_FAST || p->dquad)) {
         FastParams P;
         P.GT = reinterpret_cast<const float *>(img_row0(p, p->GT[b]));
         P.DT = p->nearfield ? reinterpret_cast<const float *>(img_row0(p, p->DT[b])) : nullptr;
@@ -1601,6 +2044,9 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         P.c1 = p->d_c1.as<float>();
         P.c2 = p->d_c2.as<float>();
         P.fin = p->d_fin.as<float>();
+        P.c1d = p->d_c1d.as<double>();
+        P.c2d = p->d_c2d.as<double>();
+        P.find = p->d_find.as<double>();
         P.TKB = p->d_TK[b].p;
         P.WIN = p->d_WIN.as<int2>();
         P.nrows = p->nrows;
@@ -1615,7 +2061,10 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         int rc;
         const char *oe0 = getenv("IMPDAR_KIRCH_OCC");      // tuning knob: min waves per SIMD to compile for
         const int occ0 = oe0 ? atoi(oe0) : 0;
-        if (p->quad && p->quadSH == 0)
+        if (p->dquad)
+            rc = p->quadSH == 0 ? (p->xb == 20 ? launch_dquad<20, 0>(p, P, st) : launch_dquad<16, 0>(p, P, st))
+                                : (p->xb == 20 ? launch_dquad<20, 4>(p, P, st) : launch_dquad<16, 4>(p, P, st));
+        else if (p->quad && p->quadSH == 0)
             rc = p->xb == 40 ? launch_quad<40, 2, 0>(p, P, nx, st)
                  : p->xb == 32 ? launch_quad<32, 2, 0>(p, P, nx, st)
                  : (occ0 == 2) ? launch_quad<24, 2, 0>(p, P, nx, st) : launch_quad<24, 3, 0>(p, P, nx, st);
@@ -1943,6 +2392,7 @@ extern "C" void mig_kirch_loop(double *migdata, int tnum, int snum, double *dist
     // exact kernel derives its aperture from the plan's own tmax, so the hook keeps the per-pair kernel
     p->tmax = max_travel_time;
     p->xtab_off = true;
+    p->dquad = false;
     const size_t bytes = (size_t)snum * tnum * 8;
     DevBuf din, dout;
     if (hipMemcpy(p->d_zs.p, zs, (size_t)snum * 8, hipMemcpyHostToDevice) == hipSuccess &&
