@@ -112,7 +112,7 @@ def pmc_traffic(args, kernel_substr, timeout_s=150.0):
         d = tempfile.mkdtemp(prefix='impdar_pmc_', dir='/tmp')
         cmd = [prof, '--pmc', counter, '--kernel-trace', '-d', d, '-o', 'x', '--output-format', 'csv', '--',
                sys.executable, os.path.abspath(__file__), '--pmc-child', '--steps', '2', '--warmup', '1',
-               '--tnum', str(args.tnum), '--snum', str(args.snum), '--mode', args.mode]
+               '--tnum', str(args.tnum), '--snum', str(args.snum), '--mode', args.mode, '--dtype', args.dtype]
         try:
             env = dict(os.environ, TMPDIR='/tmp')
             p = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -373,7 +373,7 @@ def main():
         pairs0 = sk.pairs[0]
         algo_bytes = pairs0 * esz + snum * (xhi - xlo) * esz       # one element per in-aperture pair + output
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
-        kname = {'fast': 'kirch_quad_kernel', 'exact': 'kirch_exact'}.get(plan.mode, 'kirch')
+        kname = plan.kernel
         res = {
             "metric": "migrated traces/sec + achieved HBM GB/s, Kirchhoff 10000x4096 radargram",
             "value": value, "unit": "traces/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -457,13 +457,13 @@ def main():
                                  "note": "RadarData.migrate('kirch') on a host float32 array: plan + tables + H2D + prep + "
                                          "diffraction sum + D2H + widening to the float64 the reference returns; median of 3"}
         # ---- HBM-side traffic of the dominant kernel, counted in child runs of this command
-        if not args.no_pmc and args.mode == 'fast':
+        if not args.no_pmc and kname in ('kirch_quad_kernel', 'kirch_dquad_kernel'):
             t0 = time.time()
-            traffic, raw, note = pmc_traffic(args, 'kirch_quad_kernel')
+            traffic, raw, note = pmc_traffic(args, kname)
             res["roofline"]["traffic"] = traffic
             res["roofline"]["traffic_source"] = note
             if traffic:
-                compulsory = 2 * snum * tnum * 4
+                compulsory = 2 * snum * tnum * esz
                 res["roofline"]["fabric"] = {"bytes": traffic, "fetch_size_kib_raw": raw['FETCH_SIZE'],
                                              "write_size_kib_raw": raw['WRITE_SIZE'],
                                              "GBps": traffic / (k_ms * 1e-3) / 1e9,

@@ -290,6 +290,37 @@ __global__ __launch_bounds__(256) void kirch_tablex_kernel(TableXParams P)
     if (P.near) P.XW2[o] = w2;
 }
 
+// Every table above assumes that the pick of a pair depends on (sample, |trace offset|) only.  That fails exactly
+// where the reference's own answer is decided by rounding noise: a travel time that falls (to float64 rounding) on
+// the midpoint between two samples, or on t_max itself.  The reference evaluates t from dist[j] - dist[xi], whose
+// last bits differ from pair to pair with the same offset, so such ties break either way inside ONE offset
+// (geometries with a rational moveout 2dx/(v dt), e.g. 2.5 samples per trace, are full of them: 4a^2 + 25n^2 is
+// an odd square for whole families of (a, n)).  This scan flags a geometry that has any such entry inside an
+// aperture; the plan then keeps the per-pair kernel, which repeats the reference's arithmetic pair by pair.
+// Margin: the relative rounding noise of t, ~1e-15 plus the cancellation in dist[j] - dist[xi]
+// (2.2e-16 * tnum / |n|), times |t|/dt, in samples.
+__global__ __launch_bounds__(256) void kirch_tiescan_kernel(TableXParams P, double tnum, int *flag)
+{
+    const int ti = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    if (ti >= P.snum) return;
+    const double dx = (double)n * P.dx;
+    const double q = dx * dx + P.zs2[ti];
+    const double rs = sqrt(q);
+    const double cost = P.zs[ti] / rs;
+    const double t = 2.0 * rs / P.vel;
+    if (!(cost == cost)) return;                       // 0/0 apex: dropped whatever the noise
+    const double u = (t - P.tt0) * P.inv_dt, um = (P.tmax - P.tt0) * P.inv_dt;
+    const double eps = (fabs(t * P.inv_dt) + 1.0) * (1.0e-15 + 4.5e-16 * tnum / (double)max(n, 1));
+    if (u > um + eps) return;                          // clearly outside the aperture
+    bool amb = fabs(u - um) <= eps && n > 0;           // the t > t_max test itself (n = 0: t = tt exactly)
+    if (u >= 0.0 && u <= um && n > 0) {
+        const double fr = u - floor(u);
+        amb = amb || fabs(fr - 0.5) <= eps;
+    }
+    if (amb) atomicOr(flag, 1);
+}
+
 struct ExactTabParams {
     const void *GT, *DT;
     void *out;
@@ -1429,6 +1460,7 @@ struct impdar_kirch_plan {
     int nb = 0, ntab = 0;
     bool quad = false;          // sample-major LDS ring (kirch_quad_kernel)
     bool dquad = false;         // the same ring in float64 (kirch_dquad_kernel): exact mode, float64 data, uniform grids
+    bool tie_ambiguous = false; // kirch_tiescan_kernel found a pick that rounding noise decides: per-pair kernel only
     DevBuf d_c1d, d_c2d, d_find;
     int quadW = 0;              // samples per ring slot in that layout
     // host copies for pair counting
@@ -1558,6 +1590,7 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     const bool fast_ok = dtype == IMPDAR_F32 && p->uniform && window_ok && snum < 65536 &&
                          std::fabs(tmax / dt) / sa < 65000.0 && span_ok;
 
+    const int requested_mode = mode;
     if (mode == IMPDAR_KIRCH_AUTO) mode = fast_ok ? IMPDAR_KIRCH_FAST : IMPDAR_KIRCH_EXACT;
     if (mode == IMPDAR_KIRCH_FAST && !fast_ok) {
         delete p;
@@ -1636,6 +1669,54 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
             const double a = tt_sec[k] / dt;
             const double rem = um * um - a * a;
             p->h_half[k] = rem < 0 ? -1 : (int)std::floor(std::sqrt(rem / p->alpha) + 1e-12);
+        }
+    }
+    // ---- picks that rounding noise decides (see kirch_tiescan_kernel): the table-driven kernels would break those
+    // ties one way per offset, the reference breaks them pair by pair
+    if (p->uniform && (mode == IMPDAR_KIRCH_FAST || p->dquad || !getenv("IMPDAR_KIRCH_EXACT_IMPL") ||
+                       strcmp(getenv("IMPDAR_KIRCH_EXACT_IMPL"), "pair"))) {
+        int hg = 0;
+        for (int k = 0; k < snum; ++k) hg = std::max(hg, p->h_half[k] + 1);
+        hg = std::min(hg, tnum) + 1;
+        DevBuf d_flag;
+        if (d_flag.ensure(64) != hipSuccess) {
+            impdar_set_error("hipMalloc failed");
+            return fail(IMPDAR_ERR_HIP);
+        }
+        (void)hipMemsetAsync(d_flag.p, 0, 64, ctx->stream);
+        TableXParams T;
+        T.XK = nullptr;
+        T.XW = T.XW2 = nullptr;
+        T.zs = p->d_zs.as<double>();
+        T.zs2 = p->d_zs2.as<double>();
+        T.tt = p->d_tt.as<double>();
+        T.dx = dx;
+        T.vel = vel;
+        T.tmax = tmax;
+        T.inv_dt = 1.0 / dt;
+        T.tt0 = tt_sec[0];
+        T.snum = snum;
+        T.ntab = hg;
+        T.near = 0;
+        hipLaunchKernelGGL(kirch_tiescan_kernel, dim3((snum + 255) / 256, hg), dim3(256), 0, ctx->stream, T, (double)tnum,
+                           d_flag.as<int>());
+        int flag = 0;
+        if (hipMemcpyAsync(&flag, d_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            impdar_set_error("tie scan failed: %s", hipGetErrorString(hipGetLastError()));
+            return fail(IMPDAR_ERR_HIP);
+        }
+        p->tie_ambiguous = flag != 0;
+        if (p->tie_ambiguous) {
+            // the float32 ring kernels stay available when asked for by name (their contract is a float32
+            // tolerance on band-limited data); everything the library chooses itself goes per pair
+            if (mode == IMPDAR_KIRCH_FAST && requested_mode == IMPDAR_KIRCH_AUTO) {
+                mode = p->mode = IMPDAR_KIRCH_EXACT;
+                p->quad = false;
+                p->xb = 16;
+            }
+            p->dquad = false;
+            p->xtab_off = true;
         }
     }
     const int ringS = p->dquad ? 4 : 8;            // steps per block of the ring kernels (traces per 32-byte row)
@@ -1790,6 +1871,16 @@ extern "C" void impdar_kirch_plan_destroy(impdar_kirch_plan *p)
 
 extern "C" int impdar_kirch_plan_mode(const impdar_kirch_plan *p) { return p ? p->mode : IMPDAR_ERR_ARG; }
 extern "C" int impdar_kirch_plan_tnum_pad(const impdar_kirch_plan *p) { return p ? p->tnum_pad : IMPDAR_ERR_ARG; }
+
+extern "C" int impdar_kirch_plan_kernel(const impdar_kirch_plan *p)
+{
+    if (!p) return IMPDAR_ERR_ARG;
+    if (p->mode == IMPDAR_KIRCH_FAST) return p->quad ? IMPDAR_KERNEL_QUAD : IMPDAR_KERNEL_TAB;
+    if (p->dquad) return IMPDAR_KERNEL_DQUAD;
+    const char *e = getenv("IMPDAR_KIRCH_EXACT_IMPL");
+    if (p->uniform && !p->xtab_off && !(e && !strcmp(e, "pair"))) return IMPDAR_KERNEL_EXACT_TAB;
+    return IMPDAR_KERNEL_EXACT_PAIR;
+}
 
 static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int jlo, int nloc, int precomputed)
 {

@@ -8,6 +8,8 @@ from . import _hip
 from .lib.migrationlib.mig_hip import gradient_coefficients
 
 MODE_NAMES = {_hip.KIRCH_EXACT: 'exact', _hip.KIRCH_FAST: 'fast'}
+KERNEL_NAMES = {0: 'kirch_exact_kernel', 1: 'kirch_exact_tab_kernel', 2: 'kirch_dquad_kernel', 3: 'kirch_quad_kernel',
+                4: 'kirch_tab_kernel'}
 
 
 class KirchhoffPlan(object):
@@ -30,6 +32,7 @@ class KirchhoffPlan(object):
         _hip.check(rc, 'impdar_kirch_plan_create')
         self.mode = MODE_NAMES[self.lib.impdar_kirch_plan_mode(self.h)]
         self.tnum_pad = self.lib.impdar_kirch_plan_tnum_pad(self.h)
+        self.kernel = KERNEL_NAMES[self.lib.impdar_kirch_plan_kernel(self.h)]
 
     def prep(self, d_data, ld, jlo, nloc):
         """Gradient + transpose of a local column block (device array)."""

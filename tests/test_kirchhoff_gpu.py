@@ -412,3 +412,155 @@ def test_config4_size_on_one_gpu(hip):
         d.free()
     plan.destroy()
     plan8.destroy()
+
+
+# ---- float64 LDS-ring kernel (kirch_dquad_kernel): what the float64 default runs on uniform grids ------------
+def _exact_with(monkeypatch, impl, data, geo, vel=1.69e8, nearfield=False, xbd=None):
+    """mode='exact' with IMPDAR_KIRCH_EXACT_IMPL = None (ring) | 'tab' | 'pair'."""
+    from impdar_amd import _hip
+    from impdar_amd.kirchhoff import KirchhoffPlan
+    for k, v in (('IMPDAR_KIRCH_EXACT_IMPL', impl), ('IMPDAR_KIRCH_XBD', xbd)):
+        if v is None:
+            monkeypatch.delenv(k, raising=False)
+        else:
+            monkeypatch.setenv(k, v)
+    ctx = _hip.context()
+    snum, tnum = data.shape
+    plan = KirchhoffPlan(ctx, data.dtype, snum, tnum, geo['dist'], geo['travel_time'], vel, nearfield, 'exact')
+    _exact_with.kernel = plan.kernel
+    d_in = _hip.DeviceArray.from_host(ctx, data)
+    d_out = _hip.DeviceArray(ctx, (snum, tnum), data.dtype)
+    plan.prep(d_in, tnum, 0, tnum)
+    plan.migrate(d_out, 0, tnum)
+    plan.sync()
+    out = d_out.to_host()
+    plan.destroy()
+    d_in.free()
+    d_out.free()
+    return out
+
+
+@pytest.mark.parametrize('nearfield', [False, True])
+@pytest.mark.parametrize('xbd', ['20', '16'])
+def test_float64_ring_agrees_with_the_global_memory_exact_kernels(hip, monkeypatch, nearfield, xbd):
+    """The three float64 kernels (LDS ring, tabulated gather, per-pair reference order) on one radargram whose
+    size is ragged in both directions, with a first sample before the trigger (negative zs: cos < 0)."""
+    from impdar_amd import synth
+    from oracle import c_oracle
+    snum, tnum = 777, 203
+    geo = synth.geometry(snum, tnum, dx=1.7, t0_us=-0.03)
+    x = synth.noise_radargram(snum, tnum, seed=21)
+    want = c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], 1.69e8, nearfield)
+    ring = _exact_with(monkeypatch, None, x, geo, nearfield=nearfield, xbd=xbd)
+    assert _exact_with.kernel == 'kirch_dquad_kernel'
+    assert rel_max(ring, want) < EXACT_TOL, rel_max(ring, want)
+    for impl in ('tab', 'pair'):
+        other = _exact_with(monkeypatch, impl, x, geo, nearfield=nearfield)
+        assert _exact_with.kernel == {'tab': 'kirch_exact_tab_kernel', 'pair': 'kirch_exact_kernel'}[impl]
+        assert rel_max(other, want) < EXACT_TOL
+        assert rel_max(ring, other) < EXACT_TOL
+
+
+def test_float64_ring_infinities_and_nans_follow_nansum(hip, monkeypatch):
+    """mig_python.py:53: NaN terms are skipped, infinite ones are not; a row with zs = 0 is exactly 0 whatever
+    the data holds (cos = 0 off the apex, the apex itself is 0/0 and dropped)."""
+    from impdar_amd import synth
+    from oracle import mig_oracle
+    snum, tnum = 300, 64
+    geo = synth.geometry(snum, tnum)
+    x = synth.noise_radargram(snum, tnum, seed=22)
+    x[100, 20] = np.nan
+    x[200, 40] = np.inf
+    x[201, 41] = -np.inf
+    with np.errstate(invalid='ignore'):
+        want = mig_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], 1.69e8)
+    got = _exact_with(monkeypatch, None, x, geo)
+    pair = _exact_with(monkeypatch, 'pair', x, geo)
+    assert not got[0].any()
+    fin = np.isfinite(want)
+    assert fin.any() and (~fin).any()
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isposinf(got), np.isposinf(want))
+    assert np.array_equal(np.isneginf(got), np.isneginf(want))
+    assert np.max(np.abs(got[fin] - want[fin])) < EXACT_TOL * np.max(np.abs(want[fin]))
+    assert np.array_equal(np.isfinite(pair), fin)
+
+
+def test_float64_ring_random_geometries(hip, monkeypatch):
+    """Seeded sweep over sizes, spacings, velocity, first-sample time and near field against the C oracle (the ring
+    serves what fits its LDS window; steeper moveouts fall back to the tabulated kernel: both must meet the bar)."""
+    from impdar_amd import synth
+    from oracle import c_oracle
+    rng = np.random.default_rng(7)
+    used = set()
+    for case in range(10):
+        snum, tnum = int(rng.integers(40, 900)), int(rng.integers(3, 300))
+        dt, dx = float(rng.choice([2e-9, 5e-9, 1e-8])), float(rng.choice([0.3, 1.0, 2.5, 6.0]))
+        vel, t0 = float(rng.choice([1.2e8, 1.69e8, 3e8])), float(rng.choice([0.0, 0.004, -0.02]))
+        near = bool(rng.integers(0, 2))
+        geo = synth.geometry(snum, tnum, dt=dt, dx=dx, t0_us=t0)
+        x = synth.noise_radargram(snum, tnum, seed=100 + case)
+        want = c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], vel, near)
+        got = _exact_with(monkeypatch, None, x, geo, vel=vel, nearfield=near)
+        err = rel_max(got, want)
+        used.add(_exact_with.kernel)
+        assert err < EXACT_TOL, (case, err, _exact_with.kernel, snum, tnum, dt, dx, vel, t0, near)
+    assert 'kirch_dquad_kernel' in used
+
+
+def test_float64_ring_output_blocks_of_a_sharded_run(hip, monkeypatch):
+    """Output blocks that start and end anywhere (ragged against the 4-trace groups of the float64 image) from
+    input shards prepared separately: the sharded float64 path equals the one-shot one bit for bit."""
+    from impdar_amd import _hip, parallel, synth
+    from impdar_amd.kirchhoff import KirchhoffPlan
+    monkeypatch.delenv('IMPDAR_KIRCH_EXACT_IMPL', raising=False)
+    snum, tnum = 512, 333
+    geo = synth.geometry(snum, tnum)
+    x = synth.noise_radargram(snum, tnum, seed=23)
+    one = _exact_with(monkeypatch, None, x, geo)
+    ctx = _hip.context()
+    tnum_pad, shards = parallel.input_shards(tnum, 3)
+    plan = KirchhoffPlan(ctx, np.float64, snum, tnum, geo['dist'], geo['travel_time'], mode='exact', nranks=3)
+    assert plan.tnum_pad == tnum_pad
+    for jlo, jhi in shards:                     # every rank's prep, here on one GPU (what the all-gather assembles)
+        d = _hip.DeviceArray.from_host(ctx, np.ascontiguousarray(x[:, jlo:jhi]))
+        plan.prep(d, jhi - jlo, jlo, jhi - jlo)
+        plan.sync()
+        d.free()
+    for xlo, xhi in ((0, 101), (101, 102), (102, 333), (7, 7)):
+        d_out = _hip.DeviceArray(ctx, (snum, max(xhi - xlo, 1)), np.float64)
+        plan.migrate(d_out, xlo, xhi)
+        plan.sync()
+        got = d_out.to_host()[:, :xhi - xlo]
+        d_out.free()
+        assert np.array_equal(got, one[:, xlo:xhi])
+    plan.destroy()
+
+
+def test_ties_that_rounding_noise_decides_go_to_the_per_pair_kernel(hip, monkeypatch):
+    """Moveout 2dx/(v dt) = 2.5 samples per trace with whole-sample times: 4a^2 + 25n^2 is an odd square for whole
+    families of (a, n), i.e. travel times exactly half way between two samples.  The reference breaks those ties
+    pair by pair (the last bits of dist[j] - dist[xi]); a per-offset table cannot (it was 10 % off on this
+    radargram).  The plan must see that and keep the per-pair kernel; an irrational moveout keeps the ring."""
+    from impdar_amd import _hip, synth
+    from impdar_amd.kirchhoff import KirchhoffPlan
+    from oracle import c_oracle
+    monkeypatch.delenv('IMPDAR_KIRCH_EXACT_IMPL', raising=False)
+    snum, tnum, vel = 252, 297, 1.2e8
+    geo = synth.geometry(snum, tnum, dt=2e-9, dx=0.3, t0_us=-0.02)
+    x = synth.noise_radargram(snum, tnum, seed=109)
+    want = c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], vel, True)
+    got = _exact_with(monkeypatch, None, x, geo, vel=vel, nearfield=True)
+    assert _exact_with.kernel == 'kirch_exact_kernel'
+    assert rel_max(got, want) < EXACT_TOL
+    ctx = _hip.context()
+    # what the library chooses by itself for float32 data on that geometry, and what it does when asked by name
+    auto = KirchhoffPlan(ctx, np.float32, snum, tnum, geo['dist'], geo['travel_time'], vel, True, 'auto')
+    fast = KirchhoffPlan(ctx, np.float32, snum, tnum, geo['dist'], geo['travel_time'], vel, True, 'fast')
+    assert (auto.mode, auto.kernel) == ('exact', 'kirch_exact_kernel') and fast.mode == 'fast'
+    auto.destroy()
+    fast.destroy()
+    g3 = synth.geometry(4096, 10000)               # BASELINE config 3: 2 / 1.69 samples per trace
+    for dtype, kern in ((np.float64, 'kirch_dquad_kernel'), (np.float32, 'kirch_quad_kernel')):
+        plan = KirchhoffPlan(ctx, dtype, 4096, 10000, g3['dist'], g3['travel_time'], 1.69e8, False, 'auto')
+        assert plan.kernel == kern
+        plan.destroy()
