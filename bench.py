@@ -260,6 +260,7 @@ def main():
     ap.add_argument('--no-e2e', action='store_true', help='skip the PCIe-inclusive one-shot figure')
     ap.add_argument('--cpu-budget', type=float, default=15.0)
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--data-child', default='zeros', choices=['zeros', 'synthetic'], help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     # ---- `python bench.py --gpus N` without a launcher: start the N ranks here, BEFORE anything touches the GPU
@@ -308,11 +309,11 @@ def main():
 
     t0 = time.time()
     full_data = None
-    if args.pmc_child:
+    if args.pmc_child and args.data_child == 'zeros':
         local_data = np.zeros((snum, max(nloc, 1)), dtype=np_dtype)
     elif args.data == 'synthetic':
         # rank 0 builds the whole radargram when it needs it for the CPU legs / parity anyway
-        need_full = rank == 0 and not args.no_cpu
+        need_full = rank == 0 and not args.no_cpu and not args.pmc_child
         lo, hi = (0, tnum) if need_full else (jlo, jhi)
         blk = synth.diffractor_radargram(snum, tnum, vel=vel, dtype=np_dtype, trace_lo=lo, trace_hi=hi, chunk=128,
                                          threads=host_threads())

@@ -720,20 +720,47 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_tab_kernel(FastParams P
 // banks inside one ds_read_b128 lane group)
 __host__ __device__ constexpr int kq_ring_slots(int xb) { return ((xb + 15 + 7) / 8) * 8; }
 __host__ __device__ constexpr int kq_piece_bytes(int xb) { return ((kq_ring_slots(xb) / 8 * KQ_GS + 255) / 256) * 256; }
+// ... and with LK extra ring groups (deeper staging lookahead, see kirch_quad_kernel)
+__host__ __device__ constexpr int kq_piece_bytes_lk(int xb, int lk) { return (((kq_ring_slots(xb) / 8 + lk) * KQ_GS + 255) / 256) * 256; }
+static_assert(kq_piece_bytes_lk(40, 0) == 7424 && kq_piece_bytes_lk(40, 1) == 8448 && kq_piece_bytes_lk(24, 0) == 5376, "");
 static_assert(kq_ring_slots(24) == 40 && kq_piece_bytes(24) == 5376 && kq_ring_slots(32) == 48 && kq_piece_bytes(32) == 6400 &&
               kq_ring_slots(40) == 56 && kq_piece_bytes(40) == 7424, "");
+#ifndef KQ_DEFAULT_NH
+#define KQ_DEFAULT_NH 1     // output tiles per workgroup of the quad kernel (IMPDAR_KIRCH_NH overrides)
+#endif
+#ifndef KQ_DEFAULT_LK
+#define KQ_DEFAULT_LK 0     // extra ring groups / blocks of staging lookahead with NH >= 2 (IMPDAR_KIRCH_LK overrides)
+#endif
 #ifndef KQ_PER
 #define KQ_PER 4            // quads per interleave slice (1..7 all measure within 2 %; 4 keeps 97 VGPRs)
 #endif
 typedef float kq_f4 __attribute__((ext_vector_type(4)));
 typedef unsigned kq_u4 __attribute__((ext_vector_type(4)));
 
-template <int XB, bool NEAR, int OCC, int SH>
-__global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams P, int W)
+// NH > 1: NH tiles of XB output traces share ONE ring in one workgroup of 256 NH threads (waves 4h .. 4h+3 own
+// tile h = outputs x0 + h XB ...).  Tile h walks the trace offset XB steps BEHIND tile h - 1
+// (n_h = n_0 - h XB), so that at every step all tiles read the same XB + 16 ring slots: the staged traces, the
+// DMA that brings them and the barrier are shared, only the pick row (h XB / 8 rows behind, re-read from L2 a few
+// blocks after the neighbour tile fetched it) and the obliquity factor differ.  The staging window grows by the
+// moveout over (NH - 1) XB traces.  Per output this stages NH x fewer image bytes and puts 4 NH waves on the CU.
+//
+// LK = 1: one more 8-trace group in the ring, and the staging DMA runs one block further ahead (it then has two
+// blocks, ~2.6 us, to land instead of one).  What the kernel loses to vector memory is not bytes (NH = 2 halves
+// the fabric traffic and gains nothing) but the tail of the load latency: s_waitcnt vmcnt retires loads in issue
+// order and every wave must see its DMA landed in front of each block's barrier, so one slow fetch parks four
+// (or 4 NH) waves.  The extra group only fits with NH >= 2 (one workgroup per CU, LDS to spare).  The pick rows
+// and window lookups are ordinary loads the compiler counts; their pipeline is deepened to PD blocks so that
+// each is older than everything the block's wait leaves in flight (the compiler then adds no waits of its own,
+// which would drain the younger DMA as well).
+template <int XB, bool NEAR, int OCC, int SH, int NH, int LK>
+__global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastParams P, int W)
 {
     constexpr int S = 8;
-    constexpr int RG = kq_ring_slots(XB);     // ring slots
-    constexpr int KQ_PS = kq_piece_bytes(XB);
+    constexpr int RG = kq_ring_slots(XB) + 8 * LK;     // ring slots
+    constexpr int KQ_PS = kq_piece_bytes_lk(XB, LK);
+    constexpr int PD = 2 * LK + 1;            // blocks between the issue of a pick row / window lookup and its first use
+    static_assert(LK == 0 || LK == 1, "staging lookahead of one or two blocks");
+    static_assert(LK == 0 || !NEAR, "the deeper ring is not laid out for the second (near field) image");
     constexpr int G0 = XB / 8;                // a block's new traces belong to image / ring group blk + G0
     constexpr int KQ_PARTS = (XB / 4 + 1 + KQ_PER - 1) / KQ_PER;   // interleave slices per step
     constexpr int NB = RG / S;                // step blocks per ring revolution (unroll length)
@@ -753,9 +780,11 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & (KF_THREADS - 1);                  // lane-and-wave index inside the tile
+    const int half = NH > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;   // which tile of the workgroup
     const int s0 = chunk * KF_THREADS;
-    const int x0 = (P.xlo & ~7) + xt * XB;       // tiles start at a multiple of 8 (outputs left of xlo are not stored)
+    const int x0w = (P.xlo & ~7) + xt * (XB * NH);   // workgroup's first output trace: a multiple of 8 (outputs left of xlo are not stored)
+    const int x0 = x0w + half * XB;
     const int snum = P.snum, tnum = P.tnum;
     // ds_read_b128 is serviced in four groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31},
     // {32-35,44-47,52-59}, {36-43,48-51,60-63}).  Give every group 16 CONSECUTIVE samples: their
@@ -773,24 +802,28 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     // first offset: the 8 traces a step block adds must be one aligned 8-row group of the image
     // (ring-relative trace q0 = 8 blk + XB - 1  ->  x0 + nlo = 1 mod 8, i.e. nlo = 1 mod 8); the up to
     // 7 extra leading steps lie outside every aperture of the chunk and pick the all-zero row
-    int nlo_ = max(-hmax, -(x0 + XB - 1));
+    // (the offsets below are tile 0's: the ring clock.  Tile h is at offset n - h XB and needs the clock to run
+    // until its own last offset, (NH - 1) XB steps longer)
+    int nlo_ = max(-hmax, -(x0w + XB - 1));
     nlo_ -= (nlo_ - 1) & 7;
     const int nlo = nlo_;
-    const int nhi = min(hmax, tnum - 1 - x0);
+    const int nhi = min(hmax + (NH - 1) * XB, tnum - 1 - x0w);
     const int nsteps = nhi - nlo + 1;
     const int nblocks = (nsteps + S - 1) / S;
     // the main loop always runs whole ring revolutions (NB blocks); steps past the
     // aperture pick the table's all-zero row, so they add nothing
     const int nrev = (nblocks + NB - 1) / NB;
-    const int jbase = x0 + nlo;
+    const int jbase = x0w + nlo;
     // table row of block 0 (block b covers n = nlo + 8 b .. + 7); rows past the tables' end (only the
     // padding blocks of the last revolution can get there) are clamped to the last, all-dropped row
     const int mrow = ((nlo - 1) >> 3) + P.mrow0;
     auto row_of = [&](int blk) { return min(mrow + blk, P.nrows - 1); };
+    // this tile's pick rows: half * XB offsets behind the clock (the table keeps 8 all-dropped rows at its start)
+    const int mrow_h = mrow - half * (XB / 8);
 #ifdef KQ_DIAG_PICKHOT      // diagnostic build: every pick load hits the same 16 table rows (L2-hot); results invalid
-    auto prow_of = [&](int blk) { return (mrow + blk) & 15; };
+    auto prow_of = [&](int blk) { return (mrow_h + blk) & 15; };
 #else
-    auto prow_of = row_of;
+    auto prow_of = [&](int blk) { return max(min(mrow_h + blk, P.nrows - 1), 0); };
 #endif
 
     // Staging window of the 8 traces block `blk_for` adds: one 8-byte lookup, issued ONE BLOCK EARLIER
@@ -834,13 +867,14 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     const float c1 = P.c1[ti], c2 = NEAR ? P.c2[ti] : 0.f, fin = P.fin[ti];
     // n^2 of a step: scalar multiply + one conversion (in-aperture offsets are < 65536, so the product
     // fits 32 bits; padding steps may wrap, they only ever meet the all-zero row)
+    const int nlo_h = nlo - half * XB;
     auto n2_of = [&](int step) {
-        const int n = nlo + step;
+        const int n = nlo_h + step;
         return (float)((unsigned)n * (unsigned)n);
     };
 
     if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds != 0u) __builtin_trap();
-    for (int e = tid; e < (int)(img_bytes / 4) * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
+    for (int e = threadIdx.x; e < (int)(img_bytes / 4) * (NEAR ? 2 : 1); e += KF_THREADS * NH) lds[e] = 0.f;
     __syncthreads();
     // Pick rows are requested TWO blocks ahead (KQ_PICK_AHEAD = 2): a row that misses the XCD's L2 (the table is
     // 61 MB, a chunk's slice 3.8 MB) takes longer than one block (~1.3 us) to arrive, and with one block of
@@ -853,7 +887,9 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
 #endif
     kq_u4 tkc = picks(0);                          // picks of the current block
 #if KQ_PICK_AHEAD == 2
-    kq_u4 tkn = picks(1);                          // ... and of the next one
+    kq_u4 tkp[PD + 1];                             // ... of the next one (tkp[0]) and of those behind it
+#pragma unroll
+    for (int j = 0; j < PD; ++j) tkp[j] = picks(1 + j);
 #endif
 
     // accumulators in quads: the ordering pin below takes them as XB/4 operands of ONE asm statement
@@ -867,7 +903,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     // ds_write.  Lane l of a piece writes bytes [16 l, 16 l + 16) of the piece: row 32 piece + l/2,
     // half (l & 1); its SOURCE is the sample congruent to that row in [kmin, kmin + W) and the half
     // the row's swap puts there.  Pieces are dealt to the four waves round robin.
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave index, in a scalar register
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wave index in the workgroup, in a scalar register
     const int rl = lane >> 1;                                  // row of this lane inside a piece
     const unsigned hsel = ((unsigned)(lane & 1) ^ ((unsigned)(rl >> 3) & 1u)) * 16u;
     // The DMA is inline asm on purpose: hipcc treats its own LDS-DMA as a pending LDS write and drains it
@@ -891,7 +927,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
 #else
         const unsigned so = (unsigned)(blk_for + G0) * grp_bytes;     // image group of trace jbase + q0
 #endif
-        for (int pc = wv; pc < npieces; pc += 4) {
+        for (int pc = wv; pc < npieces; pc += 4 * NH) {
             int t = pc * 32 + rl - kmod;
             t += (t < 0) ? W : 0;
 #ifdef KQ_DIAG_STAGEONE     // diagnostic build: every DMA lane reads the same 32 bytes of its image group
@@ -906,16 +942,23 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
     };
     // ring position of ring-relative trace q is (q + 1) % RG: the 8 traces a block adds are one ring
     // group; the ring starts with the four groups q = -1 .. 30
-    int wa, wb, wn = 0;
+    int wa, wb;
     for (int pb = -G0; pb <= 0; ++pb) {
         fetch_for(pb, wa, wb);
         dma_issue(pb, wa);
     }
-    fetch_for(1, wa, wb);
+    int wl[LK + 1], wp[PD];                        // windows of the DMAs issued in the prologue / in the first PD blocks
+#pragma unroll
+    for (int j = 0; j <= LK; ++j) fetch_for(1 + j, wl[j], wb);
+#pragma unroll
+    for (int j = 0; j < PD; ++j) fetch_for(2 + LK + j, wp[j], wb);
     __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
     __syncthreads();
-    dma_issue(1, wa);                              // block 1's traces land during block 0
-    fetch_for(2, wa, wb);                          // used by the DMA issued at the end of block 0
+#pragma unroll
+    for (int j = 0; j <= LK; ++j) dma_issue(1 + j, wl[j]);     // block 1's (and 2's) traces land during block 0
+    // DMA instructions this wave issues per block (its share of the pieces): the in-order wait in front of the
+    // barrier leaves one block's worth of them in flight when LK = 1
+    const int dma_c = __builtin_amdgcn_readfirstlane((npieces - wv + 4 * NH - 1) / (4 * NH));
 
     // ---- the resident ring is read software pipelined: the ds_read_b128 of step s+1 are in flight
     // while the FMAs of step s run (two statically indexed quad buffers), also across block ends
@@ -1017,14 +1060,15 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
             // held traces last read at step 6 of the previous block, and every wave is past that block's
             // barrier, which sits after step 6: no wave can still be reading them.
 #ifdef KQ_DIAG_NOPICK
-            const kq_u4 tkf = tkc;
+            tkp[PD] = tkc;
 #elif KQ_PICK_AHEAD == 2
-            const kq_u4 tkf = picks(blk + 2);
+            tkp[PD] = picks(blk + PD + 1);
 #else
             const kq_u4 tkn = picks(blk + 1);
 #endif
+            int wn = 0;
 #if !defined(KQ_DIAG_NOSTAGE)
-            fetch_for(blk + 3, wn, wb);                // staging window of the DMA after the next one
+            fetch_for(blk + 2 + LK + PD, wn, wb);      // staging window of a DMA issued PD blocks from now
 #endif
             // obliquity cos(theta) of this block's steps
             float twc[S], tw2c[NEAR ? S : 1];
@@ -1060,7 +1104,15 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
 #ifndef KQ_DIAG_NODMAWAIT
             // a builtin so that hipcc's own wait counting sees it
 #if KQ_PICK_AHEAD == 2 && !defined(KQ_DIAG_NOSTAGE) && !defined(KQ_DIAG_NOPICK)
-            __builtin_amdgcn_s_waitcnt(0x0F72);        // vmcnt(2): all but this block's pick row + window lookup
+            if (LK == 0) {
+                __builtin_amdgcn_s_waitcnt(0x0F72);    // vmcnt(2): all but this block's pick row + window lookup
+            } else if (blk < LK || dma_c == 0) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);    // pipeline not yet full (or a wave without a DMA share): everything
+            } else if (dma_c == 1) {
+                __builtin_amdgcn_s_waitcnt(0x0F75);    // vmcnt(5): two blocks of pick + window lookups and one DMA
+            } else {
+                __builtin_amdgcn_s_waitcnt(0x0F76);    // vmcnt(6): ... and two DMAs
+            }
 #else
             __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) only
 #endif
@@ -1070,16 +1122,25 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
 #endif
 #if !defined(KQ_DIAG_NOSTAGE)
             // every wave is past step 6 of this block: the ring group of the traces last read there is free
-            dma_issue(blk + 2, wa);
-            wa = wn;
+            dma_issue(blk + 2 + LK, wp[0]);
+#pragma unroll
+            for (int j = 0; j + 1 < PD; ++j) wp[j] = wp[j + 1];
+            wp[PD - 1] = wn;
 #endif
-            KQ_STEP(((pm0 + 8) % RG, KQ_TK(tkn, 0), va, ua), (pm0 + 7, twc[7], KQ_W2(7), vb, ub));
+#if KQ_PICK_AHEAD == 2
+#define KQ_NEXT tkp[0]
+#else
+#define KQ_NEXT tkn
+#endif
+            KQ_STEP(((pm0 + 8) % RG, KQ_TK(KQ_NEXT, 0), va, ua), (pm0 + 7, twc[7], KQ_W2(7), vb, ub));
 #undef KQ_W2
 #undef KQ_STEP
 #undef KQ_UNPACK
-            tkc = tkn;
-#if KQ_PICK_AHEAD == 2 || defined(KQ_DIAG_NOPICK)
-            tkn = tkf;
+            tkc = KQ_NEXT;
+#undef KQ_NEXT
+#if KQ_PICK_AHEAD == 2
+#pragma unroll
+            for (int j = 0; j < PD; ++j) tkp[j] = tkp[j + 1];
 #endif
         }
     }
@@ -1101,7 +1162,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_quad_kernel(FastParams 
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long *o = P.stamps + (size_t)blockIdx.x * 4;
+        unsigned long long *o = P.stamps + ((size_t)blockIdx.x * NH + half) * 4;
         o[0] = t_start;
         o[1] = __builtin_amdgcn_s_memrealtime();
         o[2] = ((unsigned long long)xcc << 32) | hwid;
@@ -1459,6 +1520,8 @@ struct impdar_kirch_plan {
     DevBuf d_stamps;               // diagnostic builds only
     int nb = 0, ntab = 0;
     bool quad = false;          // sample-major LDS ring (kirch_quad_kernel)
+    int nh = 1;                 // quad kernel: output tiles per workgroup sharing one ring (256 nh threads)
+    int lk = 0;                 // ... and extra ring groups = blocks of additional staging lookahead (nh >= 2 only)
     bool dquad = false;         // the same ring in float64 (kirch_dquad_kernel): exact mode, float64 data, uniform grids
     bool tie_ambiguous = false; // kirch_tiescan_kernel found a pick that rounding noise decides: per-pair kernel only
     DevBuf d_c1d, d_c2d, d_find;
@@ -1576,11 +1639,34 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         else if ((size_t)(rows_for(40) / 32) * kq_piece_bytes(40) <= 80 * 1024 && (long long)tnum >= 2000LL * nranks)
             xbq = 40;
     }
-    const int kq_ps = kq_piece_bytes(xbq);
-    const int wq = ((KF_THREADS + (int)std::ceil(sa * (xbq + 8 - 2)) + 8 + 31) / 32) * 32;   // whole 32-row pieces
+    int kq_ps = kq_piece_bytes(xbq);
+    // tiles per workgroup on one ring (see kirch_quad_kernel, NH): the staging window grows by the moveout over
+    // the (nh - 1) xb traces the later tiles lag behind; one workgroup per CU then (up to the whole 160 KB)
+    int nhq = 1;
+    {
+        const char *ne = getenv("IMPDAR_KIRCH_NH");         // tuning knob: 1 | 2 | 3
+        const int want = ne ? atoi(ne) : KQ_DEFAULT_NH;
+        auto rows_nh = [&](int nh) { return ((KF_THREADS + (int)std::ceil(sa * (xbq * nh + 8 - 2)) + 8 + 31) / 32) * 32; };
+        if ((want == 2 || want == 3) && xbq == 40 && !nearfield && (ne || (long long)tnum >= 2000LL * nranks) &&
+            (size_t)(rows_nh(want) / 32) * kq_ps <= 160 * 1024 && (size_t)(rows_nh(want) / 32) * kq_ps > 65535)
+            nhq = want;
+    }
+    p->nh = nhq;
+    int lkq = 0;
+    {
+        const char *le = getenv("IMPDAR_KIRCH_LK");         // tuning knob: 0 | 1
+        const int want = le ? atoi(le) : KQ_DEFAULT_LK;
+        const int rows = ((KF_THREADS + (int)std::ceil(sa * (xbq * nhq + 8 - 2)) + 8 + 31) / 32) * 32;
+        // every wave must own at least one DMA piece per block (the in-order wait counts on it)
+        if (want == 1 && nhq >= 2 && rows / 32 >= 4 * nhq && (size_t)(rows / 32) * kq_piece_bytes_lk(xbq, 1) <= 160 * 1024)
+            lkq = 1;
+    }
+    p->lk = lkq;
+    kq_ps = kq_piece_bytes_lk(xbq, lkq);
+    const int wq = ((KF_THREADS + (int)std::ceil(sa * (xbq * nhq + 8 - 2)) + 8 + 31) / 32) * 32;   // whole 32-row pieces
     // (two workgroups per CU: 80 KB of LDS each; table entries are 16-bit byte offsets up to 12 pieces,
     // 16-byte units beyond)
-    const bool quad_ok = (size_t)(wq / 32) * kq_ps <= 80 * 1024;
+    const bool quad_ok = (size_t)(wq / 32) * kq_ps <= (nhq > 1 ? 160 : 80) * 1024;
     const bool tab_ok = (KF_THREADS + sa * (16 - 1) + 8.0) <= (double)KF_W;
     const bool window_ok = quad_ok || tab_ok;
     // aperture half width in traces (upper bound): below 65536 (the kernel squares trace offsets in 32
@@ -1827,7 +1913,9 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
             // the XB-trace window of a lane at its last slot and leave it XB - 1 steps later)
             std::vector<int> win((size_t)nch * p->nrows * 2);
             for (int r = 0; r < p->nrows; ++r) {
-                const long long na = (long long)ringS * (r - p->mrow0) + 1, nz = na + p->xb + ringS - 2;
+                // (with nh tiles on one ring the later tiles read the same traces (nh - 1) xb offsets earlier)
+                const long long nz = (long long)ringS * (r - p->mrow0) + 1 + p->xb + ringS - 2;
+                const long long na = (long long)ringS * (r - p->mrow0) + 1 - (long long)(p->quad ? p->nh - 1 : 0) * p->xb;
                 const long long lo = (na <= 0 && nz >= 0) ? 0 : std::min(std::llabs(na), std::llabs(nz));
                 const long long hi = std::max(std::llabs(na), std::llabs(nz));
                 for (int c = 0; c < nch; ++c) {
@@ -1963,7 +2051,7 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
         T.nmax = p->ntab - 1;
         T.wmod = p->quadW;
         T.sh = p->quadSH;
-        T.ps = p->dquad ? kd_piece_bytes(p->xb) : kq_piece_bytes(p->xb);
+        T.ps = p->dquad ? kd_piece_bytes(p->xb) : kq_piece_bytes_lk(p->xb, p->lk);
         // rows a + mrow0 (a >= 0) and mrow0 - a - 1: a runs over the larger of the two sides
         const int na = std::max(p->nrows - p->mrow0, p->mrow0);
         if (p->dquad)
@@ -2011,11 +2099,11 @@ int impdar_kirch_prep_precomputed(impdar_kirch_plan *p, const void *d_grad, int 
     return kirch_prep_impl(p, d_grad, ld, jlo, nloc, 1);
 }
 
-template <int XB, int OCC, int SH>
+template <int XB, int OCC, int SH, int NH = 1, int LK = 0>
 static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipStream_t st)
 {
     FastParams P = P0;
-    const int ntiles = (P.xhi - (P.xlo & ~7) + XB - 1) / XB;      // tiles start at a multiple of 8
+    const int ntiles = (P.xhi - (P.xlo & ~7) + XB * NH - 1) / (XB * NH);      // workgroup tiles start at a multiple of 8
     P.nxt = ntiles;
     {
         const char *ge = getenv("IMPDAR_KIRCH_G");        // tuning knob: adjacent trace tiles per XCD group
@@ -2030,15 +2118,15 @@ static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipSt
     P.tiles_per_xcd = nxt_pad / 8;
     const int nblk = P.nchunks * nxt_pad;
     const int W = p->quadW;
-    const size_t shmem = (size_t)(W / 32) * kq_piece_bytes(XB) * (p->nearfield ? 2 : 1);
+    const size_t shmem = (size_t)(W / 32) * kq_piece_bytes_lk(XB, LK) * (p->nearfield ? 2 : 1);
     if (p->nearfield) {
-        auto k = kirch_quad_kernel<XB, true, 1, SH>;
+        auto k = kirch_quad_kernel<XB, true, 1, SH, 1, 0>;
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(k, dim3(nblk), dim3(KF_THREADS), shmem, st, P, W);
     } else {
-        auto k = kirch_quad_kernel<XB, false, OCC, SH>;
+        auto k = kirch_quad_kernel<XB, false, OCC, SH, NH, LK>;
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k, dim3(nblk), dim3(KF_THREADS), shmem, st, P, W);
+        hipLaunchKernelGGL(k, dim3(nblk), dim3(KF_THREADS * NH), shmem, st, P, W);
     }
     IMPDAR_HIP_CHECK(hipGetLastError());
     return IMPDAR_OK;
@@ -2159,6 +2247,10 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
             rc = p->xb == 40 ? launch_quad<40, 2, 0>(p, P, nx, st)
                  : p->xb == 32 ? launch_quad<32, 2, 0>(p, P, nx, st)
                  : (occ0 == 2) ? launch_quad<24, 2, 0>(p, P, nx, st) : launch_quad<24, 3, 0>(p, P, nx, st);
+        else if (p->quad && p->nh == 2 && p->xb == 40)
+            rc = p->lk ? launch_quad<40, 2, 4, 2, 1>(p, P, nx, st) : launch_quad<40, 2, 4, 2, 0>(p, P, nx, st);
+        else if (p->quad && p->nh == 3 && p->xb == 40)
+            rc = p->lk ? launch_quad<40, 3, 4, 3, 1>(p, P, nx, st) : launch_quad<40, 3, 4, 3, 0>(p, P, nx, st);
         else if (p->quad)
             rc = p->xb == 40 ? launch_quad<40, 2, 4>(p, P, nx, st)
                  : p->xb == 32 ? launch_quad<32, 2, 4>(p, P, nx, st)

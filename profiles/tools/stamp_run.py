@@ -45,3 +45,7 @@ for x in range(8):
     m=xcc==x
     print('xcc',x,'WGs',int(m.sum()),'last end',round(float(end[m].max()),1),'sum dur',round(float(dur[m].sum()),0))
 cu=(hwid>>8)&0xf; se=(hwid>>13)&0x7
+slots = 256 * (2 if os.environ.get('IMPDAR_KIRCH_NH', '1') == '1' else 1)
+print('slot utilisation: sum of workgroup durations / (%d slots x kernel span) = %.4f' % (slots, dur.sum() / (slots * end.max())))
+T2 = np.linspace(0.80 * end.max(), end.max(), 21)
+print('resident WGs over the last 20 %:', [int(((start <= t) & (end > t)).sum()) for t in T2])

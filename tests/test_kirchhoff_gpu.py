@@ -564,3 +564,42 @@ def test_ties_that_rounding_noise_decides_go_to_the_per_pair_kernel(hip, monkeyp
         plan = KirchhoffPlan(ctx, dtype, 4096, 10000, g3['dist'], g3['travel_time'], 1.69e8, False, 'auto')
         assert plan.kernel == kern
         plan.destroy()
+
+
+@pytest.mark.parametrize('nh,lk', [('2', '0'), ('3', '0'), ('2', '1'), ('3', '1')])
+def test_several_tiles_per_workgroup_on_one_ring(hip, nh, lk, monkeypatch):
+    """IMPDAR_KIRCH_NH: nh tiles of 40 output traces share one LDS ring in a workgroup of 256 nh threads, tile h
+    walking 40 h offsets behind tile 0.  Same picks, same sums: the result must equal the one-tile kernel bit for
+    bit (every output accumulates its pairs in the same order), on ragged sizes, blocks that start anywhere and
+    a first sample before the trigger.  IMPDAR_KIRCH_LK = 1 adds a ring group and runs the staging DMA one block
+    further ahead."""
+    from impdar_amd import _hip, synth
+    from impdar_amd.kirchhoff import KirchhoffPlan
+    from oracle import c_oracle
+    ctx = hip.context()
+    for snum, tnum, dx, t0 in ((700, 333, 1.0, 0.0), (300, 95, 1.3, -0.02), (1100, 170, 0.4, 0.004)):
+        geo = synth.geometry(snum, tnum, dx=dx, t0_us=t0)
+        x = synth.noise_radargram(snum, tnum, seed=31).astype(np.float32)
+        outs = {}
+        for which in ('1', nh):
+            monkeypatch.setenv('IMPDAR_KIRCH_XB', '40')
+            monkeypatch.setenv('IMPDAR_KIRCH_NH', which)
+            monkeypatch.setenv('IMPDAR_KIRCH_LK', lk if which != '1' else '0')
+            plan = KirchhoffPlan(ctx, np.float32, snum, tnum, geo['dist'], geo['travel_time'], mode='fast')
+            assert plan.kernel == 'kirch_quad_kernel'
+            d_in = _hip.DeviceArray.from_host(ctx, x)
+            plan.prep(d_in, tnum, 0, tnum)
+            res = []
+            for xlo, xhi in ((0, tnum), (13, min(141, tnum)), (tnum - 1, tnum)):
+                d_out = _hip.DeviceArray(ctx, (snum, xhi - xlo), np.float32)
+                plan.migrate(d_out, xlo, xhi)
+                plan.sync()
+                res.append(d_out.to_host())
+                d_out.free()
+            plan.destroy()
+            d_in.free()
+            outs[which] = res
+        want = c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], 1.69e8)
+        assert rel_l2(outs[nh][0], want) < FAST_L2
+        for a, b in zip(outs['1'], outs[nh]):
+            assert np.array_equal(a, b)
