@@ -123,6 +123,8 @@ struct PsParams {
     const double *thr;      // [snum] (v(z) mode): (tau/tt[-1]/1e6)^2
     double vconst, dt;
     double vtol;            // float32 v(z): relative velocity change below which the phase increments are reused
+    const int *sched;       // float32 v(z), ps_vz32_kernel: [snum] 1 where a new constant-velocity run starts
+    const int *tsched;      // ... [ceil(snum/16)] 1 where a 16-step tile holds such a step
     int snum, tnum, nt, vz_mode;
 };
 
@@ -482,11 +484,215 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
     }
 }
 
+// ---------------------------------------------------------------------------
+// float32 v(z) (Gazdag), layered profiles: the depth axis is cut into runs of constant velocity (the host
+// marks the steps where the velocity moves by more than P.vtol, the same rule ps_kernel applies on the fly),
+// and inside a run every frequency turns by a fixed rotation -- the constant-velocity inner loop.  A 16-step
+// tile without a run boundary, without a boundary frequency in the workgroup and inside the axis takes the
+// fully unrolled rotate-accumulate body of the constant-velocity kernel (6 instructions per (tau, frequency));
+// every other tile walks its steps one by one with the general update (velocity change: fold the pending
+// steps into the fp64 phase, new fp64 increment, evanescence settled for the run, mig_python.py:456-485;
+// boundary frequencies re-evaluated in fp64 at every step's own velocity; anchors).  The state is anchored
+// to FK0 * exp(i Phi) with the fp64 phase at every run start and at least every 64 steps.
+// Registers per owned frequency: the rotating state, the run's rotation and the fp64 phase at the last
+// anchor; the original spectrum FK0 and the fp64 increment live in LDS ([m][thread], each thread reads only
+// what it wrote) -- 128 KB at 8192 frequencies, one workgroup per CU.
+// ---------------------------------------------------------------------------
+template <int BLOCK, int M>
+__global__ __launch_bounds__(BLOCK) void ps_vz32_kernel(PsParams P)
+{
+    constexpr int TT = 16;
+    constexpr int NW = BLOCK / 64;
+    extern __shared__ __attribute__((aligned(16))) char ps_smem[];
+    double *phd_lds = reinterpret_cast<double *>(ps_smem);                              // [M][BLOCK] fp64 increment of the run
+    float2 *f0_lds = reinterpret_cast<float2 *>(ps_smem + (size_t)M * BLOCK * 8);       // [M][BLOCK] original spectrum
+    float(*red)[NW][2 * TT] = reinterpret_cast<float(*)[NW][2 * TT]>(ps_smem + (size_t)M * BLOCK * 16);
+    const int k = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Cp<float> *F = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.nt;
+    Cp<float> *TK = reinterpret_cast<Cp<float> *>(P.TK) + (size_t)k * P.snum;
+    const double kxk = P.kx[k];
+
+    float gr[M], gi[M];      // FK0 * exp(i Phi_tau): the rotating state
+    float pc[M], ps[M];      // exp(i increment) of the current run
+    double Phi[M];           // accumulated phase at the last anchor, kept in [-pi, pi]
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int iw = tid + m * BLOCK;
+        float2 f = make_float2(0.f, 0.f);
+        if (iw < P.nt) {
+            const Cp<float> c = F[iw];
+            f = make_float2(c.x, c.y);
+        }
+        f0_lds[m * BLOCK + tid] = f;
+        phd_lds[m * BLOCK + tid] = 0.0;
+        gr[m] = gi[m] = ps[m] = 0.f;
+        pc[m] = 1.f;
+        Phi[m] = 0.0;
+    }
+    auto rot32 = [](double ph, float *s, float *c) { sincos_t<float>((float)ph, s, c); };
+    auto anchor = [&](int nrec) {
+        // the state from the ORIGINAL spectrum and the fp64 phase: nrec steps at the run's increment since the last anchor
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            double ph = Phi[m] + (double)nrec * phd_lds[m * BLOCK + tid];
+            ph -= 6.283185307179586 * rint(ph * 0.15915494309189535);
+            Phi[m] = ph;
+            float sn, cs;
+            rot32(ph, &sn, &cs);
+            const float2 f = f0_lds[m * BLOCK + tid];
+            gr[m] = fmaf(f.x, cs, -(f.y * sn));          // FK0 * exp(i Phi), :464 cumulated
+            gi[m] = fmaf(f.x, sn, f.y * cs);
+            asm volatile("" : "+v"(gr[m]), "+v"(gi[m]));
+        }
+    };
+    unsigned edge = 0;       // bit m = frequency m sits on the evanescent boundary of the current run (|coss| < 1e-8)
+    bool wg_edge = false;    // ... some thread of the workgroup has one (uniform)
+    int nrec = 0;            // depth steps since the last anchor (uniform)
+
+    const int ntile = (P.snum + TT - 1) / TT;
+    for (int tile = 0; tile < ntile; ++tile) {
+        float acc[2 * TT];
+#pragma unroll
+        for (int i = 0; i < 2 * TT; ++i) acc[i] = 0.f;
+        const int tau0 = tile * TT;
+        const bool quiet = P.tsched[tile] == 0 && !wg_edge && tau0 + TT <= P.snum;      // uniform
+        if (quiet) {
+            if (nrec + TT > 64) {
+                anchor(nrec);
+                nrec = 0;
+            }
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const float nr = fmaf(gr[m], pc[m], -(gi[m] * ps[m]));     // FK *= exp(i w dt sqrt(coss)), :464
+                    const float ni = fmaf(gr[m], ps[m], gi[m] * pc[m]);
+                    gr[m] = nr;
+                    gi[m] = ni;
+                    acc[2 * t] += nr;                                           // TK[itau] += FK, :487
+                    acc[2 * t + 1] += ni;
+                    asm volatile("" : "+v"(gr[m]), "+v"(gi[m]), "+v"(acc[2 * t]), "+v"(acc[2 * t + 1]));
+                }
+            }
+            nrec += TT;
+        } else {
+#pragma unroll 1
+            for (int t = 0; t < TT; ++t) {
+                const int tau = tau0 + t;
+                if (tau >= P.snum) break;      // uniform
+                const double vd = P.vz[tau];
+                const float thr = (float)P.thr[tau];
+                const bool changed = P.sched[tau] != 0;      // uniform
+                if (changed) {
+                    unsigned new_edge = 0;
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        const int iw = tid + m * BLOCK;
+                        if (nrec > 0) {   // the steps since the last anchor turned by the OLD increment
+                            const double ph = Phi[m] + (double)nrec * phd_lds[m * BLOCK + tid];
+                            Phi[m] = ph - 6.283185307179586 * rint(ph * 0.15915494309189535);
+                        }
+                        double inc = 0.0, cs = 1.0;
+                        if (iw < P.nt) {
+                            const double w = P.w[iw];
+                            const double a = 0.5 * vd * kxk / w;                 // :456
+                            cs = 1.0 - a * a;
+                            inc = w * P.dt * (cs > 0.0 ? sqrt(cs) : 0.0);       // :458-460
+                        }
+                        // a frequency on the evanescent boundary (coss = 0 to rounding) is kept or dropped by the
+                        // sign of coss at every step's own velocity: advanced step by step below, in fp64
+                        const bool on_edge = fabs(cs) < 1e-8;
+                        const double use = on_edge ? 0.0 : inc;
+                        phd_lds[m * BLOCK + tid] = use;
+                        new_edge |= (on_edge ? 1u : 0u) << m;
+                        // evanescent at this velocity: zero from here on (:484-485; away from the boundary the
+                        // reference's threshold (tau/tt_end/1e6)^2 <= 1e-12 is the sign of coss)
+                        if (!on_edge && cs <= 0.0) f0_lds[m * BLOCK + tid] = make_float2(0.f, 0.f);
+                        float sn, c2;
+                        rot32(use, &sn, &c2);                                   // |increment| <= |w| dt <= pi
+                        pc[m] = c2;
+                        ps[m] = sn;
+                        asm volatile("" : "+v"(pc[m]), "+v"(ps[m]));
+                    }
+                    edge = new_edge;
+                    wg_edge = __syncthreads_or(new_edge != 0) != 0;
+                    nrec = 0;
+                }
+                nrec += 1;
+                if (changed || nrec == 64) {
+                    anchor(nrec);
+                    nrec = 0;
+                } else {
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        const float a = gr[m], b = gi[m];
+                        gr[m] = fmaf(a, pc[m], -(b * ps[m]));
+                        gi[m] = fmaf(a, ps[m], b * pc[m]);
+                    }
+                }
+                if (edge) {
+                    // boundary frequencies: this step's increment from this step's velocity, in fp64
+#pragma unroll
+                    for (int m = 0; m < M; ++m)
+                        if ((edge >> m) & 1u) {
+                            const double w = P.w[tid + m * BLOCK];
+                            const double a = 0.5 * vd * kxk / w;
+                            const double cs = 1.0 - a * a;
+                            double ph = Phi[m] + w * P.dt * (cs > 0.0 ? sqrt(cs) : 0.0);
+                            ph -= 6.283185307179586 * rint(ph * 0.15915494309189535);
+                            Phi[m] = ph;
+                            float sn, c2;
+                            rot32(ph, &sn, &c2);
+                            float2 f = f0_lds[m * BLOCK + tid];
+                            if ((float)cs <= thr) {                             // :484-485, stays zero afterwards
+                                f = make_float2(0.f, 0.f);
+                                f0_lds[m * BLOCK + tid] = f;
+                            }
+                            gr[m] = fmaf(f.x, c2, -(f.y * sn));
+                            gi[m] = fmaf(f.x, sn, f.y * c2);
+                        }
+                }
+                float pr[4] = {0, 0, 0, 0}, pi[4] = {0, 0, 0, 0};               // :487
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    pr[m & 3] += gr[m];
+                    pi[m & 3] += gi[m];
+                }
+                const float sr = (pr[0] + pr[1]) + (pr[2] + pr[3]), si = (pi[0] + pi[1]) + (pi[2] + pi[3]);
+#pragma unroll
+                for (int u = 0; u < TT; ++u)
+                    if (t == u) {   // uniform
+                        acc[2 * u] = sr;
+                        acc[2 * u + 1] = si;
+                    }
+            }
+        }
+        // ---- sum over frequencies: wave butterfly, then across waves via LDS
+        wave_reduce_scatter<float, 2 * TT>(acc, lane);
+        float(*buf)[2 * TT] = red[tile & 1];
+        if ((lane & 1) == 0) buf[wave][lane >> 1] = acc[0];
+        __syncthreads();
+        if (tid < 2 * TT) {
+            float sum = 0;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) sum += buf[q][tid];
+            const int tau = tau0 + (tid >> 1);
+            if (tau < P.snum) {
+                float *dst = reinterpret_cast<float *>(TK + tau) + (tid & 1);
+                *dst = sum / (float)P.snum;                                     // TK /= snum, :492
+            }
+        }
+        // red[] is double-buffered: the next tile writes the other buffer and the barrier of that tile
+        // orders it against these reads
+    }
+}
+
 struct PsPlan {
     int dtype = -1, snum = 0, tnum = 0, nt = 0;
     const impdar_ctx *owner = nullptr;   // plans and buffers live on this context's device and stream
     FftPlan f_time, f_trace, b_trace;
-    DevBuf X, TK, d_kx, d_w, d_vz, d_thr;
+    DevBuf X, TK, d_kx, d_w, d_vz, d_thr, d_sched;
 };
 static std::mutex g_ps_mu;
 static PsPlan *g_ps_plan = nullptr;
@@ -504,6 +710,16 @@ void impdar_ps_forget(const impdar_ctx *ctx)
 template <typename T, int BLOCK, int M>
 static void ps_launch(const PsParams &P, hipStream_t st)
 {
+    constexpr size_t vz32_lds = (size_t)M * BLOCK * 16 + 2 * (BLOCK / 64) * 32 * sizeof(float);
+    if constexpr (sizeof(T) == 4 && vz32_lds <= 160 * 1024) {
+        static const bool old_kernel = getenv("IMPDAR_PS_VZ_OLD") != nullptr;     // tuning knob: the per-step kernel
+        if (P.vz_mode && P.sched && !old_kernel) {
+            auto k = ps_vz32_kernel<BLOCK, M>;
+            (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vz32_lds);
+            hipLaunchKernelGGL(k, dim3(P.tnum), dim3(BLOCK), vz32_lds, st, P);
+            return;
+        }
+    }
     if (P.vz_mode)
         hipLaunchKernelGGL((ps_kernel<T, BLOCK, M, true>), dim3(P.tnum), dim3(BLOCK), 0, st, P);
     else
@@ -542,6 +758,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         pl.dtype = -1;
         if (pl.owner != ctx) {               // another device / stream: drop everything bound to the old one
             pl.X.release(); pl.TK.release(); pl.d_kx.release(); pl.d_w.release(); pl.d_vz.release(); pl.d_thr.release();
+            pl.d_sched.release();
             pl.owner = ctx;
         }
         int rc;
@@ -602,6 +819,31 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     {
         const char *e = getenv("IMPDAR_PS_VTOL");     // diagnostic knob
         P.vtol = e ? atof(e) : 1e-10;
+    }
+    P.sched = P.tsched = nullptr;
+    std::vector<int> sched;
+    if (vlen && !dbl) {
+        // runs of constant velocity (ps_vz32_kernel): a step starts a new run when its velocity differs from the
+        // run's first by more than vtol (relative) -- 2*gradient(z(t)) of a layered table is constant inside a
+        // layer up to ~4e-13 of rounding noise, and a 1e-10 velocity error moves the phase by < 3e-6 rad over
+        // 8192 steps (float32 path only).  Profiles that change at (nearly) every step keep the per-step kernel.
+        const int ntile = (snum + 15) / 16;
+        sched.assign((size_t)snum + ntile, 0);
+        double vrun = -1.0;
+        int ndirty = 0;
+        for (int i = 0; i < snum; ++i)
+            if (std::fabs(vmig[i] - vrun) > P.vtol * std::fabs(vmig[i])) {
+                sched[i] = 1;
+                ndirty += sched[snum + i / 16] ? 0 : 1;
+                sched[snum + i / 16] = 1;
+                vrun = vmig[i];
+            }
+        if (2 * ndirty <= ntile || snum <= 64) {
+            IMPDAR_HIP_CHECK(pl.d_sched.ensure(sched.size() * sizeof(int)));
+            IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_sched.p, sched.data(), sched.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            P.sched = pl.d_sched.as<int>();
+            P.tsched = P.sched + snum;
+        }
     }
     if ((rc = ps_dispatch<T>(P, st))) return rc;
     if ((rc = pl.b_trace.exec(pl.TK.p, nullptr))) return rc;

@@ -1,0 +1,7 @@
+"""Device ms of the config-2 (Stolt) and config-5 (Gazdag v(z)) paths, resident, a few repetitions (same-box A/B of
+environment knobs: run it under different IMPDAR_* settings)."""
+import sys, os, json
+sys.path.insert(0, os.getcwd())
+import bench
+r = bench.path_records(True)
+print(json.dumps({k: {'device_ms': v['device_ms'], 'call_ms': v['call_ms'], 'frac': v['roofline']['frac']} for k, v in r.items()}))
