@@ -22,11 +22,30 @@ def _gpu_present():
 def test_host_shim_under_asan_and_ubsan(tmp_path):
     san = ['-fsanitize=address,undefined', '-fno-gpu-sanitize', '-fno-omit-frame-pointer', '-fno-sanitize-recover=undefined']
     lib = str(tmp_path / 'libimpdar_hip_san.so')
-    srcs = [os.path.join(ROOT, 'impdar_amd', 'csrc', s) for s in SOURCES]
-    cmd = [HIPCC, '--offload-arch=gfx950', '-O1', '-g', '-fPIC', '-std=c++17', '-ffp-contract=off', '-fno-slp-vectorize',
-           '-Wno-unused-function', '-shared'] + san + srcs + ['-o', lib, '-L/opt/rocm/lib', '-lrocfft', '-lrccl',
-                                                              '-Wl,-rpath,/opt/rocm/lib']
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1800)
+    # host pass only (--offload-host-only): the kernels' device code is what build() compiles; here it is the shim
+    # around them that runs, and no kernel can be launched without a device anyway.  Seconds instead of minutes.
+    objs, procs = [], []
+    for src in SOURCES:
+        o = str(tmp_path / (src[:-4] + '.o'))
+        objs.append(o)
+        procs.append(subprocess.Popen([HIPCC, '--offload-arch=gfx950', '--offload-host-only', '-O1', '-g', '-fPIC', '-std=c++17',
+                                       '-ffp-contract=off', '-Wno-unused-function', '-Wno-unused-command-line-argument'] + san +
+                                      ['-c', os.path.join(ROOT, 'impdar_amd', 'csrc', src), '-o', o],
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for pr in procs:
+        log = pr.communicate(timeout=1800)[0]
+        assert pr.returncode == 0, log[-4000:]
+    # a host-only object refers to its translation unit's device image by symbol; give each an empty one (it is only
+    # registered by address at load time, never opened without a device)
+    undef = subprocess.run(['nm', '-u'] + objs, capture_output=True, text=True).stdout
+    fat = sorted({w for w in undef.split() if w.startswith('__hip_fatbin_')})
+    stub = str(tmp_path / 'fatbin_stub.c')
+    with open(stub, 'w') as fo:
+        for sym in fat:
+            fo.write('__attribute__((aligned(4096))) const char %s[4096] = {0};\n' % sym)
+    out = subprocess.run([HIPCC, '-shared', '-fPIC'] + san + objs + ['-x', 'c', stub, '-o', lib, '-L/opt/rocm/lib', '-lrocfft', '-lrccl',
+                                                                     '-Wl,-rpath,/opt/rocm/lib'],
+                         capture_output=True, text=True, timeout=1800)
     assert out.returncode == 0, out.stderr[-4000:]
     exe = str(tmp_path / 'san_driver')
     clang = os.path.join(os.path.dirname(os.path.realpath(HIPCC)), '..', 'lib', 'llvm', 'bin', 'clang')
