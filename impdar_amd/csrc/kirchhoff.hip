@@ -383,6 +383,10 @@ struct FastParams {
     int snum, tnum, xlo, xhi;
     const int *hmax;               // per sample-chunk aperture half width (+1 guard)     [nchunks]
     int nchunks, nxt, tiles_per_xcd, G;
+    int *queue;                    // quad kernel, persistent workgroups: 8 item counters (one per XCD, 64 bytes apart), zeroed
+                                   // before the launch; null = one item per block
+    const short *tilemap;          // ring kernels: [nchunks][tiles_per_xcd][8] output tile of (chunk, slot, XCD), -1 = none
+                                   // (host-balanced over the XCDs by step count, build_tilemap); null: arithmetic rule
     // tab kernel only:
     const int *klo, *khi;          // per (chunk, |n|) first / last sample a trace at offset n is asked for
     int nb;                        // entries per chunk in klo/khi
@@ -770,18 +774,59 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
     const int npieces = W >> 5;               // W is a multiple of 32
     const unsigned img_bytes = (unsigned)npieces * KQ_PS;      // one image (gradient; data image behind it)
 
-    const int b = blockIdx.x;
-    const int xcd = b & 7, r = b >> 3;
-    const int chunk = r / P.tiles_per_xcd;
-    const int qx = r - chunk * P.tiles_per_xcd;
-    const int xt = ((qx / P.G) * 8 + xcd) * P.G + (qx % P.G);
-    if (chunk >= P.nchunks || xt >= P.nxt) return;
+    const int tid = threadIdx.x & (KF_THREADS - 1);                  // lane-and-wave index inside the tile
+    const int half = NH > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;   // which tile of the workgroup
+    // P.queue != null: persistent workgroups.  As many workgroups as fit the chip are launched, and each keeps
+    // pulling (chunk, tile) items: first from the list of the XCD it runs on (the balanced tile map, longest
+    // first), then, when that is empty, from the other XCDs' lists.  The XCDs of one MI355X differ by ~3 % in
+    // speed on this loop and blocks are dealt to them statically, so with one item per block the slowest XCD set
+    // the kernel's end; the queue also closes the gaps between workgroups and shortens the tail.
+    bool first_item = true;
+    int *item_slot = reinterpret_cast<int *>(lds) + (size_t)(img_bytes / 4) * (NEAR ? 2 : 1);
+    for (;;) {
+    int chunk, xt;
+    unsigned stamp_slot = blockIdx.x;
+    if (P.queue) {
+        __syncthreads();                       // every wave is done with the previous item (ring reads, the slot)
+        if (threadIdx.x == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            const int total = P.nchunks * P.tiles_per_xcd;
+            int it = -1;
+            for (int v = 0; v < 8 && it < 0; ++v) {
+                const int x = (int)((xcc + v) & 7u);
+                for (;;) {
+                    const int i = atomicAdd(P.queue + x * 16, 1);
+                    if (i >= total) break;
+                    const int t = (int)P.tilemap[(size_t)i * 8 + x];
+                    if (t >= 0 && t < P.nxt) {
+                        it = ((i / P.tiles_per_xcd) << 16) | t;
+                        item_slot[1] = i * 8 + x;
+                        break;
+                    }
+                }
+            }
+            item_slot[0] = it;
+        }
+        __syncthreads();
+        const int it = item_slot[0];
+        stamp_slot = (unsigned)item_slot[1];
+        if (it < 0) break;
+        chunk = it >> 16;
+        xt = it & 0xffff;
+    } else {
+        const int b = blockIdx.x;
+        const int xcd = b & 7, r = b >> 3;
+        chunk = r / P.tiles_per_xcd;
+        const int qx = r - chunk * P.tiles_per_xcd;
+        if (chunk >= P.nchunks) return;
+        xt = P.tilemap ? (int)P.tilemap[((size_t)chunk * P.tiles_per_xcd + qx) * 8 + xcd]
+                       : ((qx / P.G) * 8 + xcd) * P.G + (qx % P.G);
+        if (xt < 0 || xt >= P.nxt) return;
+    }
 #ifdef KQ_STAMP
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 #endif
-
-    const int tid = threadIdx.x & (KF_THREADS - 1);                  // lane-and-wave index inside the tile
-    const int half = NH > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;   // which tile of the workgroup
     const int s0 = chunk * KF_THREADS;
     const int x0w = (P.xlo & ~7) + xt * (XB * NH);   // workgroup's first output trace: a multiple of 8 (outputs left of xlo are not stored)
     const int x0 = x0w + half * XB;
@@ -873,9 +918,14 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
         return (float)((unsigned)n * (unsigned)n);
     };
 
-    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds != 0u) __builtin_trap();
-    for (int e = threadIdx.x; e < (int)(img_bytes / 4) * (NEAR ? 2 : 1); e += KF_THREADS * NH) lds[e] = 0.f;
-    __syncthreads();
+    if (first_item) {
+        // (later items of a persistent workgroup keep the image: every row a pick can point at is re-staged before
+        // it is read, and the all-zero spare row is never written)
+        if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds != 0u) __builtin_trap();
+        for (int e = threadIdx.x; e < (int)(img_bytes / 4) * (NEAR ? 2 : 1); e += KF_THREADS * NH) lds[e] = 0.f;
+        __syncthreads();
+        first_item = false;
+    }
     // Pick rows are requested TWO blocks ahead (KQ_PICK_AHEAD = 2): a row that misses the XCD's L2 (the table is
     // 61 MB, a chunk's slice 3.8 MB) takes longer than one block (~1.3 us) to arrive, and with one block of
     // lookahead that latency sat in front of every barrier (a build whose pick rows were always L2-hot ran
@@ -1162,13 +1212,16 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long *o = P.stamps + ((size_t)blockIdx.x * NH + half) * 4;
+        unsigned long long *o = P.stamps + ((size_t)stamp_slot * NH + half) * 4;
         o[0] = t_start;
         o[1] = __builtin_amdgcn_s_memrealtime();
         o[2] = ((unsigned long long)xcc << 32) | hwid;
         o[3] = ((unsigned long long)chunk << 32) | (unsigned)nsteps;
     }
 #endif
+    (void)stamp_slot;
+    if (!P.queue) break;
+    }   // item loop
 }
 
 // ---------------------------------------------------------------------------
@@ -1252,14 +1305,48 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_dquad_kernel(FastParams
     const int npieces = W >> 5;
     const unsigned img_bytes = (unsigned)npieces * KQ_PS;
 
-    const int b = blockIdx.x;
-    const int xcd = b & 7, r = b >> 3;
-    const int chunk = r / P.tiles_per_xcd;
-    const int qx = r - chunk * P.tiles_per_xcd;
-    const int xt = ((qx / P.G) * 8 + xcd) * P.G + (qx % P.G);
-    if (chunk >= P.nchunks || xt >= P.nxt) return;
-
     const int tid = threadIdx.x;
+    // persistent workgroups pulling (chunk, tile) items from per-XCD queues: see kirch_quad_kernel
+    bool first_item = true;
+    int *item_slot = reinterpret_cast<int *>(lds) + (size_t)(img_bytes / 4) * (NEAR ? 2 : 1);
+    for (;;) {
+    int chunk, xt;
+    if (P.queue) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            const int total = P.nchunks * P.tiles_per_xcd;
+            int it = -1;
+            for (int v = 0; v < 8 && it < 0; ++v) {
+                const int x = (int)((xcc + v) & 7u);
+                for (;;) {
+                    const int i = atomicAdd(P.queue + x * 16, 1);
+                    if (i >= total) break;
+                    const int t = (int)P.tilemap[(size_t)i * 8 + x];
+                    if (t >= 0 && t < P.nxt) {
+                        it = ((i / P.tiles_per_xcd) << 16) | t;
+                        break;
+                    }
+                }
+            }
+            item_slot[0] = it;
+        }
+        __syncthreads();
+        const int it = item_slot[0];
+        if (it < 0) break;
+        chunk = it >> 16;
+        xt = it & 0xffff;
+    } else {
+        const int b = blockIdx.x;
+        const int xcd = b & 7, r = b >> 3;
+        chunk = r / P.tiles_per_xcd;
+        const int qx = r - chunk * P.tiles_per_xcd;
+        if (chunk >= P.nchunks) return;
+        xt = P.tilemap ? (int)P.tilemap[((size_t)chunk * P.tiles_per_xcd + qx) * 8 + xcd]
+                       : ((qx / P.G) * 8 + xcd) * P.G + (qx % P.G);
+        if (xt < 0 || xt >= P.nxt) return;
+    }
     const int s0 = chunk * KF_THREADS;
     const int x0 = (P.xlo & ~3) + xt * XB;       // tiles start at a multiple of 4 (outputs left of xlo are not stored)
     const int snum = P.snum, tnum = P.tnum;
@@ -1328,9 +1415,12 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_dquad_kernel(FastParams
         return fma(y0, pp, y0);
     };
 
-    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds != 0u) __builtin_trap();
-    for (int e = tid; e < (int)(img_bytes / 4) * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
-    __syncthreads();
+    if (first_item) {
+        if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds != 0u) __builtin_trap();
+        for (int e = tid; e < (int)(img_bytes / 4) * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
+        __syncthreads();
+        first_item = false;
+    }
     kd_u2 tkc = picks(0);
 
     kd_d2 acc2[XB / 2];
@@ -1482,6 +1572,8 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_dquad_kernel(FastParams
             if (x0 + i >= P.xlo && x0 + i < P.xhi) o[i] = (fin == 0.0) ? 0.0 : KD_ACC(i) * fin;
     }
 #undef KD_ACC
+    if (!P.queue) break;
+    }   // item loop
 }
 
 // ===========================================================================
@@ -1520,6 +1612,11 @@ struct impdar_kirch_plan {
     DevBuf d_stamps;               // diagnostic builds only
     int nb = 0, ntab = 0;
     bool quad = false;          // sample-major LDS ring (kirch_quad_kernel)
+    std::vector<int> h_hmax;    // host copy of the per-chunk aperture half widths (tile cost model)
+    DevBuf d_queue;             // quad kernel, persistent workgroups: per-XCD item counters
+    DevBuf d_tilemap;           // ring kernels: (chunk, slot, XCD) -> output tile, balanced over the XCDs
+    std::vector<short> h_tilemap;
+    int tm_key[5] = {-1, -1, -1, -1, -1};   // (xlo, xhi, tile width, G, tiles_per_xcd) the cached map was built for
     int nh = 1;                 // quad kernel: output tiles per workgroup sharing one ring (256 nh threads)
     int lk = 0;                 // ... and extra ring groups = blocks of additional staging lookahead (nh >= 2 only)
     bool dquad = false;         // the same ring in float64 (kirch_dquad_kernel): exact mode, float64 data, uniform grids
@@ -1927,6 +2024,7 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
             }
             if ((rc = upload(p->d_WIN, win.data(), win.size() * 4))) return fail(rc);
         }
+        p->h_hmax = hmax;
         if ((rc = upload(p->d_hmax, hmax.data(), nch * 4)) || (rc = upload(p->d_klo, klo.data(), klo.size() * 4)) ||
             (rc = upload(p->d_khi, khi.data(), khi.size() * 4)))
             return fail(rc);
@@ -2099,6 +2197,65 @@ int impdar_kirch_prep_precomputed(impdar_kirch_plan *p, const void *d_grad, int 
     return kirch_prep_impl(p, d_grad, ld, jlo, nloc, 1);
 }
 
+// Which output tile a workgroup takes: blocks are dealt round-robin over the 8 XCDs (block b -> XCD b & 7), so slot
+// q of chunk c on XCD x is block ((c * tiles_per_xcd + q) * 8 + x).  The arithmetic rule (groups of G adjacent tiles
+// per XCD in turn) leaves the XCDs up to +-3 % apart in work at config 3: tiles near the ends of the profile walk
+// clipped apertures, and which XCD gets them depends on the tile count.  Here the groups of G adjacent tiles (they
+// share staging lines in the XCD's L2) are handed out per chunk, longest first, each to the XCD with the least
+// accumulated walk so far (steps rounded up to ring revolutions, plus a prologue's worth).  -1 = empty slot.
+static int build_tilemap(impdar_kirch_plan *p, FastParams &P, int tile_w, int align_mask, int ring_blocks, int step_block,
+                         hipStream_t st)
+{
+    static const bool off = getenv("IMPDAR_KIRCH_TILEMAP") && !strcmp(getenv("IMPDAR_KIRCH_TILEMAP"), "0");
+    P.tilemap = nullptr;
+    if (off || (int)p->h_hmax.size() != P.nchunks) return IMPDAR_OK;
+    const int key[5] = {P.xlo, P.xhi, tile_w, P.G, P.tiles_per_xcd};
+    const size_t n = (size_t)P.nchunks * P.tiles_per_xcd * 8;
+    if (memcmp(key, p->tm_key, sizeof(key)) != 0 || p->h_tilemap.size() != n) {
+        std::vector<short> map(n, (short)-1);
+        const int x00 = P.xlo & ~align_mask;
+        const int G = P.G, units = (P.nxt + G - 1) / G, cap = P.tiles_per_xcd / G;
+        std::vector<double> load(8, 0.0);
+        std::vector<std::pair<double, int>> cost(units);
+        for (int c = 0; c < P.nchunks; ++c) {
+            const int hm = p->h_hmax[c];
+            for (int u = 0; u < units; ++u) {
+                double w = 0;
+                for (int t = u * G; t < std::min((u + 1) * G, P.nxt); ++t) {
+                    const int x0 = x00 + t * tile_w;
+                    const int nlo = std::max(-hm, -(x0 + tile_w - 1)), nhi = std::min(hm, p->tnum - 1 - x0);
+                    const int blocks = std::max(0, nhi - nlo + step_block) / step_block;
+                    w += ((blocks + ring_blocks - 1) / ring_blocks) * ring_blocks + 8;
+                }
+                cost[u] = {w, u};
+            }
+            std::sort(cost.begin(), cost.end(), [](const std::pair<double, int> &a, const std::pair<double, int> &b) {
+                return a.first > b.first || (a.first == b.first && a.second < b.second);
+            });
+            int used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (const auto &cu : cost) {
+                int best = -1;
+                for (int x = 0; x < 8; ++x)
+                    if (used[x] < cap && (best < 0 || load[x] < load[best])) best = x;
+                if (best < 0) return IMPDAR_OK;          // cannot happen (8 cap >= units); keep the arithmetic rule
+                for (int g = 0; g < G; ++g) {
+                    const int t = cu.second * G + g;
+                    map[((size_t)c * P.tiles_per_xcd + (size_t)used[best] * G + g) * 8 + best] = (short)(t < P.nxt ? t : -1);
+                }
+                ++used[best];
+                load[best] += cu.first;
+            }
+        }
+        if (P.nxt > 32767) return IMPDAR_OK;
+        p->h_tilemap.swap(map);
+        memcpy(p->tm_key, key, sizeof(key));
+        IMPDAR_HIP_CHECK(p->d_tilemap.ensure(n * sizeof(short)));
+        IMPDAR_HIP_CHECK(hipMemcpyAsync(p->d_tilemap.p, p->h_tilemap.data(), n * sizeof(short), hipMemcpyHostToDevice, st));
+    }
+    P.tilemap = p->d_tilemap.as<short>();
+    return IMPDAR_OK;
+}
+
 template <int XB, int OCC, int SH, int NH = 1, int LK = 0>
 static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipStream_t st)
 {
@@ -2118,7 +2275,11 @@ static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipSt
     P.tiles_per_xcd = nxt_pad / 8;
     const int nblk = P.nchunks * nxt_pad;
     const int W = p->quadW;
-    const size_t shmem = (size_t)(W / 32) * kq_piece_bytes_lk(XB, LK) * (p->nearfield ? 2 : 1);
+    {
+        const int trc = build_tilemap(p, P, XB * NH, 7, (kq_ring_slots(XB) + 8 * LK) / 8, 8, st);
+        if (trc) return trc;
+    }
+    const size_t shmem = (size_t)(W / 32) * kq_piece_bytes_lk(XB, LK) * (p->nearfield ? 2 : 1) + 16;   // + the item slot
     if (p->nearfield) {
         auto k = kirch_quad_kernel<XB, true, 1, SH, 1, 0>;
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -2126,7 +2287,22 @@ static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipSt
     } else {
         auto k = kirch_quad_kernel<XB, false, OCC, SH, NH, LK>;
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k, dim3(nblk), dim3(KF_THREADS * NH), shmem, st, P, W);
+        int grid = nblk;
+        static const bool no_queue = getenv("IMPDAR_KIRCH_QUEUE") && !strcmp(getenv("IMPDAR_KIRCH_QUEUE"), "0");
+        if (P.tilemap && !no_queue) {
+            // persistent workgroups: as many as are resident at once, each pulling items from the per-XCD queues
+            int per_cu = 0, ncu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, KF_THREADS * NH, shmem) == hipSuccess &&
+                hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->ctx->device) == hipSuccess &&
+                per_cu > 0 && ncu > 0 && (long long)per_cu * ncu < nblk && p->d_queue.ensure(8 * 64) == hipSuccess) {
+                IMPDAR_HIP_CHECK(hipMemsetAsync(p->d_queue.p, 0, 8 * 64, st));
+                P.queue = p->d_queue.as<int>();
+                grid = per_cu * ncu;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        hipLaunchKernelGGL(k, dim3(grid), dim3(KF_THREADS * NH), shmem, st, P, W);
     }
     IMPDAR_HIP_CHECK(hipGetLastError());
     return IMPDAR_OK;
@@ -2148,7 +2324,11 @@ static int launch_dquad(impdar_kirch_plan *p, const FastParams &P0, hipStream_t 
     P.tiles_per_xcd = nxt_pad / 8;
     const int nblk = P.nchunks * nxt_pad;
     const int W = p->quadW;
-    const size_t shmem = (size_t)(W / 32) * kd_piece_bytes(XB) * (p->nearfield ? 2 : 1);
+    {
+        const int trc = build_tilemap(p, P, XB, 3, kd_ring_slots(XB) / 4, 4, st);
+        if (trc) return trc;
+    }
+    const size_t shmem = (size_t)(W / 32) * kd_piece_bytes(XB) * (p->nearfield ? 2 : 1) + 16;      // + the item slot
     if (p->nearfield) {
         auto k = kirch_dquad_kernel<XB, true, 1, SH>;
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -2156,7 +2336,21 @@ static int launch_dquad(impdar_kirch_plan *p, const FastParams &P0, hipStream_t 
     } else {
         auto k = kirch_dquad_kernel<XB, false, 2, SH>;
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k, dim3(nblk), dim3(KF_THREADS), shmem, st, P, W);
+        int grid = nblk;
+        static const bool no_queue = getenv("IMPDAR_KIRCH_QUEUE") && !strcmp(getenv("IMPDAR_KIRCH_QUEUE"), "0");
+        if (P.tilemap && !no_queue) {
+            int per_cu = 0, ncu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, KF_THREADS, shmem) == hipSuccess &&
+                hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->ctx->device) == hipSuccess &&
+                per_cu > 0 && ncu > 0 && (long long)per_cu * ncu < nblk && p->d_queue.ensure(8 * 64) == hipSuccess) {
+                IMPDAR_HIP_CHECK(hipMemsetAsync(p->d_queue.p, 0, 8 * 64, st));
+                P.queue = p->d_queue.as<int>();
+                grid = per_cu * ncu;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        hipLaunchKernelGGL(k, dim3(grid), dim3(KF_THREADS), shmem, st, P, W);
     }
     IMPDAR_HIP_CHECK(hipGetLastError());
     return IMPDAR_OK;
@@ -2231,6 +2425,8 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         P.nrows = p->nrows;
         P.mrow0 = p->mrow0;
         P.stamps = nullptr;
+        P.tilemap = nullptr;
+        P.queue = nullptr;
 #ifdef KQ_STAMP
         if (p->d_stamps.ensure((size_t)1 << 22) == hipSuccess) {
             (void)hipMemsetAsync(p->d_stamps.p, 0, (size_t)1 << 22, st);
