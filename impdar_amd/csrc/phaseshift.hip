@@ -737,7 +737,7 @@ static int ps_dispatch(const PsParams &P, hipStream_t st)
     else if (nt <= 1024) ps_launch<T, 512, 2>(P, st);
     else if (nt <= 2048) ps_launch<T, 512, 4>(P, st);
     else if (nt <= 4096) ps_launch<T, 512, 8>(P, st);
-    else if (nt <= 8192) ps_launch<T, 512, 16>(P, st);
+    else if (nt <= 8192) ps_launch<T, 512, 16>(P, st);     // (1024 x 8 for the float32 v(z) runs kernel: 33 spilled VGPRs, 12 % slower)
     else if (nt <= 16384) ps_launch<T, 512, 32>(P, st);
     else {
         impdar_set_error("phase-shift kernel supports up to 16384 padded samples (got %d)", nt);
