@@ -59,8 +59,11 @@ struct FftPlan {
         return IMPDAR_OK;
     }
     // 2-D transform of one array: len0 along the contiguous axis, len1 rows `in_row` / `out_row` elements apart.
+    // in_col / out_col != 0: that side is stored with the SECOND dimension contiguous instead (element (i0, i1) at
+    // i0 * col + i1): handing rocFFT's own transposed intermediate to the next kernel saves it a transpose pass.
     int create2d(rocfft_transform_type type, bool dbl, bool inplace, size_t len0, size_t len1, rocfft_array_type in_t,
-                 rocfft_array_type out_t, size_t in_row, size_t out_row, double scale, hipStream_t stream)
+                 rocfft_array_type out_t, size_t in_row, size_t out_row, double scale, hipStream_t stream,
+                 size_t in_col = 0, size_t out_col = 0, size_t in_dist = 0, size_t out_dist = 0)
     {
         release();
         int rc = impdar_fft_global_setup();
@@ -68,8 +71,11 @@ struct FftPlan {
         rocfft_plan_description desc = nullptr;
         IMPDAR_FFT_CHECK(rocfft_plan_description_create(&desc));
         size_t is[2] = {1, in_row}, os[2] = {1, out_row};
-        rocfft_status s = rocfft_plan_description_set_data_layout(desc, in_t, out_t, nullptr, nullptr, 2, is, in_row * len1,
-                                                                  2, os, out_row * len1);
+        if (in_col) { is[0] = in_col; is[1] = 1; }
+        if (out_col) { os[0] = out_col; os[1] = 1; }
+        rocfft_status s = rocfft_plan_description_set_data_layout(desc, in_t, out_t, nullptr, nullptr, 2, is,
+                                                                  in_dist ? in_dist : in_row * len1, 2, os,
+                                                                  out_dist ? out_dist : out_row * len1);
         if (s == rocfft_status_success && scale != 1.0) s = rocfft_plan_description_set_scale_factor(desc, scale);
         size_t lengths[2] = {len0, len1};
         if (s == rocfft_status_success)
