@@ -40,15 +40,18 @@ __global__ __launch_bounds__(256) void stolt_taper_transpose(const T *__restrict
     __shared__ T tile[64][65];
     const int k0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    // the trace weight is the thread's own for all of its rows; the 64 sample weights of the tile are computed once
+    // (two float64 divisions per element were most of this kernel's time)
+    __shared__ double wrow[64];
+    if (threadIdx.x < 64) wrow[threadIdx.x] = impdar_taper_w(min(k0 + (int)threadIdx.x, snum - 1), snum, vtaper);
+    const double h = impdar_taper_w(min(j0 + tx, tnum - 1), tnum, htaper);
+    __syncthreads();
     for (int r = ty; r < 64; r += 4) {
         const int k = k0 + r, j = j0 + tx;
         T v = 0;
         if (k < snum && j < tnum) {
             v = in[(size_t)k * tnum + j];
-            if (do_taper) {
-                const double h = impdar_taper_w(j, tnum, htaper), w = impdar_taper_w(k, snum, vtaper);
-                v = (T)(((double)v * h) * w);               // (data*H)*V then astype(dtype), :157
-            }
+            if (do_taper) v = (T)(((double)v * h) * wrow[r]);      // (data*H)*V then astype(dtype), :157
         }
         tile[r][tx] = v;
     }
@@ -94,7 +97,8 @@ __global__ __launch_bounds__(256) void stolt_stretch(const Cx<T> *__restrict__ F
     if (zj < nz) {
         const double kxi = kx[xi];
         const double kz = ws[zj] * 2.0 / vel;                       // :180
-        double wq = vel / 2.0 * sqrt(kz * kz + kxi * kxi);          // :188
+        const double kk = sqrt(kz * kz + kxi * kxi);                // :188 and :196 (kx^2 + kz^2: the same sum)
+        double wq = vel / 2.0 * kk;
         const double wlast = ws[m - 1];
         if (wq > wlast) wq = wlast;                                 // FITPACK clamps to the last knot
         const double dw = ws[1] - ws[0];
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void stolt_stretch(const Cx<T> *__restrict__ F
         // scaled in place in double and rounded again (:190, :198)
         const T re = (T)((1.0 - w) * (double)a.x + w * (double)b.x);
         const T im = (T)((1.0 - w) * (double)a.y + w * (double)b.y);
-        const double sc = kz / sqrt(kxi * kxi + kz * kz);           // :196
+        const double sc = kz / kk;                                  // :196
         o.x = (T)((double)re * sc);
         o.y = (T)((double)im * sc);
         if (zj == 0 && xi == 0) {                                   // :200
@@ -136,7 +140,8 @@ __global__ __launch_bounds__(256) void stolt_stretch_wmajor(const Cx<T> *__restr
     if (zj < nz) {
         const double kxi = kx[xi];
         const double kz = ws[zj] * 2.0 / vel;                       // :180
-        double wq = vel / 2.0 * sqrt(kz * kz + kxi * kxi);          // :188
+        const double kk = sqrt(kz * kz + kxi * kxi);                // :188 and :196 (kx^2 + kz^2: the same sum)
+        double wq = vel / 2.0 * kk;
         const double wlast = ws[m - 1];
         if (wq > wlast) wq = wlast;                                 // FITPACK clamps to the last knot
         const double dw = ws[1] - ws[0];
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256) void stolt_stretch_wmajor(const Cx<T> *__restr
         const Cx<T> a = F[(size_t)i0 * tnum + xi], b = F[(size_t)(i0 + 1) * tnum + xi];
         const T re = (T)((1.0 - w) * (double)a.x + w * (double)b.x);       // :190, rounded into the complex array
         const T im = (T)((1.0 - w) * (double)a.y + w * (double)b.y);
-        const double sc = kz / sqrt(kxi * kxi + kz * kz);           // :196
+        const double sc = kz / kk;                                  // :196
         o.x = (T)((double)re * sc);                                 // :198, scaled in place in double
         o.y = (T)((double)im * sc);
         if (zj == 0 && xi == 0) {                                   // :200
