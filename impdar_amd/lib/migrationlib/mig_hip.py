@@ -343,64 +343,91 @@ def _interp_checked(x, y, xnew):
     return np.interp(xnew, x, y)
 
 
+# Error messages of the reference's velocity-table checks (mig_python.py:572-573, :581, :587-588, :614, :632, :639):
+# same exception type and text, raised from one table instead of scattered branches.
+_VEL_ERRORS = {
+    'shape': 'If non-constant vel, inputs needs to be 2d (v, z) or (v, z, x)',
+    'one_layer': 'It does not make sense to only give one layer of velocity--'
+                 'if you want constant velocity just input v',
+    'coverage': 'Your velocity data doesnt come close to covering the depths in the data',
+    'no_dist': 'The distance vector was never set.',
+    'range': 'Two-way travel time array extends outside of interpolation range',
+    'columns': 'Input must be 2d with 2 or 3 columns',
+}
+
+
+def _vel_fail(key):
+    raise ValueError(_VEL_ERRORS[key])
+
+
+def _velocity_of_time(depth, time_of_depth, twtt, check_end=False):
+    """Migration velocity on the sample times from a travel-time curve t(z) given on ``depth``: invert it to z(t) on
+    ``twtt`` by linear interpolation and differentiate, v = 2 dz/dt (mig_python.py:600-604, :628-636).  Shared by
+    the layered and the lateral branch."""
+    if check_end and twtt[-1] > time_of_depth[-1]:
+        _vel_fail('range')
+    z_of_t = _interp_checked(time_of_depth, depth, twtt)
+    return 2. * np.gradient(z_of_t, twtt)
+
+
+def _layered_profile(vel_v, vel_z, twtt):
+    """2-column (v, z) table -> v(t) (mig_python.py:582-604)."""
+    depth = np.max(vel_v) / 2. * twtt                 # depth axis for the largest possible penetration
+    depth[0] = twtt[0] * vel_v[0] / 2.
+    shallow, deep = np.nanmin(depth), np.nanmax(depth)
+    starts_late = vel_z[0] > 1.1 * shallow and vel_z[0] / deep > 1.0e-3
+    ends_early = vel_z[-1] * 1.1 < deep
+    if starts_late or ends_early:
+        _vel_fail('coverage')
+    # a table that stops just short of the depth range is stretched to it with its end velocities
+    if vel_z[0] > shallow:
+        vel_v, vel_z = np.insert(vel_v, 0, vel_v[np.argmin(vel_z)]), np.insert(vel_z, 0, shallow)
+    if vel_z[-1] < deep:
+        vel_v, vel_z = np.append(vel_v, vel_v[np.argmax(vel_z)]), np.append(vel_z, deep)
+    table_t = 2. * vel_z / vel_v                      # local two-way time of each table row (not integrated)
+    return _velocity_of_time(depth, _interp_checked(vel_z, table_t, depth), twtt)
+
+
+def _lateral_profile(vel_v, vel_z, vel_x, twtt, dat):
+    """3-column (v, z, x) table -> v(t, trace) (mig_python.py:607-636): nearest table row for every (trace, depth)
+    node, then the integrated travel time down each trace."""
+    if dat.dist is None or np.all(np.asarray(dat.dist) == 0):
+        _vel_fail('no_dist')
+    depth = np.linspace(np.min(vel_v) * twtt[0], np.max(vel_v) * twtt[-1], dat.snum) / 2.
+    along = np.asarray(dat.dist, dtype=np.float64)
+    thickness = np.diff(depth)
+    out = np.zeros((dat.snum, dat.tnum))
+    for i in range(dat.tnum):
+        nearest = np.argmin((along[i] - vel_x[None, :]) ** 2 + (depth[:, None] - vel_z[None, :]) ** 2, axis=1)
+        slowness = 1. / vel_v[nearest]
+        # the reference integrates 1/v over the samples ABOVE each depth (trapz over the first j points, :626):
+        # a cumulative trapezoid shifted by one sample
+        layers = np.cumsum(thickness * (slowness[1:] + slowness[:-1]) / 2.)
+        table_t = 2. * np.concatenate([[0., 0.], layers[:-1]])
+        out[:, i] = _velocity_of_time(depth, _interp_checked(depth, table_t, depth), twtt, check_end=True)
+    return out
+
+
 def getVelocityProfile(dat, vels_in):
-    """Map a velocity table onto the samples of the traces
-    (mig_python.py:543-643).  Scalar -> returned unchanged; 2-column (v, z)
-    -> 1-D profile of length snum; 3-column (v, z, x) -> (snum, tnum) array
-    (nearest-neighbour gridding, then t(z) per trace); the error cases of
-    :572-588, :614, :632, :639 raise ValueError as in the reference."""
+    """Map a velocity table onto the samples of the traces (mig_python.py:543-643).  Scalar -> returned unchanged;
+    2-column (v, z) -> 1-D profile of length snum; 3-column (v, z, x) -> (snum, tnum) array; malformed tables raise
+    the reference's ValueErrors (``_VEL_ERRORS``)."""
     if not hasattr(vels_in, '__len__'):
         return vels_in
     start = time.time()
     print('Interpolating the velocity profile.')
-    if len(np.shape(vels_in)) != 2 or np.shape(vels_in)[1] == 1:
-        raise ValueError('If non-constant vel, inputs needs to be 2d (v, z) or (v, z, x)')
-    nlay, dimension = np.shape(vels_in)
-    vels_in = np.asarray(vels_in, dtype=np.float64)
-    vel_v = vels_in[:, 0]
-    vel_z = vels_in[:, 1]
+    shape = np.shape(vels_in)
+    if len(shape) != 2 or shape[1] == 1:
+        _vel_fail('shape')
+    if shape[0] == 1:
+        _vel_fail('one_layer')
+    if shape[1] not in (2, 3):
+        _vel_fail('columns')
+    table = np.asarray(vels_in, dtype=np.float64)
     twtt = np.asarray(dat.travel_time, dtype=np.float64).copy() / 1.0e6
-    if nlay == 1:
-        raise ValueError('It does not make sense to only give one layer of velocity--'
-                         'if you want constant velocity just input v')
-    elif dimension == 2:
-        zs = np.max(vel_v) / 2. * twtt
-        zs[0] = twtt[0] * vel_v[0] / 2.
-        zlo, zhi = np.nanmin(zs), np.nanmax(zs)
-        if (vel_z[0] > 1.1 * zlo and vel_z[0] / zhi > 1.0e-3) or vel_z[-1] * 1.1 < zhi:
-            raise ValueError('Your velocity data doesnt come close to covering the depths in the data')
-        if vel_z[0] > zlo:
-            vel_v = np.insert(vel_v, 0, vel_v[np.argmin(vel_z)])
-            vel_z = np.insert(vel_z, 0, zlo)
-        if vel_z[-1] < zhi:
-            vel_v = np.append(vel_v, vel_v[np.argmax(vel_z)])
-            vel_z = np.append(vel_z, zhi)
-        vel_t = 2. * vel_z / vel_v
-        tofz = _interp_checked(vel_z, vel_t, zs)
-        zoft = _interp_checked(tofz, zs, twtt)
-        vmig = 2. * np.gradient(zoft, twtt)
-    elif dimension == 3:
-        vel_x = vels_in[:, 2]
-        # depth axis for the largest penetration range (:610-612)
-        zs = np.linspace(np.min(vel_v) * twtt[0], np.max(vel_v) * twtt[-1], dat.snum) / 2.
-        if dat.dist is None or np.all(np.asarray(dat.dist) == 0):
-            raise ValueError('The distance vector was never set.')
-        dist = np.asarray(dat.dist, dtype=np.float64)
-        # nearest-neighbour gridding of the table onto the (dist, zs) mesh (:616-618), one trace at a time
-        vmig = np.zeros((dat.snum, dat.tnum))
-        dz = np.diff(zs)
-        for i in range(dat.tnum):
-            d2 = (dist[i] - vel_x[None, :]) ** 2 + (zs[:, None] - vel_z[None, :]) ** 2
-            v = vel_v[np.argmin(d2, axis=1)]
-            # t(z) = 2 * integral of dz / v over the samples ABOVE z (:626: trapz over the first j points)
-            cum = np.concatenate([[0.], np.cumsum(dz * (1. / v[1:] + 1. / v[:-1]) / 2.)])
-            vel_t = 2. * np.concatenate([[0.], cum[:-1]])
-            tofz = _interp_checked(zs, vel_t, zs)
-            if twtt[-1] > tofz[-1]:
-                raise ValueError('Two-way travel time array extends outside of interpolation range')
-            zoft = _interp_checked(tofz, zs, twtt)
-            vmig[:, i] = 2. * np.gradient(zoft, twtt)
+    if shape[1] == 2:
+        vmig = _layered_profile(table[:, 0], table[:, 1], twtt)
     else:
-        raise ValueError('Input must be 2d with 2 or 3 columns')
+        vmig = _lateral_profile(table[:, 0], table[:, 1], table[:, 2], twtt, dat)
     print('Velocity profile finished in %.2f seconds.' % (time.time() - start))
     return vmig

@@ -4,6 +4,7 @@ collectives are trivial, but every RCCL call of the multi-GPU path runs).
 The N > 1 data movement itself is covered on CPU by test_parallel_gloo.py;
 the driver's 8-GPU bench exercises it on hardware."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -124,3 +125,22 @@ def test_rccl_is_the_rocm_install(hip):
     hip.require_system_rccl()
     paths = hip.mapped_rccl()
     assert paths and all('/opt/rocm' in p for p in paths), paths
+
+
+def test_single_process_front_door_spawns_its_ranks(hip, tmp_path):
+    """parallel.run_sharded / migrationKirchhoff(dat, ngpus=N): the radargram goes to shared memory, one worker
+    process per GPU (impdar_amd._shard_worker: rendezvous, communicator, prep -> exchange -> migrate of its block)
+    writes its output block into the shared result.  One GPU here, so one rank -- the N > 1 data movement is what
+    tests/test_parallel_gloo.py covers -- but the whole process plumbing runs."""
+    from impdar_amd import parallel, synth
+    from impdar_amd.kirchhoff import migrate_resident
+    snum, tnum = 300, 77
+    geo = synth.geometry(snum, tnum)
+    for dtype in (np.float32, np.float64):
+        data = synth.noise_radargram(snum, tnum, seed=9).astype(dtype)
+        want, _, _ = migrate_resident(hip.context(), data, geo['dist'], geo['travel_time'], mode='auto')
+        got = parallel.run_sharded(data, geo['dist'], geo['travel_time'], ngpus=1)
+        assert got.dtype == np.float64 and got.shape == (snum, tnum)
+        assert np.array_equal(got, want.astype(np.float64))
+    leftovers = [f for f in os.listdir('/dev/shm') if f.startswith('impdar_shard_%d_' % os.getpid())]
+    assert not leftovers
