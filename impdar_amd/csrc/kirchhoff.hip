@@ -1736,15 +1736,28 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         else if ((size_t)(rows_for(40) / 32) * kq_piece_bytes(40) <= 80 * 1024 && (long long)tnum >= 2000LL * nranks)
             xbq = 40;
     }
+    // Whole radargrams by default: TWO tiles of 32 traces per workgroup on one ring (kirch_quad_kernel, NH = 2),
+    // when that ring fits half a CU's LDS: two workgroups of 8 waves per CU (four waves per SIMD at 128 VGPRs)
+    // instead of two of 4.  Same-box A/B at config 3: 2 % faster than one 40-trace tile per workgroup (the same
+    // tile pair with one workgroup per CU, 40 x 2, is 1 % slower), and the fabric traffic roughly halves.
+    bool pair32 = false;
+    if (!getenv("IMPDAR_KIRCH_XB") && !getenv("IMPDAR_KIRCH_NH") && !nearfield && xbq == 40) {
+        const int rows = ((KF_THREADS + (int)std::ceil(sa * (32 * 2 + 8 - 2)) + 8 + 31) / 32) * 32;
+        if ((size_t)(rows / 32) * kq_piece_bytes(32) <= 80 * 1024 && (size_t)(rows / 32) * kq_piece_bytes(32) > 65535) {
+            pair32 = true;
+            xbq = 32;
+        }
+    }
     int kq_ps = kq_piece_bytes(xbq);
     // tiles per workgroup on one ring (see kirch_quad_kernel, NH): the staging window grows by the moveout over
     // the (nh - 1) xb traces the later tiles lag behind; one workgroup per CU then (up to the whole 160 KB)
     int nhq = 1;
     {
         const char *ne = getenv("IMPDAR_KIRCH_NH");         // tuning knob: 1 | 2 | 3
-        const int want = ne ? atoi(ne) : KQ_DEFAULT_NH;
+        const int want = ne ? atoi(ne) : (pair32 ? 2 : KQ_DEFAULT_NH);
         auto rows_nh = [&](int nh) { return ((KF_THREADS + (int)std::ceil(sa * (xbq * nh + 8 - 2)) + 8 + 31) / 32) * 32; };
-        if ((want == 2 || want == 3) && xbq == 40 && !nearfield && (ne || (long long)tnum >= 2000LL * nranks) &&
+        if ((want == 2 || want == 3) && (xbq == 40 || (xbq == 32 && want == 2)) && !nearfield &&
+            (ne || pair32 || (long long)tnum >= 2000LL * nranks) &&
             (size_t)(rows_nh(want) / 32) * kq_ps <= 160 * 1024 && (size_t)(rows_nh(want) / 32) * kq_ps > 65535)
             nhq = want;
     }
@@ -2443,6 +2456,8 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
             rc = p->xb == 40 ? launch_quad<40, 2, 0>(p, P, nx, st)
                  : p->xb == 32 ? launch_quad<32, 2, 0>(p, P, nx, st)
                  : (occ0 == 2) ? launch_quad<24, 2, 0>(p, P, nx, st) : launch_quad<24, 3, 0>(p, P, nx, st);
+        else if (p->quad && p->nh == 2 && p->xb == 32)
+            rc = launch_quad<32, 4, 4, 2, 0>(p, P, nx, st);      // 70 KB of LDS: two workgroups of 8 waves per CU
         else if (p->quad && p->nh == 2 && p->xb == 40)
             rc = p->lk ? launch_quad<40, 2, 4, 2, 1>(p, P, nx, st) : launch_quad<40, 2, 4, 2, 0>(p, P, nx, st);
         else if (p->quad && p->nh == 3 && p->xb == 40)

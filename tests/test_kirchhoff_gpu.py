@@ -566,8 +566,8 @@ def test_ties_that_rounding_noise_decides_go_to_the_per_pair_kernel(hip, monkeyp
         plan.destroy()
 
 
-@pytest.mark.parametrize('nh,lk', [('2', '0'), ('3', '0'), ('2', '1'), ('3', '1')])
-def test_several_tiles_per_workgroup_on_one_ring(hip, nh, lk, monkeypatch):
+@pytest.mark.parametrize('xb,nh,lk', [('40', '2', '0'), ('40', '3', '0'), ('40', '2', '1'), ('40', '3', '1'), ('32', '2', '0')])
+def test_several_tiles_per_workgroup_on_one_ring(hip, xb, nh, lk, monkeypatch):
     """IMPDAR_KIRCH_NH: nh tiles of 40 output traces share one LDS ring in a workgroup of 256 nh threads, tile h
     walking 40 h offsets behind tile 0.  Same picks, same sums: the result must equal the one-tile kernel bit for
     bit (every output accumulates its pairs in the same order), on ragged sizes, blocks that start anywhere and
@@ -582,7 +582,7 @@ def test_several_tiles_per_workgroup_on_one_ring(hip, nh, lk, monkeypatch):
         x = synth.noise_radargram(snum, tnum, seed=31).astype(np.float32)
         outs = {}
         for which in ('1', nh):
-            monkeypatch.setenv('IMPDAR_KIRCH_XB', '40')
+            monkeypatch.setenv('IMPDAR_KIRCH_XB', xb)
             monkeypatch.setenv('IMPDAR_KIRCH_NH', which)
             monkeypatch.setenv('IMPDAR_KIRCH_LK', lk if which != '1' else '0')
             plan = KirchhoffPlan(ctx, np.float32, snum, tnum, geo['dist'], geo['travel_time'], mode='fast')
