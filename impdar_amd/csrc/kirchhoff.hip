@@ -732,6 +732,12 @@ static_assert(kq_ring_slots(24) == 40 && kq_piece_bytes(24) == 5376 && kq_ring_s
 #ifndef KQ_DEFAULT_NH
 #define KQ_DEFAULT_NH 1     // output tiles per workgroup of the quad kernel (IMPDAR_KIRCH_NH overrides)
 #endif
+#ifndef KD_DEFAULT_NH
+#define KD_DEFAULT_NH 1     // the same for the float64 ring kernel (IMPDAR_KIRCH_NHD), with tiles of KD_DEFAULT_XB2 traces
+#endif
+#ifndef KD_DEFAULT_XB2
+#define KD_DEFAULT_XB2 16
+#endif
 #ifndef KQ_DEFAULT_LK
 #define KQ_DEFAULT_LK 0     // extra ring groups / blocks of staging lookahead with NH >= 2 (IMPDAR_KIRCH_LK overrides)
 #endif
@@ -1290,9 +1296,9 @@ __global__ __launch_bounds__(256) void kirch_tabled_kernel(TableQParams P)
     if (rn >= 0) T[(size_t)rn * kq_tkb_stride(P.snum) + ti] = make_uint2(pk[3] | (pk[2] << 16), pk[1] | (pk[0] << 16));
 }
 
-template <int XB, bool NEAR, int OCC, int SH>
-__global__ __launch_bounds__(KF_THREADS, OCC) void kirch_dquad_kernel(FastParams P, int W)
-{
+template <int XB, bool NEAR, int OCC, int SH, int NH>
+__global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_dquad_kernel(FastParams P, int W)
+{   // NH tiles of XB traces per workgroup on one ring, tile h walking h XB offsets behind tile 0: see kirch_quad_kernel
     constexpr int S = 4;
     constexpr int RG = kd_ring_slots(XB);     // ring slots (traces)
     constexpr int KQ_PS = kd_piece_bytes(XB);
@@ -1305,7 +1311,8 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_dquad_kernel(FastParams
     const int npieces = W >> 5;
     const unsigned img_bytes = (unsigned)npieces * KQ_PS;
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & (KF_THREADS - 1);
+    const int half = NH > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
     // persistent workgroups pulling (chunk, tile) items from per-XCD queues: see kirch_quad_kernel
     bool first_item = true;
     int *item_slot = reinterpret_cast<int *>(lds) + (size_t)(img_bytes / 4) * (NEAR ? 2 : 1);
@@ -1348,7 +1355,8 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_dquad_kernel(FastParams
         if (xt < 0 || xt >= P.nxt) return;
     }
     const int s0 = chunk * KF_THREADS;
-    const int x0 = (P.xlo & ~3) + xt * XB;       // tiles start at a multiple of 4 (outputs left of xlo are not stored)
+    const int x0w = (P.xlo & ~3) + xt * (XB * NH);   // workgroup tiles start at a multiple of 4 (outputs left of xlo are not stored)
+    const int x0 = x0w + half * XB;
     const int snum = P.snum, tnum = P.tnum;
     // lane -> sample permutation: the 16 lanes a ds_read_b128 services together hold 16 consecutive samples
     // (see kirch_quad_kernel)
@@ -1362,16 +1370,18 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_dquad_kernel(FastParams
     const int ti = min(ti_raw, snum - 1);
 
     const int hmax = P.hmax[chunk];
-    int nlo_ = max(-hmax, -(x0 + XB - 1));
-    nlo_ -= (nlo_ - 1) & 3;                      // x0 + nlo = 1 mod 4: a block's 4 new traces are one image group
+    int nlo_ = max(-hmax, -(x0w + XB - 1));      // tile 0's offsets are the ring clock
+    nlo_ -= (nlo_ - 1) & 3;                      // x0w + nlo = 1 mod 4: a block's 4 new traces are one image group
     const int nlo = nlo_;
-    const int nhi = min(hmax, tnum - 1 - x0);
+    const int nhi = min(hmax + (NH - 1) * XB, tnum - 1 - x0w);
     const int nsteps = nhi - nlo + 1;
     const int nblocks = (nsteps + S - 1) / S;
     const int nrev = (nblocks + NB - 1) / NB;
-    const int jbase = x0 + nlo;
+    const int jbase = x0w + nlo;
     const int mrow = ((nlo - 1) >> 2) + P.mrow0;
     auto row_of = [&](int blk) { return min(mrow + blk, P.nrows - 1); };
+    const int mrow_h = mrow - half * (XB / 4);   // this tile's pick rows: half * XB offsets behind the clock
+    auto prow_of = [&](int blk) { return max(min(mrow_h + blk, P.nrows - 1), 0); };
 
     const int2 *WIN = P.WIN + (size_t)chunk * P.nrows;
     auto fetch_for = [&](int blk_for, int &a, int &b) {
@@ -1397,12 +1407,13 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_dquad_kernel(FastParams
     const unsigned rowbytes = (unsigned)kq_tkb_stride(snum) * 8u;
     typedef unsigned kd_u2 __attribute__((ext_vector_type(2)));
     auto picks = [&](int blk) -> kd_u2 {
-        return __builtin_amdgcn_raw_buffer_load_b64(tkres, tioff, (unsigned)row_of(blk) * rowbytes, 0);
+        return __builtin_amdgcn_raw_buffer_load_b64(tkres, tioff, (unsigned)prow_of(blk) * rowbytes, 0);
     };
 #define KD_TK(q, s) (((q)[(s) >> 1] >> (16 * ((s) & 1))) & 0xffffu)
     const double c1 = P.c1d[ti], c2 = NEAR ? P.c2d[ti] : 0.0, fin = P.find[ti];
+    const int nlo_h = nlo - half * XB;
     auto n2_of = [&](int step) {
-        const int n = nlo + step;
+        const int n = nlo_h + step;
         return (double)((unsigned)n * (unsigned)n);
     };
     // cos(theta) = rsqrt(1 + c1 n^2) in float64: float32 seed + one third-order correction (see the header)
@@ -1417,7 +1428,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_dquad_kernel(FastParams
 
     if (first_item) {
         if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds != 0u) __builtin_trap();
-        for (int e = tid; e < (int)(img_bytes / 4) * (NEAR ? 2 : 1); e += KF_THREADS) lds[e] = 0.f;
+        for (int e = threadIdx.x; e < (int)(img_bytes / 4) * (NEAR ? 2 : 1); e += KF_THREADS * NH) lds[e] = 0.f;
         __syncthreads();
         first_item = false;
     }
@@ -1428,7 +1439,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_dquad_kernel(FastParams
     for (int i = 0; i < XB / 2; ++i) acc2[i] = kd_d2{0.0, 0.0};
 #define KD_ACC(i) acc2[(i) >> 1][(i) & 1]
 
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rl = lane >> 1;
     const unsigned hsel = ((unsigned)(lane & 1) ^ ((unsigned)(rl >> 3) & 1u)) * 16u;
     auto dma16 = [&](unsigned lds_dst, unsigned vo, kq_u4 desc, unsigned so) {
@@ -1443,7 +1454,7 @@ __global__ __launch_bounds__(KF_THREADS, OCC) void kirch_dquad_kernel(FastParams
         const int kmin = wa & 0xffff, kmod = (int)((unsigned)wa >> 16);
         const int gidx = ((blk_for + G0) % NB + NB) % NB;
         const unsigned so = (unsigned)(blk_for + G0) * grp_bytes;
-        for (int pc = wv; pc < npieces; pc += 4) {
+        for (int pc = wv; pc < npieces; pc += 4 * NH) {
             int t = pc * 32 + rl - kmod;
             t += (t < 0) ? W : 0;
             const int c = min(kmin + t, snum - 1);
@@ -1809,14 +1820,23 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     if (mode == IMPDAR_KIRCH_EXACT && dtype == IMPDAR_F64 && p->uniform && snum < 65536 &&
         std::fabs(tmax / dt) / sa < 65000.0 && (2.0 * hest + 400.0) / 4.0 * (double)snum * 32.0 < 2147483648.0 &&
         !getenv("IMPDAR_KIRCH_EXACT_IMPL")) {
-        auto rows_for = [&](int xb) { return ((KF_THREADS + (int)std::ceil(sa * (xb + 4 - 2)) + 8 + 31) / 32) * 32; };
+        const char *ne = getenv("IMPDAR_KIRCH_NHD");        // tuning knob: tiles per workgroup, 1 | 2
+        int nhd = ne ? atoi(ne) : KD_DEFAULT_NH;
+        if (nhd != 2 || nearfield) nhd = 1;
+        auto rows_for = [&](int xb, int nh) { return ((KF_THREADS + (int)std::ceil(sa * (xb * nh + 4 - 2)) + 8 + 31) / 32) * 32; };
         const char *xe = getenv("IMPDAR_KIRCH_XBD");        // tuning knob: 16 | 20
-        int xbd = (xe && atoi(xe) == 16) ? 16 : 20;
-        if ((size_t)(rows_for(xbd) / 32) * kd_piece_bytes(xbd) > 80 * 1024) xbd = 16;
-        if ((size_t)(rows_for(xbd) / 32) * kd_piece_bytes(xbd) <= 80 * 1024) {
+        int xbd = (xe && atoi(xe) == 16) ? 16 : ((xe && atoi(xe) == 20) ? 20 : (nhd == 2 ? KD_DEFAULT_XB2 : 20));
+        auto fits = [&](int xb, int nh) {
+            const size_t b = (size_t)(rows_for(xb, nh) / 32) * kd_piece_bytes(xb);
+            return b <= 80 * 1024 && (nh == 1 || b > 65535);
+        };
+        if (nhd == 2 && !fits(xbd, 2)) nhd = 1;
+        if (!fits(xbd, nhd)) xbd = 16;
+        if (fits(xbd, nhd)) {
             p->dquad = true;
             p->xb = xbd;
-            p->quadW = rows_for(xbd);
+            p->nh = nhd;
+            p->quadW = rows_for(xbd, nhd);
             p->quadSH = ((size_t)(p->quadW / 32) * kd_piece_bytes(xbd) <= 65535) ? 0 : 4;
         }
     }
@@ -2025,7 +2045,7 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
             for (int r = 0; r < p->nrows; ++r) {
                 // (with nh tiles on one ring the later tiles read the same traces (nh - 1) xb offsets earlier)
                 const long long nz = (long long)ringS * (r - p->mrow0) + 1 + p->xb + ringS - 2;
-                const long long na = (long long)ringS * (r - p->mrow0) + 1 - (long long)(p->quad ? p->nh - 1 : 0) * p->xb;
+                const long long na = (long long)ringS * (r - p->mrow0) + 1 - (long long)((p->quad || p->dquad) ? p->nh - 1 : 0) * p->xb;
                 const long long lo = (na <= 0 && nz >= 0) ? 0 : std::min(std::llabs(na), std::llabs(nz));
                 const long long hi = std::max(std::llabs(na), std::llabs(nz));
                 for (int c = 0; c < nch; ++c) {
@@ -2321,11 +2341,11 @@ static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipSt
     return IMPDAR_OK;
 }
 
-template <int XB, int SH>
+template <int XB, int SH, int NH = 1>
 static int launch_dquad(impdar_kirch_plan *p, const FastParams &P0, hipStream_t st)
 {
     FastParams P = P0;
-    const int ntiles = (P.xhi - (P.xlo & ~3) + XB - 1) / XB;      // tiles start at a multiple of 4
+    const int ntiles = (P.xhi - (P.xlo & ~3) + XB * NH - 1) / (XB * NH);      // workgroup tiles start at a multiple of 4
     P.nxt = ntiles;
     {
         const char *ge = getenv("IMPDAR_KIRCH_G");
@@ -2338,22 +2358,22 @@ static int launch_dquad(impdar_kirch_plan *p, const FastParams &P0, hipStream_t 
     const int nblk = P.nchunks * nxt_pad;
     const int W = p->quadW;
     {
-        const int trc = build_tilemap(p, P, XB, 3, kd_ring_slots(XB) / 4, 4, st);
+        const int trc = build_tilemap(p, P, XB * NH, 3, kd_ring_slots(XB) / 4, 4, st);
         if (trc) return trc;
     }
     const size_t shmem = (size_t)(W / 32) * kd_piece_bytes(XB) * (p->nearfield ? 2 : 1) + 16;      // + the item slot
     if (p->nearfield) {
-        auto k = kirch_dquad_kernel<XB, true, 1, SH>;
+        auto k = kirch_dquad_kernel<XB, true, 1, SH, 1>;
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(k, dim3(nblk), dim3(KF_THREADS), shmem, st, P, W);
     } else {
-        auto k = kirch_dquad_kernel<XB, false, 2, SH>;
+        auto k = kirch_dquad_kernel<XB, false, (NH > 1 ? 4 : 2), SH, NH>;
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         int grid = nblk;
         static const bool no_queue = getenv("IMPDAR_KIRCH_QUEUE") && !strcmp(getenv("IMPDAR_KIRCH_QUEUE"), "0");
         if (P.tilemap && !no_queue) {
             int per_cu = 0, ncu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, KF_THREADS, shmem) == hipSuccess &&
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, KF_THREADS * NH, shmem) == hipSuccess &&
                 hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->ctx->device) == hipSuccess &&
                 per_cu > 0 && ncu > 0 && (long long)per_cu * ncu < nblk && p->d_queue.ensure(8 * 64) == hipSuccess) {
                 IMPDAR_HIP_CHECK(hipMemsetAsync(p->d_queue.p, 0, 8 * 64, st));
@@ -2363,7 +2383,7 @@ static int launch_dquad(impdar_kirch_plan *p, const FastParams &P0, hipStream_t 
                 (void)hipGetLastError();
             }
         }
-        hipLaunchKernelGGL(k, dim3(grid), dim3(KF_THREADS), shmem, st, P, W);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(KF_THREADS * NH), shmem, st, P, W);
     }
     IMPDAR_HIP_CHECK(hipGetLastError());
     return IMPDAR_OK;
@@ -2449,7 +2469,9 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         int rc;
         const char *oe0 = getenv("IMPDAR_KIRCH_OCC");      // tuning knob: min waves per SIMD to compile for
         const int occ0 = oe0 ? atoi(oe0) : 0;
-        if (p->dquad)
+        if (p->dquad && p->nh == 2 && p->quadSH == 4)
+            rc = p->xb == 20 ? launch_dquad<20, 4, 2>(p, P, st) : launch_dquad<16, 4, 2>(p, P, st);
+        else if (p->dquad)
             rc = p->quadSH == 0 ? (p->xb == 20 ? launch_dquad<20, 0>(p, P, st) : launch_dquad<16, 0>(p, P, st))
                                 : (p->xb == 20 ? launch_dquad<20, 4>(p, P, st) : launch_dquad<16, 4>(p, P, st));
         else if (p->quad && p->quadSH == 0)

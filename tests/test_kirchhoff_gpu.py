@@ -415,11 +415,11 @@ def test_config4_size_on_one_gpu(hip):
 
 
 # ---- float64 LDS-ring kernel (kirch_dquad_kernel): what the float64 default runs on uniform grids ------------
-def _exact_with(monkeypatch, impl, data, geo, vel=1.69e8, nearfield=False, xbd=None):
+def _exact_with(monkeypatch, impl, data, geo, vel=1.69e8, nearfield=False, xbd=None, nhd=None):
     """mode='exact' with IMPDAR_KIRCH_EXACT_IMPL = None (ring) | 'tab' | 'pair'."""
     from impdar_amd import _hip
     from impdar_amd.kirchhoff import KirchhoffPlan
-    for k, v in (('IMPDAR_KIRCH_EXACT_IMPL', impl), ('IMPDAR_KIRCH_XBD', xbd)):
+    for k, v in (('IMPDAR_KIRCH_EXACT_IMPL', impl), ('IMPDAR_KIRCH_XBD', xbd), ('IMPDAR_KIRCH_NHD', nhd)):
         if v is None:
             monkeypatch.delenv(k, raising=False)
         else:
@@ -441,8 +441,8 @@ def _exact_with(monkeypatch, impl, data, geo, vel=1.69e8, nearfield=False, xbd=N
 
 
 @pytest.mark.parametrize('nearfield', [False, True])
-@pytest.mark.parametrize('xbd', ['20', '16'])
-def test_float64_ring_agrees_with_the_global_memory_exact_kernels(hip, monkeypatch, nearfield, xbd):
+@pytest.mark.parametrize('xbd,nhd', [('20', '1'), ('16', '1'), ('16', '2'), ('20', '2')])
+def test_float64_ring_agrees_with_the_global_memory_exact_kernels(hip, monkeypatch, nearfield, xbd, nhd):
     """The three float64 kernels (LDS ring, tabulated gather, per-pair reference order) on one radargram whose
     size is ragged in both directions, with a first sample before the trigger (negative zs: cos < 0)."""
     from impdar_amd import synth
@@ -451,8 +451,10 @@ def test_float64_ring_agrees_with_the_global_memory_exact_kernels(hip, monkeypat
     geo = synth.geometry(snum, tnum, dx=1.7, t0_us=-0.03)
     x = synth.noise_radargram(snum, tnum, seed=21)
     want = c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], 1.69e8, nearfield)
-    ring = _exact_with(monkeypatch, None, x, geo, nearfield=nearfield, xbd=xbd)
+    ring = _exact_with(monkeypatch, None, x, geo, nearfield=nearfield, xbd=xbd, nhd=nhd)
     assert _exact_with.kernel == 'kirch_dquad_kernel'
+    one = _exact_with(monkeypatch, None, x, geo, nearfield=nearfield, xbd=xbd, nhd='1')
+    assert np.array_equal(ring, one)            # tiles per workgroup do not change a single bit
     assert rel_max(ring, want) < EXACT_TOL, rel_max(ring, want)
     for impl in ('tab', 'pair'):
         other = _exact_with(monkeypatch, impl, x, geo, nearfield=nearfield)
