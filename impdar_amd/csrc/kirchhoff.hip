@@ -1744,15 +1744,20 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         const char *xe = getenv("IMPDAR_KIRCH_XB");
         if (xe && (atoi(xe) == 24 || atoi(xe) == 32 || atoi(xe) == 40))
             xbq = atoi(xe);
-        else if ((size_t)(rows_for(40) / 32) * kq_piece_bytes(40) <= 80 * 1024 && (long long)tnum >= 2000LL * nranks)
-            xbq = 40;
+        else if ((size_t)(rows_for(40) / 32) * kq_piece_bytes(40) <= 80 * 1024)
+            xbq = 40;       // (round 1 kept 24 for the short launches of a many-rank run; with the balanced tile map and
+                            // the work queues 40 is ahead there too: 1.31 vs 1.41 ms for an 8-rank block of config 3)
     }
     // Whole radargrams by default: TWO tiles of 32 traces per workgroup on one ring (kirch_quad_kernel, NH = 2),
     // when that ring fits half a CU's LDS: two workgroups of 8 waves per CU (four waves per SIMD at 128 VGPRs)
     // instead of two of 4.  Same-box A/B at config 3: 2 % faster than one 40-trace tile per workgroup (the same
     // tile pair with one workgroup per CU, 40 x 2, is 1 % slower), and the fabric traffic roughly halves.
     bool pair32 = false;
-    if (!getenv("IMPDAR_KIRCH_XB") && !getenv("IMPDAR_KIRCH_NH") && !nearfield && xbq == 40) {
+    // (a rank's block of under ~8000 traces gives the 64-trace workgroup tiles too few items per slot: 40 x 1 there;
+    // emulated per-rank steps at config 3, profiles/r02_rank_steps_tiles.txt: 4.28 / 2.32 / 1.31 ms at 2 / 4 / 8 ranks
+    // against 4.33 / 2.39 / 1.65 with the tile pair)
+    if (!getenv("IMPDAR_KIRCH_XB") && !getenv("IMPDAR_KIRCH_NH") && !nearfield && xbq == 40 &&
+        (long long)tnum >= 8000LL * nranks) {
         const int rows = ((KF_THREADS + (int)std::ceil(sa * (32 * 2 + 8 - 2)) + 8 + 31) / 32) * 32;
         if ((size_t)(rows / 32) * kq_piece_bytes(32) <= 80 * 1024 && (size_t)(rows / 32) * kq_piece_bytes(32) > 65535) {
             pair32 = true;
@@ -1768,7 +1773,7 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         const int want = ne ? atoi(ne) : (pair32 ? 2 : KQ_DEFAULT_NH);
         auto rows_nh = [&](int nh) { return ((KF_THREADS + (int)std::ceil(sa * (xbq * nh + 8 - 2)) + 8 + 31) / 32) * 32; };
         if ((want == 2 || want == 3) && (xbq == 40 || (xbq == 32 && want == 2)) && !nearfield &&
-            (ne || pair32 || (long long)tnum >= 2000LL * nranks) &&
+            (ne || pair32) &&
             (size_t)(rows_nh(want) / 32) * kq_ps <= 160 * 1024 && (size_t)(rows_nh(want) / 32) * kq_ps > 65535)
             nhq = want;
     }
