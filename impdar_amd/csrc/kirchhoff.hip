@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void kirch_tablex_kernel(TableXParams P)
 // aperture; the plan then keeps the per-pair kernel, which repeats the reference's arithmetic pair by pair.
 // Margin: the relative rounding noise of t, ~1e-15 plus the cancellation in dist[j] - dist[xi]
 // (2.2e-16 * tnum / |n|), times |t|/dt, in samples.
-__global__ __launch_bounds__(256) void kirch_tiescan_kernel(TableXParams P, double tnum, int *flag)
+__global__ __launch_bounds__(256) void kirch_tiescan_kernel(TableXParams P, double tnum, int *count, int2 *list, int cap)
 {
     const int ti = blockIdx.x * 256 + threadIdx.x;
     const int n = blockIdx.y;
@@ -311,14 +311,100 @@ __global__ __launch_bounds__(256) void kirch_tiescan_kernel(TableXParams P, doub
     const double t = 2.0 * rs / P.vel;
     if (!(cost == cost)) return;                       // 0/0 apex: dropped whatever the noise
     const double u = (t - P.tt0) * P.inv_dt, um = (P.tmax - P.tt0) * P.inv_dt;
-    const double eps = (fabs(t * P.inv_dt) + 1.0) * (1.0e-15 + 4.5e-16 * tnum / (double)max(n, 1));
+    // ten times the noise estimate: a wider net only makes the list (a handful of entries) longer
+    const double eps = 10.0 * (fabs(t * P.inv_dt) + 1.0) * (1.0e-15 + 4.5e-16 * tnum / (double)max(n, 1));
     if (u > um + eps) return;                          // clearly outside the aperture
     bool amb = fabs(u - um) <= eps && n > 0;           // the t > t_max test itself (n = 0: t = tt exactly)
-    if (u >= 0.0 && u <= um && n > 0) {
+    if (u >= 0.0 && u <= um + eps && n > 0) {
         const double fr = u - floor(u);
         amb = amb || fabs(fr - 0.5) <= eps;
     }
-    if (amb) atomicOr(flag, 1);
+    if (amb) {
+        const int at = atomicAdd(count, 1);
+        if (at < cap) list[at] = make_int2(ti, n);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// ... and the table-driven kernels keep running on such geometries: the flagged (sample, offset) entries (one in
+// 1.1e7 for dx 1 m, dt 10 ns, v 1.68e8 m/s -- the velocity RadarData.migrate defaults to -- a few thousand for a
+// moveout of exactly 2.5) are re-done pair by pair in the reference's arithmetic after the diffraction sum, and
+// where a pair's own answer (pick, or the t > t_max drop) differs from the table's, the output gets the
+// difference.  One thread per (sample with flagged offsets, output trace), its offsets and the two sides in a
+// fixed order: deterministic, no atomics.  Per-pair parity on every geometry at the cost of a few microseconds.
+// ---------------------------------------------------------------------------
+struct TieFixParams {
+    const void *GT, *DT;     // images (layout: grp = 0 trace-major [row][k]; else groups of `grp` rows, sample-major inside)
+    void *out;
+    int ldo, snum, tnum, xlo, xhi, grp, near;
+    const double *dist, *zs, *zs2, *tt;
+    double dx, vel, tmax, inv_dt, tt0;
+    const int *g_ti, *g_off, *g_n;   // groups: sample, [first, last) into g_n (offsets, ascending)
+    const int *hmax;                 // per 256-sample chunk: offsets beyond are not walked
+    int nmax;                        // offsets >= nmax are dropped by the tables whatever t is
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void kirch_tiefix_kernel(TieFixParams P)
+{
+    const int g = blockIdx.y;
+    const int xi = P.xlo + blockIdx.x * 256 + threadIdx.x;
+    if (xi >= P.xhi) return;
+    const int ti = P.g_ti[g];
+    const T *GT = reinterpret_cast<const T *>(P.GT);
+    const T *DT = reinterpret_cast<const T *>(P.DT);
+    const int ns = P.snum;
+    auto at = [&](const T *img, int j, int k) -> double {
+        const size_t o = P.grp ? ((size_t)(j / P.grp) * ns + k) * P.grp + (j % P.grp) : (size_t)j * ns + k;
+        return (double)img[o];
+    };
+    auto pick = [&](double t) {
+        int k0 = (int)floor((t - P.tt0) * P.inv_dt);
+        k0 = min(max(k0, 0), ns - 1);
+        while (k0 < ns - 1 && P.tt[k0 + 1] <= t) ++k0;
+        while (k0 > 0 && P.tt[k0] > t) --k0;
+        const int k1 = min(k0 + 1, ns - 1);
+        return (fabs(P.tt[k1] - t) < fabs(P.tt[k0] - t)) ? k1 : k0;      // :49, ties to the lower index
+    };
+    const double z = P.zs[ti], z2 = P.zs2[ti];
+    const double c2pi = 1.0 / (2.0 * 3.141592653589793);
+    const int hm = P.hmax[ti >> 8];
+    double far = 0.0, nearsum = 0.0;
+    for (int e = P.g_off[g]; e < P.g_off[g + 1]; ++e) {
+        const int n = P.g_n[e];
+        // what the table holds for (ti, n): the pick at dx = n * spacing (kirch_tableq / tabled / tablex kernels)
+        const double dxn = (double)n * P.dx;
+        const double rsn = sqrt(dxn * dxn + z2);
+        const double costn = z / rsn;
+        const double tn = 2.0 * rsn / P.vel;
+        const bool drop_tab = n >= P.nmax || n > hm || tn > P.tmax || !(costn == costn);
+        const int k_tab = drop_tab ? 0 : pick(tn);
+        for (int sgn = -1; sgn <= 1; sgn += 2) {
+            const int j = xi + sgn * n;
+            if (j < 0 || j >= P.tnum) continue;
+            const double dxj = P.dist[j] - P.dist[xi];
+            const double q = dxj * dxj + z2;                   // :44
+            const double rs = sqrt(q);
+            const double cost = z / rs;                        // :47
+            const double t = 2.0 * rs / P.vel;                 // :49
+            const bool drop = t > P.tmax || !(cost == cost);   // :52, nansum
+            const int k = drop ? 0 : pick(t);
+            if (drop == drop_tab && (drop || k == k_tab)) continue;
+            // the weight the diffraction sum gave this offset (a function of (ti, n) in every table-driven kernel)
+            const double wf = costn / P.vel, wn = costn / (rsn * rsn);
+            const double gt = drop ? 0.0 : at(GT, j, k), gb = drop_tab ? 0.0 : at(GT, j, k_tab);
+            far += (gt - gb) * wf;
+            if (P.near) {
+                const double dt_ = drop ? 0.0 : at(DT, j, k), db = drop_tab ? 0.0 : at(DT, j, k_tab);
+                nearsum += (dt_ - db) * wn;
+            }
+        }
+    }
+    const double delta = c2pi * (far + nearsum);
+    if (delta != 0.0) {
+        T *o = reinterpret_cast<T *>(P.out) + (size_t)ti * P.ldo + (xi - P.xlo);
+        *o = (T)((double)*o + delta);
+    }
 }
 
 struct ExactTabParams {
@@ -1631,7 +1717,9 @@ struct impdar_kirch_plan {
     int nh = 1;                 // quad kernel: output tiles per workgroup sharing one ring (256 nh threads)
     int lk = 0;                 // ... and extra ring groups = blocks of additional staging lookahead (nh >= 2 only)
     bool dquad = false;         // the same ring in float64 (kirch_dquad_kernel): exact mode, float64 data, uniform grids
-    bool tie_ambiguous = false; // kirch_tiescan_kernel found a pick that rounding noise decides: per-pair kernel only
+    bool tie_ambiguous = false; // more rounding-noise ties than the list holds: per-pair kernel only
+    int ntie_groups = 0;        // samples with flagged offsets (kirch_tiefix_kernel after every table-driven diffraction sum)
+    DevBuf d_tie_ti, d_tie_off, d_tie_n;
     DevBuf d_c1d, d_c2d, d_find;
     int quadW = 0;              // samples per ring slot in that layout
     // host copies for pair counting
@@ -1899,8 +1987,9 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         int hg = 0;
         for (int k = 0; k < snum; ++k) hg = std::max(hg, p->h_half[k] + 1);
         hg = std::min(hg, tnum) + 1;
-        DevBuf d_flag;
-        if (d_flag.ensure(64) != hipSuccess) {
+        constexpr int TIE_CAP = 1 << 20;
+        DevBuf d_flag, d_list;
+        if (d_flag.ensure(64) != hipSuccess || d_list.ensure((size_t)TIE_CAP * sizeof(int2)) != hipSuccess) {
             impdar_set_error("hipMalloc failed");
             return fail(IMPDAR_ERR_HIP);
         }
@@ -1920,17 +2009,40 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         T.ntab = hg;
         T.near = 0;
         hipLaunchKernelGGL(kirch_tiescan_kernel, dim3((snum + 255) / 256, hg), dim3(256), 0, ctx->stream, T, (double)tnum,
-                           d_flag.as<int>());
-        int flag = 0;
-        if (hipMemcpyAsync(&flag, d_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                           d_flag.as<int>(), d_list.as<int2>(), TIE_CAP);
+        int count = 0;
+        if (hipMemcpyAsync(&count, d_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) {
             impdar_set_error("tie scan failed: %s", hipGetErrorString(hipGetLastError()));
             return fail(IMPDAR_ERR_HIP);
         }
-        p->tie_ambiguous = flag != 0;
+        const bool no_fix = getenv("IMPDAR_KIRCH_TIEFIX") && !strcmp(getenv("IMPDAR_KIRCH_TIEFIX"), "0");   // diagnostic
+        if (count > 0 && count <= TIE_CAP && !no_fix) {
+            // group the flagged offsets by sample (sorted: the correction adds them in a fixed order)
+            std::vector<int2> list(count);
+            if (hipMemcpy(list.data(), d_list.p, (size_t)count * sizeof(int2), hipMemcpyDeviceToHost) != hipSuccess) {
+                impdar_set_error("tie list download failed");
+                return fail(IMPDAR_ERR_HIP);
+            }
+            std::sort(list.begin(), list.end(), [](const int2 &a, const int2 &b) { return a.x < b.x || (a.x == b.x && a.y < b.y); });
+            std::vector<int> g_ti, g_off, g_n(count);
+            for (int i = 0; i < count; ++i) {
+                if (i == 0 || list[i].x != list[i - 1].x) {
+                    g_ti.push_back(list[i].x);
+                    g_off.push_back(i);
+                }
+                g_n[i] = list[i].y;
+            }
+            g_off.push_back(count);
+            p->ntie_groups = (int)g_ti.size();
+            if ((rc = upload(p->d_tie_ti, g_ti.data(), g_ti.size() * 4)) || (rc = upload(p->d_tie_off, g_off.data(), g_off.size() * 4)) ||
+                (rc = upload(p->d_tie_n, g_n.data(), g_n.size() * 4)))
+                return fail(rc);
+        }
+        p->tie_ambiguous = count > TIE_CAP || (count > 0 && no_fix);
         if (p->tie_ambiguous) {
-            // the float32 ring kernels stay available when asked for by name (their contract is a float32
-            // tolerance on band-limited data); everything the library chooses itself goes per pair
+            // more ties than the list holds (or the correction switched off): the float32 ring kernels stay available
+            // when asked for by name; everything the library chooses itself goes per pair
             if (mode == IMPDAR_KIRCH_FAST && requested_mode == IMPDAR_KIRCH_AUTO) {
                 mode = p->mode = IMPDAR_KIRCH_EXACT;
                 p->quad = false;
@@ -2600,6 +2712,42 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
             else
                 hipLaunchKernelGGL((kirch_exact_kernel<double, false>), grid, dim3(256), 0, st, P);
         }
+        IMPDAR_HIP_CHECK(hipGetLastError());
+    }
+    if (nx > 0 && p->ntie_groups > 0 && impdar_kirch_plan_kernel(p) != IMPDAR_KERNEL_EXACT_PAIR) {
+        // the (sample, offset) entries whose pick rounding noise decides, pair by pair (kirch_tiefix_kernel)
+        const int kern = impdar_kirch_plan_kernel(p);
+        TieFixParams F;
+        F.GT = img_row0(p, p->GT[b]);
+        F.DT = p->nearfield ? img_row0(p, p->DT[b]) : nullptr;
+        F.out = d_out;
+        F.ldo = nx;
+        F.snum = p->snum;
+        F.tnum = p->tnum;
+        F.xlo = xlo;
+        F.xhi = xhi;
+        F.grp = kern == IMPDAR_KERNEL_QUAD ? 8 : (kern == IMPDAR_KERNEL_DQUAD ? 4 : 0);
+        F.near = p->nearfield;
+        F.dist = p->d_dist.as<double>();
+        F.zs = p->d_zs.as<double>();
+        F.zs2 = p->d_zs2.as<double>();
+        F.tt = p->d_tt.as<double>();
+        F.dx = p->dx;
+        F.vel = p->vel;
+        F.tmax = p->tmax;
+        F.inv_dt = 1.0 / p->dt;
+        F.tt0 = p->tt0;
+        F.g_ti = p->d_tie_ti.as<int>();
+        F.g_off = p->d_tie_off.as<int>();
+        F.g_n = p->d_tie_n.as<int>();
+        const bool xtab = kern == IMPDAR_KERNEL_EXACT_TAB;
+        F.hmax = xtab ? p->d_xhmax.as<int>() : p->d_hmax.as<int>();
+        F.nmax = xtab ? p->xntab : p->ntab - 1;
+        const dim3 grid((nx + 255) / 256, p->ntie_groups);
+        if (p->dtype == IMPDAR_F32)
+            hipLaunchKernelGGL(kirch_tiefix_kernel<float>, grid, dim3(256), 0, st, F);
+        else
+            hipLaunchKernelGGL(kirch_tiefix_kernel<double>, grid, dim3(256), 0, st, F);
         IMPDAR_HIP_CHECK(hipGetLastError());
     }
     IMPDAR_HIP_CHECK(hipEventRecord(ev[5], st));

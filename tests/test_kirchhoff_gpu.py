@@ -538,34 +538,58 @@ def test_float64_ring_output_blocks_of_a_sharded_run(hip, monkeypatch):
     plan.destroy()
 
 
-def test_ties_that_rounding_noise_decides_go_to_the_per_pair_kernel(hip, monkeypatch):
+def test_ties_that_rounding_noise_decides_are_redone_pair_by_pair(hip, monkeypatch):
     """Moveout 2dx/(v dt) = 2.5 samples per trace with whole-sample times: 4a^2 + 25n^2 is an odd square for whole
     families of (a, n), i.e. travel times exactly half way between two samples.  The reference breaks those ties
-    pair by pair (the last bits of dist[j] - dist[xi]); a per-offset table cannot (it was 10 % off on this
-    radargram).  The plan must see that and keep the per-pair kernel; an irrational moveout keeps the ring."""
+    pair by pair (the last bits of dist[j] - dist[xi]); a per-offset table cannot (round 1's tabulated kernel was
+    10 % off on this radargram).  The plan lists the flagged (sample, offset) entries and kirch_tiefix_kernel re-does
+    them in the reference's arithmetic after the table-driven sum: every kernel meets its bar, the ring kernels stay
+    in use; with the correction switched off the plan falls back to the per-pair kernel."""
     from impdar_amd import _hip, synth
-    from impdar_amd.kirchhoff import KirchhoffPlan
+    from impdar_amd.kirchhoff import KirchhoffPlan, migrate_resident
     from oracle import c_oracle
     monkeypatch.delenv('IMPDAR_KIRCH_EXACT_IMPL', raising=False)
     snum, tnum, vel = 252, 297, 1.2e8
     geo = synth.geometry(snum, tnum, dt=2e-9, dx=0.3, t0_us=-0.02)
     x = synth.noise_radargram(snum, tnum, seed=109)
-    want = c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], vel, True)
-    got = _exact_with(monkeypatch, None, x, geo, vel=vel, nearfield=True)
-    assert _exact_with.kernel == 'kirch_exact_kernel'
-    assert rel_max(got, want) < EXACT_TOL
     ctx = _hip.context()
-    # what the library chooses by itself for float32 data on that geometry, and what it does when asked by name
+    for near in (True, False):
+        want = c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], vel, near)
+        for impl, kern in ((None, 'kirch_dquad_kernel'), ('tab', 'kirch_exact_tab_kernel'), ('pair', 'kirch_exact_kernel')):
+            got = _exact_with(monkeypatch, impl, x, geo, vel=vel, nearfield=near)
+            assert _exact_with.kernel == kern
+            assert rel_max(got, want) < EXACT_TOL, (near, impl, rel_max(got, want))
+        monkeypatch.delenv('IMPDAR_KIRCH_EXACT_IMPL', raising=False)
+        out, mode, _ = migrate_resident(ctx, x.astype(np.float32), geo['dist'], geo['travel_time'], vel, near, 'auto')
+        assert mode == 'fast' and rel_l2(out, want) < FAST_L2 and rel_max(out, want) < FAST_MAX
+    # output blocks of a sharded run get the same corrections
+    got = _exact_with(monkeypatch, None, x, geo, vel=vel, nearfield=False)
+    plan = KirchhoffPlan(ctx, np.float64, snum, tnum, geo['dist'], geo['travel_time'], vel, False, 'exact')
+    d_in = _hip.DeviceArray.from_host(ctx, x)
+    d_out = _hip.DeviceArray(ctx, (snum, 100), np.float64)
+    plan.prep(d_in, tnum, 0, tnum)
+    plan.migrate(d_out, 57, 157)
+    plan.sync()
+    assert np.array_equal(d_out.to_host(), got[:, 57:157])
+    plan.destroy()
+    d_in.free()
+    d_out.free()
+    # correction off: what the library chooses by itself goes per pair, a kernel asked for by name is served
+    monkeypatch.setenv('IMPDAR_KIRCH_TIEFIX', '0')
     auto = KirchhoffPlan(ctx, np.float32, snum, tnum, geo['dist'], geo['travel_time'], vel, True, 'auto')
     fast = KirchhoffPlan(ctx, np.float32, snum, tnum, geo['dist'], geo['travel_time'], vel, True, 'fast')
     assert (auto.mode, auto.kernel) == ('exact', 'kirch_exact_kernel') and fast.mode == 'fast'
     auto.destroy()
     fast.destroy()
-    g3 = synth.geometry(4096, 10000)               # BASELINE config 3: 2 / 1.69 samples per trace
-    for dtype, kern in ((np.float64, 'kirch_dquad_kernel'), (np.float32, 'kirch_quad_kernel')):
-        plan = KirchhoffPlan(ctx, dtype, 4096, 10000, g3['dist'], g3['travel_time'], 1.69e8, False, 'auto')
-        assert plan.kernel == kern
-        plan.destroy()
+    monkeypatch.delenv('IMPDAR_KIRCH_TIEFIX')
+    # BASELINE config 3 (2 / 1.69 samples per trace: no ties) and the same with RadarData.migrate's default velocity
+    # 1.68e8 (25/21 samples per trace: one flagged entry in 1.1e7): ring kernels either way
+    g3 = synth.geometry(4096, 10000)
+    for v in (1.69e8, 1.68e8):
+        for dtype, kern in ((np.float64, 'kirch_dquad_kernel'), (np.float32, 'kirch_quad_kernel')):
+            plan = KirchhoffPlan(ctx, dtype, 4096, 10000, g3['dist'], g3['travel_time'], v, False, 'auto')
+            assert plan.kernel == kern
+            plan.destroy()
 
 
 @pytest.mark.parametrize('xb,nh,lk', [('40', '2', '0'), ('40', '3', '0'), ('40', '2', '1'), ('40', '3', '1'), ('32', '2', '0')])
