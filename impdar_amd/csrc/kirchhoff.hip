@@ -1711,6 +1711,7 @@ struct impdar_kirch_plan {
     bool quad = false;          // sample-major LDS ring (kirch_quad_kernel)
     std::vector<int> h_hmax;    // host copy of the per-chunk aperture half widths (tile cost model)
     DevBuf d_queue;             // quad kernel, persistent workgroups: per-XCD item counters
+    int slots = 0;              // ... and how many of them are resident at once (occupancy query, cached)
     DevBuf d_tilemap;           // ring kernels: (chunk, slot, XCD) -> output tile, balanced over the XCDs
     std::vector<short> h_tilemap;
     int tm_key[5] = {-1, -1, -1, -1, -1};   // (xlo, xhi, tile width, G, tiles_per_xcd) the cached map was built for
@@ -2441,15 +2442,19 @@ static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipSt
         static const bool no_queue = getenv("IMPDAR_KIRCH_QUEUE") && !strcmp(getenv("IMPDAR_KIRCH_QUEUE"), "0");
         if (P.tilemap && !no_queue) {
             // persistent workgroups: as many as are resident at once, each pulling items from the per-XCD queues
-            int per_cu = 0, ncu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, KF_THREADS * NH, shmem) == hipSuccess &&
-                hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->ctx->device) == hipSuccess &&
-                per_cu > 0 && ncu > 0 && (long long)per_cu * ncu < nblk && p->d_queue.ensure(8 * 64) == hipSuccess) {
+            if (p->slots <= 0) {        // resident workgroups of this plan's kernel on this device: asked once
+                int per_cu = 0, ncu = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, KF_THREADS * NH, shmem) == hipSuccess &&
+                    hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->ctx->device) == hipSuccess &&
+                    per_cu > 0 && ncu > 0)
+                    p->slots = per_cu * ncu;
+                else
+                    (void)hipGetLastError();
+            }
+            if (p->slots > 0 && p->slots < nblk && p->d_queue.ensure(8 * 64) == hipSuccess) {
                 IMPDAR_HIP_CHECK(hipMemsetAsync(p->d_queue.p, 0, 8 * 64, st));
                 P.queue = p->d_queue.as<int>();
-                grid = per_cu * ncu;
-            } else {
-                (void)hipGetLastError();
+                grid = p->slots;
             }
         }
         hipLaunchKernelGGL(k, dim3(grid), dim3(KF_THREADS * NH), shmem, st, P, W);
@@ -2489,15 +2494,19 @@ static int launch_dquad(impdar_kirch_plan *p, const FastParams &P0, hipStream_t 
         int grid = nblk;
         static const bool no_queue = getenv("IMPDAR_KIRCH_QUEUE") && !strcmp(getenv("IMPDAR_KIRCH_QUEUE"), "0");
         if (P.tilemap && !no_queue) {
-            int per_cu = 0, ncu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, KF_THREADS * NH, shmem) == hipSuccess &&
-                hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->ctx->device) == hipSuccess &&
-                per_cu > 0 && ncu > 0 && (long long)per_cu * ncu < nblk && p->d_queue.ensure(8 * 64) == hipSuccess) {
+            if (p->slots <= 0) {        // resident workgroups of this plan's kernel on this device: asked once
+                int per_cu = 0, ncu = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, KF_THREADS * NH, shmem) == hipSuccess &&
+                    hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->ctx->device) == hipSuccess &&
+                    per_cu > 0 && ncu > 0)
+                    p->slots = per_cu * ncu;
+                else
+                    (void)hipGetLastError();
+            }
+            if (p->slots > 0 && p->slots < nblk && p->d_queue.ensure(8 * 64) == hipSuccess) {
                 IMPDAR_HIP_CHECK(hipMemsetAsync(p->d_queue.p, 0, 8 * 64, st));
                 P.queue = p->d_queue.as<int>();
-                grid = per_cu * ncu;
-            } else {
-                (void)hipGetLastError();
+                grid = p->slots;
             }
         }
         hipLaunchKernelGGL(k, dim3(grid), dim3(KF_THREADS * NH), shmem, st, P, W);
