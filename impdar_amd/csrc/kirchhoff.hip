@@ -1689,6 +1689,7 @@ struct impdar_kirch_plan {
     int xntab = 0;
     bool xtab_ready = false, xtab_off = false;
     int diag_tables_built = 0;
+    bool table_built[2] = {false, false};   // ring kernels: the geometry-only pick table of buffer set b exists
     // device tables
     DevBuf d_dist, d_tt, d_zs, d_zs2, d_ga, d_gb, d_gc;
     // Everything a prep produces is double-buffered: prep / table / all-gather of radargram
@@ -2278,11 +2279,15 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
             hipLaunchKernelGGL((kirch_prep_kernel<double, double>), grid, dim3(256), 0, st, P);
         IMPDAR_HIP_CHECK(hipGetLastError());
     }
-    static const bool diag_table_once = getenv("IMPDAR_DIAG_TABLE_ONCE") != nullptr;   // timing diagnostic only
-    if (p->mode == IMPDAR_KIRCH_FAST && p->quad && diag_table_once && p->diag_tables_built >= 2) {
-        // timing diagnostic: both table buffers are built, leave them
+    // The pick table depends on the plan's geometry only (like an FFT plan's twiddles): it is built by the first prep
+    // into each of the two buffer sets and kept.  (Round 1 rebuilt it with every prep -- 0.06-0.13 ms on the producer
+    // stream, hidden behind a whole-radargram diffraction sum but a tenth of the step of an 8-rank block;
+    // IMPDAR_KIRCH_TABLE_EVERY_PREP=1 restores that.)
+    static const bool table_every_prep = getenv("IMPDAR_KIRCH_TABLE_EVERY_PREP") != nullptr;
+    if (((p->mode == IMPDAR_KIRCH_FAST && p->quad) || p->dquad) && !table_every_prep && p->table_built[b]) {
+        // this buffer set's table is in place
     } else if ((p->mode == IMPDAR_KIRCH_FAST && p->quad) || p->dquad) {
-        // geometry-only pick table, rebuilt with every prep (counted in prep time)
+        p->table_built[b] = true;
         ++p->diag_tables_built;
         TableQParams T;
         T.TKB = p->d_TK[b].as<uint4>();
