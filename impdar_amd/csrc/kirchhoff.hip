@@ -469,6 +469,9 @@ struct FastParams {
     int snum, tnum, xlo, xhi;
     const int *hmax;               // per sample-chunk aperture half width (+1 guard)     [nchunks]
     int nchunks, nxt, tiles_per_xcd, G;
+    int parts_log2;                // persistent ring kernels: every tile's walk as 1 << parts_log2 queue items (pieces)
+    void *partial;                 // ... their partial images [piece][snum][ldo] (element type = image type)
+    size_t part_stride;            // ... elements per partial image
     int *queue;                    // quad kernel, persistent workgroups: 8 item counters (one per XCD, 64 bytes apart), zeroed
                                    // before the launch; null = one item per block
     const short *tilemap;          // ring kernels: [nchunks][tiles_per_xcd][8] output tile of (chunk, slot, XCD), -1 = none
@@ -877,6 +880,11 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
     int *item_slot = reinterpret_cast<int *>(lds) + (size_t)(img_bytes / 4) * (NEAR ? 2 : 1);
     for (;;) {
     int chunk, xt;
+    // part: which piece of the tile's aperture walk this item is.  Plans of 4+ ranks cut every walk into 2 or 4
+    // pieces at fixed offsets (n = 1 and n = 1 -+ 56 k: whole ring revolutions, the same for every tile of a
+    // chunk) -- one walk of a shallow chunk is as long as such a rank's whole step should be.  A piece writes its
+    // sums to its own partial image; kirch_combine_kernel adds the pieces in a fixed order.
+    int part = 0;
     unsigned stamp_slot = blockIdx.x;
     if (P.queue) {
         __syncthreads();                       // every wave is done with the previous item (ring reads, the slot)
@@ -888,8 +896,10 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
             for (int v = 0; v < 8 && it < 0; ++v) {
                 const int x = (int)((xcc + v) & 7u);
                 for (;;) {
-                    const int i = atomicAdd(P.queue + x * 16, 1);
+                    const int i2 = atomicAdd(P.queue + x * 16, 1);
+                    const int i = i2 >> P.parts_log2;            // many-rank plans: 2 or 4 queue items per tile
                     if (i >= total) break;
+                    item_slot[2] = i2 & ((1 << P.parts_log2) - 1);
                     const int t = (int)P.tilemap[(size_t)i * 8 + x];
                     if (t >= 0 && t < P.nxt) {
                         it = ((i / P.tiles_per_xcd) << 16) | t;
@@ -903,6 +913,7 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
         __syncthreads();
         const int it = item_slot[0];
         stamp_slot = (unsigned)item_slot[1];
+        part = item_slot[2];
         if (it < 0) break;
         chunk = it >> 16;
         xt = it & 0xffff;
@@ -943,8 +954,23 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
     // until its own last offset, (NH - 1) XB steps longer)
     int nlo_ = max(-hmax, -(x0w + XB - 1));
     nlo_ -= (nlo_ - 1) & 7;
+    int nhi_ = min(hmax + (NH - 1) * XB, tnum - 1 - x0w);
+    bool empty_part = false;
+    if (P.parts_log2) {
+        // piece boundaries (all = 1 mod 8): ..., 1 - U k | 1 - U k .. 0 | 1 .. U k | 1 + U k, ...   (2 pieces: n <= 0 | n >= 1)
+        const int uk = (NB * S) * max(1, (hmax + NB * S) / (2 * NB * S));
+        const int inner = P.parts_log2 == 2 ? uk : (1 << 28);
+        const int side = P.parts_log2 == 2 ? (part >> 1) : part;          // 0: n <= 0, 1: n >= 1
+        const bool far = P.parts_log2 == 2 && ((part & 1) ^ side) == 0;    // pieces 0 and 3 are the outer ones
+        const int lo = side == 0 ? (far ? -(1 << 28) : 1 - inner) : (far ? 1 + inner : 1);
+        const int hi = side == 0 ? (far ? -inner : 0) : (far ? (1 << 28) : inner);
+        nlo_ = max(nlo_, lo);
+        nhi_ = min(nhi_, hi);
+        empty_part = nhi_ < nlo_;
+    }
+    if (empty_part) continue;                    // uniform; the partial images are zeroed before the launch
     const int nlo = nlo_;
-    const int nhi = min(hmax + (NH - 1) * XB, tnum - 1 - x0w);
+    const int nhi = nhi_;
     const int nsteps = nhi - nlo + 1;
     const int nblocks = (nsteps + S - 1) / S;
     // the main loop always runs whole ring revolutions (NB blocks); steps past the
@@ -960,7 +986,9 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
 #ifdef KQ_DIAG_PICKHOT      // diagnostic build: every pick load hits the same 16 table rows (L2-hot); results invalid
     auto prow_of = [&](int blk) { return (mrow_h + blk) & 15; };
 #else
-    auto prow_of = [&](int blk) { return max(min(mrow_h + blk, P.nrows - 1), 0); };
+    // (blocks past the walk -- the padding of the last ring revolution -- read the table's last, all-dropped row: after
+    // a piece of a walk they would otherwise be offsets that the next piece owns)
+    auto prow_of = [&](int blk) { return blk >= nblocks ? P.nrows - 1 : max(min(mrow_h + blk, P.nrows - 1), 0); };
 #endif
 
     // Staging window of the 8 traces block `blk_for` adds: one 8-byte lookup, issued ONE BLOCK EARLIER
@@ -1292,7 +1320,8 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // the look-ahead DMA must land before the LDS is released
 
     if (ti_raw < snum) {
-        float *o = P.out + (size_t)ti_raw * P.ldo + (x0 - P.xlo);
+        float *o = (P.parts_log2 ? reinterpret_cast<float *>(P.partial) + (size_t)part * P.part_stride : P.out) +
+                   (size_t)ti_raw * P.ldo + (x0 - P.xlo);
 #pragma unroll
         for (int i = 0; i < XB; ++i)
             if (x0 + i >= P.xlo && x0 + i < P.xhi) o[i] = KQ_ACC(i) * fin;
@@ -1404,6 +1433,7 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_dquad_kernel(FastP
     int *item_slot = reinterpret_cast<int *>(lds) + (size_t)(img_bytes / 4) * (NEAR ? 2 : 1);
     for (;;) {
     int chunk, xt;
+    int part = 0;            // see kirch_quad_kernel: which piece of the tile's aperture walk (plans of 4+ ranks)
     if (P.queue) {
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1414,8 +1444,10 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_dquad_kernel(FastP
             for (int v = 0; v < 8 && it < 0; ++v) {
                 const int x = (int)((xcc + v) & 7u);
                 for (;;) {
-                    const int i = atomicAdd(P.queue + x * 16, 1);
+                    const int i2 = atomicAdd(P.queue + x * 16, 1);
+                    const int i = i2 >> P.parts_log2;            // many-rank plans: 2 or 4 queue items per tile
                     if (i >= total) break;
+                    item_slot[2] = i2 & ((1 << P.parts_log2) - 1);
                     const int t = (int)P.tilemap[(size_t)i * 8 + x];
                     if (t >= 0 && t < P.nxt) {
                         it = ((i / P.tiles_per_xcd) << 16) | t;
@@ -1427,6 +1459,7 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_dquad_kernel(FastP
         }
         __syncthreads();
         const int it = item_slot[0];
+        part = item_slot[2];
         if (it < 0) break;
         chunk = it >> 16;
         xt = it & 0xffff;
@@ -1458,8 +1491,22 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_dquad_kernel(FastP
     const int hmax = P.hmax[chunk];
     int nlo_ = max(-hmax, -(x0w + XB - 1));      // tile 0's offsets are the ring clock
     nlo_ -= (nlo_ - 1) & 3;                      // x0w + nlo = 1 mod 4: a block's 4 new traces are one image group
+    int nhi_ = min(hmax + (NH - 1) * XB, tnum - 1 - x0w);
+    bool empty_part = false;
+    if (P.parts_log2) {                          // piece boundaries: see kirch_quad_kernel
+        const int uk = (NB * S) * max(1, (hmax + NB * S) / (2 * NB * S));
+        const int inner = P.parts_log2 == 2 ? uk : (1 << 28);
+        const int side = P.parts_log2 == 2 ? (part >> 1) : part;
+        const bool far = P.parts_log2 == 2 && ((part & 1) ^ side) == 0;
+        const int lo = side == 0 ? (far ? -(1 << 28) : 1 - inner) : (far ? 1 + inner : 1);
+        const int hi = side == 0 ? (far ? -inner : 0) : (far ? (1 << 28) : inner);
+        nlo_ = max(nlo_, lo);
+        nhi_ = min(nhi_, hi);
+        empty_part = nhi_ < nlo_;
+    }
+    if (empty_part) continue;                    // uniform; the partial images are zeroed before the launch
     const int nlo = nlo_;
-    const int nhi = min(hmax + (NH - 1) * XB, tnum - 1 - x0w);
+    const int nhi = nhi_;
     const int nsteps = nhi - nlo + 1;
     const int nblocks = (nsteps + S - 1) / S;
     const int nrev = (nblocks + NB - 1) / NB;
@@ -1467,7 +1514,7 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_dquad_kernel(FastP
     const int mrow = ((nlo - 1) >> 2) + P.mrow0;
     auto row_of = [&](int blk) { return min(mrow + blk, P.nrows - 1); };
     const int mrow_h = mrow - half * (XB / 4);   // this tile's pick rows: half * XB offsets behind the clock
-    auto prow_of = [&](int blk) { return max(min(mrow_h + blk, P.nrows - 1), 0); };
+    auto prow_of = [&](int blk) { return blk >= nblocks ? P.nrows - 1 : max(min(mrow_h + blk, P.nrows - 1), 0); };
 
     const int2 *WIN = P.WIN + (size_t)chunk * P.nrows;
     auto fetch_for = [&](int blk_for, int &a, int &b) {
@@ -1663,7 +1710,8 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_dquad_kernel(FastP
     __builtin_amdgcn_s_waitcnt(0x0F70);
 
     if (ti_raw < snum) {
-        double *o = reinterpret_cast<double *>(P.out) + (size_t)ti_raw * P.ldo + (x0 - P.xlo);
+        double *o = (P.parts_log2 ? reinterpret_cast<double *>(P.partial) + (size_t)part * P.part_stride
+                                  : reinterpret_cast<double *>(P.out)) + (size_t)ti_raw * P.ldo + (x0 - P.xlo);
 #pragma unroll
         for (int i = 0; i < XB; ++i)
             if (x0 + i >= P.xlo && x0 + i < P.xhi) o[i] = (fin == 0.0) ? 0.0 : KD_ACC(i) * fin;
@@ -1671,6 +1719,17 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_dquad_kernel(FastP
 #undef KD_ACC
     if (!P.queue) break;
     }   // item loop
+}
+
+// sum of the pieces of every aperture walk, in piece order (many-rank plans, see kirch_quad_kernel)
+template <typename T, int K>
+__global__ __launch_bounds__(256) void kirch_combine_kernel(const T *__restrict__ partial, T *__restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    T v = partial[i] + partial[n + i];
+    if (K == 4) v = (v + partial[2 * n + i]) + partial[3 * n + i];
+    out[i] = v;
 }
 
 // ===========================================================================
@@ -1713,6 +1772,8 @@ struct impdar_kirch_plan {
     std::vector<int> h_hmax;    // host copy of the per-chunk aperture half widths (tile cost model)
     DevBuf d_queue;             // quad kernel, persistent workgroups: per-XCD item counters
     int slots = 0;              // ... and how many of them are resident at once (occupancy query, cached)
+    int walk_parts_log2 = 0;    // every tile's aperture walk as 1, 2 or 4 queue items (plans of 4+ / 8+ ranks)
+    DevBuf d_partial;           // ... and the partial images of the pieces
     DevBuf d_tilemap;           // ring kernels: (chunk, slot, XCD) -> output tile, balanced over the XCDs
     std::vector<short> h_tilemap;
     int tm_key[5] = {-1, -1, -1, -1, -1};   // (xlo, xhi, tile width, G, tiles_per_xcd) the cached map was built for
@@ -1902,6 +1963,15 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         return IMPDAR_ERR_UNSUPPORTED;
     }
     p->mode = mode;
+    {
+        // One full-aperture walk of a shallow chunk takes ~1.2 ms at config 3 -- as long as the whole step of a rank of
+        // an 8-GPU run should be, and such a rank's block has fewer items than the chip has workgroup slots.  Plans
+        // of 4+ ranks cut every walk in 2, of 8+ ranks in 4 pieces (kirch_quad_kernel); the pieces are summed in a
+        // fixed order, so launches stay bit-reproducible (against whole walks the sum differs by rounding).
+        const char *pe = getenv("IMPDAR_KIRCH_PARTS");      // tuning knob: 1 | 2 | 4
+        const int parts = pe ? atoi(pe) : (nranks >= 8 ? 4 : (nranks >= 4 ? 2 : 1));
+        p->walk_parts_log2 = parts == 4 ? 2 : (parts == 2 ? 1 : 0);
+    }
     {
         const char *ie = getenv("IMPDAR_KIRCH_IMPL");       // tuning knob: "tab" forces the b32 ring
         p->quadW = wq;
@@ -2456,13 +2526,39 @@ static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipSt
                 else
                     (void)hipGetLastError();
             }
-            if (p->slots > 0 && p->slots < nblk && p->d_queue.ensure(8 * 64) == hipSuccess) {
+            // many-rank plans: every walk in 2 or 4 pieces with partial images of their own (p->walk_parts_log2)
+            const int pl2 = NH == 1 ? p->walk_parts_log2 : 0;
+            const size_t nout = (size_t)P.snum * P.ldo, esz = impdar_dtype_size(p->dtype);
+            const bool pieces = pl2 > 0 && p->slots > 0 && p->d_partial.ensure((nout << pl2) * esz) == hipSuccess;
+            if (p->slots > 0 && (p->slots < nblk || pieces) && p->d_queue.ensure(8 * 64) == hipSuccess) {
                 IMPDAR_HIP_CHECK(hipMemsetAsync(p->d_queue.p, 0, 8 * 64, st));
                 P.queue = p->d_queue.as<int>();
-                grid = p->slots;
+                if (pieces) {
+                    P.parts_log2 = pl2;
+                    P.partial = p->d_partial.p;
+                    P.part_stride = nout;
+                    // a piece no workgroup reaches (tiles beyond the block's end) must read as zero
+                    IMPDAR_HIP_CHECK(hipMemsetAsync(p->d_partial.p, 0, (nout << pl2) * esz, st));
+                }
+                grid = (int)std::min<long long>(p->slots, (long long)nblk << P.parts_log2);
             }
         }
         hipLaunchKernelGGL(k, dim3(grid), dim3(KF_THREADS * NH), shmem, st, P, W);
+        if (P.parts_log2) {
+            const size_t nout = (size_t)P.snum * P.ldo;
+            const dim3 cg((unsigned)((nout + 255) / 256));
+            if (p->dtype == IMPDAR_F32) {
+                if (P.parts_log2 == 2)
+                    hipLaunchKernelGGL((kirch_combine_kernel<float, 4>), cg, dim3(256), 0, st, (const float *)P.partial, (float *)P.out, nout);
+                else
+                    hipLaunchKernelGGL((kirch_combine_kernel<float, 2>), cg, dim3(256), 0, st, (const float *)P.partial, (float *)P.out, nout);
+            } else {
+                if (P.parts_log2 == 2)
+                    hipLaunchKernelGGL((kirch_combine_kernel<double, 4>), cg, dim3(256), 0, st, (const double *)P.partial, (double *)P.out, nout);
+                else
+                    hipLaunchKernelGGL((kirch_combine_kernel<double, 2>), cg, dim3(256), 0, st, (const double *)P.partial, (double *)P.out, nout);
+            }
+        }
     }
     IMPDAR_HIP_CHECK(hipGetLastError());
     return IMPDAR_OK;
@@ -2508,13 +2604,39 @@ static int launch_dquad(impdar_kirch_plan *p, const FastParams &P0, hipStream_t 
                 else
                     (void)hipGetLastError();
             }
-            if (p->slots > 0 && p->slots < nblk && p->d_queue.ensure(8 * 64) == hipSuccess) {
+            // many-rank plans: every walk in 2 or 4 pieces with partial images of their own (p->walk_parts_log2)
+            const int pl2 = NH == 1 ? p->walk_parts_log2 : 0;
+            const size_t nout = (size_t)P.snum * P.ldo, esz = impdar_dtype_size(p->dtype);
+            const bool pieces = pl2 > 0 && p->slots > 0 && p->d_partial.ensure((nout << pl2) * esz) == hipSuccess;
+            if (p->slots > 0 && (p->slots < nblk || pieces) && p->d_queue.ensure(8 * 64) == hipSuccess) {
                 IMPDAR_HIP_CHECK(hipMemsetAsync(p->d_queue.p, 0, 8 * 64, st));
                 P.queue = p->d_queue.as<int>();
-                grid = p->slots;
+                if (pieces) {
+                    P.parts_log2 = pl2;
+                    P.partial = p->d_partial.p;
+                    P.part_stride = nout;
+                    // a piece no workgroup reaches (tiles beyond the block's end) must read as zero
+                    IMPDAR_HIP_CHECK(hipMemsetAsync(p->d_partial.p, 0, (nout << pl2) * esz, st));
+                }
+                grid = (int)std::min<long long>(p->slots, (long long)nblk << P.parts_log2);
             }
         }
         hipLaunchKernelGGL(k, dim3(grid), dim3(KF_THREADS * NH), shmem, st, P, W);
+        if (P.parts_log2) {
+            const size_t nout = (size_t)P.snum * P.ldo;
+            const dim3 cg((unsigned)((nout + 255) / 256));
+            if (p->dtype == IMPDAR_F32) {
+                if (P.parts_log2 == 2)
+                    hipLaunchKernelGGL((kirch_combine_kernel<float, 4>), cg, dim3(256), 0, st, (const float *)P.partial, (float *)P.out, nout);
+                else
+                    hipLaunchKernelGGL((kirch_combine_kernel<float, 2>), cg, dim3(256), 0, st, (const float *)P.partial, (float *)P.out, nout);
+            } else {
+                if (P.parts_log2 == 2)
+                    hipLaunchKernelGGL((kirch_combine_kernel<double, 4>), cg, dim3(256), 0, st, (const double *)P.partial, (double *)P.out, nout);
+                else
+                    hipLaunchKernelGGL((kirch_combine_kernel<double, 2>), cg, dim3(256), 0, st, (const double *)P.partial, (double *)P.out, nout);
+            }
+        }
     }
     IMPDAR_HIP_CHECK(hipGetLastError());
     return IMPDAR_OK;
@@ -2591,6 +2713,9 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         P.stamps = nullptr;
         P.tilemap = nullptr;
         P.queue = nullptr;
+        P.parts_log2 = 0;
+        P.partial = nullptr;
+        P.part_stride = 0;
 #ifdef KQ_STAMP
         if (p->d_stamps.ensure((size_t)1 << 22) == hipSuccess) {
             (void)hipMemsetAsync(p->d_stamps.p, 0, (size_t)1 << 22, st);
