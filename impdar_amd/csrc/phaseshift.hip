@@ -20,6 +20,7 @@
 // contiguous runs of TK_T[k][tau].
 #include "fft.h"
 #include <mutex>
+#include <type_traits>
 
 template <typename T> struct Cp { T x, y; };
 
@@ -114,6 +115,30 @@ template <> __device__ inline void sincos_t<float>(float x, float *s, float *c)
 }
 template <> __device__ inline void sincos_t<double>(double x, double *s, double *c) { sincos(x, s, c); }
 
+// float32 recurrences are re-anchored to the original spectrum and the fp64 phase every PS_ANCHOR depth steps.
+// Measured at config 5 (8192^2, same box): 64 -> 65.8 / 84.0 ms (const / v(z)) with a spot-wavenumber error of
+// 0.8e-6 / 2.1e-6 against the fp64 oracle; 128 -> 63.0 / 80.5 ms, 1.6e-6 / 4.2e-6; 256 -> 62.0 / 78.9 ms,
+// 3.1e-6 / 8.2e-6 (the drift is systematic: it doubles with the interval).  128 keeps the error at the scale of
+// the fp32 FFTs around the kernel, 50x inside the stated 2e-4.
+#ifndef IMPDAR_PS_ANCHOR
+#define IMPDAR_PS_ANCHOR 128
+#endif
+constexpr int PS_ANCHOR = IMPDAR_PS_ANCHOR;
+
+#ifdef IMPDAR_PS_DIAG_STAMPS
+// diagnostics build: core-clock stamps of one workgroup's tiles 100..115 (5 points per tile, waves 0 and 7)
+__device__ long long ps_dbg_stamps[2 * 16 * 5];
+#define PS_STAMP(point) \
+    if (blockIdx.x == 300 && (tid == 0 || tid == 448) && tile >= 100 && tile < 116) \
+        ps_dbg_stamps[((tid ? 1 : 0) * 16 + (tile - 100)) * 5 + (point)] = (long long)__builtin_readcyclecounter();
+extern "C" int impdar_ps_debug_stamps(long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ps_dbg_stamps), sizeof(long long) * 2 * 16 * 5) == hipSuccess ? 0 : 1;
+}
+#else
+#define PS_STAMP(point)
+#endif
+
 struct PsParams {
     const void *F;          // [tnum][nt] complex
     void *TK;               // [tnum][snum] complex
@@ -124,7 +149,7 @@ struct PsParams {
     double vconst, dt;
     double vtol;            // float32 v(z): relative velocity change below which the phase increments are reused
     const int *sched;       // float32 v(z), ps_vz32_kernel: [snum] 1 where a new constant-velocity run starts
-    const int *tsched;      // ... [ceil(snum/16)] 1 where a 16-step tile holds such a step
+    const int *tsched;      // ... [ceil(ntile/32)] bit t of word t/32 set where 16-step tile t holds such a step
     int snum, tnum, nt, vz_mode;
 };
 
@@ -132,16 +157,63 @@ struct PsParams {
 // halving step sends half of the remaining values to the partner lane; once one value is
 // left the remaining lane bits are folded with plain butterflies.  On return v[0] of lane
 // L holds the total of value index (L >> (6 - log2 NV)) & (NV - 1).
+// value of the lane MASK away (lane ^ MASK).  float32: DPP moves inside a 16-lane row (no LDS crossbar round trip:
+// ds_bpermute costs a wave ~100 cycles of latency per dependent step, and all waves of the one resident
+// workgroup reduce at the same moment, so nothing hides it)
+template <typename T, int MASK> __device__ __forceinline__ T lane_xor(T v)
+{
+#ifdef IMPDAR_PS_DIAG_SHFL
+    constexpr bool DPP = false;
+#else
+    constexpr bool DPP = true;
+#endif
+    if constexpr (DPP && sizeof(T) == 4 && MASK <= 8) {
+        const unsigned u = __float_as_uint(v);
+        unsigned x;
+        if constexpr (MASK == 1) x = __builtin_amdgcn_update_dpp(0u, u, 0xB1, 0xf, 0xf, false);        // quad_perm:[1,0,3,2]
+        else if constexpr (MASK == 2) x = __builtin_amdgcn_update_dpp(0u, u, 0x4E, 0xf, 0xf, false);   // quad_perm:[2,3,0,1]
+        else if constexpr (MASK == 4) {
+            x = __builtin_amdgcn_update_dpp(0u, u, 0x104, 0xf, 0x5, false);    // row_shl:4 into banks 0 and 2 (lane <- lane + 4)
+            x = __builtin_amdgcn_update_dpp(x, u, 0x114, 0xf, 0xa, false);     // row_shr:4 into banks 1 and 3 (lane <- lane - 4)
+        } else x = __builtin_amdgcn_update_dpp(0u, u, 0x128, 0xf, 0xf, false);                         // row_ror:8
+        return __uint_as_float(x);
+    } else {
+        return __shfl_xor(v, MASK, 64);
+    }
+}
+
 template <typename T, int HALF, int MASK, int NV>
 __device__ __forceinline__ void wrs_halve(T (&v)[NV], int lane)
 {
-    // keep HALF of the 2*HALF live values, hand the other half to the lane MASK away
-    const bool up = (lane & MASK) != 0;
+#ifdef IMPDAR_PS_DIAG_SHFL
+    constexpr bool SWAP = false;
+#else
+    constexpr bool SWAP = true;
+#endif
+    if constexpr (SWAP && sizeof(T) == 4 && (MASK == 32 || MASK == 16)) {
+        // gfx950 v_permlane32_swap / v_permlane16_swap: the upper half (odd rows) of the first operand trades places
+        // with the lower half (even rows) of the second -- afterwards every lane holds the value it keeps and the one
+        // its partner sent, in the two registers
 #pragma unroll
-    for (int i = 0; i < HALF; ++i) {
-        const T send = up ? v[i] : v[i + HALF];
-        const T keep = up ? v[i + HALF] : v[i];
-        v[i] = keep + __shfl_xor(send, MASK, 64);
+        for (int i = 0; i < HALF; ++i) {
+            const unsigned a = __float_as_uint(v[i]), b = __float_as_uint(v[i + HALF]);
+            if constexpr (MASK == 32) {
+                const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+                v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            } else {
+                const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+                v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            }
+        }
+    } else {
+        // keep HALF of the 2*HALF live values, hand the other half to the lane MASK away
+        const bool up = (lane & MASK) != 0;
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) {
+            const T send = up ? v[i] : v[i + HALF];
+            const T keep = up ? v[i + HALF] : v[i];
+            v[i] = keep + lane_xor<T, MASK>(send);
+        }
     }
 }
 
@@ -157,14 +229,14 @@ __device__ __forceinline__ void wave_reduce_scatter(T (&v)[NV], int lane)
         wrs_halve<T, 4, 8>(v, lane);
         wrs_halve<T, 2, 4>(v, lane);
         wrs_halve<T, 1, 2>(v, lane);
-        v[0] += __shfl_xor(v[0], 1, 64);
+        v[0] += lane_xor<T, 1>(v[0]);
     } else {
         wrs_halve<T, 4, 32>(v, lane);
         wrs_halve<T, 2, 16>(v, lane);
         wrs_halve<T, 1, 8>(v, lane);
-        v[0] += __shfl_xor(v[0], 4, 64);
-        v[0] += __shfl_xor(v[0], 2, 64);
-        v[0] += __shfl_xor(v[0], 1, 64);
+        v[0] += lane_xor<T, 4>(v[0]);
+        v[0] += lane_xor<T, 2>(v[0]);
+        v[0] += lane_xor<T, 1>(v[0]);
     }
 }
 
@@ -179,7 +251,7 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
     __shared__ T red[2][NW][2 * PS_TT];
     // float32 v(z): the fp64 phase increment of every owned frequency at the current velocity lives in LDS
     // ([m][thread], each thread reads only what it wrote): 2M registers too many, and recomputing it (fp64
-    // divide + square root) at every anchor cost as much as the 64 steps in between
+    // divide + square root) at every anchor cost as much as the steps in between
     __shared__ double phd_lds[(VZ && sizeof(T) == 4) ? M * BLOCK : 1];
     const int k = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -190,9 +262,9 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
     // float32 data: a multiplicative recurrence in fp32 drifts systematically (the rounded rotation is the
     // same at every depth step of a constant-velocity run: 8192 steps x 6e-8 = 5e-4 .. 2e-3 at config 5),
     // so the accumulated phase is kept in fp64 and the spectrum is rotated from its ORIGINAL value:
-    //   constant v: recurrence, re-anchored to FK0 * exp(i tau phi) every 64 depth steps
+    //   constant v: recurrence, re-anchored to FK0 * exp(i tau phi) every PS_ANCHOR depth steps
     //   v(z):       Phi += w dt sqrt(coss) in fp64 (the increment is recomputed in fp64 only when the
-    //               velocity changes); F = FK0 * exp(i Phi) at every velocity change and every 64th step,
+    //               velocity changes); F = FK0 * exp(i Phi) at every velocity change and every PS_ANCHOR-th step,
     //               a fixed fp32 rotation per step in between (as for constant v)
     // float64 data keeps the reference's recurrence (rounding 1e-16 per step).
     constexpr bool F32 = sizeof(T) == 4;
@@ -268,6 +340,7 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
 
     const int ntile = (P.snum + PS_TT - 1) / PS_TT;
     for (int tile = 0; tile < ntile; ++tile) {
+        PS_STAMP(0)
         T acc[2 * PS_TT];
 #pragma unroll
         for (int i = 0; i < 2 * PS_TT; ++i) acc[i] = 0;
@@ -276,7 +349,7 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
         // all M x TT of them and the live temporaries spill; threading the state through an empty
         // volatile asm after every (tau, frequency) update pins the order without adding code.
         if (!VZ) {
-            if (F32 && tile > 0 && (tile & 3) == 0) {
+            if (F32 && tile > 0 && (tile & (PS_ANCHOR / PS_TT - 1)) == 0) {
                 // re-anchor: state after tau0 steps = FK0 * exp(i tau0 phi), phase reduced in fp64
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
@@ -358,7 +431,7 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
                         nrec = 0;
                     }
                     nrec += 1;
-                    if (changed || nrec == 64) {
+                    if (changed || nrec == PS_ANCHOR) {
                         // anchor: the state from the ORIGINAL spectrum and the fp64 phase
 #pragma unroll
                         for (int m = 0; m < M; ++m) {
@@ -374,7 +447,7 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
                         nrec = 0;
                     } else {
                         // same velocity as the last step: every frequency turns by its fixed increment; the
-                        // fp32 recurrence runs for at most 63 steps between anchors (4e-6 rad of drift)
+                        // fp32 recurrence runs for fewer than PS_ANCHOR steps between anchors (8e-6 rad of drift)
                         if (!rot_valid) {
 #pragma unroll
                             for (int m = 0; m < M; ++m) {
@@ -465,10 +538,20 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
             }
         }
         // ---- sum over frequencies: wave butterfly, then across waves via LDS
+#ifdef IMPDAR_PS_DIAG_NOREDUCE
+        { T z = 0;
+#pragma unroll
+          for (int i = 0; i < 2 * PS_TT; ++i) z += acc[i];
+          if (z == (T)12345.678) reinterpret_cast<T *>(TK)[tile] = z;
+          continue; }
+#endif
+        PS_STAMP(1)
         wave_reduce_scatter<T, 2 * PS_TT>(acc, lane);
         T (*buf)[2 * PS_TT] = red[tile & 1];
         if ((lane & ((1 << SH) - 1)) == 0) buf[wave][lane >> SH] = acc[0];
+        PS_STAMP(2)
         __syncthreads();
+        PS_STAMP(3)
         if (tid < 2 * PS_TT) {
             T s = 0;
 #pragma unroll
@@ -479,21 +562,44 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
                 *dst = s / (T)P.snum;                                   // TK /= snum, :492
             }
         }
+        PS_STAMP(4)
         // red[] is double-buffered: the next tile writes the other buffer and the
         // barrier of that tile orders it against these reads
     }
+}
+
+// loads through the scalar cache (uniform address, data read-only for the kernel), load and wait in one statement:
+// a split request / wait pair is not safe in C++ -- the compiler is free to copy the destination register between
+// the two statements, i.e. before the data has arrived
+__device__ __forceinline__ int scalar_load_i32(const int *p)
+{
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void scalar_load_2f64(const double *p, const double *q, double *a, double *b)
+{
+    double x, y;
+    asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(x), "=&s"(y)
+                 : "s"(p), "s"(q)
+                 : "memory");
+    *a = x;
+    *b = y;
 }
 
 // ---------------------------------------------------------------------------
 // float32 v(z) (Gazdag), layered profiles: the depth axis is cut into runs of constant velocity (the host
 // marks the steps where the velocity moves by more than P.vtol, the same rule ps_kernel applies on the fly),
 // and inside a run every frequency turns by a fixed rotation -- the constant-velocity inner loop.  A 16-step
-// tile without a run boundary, without a boundary frequency in the workgroup and inside the axis takes the
-// fully unrolled rotate-accumulate body of the constant-velocity kernel (6 instructions per (tau, frequency));
-// every other tile walks its steps one by one with the general update (velocity change: fold the pending
-// steps into the fp64 phase, new fp64 increment, evanescence settled for the run, mig_python.py:456-485;
-// boundary frequencies re-evaluated in fp64 at every step's own velocity; anchors).  The state is anchored
-// to FK0 * exp(i Phi) with the fp64 phase at every run start and at least every 64 steps.
+// tile without a run boundary and inside the axis ("quiet") takes the fully unrolled rotate-accumulate body of
+// the constant-velocity kernel (6 instructions per (tau, frequency)); every other tile walks its steps one by
+// one with the general update (velocity change: fold the pending steps into the fp64 phase, new fp64 increment,
+// evanescence settled for the run, mig_python.py:456-485; anchors).  Frequencies on the evanescent boundary
+// (|coss| < 1e-8: kept or dropped by the sign of coss at every step's own velocity) take no part in the shared
+// rotation: they are walked in fp64, step by step -- inline in the per-step tiles, as a correction to the
+// step sums after the unrolled body in quiet tiles.  The state is anchored to FK0 * exp(i Phi) with the fp64
+// phase at every run start and at least every PS_ANCHOR steps.
 // Registers per owned frequency: the rotating state, the run's rotation and the fp64 phase at the last
 // anchor; the original spectrum FK0 and the fp64 increment live in LDS ([m][thread], each thread reads only
 // what it wrote) -- 128 KB at 8192 frequencies, one workgroup per CU.
@@ -507,11 +613,14 @@ __global__ __launch_bounds__(BLOCK) void ps_vz32_kernel(PsParams P)
     double *phd_lds = reinterpret_cast<double *>(ps_smem);                              // [M][BLOCK] fp64 increment of the run
     float2 *f0_lds = reinterpret_cast<float2 *>(ps_smem + (size_t)M * BLOCK * 8);       // [M][BLOCK] original spectrum
     float(*red)[NW][2 * TT] = reinterpret_cast<float(*)[NW][2 * TT]>(ps_smem + (size_t)M * BLOCK * 16);
+    // boundary frequencies in quiet tiles (see below): per-step corrections to the frequency sum, double-buffered over tiles
+    float *corr = reinterpret_cast<float *>(ps_smem + (size_t)M * BLOCK * 16 + 2 * NW * 2 * TT * sizeof(float));   // [2][2 * TT]
     const int k = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Cp<float> *F = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.nt;
     Cp<float> *TK = reinterpret_cast<Cp<float> *>(P.TK) + (size_t)k * P.snum;
     const double kxk = P.kx[k];
+    if (tid < 4 * TT) corr[tid] = 0.f;
 
     float gr[M], gi[M];      // FK0 * exp(i Phi_tau): the rotating state
     float pc[M], ps[M];      // exp(i increment) of the current run
@@ -551,14 +660,19 @@ __global__ __launch_bounds__(BLOCK) void ps_vz32_kernel(PsParams P)
     int nrec = 0;            // depth steps since the last anchor (uniform)
 
     const int ntile = (P.snum + TT - 1) / TT;
-    for (int tile = 0; tile < ntile; ++tile) {
+    // One 16-step tile, instantiated twice: quiet tiles and per-step tiles each get their own loop below.  With both
+    // paths in one loop body (the per-step path is ~40 KB of code between the unrolled body and the tile's tail)
+    // every part of a quiet tile ran 8-40 % slower -- same instructions, stamps in profiles/r02_ps_stamps.txt:
+    // 9140 cycles per tile against 7870 with the per-step code out of the loop (12 % of the kernel at config 5).
+    auto do_tile = [&](const int tile, auto quiet_tag) __attribute__((always_inline)) {
+        constexpr bool quiet = decltype(quiet_tag)::value;
         float acc[2 * TT];
 #pragma unroll
         for (int i = 0; i < 2 * TT; ++i) acc[i] = 0.f;
         const int tau0 = tile * TT;
-        const bool quiet = P.tsched[tile] == 0 && !wg_edge && tau0 + TT <= P.snum;      // uniform
-        if (quiet) {
-            if (nrec + TT > 64) {
+        PS_STAMP(0)
+        if constexpr (quiet) {
+            if (nrec + TT > PS_ANCHOR) {
                 anchor(nrec);
                 nrec = 0;
             }
@@ -586,9 +700,13 @@ __global__ __launch_bounds__(BLOCK) void ps_vz32_kernel(PsParams P)
                 const bool changed = P.sched[tau] != 0;      // uniform
                 if (changed) {
                     unsigned new_edge = 0;
+                    // opaque copy of the thread index: otherwise the M 64-bit addresses of P.w[...] below are hoisted
+                    // out of the tile loop and held in 2M registers for the whole kernel (spills in the tile tail)
+                    int tid_here = tid;
+                    asm volatile("" : "+v"(tid_here));
 #pragma unroll
                     for (int m = 0; m < M; ++m) {
-                        const int iw = tid + m * BLOCK;
+                        const int iw = tid_here + m * BLOCK;
                         if (nrec > 0) {   // the steps since the last anchor turned by the OLD increment
                             const double ph = Phi[m] + (double)nrec * phd_lds[m * BLOCK + tid];
                             Phi[m] = ph - 6.283185307179586 * rint(ph * 0.15915494309189535);
@@ -620,7 +738,7 @@ __global__ __launch_bounds__(BLOCK) void ps_vz32_kernel(PsParams P)
                     nrec = 0;
                 }
                 nrec += 1;
-                if (changed || nrec == 64) {
+                if (changed || nrec == PS_ANCHOR) {
                     anchor(nrec);
                     nrec = 0;
                 } else {
@@ -633,10 +751,12 @@ __global__ __launch_bounds__(BLOCK) void ps_vz32_kernel(PsParams P)
                 }
                 if (edge) {
                     // boundary frequencies: this step's increment from this step's velocity, in fp64
+                    int tid_here = tid;
+                    asm volatile("" : "+v"(tid_here));
 #pragma unroll
                     for (int m = 0; m < M; ++m)
                         if ((edge >> m) & 1u) {
-                            const double w = P.w[tid + m * BLOCK];
+                            const double w = P.w[tid_here + m * BLOCK];
                             const double a = 0.5 * vd * kxk / w;
                             const double cs = 1.0 - a * a;
                             double ph = Phi[m] + w * P.dt * (cs > 0.0 ? sqrt(cs) : 0.0);
@@ -669,12 +789,82 @@ __global__ __launch_bounds__(BLOCK) void ps_vz32_kernel(PsParams P)
             }
         }
         // ---- sum over frequencies: wave butterfly, then across waves via LDS
+#ifdef IMPDAR_PS_DIAG_NOREDUCE
+        { float z = 0;
+#pragma unroll
+          for (int i = 0; i < 2 * TT; ++i) z += acc[i];
+          if (z == 12345.678f) reinterpret_cast<float *>(TK)[tile] = z;
+          return; }
+#endif
+        PS_STAMP(1)
         wave_reduce_scatter<float, 2 * TT>(acc, lane);
         float(*buf)[2 * TT] = red[tile & 1];
         if ((lane & 1) == 0) buf[wave][lane >> 1] = acc[0];
+        PS_STAMP(2)
+        if (quiet && wg_edge && edge) {
+            // Boundary frequencies of this thread (a handful per radargram; whole families of (kx, w) with
+            // round-number geometries: dx 1 m, dt 10 ns, v 1.68e8 puts one on every 25th wavenumber).  Their
+            // shared increment is zero, so the unrolled body carried their state through the tile unchanged and
+            // added it to every step's sum; here each is walked through the tile's 16 steps in fp64 at every
+            // step's own velocity (kept or dropped by the sign of coss, mig_python.py:456-485, as in the
+            // per-step path below) and the difference to the state the body added goes to the step's
+            // correction, which the tile's tail adds to the frequency sum.  Placed here, after the reduce-scatter,
+            // because the 32 per-step sums are then out of the registers (before it: 35 spilled).  (Sending such workgroups through
+            // the per-step path for the whole run cost them 12x: 28 ms of tail at config 5.)
+            int tid_here = tid;
+            asm volatile("" : "+v"(tid_here));
+            // the steps' velocities and thresholds come through the scalar cache (uniform addresses; as vector loads
+            // each would stall the walk for a microsecond)
+            const double *svz = P.vz + tau0, *sthr = P.thr + tau0;
+            float *cr = corr + (tile & 1) * 2 * TT;
+            // one copy of the walk, the owned frequency picked by compare-and-select (an unrolled copy per m kept
+            // 16 sets of fp64 temporaries alive: 28 spilled registers)
+            for (unsigned e = edge; e; e &= e - 1) {
+                const int m = __builtin_ctz(e);
+                double ph = 0.0;
+                float hr = 0.f, hi = 0.f;
+#pragma unroll
+                for (int q = 0; q < M; ++q)
+                    if (q == m) {
+                        ph = Phi[q];
+                        hr = gr[q];
+                        hi = gi[q];
+                    }
+                const double w = P.w[tid_here + m * BLOCK];
+                float2 f = f0_lds[m * BLOCK + tid];
+                float sr = hr, si = hi;
+#pragma unroll 1
+                for (int t = 0; t < TT; ++t) {
+                    double vd, thr_d;
+                    scalar_load_2f64(svz + t, sthr + t, &vd, &thr_d);
+                    const float thr = (float)thr_d;
+                    const double a = 0.5 * vd * kxk / w;
+                    const double cs = 1.0 - a * a;
+                    ph += w * P.dt * (cs > 0.0 ? sqrt(cs) : 0.0);
+                    ph -= 6.283185307179586 * rint(ph * 0.15915494309189535);
+                    float sn, c2;
+                    rot32(ph, &sn, &c2);
+                    if ((float)cs <= thr) f = make_float2(0.f, 0.f);      // :484-485, stays zero afterwards
+                    sr = fmaf(f.x, c2, -(f.y * sn));
+                    si = fmaf(f.x, sn, f.y * c2);
+                    atomicAdd(&cr[2 * t], sr - hr);
+                    atomicAdd(&cr[2 * t + 1], si - hi);
+                }
+                f0_lds[m * BLOCK + tid] = f;
+#pragma unroll
+                for (int q = 0; q < M; ++q)
+                    if (q == m) {
+                        Phi[q] = ph;
+                        gr[q] = sr;
+                        gi[q] = si;
+                    }
+            }
+        }
         __syncthreads();
+        PS_STAMP(3)
         if (tid < 2 * TT) {
-            float sum = 0;
+            float sum = corr[(tile & 1) * 2 * TT + tid];     // boundary frequencies of a quiet tile (zero otherwise)
+            corr[(tile & 1) * 2 * TT + tid] = 0.f;           // next written two tiles on, a barrier in between
 #pragma unroll
             for (int q = 0; q < NW; ++q) sum += buf[q][tid];
             const int tau = tau0 + (tid >> 1);
@@ -683,8 +873,22 @@ __global__ __launch_bounds__(BLOCK) void ps_vz32_kernel(PsParams P)
                 *dst = sum / (float)P.snum;                                     // TK /= snum, :492
             }
         }
+        PS_STAMP(4)
         // red[] is double-buffered: the next tile writes the other buffer and the barrier of that tile
         // orders it against these reads
+    };
+    // the tiles' schedule flags come through the scalar cache, 32 tiles per word (as plain loads they are vector
+    // loads -- the compiler cannot prove the table read-only -- whose s_waitcnt vmcnt(0) also waits for the write
+    // acknowledgement of the sums wave 0 stored a few instructions earlier)
+    unsigned dirty_bits = 0;
+    auto is_quiet = [&](const int tile) __attribute__((always_inline)) {
+        if ((tile & 31) == 0) dirty_bits = (unsigned)scalar_load_i32(P.tsched + (tile >> 5));
+        return ((dirty_bits >> (tile & 31)) & 1u) == 0 && tile * TT + TT <= P.snum;      // uniform
+    };
+    int tile = 0;
+    while (tile < ntile) {
+        for (; tile < ntile && !is_quiet(tile); ++tile) do_tile(tile, std::false_type());
+        for (; tile < ntile && is_quiet(tile); ++tile) do_tile(tile, std::true_type());
     }
 }
 
@@ -710,7 +914,7 @@ void impdar_ps_forget(const impdar_ctx *ctx)
 template <typename T, int BLOCK, int M>
 static void ps_launch(const PsParams &P, hipStream_t st)
 {
-    constexpr size_t vz32_lds = (size_t)M * BLOCK * 16 + 2 * (BLOCK / 64) * 32 * sizeof(float);
+    constexpr size_t vz32_lds = (size_t)M * BLOCK * 16 + 2 * (BLOCK / 64) * 32 * sizeof(float) + 2 * 32 * sizeof(float);
     if constexpr (sizeof(T) == 4 && vz32_lds <= 160 * 1024) {
         static const bool old_kernel = getenv("IMPDAR_PS_VZ_OLD") != nullptr;     // tuning knob: the per-step kernel
         if (P.vz_mode && P.sched && !old_kernel) {
@@ -828,14 +1032,17 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         // layer up to ~4e-13 of rounding noise, and a 1e-10 velocity error moves the phase by < 3e-6 rad over
         // 8192 steps (float32 path only).  Profiles that change at (nearly) every step keep the per-step kernel.
         const int ntile = (snum + 15) / 16;
-        sched.assign((size_t)snum + ntile, 0);
+        sched.assign((size_t)snum + (ntile + 31) / 32, 0);
         double vrun = -1.0;
         int ndirty = 0;
         for (int i = 0; i < snum; ++i)
             if (std::fabs(vmig[i] - vrun) > P.vtol * std::fabs(vmig[i])) {
+                const int tile = i / 16;
+                const unsigned bit = 1u << (tile & 31);
+                unsigned &word = reinterpret_cast<unsigned &>(sched[snum + tile / 32]);
                 sched[i] = 1;
-                ndirty += sched[snum + i / 16] ? 0 : 1;
-                sched[snum + i / 16] = 1;
+                ndirty += (word & bit) ? 0 : 1;
+                word |= bit;
                 vrun = vmig[i];
             }
         if (2 * ndirty <= ntile || snum <= 64) {
