@@ -276,10 +276,13 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
     T gr[FZ ? M : 1], gi[FZ ? M : 1];   // F32 v(z): rotated state FK0 * exp(i Phi_tau)
     T pc[FZ ? M : 1], ps[FZ ? M : 1];   // F32 v(z): exp(i increment) of the current velocity
     T f0r[F32 && !VZ ? M : 1], f0i[F32 && !VZ ? M : 1];   // F32 const v: original spectrum for re-anchoring
+    constexpr bool FD = VZ && !F32;
+    T pw[FD ? M : 1];                 // fp64 v(z): w (pa holds 1/w)
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const int iw = tid + m * BLOCK;
         fr[m] = fi[m] = pa[m] = pb[m] = 0;
+        if (FD) pw[FD ? m : 0] = 0;
         if (F32 && !VZ) phd[F32 && !VZ ? m : 0] = 0.0;
         if (FZ) {
             Phi[FZ ? m : 0] = 0.0;
@@ -307,9 +310,13 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
                     }
                 }
             } else {
-                const double h = 0.5 * kxk / w;                         // coss = 1 - (v h)^2, :458
-                pa[m] = (T)(h * h);
+                // coss = 1 - ((0.5 v) kx / w)^2 in the reference's own rounding (:460): a frequency that sits on the
+                // evanescent boundary (coss = 0 up to an ulp or two; round-number geometries produce whole families)
+                // is kept or dropped by the sign of that rounding.  pa = rn(1/w) and w itself turn the per-step
+                // division into three operations with the correctly rounded quotient (below).
+                pa[m] = (T)(1.0 / w);
                 pb[m] = (T)(w * P.dt);
+                pw[FD ? m : 0] = (T)w;
                 fr[m] = f.x;
                 fi[m] = f.y;
             }
@@ -511,13 +518,16 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
 #pragma unroll
             for (int t = 0; t < PS_TT; ++t) {
                 const int tau = min(tau0 + t, P.snum - 1);
-                const T v = (T)P.vz[tau];
-                const T v2 = v * v;
+                const T num = ((T)0.5 * (T)P.vz[tau]) * (T)kxk;         // (0.5 vbg) kx, :460
                 const T thr = (T)P.thr[tau];
                 const bool live_tau = (tau0 + t) < P.snum;
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    const T coss = (T)1 - v2 * pa[m];                   // :458
+                    // a = rn(num / w): q = rn(num rn(1/w)), exact remainder by fma, one correction (Markstein);
+                    // a padded lane has pa = pw = 0 and gets a = 0
+                    const T q = num * pa[m];
+                    const T a = fma(fma(-q, pw[FD ? m : 0], num), pa[m], q);
+                    const T coss = (T)1 - a * a;                        // :460
                     const T ph = pb[m] * sqrt(coss > 0 ? coss : (T)0);  // :460 (real part of the complex sqrt)
                     T s, c;
                     sincos_t<T>(ph, &s, &c);
