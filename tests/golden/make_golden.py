@@ -314,6 +314,12 @@ def main():
     Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
     tab = [[1.69e8, 0.], [1.5e8, 0.3 * Rp], [1.9e8, 0.6 * Rp], [1.9e8, 1.2 * Rp]]
     phsh_case('P2b_phsh_vz_50x70', 50, 70, 1e-8, 2.0, tab, 8, 6)
+    # (kx, w) pairs exactly on the evanescent boundary: dx 1 m, dt 10 ns, 1.68e8 m/s and nt = 128 = 2 tnum put
+    # wavenumber 25 on frequency 42 (coss = 0 up to the rounding of (0.5 v kx / w)^2, mig_python.py:460,484)
+    geo = synth.geometry(100, 64)
+    Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+    tab = [[1.68e8, 0.], [1.68e8, 0.45 * Rp], [1.8e8, 0.7 * Rp], [1.9e8, 1.2 * Rp]]
+    phsh_case('P5_phsh_vz_boundary_100x64', 100, 64, 1e-8, 1.0, tab, 8, 6)
     velprof_cases()
     # 2-D v(x,z) Fourier finite-difference branch (mig_python.py:428-432,448-487,496-540)
     ffd_case('P4_phsh_ffd_32x16', 32, 16, 3, 4, 0)

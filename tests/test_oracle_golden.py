@@ -35,7 +35,7 @@ def test_stolt(name):
     assert rel_max(out, g['expected']) < tol
 
 
-@pytest.mark.parametrize('name', golden_names('P1') + golden_names('P2'))
+@pytest.mark.parametrize('name', golden_names('P1') + golden_names('P2') + golden_names('P5'))
 def test_phase_shift(name):
     g = golden(name)
     vel = float(g['vel']) if g['vel'].ndim == 0 else g['vel']

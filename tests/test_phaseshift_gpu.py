@@ -18,7 +18,7 @@ F64_TOL = 1e-9
 F32_L2 = 2e-4
 
 
-@pytest.mark.parametrize('name', golden_names('P1') + golden_names('P2'))
+@pytest.mark.parametrize('name', golden_names('P1') + golden_names('P2') + golden_names('P5'))
 def test_golden(hip, name):
     g = golden(name)
     dat = make_dat(g)
@@ -29,7 +29,7 @@ def test_golden(hip, name):
     assert rel_max(dat.data, g['expected']) < F64_TOL, rel_max(dat.data, g['expected'])
 
 
-@pytest.mark.parametrize('name', ['P1r_phsh_const_ricker', 'P2_phsh_vz_64x48'])
+@pytest.mark.parametrize('name', ['P1r_phsh_const_ricker', 'P2_phsh_vz_64x48', 'P5_phsh_vz_boundary_100x64'])
 def test_golden_float32(hip, name):
     g = golden(name)
     dat = make_dat(g)
