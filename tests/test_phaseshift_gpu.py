@@ -207,6 +207,27 @@ def test_float32_boundary_frequencies_in_quiet_tiles(hip, snum, tnum):
         assert measure(d.data, want) < tol, (dtype, measure(d.data, want))
 
 
+@pytest.mark.parametrize('snum,tnum', [(1100, 48), (2100, 24)])
+def test_float32_vz_four_and_eight_frequencies_per_lane(hip, snum, tnum):
+    """float32 layered v(z) at nt = 2048 and 4096: the 4- and 8-frequencies-per-lane instantiations of the
+    constant-velocity-runs kernel (the other float32 cases cover 1, 2 and 16)."""
+    from impdar_amd import synth
+    from impdar_amd.lib.RadarData import RadarData
+    from impdar_amd.lib import migrationlib
+    from oracle import mig_oracle
+    geo = synth.geometry(snum, tnum)
+    data = synth.noise_radargram(snum, tnum, seed=snum).astype(np.float32)
+    Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+    vel = np.array([[1.68e8, 0.], [1.68e8, 0.3 * Rp], [1.8e8, 0.6 * Rp], [1.9e8, 1.2 * Rp]])
+    want = mig_oracle.phase_shift(data.astype(np.float64), geo['dt'], geo['trace_int'], geo['travel_time'],
+                                  geo['dist'], vel, 20, 30)
+    d = RadarData(None)
+    d.data, d.snum, d.tnum = data.copy(), snum, tnum
+    d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
+    migrationlib.migrationPhaseShift(d, vel=vel, htaper=20, vtaper=30)
+    assert rel_l2(d.data, want) < F32_L2, rel_l2(d.data, want)
+
+
 @pytest.mark.parametrize('layered', [False, True])
 def test_float32_larger_size_vs_oracle(hip, layered):
     """float32 recurrences over ~1000 depth steps (nt = 1024, two frequencies per lane)."""
