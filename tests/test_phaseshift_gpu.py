@@ -228,6 +228,32 @@ def test_float32_vz_four_and_eight_frequencies_per_lane(hip, snum, tnum):
     assert rel_l2(d.data, want) < F32_L2, rel_l2(d.data, want)
 
 
+def test_float32_velocity_changing_in_most_tiles(hip):
+    """A table of 60 thin layers: the velocity moves in more than half of the 16-step tiles, so the host keeps the
+    per-step float32 kernel (ps_kernel<float, ..., v(z)>) instead of the constant-velocity-runs kernel."""
+    from impdar_amd import synth
+    from impdar_amd.lib.RadarData import RadarData
+    from impdar_amd.lib import migrationlib
+    from oracle import mig_oracle
+    snum, tnum = 600, 64
+    geo = synth.geometry(snum, tnum)
+    data = synth.noise_radargram(snum, tnum, seed=11).astype(np.float32)
+    Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+    nl = 60
+    vel = np.stack([np.linspace(1.68e8, 1.9e8, nl), np.linspace(0., 1.2 * Rp, nl)], axis=1)
+    vmig = mig_oracle.get_velocity_profile(geo['travel_time'], vel)
+    moved = np.abs(np.diff(vmig)) > 1e-10 * np.abs(vmig[1:])
+    tiles = np.unique((np.nonzero(moved)[0] + 1) // 16)
+    assert 2 * len(tiles) > (snum + 15) // 16           # the case is what it claims
+    want = mig_oracle.phase_shift(data.astype(np.float64), geo['dt'], geo['trace_int'], geo['travel_time'],
+                                  geo['dist'], vel, 20, 30)
+    d = RadarData(None)
+    d.data, d.snum, d.tnum = data.copy(), snum, tnum
+    d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
+    migrationlib.migrationPhaseShift(d, vel=vel, htaper=20, vtaper=30)
+    assert rel_l2(d.data, want) < F32_L2, rel_l2(d.data, want)
+
+
 @pytest.mark.parametrize('layered', [False, True])
 def test_float32_larger_size_vs_oracle(hip, layered):
     """float32 recurrences over ~1000 depth steps (nt = 1024, two frequencies per lane)."""
