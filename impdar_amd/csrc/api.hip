@@ -95,6 +95,7 @@ void impdar_comm_destroy(impdar_ctx *ctx);   // comm.hip
 
 void impdar_stolt_forget(const impdar_ctx *ctx);   // stolt.hip
 void impdar_ps_forget(const impdar_ctx *ctx);      // phaseshift.hip
+void impdar_kirch_forget(const impdar_ctx *ctx);   // kirchhoff.hip
 void impdar_preproc_forget(impdar_ctx *ctx);       // preproc.hip
 
 void *impdar_ctx_pinned(impdar_ctx *ctx, size_t bytes)
@@ -241,6 +242,7 @@ extern "C" void impdar_ctx_destroy(impdar_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     impdar_stolt_forget(ctx);
     impdar_ps_forget(ctx);
+    impdar_kirch_forget(ctx);
     impdar_preproc_forget(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->ev_produced) (void)hipEventDestroy(ctx->ev_produced);

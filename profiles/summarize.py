@@ -43,6 +43,26 @@ def main():
             shutil.copy(f, os.path.join(here, '%s_%s_kernel_stats.csv' % (tag, name)))
     if os.path.exists(os.path.join(src, 'bench_under_rocprof.json')):
         shutil.copy(os.path.join(src, 'bench_under_rocprof.json'), os.path.join(here, '%s_bench_n1.json' % tag))
+    # per-launch durations of the headline kernel in launch order: the stats average above also holds the warm-up
+    # launches and the one-shot (end_to_end) launches of a cold plan; the timed region is launches warmup+1 .. warmup+steps
+    tr = first(os.path.join(src, 'stats', 'run', '**', '*kernel_trace.csv'))
+    bj = os.path.join(src, 'bench_under_rocprof.json')
+    if tr and os.path.exists(bj):
+        b = json.loads(open(bj).read().strip().splitlines()[-1])
+        kname = b['roofline']['kernel']
+        ls = sorted((int(r['Start_Timestamp']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6)
+                    for r in csv.DictReader(open(tr)) if kname in r['Kernel_Name'])
+        d = [x[1] for x in ls]
+        w, k = int(b['warmup']), int(b['steps'])
+        timed = d[w:w + k]
+        with open(os.path.join(here, '%s_bench_kernel_launches.txt' % tag), 'w') as fo:
+            fo.write('%s: %d launches in this rocprofv3 --kernel-trace run of `python3 bench.py --no-pmc`, ms each, launch order\n'
+                     % (kname, len(d)))
+            fo.write(' '.join('%.3f' % x for x in d) + '\n')
+            fo.write('average of all launches (what --stats reports): %.4f ms\n' % (sum(d) / len(d)))
+            if len(timed) == k:
+                fo.write('average of the timed region (launches %d..%d): %.4f ms; bench.py reported kernel_ms = %.4f from HIP '
+                         'events in the same process\n' % (w + 1, w + k, sum(timed) / k, b['roofline']['kernel_ms']))
     rows, allc = [], {}
     for sub, fn in (('pmc_fetch', 'bench'), ('pmc_write', 'bench'), ('pmc_sq', 'bench'), ('pmc_sq2', 'bench'),
                     ('paths_sq', 'paths'), ('paths_sq2', 'paths')):
