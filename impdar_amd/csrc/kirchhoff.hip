@@ -3024,9 +3024,8 @@ extern "C" long long impdar_kirch_count_pairs(const impdar_kirch_plan *p, int xl
 // one-shot host-buffer entry point
 // ---------------------------------------------------------------------------
 // The one-shot entry point keeps its last plan and device buffers (as the Stolt and phase-shift entry points do):
-// a second radargram of the same geometry skips the plan, the pick table and the allocations, and -- what
-// matters more -- runs on warm buffers: the diffraction sum on freshly allocated memory takes 8.85 ms at config 3
-// against 7.43 ms on buffers that have been touched before (profiles/r02_bench_kernel_launches.txt).
+// a second radargram of the same geometry skips the plan, the pick table, the allocations and their release
+// (19.9 -> 18.1 ms host-to-host at config 3).
 // IMPDAR_KIRCH_ONESHOT_CACHE=0 releases everything at the end of each call, as before.
 namespace {
 struct KirchOneShot {
