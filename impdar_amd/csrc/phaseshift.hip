@@ -19,6 +19,7 @@
 // followed by one LDS pass across the waves, so each workgroup emits 128-byte
 // contiguous runs of TK_T[k][tau].
 #include "fft.h"
+#include <algorithm>
 #include <mutex>
 #include <type_traits>
 
@@ -150,6 +151,7 @@ struct PsParams {
     double vtol;            // float32 v(z): relative velocity change below which the phase increments are reused
     const int *sched;       // float32 v(z), ps_vz32_kernel: [snum] 1 where a new constant-velocity run starts
     const int *tsched;      // ... [ceil(ntile/32)] bit t of word t/32 set where 16-step tile t holds such a step
+    const int *rowmap;      // ... [tnum] wavenumber of workgroup b (rows holding boundary frequencies first), or null
     int snum, tnum, nt, vz_mode;
 };
 
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(BLOCK) void ps_vz32_kernel(PsParams P)
     float(*red)[NW][2 * TT] = reinterpret_cast<float(*)[NW][2 * TT]>(ps_smem + (size_t)M * BLOCK * 16);
     // boundary frequencies in quiet tiles (see below): per-step corrections to the frequency sum, double-buffered over tiles
     float *corr = reinterpret_cast<float *>(ps_smem + (size_t)M * BLOCK * 16 + 2 * NW * 2 * TT * sizeof(float));   // [2][2 * TT]
-    const int k = blockIdx.x;
+    const int k = P.rowmap ? P.rowmap[blockIdx.x] : (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Cp<float> *F = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.nt;
     Cp<float> *TK = reinterpret_cast<Cp<float> *>(P.TK) + (size_t)k * P.snum;
@@ -906,7 +908,7 @@ struct PsPlan {
     int dtype = -1, snum = 0, tnum = 0, nt = 0;
     const impdar_ctx *owner = nullptr;   // plans and buffers live on this context's device and stream
     FftPlan f_time, f_trace, b_trace;
-    DevBuf X, TK, d_kx, d_w, d_vz, d_thr, d_sched;
+    DevBuf X, TK, d_kx, d_w, d_vz, d_thr, d_sched, d_rowmap;
 };
 static std::mutex g_ps_mu;
 static PsPlan *g_ps_plan = nullptr;
@@ -973,6 +975,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         if (pl.owner != ctx) {               // another device / stream: drop everything bound to the old one
             pl.X.release(); pl.TK.release(); pl.d_kx.release(); pl.d_w.release(); pl.d_vz.release(); pl.d_thr.release();
             pl.d_sched.release();
+            pl.d_rowmap.release();
             pl.owner = ctx;
         }
         int rc;
@@ -1034,8 +1037,8 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         const char *e = getenv("IMPDAR_PS_VTOL");     // diagnostic knob
         P.vtol = e ? atof(e) : 1e-10;
     }
-    P.sched = P.tsched = nullptr;
-    std::vector<int> sched;
+    P.sched = P.tsched = P.rowmap = nullptr;
+    std::vector<int> sched, rowmap;
     if (vlen && !dbl) {
         // runs of constant velocity (ps_vz32_kernel): a step starts a new run when its velocity differs from the
         // run's first by more than vtol (relative) -- 2*gradient(z(t)) of a layered table is constant inside a
@@ -1060,6 +1063,42 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_sched.p, sched.data(), sched.size() * sizeof(int), hipMemcpyHostToDevice, st));
             P.sched = pl.d_sched.as<int>();
             P.tsched = P.sched + snum;
+            // Launch order.  A wavenumber that holds a frequency on the evanescent boundary of a run walks it in
+            // fp64 in every tile of that run (~2x the tile time); spread over the launch, the last such rows finish
+            // alone after everything else (2 ms at config 5).  They go first, longest first.  The test here only
+            // orders the launch -- generous tolerance, the kernel decides for itself: |0.5 v kx| within 1e-7 of
+            // some |w|.
+            std::vector<std::pair<double, int>> runs;      // (velocity, steps) of every run
+            for (int i = 0; i < snum; ++i) {
+                if (sched[i]) runs.emplace_back(vmig[i], 0);
+                runs.back().second += 1;
+            }
+            if (runs.size() <= 64 && tnum >= 512) {
+                std::vector<double> aw(nt);
+                for (int j = 0; j < nt; ++j) aw[j] = std::fabs(ws[j] == 0.0 ? 1e-10 / dt : ws[j]);
+                std::sort(aw.begin(), aw.end());
+                std::vector<std::pair<int, int>> score(tnum);      // (-steps spent walking, row)
+                int flagged = 0;
+                for (int k = 0; k < tnum; ++k) {
+                    int steps = 0;
+                    for (const auto &r : runs) {
+                        const double target = 0.5 * r.first * std::fabs(kx[k]);
+                        const auto it = std::lower_bound(aw.begin(), aw.end(), target);
+                        const double hi = it != aw.end() ? *it : aw.back(), lo = it != aw.begin() ? *(it - 1) : aw.front();
+                        if (std::fabs(hi - target) <= 1e-7 * target || std::fabs(lo - target) <= 1e-7 * target) steps += r.second;
+                    }
+                    score[k] = std::make_pair(-steps, k);
+                    flagged += steps > 0;
+                }
+                if (flagged > 0 && flagged < tnum) {
+                    std::stable_sort(score.begin(), score.end());
+                    rowmap.resize(tnum);
+                    for (int b = 0; b < tnum; ++b) rowmap[b] = score[b].second;
+                    IMPDAR_HIP_CHECK(pl.d_rowmap.ensure((size_t)tnum * sizeof(int)));
+                    IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_rowmap.p, rowmap.data(), (size_t)tnum * sizeof(int), hipMemcpyHostToDevice, st));
+                    P.rowmap = pl.d_rowmap.as<int>();
+                }
+            }
         }
     }
     if ((rc = ps_dispatch<T>(P, st))) return rc;
