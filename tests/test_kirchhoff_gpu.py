@@ -633,8 +633,9 @@ def test_several_tiles_per_workgroup_on_one_ring(hip, xb, nh, lk, monkeypatch):
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize('dtype,mode,tol', [(np.float32, 'fast', 1e-5), (np.float64, 'exact', 1e-13)])
 @pytest.mark.parametrize('world', [2, 4, 8])
-def test_halo_exchange_ranges_cover_everything_a_rank_reads(hip, world, monkeypatch):
+def test_halo_exchange_ranges_cover_everything_a_rank_reads(hip, world, dtype, mode, tol, monkeypatch):
     """Halo mode on hardware, one rank at a time: the rank's image holds its own input shard and the row ranges
     parallel.plan_exchange has it receive; every other trace is poison (1e25-scale noise, which survives the time
     gradient of prep).  Its output block must still equal the block of the whole-image run -- the diffraction sum,
@@ -646,10 +647,10 @@ def test_halo_exchange_ranges_cover_everything_a_rank_reads(hip, world, monkeypa
     ctx = hip.context()
     snum, tnum, vel = 600, 4096, 1.69e8
     geo = synth.geometry(snum, tnum, dx=4.0)
-    x = synth.noise_radargram(snum, tnum, seed=5).astype(np.float32)
-    ref_plan = KirchhoffPlan(ctx, np.float32, snum, tnum, geo['dist'], geo['travel_time'], vel, mode='fast', nranks=1)
+    x = synth.noise_radargram(snum, tnum, seed=5).astype(dtype)
+    ref_plan = KirchhoffPlan(ctx, dtype, snum, tnum, geo['dist'], geo['travel_time'], vel, mode=mode, nranks=1)
     d_in = _hip.DeviceArray.from_host(ctx, x)
-    d_out = _hip.DeviceArray(ctx, (snum, tnum), np.float32)
+    d_out = _hip.DeviceArray(ctx, (snum, tnum), dtype)
     ref_plan.prep(d_in, tnum, 0, tnum)
     ref_plan.migrate(d_out, 0, tnum)
     ref_plan.sync()
@@ -658,10 +659,10 @@ def test_halo_exchange_ranges_cover_everything_a_rank_reads(hip, world, monkeypa
     d_in.free()
     d_out.free()
     scale = np.max(np.abs(full))
-    poison = (1e25 * np.random.default_rng(1).standard_normal((snum, tnum))).astype(np.float32)
+    poison = (1e25 * np.random.default_rng(1).standard_normal((snum, tnum))).astype(dtype)
     for rank in range(world):
-        sk = parallel.ShardedKirchhoff(ctx, snum, tnum, geo['dist'], geo['travel_time'], vel, rank, world, np.float32,
-                                       mode='fast', engine=parallel.HipEngine(ctx))
+        sk = parallel.ShardedKirchhoff(ctx, snum, tnum, geo['dist'], geo['travel_time'], vel, rank, world, dtype,
+                                       mode=mode, engine=parallel.HipEngine(ctx))
         assert sk.xplan['mode'] == 'halo'
         have = np.zeros(sk.tnum_pad, dtype=bool)
         have[sk.jlo:sk.jhi] = True
@@ -670,7 +671,7 @@ def test_halo_exchange_ranges_cover_everything_a_rank_reads(hip, world, monkeypa
         assert have.sum() < 0.6 * tnum                      # the case is what it claims: most rows are poison
         masked = np.where(have[None, :tnum], x, poison)
         d_in = _hip.DeviceArray.from_host(ctx, np.ascontiguousarray(masked))
-        d_out = _hip.DeviceArray(ctx, (snum, max(sk.xhi - sk.xlo, 1)), np.float32)
+        d_out = _hip.DeviceArray(ctx, (snum, max(sk.xhi - sk.xlo, 1)), dtype)
         sk.engine.prep(d_in, tnum, 0, tnum)
         sk.engine.migrate(d_out, sk.xlo, sk.xhi)
         sk.engine.plan.sync()
@@ -679,11 +680,11 @@ def test_halo_exchange_ranges_cover_everything_a_rank_reads(hip, world, monkeypa
         d_in.free()
         d_out.free()
         assert np.isfinite(got).all(), rank
-        assert np.max(np.abs(got.astype(np.float64) - full[:, sk.xlo:sk.xhi])) <= 1e-5 * scale, rank
+        assert np.max(np.abs(got.astype(np.float64) - full[:, sk.xlo:sk.xhi])) <= tol * scale, rank
     # the test can fail: with 64 traces less of halo the poison reaches the block
     rank = world // 2
-    sk = parallel.ShardedKirchhoff(ctx, snum, tnum, geo['dist'], geo['travel_time'], vel, rank, world, np.float32,
-                                   mode='fast', engine=parallel.HipEngine(ctx))
+    sk = parallel.ShardedKirchhoff(ctx, snum, tnum, geo['dist'], geo['travel_time'], vel, rank, world, dtype,
+                                   mode=mode, engine=parallel.HipEngine(ctx))
     tt_sec, dist_m = geo['travel_time'] / 1e6, geo['dist'] * 1e3
     short = parallel.plan_exchange(sk.blocks, sk.tnum_pad, world,
                                    parallel.halo_traces(tt_sec, (dist_m[-1] - dist_m[0]) / (tnum - 1), vel) - 64)
@@ -692,7 +693,7 @@ def test_halo_exchange_ranges_cover_everything_a_rank_reads(hip, world, monkeypa
     for _peer, lo, hi in short['recv'][rank]:
         have[lo:hi] = True
     d_in = _hip.DeviceArray.from_host(ctx, np.ascontiguousarray(np.where(have[None, :tnum], x, poison)))
-    d_out = _hip.DeviceArray(ctx, (snum, sk.xhi - sk.xlo), np.float32)
+    d_out = _hip.DeviceArray(ctx, (snum, sk.xhi - sk.xlo), dtype)
     sk.engine.prep(d_in, tnum, 0, tnum)
     sk.engine.migrate(d_out, sk.xlo, sk.xhi)
     sk.engine.plan.sync()
