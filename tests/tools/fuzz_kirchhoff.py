@@ -38,6 +38,13 @@ def main():
         near = bool(rng.integers(0, 2))
         kind = str(rng.choice(['f32', 'f32', 'f64', 'i16']))
         geo = synth.geometry(snum, tnum, dt=dt, dx=dx, t0_us=t0)
+        irregular = tnum > 2 and rng.integers(0, 5) == 0
+        if irregular:      # uneven trace spacing (and, half of the time, an uneven time axis): the per-pair kernels
+            geo['dist'] = np.cumsum(np.concatenate([[0.], rng.uniform(0.3, 1.7, tnum - 1) * dx])) / 1e3
+            if rng.integers(0, 2) and snum > 2:
+                tt = geo['travel_time'].copy()
+                tt[1:] += np.cumsum(rng.uniform(-0.2, 0.2, snum - 1)) * dt * 1e6 * 0.1
+                geo['travel_time'] = np.sort(tt)
         x = rng.standard_normal((snum, tnum))
         data = {'f32': x.astype(np.float32), 'f64': x, 'i16': (x * 1000).astype(np.int16)}[kind]
         want = c_oracle.kirchhoff(data, geo['travel_time'], geo['dist'], vel, near)
@@ -56,8 +63,9 @@ def main():
         ok = bool(np.isfinite(d.data).all() == np.isfinite(want).all() and err < tol)
         bad += 0 if ok else 1
         worst[key] = max(worst[key], err)
-        print('%3d %s snum %4d tnum %3d dt %.3g dx %.3g vel %.4g t0 %.3g near %d err %.3g %s'
-              % (case, kind, snum, tnum, dt, dx, vel, t0, near, err, 'ok' if ok else 'MISS'), flush=True)
+        print('%3d %s snum %4d tnum %3d dt %.3g dx %.3g vel %.4g t0 %.3g near %d %s err %.3g %s'
+              % (case, kind, snum, tnum, dt, dx, vel, t0, near, 'irregular' if irregular else 'uniform', err,
+                 'ok' if ok else 'MISS'), flush=True)
     print('cases %d, misses %d, worst float32 rel-L2 %.3g (bar 1e-4), worst float64/int16 rel-max %.3g (bar 1e-12), %.0f s'
           % (ncases, bad, worst['f32'], worst['f64'], time.time() - t_start))
     return 1 if bad else 0
