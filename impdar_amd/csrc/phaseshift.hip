@@ -1314,6 +1314,204 @@ __global__ __launch_bounds__(256) void ffd_mid(FfdMid P)
     }
 }
 
+// ---------------------------------------------------------------------------
+// The whole (tau, omega) chain in ONE workgroup (power-of-two trace counts up to 1024).  The chain is serial by the
+// reference's construction (one FFX_last for the whole nest), each step touches one row of tnum complex numbers,
+// and issued as four launches per step it costs ~26 us a step, all of it launch / enqueue overhead.  Here the
+// row lives in LDS for the whole step: retardation phase on load, inverse FFT over the traces (radix-2 Stockham,
+// float64, twiddles from a table built on the host), thin-lens phase and finite-difference update against the
+// FFX_last kept in LDS, forward FFT, evanescent zeroing, row written back; the sums into TK[itau] stay in
+// registers over the frequencies of a depth step.  Same element formulas, in the same operation order, as
+// ffd_post_pre / ffd_mid above; the transforms are its own instead of rocFFT's (rounding-level differences).
+// LDS: four rows (two transform buffers, FFX_last, the thin-lensed field) + the twiddles = 4.5 tnum x 16 B.
+// ---------------------------------------------------------------------------
+struct FfdChain {
+    Cd *FK;              // (nt, tnum) spectrum, updated in place
+    Cd *TK;              // (snum, tnum)
+    const double *kx;    // (tnum)
+    const double *vmig;  // (snum, tnum)
+    const double *vbg;   // (snum)
+    const double *thr;   // (snum)
+    const double *w;     // (nt), zero frequency already replaced
+    const Cd *tw;        // (tnum / 2) exp(-2 pi i k / tnum)
+    int tnum, snum, nt;
+    double dt, dx;
+};
+
+template <bool INV>
+__device__ __forceinline__ Cd *ffd_fft_lds(Cd *in, Cd *out, const Cd *W, int n, int tid, int nthr)
+{
+    const int half = n >> 1;
+    for (int Ns = 1; Ns < n; Ns <<= 1) {
+        const int wstep = half / Ns;
+        for (int j = tid; j < half; j += nthr) {
+            const int k = j & (Ns - 1);
+            Cd t = W[k * wstep];
+            if (INV) t.y = -t.y;
+            const Cd a = in[j], b = cmul(in[j + half], t);
+            const int j0 = ((j - k) << 1) + k;
+            out[j0] = Cd{a.x + b.x, a.y + b.y};
+            out[j0 + Ns] = Cd{a.x - b.x, a.y - b.y};
+        }
+        __syncthreads();
+        Cd *sw = in;
+        in = out;
+        out = sw;
+    }
+    return in;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void ffd_chain_kernel(FfdChain P)
+{
+    extern __shared__ Cd sm[];
+    const int n = P.tnum, tid = threadIdx.x;
+    Cd *A = sm, *B = sm + n, *L = sm + 2 * n, *F = sm + 3 * n, *W = sm + 4 * n;
+    Cd *part = W + (n >> 1);                 // 2 x (BLOCK / 64) partial sums
+    constexpr int NW = BLOCK / 64;
+    constexpr int EPT = 2;                   // BLOCK >= tnum / 2
+    const double inv_n = 1.0 / n;
+    for (int x = tid; x < n; x += BLOCK) L[x] = Cd{0.0, 0.0};
+    for (int k = tid; k < (n >> 1); k += BLOCK) W[k] = P.tw[k];
+    __syncthreads();
+    for (int itau = 0; itau < P.snum; ++itau) {
+        const double vbg = P.vbg[itau], thr = P.thr[itau];
+        const double *vm = P.vmig + (size_t)itau * n;
+        // what a depth step's frequencies share, per owned trace / wavenumber (the same expressions, evaluated once)
+        Cd tk[EPT];
+        double kxe[EPT], ufg[EPT], vs2[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int x = tid + e * BLOCK;
+            tk[e] = Cd{0.0, 0.0};
+            kxe[e] = x < n ? P.kx[x] : 0.0;
+            const double v = x < n ? vm[x] : vbg;
+            ufg[e] = 1. / v - 1. / vbg;                                            // :453
+            const double vs = v - vbg;                                             // :452
+            vs2[e] = vs * vs;
+        }
+        for (int iw = 0; iw < P.nt; ++iw) {
+            const double w = P.w[iw];
+            Cd *row = P.FK + (size_t)iw * n;
+            // retardation phase (:456-464); coss is needed again after the forward transform (:484)
+            double coss[EPT];
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int k = tid + e * BLOCK;
+                coss[e] = ffd_coss(vbg, kxe[e], w);
+                if (k < n) {
+                    const double root = coss[e] >= 0.0 ? sqrt(coss[e]) : 0.0;
+                    const double phase = -w * P.dt * root;
+                    double sn, cs;
+                    sincos(phase, &sn, &cs);
+                    A[k] = cmul(row[k], Cd{cs, -sn});
+                }
+            }
+            __syncthreads();
+            Cd *R = ffd_fft_lds<true>(A, B, W, n, tid, BLOCK);          // :467, unscaled
+            Cd *S = R == A ? B : A;
+            // thin-lens term (:470-473) and the sums the last stencil row needs
+            Cd sf = {0.0, 0.0}, sl = {0.0, 0.0};
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int x = tid + e * BLOCK;
+                if (x < n) {
+                    const double phase2 = 2. * ufg[e] * w * P.dt + 1. * vbg * w * P.dt;   // :471
+                    double sn, cs;
+                    sincos(phase2, &sn, &cs);
+                    const Cd r = {R[x].x * inv_n, R[x].y * inv_n};
+                    const Cd f = cmul(r, Cd{cs, sn});
+                    F[x] = f;
+                    sf.x += f.x;
+                    sf.y += f.y;
+                    if (itau > 0) {
+                        sl.x += L[x].x;
+                        sl.y += L[x].y;
+                    }
+                }
+            }
+#pragma unroll
+            for (int msk = 32; msk > 0; msk >>= 1) {
+                sf.x += __shfl_xor(sf.x, msk, 64);
+                sf.y += __shfl_xor(sf.y, msk, 64);
+                sl.x += __shfl_xor(sl.x, msk, 64);
+                sl.y += __shfl_xor(sl.y, msk, 64);
+            }
+            if ((tid & 63) == 0) {
+                part[tid >> 6] = sf;
+                part[NW + (tid >> 6)] = sl;
+            }
+            __syncthreads();
+            Cd sumf = {0.0, 0.0}, suml = {0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+                sumf.x += part[q].x;
+                sumf.y += part[q].y;
+                suml.x += part[NW + q].x;
+                suml.y += part[NW + q].y;
+            }
+            // finite-difference update (:496-525) -> S
+            const double den = 4. * w * (P.dx * P.dx);                   // imaginary part of 1j*4.*w*dx**2
+            const double scl = 1.0 / den;                                // real / (0 + i den), NumPy's way (:517)
+            const double den2 = 4. * (w * w) * (P.dx * P.dx);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int x = tid + e * BLOCK;
+                if (x < n) {
+                    Cd out = F[x];
+                    if (itau > 0) {
+                        Cd a, b;
+                        if (x == 0) {
+                            a = F[0];
+                            b = L[0];
+                        } else if (x == n - 1) {
+                            a = sumf;
+                            b = suml;
+                        } else {
+                            a = Cd{F[x - 1].x + F[x + 1].x, F[x - 1].y + F[x + 1].y};
+                            b = Cd{L[x - 1].x + L[x + 1].x, L[x - 1].y + L[x + 1].y};
+                        }
+                        const double num = P.dt * 0.5 * vs2[e];                    // dt*alpha*vs**2, alpha = 0.5
+                        const Cd c1 = {0.0, (0.0 - num) * scl};
+                        const double c2 = (-0.25 * vs2[e]) / den2;                 // :518
+                        const Cd t1 = cmul(c1, a);
+                        const Cd d = {a.x - b.x, a.y - b.y};
+                        const Cd l = L[x];
+                        out = Cd{(l.x + t1.x) + c2 * d.x, (l.y + t1.y) + c2 * d.y};   // :521
+                    }
+                    S[x] = out;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int x = tid + e * BLOCK;
+                if (x < n) L[x] = S[x];                                            // FFX_last = FFX, :478
+            }
+            Cd *Q = ffd_fft_lds<false>(S, R, W, n, tid, BLOCK);                   // :481
+            // zero outside the domain, accumulate, keep the row (:484-487)
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int k = tid + e * BLOCK;
+                if (k < n) {
+                    Cd v = Q[k];
+                    if (coss[e] <= thr) v = Cd{0.0, 0.0};
+                    row[k] = v;
+                    tk[e].x += v.x;
+                    tk[e].y += v.y;
+                }
+            }
+            // the next load writes A[k] for the same k this thread just read from Q: no barrier needed before it,
+            // and its own barrier comes before anyone reads a neighbour's element
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int k = tid + e * BLOCK;
+            if (k < n) P.TK[(size_t)itau * n + k] = tk[e];
+        }
+    }
+}
+
 // TK (snum,tnum) complex -> out (snum,tnum) real: ifft over the traces done by rocFFT, /snum here (:491)
 __global__ __launch_bounds__(256) void ffd_real_out(const Cd *__restrict__ Z, double *__restrict__ out, size_t n)
 {
@@ -1385,6 +1583,58 @@ extern "C" int impdar_phaseshift_ffd(impdar_ctx *ctx, const double *data, int sn
     hipLaunchKernelGGL(ffd_load, dim3(gall), dim3(256), 0, st, din.as<double>(), X.as<Cd>(), snum, tnum, nt, htaper, vtaper);
     if ((rc = f_x.exec(X.p, nullptr))) return rc;
     if ((rc = f_t.exec(X.p, nullptr))) return rc;
+
+    // power-of-two trace counts up to 1024: the whole chain in one persistent workgroup (IMPDAR_FFD_CHAIN=0 keeps the
+    // launch-per-step form below, which also serves every other trace count).  Measured us per step, one workgroup /
+    // launch per step: 64 traces 4.4 / 14.0, 512 traces 9.5 / 17.5, 1024 traces 18.6 / 20.1, 2048 traces 37 / 28 --
+    // one CU does all of a step's float64 sincos and butterflies, so the wide rows stay with the spread-out form.
+    const bool pow2 = tnum >= 2 && tnum <= 1024 && (tnum & (tnum - 1)) == 0;
+    const char *ce = getenv("IMPDAR_FFD_CHAIN");
+    if (pow2 && !(ce && ce[0] == '0')) {
+        DevBuf d_w, d_tw;
+        IMPDAR_HIP_CHECK(d_w.ensure((size_t)nt * 8));
+        IMPDAR_HIP_CHECK(d_tw.ensure((size_t)(tnum / 2) * 16));
+        std::vector<Cd> twid(tnum / 2);
+        for (int k = 0; k < tnum / 2; ++k) {
+            const long double ang = -2.0L * 3.141592653589793238462643383279502884L * (long double)k / (long double)tnum;
+            twid[k] = Cd{(double)cosl(ang), (double)sinl(ang)};
+        }
+        IMPDAR_HIP_CHECK(hipMemcpyAsync(d_w.p, w.data(), (size_t)nt * 8, hipMemcpyHostToDevice, st));
+        IMPDAR_HIP_CHECK(hipMemcpyAsync(d_tw.p, twid.data(), twid.size() * 16, hipMemcpyHostToDevice, st));
+        FfdChain C;
+        C.FK = X.as<Cd>();
+        C.TK = TK.as<Cd>();
+        C.kx = d_kx.as<double>();
+        C.vmig = d_vm.as<double>();
+        C.vbg = d_vbg.as<double>();
+        C.thr = d_thr.as<double>();
+        C.w = d_w.as<double>();
+        C.tw = d_tw.as<Cd>();
+        C.tnum = tnum, C.snum = snum, C.nt = nt;
+        C.dt = dt, C.dx = dx_mean;
+        const int block = std::max(64, tnum / 2);
+        const size_t lds = ((size_t)tnum * 4 + tnum / 2 + 2 * (block / 64)) * 16;
+        auto launch = [&](auto kern) {
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(1), dim3(block), lds, st, C);
+        };
+        switch (block) {
+        case 64: launch(ffd_chain_kernel<64>); break;
+        case 128: launch(ffd_chain_kernel<128>); break;
+        case 256: launch(ffd_chain_kernel<256>); break;
+        case 512: launch(ffd_chain_kernel<512>); break;
+        default: launch(ffd_chain_kernel<1024>); break;
+        }
+        IMPDAR_HIP_CHECK(hipGetLastError());
+        const unsigned gtk2 = (unsigned)((nreal + 255) / 256);
+        hipLaunchKernelGGL(ffd_scale, dim3(gtk2), dim3(256), 0, st, TK.as<Cd>(), nreal, (double)snum);     // :491
+        if ((rc = tk_inv.exec(TK.p, nullptr))) return rc;                                                   // :282
+        hipLaunchKernelGGL(ffd_real_out, dim3(gtk2), dim3(256), 0, st, TK.as<Cd>(), dout.as<double>(), nreal);
+        IMPDAR_HIP_CHECK(hipGetLastError());
+        IMPDAR_HIP_CHECK(hipMemcpyAsync(out, dout.p, nreal * 8, hipMemcpyDeviceToHost, st));
+        IMPDAR_HIP_CHECK(hipStreamSynchronize(st));      // the staging vectors above live until here
+        return IMPDAR_OK;
+    }
 
     FfdStep S;
     S.FK = X.as<Cd>();

@@ -77,6 +77,31 @@ def test_ffd_vs_oracle_and_float32(hip, tmp_path):
     assert rel_l2(dat.data, want) < F32_L2, rel_l2(dat.data, want)
 
 
+@pytest.mark.parametrize('tnum', [64, 256])
+def test_ffd_chain_in_one_workgroup(hip, tnum, monkeypatch):
+    """Power-of-two trace counts run the whole (tau, omega) chain in one persistent workgroup (its own LDS
+    transforms); every other count, and IMPDAR_FFD_CHAIN=0, the launch-per-step form with rocFFT.  Both against the
+    oracle, and against each other."""
+    from oracle import mig_oracle
+    from impdar_amd.lib import migrationlib
+    g = golden('P4_phsh_ffd_32x16')
+    rng = np.random.default_rng(tnum)
+    snum = 32
+    data = rng.standard_normal((snum, tnum))
+    gg = dict(data=data, travel_time=g['travel_time'], dist=np.arange(tnum) * 5.0 / 1e3,
+              trace_int=np.ones(tnum) * 5.0, dt=g['dt'])
+    want = mig_oracle.phase_shift(data, float(g['dt']), gg['trace_int'], gg['travel_time'], gg['dist'], g['vel'], 4, 3)
+    assert np.isfinite(want).all()
+    outs = {}
+    for chain in ('1', '0'):
+        monkeypatch.setenv('IMPDAR_FFD_CHAIN', chain)
+        dat = make_dat(gg)
+        migrationlib.migrationPhaseShift(dat, vel=g['vel'], htaper=4, vtaper=3)
+        outs[chain] = dat.data
+        assert rel_max(dat.data, want) < F64_TOL, (chain, rel_max(dat.data, want))
+    assert rel_max(outs['1'], outs['0']) < F64_TOL
+
+
 @pytest.mark.parametrize('kind', ['vz', 'const'])
 def test_config5_size_spot_wavenumbers_and_linearity(hip, kind):
     """BASELINE config 5 (8192 x 8192 float32, 1-D v(z) table; also constant v) at full size.  Wavenumbers are independent
