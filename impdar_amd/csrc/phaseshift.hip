@@ -1315,7 +1315,7 @@ __global__ __launch_bounds__(256) void ffd_mid(FfdMid P)
 }
 
 // ---------------------------------------------------------------------------
-// The whole (tau, omega) chain in ONE workgroup (power-of-two trace counts up to 1024).  The chain is serial by the
+// The whole (tau, omega) chain in ONE workgroup (power-of-two trace counts up to 512).  The chain is serial by the
 // reference's construction (one FFX_last for the whole nest), each step touches one row of tnum complex numbers,
 // and issued as four launches per step it costs ~26 us a step, all of it launch / enqueue overhead.  Here the
 // row lives in LDS for the whole step: retardation phase on load, inverse FFT over the traces (radix-2 Stockham,
@@ -1584,11 +1584,13 @@ extern "C" int impdar_phaseshift_ffd(impdar_ctx *ctx, const double *data, int sn
     if ((rc = f_x.exec(X.p, nullptr))) return rc;
     if ((rc = f_t.exec(X.p, nullptr))) return rc;
 
-    // power-of-two trace counts up to 1024: the whole chain in one persistent workgroup (IMPDAR_FFD_CHAIN=0 keeps the
+    // power-of-two trace counts up to 512: the whole chain in one persistent workgroup (IMPDAR_FFD_CHAIN=0 keeps the
     // launch-per-step form below, which also serves every other trace count).  Measured us per step, one workgroup /
-    // launch per step: 64 traces 4.4 / 14.0, 512 traces 9.5 / 17.5, 1024 traces 18.6 / 20.1, 2048 traces 37 / 28 --
-    // one CU does all of a step's float64 sincos and butterflies, so the wide rows stay with the spread-out form.
-    const bool pow2 = tnum >= 2 && tnum <= 1024 && (tnum & (tnum - 1)) == 0;
+    // launch per step (the latter varies by box): 64 traces 4.4 / 14-17, 128 traces 5.7 / 14, 512 traces 9.4 / 12.4-17.5,
+    // 1024 traces 19 / 18.5-20, 2048 traces 37 / 28 -- one CU does all of a step's float64 sincos and butterflies and
+    // the barriers of a wider workgroup cost more (one trace per thread: 28 us at 1024; four per thread: 11.8 us at 512),
+    // so the wide rows stay with the spread-out form.
+    const bool pow2 = tnum >= 2 && tnum <= 512 && (tnum & (tnum - 1)) == 0;
     const char *ce = getenv("IMPDAR_FFD_CHAIN");
     if (pow2 && !(ce && ce[0] == '0')) {
         DevBuf d_w, d_tw;
