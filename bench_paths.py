@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Secondary measurements (not the driver's bench contract): Stolt f-k at
 BASELINE config 2 (4096x4096 float32), phase-shift at config 5 (8192x8192,
-constant v and 1-D v(z)) and the band-pass / re-spacing steps in front of a
+constant v and 1-D v(z)), the v(x,z) finite-difference branch (256x512) and the band-pass / re-spacing steps in front of a
 migration at config-3 size (4096x10000 float32, resident in HBM, plus the
 three-step chain with and without residency), each through the product path on
 one MI355X.
@@ -105,6 +105,30 @@ def main():
                           "host_seconds": el, "traces_per_s": n / el, "finite": bool(np.isfinite(d.data).all()),
                           "rotate_accumulate_steps": float(n) ** 3, "reference_extrapolated_hours": 7.6,
                           "cpu_baseline": cb}), flush=True)
+    if 'ffd' not in args.skip:
+        # v(x,z) table: the Fourier finite-difference branch, a serial chain of snum * nt steps (one workgroup, the
+        # row in LDS, for power-of-two trace counts up to 512)
+        sn, tn = 256, 512
+        geo = synth.geometry(sn, tn, dx=5.0)
+        x = rng.standard_normal((sn, tn))
+        Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+        xs_ = np.linspace(0., geo['dist'][-1] * 1e3, 5)
+        tab3 = np.array([(v + (2e5 * xx / xs_[-1] if z else 0.), z * Rp, xx) for xx in xs_
+                         for v, z in ((1.69e8, 0.), (1.72e8, 0.6), (1.8e8, 1.3))])
+        el, d = timed(lambda d: migrationlib.migrationPhaseShift(d, vel=tab3, htaper=10, vtaper=10), lambda: dat_of(x.copy(), geo))
+        nt_ = 1 << int(np.ceil(np.log2(sn)))
+        ms_, mt_ = 32, 64
+        gs = synth.geometry(ms_, mt_, dx=5.0)
+        Rs = 1.9e8 * gs['travel_time'][-1] * 1e-6 / 2.
+        xq = np.linspace(0., gs['dist'][-1] * 1e3, 5)
+        tabs3 = np.array([(v + (2e5 * xx / xq[-1] if z else 0.), z * Rs, xx) for xx in xq
+                          for v, z in ((1.69e8, 0.), (1.72e8, 0.6), (1.8e8, 1.3))])
+        cb = cpu(lambda o: o.phase_shift(x[:ms_, :mt_], gs['dt'], gs['trace_int'], gs['travel_time'], gs['dist'], tabs3, 10, 10),
+                 "NumPy oracle on a %dx%d radargram: %d chain steps of %d traces (the full size has %d steps of %d)"
+                 % (ms_, mt_, ms_ * ms_, mt_, sn * nt_, tn))
+        print(json.dumps({"path": "phase-shift v(x,z) Fourier finite-difference", "config": "%dx%d float64" % (sn, tn),
+                          "host_seconds": el, "chain_steps": sn * nt_, "us_per_step": el / (sn * nt_) * 1e6,
+                          "finite": bool(np.isfinite(d.data).all()), "cpu_baseline": cb}), flush=True)
     if 'chain' not in args.skip:
         from impdar_amd import preproc
         from impdar_amd.lib.NoInitRadarData import NoInitRadarDataFiltering
