@@ -1318,7 +1318,7 @@ __global__ __launch_bounds__(256) void ffd_mid(FfdMid P)
 // The whole (tau, omega) chain in ONE workgroup (power-of-two trace counts up to 512).  The chain is serial by the
 // reference's construction (one FFX_last for the whole nest), each step touches one row of tnum complex numbers,
 // and issued as four launches per step it costs ~26 us a step, all of it launch / enqueue overhead.  Here the
-// row lives in LDS for the whole step: retardation phase on load, inverse FFT over the traces (radix-2 Stockham,
+// row lives in LDS for the whole step: retardation phase on load, inverse FFT over the traces (radix-4 Stockham,
 // float64, twiddles from a table built on the host), thin-lens phase and finite-difference update against the
 // FFX_last kept in LDS, forward FFT, evanescent zeroing, row written back; the sums into TK[itau] stay in
 // registers over the frequencies of a depth step.  Same element formulas, in the same operation order, as
@@ -1338,17 +1338,48 @@ struct FfdChain {
     double dt, dx;
 };
 
+// Stockham autosort transform of n (a power of two) points between two LDS buffers: radix-4 passes, one radix-2
+// pass at the end when log2 n is odd (every pass is one barrier; with a handful of waves the barriers are most of
+// a pass).  W[m] = exp(-2 pi i m / n), m < n / 2.  Returns the buffer that holds the result.
 template <bool INV>
 __device__ __forceinline__ Cd *ffd_fft_lds(Cd *in, Cd *out, const Cd *W, int n, int tid, int nthr)
 {
-    const int half = n >> 1;
-    for (int Ns = 1; Ns < n; Ns <<= 1) {
-        const int wstep = half / Ns;
+    const int half = n >> 1, quarter = n >> 2;
+    auto twiddle = [&](int m) {             // exp(-+ 2 pi i m / n) for m < n
+        Cd t = W[m < half ? m : m - half];
+        if (m >= half) t = Cd{-t.x, -t.y};
+        if (INV) t.y = -t.y;
+        return t;
+    };
+    int Ns = 1;
+    for (; Ns * 4 <= n; Ns <<= 2) {
+        const int wstep = quarter / Ns;
+        for (int j = tid; j < quarter; j += nthr) {
+            const int k = j & (Ns - 1);
+            const int m1 = k * wstep;
+            const Cd v0 = in[j];
+            const Cd v1 = cmul(in[j + quarter], twiddle(m1));
+            const Cd v2 = cmul(in[j + 2 * quarter], twiddle(2 * m1));
+            const Cd v3 = cmul(in[j + 3 * quarter], twiddle(3 * m1));
+            const Cd t0 = {v0.x + v2.x, v0.y + v2.y}, t1 = {v0.x - v2.x, v0.y - v2.y};
+            const Cd t2 = {v1.x + v3.x, v1.y + v3.y};
+            const Cd d = {v1.x - v3.x, v1.y - v3.y};
+            const Cd t3 = INV ? Cd{-d.y, d.x} : Cd{d.y, -d.x};      // (v1 - v3) times +i / -i
+            const int j0 = ((j - k) << 2) + k;
+            out[j0] = Cd{t0.x + t2.x, t0.y + t2.y};
+            out[j0 + Ns] = Cd{t1.x + t3.x, t1.y + t3.y};
+            out[j0 + 2 * Ns] = Cd{t0.x - t2.x, t0.y - t2.y};
+            out[j0 + 3 * Ns] = Cd{t1.x - t3.x, t1.y - t3.y};
+        }
+        __syncthreads();
+        Cd *sw = in;
+        in = out;
+        out = sw;
+    }
+    if (Ns < n) {                           // Ns == n / 2
         for (int j = tid; j < half; j += nthr) {
             const int k = j & (Ns - 1);
-            Cd t = W[k * wstep];
-            if (INV) t.y = -t.y;
-            const Cd a = in[j], b = cmul(in[j + half], t);
+            const Cd a = in[j], b = cmul(in[j + half], twiddle(k));      // angle -2 pi k / (2 Ns) = -2 pi k / n
             const int j0 = ((j - k) << 1) + k;
             out[j0] = Cd{a.x + b.x, a.y + b.y};
             out[j0 + Ns] = Cd{a.x - b.x, a.y - b.y};
@@ -1586,7 +1617,7 @@ extern "C" int impdar_phaseshift_ffd(impdar_ctx *ctx, const double *data, int sn
 
     // power-of-two trace counts up to 512: the whole chain in one persistent workgroup (IMPDAR_FFD_CHAIN=0 keeps the
     // launch-per-step form below, which also serves every other trace count).  Measured us per step, one workgroup /
-    // launch per step (the latter varies by box): 64 traces 4.4 / 14-17, 128 traces 5.7 / 14, 512 traces 9.4 / 12.4-17.5,
+    // launch per step (the latter varies by box): 64 traces 4.5 / 11-17, 128 traces 5.4 / 12-15, 512 traces 8.2 / 12.4-17.5,
     // 1024 traces 19 / 18.5-20, 2048 traces 37 / 28 -- one CU does all of a step's float64 sincos and butterflies and
     // the barriers of a wider workgroup cost more (one trace per thread: 28 us at 1024; four per thread: 11.8 us at 512),
     // so the wide rows stay with the spread-out form.
