@@ -633,6 +633,48 @@ def test_several_tiles_per_workgroup_on_one_ring(hip, xb, nh, lk, monkeypatch):
             assert np.array_equal(a, b)
 
 
+def test_one_shot_entry_point_reuses_its_plan(hip, monkeypatch, capfd):
+    """impdar_kirchhoff keeps its last plan and device buffers: a second radargram of the same geometry (a cache hit,
+    reported by IMPDAR_TIMING) must come out exactly as with a plan of its own (IMPDAR_KIRCH_ONESHOT_CACHE=0), and a
+    change of geometry or velocity must not reuse anything."""
+    from impdar_amd import synth
+    from impdar_amd.lib.RadarData import RadarData
+    from impdar_amd.lib import migrationlib
+    from oracle import c_oracle
+    snum, tnum = 400, 333
+    geo = synth.geometry(snum, tnum)
+    rng = np.random.default_rng(3)
+    xs = [rng.standard_normal((snum, tnum)).astype(np.float32) for _ in range(2)]
+
+    def run(x, g=geo, vel=1.69e8):
+        d = RadarData(None)
+        d.data, d.snum, d.tnum = x.copy(), x.shape[0], x.shape[1]
+        d.travel_time, d.dist, d.trace_int, d.dt = g['travel_time'], g['dist'], g['trace_int'], g['dt']
+        migrationlib.migrationKirchhoff(d, vel=vel)
+        return d.data
+
+    monkeypatch.setenv('IMPDAR_TIMING', '1')
+    monkeypatch.delenv('IMPDAR_KIRCH_ONESHOT_CACHE', raising=False)
+    capfd.readouterr()
+    kept = [run(x) for x in xs]
+    err = capfd.readouterr().err
+    assert err.count('impdar_kirchhoff: new plan') == 1 and err.count('impdar_kirchhoff: cached plan') == 1, err
+    other = run(xs[0], vel=1.8e8)                       # same sizes, another velocity: a plan of its own
+    geo2 = synth.geometry(snum, tnum, dx=2.0)
+    wide = run(xs[0], g=geo2)                           # another trace spacing
+    err = capfd.readouterr().err
+    assert err.count('new plan') == 2 and 'cached plan' not in err, err
+    monkeypatch.setenv('IMPDAR_KIRCH_ONESHOT_CACHE', '0')
+    fresh = [run(x) for x in xs]
+    err = capfd.readouterr().err
+    assert err.count('new plan') == 2 and 'cached plan' not in err, err
+    for a, b, x in zip(kept, fresh, xs):
+        assert np.array_equal(a, b)
+        assert rel_l2(a, c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], 1.69e8, False)) < FAST_L2
+    assert rel_l2(other, c_oracle.kirchhoff(xs[0], geo['travel_time'], geo['dist'], 1.8e8, False)) < FAST_L2
+    assert rel_l2(wide, c_oracle.kirchhoff(xs[0], geo2['travel_time'], geo2['dist'], 1.69e8, False)) < FAST_L2
+
+
 @pytest.mark.parametrize('dtype,mode,tol', [(np.float32, 'fast', 1e-5), (np.float64, 'exact', 1e-13)])
 @pytest.mark.parametrize('world', [2, 4, 8])
 def test_halo_exchange_ranges_cover_everything_a_rank_reads(hip, world, dtype, mode, tol, monkeypatch):
