@@ -3,7 +3,7 @@
 suites).  Random sizes, spacings (round numbers included: they produce rounding-noise ties), velocities, first-sample
 times, near field, float32 / float64 / int16 data, through the product entry point in its default mode.
 
-    python tests/tools/fuzz_kirchhoff.py [ncases] [seed]  ->  one line per case, summary at the end, exit code 1 on a miss
+    python tests/tools/fuzz_kirchhoff.py [ncases] [seed] [size scale]  ->  one line per case, summary at the end, exit code 1 on a miss
 """
 import contextlib
 import io
@@ -23,11 +23,12 @@ from oracle import c_oracle                                     # noqa: E402
 def main():
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    scale_up = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
     worst = {'f32': 0.0, 'f64': 0.0}
     bad = 0
     t_start = time.time()
     for case in range(ncases):
-        snum, tnum = int(rng.integers(2, 1500)), int(rng.integers(1, 700))
+        snum, tnum = int(rng.integers(2, int(1500 * scale_up))), int(rng.integers(1, int(700 * scale_up)))
         if rng.integers(0, 2):
             dt, dx = float(rng.choice([1e-8, 2e-9, 5e-9, 1.25e-8])), float(rng.choice([0.25, 0.5, 1.0, 2.0, 2.5, 4.0]))
             vel = float(rng.choice([1.68e8, 1.69e8, 2.0e8, 1.5e8, 3.0e8]))
