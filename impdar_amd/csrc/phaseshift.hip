@@ -152,6 +152,7 @@ struct PsParams {
     const int *sched;       // float32 v(z), ps_vz32_kernel: [snum] 1 where a new constant-velocity run starts
     const int *tsched;      // ... [ceil(ntile/32)] bit t of word t/32 set where 16-step tile t holds such a step
     const int *rowmap;      // ... [tnum] wavenumber of workgroup b (rows holding boundary frequencies first), or null
+    const double *eps;      // float64 v(z), ps_vz64_kernel: [ceil(snum/16)] sum over the tile's steps of v / v_run - 1
     int snum, tnum, nt, vz_mode;
 };
 
@@ -904,11 +905,256 @@ __global__ __launch_bounds__(BLOCK) void ps_vz32_kernel(PsParams P)
     }
 }
 
+// ---------------------------------------------------------------------------
+// float64 v(z), layered profiles: the float64 counterpart of ps_vz32_kernel (what a float64 .mat file gets).  The
+// per-step kernel (ps_kernel<double, ..., true>) evaluates a square root and a sincos for every (tau, frequency):
+// 232 ms at 4096^2 where the constant-velocity float64 kernel takes 19 ms.  Here, inside a run of constant velocity
+// every frequency turns by the run's rotation (float64: no anchors needed, the recurrence loses ~1e-16 per step
+// like the reference's own product), 6 float64 instructions per (tau, frequency) in fully unrolled 16-step tiles.
+//  * Velocity noise inside a run (2*gradient(z(t)) of a layered table is constant only to ~4e-13) is not
+//    dropped: the host sums eps = v/v_run - 1 over every tile, and at the end of the tile each frequency is turned
+//    by exp(i coef eps_sum) to second order, coef = d(increment)/d(ln v) = -w dt a^2 / sqrt(coss) kept in LDS
+//    ([m][thread]); the per-step tiles apply it step by step.
+//  * Frequencies near the evanescent boundary (|coss| < 1e-6) take no part in the shared rotation: they are walked
+//    step by step at every step's own velocity with the reference's rounding of coss (kept or dropped by its sign,
+//    mig_python.py:456-485) -- inline in the per-step tiles, as a correction to the step sums in quiet tiles
+//    (float64 LDS atomics), exactly as in ps_vz32_kernel.
+// ---------------------------------------------------------------------------
+template <int BLOCK, int M>
+__global__ __launch_bounds__(BLOCK) void ps_vz64_kernel(PsParams P)
+{
+    constexpr int TT = 16;
+    constexpr int NW = BLOCK / 64;
+    extern __shared__ __attribute__((aligned(16))) char ps_smem[];
+    double *coef = reinterpret_cast<double *>(ps_smem);                                  // [M][BLOCK]
+    double(*red)[NW][2 * TT] = reinterpret_cast<double(*)[NW][2 * TT]>(ps_smem + (size_t)M * BLOCK * 8);
+    double *corr = reinterpret_cast<double *>(ps_smem + (size_t)M * BLOCK * 8 + 2 * NW * 2 * TT * sizeof(double));   // [2][2 * TT]
+    const int k = P.rowmap ? P.rowmap[blockIdx.x] : (int)blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Cp<double> *F = reinterpret_cast<const Cp<double> *>(P.F) + (size_t)k * P.nt;
+    Cp<double> *TK = reinterpret_cast<Cp<double> *>(P.TK) + (size_t)k * P.snum;
+    const double kxk = P.kx[k];
+    if (tid < 4 * TT) corr[tid] = 0.0;
+
+    double gr[M], gi[M];     // the field of every owned frequency
+    double pc[M], ps[M];     // exp(i increment) of the current run (identity for boundary and dead frequencies)
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int iw = tid + m * BLOCK;
+        gr[m] = gi[m] = ps[m] = 0.0;
+        pc[m] = 1.0;
+        if (iw < P.nt) {
+            const Cp<double> c = F[iw];
+            gr[m] = c.x;
+            gi[m] = c.y;
+        }
+        coef[m * BLOCK + tid] = 0.0;
+    }
+    unsigned edge = 0;       // bit m = frequency m sits near the evanescent boundary of the current run
+    bool wg_edge = false;    // ... some thread of the workgroup has one (uniform)
+    double v_run = 1.0;      // the current run's velocity (uniform)
+
+    const int ntile = (P.snum + TT - 1) / TT;
+    // one boundary frequency, one depth step, the reference's way: FK *= exp(i w dt sqrt(coss)), zero for good once
+    // coss <= threshold
+    auto edge_step = [&](double w, double vd, double thr, double &sr, double &si) {
+        const double a = 0.5 * vd * kxk / w;                                    // :456
+        const double cs = 1.0 - a * a;
+        const double inc = w * P.dt * (cs > 0.0 ? sqrt(cs) : 0.0);              // :458-460
+        double sn, c2;
+        sincos(inc, &sn, &c2);
+        const double nr = sr * c2 - si * sn, ni = sr * sn + si * c2;           // :464
+        sr = nr;
+        si = ni;
+        if (cs <= thr) {                                                        // :484-485
+            sr = 0.0;
+            si = 0.0;
+        }
+    };
+    auto do_tile = [&](const int tile, auto quiet_tag) __attribute__((always_inline)) {
+        constexpr bool quiet = decltype(quiet_tag)::value;
+        double acc[2 * TT];
+#pragma unroll
+        for (int i = 0; i < 2 * TT; ++i) acc[i] = 0.0;
+        const int tau0 = tile * TT;
+        if constexpr (quiet) {
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const double nr = fma(gr[m], pc[m], -(gi[m] * ps[m]));      // FK *= exp(i w dt sqrt(coss)), :464
+                    const double ni = fma(gr[m], ps[m], gi[m] * pc[m]);
+                    gr[m] = nr;
+                    gi[m] = ni;
+                    acc[2 * t] += nr;                                           // TK[itau] += FK, :487
+                    acc[2 * t + 1] += ni;
+                    asm volatile("" : "+v"(gr[m]), "+v"(gi[m]), "+v"(acc[2 * t]), "+v"(acc[2 * t + 1]));
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int t = 0; t < TT; ++t) {
+                const int tau = tau0 + t;
+                if (tau >= P.snum) break;      // uniform
+                const double vd = P.vz[tau];
+                const double thr = P.thr[tau];
+                const bool changed = P.sched[tau] != 0;      // uniform
+                int tid_here = tid;
+                asm volatile("" : "+v"(tid_here));
+                if (changed) {
+                    unsigned new_edge = 0;
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        const int iw = tid_here + m * BLOCK;
+                        double c2 = 1.0, sn = 0.0, cf = 0.0;
+                        if (iw < P.nt) {
+                            const double w = P.w[iw];
+                            const double a = 0.5 * vd * kxk / w;                 // :456
+                            const double cs = 1.0 - a * a;
+                            const bool on_edge = fabs(cs) < 1e-6;
+                            new_edge |= (on_edge ? 1u : 0u) << m;
+                            if (!on_edge) {
+                                if (cs <= 0.0) {
+                                    // evanescent at this velocity: zero from here on (:484-485; away from the
+                                    // boundary the threshold (tau/tt_end/1e6)^2 <= 1e-12 is the sign of coss)
+                                    gr[m] = 0.0;
+                                    gi[m] = 0.0;
+                                } else {
+                                    const double root = sqrt(cs);
+                                    sincos(w * P.dt * root, &sn, &c2);          // :458-464
+                                    cf = -(w * P.dt) * (a * a) / root;
+                                }
+                            }
+                        }
+                        pc[m] = c2;
+                        ps[m] = sn;
+                        coef[m * BLOCK + tid] = cf;
+                        asm volatile("" : "+v"(pc[m]), "+v"(ps[m]), "+v"(gr[m]), "+v"(gi[m]));
+                    }
+                    edge = new_edge;
+                    wg_edge = __syncthreads_or(new_edge != 0) != 0;
+                    v_run = vd;
+                }
+                const double eps = vd / v_run - 1.0;         // this step's velocity against the run's (uniform)
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    double a = gr[m], b = gi[m];
+                    const double nr = fma(a, pc[m], -(b * ps[m]));
+                    const double ni = fma(a, ps[m], b * pc[m]);
+                    a = nr;
+                    b = ni;
+                    if (eps != 0.0) {                        // uniform
+                        const double d = coef[m * BLOCK + tid] * eps, h = 1.0 - 0.5 * d * d;
+                        a = nr * h - ni * d;
+                        b = nr * d + ni * h;
+                    }
+                    gr[m] = a;
+                    gi[m] = b;
+                }
+                if (edge) {
+                    // boundary frequencies: this step's increment from this step's velocity (their pc/ps are the identity)
+#pragma unroll
+                    for (int m = 0; m < M; ++m)
+                        if ((edge >> m) & 1u) edge_step(P.w[tid_here + m * BLOCK], vd, thr, gr[m], gi[m]);
+                }
+                double pr[4] = {0, 0, 0, 0}, pi[4] = {0, 0, 0, 0};              // :487
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    pr[m & 3] += gr[m];
+                    pi[m & 3] += gi[m];
+                }
+                const double sr = (pr[0] + pr[1]) + (pr[2] + pr[3]), si = (pi[0] + pi[1]) + (pi[2] + pi[3]);
+#pragma unroll
+                for (int u = 0; u < TT; ++u)
+                    if (t == u) {   // uniform
+                        acc[2 * u] = sr;
+                        acc[2 * u + 1] = si;
+                    }
+            }
+        }
+        // ---- sum over frequencies: wave butterfly, then across waves via LDS
+        wave_reduce_scatter<double, 2 * TT>(acc, lane);
+        double(*buf)[2 * TT] = red[tile & 1];
+        if ((lane & 1) == 0) buf[wave][lane >> 1] = acc[0];
+        if constexpr (quiet) {
+            // velocity noise of the tile, to second order: F *= exp(i coef eps_sum)
+            double es, unused;
+            scalar_load_2f64(P.eps + tile, P.eps + tile, &es, &unused);
+            if (es != 0.0) {     // uniform
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const double d = coef[m * BLOCK + tid] * es, h = 1.0 - 0.5 * d * d;
+                    const double a = gr[m], b = gi[m];
+                    gr[m] = a * h - b * d;
+                    gi[m] = a * d + b * h;
+                }
+            }
+            if (wg_edge && edge) {
+                // boundary frequencies of this thread: the unrolled body carried their state through the tile
+                // unchanged (identity rotation) and added it to every step's sum; walk the 16 steps and file the
+                // difference (see ps_vz32_kernel)
+                int tid_here = tid;
+                asm volatile("" : "+v"(tid_here));
+                const double *svz = P.vz + tau0, *sthr = P.thr + tau0;
+                double *cr = corr + (tile & 1) * 2 * TT;
+                for (unsigned e = edge; e; e &= e - 1) {
+                    const int m = __builtin_ctz(e);
+                    double hr = 0.0, hi = 0.0;
+#pragma unroll
+                    for (int q = 0; q < M; ++q)
+                        if (q == m) {
+                            hr = gr[q];
+                            hi = gi[q];
+                        }
+                    const double w = P.w[tid_here + m * BLOCK];
+                    double sr = hr, si = hi;
+#pragma unroll 1
+                    for (int t = 0; t < TT; ++t) {
+                        double vd, thr;
+                        scalar_load_2f64(svz + t, sthr + t, &vd, &thr);
+                        edge_step(w, vd, thr, sr, si);
+                        atomicAdd(&cr[2 * t], sr - hr);
+                        atomicAdd(&cr[2 * t + 1], si - hi);
+                    }
+#pragma unroll
+                    for (int q = 0; q < M; ++q)
+                        if (q == m) {
+                            gr[q] = sr;
+                            gi[q] = si;
+                        }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * TT) {
+            double sum = corr[(tile & 1) * 2 * TT + tid];    // boundary frequencies of a quiet tile (zero otherwise)
+            corr[(tile & 1) * 2 * TT + tid] = 0.0;           // next written two tiles on, a barrier in between
+#pragma unroll
+            for (int q = 0; q < NW; ++q) sum += buf[q][tid];
+            const int tau = tau0 + (tid >> 1);
+            if (tau < P.snum) {
+                double *dst = reinterpret_cast<double *>(TK + tau) + (tid & 1);
+                *dst = sum / (double)P.snum;                                    // TK /= snum, :492
+            }
+        }
+    };
+    unsigned dirty_bits = 0;
+    auto is_quiet = [&](const int tile) __attribute__((always_inline)) {
+        if ((tile & 31) == 0) dirty_bits = (unsigned)scalar_load_i32(P.tsched + (tile >> 5));
+        return ((dirty_bits >> (tile & 31)) & 1u) == 0 && tile * TT + TT <= P.snum;      // uniform
+    };
+    int tile = 0;
+    while (tile < ntile) {
+        for (; tile < ntile && !is_quiet(tile); ++tile) do_tile(tile, std::false_type());
+        for (; tile < ntile && is_quiet(tile); ++tile) do_tile(tile, std::true_type());
+    }
+}
+
 struct PsPlan {
     int dtype = -1, snum = 0, tnum = 0, nt = 0;
     const impdar_ctx *owner = nullptr;   // plans and buffers live on this context's device and stream
     FftPlan f_time, f_trace, b_trace;
-    DevBuf X, TK, d_kx, d_w, d_vz, d_thr, d_sched, d_rowmap;
+    DevBuf X, TK, d_kx, d_w, d_vz, d_thr, d_sched, d_rowmap, d_eps;
 };
 static std::mutex g_ps_mu;
 static PsPlan *g_ps_plan = nullptr;
@@ -933,6 +1179,16 @@ static void ps_launch(const PsParams &P, hipStream_t st)
             auto k = ps_vz32_kernel<BLOCK, M>;
             (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vz32_lds);
             hipLaunchKernelGGL(k, dim3(P.tnum), dim3(BLOCK), vz32_lds, st, P);
+            return;
+        }
+    }
+    constexpr size_t vz64_lds = (size_t)M * BLOCK * 8 + 2 * (BLOCK / 64) * 32 * sizeof(double) + 2 * 32 * sizeof(double);
+    if constexpr (sizeof(T) == 8 && vz64_lds <= 160 * 1024 && M <= 16) {
+        static const bool old_kernel64 = getenv("IMPDAR_PS_VZ_OLD") != nullptr;
+        if (P.vz_mode && P.sched && P.eps && !old_kernel64) {
+            auto k = ps_vz64_kernel<BLOCK, M>;
+            (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vz64_lds);
+            hipLaunchKernelGGL(k, dim3(P.tnum), dim3(BLOCK), vz64_lds, st, P);
             return;
         }
     }
@@ -976,6 +1232,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             pl.X.release(); pl.TK.release(); pl.d_kx.release(); pl.d_w.release(); pl.d_vz.release(); pl.d_thr.release();
             pl.d_sched.release();
             pl.d_rowmap.release();
+            pl.d_eps.release();
             pl.owner = ctx;
         }
         int rc;
@@ -1035,20 +1292,24 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     P.vz_mode = vlen ? 1 : 0;
     {
         const char *e = getenv("IMPDAR_PS_VTOL");     // diagnostic knob
-        P.vtol = e ? atof(e) : 1e-10;
+        P.vtol = e ? atof(e) : (dbl ? 1e-11 : 1e-10);
     }
     P.sched = P.tsched = P.rowmap = nullptr;
+    P.eps = nullptr;
     std::vector<int> sched, rowmap;
-    if (vlen && !dbl) {
+    std::vector<double> epsum;
+    if (vlen) {
         // runs of constant velocity (ps_vz32_kernel): a step starts a new run when its velocity differs from the
         // run's first by more than vtol (relative) -- 2*gradient(z(t)) of a layered table is constant inside a
         // layer up to ~4e-13 of rounding noise, and a 1e-10 velocity error moves the phase by < 3e-6 rad over
-        // 8192 steps (float32 path only).  Profiles that change at (nearly) every step keep the per-step kernel.
+        // 8192 steps (float32: ignored; float64: vtol 1e-11 and the deviation is carried to second order,
+        // ps_vz64_kernel).  Profiles that change at (nearly) every step keep the per-step kernels.
         const int ntile = (snum + 15) / 16;
         sched.assign((size_t)snum + (ntile + 31) / 32, 0);
         double vrun = -1.0;
         int ndirty = 0;
-        for (int i = 0; i < snum; ++i)
+        epsum.assign(ntile, 0.0);
+        for (int i = 0; i < snum; ++i) {
             if (std::fabs(vmig[i] - vrun) > P.vtol * std::fabs(vmig[i])) {
                 const int tile = i / 16;
                 const unsigned bit = 1u << (tile & 31);
@@ -1058,11 +1319,18 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
                 word |= bit;
                 vrun = vmig[i];
             }
+            epsum[i / 16] += vmig[i] / vrun - 1.0;      // float64 kernel: the run's velocity noise, tile by tile
+        }
         if (2 * ndirty <= ntile || snum <= 64) {
             IMPDAR_HIP_CHECK(pl.d_sched.ensure(sched.size() * sizeof(int)));
             IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_sched.p, sched.data(), sched.size() * sizeof(int), hipMemcpyHostToDevice, st));
             P.sched = pl.d_sched.as<int>();
             P.tsched = P.sched + snum;
+            if (dbl) {
+                IMPDAR_HIP_CHECK(pl.d_eps.ensure(epsum.size() * sizeof(double)));
+                IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_eps.p, epsum.data(), epsum.size() * sizeof(double), hipMemcpyHostToDevice, st));
+                P.eps = pl.d_eps.as<double>();
+            }
             // Launch order.  A wavenumber that holds a frequency on the evanescent boundary of a run walks it in
             // fp64 in every tile of that run (~2x the tile time); spread over the launch, the last such rows finish
             // alone after everything else (2 ms at config 5).  They go first, longest first.  The test here only
@@ -1085,7 +1353,8 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
                         const double target = 0.5 * r.first * std::fabs(kx[k]);
                         const auto it = std::lower_bound(aw.begin(), aw.end(), target);
                         const double hi = it != aw.end() ? *it : aw.back(), lo = it != aw.begin() ? *(it - 1) : aw.front();
-                        if (std::fabs(hi - target) <= 1e-7 * target || std::fabs(lo - target) <= 1e-7 * target) steps += r.second;
+                        const double band = dbl ? 2e-6 : 1e-7;
+                        if (std::fabs(hi - target) <= band * target || std::fabs(lo - target) <= band * target) steps += r.second;
                     }
                     score[k] = std::make_pair(-steps, k);
                     flagged += steps > 0;

@@ -1,0 +1,34 @@
+"""Device ms of the phase-shift migration on FLOAT64 data (what a float64 .mat file gets), constant velocity and a
+layered v(z) table, resident.  usage: ps_quick64.py [n] [reps]"""
+import sys, os, json, io, contextlib
+import ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from impdar_amd import _hip, synth
+from impdar_amd.lib.RadarData import RadarData
+
+lib, ctx = _hip.load(), _hip.context()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+rng = np.random.default_rng(0)
+geo = synth.geometry(n, n)
+x = rng.standard_normal((n, n))
+Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+tab = np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rp], [1.8e8, 0.5 * Rp], [1.9e8, 1.2 * Rp]])
+out = {}
+for name, vel in (('const', 1.69e8), ('vz', tab)):
+    ms = []
+    for i in range(reps + 1):
+        d = RadarData(None)
+        d.data, (d.snum, d.tnum) = x, x.shape
+        d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
+        d.to_device()
+        with contextlib.redirect_stdout(io.StringIO()):
+            d.migrate('phsh', vel=vel, htaper=100, vtaper=1000)
+        v = C.c_float()
+        _hip.check(lib.impdar_ctx_last_ms(ctx, C.byref(v)), 'impdar_ctx_last_ms')
+        ms.append(v.value)
+        d._dev.free()
+        d._dev = None
+    out[name] = {'device_ms': float(np.median(ms[1:])), 'all': [round(m, 2) for m in ms]}
+print(json.dumps({'n': n, 'dtype': 'float64', **out}))
