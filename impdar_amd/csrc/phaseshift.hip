@@ -170,8 +170,7 @@ template <typename T, int MASK> __device__ __forceinline__ T lane_xor(T v)
 #else
     constexpr bool DPP = true;
 #endif
-    if constexpr (DPP && sizeof(T) == 4 && MASK <= 8) {
-        const unsigned u = __float_as_uint(v);
+    auto dpp32 = [](unsigned u) {
         unsigned x;
         if constexpr (MASK == 1) x = __builtin_amdgcn_update_dpp(0u, u, 0xB1, 0xf, 0xf, false);        // quad_perm:[1,0,3,2]
         else if constexpr (MASK == 2) x = __builtin_amdgcn_update_dpp(0u, u, 0x4E, 0xf, 0xf, false);   // quad_perm:[2,3,0,1]
@@ -179,7 +178,13 @@ template <typename T, int MASK> __device__ __forceinline__ T lane_xor(T v)
             x = __builtin_amdgcn_update_dpp(0u, u, 0x104, 0xf, 0x5, false);    // row_shl:4 into banks 0 and 2 (lane <- lane + 4)
             x = __builtin_amdgcn_update_dpp(x, u, 0x114, 0xf, 0xa, false);     // row_shr:4 into banks 1 and 3 (lane <- lane - 4)
         } else x = __builtin_amdgcn_update_dpp(0u, u, 0x128, 0xf, 0xf, false);                         // row_ror:8
-        return __uint_as_float(x);
+        return x;
+    };
+    if constexpr (DPP && sizeof(T) == 4 && MASK <= 8) {
+        return __uint_as_float(dpp32(__float_as_uint(v)));
+    } else if constexpr (DPP && sizeof(T) == 8 && MASK <= 8) {
+        // a double moves as its two words
+        return __hiloint2double((int)dpp32((unsigned)__double2hiint(v)), (int)dpp32((unsigned)__double2loint(v)));
     } else {
         return __shfl_xor(v, MASK, 64);
     }
@@ -206,6 +211,22 @@ __device__ __forceinline__ void wrs_halve(T (&v)[NV], int lane)
             } else {
                 const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
                 v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            }
+        }
+    } else if constexpr (SWAP && sizeof(T) == 8 && (MASK == 32 || MASK == 16)) {
+        // float64: the same swap on the low and the high words
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) {
+            const unsigned alo = (unsigned)__double2loint(v[i]), ahi = (unsigned)__double2hiint(v[i]);
+            const unsigned blo = (unsigned)__double2loint(v[i + HALF]), bhi = (unsigned)__double2hiint(v[i + HALF]);
+            if constexpr (MASK == 32) {
+                const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+                const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+                v[i] = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+            } else {
+                const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+                const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+                v[i] = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
             }
         }
     } else {
