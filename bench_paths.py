@@ -105,6 +105,18 @@ def main():
                           "host_seconds": el, "traces_per_s": n / el, "finite": bool(np.isfinite(d.data).all()),
                           "rotate_accumulate_steps": float(n) ** 3, "reference_extrapolated_hours": 7.6,
                           "cpu_baseline": cb}), flush=True)
+    if 'phsh64' not in args.skip:
+        # the same layered table on float64 data (what a float64 .mat file gets): ps_vz64_kernel
+        n = args.phsh
+        geo = synth.geometry(n, n)
+        x64 = rng.standard_normal((n, n))
+        Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+        tab = np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rp], [1.8e8, 0.5 * Rp], [1.9e8, 1.2 * Rp]])
+        el, d = timed(lambda d: migrationlib.migrationPhaseShift(d, vel=tab), lambda: dat_of(x64.copy(), geo))
+        print(json.dumps({"path": "phase-shift v(z) Gazdag, float64 data", "config": "%dx%d float64" % (n, n),
+                          "host_seconds": el, "traces_per_s": n / el, "finite": bool(np.isfinite(d.data).all()),
+                          "rotate_accumulate_steps": float(n) ** 3}), flush=True)
+        del x64, d
     if 'ffd' not in args.skip:
         # v(x,z) table: the Fourier finite-difference branch, a serial chain of snum * nt steps (one workgroup, the
         # row in LDS, for power-of-two trace counts up to 512)
