@@ -1342,7 +1342,14 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             }
             epsum[i / 16] += vmig[i] / vrun - 1.0;      // float64 kernel: the run's velocity noise, tile by tile
         }
-        if (2 * ndirty <= ntile || snum <= 64) {
+        // the per-step tiles of the runs kernels cost several quiet tiles each: beyond a share of such tiles the
+        // per-step kernel is faster for float32 (2048^2, 40 / 80 / 160 layers: 4.6 / 7.5 / 12.2 ms against
+        // 5.5 / 6.8 / 9.5 ms); the float64 runs kernel stays ahead until every tile holds a change (10.1 / 16.6 /
+        // 27.5 ms against 26.4 ms throughout: its per-step tiles pay the square root and sincos at the changes
+        // only).  profiles/tools/ps_dirty.py; IMPDAR_PS_DIRTY_MAX overrides the share.
+        const char *dm = getenv("IMPDAR_PS_DIRTY_MAX");
+        const double dirty_max = dm ? atof(dm) : (dbl ? 0.9 : 0.5);
+        if ((double)ndirty <= dirty_max * ntile || snum <= 64) {
             IMPDAR_HIP_CHECK(pl.d_sched.ensure(sched.size() * sizeof(int)));
             IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_sched.p, sched.data(), sched.size() * sizeof(int), hipMemcpyHostToDevice, st));
             P.sched = pl.d_sched.as<int>();
