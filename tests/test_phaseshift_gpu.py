@@ -279,6 +279,26 @@ def test_float32_velocity_changing_in_most_tiles(hip):
     assert rel_l2(d.data, want) < F32_L2, rel_l2(d.data, want)
 
 
+@pytest.mark.parametrize('snum,tnum', [(2100, 12), (4200, 8)])
+def test_float64_vz_eight_and_sixteen_frequencies_per_lane(hip, snum, tnum):
+    """float64 layered v(z) at nt = 4096 and 8192: the 8- and 16-frequencies-per-lane instantiations of the float64
+    constant-velocity-runs kernel (what a float64 file of that length gets), against the oracle."""
+    from impdar_amd import synth
+    from impdar_amd.lib.RadarData import RadarData
+    from impdar_amd.lib import migrationlib
+    from oracle import mig_oracle
+    geo = synth.geometry(snum, tnum)
+    data = synth.noise_radargram(snum, tnum, seed=snum)
+    Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+    vel = np.array([[1.68e8, 0.], [1.68e8, 0.3 * Rp], [1.8e8, 0.6 * Rp], [1.9e8, 1.2 * Rp]])
+    want = mig_oracle.phase_shift(data, geo['dt'], geo['trace_int'], geo['travel_time'], geo['dist'], vel, 20, 30)
+    d = RadarData(None)
+    d.data, d.snum, d.tnum = data.copy(), snum, tnum
+    d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
+    migrationlib.migrationPhaseShift(d, vel=vel, htaper=20, vtaper=30)
+    assert rel_max(d.data, want) < F64_TOL, rel_max(d.data, want)
+
+
 @pytest.mark.parametrize('layered', [False, True])
 def test_float32_larger_size_vs_oracle(hip, layered):
     """float32 recurrences over ~1000 depth steps (nt = 1024, two frequencies per lane)."""
