@@ -1325,7 +1325,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         // runs of constant velocity (ps_vz32_kernel): a step starts a new run when its velocity differs from the
         // run's first by more than vtol (relative) -- 2*gradient(z(t)) of a layered table is constant inside a
         // layer up to ~4e-13 of rounding noise, and a 1e-10 velocity error moves the phase by < 3e-6 rad over
-        // 8192 steps (float32: ignored; float64: vtol 1e-11 and the deviation is carried to second order,
+        // 8192 steps (float32: ignored; float64: vtol 1e-11 and the deviation is carried along as a phase,
         // ps_vz64_kernel).  Profiles that change at (nearly) every step keep the per-step kernels.
         const int ntile = (snum + 15) / 16;
         sched.assign((size_t)snum + (ntile + 31) / 32, 0);
