@@ -23,7 +23,7 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     deps = srcs + [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'impdar_hip.h')]
-    objs = []
+    objs, jobs = [], []
     for s in srcs:
         o = s[:-4] + '.o'
         objs.append(o)
@@ -31,7 +31,10 @@ def build(force=False, verbose=True):
             cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            jobs.append((cmd, subprocess.Popen(cmd)))      # the sources compile side by side (kirchhoff.hip is minutes)
+    failed = [cmd for cmd, proc in jobs if proc.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
     if force or any(_newer(o, LIB) for o in objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + \
               ['-o', LIB, '-L/opt/rocm/lib', '-lrocfft', '-lrccl', '-Wl,-rpath,/opt/rocm/lib']
