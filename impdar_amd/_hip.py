@@ -155,12 +155,15 @@ def device_count():
 
 
 def context(device=None):
-    """Per-process context for ``device`` (default: $LOCAL_RANK or 0)."""
+    """Per-process context for ``device`` (default: $IMPDAR_DEVICE, else $LOCAL_RANK, else 0).  A rank whose
+    device does not exist is an error -- two ranks must never end up sharing GPU 0 silently."""
     lib = load()
     if device is None:
         device = int(os.environ.get('IMPDAR_DEVICE', os.environ.get('LOCAL_RANK', '0')))
-        if device >= max(lib.impdar_device_count(), 1):
-            device = 0
+        ndev = lib.impdar_device_count()
+        if device < 0 or device >= max(ndev, 1):
+            raise HipUnavailableError('rank wants GPU %d but only %d device(s) are visible (LOCAL_RANK / '
+                                      'IMPDAR_DEVICE / IMPDAR_NGPUS larger than the node)' % (device, ndev))
     with _lock:
         if device in _ctx:
             return _ctx[device]

@@ -23,6 +23,7 @@
 //                        same idea with a trace-major ring, ds_read_b32 and an fp32 weight table,
 //                        for geometries whose moveout does not fit the quad ring.
 #include "common.h"
+#include <limits>
 #include <cmath>
 #include <algorithm>
 #include <chrono>
@@ -297,9 +298,12 @@ __global__ __launch_bounds__(256) void kirch_tablex_kernel(TableXParams P)
 // (geometries with a rational moveout 2dx/(v dt), e.g. 2.5 samples per trace, are full of them: 4a^2 + 25n^2 is
 // an odd square for whole families of (a, n)).  This scan flags a geometry that has any such entry inside an
 // aperture; the plan then keeps the per-pair kernel, which repeats the reference's arithmetic pair by pair.
-// Margin: the relative rounding noise of t, ~1e-15 plus the cancellation in dist[j] - dist[xi]
-// (2.2e-16 * tnum / |n|), times |t|/dt, in samples.
-__global__ __launch_bounds__(256) void kirch_tiescan_kernel(TableXParams P, double tnum, int *count, int2 *list, int cap)
+// Margin: the relative rounding noise of t, ~1e-15, plus the noise of dist[j] - dist[xi] against n * dx, times
+// |t|/dt, in samples.  `xnoise` is that position noise in units of dx, MEASURED on the profile by the host: twice the
+// largest deviation of dist[] from the fitted grid (the plan accepts up to 1e-9 dx as "uniform") plus the rounding of
+// the largest |dist| (a profile that starts 50 km along a line has ulp(dist)/dx ~ 7e-12, far above what a profile
+// starting at 0 has), never less than 4.5e-16 * tnum.
+__global__ __launch_bounds__(256) void kirch_tiescan_kernel(TableXParams P, double xnoise, int *count, int2 *list, int cap)
 {
     const int ti = blockIdx.x * 256 + threadIdx.x;
     const int n = blockIdx.y;
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(256) void kirch_tiescan_kernel(TableXParams P, doub
     if (!(cost == cost)) return;                       // 0/0 apex: dropped whatever the noise
     const double u = (t - P.tt0) * P.inv_dt, um = (P.tmax - P.tt0) * P.inv_dt;
     // ten times the noise estimate: a wider net only makes the list (a handful of entries) longer
-    const double eps = 10.0 * (fabs(t * P.inv_dt) + 1.0) * (1.0e-15 + 4.5e-16 * tnum / (double)max(n, 1));
+    const double eps = 10.0 * (fabs(t * P.inv_dt) + 1.0) * (1.0e-15 + xnoise / (double)max(n, 1));
     if (u > um + eps) return;                          // clearly outside the aperture
     bool amb = fabs(u - um) <= eps && n > 0;           // the t > t_max test itself (n = 0: t = tt exactly)
     if (u >= 0.0 && u <= um + eps && n > 0) {
@@ -1818,6 +1822,10 @@ static int upload(DevBuf &b, const void *src, size_t bytes)
     return IMPDAR_OK;
 }
 
+// set by mig_kirch_loop around its plan creation: the time limit t > t_max drops a pair at (mig_python.py:52) is the
+// caller's argument there, not max(tt)
+static thread_local const double *g_tmax_override = nullptr;
+
 extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, int tnum,
                                         const double *dist_m, const double *tt_sec, double vel,
                                         int nearfield, int grad_uniform, double grad_h,
@@ -1854,6 +1862,7 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         tmax = std::max(tmax, tt_sec[k]);
         if (!(tt_sec[k] > tt_sec[k - 1])) increasing = false;
     }
+    if (g_tmax_override) tmax = *g_tmax_override;      // mig_kirch_loop: the caller's own time limit (see there)
     p->tmax = tmax;
     if (!increasing) {
         delete p;
@@ -2080,7 +2089,14 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         T.snum = snum;
         T.ntab = hg;
         T.near = 0;
-        hipLaunchKernelGGL(kirch_tiescan_kernel, dim3((snum + 255) / 256, hg), dim3(256), 0, ctx->stream, T, (double)tnum,
+        // position noise of a pair's dist[j] - dist[xi] in units of dx, from the profile itself
+        double dev = 0.0, amax = 0.0;
+        for (int j = 0; j < tnum; ++j) {
+            dev = std::max(dev, std::fabs(dist_m[j] - (dist_m[0] + j * dx)));
+            amax = std::max(amax, std::fabs(dist_m[j]));
+        }
+        const double xnoise = std::max(4.5e-16 * (double)tnum, (2.0 * dev + 4.5e-16 * amax) / dx);
+        hipLaunchKernelGGL(kirch_tiescan_kernel, dim3((snum + 255) / 256, hg), dim3(256), 0, ctx->stream, T, xnoise,
                            d_flag.as<int>(), d_list.as<int2>(), TIE_CAP);
         int count = 0;
         if (hipMemcpyAsync(&count, d_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -2482,6 +2498,23 @@ static int build_tilemap(impdar_kirch_plan *p, FastParams &P, int tile_w, int al
     return IMPDAR_OK;
 }
 
+// Workgroup slots the persistent ring kernels leave EMPTY in a multi-rank plan.  They launch exactly as many
+// workgroups as are resident at once and keep them until the diffraction sum ends; RCCL's send/recv and all-gather
+// are kernels too (a few workgroups of their own, with LDS), so queued on the producer stream behind a full chip they
+// could only start when a persistent workgroup retires -- at the end of the diffraction sum -- and the exchange of
+// radargram s+1 would serialise behind the sum of radargram s instead of hiding under it.  With R slots free
+// (R/2 CUs with one of their two slots open) RCCL's workgroups are placed at once; the diffraction sum loses R/512 of
+// its slots.  IMPDAR_KIRCH_RESERVE=<R> overrides (0: none); measured in profiles/r03_exchange_overlap.txt.
+#ifndef KQ_DEFAULT_RESERVE
+#define KQ_DEFAULT_RESERVE 16
+#endif
+static int kirch_reserved_slots(const impdar_kirch_plan *p)
+{
+    const char *re = getenv("IMPDAR_KIRCH_RESERVE");
+    const int r = re ? atoi(re) : (p->nranks > 1 ? KQ_DEFAULT_RESERVE : 0);
+    return std::min(std::max(r, 0), 256);
+}
+
 template <int XB, int OCC, int SH, int NH = 1, int LK = 0>
 static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipStream_t st)
 {
@@ -2540,7 +2573,7 @@ static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipSt
                     // a piece no workgroup reaches (tiles beyond the block's end) must read as zero
                     IMPDAR_HIP_CHECK(hipMemsetAsync(p->d_partial.p, 0, (nout << pl2) * esz, st));
                 }
-                grid = (int)std::min<long long>(p->slots, (long long)nblk << P.parts_log2);
+                grid = (int)std::min<long long>(std::max(p->slots - kirch_reserved_slots(p), 1), (long long)nblk << P.parts_log2);
             }
         }
         hipLaunchKernelGGL(k, dim3(grid), dim3(KF_THREADS * NH), shmem, st, P, W);
@@ -2618,7 +2651,7 @@ static int launch_dquad(impdar_kirch_plan *p, const FastParams &P0, hipStream_t 
                     // a piece no workgroup reaches (tiles beyond the block's end) must read as zero
                     IMPDAR_HIP_CHECK(hipMemsetAsync(p->d_partial.p, 0, (nout << pl2) * esz, st));
                 }
-                grid = (int)std::min<long long>(p->slots, (long long)nblk << P.parts_log2);
+                grid = (int)std::min<long long>(std::max(p->slots - kirch_reserved_slots(p), 1), (long long)nblk << P.parts_log2);
             }
         }
         hipLaunchKernelGGL(k, dim3(grid), dim3(KF_THREADS * NH), shmem, st, P, W);
@@ -2905,8 +2938,10 @@ int impdar_allgather_rows(impdar_ctx *ctx, void *image, size_t bytes_per_rank, h
 extern "C" int impdar_kirch_allgather(impdar_kirch_plan *p)
 {
     IMPDAR_ARG_CHECK(p, "null plan");
-    IMPDAR_ARG_CHECK(p->nranks == p->ctx->nranks, "plan was built for %d ranks but the communicator has %d",
-                     p->nranks, p->ctx->nranks);
+    // (IMPDAR_COMM_EMULATE=1, diagnostics: a plan built for N ranks driven over a 1-rank communicator -- one rank of an
+    // N-rank run emulated on a single GPU with self send/recv, profiles/tools/exchange_overlap.py)
+    IMPDAR_ARG_CHECK(p->nranks == p->ctx->nranks || getenv("IMPDAR_COMM_EMULATE"),
+                     "plan was built for %d ranks but the communicator has %d", p->nranks, p->ctx->nranks);
     IMPDAR_HIP_CHECK(hipSetDevice(p->ctx->device));
     hipStream_t st = p->ctx->aux;                       // behind this radargram's prep
     hipEvent_t *ev = p->evs[p->slot];
@@ -2939,8 +2974,10 @@ extern "C" int impdar_kirch_exchange(impdar_kirch_plan *p, int nsend, const int 
     IMPDAR_ARG_CHECK(p, "null plan");
     IMPDAR_ARG_CHECK(nsend >= 0 && nrecv >= 0 && nsend <= 4096 && nrecv <= 4096, "bad range counts %d / %d", nsend, nrecv);
     IMPDAR_ARG_CHECK((nsend == 0 || (speer && slo && shi)) && (nrecv == 0 || (rpeer && rlo && rhi)), "null range arrays");
-    IMPDAR_ARG_CHECK(p->nranks == p->ctx->nranks, "plan was built for %d ranks but the communicator has %d",
-                     p->nranks, p->ctx->nranks);
+    // (IMPDAR_COMM_EMULATE=1, diagnostics: a plan built for N ranks driven over a 1-rank communicator -- one rank of an
+    // N-rank run emulated on a single GPU with self send/recv, profiles/tools/exchange_overlap.py)
+    IMPDAR_ARG_CHECK(p->nranks == p->ctx->nranks || getenv("IMPDAR_COMM_EMULATE"),
+                     "plan was built for %d ranks but the communicator has %d", p->nranks, p->ctx->nranks);
     const size_t rowb = (size_t)p->snum * impdar_dtype_size(p->dtype);
     std::vector<size_t> soff(nsend), slen(nsend), roff(nrecv), rlen(nrecv);
     auto conv = [&](int lo, int hi, size_t &off, size_t &len) {
@@ -3160,48 +3197,114 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
 // ---------------------------------------------------------------------------
 // reference-compatible native hook (mig_cython.h:11)
 // ---------------------------------------------------------------------------
+// void return, no error channel (_mig_cython.pyx:19-20): whatever goes wrong, migdata is filled with NaN -- the
+// wrapper returns it as the migrated image, and an untouched (all-zero) array would read as a result.
+//
+// The caller hands over its own depth tables and time limit (mig_python.py:98-102 computes them).  When they are what
+// the reference's driver computes -- zs = vel tt / 2 and zs2 = zs^2 bit for bit, max_travel_time = max(tt) up to the
+// single-precision rounding _mig_cython.pyx:30-32 applies to it -- on a uniform profile, the float64 LDS-ring kernel
+// runs (kirch_dquad_kernel, the library's own float64 default; its plan is created with the caller's time limit); any
+// other tables go through the per-pair kernel, which reads them as given.  The plan and the device buffers are kept
+// between calls of one geometry, as the one-shot entry point keeps its own.
 int impdar_kirch_prep_precomputed(impdar_kirch_plan *p, const void *d_grad, int ld, int jlo, int nloc);
+
+namespace {
+struct KirchHook {
+    impdar_ctx *ctx = nullptr;
+    impdar_kirch_plan *plan = nullptr;
+    DevBuf din, dout;
+    int snum = 0, tnum = 0;
+    double vel = 0, tmax = 0;
+    bool standard = false;
+    std::vector<double> dist, tt, zs, zs2;
+    std::string knobs;
+    void drop()
+    {
+        if (plan) impdar_kirch_plan_destroy(plan);
+        plan = nullptr;
+        din.release();
+        dout.release();
+    }
+};
+std::mutex g_hook_mu;
+KirchHook g_hook;
+}   // namespace
 
 extern "C" void mig_kirch_loop(double *migdata, int tnum, int snum, double *dist, double *zs, double *zs2,
                                double *tt_sec, double vel, double *gradD, double max_travel_time, int nearfield)
 {
-    static impdar_ctx *ctx = nullptr;
-    if (nearfield) {
-        fprintf(stderr, "impdar mig_kirch_loop: the reference prototype has no data pointer; "
-                        "nearfield needs impdar_kirchhoff()\n");
-        return;
+    auto fail = [&](const char *why) {
+        fprintf(stderr, "impdar mig_kirch_loop: %s -- migdata filled with NaN\n", why);
+        if (migdata && snum > 0 && tnum > 0) {
+            const double nan = std::numeric_limits<double>::quiet_NaN();
+            for (size_t i = 0, n = (size_t)snum * tnum; i < n; ++i) migdata[i] = nan;
+        }
+    };
+    if (!migdata || !dist || !zs || !zs2 || !tt_sec || !gradD || snum < 1 || tnum < 1) return fail("null pointer or empty array");
+    if (nearfield)
+        return fail("the reference prototype carries no data pointer, so the near-field term cannot be formed "
+                    "(use impdar_kirchhoff)");
+    std::lock_guard<std::mutex> lk(g_hook_mu);
+    KirchHook &c = g_hook;
+    if (!c.ctx && impdar_ctx_create(0, &c.ctx) != IMPDAR_OK) {
+        c.ctx = nullptr;
+        return fail(impdar_last_error());
     }
-    if (!ctx && impdar_ctx_create(0, &ctx) != IMPDAR_OK) {
-        fprintf(stderr, "impdar mig_kirch_loop: %s\n", impdar_last_error());
-        return;
+    impdar_ctx *ctx = c.ctx;
+    double ttmax = tt_sec[0];
+    bool standard = true;
+    for (int k = 0; k < snum; ++k) {
+        ttmax = std::max(ttmax, tt_sec[k]);
+        standard = standard && zs[k] == vel * tt_sec[k] / 2.0 && zs2[k] == zs[k] * zs[k];     // mig_python.py:101-102
     }
-    impdar_kirch_plan *p = nullptr;
-    double dummy = 1.0;
-    int rc = impdar_kirch_plan_create(ctx, IMPDAR_F64, snum, tnum, dist, tt_sec, vel, 0, 1, dummy, nullptr, nullptr,
-                                      nullptr, IMPDAR_KIRCH_EXACT, 1, &p);
-    if (rc) {
-        fprintf(stderr, "impdar mig_kirch_loop: %s\n", impdar_last_error());
-        return;
+    standard = standard && std::fabs(max_travel_time - ttmax) <= 1e-6 * std::fabs(ttmax);
+    const std::string knobs = kirch_knobs();
+    const bool hit = c.plan && c.snum == snum && c.tnum == tnum && c.vel == vel && c.tmax == max_travel_time &&
+                     c.standard == standard && same_vec(c.dist, dist, (size_t)tnum) && same_vec(c.tt, tt_sec, (size_t)snum) &&
+                     same_vec(c.zs, zs, (size_t)snum) && same_vec(c.zs2, zs2, (size_t)snum) && c.knobs == knobs;
+    if (!hit) {
+        c.drop();
+        g_tmax_override = standard ? &max_travel_time : nullptr;
+        const int rc = impdar_kirch_plan_create(ctx, IMPDAR_F64, snum, tnum, dist, tt_sec, vel, 0, 1, 1.0, nullptr, nullptr,
+                                                nullptr, IMPDAR_KIRCH_EXACT, 1, &c.plan);
+        g_tmax_override = nullptr;
+        if (rc) {
+            c.plan = nullptr;
+            return fail(impdar_last_error());
+        }
+        if (!standard) {
+            // the caller's own tables: per-pair kernel (the table-driven ones derive picks and apertures from the
+            // plan's tables)
+            c.plan->tmax = max_travel_time;
+            c.plan->xtab_off = true;
+            c.plan->dquad = false;
+            c.plan->ntie_groups = 0;
+            if (hipMemcpy(c.plan->d_zs.p, zs, (size_t)snum * 8, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(c.plan->d_zs2.p, zs2, (size_t)snum * 8, hipMemcpyHostToDevice) != hipSuccess) {
+                c.drop();
+                return fail("upload of the depth tables failed");
+            }
+        }
+        c.snum = snum, c.tnum = tnum, c.vel = vel, c.tmax = max_travel_time, c.standard = standard;
+        c.dist.assign(dist, dist + tnum);
+        c.tt.assign(tt_sec, tt_sec + snum);
+        c.zs.assign(zs, zs + snum);
+        c.zs2.assign(zs2, zs2 + snum);
+        c.knobs = knobs;
     }
-    // honour the caller's depth tables and time limit (mig_python.py:98-102 computes them): the tabulated
-    // exact kernel derives its aperture from the plan's own tmax, so the hook keeps the per-pair kernel
-    p->tmax = max_travel_time;
-    p->xtab_off = true;
-    p->dquad = false;
+    impdar_kirch_plan *p = c.plan;
     const size_t bytes = (size_t)snum * tnum * 8;
-    DevBuf din, dout;
-    if (hipMemcpy(p->d_zs.p, zs, (size_t)snum * 8, hipMemcpyHostToDevice) == hipSuccess &&
-        hipMemcpy(p->d_zs2.p, zs2, (size_t)snum * 8, hipMemcpyHostToDevice) == hipSuccess &&
-        din.ensure(bytes) == hipSuccess && dout.ensure(bytes) == hipSuccess &&
-        hipMemcpyAsync(din.p, gradD, bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
-        hipStreamSynchronize(ctx->stream) == hipSuccess &&
-        impdar_kirch_prep_precomputed(p, din.p, tnum, 0, tnum) == IMPDAR_OK &&
-        impdar_kirch_migrate(p, dout.p, 0, tnum) == IMPDAR_OK &&
-        hipMemcpyAsync(migdata, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-        hipStreamSynchronize(ctx->stream) == hipSuccess) {
-        // done
-    } else {
-        fprintf(stderr, "impdar mig_kirch_loop: %s\n", impdar_last_error());
+    const bool ok = c.din.ensure(bytes) == hipSuccess && c.dout.ensure(bytes) == hipSuccess &&
+                    hipMemcpyAsync(c.din.p, gradD, bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                    hipStreamSynchronize(ctx->stream) == hipSuccess &&          // prep runs on the producer stream
+                    impdar_kirch_prep_precomputed(p, c.din.p, tnum, 0, tnum) == IMPDAR_OK &&
+                    impdar_kirch_migrate(p, c.dout.p, 0, tnum) == IMPDAR_OK &&
+                    impdar_download(ctx, migdata, c.dout.p, bytes, ctx->stream) == IMPDAR_OK;
+    if (!ok) {
+        (void)hipGetLastError();
+        c.drop();
+        return fail(impdar_last_error());
     }
-    impdar_kirch_plan_destroy(p);
+    const char *ce = getenv("IMPDAR_KIRCH_ONESHOT_CACHE");
+    if (ce && ce[0] == '0') c.drop();
 }

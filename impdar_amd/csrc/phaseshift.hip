@@ -55,6 +55,30 @@ __global__ __launch_bounds__(256) void ps_taper_pad_transpose(const T *__restric
     }
 }
 
+// the same, real: X[tnum][nt] for the real-to-complex transform along time of the Hermitian walk
+template <typename T>
+__global__ __launch_bounds__(256) void ps_taper_pad_transpose_real(const T *__restrict__ in, T *__restrict__ X, int snum, int tnum,
+                                                                   int nt, double htaper, double vtaper)
+{
+    __shared__ T tile[64][65];
+    const int k0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int k = k0 + r, j = j0 + tx;
+        T v = 0;
+        if (k < snum && j < tnum) {
+            const double hv = impdar_taper_w(j, tnum, htaper) * impdar_taper_w(k, snum, vtaper);
+            v = (T)((double)in[(size_t)k * tnum + j] * hv);        // data *= H*V, :258
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int j = j0 + r, k = k0 + tx;
+        if (j < tnum && k < nt) X[(size_t)j * nt + k] = tile[tx][r];
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void ps_taper_inplace(T *__restrict__ d, int snum, int tnum, double htaper,
                                                         double vtaper)
@@ -154,7 +178,33 @@ struct PsParams {
     const int *rowmap;      // ... [tnum] wavenumber of workgroup b (rows holding boundary frequencies first), or null
     const double *eps;      // float64 v(z), ps_vz64_kernel: [ceil(snum/16)] sum over the tile's steps of v / v_run - 1
     int snum, tnum, nt, vz_mode;
+    // Frequency slots a workgroup walks.  Full walk: nf = nt, slot i = row i of F.  Hermitian walk (herm = 1, real
+    // radargram): nf = nt/2; slot 0 = the Nyquist row nt/2 (weight 1), slots 1..nt/2-1 = rows 1..nt/2-1 with weight 2
+    // (each stands for itself and for its mirror image (-w, -k)); the zero-frequency row is added by ps_dc_kernel.
+    // P.w is indexed by SLOT (the host uploads it in slot order).
+    int nf, herm;
+    int fstride;            // complex elements between the rows of F (nt; nt/2 + 1 when the time transform is real-to-complex)
 };
+
+// Why half of the frequencies are enough for a real radargram (mig_python.py:268-270, 282, 396-420, 438-487):
+// FK = fft2(real data) is Hermitian, FK[-w,-k] = conj FK[w,k]; the phase w dt sqrt(1 - (v kx / 2w)^2) is odd in w
+// and even in kx, the propagating / evanescent masks are even in both; so the negative-frequency half of
+// TK[tau,k] = sum_w alive FK e^{i Phi} equals conj(TK+[tau,-k]) of the positive half TK+, whose inverse transform
+// over k is the complex conjugate of ifft_k(TK+).  Only ifft_k(TK).real is kept (:282), hence
+//   image = Re ifft_k( 2 TK+  +  TK[w = 0]  +  TK[w = Nyquist] ).
+// The w = 0 row (replaced by 1e-10/dt, :400-402) propagates only where kx = 0, with coss = 1: ps_dc_kernel adds
+// FK[0,k0] e^{i (tau+1) 1e-10} there.  The host takes this walk only when the axes are exactly antisymmetric
+// (kx[-k] = -kx[k], ws[-i] = -ws[i], ws[0] = 0) and the replaced zero frequency is evanescent for every kx != 0.
+template <typename T> __device__ __forceinline__ Cp<T> ps_load_slot(const Cp<T> *__restrict__ Frow, const PsParams &P, int slot)
+{
+    if (!P.herm) return Frow[slot];
+    Cp<T> f = Frow[slot == 0 ? (P.nt >> 1) : slot];
+    if (slot != 0) {
+        f.x *= (T)2;
+        f.y *= (T)2;
+    }
+    return f;
+}
 
 // wave-level reduce-scatter of NV (power of two <= 32) values over the 64 lanes: each
 // halving step sends half of the remaining values to the partner lane; once one value is
@@ -279,7 +329,7 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
     __shared__ double phd_lds[(VZ && sizeof(T) == 4) ? M * BLOCK : 1];
     const int k = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const Cp<T> *F = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k * P.nt;
+    const Cp<T> *F = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k * P.fstride;
     Cp<T> *TK = reinterpret_cast<Cp<T> *>(P.TK) + (size_t)k * P.snum;
     const double kxk = P.kx[k];
 
@@ -313,8 +363,8 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
             gr[FZ ? m : 0] = gi[FZ ? m : 0] = pc[FZ ? m : 0] = ps[FZ ? m : 0] = 0;
         }
         if (F32 && !VZ) f0r[F32 && !VZ ? m : 0] = f0i[F32 && !VZ ? m : 0] = 0;
-        if (iw < P.nt) {
-            const Cp<T> f = F[iw];
+        if (iw < P.nf) {
+            const Cp<T> f = ps_load_slot<T>(F, P, iw);
             const double w = P.w[iw];
             if (!VZ) {
                 const double vk = P.vconst * kxk / 2.0;
@@ -354,7 +404,7 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
     auto incr = [&](int m, double v, double *cs_out) -> double {
         const int iw = tid + m * BLOCK;
         double inc = 0.0, cs = 1.0;
-        if (iw < P.nt) {
+        if (iw < P.nf) {
             const double w = P.w[iw];
             const double a = 0.5 * v * kxk / w;                 // :456
             cs = 1.0 - a * a;
@@ -638,8 +688,11 @@ __device__ __forceinline__ void scalar_load_2f64(const double *p, const double *
 // anchor; the original spectrum FK0 and the fp64 increment live in LDS ([m][thread], each thread reads only
 // what it wrote) -- 128 KB at 8192 frequencies, one workgroup per CU.
 // ---------------------------------------------------------------------------
+#ifndef IMPDAR_PS_VZ32_M8_WAVES
+#define IMPDAR_PS_VZ32_M8_WAVES 1      // min waves per SIMD asked of the 512 x 8 instantiation (4: two workgroups per CU at 128 VGPRs, with spills)
+#endif
 template <int BLOCK, int M>
-__global__ __launch_bounds__(BLOCK) void ps_vz32_kernel(PsParams P)
+__global__ __launch_bounds__(BLOCK, (BLOCK == 512 && M == 8) ? IMPDAR_PS_VZ32_M8_WAVES : 1) void ps_vz32_kernel(PsParams P)
 {
     constexpr int TT = 16;
     constexpr int NW = BLOCK / 64;
@@ -651,7 +704,7 @@ __global__ __launch_bounds__(BLOCK) void ps_vz32_kernel(PsParams P)
     float *corr = reinterpret_cast<float *>(ps_smem + (size_t)M * BLOCK * 16 + 2 * NW * 2 * TT * sizeof(float));   // [2][2 * TT]
     const int k = P.rowmap ? P.rowmap[blockIdx.x] : (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const Cp<float> *F = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.nt;
+    const Cp<float> *F = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.fstride;
     Cp<float> *TK = reinterpret_cast<Cp<float> *>(P.TK) + (size_t)k * P.snum;
     const double kxk = P.kx[k];
     if (tid < 4 * TT) corr[tid] = 0.f;
@@ -663,8 +716,8 @@ __global__ __launch_bounds__(BLOCK) void ps_vz32_kernel(PsParams P)
     for (int m = 0; m < M; ++m) {
         const int iw = tid + m * BLOCK;
         float2 f = make_float2(0.f, 0.f);
-        if (iw < P.nt) {
-            const Cp<float> c = F[iw];
+        if (iw < P.nf) {
+            const Cp<float> c = ps_load_slot<float>(F, P, iw);
             f = make_float2(c.x, c.y);
         }
         f0_lds[m * BLOCK + tid] = f;
@@ -746,7 +799,7 @@ __global__ __launch_bounds__(BLOCK) void ps_vz32_kernel(PsParams P)
                             Phi[m] = ph - 6.283185307179586 * rint(ph * 0.15915494309189535);
                         }
                         double inc = 0.0, cs = 1.0;
-                        if (iw < P.nt) {
+                        if (iw < P.nf) {
                             const double w = P.w[iw];
                             const double a = 0.5 * vd * kxk / w;                 // :456
                             cs = 1.0 - a * a;
@@ -952,7 +1005,7 @@ __global__ __launch_bounds__(BLOCK) void ps_vz64_kernel(PsParams P)
     double *corr = reinterpret_cast<double *>(ps_smem + (size_t)M * BLOCK * 8 + 2 * NW * 2 * TT * sizeof(double));   // [2][2 * TT]
     const int k = P.rowmap ? P.rowmap[blockIdx.x] : (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const Cp<double> *F = reinterpret_cast<const Cp<double> *>(P.F) + (size_t)k * P.nt;
+    const Cp<double> *F = reinterpret_cast<const Cp<double> *>(P.F) + (size_t)k * P.fstride;
     Cp<double> *TK = reinterpret_cast<Cp<double> *>(P.TK) + (size_t)k * P.snum;
     const double kxk = P.kx[k];
     if (tid < 4 * TT) corr[tid] = 0.0;
@@ -964,8 +1017,8 @@ __global__ __launch_bounds__(BLOCK) void ps_vz64_kernel(PsParams P)
         const int iw = tid + m * BLOCK;
         gr[m] = gi[m] = ps[m] = 0.0;
         pc[m] = 1.0;
-        if (iw < P.nt) {
-            const Cp<double> c = F[iw];
+        if (iw < P.nf) {
+            const Cp<double> c = ps_load_slot<double>(F, P, iw);
             gr[m] = c.x;
             gi[m] = c.y;
         }
@@ -1028,7 +1081,7 @@ __global__ __launch_bounds__(BLOCK) void ps_vz64_kernel(PsParams P)
                     for (int m = 0; m < M; ++m) {
                         const int iw = tid_here + m * BLOCK;
                         double c2 = 1.0, sn = 0.0, cf = 0.0;
-                        if (iw < P.nt) {
+                        if (iw < P.nf) {
                             const double w = P.w[iw];
                             const double a = 0.5 * vd * kxk / w;                 // :456
                             const double cs = 1.0 - a * a;
@@ -1173,10 +1226,32 @@ __global__ __launch_bounds__(BLOCK) void ps_vz64_kernel(PsParams P)
     }
 }
 
+// Hermitian walk: the zero-frequency row.  The reference replaces w = 0 by 1e-10/dt (:400-402); that frequency
+// propagates only where kx = 0, and there coss = 1 at every velocity, so both branches turn it by w0 dt per depth
+// step: TK[tau, k0] += FK[0, k0] e^{i (tau + 1) w0 dt} / snum (:415-420, :456-487, :492).  One thread per depth step,
+// after the frequency kernel has stored its sums.
+template <typename T>
+__global__ __launch_bounds__(256) void ps_dc_kernel(const Cp<T> *__restrict__ F, Cp<T> *__restrict__ TK, int k0, int fstride,
+                                                    int snum, double w0dt)
+{
+    const int tau = blockIdx.x * 256 + threadIdx.x;
+    if (tau >= snum) return;
+    const Cp<T> f = F[(size_t)k0 * fstride];
+    double sn, cs;
+    sincos((double)(tau + 1) * w0dt, &sn, &cs);
+    const double re = (double)f.x * cs - (double)f.y * sn, im = (double)f.x * sn + (double)f.y * cs;
+    Cp<T> *dst = TK + (size_t)k0 * snum + tau;
+    dst->x += (T)(re / (double)snum);
+    dst->y += (T)(im / (double)snum);
+}
+
 struct PsPlan {
     int dtype = -1, snum = 0, tnum = 0, nt = 0;
     const impdar_ctx *owner = nullptr;   // plans and buffers live on this context's device and stream
     FftPlan f_time, f_trace, b_trace;
+    FftPlan r_time, r_trace;             // Hermitian walk: real-to-complex along time (nt/2 + 1 rows), then over the traces
+    bool r_ready = false, c_ready = false;
+    DevBuf Xr;                           // ... its real input [tnum][nt]
     DevBuf X, TK, d_kx, d_w, d_vz, d_thr, d_sched, d_rowmap, d_eps;
 };
 static std::mutex g_ps_mu;
@@ -1224,18 +1299,26 @@ static void ps_launch(const PsParams &P, hipStream_t st)
 template <typename T>
 static int ps_dispatch(const PsParams &P, hipStream_t st)
 {
-    const int nt = P.nt;
+    const int nt = P.nf;                // frequency slots per wavenumber (half of the padded samples in a Hermitian walk)
+    // Workgroup shape.  "deep": 16 frequencies per lane and as few waves as that takes (the reduce-scatter and the
+    // tile barrier are a fixed cost per wave and tile, the rotate-accumulate body scales with the frequencies per
+    // lane; smaller workgroups also put two or more on a CU, so one's barrier wait overlaps another's body).
+    // "wide": 512 threads as soon as there are 512 frequencies (round 1-2 shape).  IMPDAR_PS_SHAPE=wide|deep.
+    const char *shape_env = getenv("IMPDAR_PS_SHAPE");
+    // Measured at 8192^2 with the half walk (4096 frequencies per wavenumber; profiles/r03_ps_shapes.txt): float32 constant
+    // v 35.0 (wide) / 41.6 (deep) ms, v(z) 43.4 / 44.9; float64 constant v 63.6 / 56.8, v(z) 72.6 / 70.7.
+    const bool deep = shape_env ? (strcmp(shape_env, "deep") == 0) : (sizeof(T) == 8);
     if (nt <= 64) ps_launch<T, 64, 1>(P, st);
     else if (nt <= 128) ps_launch<T, 128, 1>(P, st);
     else if (nt <= 256) ps_launch<T, 256, 1>(P, st);
     else if (nt <= 512) ps_launch<T, 512, 1>(P, st);
-    else if (nt <= 1024) ps_launch<T, 512, 2>(P, st);
-    else if (nt <= 2048) ps_launch<T, 512, 4>(P, st);
-    else if (nt <= 4096) ps_launch<T, 512, 8>(P, st);
+    else if (nt <= 1024) { if (deep) ps_launch<T, 64, 16>(P, st); else ps_launch<T, 512, 2>(P, st); }
+    else if (nt <= 2048) { if (deep) ps_launch<T, 128, 16>(P, st); else ps_launch<T, 512, 4>(P, st); }
+    else if (nt <= 4096) { if (deep) ps_launch<T, 256, 16>(P, st); else ps_launch<T, 512, 8>(P, st); }
     else if (nt <= 8192) ps_launch<T, 512, 16>(P, st);     // (1024 x 8 for the float32 v(z) runs kernel: 33 spilled VGPRs, 12 % slower)
     else if (nt <= 16384) ps_launch<T, 512, 32>(P, st);
     else {
-        impdar_set_error("phase-shift kernel supports up to 16384 padded samples (got %d)", nt);
+        impdar_set_error("phase-shift kernel supports up to 16384 frequencies per wavenumber (got %d)", nt);
         return IMPDAR_ERR_UNSUPPORTED;
     }
     IMPDAR_HIP_CHECK(hipGetLastError());
@@ -1251,7 +1334,9 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     const bool dbl = sizeof(T) == 8;
     if (pl.owner != ctx || pl.dtype != (dbl ? IMPDAR_F64 : IMPDAR_F32) || pl.snum != snum || pl.tnum != tnum || pl.nt != nt) {
         pl.dtype = -1;
+        pl.r_ready = pl.c_ready = false;
         if (pl.owner != ctx) {               // another device / stream: drop everything bound to the old one
+            pl.Xr.release();
             pl.X.release(); pl.TK.release(); pl.d_kx.release(); pl.d_w.release(); pl.d_vz.release(); pl.d_thr.release();
             pl.d_sched.release();
             pl.d_rowmap.release();
@@ -1260,10 +1345,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         }
         int rc;
         const rocfft_array_type ci = rocfft_array_type_complex_interleaved;
-        if ((rc = pl.f_time.create(rocfft_transform_type_complex_forward, dbl, true, nt, tnum, ci, ci, 1, nt, 1, nt, 1.0, st)))
-            return rc;
-        if ((rc = pl.f_trace.create(rocfft_transform_type_complex_forward, dbl, true, tnum, nt, ci, ci, nt, 1, nt, 1, 1.0, st)))
-            return rc;
+        pl.c_ready = false;              // the forward transforms are made on first use (below): which pair depends on the walk
         if ((rc = pl.b_trace.create(rocfft_transform_type_complex_inverse, dbl, true, tnum, snum, ci, ci, snum, 1, snum, 1,
                                     1.0 / tnum, st)))
             return rc;
@@ -1281,6 +1363,64 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     std::vector<double> w(ws, ws + nt), thr(snum, 0.0);
     for (int i = 0; i < nt; ++i)
         if (w[i] == 0.0) w[i] = 1e-10 / dt;                            // :400-402
+    // Hermitian walk (see ps_load_slot): the radargram is real, so frequencies 1..nt/2-1 also stand for their mirror
+    // images.  Taken only when the axes are exactly antisymmetric and the replaced zero frequency is evanescent
+    // wherever kx != 0 (it always is for a physical geometry: |v kx / 2| >= v pi / (tnum dx) against 1e-10/dt);
+    // anything else -- and IMPDAR_PS_HERMITIAN=0 -- keeps the reference's walk over all nt frequencies.
+    const double w0 = 1e-10 / dt;
+    std::vector<int> k_zero;                // wavenumbers with kx = 0 (the zero-frequency row propagates there)
+    bool herm = nt >= 4 && (nt & (nt - 1)) == 0 && ws[0] == 0.0;
+    {
+        const char *he = getenv("IMPDAR_PS_HERMITIAN");      // read per call: the tests compare the two walks in one process
+        if (he && atoi(he) == 0) herm = false;
+    }
+    if (herm) {
+        for (int i = 1; i < nt / 2 && herm; ++i) herm = std::isfinite(ws[i]) && ws[i] != 0.0 && ws[nt - i] == -ws[i];
+        herm = herm && std::isfinite(ws[nt / 2]) && ws[nt / 2] != 0.0;
+        double vmin = std::fabs(vconst);
+        if (vlen) {
+            vmin = std::fabs(vmig[0]);
+            for (int i = 0; i < snum; ++i) {
+                herm = herm && std::isfinite(vmig[i]);
+                vmin = std::min(vmin, std::fabs(vmig[i]));
+            }
+        }
+        herm = herm && std::isfinite(vmin) && std::isfinite(w0);
+        for (int k = 0; k < tnum && herm; ++k) {
+            // (the wavenumber Nyquist row of an even trace count is its own mirror image: only kx^2 enters)
+            const int km = (tnum - k) % tnum;
+            herm = std::isfinite(kx[k]) && (km == k || kx[km] == -kx[k]);
+            if (kx[k] == 0.0) k_zero.push_back(k);
+            else herm = herm && std::fabs(0.5 * vmin * kx[k]) > 2.0 * w0;     // w0 evanescent with a wide margin
+        }
+        herm = herm && k_zero.size() <= 4;
+    }
+    const int nf = herm ? nt / 2 : nt;
+    const int fstride = herm ? nt / 2 + 1 : nt;
+    if (herm) {
+        w[0] = ws[nt / 2];                  // slot order: Nyquist first, then rows 1..nt/2-1 (already in place)
+    }
+    {
+        int rc;
+        const rocfft_array_type ci = rocfft_array_type_complex_interleaved;
+        if (herm && !pl.r_ready) {
+            IMPDAR_HIP_CHECK(pl.Xr.ensure((size_t)tnum * nt * sizeof(T)));
+            if ((rc = pl.r_time.create(rocfft_transform_type_real_forward, dbl, false, nt, tnum, rocfft_array_type_real,
+                                       rocfft_array_type_hermitian_interleaved, 1, nt, 1, fstride, 1.0, st)))
+                return rc;
+            if ((rc = pl.r_trace.create(rocfft_transform_type_complex_forward, dbl, true, tnum, fstride, ci, ci, fstride, 1,
+                                        fstride, 1, 1.0, st)))
+                return rc;
+            pl.r_ready = true;
+        }
+        if (!herm && !pl.c_ready) {
+            if ((rc = pl.f_time.create(rocfft_transform_type_complex_forward, dbl, true, nt, tnum, ci, ci, 1, nt, 1, nt, 1.0, st)))
+                return rc;
+            if ((rc = pl.f_trace.create(rocfft_transform_type_complex_forward, dbl, true, tnum, nt, ci, ci, nt, 1, nt, 1, 1.0, st)))
+                return rc;
+            pl.c_ready = true;
+        }
+    }
     if (vlen)
         for (int i = 0; i < snum; ++i) {
             const double tau = tt_us[i] / 1.0e6;                         // :441
@@ -1288,7 +1428,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             thr[i] = r * r;
         }
     IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_kx.p, kx, (size_t)tnum * 8, hipMemcpyHostToDevice, st));
-    IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_w.p, w.data(), (size_t)nt * 8, hipMemcpyHostToDevice, st));
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_w.p, w.data(), (size_t)nf * 8, hipMemcpyHostToDevice, st));
     if (vlen) {
         IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_vz.p, vmig, (size_t)snum * 8, hipMemcpyHostToDevice, st));
         IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_thr.p, thr.data(), (size_t)snum * 8, hipMemcpyHostToDevice, st));
@@ -1296,12 +1436,21 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     dim3 tgrid((tnum + 63) / 64, (nt + 63) / 64);
     int rc;
     if ((rc = impdar_ctx_tic(ctx))) return rc;
-    hipLaunchKernelGGL((ps_taper_pad_transpose<T>), tgrid, dim3(256), 0, st, (const T *)d_data, pl.X.as<Cp<T>>(), snum,
-                       tnum, nt, htaper, vtaper);
-    if ((rc = pl.f_time.exec(pl.X.p, nullptr))) return rc;
-    if ((rc = pl.f_trace.exec(pl.X.p, nullptr))) return rc;
+    if (herm) {
+        // real-to-complex along time: only rows 0 .. nt/2 of the spectrum exist, and only they are walked
+        hipLaunchKernelGGL((ps_taper_pad_transpose_real<T>), tgrid, dim3(256), 0, st, (const T *)d_data, pl.Xr.as<T>(), snum,
+                           tnum, nt, htaper, vtaper);
+        if ((rc = pl.r_time.exec(pl.Xr.p, pl.X.p))) return rc;
+        if ((rc = pl.r_trace.exec(pl.X.p, nullptr))) return rc;
+    } else {
+        hipLaunchKernelGGL((ps_taper_pad_transpose<T>), tgrid, dim3(256), 0, st, (const T *)d_data, pl.X.as<Cp<T>>(), snum,
+                           tnum, nt, htaper, vtaper);
+        if ((rc = pl.f_time.exec(pl.X.p, nullptr))) return rc;
+        if ((rc = pl.f_trace.exec(pl.X.p, nullptr))) return rc;
+    }
     PsParams P;
     P.F = pl.X.p;
+    P.fstride = fstride;
     P.TK = pl.TK.p;
     P.kx = pl.d_kx.as<double>();
     P.w = pl.d_w.as<double>();
@@ -1312,6 +1461,8 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     P.snum = snum;
     P.tnum = tnum;
     P.nt = nt;
+    P.nf = nf;
+    P.herm = herm ? 1 : 0;
     P.vz_mode = vlen ? 1 : 0;
     {
         const char *e = getenv("IMPDAR_PS_VTOL");     // diagnostic knob
@@ -1333,7 +1484,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         int ndirty = 0;
         epsum.assign(ntile, 0.0);
         for (int i = 0; i < snum; ++i) {
-            if (std::fabs(vmig[i] - vrun) > P.vtol * std::fabs(vmig[i])) {
+            if (i == 0 || std::fabs(vmig[i] - vrun) > P.vtol * std::fabs(vmig[i])) {     // a run always starts at step 0
                 const int tile = i / 16;
                 const unsigned bit = 1u << (tile & 31);
                 unsigned &word = reinterpret_cast<unsigned &>(sched[snum + tile / 32]);
@@ -1351,7 +1502,9 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         // only).  profiles/tools/ps_dirty.py; IMPDAR_PS_DIRTY_MAX overrides the share.
         const char *dm = getenv("IMPDAR_PS_DIRTY_MAX");
         const double dirty_max = dm ? atof(dm) : (dbl ? 0.9 : 0.5);
-        if ((double)ndirty <= dirty_max * ntile || snum <= 64) {
+        bool vfinite = true;                // a velocity profile with NaN / inf entries takes the per-step kernel
+        for (int i = 0; i < snum; ++i) vfinite = vfinite && std::isfinite(vmig[i]) && vmig[i] != 0.0;
+        if (vfinite && ((double)ndirty <= dirty_max * ntile || snum <= 64)) {
             IMPDAR_HIP_CHECK(pl.d_sched.ensure(sched.size() * sizeof(int)));
             IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_sched.p, sched.data(), sched.size() * sizeof(int), hipMemcpyHostToDevice, st));
             P.sched = pl.d_sched.as<int>();
@@ -1401,6 +1554,10 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         }
     }
     if ((rc = ps_dispatch<T>(P, st))) return rc;
+    if (herm)
+        for (int k0 : k_zero)
+            hipLaunchKernelGGL((ps_dc_kernel<T>), dim3((snum + 255) / 256), dim3(256), 0, st, pl.X.as<Cp<T>>(),
+                               pl.TK.as<Cp<T>>(), k0, fstride, snum, w0 * dt);
     if ((rc = pl.b_trace.exec(pl.TK.p, nullptr))) return rc;
     dim3 bgrid((tnum + 63) / 64, (snum + 63) / 64);
     hipLaunchKernelGGL((ps_real_transpose<T>), bgrid, dim3(256), 0, st, pl.TK.as<Cp<T>>(), (T *)d_out, snum, tnum);

@@ -25,9 +25,15 @@ Layers, bottom up:
   (``impdar_amd._shard_worker``) around shared-memory copies of the
   radargram and collects the output blocks.
 """
+import base64
+import hashlib
+import hmac
+import json
 import os
-import pickle
+import secrets
+import shutil
 import socket
+import stat
 import struct
 import subprocess
 import sys
@@ -165,8 +171,53 @@ def halo_traces(tt_sec, dx, vel):
 # ---------------------------------------------------------------------------------------------------------
 # control plane
 # ---------------------------------------------------------------------------------------------------------
+# Wire format: nothing that executes.  A frame is an 8-byte little-endian length + UTF-8 JSON; bytes and NumPy
+# arrays of plain numeric dtypes travel as tagged base64 (``{"__b": ...}``, ``{"__nd": [dtype, shape, ...]}``),
+# tuples arrive as lists.  A connection is authenticated with the job's secret (HMAC-SHA256 challenge / response
+# of fixed size, compared in constant time) BEFORE any frame is parsed.
+_MAX_FRAME = 1 << 28
+_NONCE, _MAC = 16, 32
+
+
+def _enc(o):
+    if isinstance(o, (bytes, bytearray)):
+        return {'__b': base64.b64encode(bytes(o)).decode('ascii')}
+    if isinstance(o, np.ndarray):
+        if o.dtype.kind not in 'fiubc':
+            raise TypeError('rendezvous messages carry numeric arrays only, got dtype %s' % o.dtype)
+        return {'__nd': [o.dtype.str, list(o.shape), base64.b64encode(np.ascontiguousarray(o).tobytes()).decode('ascii')]}
+    if isinstance(o, (np.integer,)):
+        return int(o)
+    if isinstance(o, (np.floating,)):
+        return float(o)
+    if isinstance(o, (list, tuple)):
+        return [_enc(v) for v in o]
+    if isinstance(o, dict):
+        return {str(k): _enc(v) for k, v in o.items()}
+    if o is None or isinstance(o, (bool, int, float, str)):
+        return o
+    raise TypeError('rendezvous messages carry None / bool / int / float / str / bytes / numeric arrays and lists or '
+                    'dicts of them, got %s' % type(o).__name__)
+
+
+def _dec(o):
+    if isinstance(o, list):
+        return [_dec(v) for v in o]
+    if isinstance(o, dict):
+        if set(o) == {'__b'}:
+            return base64.b64decode(o['__b'])
+        if set(o) == {'__nd'}:
+            dt, shape, blob = o['__nd']
+            dt = np.dtype(str(dt))
+            if dt.kind not in 'fiubc':
+                raise ValueError('refused array dtype %s' % dt)
+            return np.frombuffer(base64.b64decode(blob), dtype=dt).reshape([int(v) for v in shape]).copy()
+        return {k: _dec(v) for k, v in o.items()}
+    return o
+
+
 def _send_msg(sock, obj):
-    blob = pickle.dumps(obj, protocol=4)
+    blob = json.dumps(_enc(obj), allow_nan=True).encode('utf-8')
     sock.sendall(struct.pack('<Q', len(blob)) + blob)
 
 
@@ -182,15 +233,37 @@ def _recv_exact(sock, n):
 
 def _recv_msg(sock):
     (n,) = struct.unpack('<Q', _recv_exact(sock, 8))
-    return pickle.loads(_recv_exact(sock, n))
+    if n > _MAX_FRAME:
+        raise ConnectionError('rendezvous frame of %d bytes refused' % n)
+    return _dec(json.loads(_recv_exact(sock, n).decode('utf-8')))
+
+
+def _mac(secret, *parts):
+    return hmac.new(secret, b'|'.join(parts), hashlib.sha256).digest()
+
+
+def _owned_private_file(path):
+    """Open ``path`` for reading only if it is a regular file of this user with no group / other access."""
+    fd = os.open(path, os.O_RDONLY | getattr(os, 'O_NOFOLLOW', 0))
+    try:
+        st = os.fstat(fd)
+        if not stat.S_ISREG(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise PermissionError('%s is not a private file of uid %d' % (path, os.getuid()))
+        return os.fdopen(fd, 'r')
+    except Exception:
+        os.close(fd)
+        raise
 
 
 class Rendezvous(object):
     """Control plane of one multi-process job on one node: rank 0 listens on an ephemeral TCP port of
-    127.0.0.1 and publishes it in ``/tmp/impdar_rdv_<job>``; the other ranks connect.  ``job`` defaults to
-    ``$MASTER_PORT`` + the launcher's pid (the same for every rank under ``torch.distributed.run`` and under
-    ``bench.py``'s own spawner), so concurrent jobs do not meet.  Collectives are tiny (a unique id, a
-    float, a barrier) and go through rank 0.  Ranks must call the same collectives in the same order."""
+    127.0.0.1 and publishes ``port secret`` in ``<tmp>/impdar_rdv_<job>``, a file it creates exclusively with
+    mode 0600; the other ranks read it only if it is a private file of their own uid, connect, and prove they know
+    the secret (challenge / response, both directions) before a single frame is parsed.  ``$IMPDAR_RDV_SECRET``
+    (set by ``spawn_ranks``) is mixed into the secret when present.  ``job`` defaults to ``$MASTER_PORT`` + the
+    launcher's pid (the same for every rank under ``torch.distributed.run`` and under ``bench.py``'s own spawner),
+    so concurrent jobs do not meet.  Collectives are tiny (a unique id, a float, a barrier) and go through rank 0.
+    Ranks must call the same collectives in the same order."""
 
     def __init__(self, rank=None, world=None, job=None, timeout=120.0):
         self.rank = int(os.environ.get('RANK', '0')) if rank is None else int(rank)
@@ -204,27 +277,36 @@ class Rendezvous(object):
         if job is None:
             job = os.environ.get('IMPDAR_RDV_JOB') or '%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getppid())
         self.path = os.path.join(tempfile.gettempdir(), 'impdar_rdv_%s' % job)
-        token = 'impdar-rdv %s world=%d' % (job, self.world)
+        env_secret = os.environ.get('IMPDAR_RDV_SECRET', '').encode('utf-8')
+        tag = ('impdar-rdv %s world=%d' % (job, self.world)).encode('utf-8')
         if self.rank == 0:
+            file_secret = secrets.token_hex(32)
+            secret = hashlib.sha256(env_secret + b'|' + file_secret.encode('ascii') + b'|' + tag).digest()
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind(('127.0.0.1', 0))
             srv.listen(self.world)
             srv.settimeout(timeout)
-            tmp = self.path + '.%d' % os.getpid()
-            with open(tmp, 'w') as fo:
-                fo.write('%d\n' % srv.getsockname()[1])
-            os.replace(tmp, self.path)
+            self._publish('%d %s\n' % (srv.getsockname()[1], file_secret))
             try:
                 while len(self.peers) < self.world - 1:
                     c, _ = srv.accept()
                     c.settimeout(timeout)
-                    hello = _recv_msg(c)
-                    if hello.get('token') != token or hello.get('rank') in self.peers:
+                    try:
+                        nonce = secrets.token_bytes(_NONCE)
+                        c.sendall(nonce)
+                        reply = _recv_exact(c, 4 + _MAC)                 # fixed size: rank + MAC, nothing parsed yet
+                        (r,) = struct.unpack('<I', reply[:4])
+                        good = hmac.compare_digest(reply[4:], _mac(secret, b'hello', nonce, reply[:4]))
+                        if not good or not 0 < r < self.world or r in self.peers:
+                            c.close()
+                            continue
+                        c.sendall(_mac(secret, b'welcome', nonce, reply[:4]))
+                    except (OSError, ConnectionError, struct.error):
                         c.close()
                         continue
                     c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    self.peers[hello['rank']] = c
+                    self.peers[r] = c
                 for c in self.peers.values():
                     _send_msg(c, 'go')
             finally:
@@ -235,22 +317,47 @@ class Rendezvous(object):
                     pass
         else:
             deadline = time.time() + timeout
+            rank4 = struct.pack('<I', self.rank)
             while True:
+                c = None
                 try:
-                    port = int(open(self.path).read().split()[0])
-                    c = socket.create_connection(('127.0.0.1', port), timeout=5.0)
+                    with _owned_private_file(self.path) as fi:
+                        port_s, file_secret = fi.read().split()[:2]
+                    secret = hashlib.sha256(env_secret + b'|' + file_secret.encode('ascii') + b'|' + tag).digest()
+                    c = socket.create_connection(('127.0.0.1', int(port_s)), timeout=5.0)
                     c.settimeout(timeout)
                     c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    _send_msg(c, dict(token=token, rank=self.rank))
-                    if _recv_msg(c) == 'go':
+                    nonce = _recv_exact(c, _NONCE)
+                    c.sendall(rank4 + _mac(secret, b'hello', nonce, rank4))
+                    if hmac.compare_digest(_recv_exact(c, _MAC), _mac(secret, b'welcome', nonce, rank4)) and \
+                            _recv_msg(c) == 'go':
                         self.sock = c
                         break
                     c.close()
                 except (OSError, ValueError, IndexError, ConnectionError, EOFError):
-                    pass                    # no file yet, a stale file of an earlier job, or a refused token
+                    # no file yet, a stale file of an earlier job, somebody else's file, or a refused handshake
+                    if c is not None:
+                        c.close()
                 if time.time() > deadline:
                     raise TimeoutError('rank %d found no rendezvous at %s within %.0f s' % (self.rank, self.path, timeout))
                 time.sleep(0.05)
+
+    def _publish(self, text):
+        """Create the rendezvous file exclusively, mode 0600.  A leftover of this user's earlier job is replaced;
+        a file somebody else put at the path is an error, never trusted."""
+        for _ in range(2):
+            try:
+                fd = os.open(self.path, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, 'O_NOFOLLOW', 0), 0o600)
+            except FileExistsError:
+                st = os.lstat(self.path)
+                if st.st_uid != os.getuid() or not stat.S_ISREG(st.st_mode):
+                    raise PermissionError('rendezvous path %s exists and is not a file of uid %d' % (self.path, os.getuid()))
+                os.unlink(self.path)
+                continue
+            with os.fdopen(fd, 'w') as fo:
+                fo.write(text)
+            return
+        raise FileExistsError(self.path)
 
     # every collective is a gather to rank 0 followed by a broadcast of the reduced value
     def _collect(self, value, reduce_fn):
@@ -278,6 +385,7 @@ class Rendezvous(object):
         return self._collect(float(x), max)
 
     def allgather(self, obj):
+        """List over ranks of ``obj`` (tuples arrive as lists)."""
         return self._collect(obj, list)
 
     def close(self):
@@ -439,65 +547,81 @@ def ngpus_requested():
 
 
 def spawn_ranks(argv, world, env_extra=None, timeout=None):
-    """Start ``world`` copies of ``argv`` (one per GPU: RANK / LOCAL_RANK / WORLD_SIZE set, a job name for the
-    rendezvous) and wait.  The parent must not have touched the GPU.  Returns the list of return codes."""
+    """Start ``world`` copies of ``argv`` (one per GPU: RANK / LOCAL_RANK / WORLD_SIZE set, a job name and a
+    random secret for the rendezvous) and wait for all of them.  The parent must not have touched the GPU.
+    As soon as one rank exits with an error -- or ``timeout`` seconds have passed -- the others are terminated
+    (a rank that died inside a collective would otherwise leave its peers waiting in RCCL for ever).
+    Returns the list of return codes."""
     job = 'spawn_%d_%d' % (os.getpid(), int(time.time() * 1e3) % 1000000)
+    secret = secrets.token_hex(32)
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), IMPDAR_RDV_JOB=job)
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), IMPDAR_RDV_JOB=job,
+                   IMPDAR_RDV_SECRET=secret)
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         env.update(env_extra or {})
         procs.append(subprocess.Popen(argv, env=env))
-    codes = []
     deadline = None if timeout is None else time.time() + timeout
-    for p in procs:
-        try:
-            codes.append(p.wait(None if deadline is None else max(deadline - time.time(), 0.1)))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            codes.append(p.wait())
+    codes = [None] * world
+    failed = False
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+                failed = failed or (codes[i] is not None and codes[i] != 0)
+        if failed or (deadline is not None and time.time() > deadline):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.terminate()
+            t_kill = time.time() + 5.0
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = p.wait(max(t_kill - time.time(), 0.1))
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[i] = p.wait()
+            break
+        time.sleep(0.02)
     return codes
 
 
-def run_sharded(data, dist_km, travel_time_us, vel=1.69e8, nearfield=False, ngpus=2, mode='auto'):
-    """Migrate a host radargram on ``ngpus`` GPUs from a single process: the radargram and the result live in
-    /dev/shm, one worker process per GPU (``impdar_amd._shard_worker``) runs ``migrate_kirchhoff_sharded`` on its
-    shard.  Returns the float64 migrated array like migrationKirchhoff (mig_python.py:118)."""
+def shard_timeout():
+    """Seconds ``run_sharded`` waits for its workers (``$IMPDAR_SHARD_TIMEOUT``, default half an hour)."""
+    try:
+        return float(os.environ.get('IMPDAR_SHARD_TIMEOUT', '1800'))
+    except ValueError:
+        return 1800.0
+
+
+def run_sharded(data, dist_km, travel_time_us, vel=1.69e8, nearfield=False, ngpus=2, mode='auto', timeout=None):
+    """Migrate a host radargram on ``ngpus`` GPUs from a single process: the radargram and the result live in a
+    private (mode 0700, ``mkdtemp``) directory of /dev/shm, one worker process per GPU
+    (``impdar_amd._shard_worker``) runs ``migrate_kirchhoff_sharded`` on its shard.  A worker that fails (among
+    others: ``ngpus`` larger than the number of visible GPUs) or a job that exceeds ``timeout`` seconds raises here
+    instead of hanging.  Returns the float64 migrated array like migrationKirchhoff (mig_python.py:118)."""
     data = np.ascontiguousarray(data)
     if data.dtype not in (np.float32, np.float64):
         data = data.astype(np.float64)
     snum, tnum = data.shape
+    ngpus = int(ngpus)
+    if ngpus < 1:
+        raise ValueError('ngpus must be at least 1, got %d' % ngpus)
     shm = '/dev/shm' if os.path.isdir('/dev/shm') else tempfile.gettempdir()
-    base = os.path.join(shm, 'impdar_shard_%d_%d' % (os.getpid(), int(time.time() * 1e6) % 10 ** 9))
-    f_in, f_out, f_meta = base + '_in.npy', base + '_out.npy', base + '_meta.pkl'
+    base = tempfile.mkdtemp(prefix='impdar_shard_', dir=shm)
+    f_in, f_out, f_meta = os.path.join(base, 'in.npy'), os.path.join(base, 'out.npy'), os.path.join(base, 'meta.json')
     try:
         np.save(f_in, data)
+        np.save(os.path.join(base, 'dist.npy'), np.asarray(dist_km, dtype=np.float64))
+        np.save(os.path.join(base, 'travel_time.npy'), np.asarray(travel_time_us, dtype=np.float64))
         out = np.lib.format.open_memmap(f_out, mode='w+', dtype=np.float64, shape=(snum, tnum))
         del out
-        with open(f_meta, 'wb') as fo:
-            pickle.dump(dict(snum=snum, tnum=tnum, dist=np.asarray(dist_km, dtype=np.float64),
-                             travel_time=np.asarray(travel_time_us, dtype=np.float64), vel=float(vel),
-                             nearfield=bool(nearfield), mode=mode, f_in=f_in, f_out=f_out), fo)
-        codes = spawn_ranks([sys.executable, '-m', 'impdar_amd._shard_worker', f_meta], ngpus)
+        with open(f_meta, 'w') as fo:
+            json.dump(dict(snum=snum, tnum=tnum, vel=float(vel), nearfield=bool(nearfield), mode=str(mode)), fo)
+        codes = spawn_ranks([sys.executable, '-m', 'impdar_amd._shard_worker', base], ngpus,
+                            timeout=shard_timeout() if timeout is None else timeout)
         if any(codes):
             raise RuntimeError('sharded Kirchhoff migration failed: worker exit codes %s' % codes)
-        return np.array(np.load(f_out, mmap_mode='r'))
+        return np.array(np.load(f_out, mmap_mode='r', allow_pickle=False))
     finally:
-        for f in (f_in, f_out, f_meta):
-            try:
-                os.unlink(f)
-            except OSError:
-                pass
-
-
-def exchange_host(local_image, rank, nranks, per):
-    """All-gather of per-rank (per, snum) image blocks over torch.distributed
-    (any backend; used with gloo on CPU in tests).  Returns (per*nranks, snum)."""
-    import torch
-    import torch.distributed as dist
-    block = np.zeros((per, local_image.shape[1]), dtype=local_image.dtype)
-    block[:local_image.shape[0]] = local_image
-    mine = torch.from_numpy(block)
-    parts = [torch.empty_like(mine) for _ in range(nranks)]
-    dist.all_gather(parts, mine)
-    return np.concatenate([p.numpy() for p in parts], axis=0)
+        shutil.rmtree(base, ignore_errors=True)

@@ -85,6 +85,39 @@ def kirchhoff_pick(t, tt_sec):
     return np.where(up, k1, k0)
 
 
+def kirchhoff_loop(gradD, dist_m, zs, zs2, tt_sec, vel, max_travel_time, data=None, nearfield=False, traces=None):
+    """migrationKirchhoffLoop (mig_python.py:35-60) with the caller's own tables, as the reference's native hook
+    receives them (mig_cython.h:11): ``zs`` / ``zs2`` depth and depth squared per sample, ``max_travel_time`` the
+    limit beyond which a pair is dropped (:52).  O(in-aperture pairs): the argmin of :49 in closed form."""
+    gradD = np.ascontiguousarray(gradD, dtype=np.float64)
+    snum, tnum = gradD.shape
+    tt = np.asarray(tt_sec, dtype=np.float64)
+    dist = np.asarray(dist_m, dtype=np.float64)
+    zs = np.asarray(zs, dtype=np.float64)
+    zs2 = np.asarray(zs2, dtype=np.float64)
+    d64 = None if data is None else np.asarray(data, dtype=np.float64)
+    out = np.zeros((snum, tnum), dtype=np.float64)
+    cols = np.arange(tnum)
+    todo = range(tnum) if traces is None else traces
+    for xi in todo:
+        dx2 = (dist - dist[xi]) ** 2.
+        rs = np.sqrt(dx2[None, :] + zs2[:, None])            # (snum, tnum), :44
+        with np.errstate(invalid='ignore', divide='ignore'):
+            cost = zs[:, None] / rs                          # :46-47
+        t = 2. * rs / vel
+        k = kirchhoff_pick(t, tt)                            # :49
+        g = gradD[k, cols[None, :]]
+        g = np.where(t > max_travel_time, 0., g)             # :51-52
+        acc = np.nansum(g * cost / vel, axis=1)              # :53
+        if nearfield:
+            d = d64[k, cols[None, :]]
+            d = np.where(t > max_travel_time, 0., d)
+            with np.errstate(invalid='ignore', divide='ignore'):
+                acc = acc + np.nansum(d * cost / rs ** 2., axis=1)      # :55-58
+        out[:, xi] = acc / (2. * np.pi)                      # :60
+    return out
+
+
 def kirchhoff(data, travel_time_us, dist_km, vel=1.69e8, nearfield=False,
               traces=None):
     """Diffraction-sum migration, O(in-aperture pairs).
@@ -94,35 +127,13 @@ def kirchhoff(data, travel_time_us, dist_km, vel=1.69e8, nearfield=False,
     output traces computed (others left 0) -- used for bounded CPU timing.
     """
     data = np.asarray(data)
-    snum, tnum = data.shape
     tt = np.asarray(travel_time_us) / 1.0e6
     # :93 -- gradient keeps float32 for float32 input, float64 otherwise
     gradD = np.ascontiguousarray(np.gradient(data, tt, axis=0), dtype=np.float64)
-    d64 = data.astype(np.float64)
-    tmax = np.max(tt)
-    zs = vel * tt / 2.0
-    zs2 = zs ** 2.
-    dist = np.ascontiguousarray(dist_km, dtype=np.float64) * 1.0e3
-    out = np.zeros((snum, tnum), dtype=np.float64)
-    cols = np.arange(tnum)
-    todo = range(tnum) if traces is None else traces
-    for xi in todo:
-        dx2 = (dist - dist[xi]) ** 2.
-        rs = np.sqrt(dx2[None, :] + zs2[:, None])            # (snum, tnum)
-        with np.errstate(invalid='ignore', divide='ignore'):
-            cost = zs[:, None] / rs
-        t = 2. * rs / vel
-        k = kirchhoff_pick(t, tt)
-        g = gradD[k, cols[None, :]]
-        g = np.where(t > tmax, 0., g)
-        acc = np.nansum(g * cost / vel, axis=1)
-        if nearfield:
-            d = d64[k, cols[None, :]]
-            d = np.where(t > tmax, 0., d)
-            with np.errstate(invalid='ignore', divide='ignore'):
-                acc = acc + np.nansum(d * cost / rs ** 2., axis=1)
-        out[:, xi] = acc / (2. * np.pi)
-    return out
+    zs = vel * tt / 2.0                                      # :101
+    zs2 = zs ** 2.                                           # :102
+    dist = np.ascontiguousarray(dist_km, dtype=np.float64) * 1.0e3      # :108
+    return kirchhoff_loop(gradD, dist, zs, zs2, tt, vel, np.max(tt), data.astype(np.float64), nearfield, traces)
 
 
 def kirchhoff_literal(data, travel_time_us, dist_km, vel=1.69e8, nearfield=False):

@@ -82,6 +82,24 @@ def kirch_case(name, snum, tnum, dt, dx, vel, nearfield, kind='ricker', dtype=np
          dt=geo['dt'], vel=vel, nearfield=nearfield, expected=dat.data, ref_seconds=el)
 
 
+def kirch_loop_case(name, snum, tnum, vel, tmax_scale, zs_vel, nearfield, seed):
+    """The reference's inner loop (mig_python.py:35-60) called the way its native hook is (mig_cython.h:11): the
+    caller's own depth tables and time limit -- a limit off max(tt) (the Cython wrapper rounds it to single
+    precision, _mig_cython.pyx:32) and depth tables from another velocity."""
+    geo = synth.geometry(snum, tnum)
+    data = synth.noise_radargram(snum, tnum, seed=seed)
+    tt_sec = geo['travel_time'] / 1.0e6
+    dist = geo['dist'] * 1.0e3
+    gradD = np.gradient(data, tt_sec, axis=0)
+    zs = zs_vel * tt_sec / 2.0
+    zs2 = zs ** 2.
+    tmax = float(np.float32(np.max(tt_sec))) if tmax_scale is None else tmax_scale * float(np.max(tt_sec))
+    mig = np.zeros_like(data)
+    quiet(ref.migrationKirchhoffLoop, data, mig, tnum, snum, dist, zs, zs2, tt_sec, vel, gradD, tmax, nearfield)
+    save(name, data=data, gradD=gradD, dist_m=dist, zs=zs, zs2=zs2, tt_sec=tt_sec, vel=vel, max_travel_time=tmax,
+         nearfield=nearfield, expected=mig)
+
+
 def stolt_case(name, snum, tnum, dt, dx, vel, htaper, vtaper, dtype=np.float64, kind='noise',
                trace_int_zero=False):
     geo = synth.geometry(snum, tnum, dt=dt, dx=dx)
@@ -291,6 +309,9 @@ def main():
     kirch_case('K4n_kirch_pretrigger', 32, 24, 1e-8, 1.0, 1.69e8, True, kind='noise', t0_us=-0.045)
     kirch_case('K6_kirch_float32', 64, 32, 1e-8, 1.0, 1.69e8, False, dtype=np.float32)
     kirch_case('K7_kirch_int16', 64, 32, 1e-8, 1.0, 1.69e8, False, dtype=np.int16)
+    kirch_loop_case('L1_kirch_loop_float_tmax', 40, 28, 1.69e8, None, 1.69e8, False, 3)
+    kirch_loop_case('L1b_kirch_loop_short_tmax', 36, 30, 1.69e8, 0.6, 1.69e8, False, 4)
+    kirch_loop_case('L1c_kirch_loop_own_depths', 32, 26, 1.69e8, 1.0, 1.5e8, True, 5)
     if slow:
         kirch_case('K5_kirch_config1_256x512', 512, 256, 1e-8, 1.0, 1.69e8, False)
     # ---- Stolt -----------------------------------------------------------

@@ -80,25 +80,128 @@ def test_fast_kernel_rejects_what_it_cannot_do(hip):
         migrationlib.migrationKirchhoff(dat, mode='fast')
 
 
-def test_reference_native_hook_mig_kirch_loop(hip):
-    """The symbol the reference's Cython wrapper binds (mig_cython.h:11),
-    driven the way _mig_cython.pyx:50-108 drives it."""
-    g = golden('K1n_kirch_farfield_noise')
-    data = g['data']
+def _hook(hip, data, tt_sec, dist_m, vel, tmax=None, zs=None, zs2=None, nearfield=0, fill=0.0):
+    """Drive mig_kirch_loop the way _mig_cython.pyx:50-108 drives it; returns migdata."""
     snum, tnum = data.shape
-    vel = float(g['vel'])
-    tt_sec = g['travel_time'] / 1.0e6
     gradD = np.ascontiguousarray(np.gradient(np.ascontiguousarray(data, dtype=np.float64), tt_sec, axis=0))
-    mig = np.ascontiguousarray(np.zeros_like(data, dtype=np.float64))
-    zs = np.ascontiguousarray(vel * tt_sec / 2.0)
-    zs2 = np.ascontiguousarray(zs ** 2.)
-    dist = np.ascontiguousarray(g['dist'], dtype=np.float64) * 1.0e3
+    mig = np.full(data.shape, fill, dtype=np.float64)
+    zs = np.ascontiguousarray(vel * tt_sec / 2.0 if zs is None else zs)
+    zs2 = np.ascontiguousarray(zs ** 2. if zs2 is None else zs2)
+    dist = np.ascontiguousarray(dist_m, dtype=np.float64)
     tt = np.ascontiguousarray(tt_sec)
     dp = C.POINTER(C.c_double)
     hip.load().mig_kirch_loop(mig.ctypes.data_as(dp), tnum, snum, dist.ctypes.data_as(dp), zs.ctypes.data_as(dp),
                               zs2.ctypes.data_as(dp), tt.ctypes.data_as(dp), vel, gradD.ctypes.data_as(dp),
-                              float(np.max(tt_sec)), 0)
-    assert rel_max(mig, g['expected']) < EXACT_TOL
+                              float(np.max(tt_sec)) if tmax is None else float(tmax), int(nearfield))
+    return mig
+
+
+def test_reference_native_hook_mig_kirch_loop(hip, monkeypatch):
+    """The symbol the reference's Cython wrapper binds (mig_cython.h:11), driven the way _mig_cython.pyx:50-108 drives
+    it: the reference's own depth tables on a uniform profile take the float64 ring kernel, anything else the
+    per-pair kernel; the two agree; both equal the reference's output."""
+    g = golden('K1n_kirch_farfield_noise')
+    data, vel = g['data'], float(g['vel'])
+    tt_sec = g['travel_time'] / 1.0e6
+    dist_m = np.asarray(g['dist'], dtype=np.float64) * 1.0e3
+    ring = _hook(hip, data, tt_sec, dist_m, vel)
+    assert rel_max(ring, g['expected']) < EXACT_TOL
+    again = _hook(hip, data, tt_sec, dist_m, vel)                    # the cached plan
+    assert np.array_equal(again, ring)
+    monkeypatch.setenv('IMPDAR_KIRCH_EXACT_IMPL', 'pair')
+    pair = _hook(hip, data, tt_sec, dist_m, vel)
+    monkeypatch.delenv('IMPDAR_KIRCH_EXACT_IMPL')
+    assert rel_max(pair, g['expected']) < EXACT_TOL and rel_max(ring, pair) < EXACT_TOL
+    # uneven trace spacing (K3): the per-pair kernel by itself
+    g3 = golden('K3_kirch_nonuniform_dist')
+    out = _hook(hip, g3['data'], g3['travel_time'] / 1.0e6, np.asarray(g3['dist'], dtype=np.float64) * 1.0e3, float(g3['vel']))
+    assert rel_max(out, g3['expected']) < EXACT_TOL
+
+
+def test_native_hook_time_limit_and_depth_tables_are_the_callers(hip):
+    """_mig_cython.pyx:30-32 declares vel and max_travel_time as C floats: the time limit that reaches the hook is
+    max(tt) rounded to single precision, a little below or above the last sample's time -- pairs whose travel time
+    falls in between are kept or dropped by THAT value (mig_python.py:52).  And the depth tables are arguments: a
+    caller with its own zs (here: a different velocity for the depth conversion) must get them honoured.  Both against
+    the literal NumPy loop."""
+    from oracle import mig_oracle
+    snum, tnum, vel = 96, 60, 1.69e8
+    from impdar_amd import synth
+    geo = synth.geometry(snum, tnum)
+    data = synth.noise_radargram(snum, tnum, seed=21)
+    tt_sec = geo['travel_time'] / 1.0e6
+    dist_m = geo['dist'] * 1.0e3
+    grad = np.gradient(data, tt_sec, axis=0)
+    for tmax in (float(np.float32(tt_sec.max())), float(np.nextafter(np.float32(tt_sec.max()), np.float32(0))),
+                 float(np.nextafter(np.float32(tt_sec.max()), np.float32(1))), 0.6 * tt_sec.max()):
+        zs = vel * tt_sec / 2.0
+        want = mig_oracle.kirchhoff_loop(grad, dist_m, zs, zs ** 2., tt_sec, vel, tmax)
+        got = _hook(hip, data, tt_sec, dist_m, vel, tmax=tmax)
+        assert rel_max(got, want) < EXACT_TOL, (tmax, rel_max(got, want))
+    zs = 1.5e8 * tt_sec / 2.0
+    want = mig_oracle.kirchhoff_loop(grad, dist_m, zs, zs ** 2., tt_sec, vel, tt_sec.max())
+    got = _hook(hip, data, tt_sec, dist_m, vel, zs=zs)
+    assert rel_max(got, want) < EXACT_TOL
+    # and the reference's own loop driven this way (fixtures L1*: far field only -- the prototype has no data pointer)
+    for name in ('L1_kirch_loop_float_tmax', 'L1b_kirch_loop_short_tmax'):
+        g = golden(name)
+        mig = np.zeros_like(g['expected'])
+        dp = C.POINTER(C.c_double)
+        arrs = [np.ascontiguousarray(g[k], dtype=np.float64) for k in ('dist_m', 'zs', 'zs2', 'tt_sec', 'gradD')]
+        hip.load().mig_kirch_loop(mig.ctypes.data_as(dp), mig.shape[1], mig.shape[0], arrs[0].ctypes.data_as(dp),
+                                  arrs[1].ctypes.data_as(dp), arrs[2].ctypes.data_as(dp), arrs[3].ctypes.data_as(dp),
+                                  float(g['vel']), arrs[4].ctypes.data_as(dp), float(g['max_travel_time']), 0)
+        assert rel_max(mig, g['expected']) < EXACT_TOL, name
+
+
+def test_native_hook_fails_loudly(hip, capfd):
+    """void return, no error channel: on anything the hook cannot do (the prototype has no data pointer, so no
+    near-field term; a travel-time axis that does not increase) migdata comes back all NaN, never untouched."""
+    g = golden('K1n_kirch_farfield_noise')
+    data, vel = g['data'], float(g['vel'])
+    tt_sec = g['travel_time'] / 1.0e6
+    dist_m = np.asarray(g['dist'], dtype=np.float64) * 1.0e3
+    out = _hook(hip, data, tt_sec, dist_m, vel, nearfield=1)
+    assert np.isnan(out).all()
+    out = _hook(hip, data, tt_sec[::-1].copy(), dist_m, vel)
+    assert np.isnan(out).all()
+    assert 'mig_kirch_loop' in capfd.readouterr().err
+    out = _hook(hip, data, tt_sec, dist_m, vel)                      # and the hook still works afterwards
+    assert rel_max(out, g['expected']) < EXACT_TOL
+
+
+@pytest.mark.parametrize('tnum', [10000])
+def test_native_hook_at_config3_size(hip, tnum):
+    """BASELINE config 3 through the reference's own hook (float64, host arrays in and out): the ring kernel, spot
+    traces against the C oracle, and the second call (cached plan) inside 60 ms host to host... stated, printed, and
+    asserted with a wide margin (150 ms) since host copies vary from box to box."""
+    import time
+    from impdar_amd import synth
+    from oracle import c_oracle
+    snum, vel = 4096, 1.69e8
+    geo = synth.geometry(snum, tnum)
+    data = synth.diffractor_radargram(snum, tnum, vel=vel)
+    tt_sec = geo['travel_time'] / 1.0e6
+    dist_m = geo['dist'] * 1.0e3
+    out = _hook(hip, data, tt_sec, dist_m, vel)
+    cols = np.array([0, 3, 4999, 5000, 9998, 9999])
+    want = c_oracle.kirchhoff(data, geo['travel_time'], geo['dist'], vel, False, traces=cols)
+    assert rel_max(out[:, cols], want) < EXACT_TOL, rel_max(out[:, cols], want)
+    gradD = np.ascontiguousarray(np.gradient(data, tt_sec, axis=0))
+    mig = np.zeros_like(data)
+    zs = np.ascontiguousarray(vel * tt_sec / 2.0)
+    zs2 = np.ascontiguousarray(zs ** 2.)
+    dp = C.POINTER(C.c_double)
+    walls = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        hip.load().mig_kirch_loop(mig.ctypes.data_as(dp), tnum, snum, dist_m.ctypes.data_as(dp), zs.ctypes.data_as(dp),
+                                  zs2.ctypes.data_as(dp), tt_sec.ctypes.data_as(dp), vel, gradD.ctypes.data_as(dp),
+                                  float(tt_sec.max()), 0)
+        walls.append(time.perf_counter() - t0)
+    print('mig_kirch_loop at config 3 (float64, host to host): %s ms' % [round(w * 1e3, 1) for w in walls])
+    assert np.array_equal(mig, out)
+    assert min(walls) < 0.150
 
 
 def test_reference_fixture_all_zeros(hip):
@@ -592,6 +695,33 @@ def test_ties_that_rounding_noise_decides_are_redone_pair_by_pair(hip, monkeypat
             plan = KirchhoffPlan(ctx, dtype, 4096, 10000, g3['dist'], g3['travel_time'], v, False, 'auto')
             assert plan.kernel == kern
             plan.destroy()
+
+
+@pytest.mark.parametrize('start_km', [50.0, 1234.5])
+def test_ties_on_a_profile_that_starts_far_along_the_line(hip, monkeypatch, start_km):
+    """The same rational moveout on a profile whose first trace sits tens of kilometres along the line: the last bits
+    of dist[j] - dist[xi] are now ulp(50 km) / dx ~ 2e-11 instead of 1e-13, so MORE pairs have their pick decided
+    by rounding noise.  The tie scan's margin is derived from the profile (deviation from the fitted grid + the
+    rounding of the largest |dist|), so the table-driven kernels still equal the per-pair arithmetic."""
+    from impdar_amd import _hip, synth
+    from impdar_amd.kirchhoff import migrate_resident
+    from oracle import c_oracle
+    monkeypatch.delenv('IMPDAR_KIRCH_EXACT_IMPL', raising=False)
+    snum, tnum, vel = 252, 297, 1.2e8
+    geo = synth.geometry(snum, tnum, dt=2e-9, dx=0.3, t0_us=-0.02)
+    dist = geo['dist'] + start_km
+    x = synth.noise_radargram(snum, tnum, seed=110)
+    ctx = _hip.context()
+    gg = dict(geo, dist=dist)
+    for near in (False, True):
+        want = c_oracle.kirchhoff(x, geo['travel_time'], dist, vel, near)
+        for impl, kern in ((None, 'kirch_dquad_kernel'), ('tab', 'kirch_exact_tab_kernel'), ('pair', 'kirch_exact_kernel')):
+            got = _exact_with(monkeypatch, impl, x, gg, vel=vel, nearfield=near)
+            assert _exact_with.kernel == kern
+            assert rel_max(got, want) < EXACT_TOL, (near, impl, rel_max(got, want))
+        monkeypatch.delenv('IMPDAR_KIRCH_EXACT_IMPL', raising=False)
+        out, mode, _ = migrate_resident(ctx, x.astype(np.float32), dist, geo['travel_time'], vel, near, 'auto')
+        assert mode == 'fast' and rel_l2(out, want) < FAST_L2 and rel_max(out, want) < FAST_MAX
 
 
 @pytest.mark.parametrize('xb,nh,lk', [('40', '2', '0'), ('40', '3', '0'), ('40', '2', '1'), ('40', '3', '1'), ('32', '2', '0')])

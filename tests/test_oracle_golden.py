@@ -17,6 +17,38 @@ def test_kirchhoff(name):
     assert rel_max(out, g['expected']) < TOL
 
 
+@pytest.mark.parametrize('name', golden_names('K'))
+def test_c_oracle(name):
+    """oracle/kirch_oracle.c referees the full-size GPU tests (config 3 / config 4 spot traces) and bench.py's
+    in-run parity, so it is pinned to the reference's own outputs too: every Kirchhoff fixture (far and near field,
+    uneven spacing, first sample off zero, pre-trigger times, float32 / int16 data, config 1) -- whole image, and
+    a subset of output traces (the form those tests use)."""
+    from oracle import c_oracle
+    g = golden(name)
+    near = bool(g['nearfield'])
+    out = c_oracle.kirchhoff(g['data'], g['travel_time'], g['dist'], float(g['vel']), near)
+    assert out.dtype == np.float64 and out.shape == g['expected'].shape
+    assert rel_max(out, g['expected']) < TOL, rel_max(out, g['expected'])
+    tr = np.unique(np.linspace(0, g['data'].shape[1] - 1, 5).astype(int))
+    sub = c_oracle.kirchhoff(g['data'], g['travel_time'], g['dist'], float(g['vel']), near, traces=tr)
+    assert np.array_equal(sub, out[:, tr])
+    # the gradient-in form the multi-rank CPU tests drive (a rank's exchanged image)
+    tt = np.asarray(g['travel_time']) / 1.0e6
+    grad = np.gradient(g['data'], tt, axis=0)
+    again = c_oracle.kirchhoff_from_gradient(grad, g['data'], g['travel_time'], g['dist'], float(g['vel']), near)
+    assert rel_max(again, g['expected']) < TOL
+
+
+@pytest.mark.parametrize('name', golden_names('L1'))
+def test_kirchhoff_loop_with_the_callers_tables(name):
+    """The reference's inner loop called the way its native hook is (mig_cython.h:11): a time limit off max(tt)
+    (single-precision rounding, a shortened aperture) and depth tables of the caller's own."""
+    g = golden(name)
+    out = o.kirchhoff_loop(g['gradD'], g['dist_m'], g['zs'], g['zs2'], g['tt_sec'], float(g['vel']),
+                           float(g['max_travel_time']), g['data'], bool(g['nearfield']))
+    assert rel_max(out, g['expected']) < TOL
+
+
 @pytest.mark.parametrize('name', ['K4_kirch_t0_offset', 'K4n_kirch_pretrigger'])
 def test_kirchhoff_literal_form(name):
     g = golden(name)

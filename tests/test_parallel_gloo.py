@@ -112,3 +112,101 @@ def test_partition_properties():
     tnum_pad, shards, blocks, pairs = parallel.plan_blocks(np.arange(8) * 1e-8, 1.0, 1.69e8, 3, 4)
     assert tnum_pad == 32 and sum(b[1] - b[0] for b in blocks) == 3
     assert sum(s[1] - s[0] for s in shards) == 3
+
+
+def test_rendezvous_codec_carries_data_only():
+    """Frames are JSON with tagged bytes / numeric arrays: nothing that executes on arrival."""
+    a = np.arange(6, dtype=np.float32).reshape(2, 3)
+    msg = dict(ident=b'\x00\x01\xff' * 40, t=(1, 2.5, None, 'x', True), block=a, n=np.int64(7), f=np.float64(0.5), nan=float('nan'))
+    import json
+    back = parallel._dec(json.loads(json.dumps(parallel._enc(msg))))
+    assert back['ident'] == msg['ident'] and back['t'] == [1, 2.5, None, 'x', True] and back['n'] == 7 and back['f'] == 0.5
+    assert back['block'].dtype == np.float32 and np.array_equal(back['block'], a) and np.isnan(back['nan'])
+    with pytest.raises(TypeError):
+        parallel._enc(object())
+    with pytest.raises(TypeError):
+        parallel._enc(np.array(['a', None], dtype=object))
+    with pytest.raises(ValueError):
+        parallel._dec({'__nd': ['|O', [1], '']})
+
+
+_RDV_CHILD = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from impdar_amd import parallel
+r = parallel.Rendezvous(timeout=float(sys.argv[1]))
+got = r.broadcast(b'unique-id' * 14 if r.rank == 0 else None)
+assert got == b'unique-id' * 14
+assert r.allreduce_max(float(r.rank)) == r.world - 1
+parts = r.allgather((r.rank, np.full(3, r.rank, dtype=np.float64)))
+assert [p[0] for p in parts] == list(range(r.world)) and all((p[1] == p[0]).all() for p in parts)
+r.barrier(); r.close()
+print('RDV_OK', r.rank)
+'''
+
+
+def test_rendezvous_refuses_strangers_and_foreign_files(tmp_path, capfd):
+    """A peer that does not know the job secret is dropped before anything it sent is parsed and the job still
+    forms; a rendezvous file that is not a private (0600) file of this user is never trusted."""
+    import socket
+    import stat
+    import threading
+    import time
+    script = tmp_path / 'child.py'
+    script.write_text(_RDV_CHILD % ROOT)
+    job = 'sec_%d' % os.getpid()
+    path = os.path.join(__import__('tempfile').gettempdir(), 'impdar_rdv_%s' % job)
+    if os.path.exists(path):
+        os.unlink(path)
+    stop = []
+
+    def stranger():
+        # hammer rank 0's port with junk (oversized length prefixes, wrong MACs) while the ranks gather
+        while not stop:
+            try:
+                port = int(open(path).read().split()[0])
+                with socket.create_connection(('127.0.0.1', port), timeout=1.0) as c:
+                    c.recv(16)
+                    c.sendall(b'\xff' * 36 + b'\xff' * 8 + b'cos\nsystem\n(S"true"\ntR.')
+                    time.sleep(0.01)
+            except (OSError, ValueError, IndexError):
+                time.sleep(0.005)
+    th = threading.Thread(target=stranger, daemon=True)
+    th.start()
+    codes = parallel.spawn_ranks([sys.executable, str(script), '60'], 3, env_extra=dict(IMPDAR_RDV_JOB=job), timeout=120)
+    stop.append(1)
+    th.join(5)
+    out = capfd.readouterr()
+    assert codes == [0, 0, 0], out.err[-3000:]
+    assert out.out.count('RDV_OK') == 3
+    assert not os.path.exists(path)
+    # a world-readable file at the path (what a stranger could have planted) is not trusted by rank 1
+    with open(path, 'w') as fo:
+        fo.write('1 deadbeef\n')
+    os.chmod(path, 0o644)
+    try:
+        with pytest.raises(PermissionError):
+            parallel._owned_private_file(path)
+        env = dict(os.environ, RANK='1', LOCAL_RANK='1', WORLD_SIZE='2', IMPDAR_RDV_JOB=job)
+        p = subprocess.run([sys.executable, str(script), '1.0'], env=env, capture_output=True, text=True, timeout=60)
+        assert p.returncode != 0 and 'TimeoutError' in p.stderr
+    finally:
+        os.unlink(path)
+    assert stat.S_IMODE(os.stat(tmp_path).st_mode)  # tmp_path untouched
+
+
+def test_spawn_ranks_stops_the_others_when_one_rank_dies(tmp_path):
+    """A rank that exits with an error must not leave its peers (blocked in a collective on the GPU) and the
+    caller waiting: the survivors are terminated and every return code is reported."""
+    import time
+    script = tmp_path / 'die.py'
+    script.write_text('import os, sys, time\nif os.environ["RANK"] == "1":\n    sys.exit(3)\ntime.sleep(600)\n')
+    t0 = time.time()
+    codes = parallel.spawn_ranks([sys.executable, str(script)], 3, timeout=300)
+    assert time.time() - t0 < 30
+    assert codes[1] == 3 and codes[0] != 0 and codes[2] != 0
+    # and a job that simply takes too long
+    script.write_text('import time\ntime.sleep(600)\n')
+    t0 = time.time()
+    codes = parallel.spawn_ranks([sys.executable, str(script)], 2, timeout=1.0)
+    assert time.time() - t0 < 30 and all(c != 0 for c in codes)

@@ -135,7 +135,13 @@ def test_config5_size_spot_wavenumbers_and_linearity(hip, kind):
         del my, mz
     # oracle on spot wavenumbers (the taper and the 2-D FFT restated with NumPy, float32 data as given)
     tap = mig_oracle._apply_taper(x, 100, 1000, inplace_form=True).astype(np.float32)
-    ks = np.array([0, 1, 37, 1000, 4095])
+    # 200 and 4000: wavenumbers that hold a frequency exactly on the evanescent boundary of the first layer
+    # (0.5 v dt / dx = 0.845 = 169/200: wavenumber 200 q meets frequency 169 q) -- the fp64 boundary walk at full size;
+    # 4096: the wavenumber Nyquist row (its own mirror image)
+    ks = np.array([0, 1, 37, 200, 1000, 4000, 4095, 4096])
+    kxa = mig_oracle._kx(n, geo['trace_int'], geo['dist'])
+    wsa = 2. * np.pi * np.fft.fftfreq(n, d=geo['dt'])
+    assert abs(1. - (0.5 * 1.69e8 * kxa[200] / wsa[169]) ** 2) < 1e-8 and abs(1. - (0.5 * 1.69e8 * kxa[4000] / wsa[3380]) ** 2) < 1e-8
     cols = np.concatenate([ks, (n - ks) % n])
     FKc = np.fft.fft(np.fft.fft(tap.astype(np.float64), axis=1)[:, cols], n=n, axis=0)     # (nt = n, len(cols))
     kx = mig_oracle._kx(n, geo['trace_int'], geo['dist'])[cols]
@@ -147,6 +153,70 @@ def test_config5_size_spot_wavenumbers_and_linearity(hip, kind):
     err = np.linalg.norm(got - want) / np.linalg.norm(want)
     print('config 5 (%s) spot-wavenumber relative L2 error %.3g' % (kind, err))
     assert err < F32_L2, err
+
+
+@pytest.mark.parametrize('snum,tnum', [(300, 64), (257, 65), (1100, 24), (40, 7)])
+@pytest.mark.parametrize('layered', [False, True])
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_hermitian_walk_against_the_full_walk_and_the_oracle(hip, monkeypatch, snum, tnum, layered, dtype):
+    """The radargram is real, so the default walk covers the Nyquist row and frequencies 1 .. nt/2-1 (doubled) and adds
+    the zero-frequency row at kx = 0 (mig_python.py:268-270, 282: FK Hermitian, only ifft(TK).real kept);
+    IMPDAR_PS_HERMITIAN=0 walks all nt two-sided frequencies as the reference does.  Both against the oracle at the
+    stated bars and against each other; even and odd trace counts (with and without a wavenumber Nyquist row), a
+    radargram with a large mean (the zero-frequency row carries it), both workgroup shapes."""
+    from impdar_amd import synth
+    from impdar_amd.lib.RadarData import RadarData
+    from impdar_amd.lib import migrationlib
+    from oracle import mig_oracle
+    geo = synth.geometry(snum, tnum)
+    data = (synth.noise_radargram(snum, tnum, seed=snum + tnum) + 3.0).astype(dtype)
+    if layered:
+        Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+        vel = np.array([[1.68e8, 0.], [1.68e8, 0.3 * Rp], [1.8e8, 0.6 * Rp], [1.9e8, 1.2 * Rp]])
+    else:
+        vel = 1.69e8
+    want = mig_oracle.phase_shift(data.astype(np.float64), geo['dt'], geo['trace_int'], geo['travel_time'],
+                                  geo['dist'], vel, 5, 7)
+    tol, measure = (F64_TOL, rel_max) if dtype == np.float64 else (F32_L2, rel_l2)
+    outs = {}
+    for herm, shape in (('1', 'deep'), ('0', 'deep'), ('1', 'wide'), ('0', 'wide')):
+        monkeypatch.setenv('IMPDAR_PS_HERMITIAN', herm)
+        monkeypatch.setenv('IMPDAR_PS_SHAPE', shape)
+        d = RadarData(None)
+        d.data, d.snum, d.tnum = data.copy(), snum, tnum
+        d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
+        migrationlib.migrationPhaseShift(d, vel=vel, htaper=5, vtaper=7)
+        outs[herm, shape] = d.data
+        assert measure(d.data, want) < tol, (herm, shape, measure(d.data, want))
+    assert measure(outs['1', 'deep'], outs['0', 'deep']) < tol
+
+
+def test_hermitian_walk_is_refused_when_the_axes_are_not_antisymmetric(hip):
+    """The C entry point takes kx and ws from the caller; the half walk needs kx[-k] = -kx[k] and ws[-i] = -ws[i].
+    With a wavenumber axis that is not (a caller's own, shifted axis) the library must fall back to all nt frequencies:
+    checked against the oracle's phase_shift_tk driven with the same axes."""
+    import ctypes as C
+    from impdar_amd import _hip, synth
+    from oracle import mig_oracle
+    lib, ctx = _hip.load(), _hip.context()
+    snum, tnum = 120, 32
+    nt = 128
+    geo = synth.geometry(snum, tnum)
+    data = synth.noise_radargram(snum, tnum, seed=3)
+    kx = mig_oracle._kx(tnum, geo['trace_int'], geo['dist']) + 0.013           # not antisymmetric any more
+    ws = 2. * np.pi * np.fft.fftfreq(nt, d=geo['dt'])
+    out = np.empty((snum, tnum))
+    tt = np.ascontiguousarray(geo['travel_time'], dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    _hip.check(lib.impdar_phaseshift(ctx, data.ctypes.data_as(C.c_void_p), 1, snum, tnum, nt,
+                                     kx.ctypes.data_as(dp), ws.ctypes.data_as(dp), C.c_double(geo['dt']),
+                                     tt.ctypes.data_as(dp), C.c_double(1.69e8), None, 0, C.c_double(5.), C.c_double(7.),
+                                     out.ctypes.data_as(C.c_void_p)), 'impdar_phaseshift')
+    tap = mig_oracle._apply_taper(data, 5, 7, inplace_form=True)
+    FK = np.fft.fft2(tap, (nt, tnum))
+    TK = mig_oracle.phase_shift_tk(FK, 1.69e8, kx, ws, geo['dt'], geo['travel_time'], snum, tnum)
+    want = np.fft.ifft(TK).real
+    assert rel_max(out, want) < F64_TOL, rel_max(out, want)
 
 
 def test_velocity_file_and_errors(hip, tmp_path):
