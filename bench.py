@@ -36,6 +36,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # LDS read port: 256 B/clk/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md, LDS section: "aggregate ~150 TB/s")
 LDS_PEAK_GBS = 256 * 256 * 2.4
 FP32_VECTOR_PEAK_TF = 157.3
+FP16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 PARITY_BAR = 1e-4         # relative L2 of the fast (float32) kernel against the float64 oracle, DESIGN.md section 2
 
 
@@ -141,10 +142,69 @@ def pmc_traffic(args, kernel_substr, timeout_s=150.0):
                           'radargram, same geometry); FETCH_SIZE doubled: all reads are 16 B/lane')
 
 
+def pmc_path_totals(path, calls=3, timeout_s=150.0):
+    """FETCH_SIZE / WRITE_SIZE summed over EVERY kernel of one call of a secondary path (rocFFT's included), one
+    rocprofv3 --pmc pass each, in child runs of this file (--pmc-child-path).  Returns ({counter: KiB per call}, note)."""
+    prof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(prof):
+        return None, 'rocprofv3 not found'
+    if under_profiler():
+        return None, 'bench.py itself runs under a profiler'
+    raw = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='impdar_pmc_', dir='/tmp')
+        cmd = [prof, '--pmc', counter, '--kernel-trace', '-d', d, '-o', 'x', '--output-format', 'csv', '--',
+               sys.executable, os.path.abspath(__file__), '--pmc-child-path', path, '--steps', str(calls)]
+        try:
+            p = subprocess.Popen(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL,
+                                 stderr=subprocess.DEVNULL)
+            try:
+                rc = p.wait(timeout_s)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+                return None, '%s pass timed out' % counter
+            if rc:
+                return None, '%s pass exited with %d' % (counter, rc)
+            total = 0.0
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get('Counter_Name') == counter:
+                        total += float(r['Counter_Value'])
+            raw[counter] = total / calls
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return raw, ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate child runs of this command, summed over every kernel of '
+                 '%d calls (rocFFT\'s included) / %d' % (calls, calls))
+
+
+def pmc_child_path(path, calls):
+    """Child of pmc_path_totals: `calls` resident calls of one secondary path, nothing else on the GPU."""
+    import contextlib
+    import io
+    from impdar_amd import _hip, synth
+    from impdar_amd.lib.RadarData import RadarData
+    _hip.load()
+    rng = np.random.default_rng(0)
+    n = 4096
+    geo = synth.geometry(n, n)
+    x = rng.standard_normal((n, n)).astype(np.float32)
+    for _ in range(calls):
+        d = RadarData(None)
+        d.data, (d.snum, d.tnum) = x, x.shape
+        d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
+        d.to_device()
+        with contextlib.redirect_stdout(io.StringIO()):
+            assert path == 'stolt'
+            d.migrate('stolt', vel=1.68e8, htaper=100, vtaper=1000)
+        d._dev.free()
+        d._dev = None
+
+
 # ---------------------------------------------------------------------------------------------------------
-# secondary paths, driver-timed: BASELINE configs 2 (Stolt) and 5 (Gazdag v(z))
+# secondary paths, driver-timed: BASELINE configs 2 (Stolt) and 5 (Gazdag v(z)), config 3 in float64
 # ---------------------------------------------------------------------------------------------------------
-def path_records(no_cpu):
+def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None):
     import contextlib
     import io
     import ctypes as C
@@ -160,9 +220,9 @@ def path_records(no_cpu):
         d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
         return d
 
-    def device_ms(run, make, reps=3):
+    def device_ms(run, make, reps=3, kernel=False):
         """Resident radargram: device-event duration of the path's kernels (median) and host wall of the call."""
-        ms, wall = [], []
+        ms, wall, kms = [], [], []
         for i in range(reps + 1):                 # the first call pays rocFFT plan creation
             d = make()
             d.to_device()
@@ -173,12 +233,17 @@ def path_records(no_cpu):
             v = C.c_float()
             _hip.check(lib.impdar_ctx_last_ms(ctx, C.byref(v)), 'impdar_ctx_last_ms')
             ms.append(v.value)
+            if kernel:
+                _hip.check(lib.impdar_ctx_last_kernel_ms(ctx, C.byref(v)), 'impdar_ctx_last_kernel_ms')
+                kms.append(v.value)
             if i == reps:
                 d.from_device()
                 fin = bool(np.isfinite(d.data).all())
             else:
                 d._dev.free()
                 d._dev = None
+        if kernel:
+            return float(np.median(ms[1:])), float(np.median(wall[1:])), fin, float(np.median(kms[1:]))
         return float(np.median(ms[1:])), float(np.median(wall[1:])), fin
 
     # ---- config 2: Stolt f-k, 4096 x 4096 float32
@@ -201,6 +266,20 @@ def path_records(no_cpu):
                                "sample": "NumPy closed form (pocketfft + vectorised stretch), the same 4096x4096 "
                                          "float32 radargram, %.2f s; the reference's own loop takes 100.3 s at this "
                                          "size (BASELINE.md)" % el}
+    if not no_pmc:
+        raw, note = pmc_path_totals('stolt')
+        rec["roofline"]["traffic_source"] = note
+        if raw:
+            # FETCH_SIZE halves wide (16 B/lane) reads on gfx950 and other widths are uncalibrated (MI355X_MICROARCH.md,
+            # HBM): the transposes and the stretch read 4-8 B/lane, rocFFT's kernels mixed widths.  WRITE_SIZE is exact
+            # for streaming stores, and every pass of this pipeline writes as many bytes as it reads, so the write
+            # side calibrates the read side: traffic = 2 x WRITE_SIZE (raw FETCH_SIZE kept beside it).
+            wr, fe = raw['WRITE_SIZE'] * 1024.0, raw['FETCH_SIZE'] * 1024.0
+            rec["roofline"]["traffic"] = 2.0 * wr
+            rec["roofline"]["traffic_x_algorithmic"] = 2.0 * wr / algo
+            rec["roofline"]["fabric"] = {"write_bytes": wr, "fetch_bytes_raw": fe, "fetch_raw_over_write": fe / wr if wr else None,
+                                         "fetch_bytes_if_all_16B_per_lane": 2.0 * fe,
+                                         "note": "per call, all 11 kernels; the 5-pass model moves 335.5 MB each way"}
     out["stolt_config2"] = rec
 
     # ---- config 5: Gazdag phase shift with a 1-D v(z) table, 8192 x 8192 float32
@@ -209,18 +288,28 @@ def path_records(no_cpu):
     x = rng.standard_normal((n, n)).astype(np.float32)
     Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
     tab = np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rp], [1.8e8, 0.5 * Rp], [1.9e8, 1.2 * Rp]])
-    ms, wall, fin = device_ms(lambda d: d.migrate('phsh', vel=tab, htaper=100, vtaper=1000), lambda: dat_of(x, geo), reps=2)
-    steps = float(n) ** 3                                # nt * snum * tnum rotate-accumulate steps
-    tf = steps * 8 / (ms * 1e-3) / 1e12                  # 8 flop per complex multiply-accumulate
+    ms, wall, fin, kms = device_ms(lambda d: d.migrate('phsh', vel=tab, htaper=100, vtaper=1000), lambda: dat_of(x, geo),
+                                   reps=2, kernel=True)
+    steps_ref = float(n) ** 3                            # nt * snum * tnum rotate-accumulates: what the reference executes
+    steps = float(n // 2) * n * n                        # ... and what a real radargram needs: frequencies 1..nt/2-1 stand
+    #                                                      for their mirror images too, + the Nyquist row (Hermitian walk)
+    flop = steps * 8                                     # 8 flop per complex multiply-accumulate
+    tf = flop / (kms * 1e-3) / 1e12
     rec = {"workload": "phase-shift (Gazdag) migration, 1-D v(z) table, 8192x8192 float32 (BASELINE config 5), "
                        "resident in HBM",
-           "device_ms": ms, "call_ms": wall * 1e3, "traces_per_s": n / (ms * 1e-3), "output_finite": fin,
-           "rotate_accumulate_steps": steps,
-           "roofline": {"bound": "valu", "achieved": tf, "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": tf / FP32_VECTOR_PEAK_TF,
-                        "note": "8 flop per complex rotate-accumulate of the fp32 vector units (no MFMA: "
-                                "per-element rotations, no dense contraction); device_ms also holds the two "
-                                "rocFFT passes, the inverse transform and the transposes"}}
+           "device_ms": ms, "kernel_ms": kms, "call_ms": wall * 1e3, "traces_per_s": n / (ms * 1e-3), "output_finite": fin,
+           "rotate_accumulate_steps": steps_ref, "steps_executed": steps,
+           "roofline": {"bound": "mfma", "achieved": tf, "peak": FP16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": tf / FP16_MFMA_PEAK_TF, "algorithmic_flop": flop,
+                        "mfma_flop_executed": 3.0 * flop,
+                        "frac_executed": 3.0 * tf / FP16_MFMA_PEAK_TF,
+                        "x_fp32_vector_peak": tf / FP32_VECTOR_PEAK_TF,
+                        "note": "kernel_ms = the frequency-sum kernels (ps_mfma_kernel + boundary frequencies + zero-frequency "
+                                "row); achieved = 8 flop per needed complex rotate-accumulate (half walk) over kernel_ms, "
+                                "against the dense float16 MFMA peak; the kernel executes three float16 products per "
+                                "float32 product (hi.hi + hi.lo + lo.hi) plus 1/16 of the rotations on the vector "
+                                "units; device_ms also holds the real-to-complex and trace transforms, the inverse "
+                                "transform and the transposes"}}
     if not no_cpu:
         from oracle import mig_oracle
         m = 512
@@ -236,6 +325,54 @@ def path_records(no_cpu):
                                "sample": "NumPy closed form on a 512x512 radargram, %.2f s, scaled x%d "
                                          "(work = snum*nt*tnum) to the full size" % (el, scale)}
     out["gazdag_config5"] = rec
+    del x
+
+    # ---- config 3 in the reference's own arithmetic: float64 data, kirch_dquad_kernel (mig_python.py:53,118 sum in float64)
+    from impdar_amd.kirchhoff import KirchhoffPlan
+    snum, tnum, vel = 4096, 10000, 1.69e8
+    g3 = geo3 if geo3 is not None else synth.geometry(snum, tnum)
+    if full_data is not None and full_data.shape == (snum, tnum):
+        x64 = full_data.astype(np.float64)
+    else:
+        x64 = rng.standard_normal((snum, tnum))
+    plan = KirchhoffPlan(ctx, np.float64, snum, tnum, g3['dist'], g3['travel_time'], vel, False, 'exact')
+    d_in = _hip.DeviceArray.from_host(ctx, x64)
+    d_out = _hip.DeviceArray(ctx, (snum, tnum), np.float64)
+    nstep = 5
+    for _ in range(2):
+        plan.prep(d_in, tnum, 0, tnum)
+        plan.migrate(d_out, 0, tnum)
+    plan.sync()
+    t0 = time.perf_counter()
+    for _ in range(nstep):
+        plan.prep(d_in, tnum, 0, tnum)
+        plan.migrate(d_out, 0, tnum)
+    plan.sync()
+    step_ms = (time.perf_counter() - t0) / nstep * 1e3
+    kms = float(np.mean([plan.history_ms(b)[2] for b in range(nstep)]))
+    pairs = plan.count_pairs(0, tnum)
+    algo = pairs * 8 + snum * tnum * 8
+    ach = algo / (kms * 1e-3) / 1e9
+    rec = {"workload": "Kirchhoff diffraction sum, 10000 traces x 4096 samples, float64 data and arithmetic (what the "
+                       "reference computes in), resident in HBM",
+           "kernel": plan.kernel, "ms_per_step": step_ms, "kernel_ms": kms, "traces_per_s": tnum / (step_ms * 1e-3),
+           "pairs": pairs,
+           "roofline": {"bound": "lds", "achieved": ach, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": ach / LDS_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": algo}}
+    if not no_cpu and full_data is not None and full_data.shape == (snum, tnum):
+        from oracle import c_oracle
+        cols = np.unique(np.linspace(0, tnum - 1, 24).round().astype(np.int32))
+        want = c_oracle.kirchhoff(x64, g3['travel_time'], g3['dist'], vel, False, traces=cols)
+        got = d_out.to_host()[:, cols]
+        rec["parity_max_rel"] = float(np.max(np.abs(got - want)) / np.max(np.abs(want)))
+        rec["parity_cols"] = int(len(cols))
+        rec["parity_bar"] = 1e-12
+        if not rec["parity_max_rel"] <= 1e-12:
+            rec["error"] = "float64 output differs from the C oracle"
+    plan.destroy()
+    d_in.free()
+    d_out.free()
+    out["kirchhoff_f64_config3"] = rec
     return out
 
 
@@ -260,8 +397,12 @@ def main():
     ap.add_argument('--no-e2e', action='store_true', help='skip the PCIe-inclusive one-shot figure')
     ap.add_argument('--cpu-budget', type=float, default=15.0)
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--pmc-child-path', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--data-child', default='zeros', choices=['zeros', 'synthetic'], help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child_path:
+        pmc_child_path(args.pmc_child_path, args.steps)
+        return
 
     # ---- `python bench.py --gpus N` without a launcher: start the N ranks here, BEFORE anything touches the GPU
     # (the ranks are fresh child processes; this parent never loads the HIP library)
@@ -477,7 +618,7 @@ def main():
         if not args.no_paths:
             t0 = time.time()
             try:
-                res["paths"] = path_records(args.no_cpu)
+                res["paths"] = path_records(args.no_cpu, args.no_pmc, full_data, geo)
             except Exception as exc:                      # a sub-record must not take the headline down
                 res["paths"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             log('[bench] config-2 / config-5 sub-records took %.1f s' % (time.time() - t0))

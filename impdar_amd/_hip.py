@@ -41,6 +41,7 @@ SIGNATURES = {
     'impdar_ctx_destroy': (None, [_p]),
     'impdar_ctx_sync': (_i, [_p]),
     'impdar_ctx_last_ms': (_i, [_p, C.POINTER(C.c_float)]),
+    'impdar_ctx_last_kernel_ms': (_i, [_p, C.POINTER(C.c_float)]),
     'impdar_dev_alloc': (_i, [_p, C.c_size_t, C.POINTER(_p)]),
     'impdar_dev_free': (_i, [_p, _p]),
     'impdar_dev_upload': (_i, [_p, _p, _p, C.c_size_t]),

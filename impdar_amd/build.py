@@ -22,7 +22,8 @@ def _newer(a, b):
 def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'impdar_hip.h')]
+    deps = srcs + sorted(os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith('.h')) + \
+        [os.path.join(HERE, '..', 'include', 'impdar_hip.h')]
     objs, jobs = [], []
     for s in srcs:
         o = s[:-4] + '.o'

@@ -70,7 +70,24 @@ int impdar_ctx_tic(impdar_ctx *ctx)
     if (!ctx->ev_tic) IMPDAR_HIP_CHECK(hipEventCreate(&ctx->ev_tic));
     if (!ctx->ev_toc) IMPDAR_HIP_CHECK(hipEventCreate(&ctx->ev_toc));
     ctx->timed = false;
+    ctx->ktimed = false;
     IMPDAR_HIP_CHECK(hipEventRecord(ctx->ev_tic, ctx->stream));
+    return IMPDAR_OK;
+}
+
+int impdar_ctx_ktic(impdar_ctx *ctx)
+{
+    if (!ctx->ev_ktic) IMPDAR_HIP_CHECK(hipEventCreate(&ctx->ev_ktic));
+    if (!ctx->ev_ktoc) IMPDAR_HIP_CHECK(hipEventCreate(&ctx->ev_ktoc));
+    ctx->ktimed = false;
+    IMPDAR_HIP_CHECK(hipEventRecord(ctx->ev_ktic, ctx->stream));
+    return IMPDAR_OK;
+}
+
+int impdar_ctx_ktoc(impdar_ctx *ctx)
+{
+    IMPDAR_HIP_CHECK(hipEventRecord(ctx->ev_ktoc, ctx->stream));
+    ctx->ktimed = true;
     return IMPDAR_OK;
 }
 
@@ -88,6 +105,16 @@ extern "C" int impdar_ctx_last_ms(impdar_ctx *ctx, float *ms)
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
     IMPDAR_HIP_CHECK(hipEventSynchronize(ctx->ev_toc));
     IMPDAR_HIP_CHECK(hipEventElapsedTime(ms, ctx->ev_tic, ctx->ev_toc));
+    return IMPDAR_OK;
+}
+
+extern "C" int impdar_ctx_last_kernel_ms(impdar_ctx *ctx, float *ms)
+{
+    IMPDAR_ARG_CHECK(ctx && ms, "null context/pointer");
+    IMPDAR_ARG_CHECK(ctx->ktimed, "the last timed call on this context bracketed no kernel (only impdar_phaseshift[_dev] does)");
+    IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
+    IMPDAR_HIP_CHECK(hipEventSynchronize(ctx->ev_ktoc));
+    IMPDAR_HIP_CHECK(hipEventElapsedTime(ms, ctx->ev_ktic, ctx->ev_ktoc));
     return IMPDAR_OK;
 }
 
@@ -248,6 +275,8 @@ extern "C" void impdar_ctx_destroy(impdar_ctx *ctx)
     if (ctx->ev_produced) (void)hipEventDestroy(ctx->ev_produced);
     if (ctx->ev_tic) (void)hipEventDestroy(ctx->ev_tic);
     if (ctx->ev_toc) (void)hipEventDestroy(ctx->ev_toc);
+    if (ctx->ev_ktic) (void)hipEventDestroy(ctx->ev_ktic);
+    if (ctx->ev_ktoc) (void)hipEventDestroy(ctx->ev_ktoc);
     impdar_comm_destroy(ctx);
     (void)hipStreamDestroy(ctx->aux);
     (void)hipStreamDestroy(ctx->stream);

@@ -33,11 +33,17 @@ struct impdar_ctx {
     // device-side duration of the last Stolt / phase-shift call enqueued on `stream` (impdar_ctx_last_ms)
     hipEvent_t ev_tic = nullptr, ev_toc = nullptr;
     bool timed = false;
+    // ... and of its dominant kernel alone (the frequency sum of a phase-shift call: impdar_ctx_last_kernel_ms)
+    hipEvent_t ev_ktic = nullptr, ev_ktoc = nullptr;
+    bool ktimed = false;
 };
 
 // bracket the device work of one call on ctx->stream (read back by impdar_ctx_last_ms)
 int impdar_ctx_tic(impdar_ctx *ctx);
 int impdar_ctx_toc(impdar_ctx *ctx);
+// bracket the dominant kernel(s) inside such a call (read back by impdar_ctx_last_kernel_ms)
+int impdar_ctx_ktic(impdar_ctx *ctx);
+int impdar_ctx_ktoc(impdar_ctx *ctx);
 
 // record "everything enqueued on ctx->stream so far produces data a later call may read" (see impdar_kirch_prep)
 int impdar_ctx_mark_produced(impdar_ctx *ctx);

@@ -1784,6 +1784,7 @@ struct impdar_kirch_plan {
     int nh = 1;                 // quad kernel: output tiles per workgroup sharing one ring (256 nh threads)
     int lk = 0;                 // ... and extra ring groups = blocks of additional staging lookahead (nh >= 2 only)
     bool dquad = false;         // the same ring in float64 (kirch_dquad_kernel): exact mode, float64 data, uniform grids
+    double xnoise = 0;          // position noise of dist[j] - dist[xi] in units of dx (see plan creation)
     bool tie_ambiguous = false; // more rounding-noise ties than the list holds: per-pair kernel only
     int ntie_groups = 0;        // samples with flagged offsets (kirch_tiefix_kernel after every table-driven diffraction sum)
     DevBuf d_tie_ti, d_tie_off, d_tie_n;
@@ -1884,6 +1885,16 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     p->dist_sorted = true;
     for (int j = 1; j < tnum; ++j)
         if (!(dist_m[j] >= dist_m[j - 1])) p->dist_sorted = false;
+    // position noise of a pair's dist[j] - dist[xi] against n * dx, in units of dx, measured on the profile: twice the
+    // largest deviation from the fitted grid plus the rounding of the largest |dist| (never less than 4.5e-16 tnum)
+    {
+        double dev = 0.0, amax = 0.0;
+        for (int j = 0; j < tnum; ++j) {
+            dev = std::max(dev, std::fabs(dist_m[j] - (dist_m[0] + j * dx)));
+            amax = std::max(amax, std::fabs(dist_m[j]));
+        }
+        p->xnoise = std::max(4.5e-16 * (double)tnum, (2.0 * dev + 4.5e-16 * amax) / (dx > 0 ? dx : 1.0));
+    }
     p->dt = dt;
     p->dx = dx;
     p->tt0 = tt_sec[0];
@@ -1991,7 +2002,14 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     // float64 data in exact mode on uniform grids: the same ring in float64 (20 or 16 output traces per lane,
     // step blocks of 4) when its window fits; otherwise (and for IMPDAR_KIRCH_EXACT_IMPL = tab | pair) the
     // global-memory kernels
-    if (mode == IMPDAR_KIRCH_EXACT && dtype == IMPDAR_F64 && p->uniform && snum < 65536 &&
+    // The table-driven float64 kernels weight a pair by its trace OFFSET (n dx); the reference by dist[j] - dist[xi].
+    // On a profile whose positions are noisy against the grid (a first trace tens of kilometres along the line:
+    // ulp(dist) / dx ~ 1e-10; spacing that is uniform only to 1e-9) the weights differ by that much, and the stated
+    // 1e-12 of the float64 path no longer holds (measured 2.5e-12 with the near-field term at xnoise 1e-10): such
+    // profiles keep the per-pair kernel in exact mode.  40000 traces of 1 m from 0 have xnoise 1.8e-11.
+    const bool noisy_x = p->xnoise > 3e-11;
+    if (mode == IMPDAR_KIRCH_EXACT && noisy_x && !getenv("IMPDAR_KIRCH_EXACT_IMPL")) p->xtab_off = true;
+    if (mode == IMPDAR_KIRCH_EXACT && dtype == IMPDAR_F64 && p->uniform && !noisy_x && snum < 65536 &&
         std::fabs(tmax / dt) / sa < 65000.0 && (2.0 * hest + 400.0) / 4.0 * (double)snum * 32.0 < 2147483648.0 &&
         !getenv("IMPDAR_KIRCH_EXACT_IMPL")) {
         const char *ne = getenv("IMPDAR_KIRCH_NHD");        // tuning knob: tiles per workgroup, 1 | 2
@@ -2089,13 +2107,7 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         T.snum = snum;
         T.ntab = hg;
         T.near = 0;
-        // position noise of a pair's dist[j] - dist[xi] in units of dx, from the profile itself
-        double dev = 0.0, amax = 0.0;
-        for (int j = 0; j < tnum; ++j) {
-            dev = std::max(dev, std::fabs(dist_m[j] - (dist_m[0] + j * dx)));
-            amax = std::max(amax, std::fabs(dist_m[j]));
-        }
-        const double xnoise = std::max(4.5e-16 * (double)tnum, (2.0 * dev + 4.5e-16 * amax) / dx);
+        const double xnoise = p->xnoise;     // position noise of a pair's dist[j] - dist[xi] in units of dx, from the profile itself
         hipLaunchKernelGGL(kirch_tiescan_kernel, dim3((snum + 255) / 256, hg), dim3(256), 0, ctx->stream, T, xnoise,
                            d_flag.as<int>(), d_list.as<int2>(), TIE_CAP);
         int count = 0;
@@ -2500,13 +2512,15 @@ static int build_tilemap(impdar_kirch_plan *p, FastParams &P, int tile_w, int al
 
 // Workgroup slots the persistent ring kernels leave EMPTY in a multi-rank plan.  They launch exactly as many
 // workgroups as are resident at once and keep them until the diffraction sum ends; RCCL's send/recv and all-gather
-// are kernels too (a few workgroups of their own, with LDS), so queued on the producer stream behind a full chip they
-// could only start when a persistent workgroup retires -- at the end of the diffraction sum -- and the exchange of
-// radargram s+1 would serialise behind the sum of radargram s instead of hiding under it.  With R slots free
-// (R/2 CUs with one of their two slots open) RCCL's workgroups are placed at once; the diffraction sum loses R/512 of
-// its slots.  IMPDAR_KIRCH_RESERVE=<R> overrides (0: none); measured in profiles/r03_exchange_overlap.txt.
+// are kernels too (ncclDevKernel_Generic: workgroups of their own, with LDS).  Measured on one GPU with a rank of an
+// 8-rank plan emulated and its exchange done as a self send/recv (profiles/r03_exchange_overlap.txt, kernel trace
+// profiles/r03_exchange_trace_*.txt): queued on the producer stream behind a full chip the RCCL kernel is dispatched
+// 0.1 ms into the diffraction sum but ENDS with it (4.5 of 4.7 ms; 1.06 of 1.08 ms) -- the exchange of radargram
+// s+1 serialises behind the sum of radargram s instead of hiding under it.  With 32 of the 512 slots left free it
+// completes in 0.15-0.3 ms while the sum runs (8 and 16 free slots do not change anything); the diffraction sum pays
+// 2.7-2.9 % (4.665 -> 4.800 ms, 1.081 -> 1.110 ms), 5.7 % with 64.  IMPDAR_KIRCH_RESERVE=<R> overrides (0: none).
 #ifndef KQ_DEFAULT_RESERVE
-#define KQ_DEFAULT_RESERVE 16
+#define KQ_DEFAULT_RESERVE 32
 #endif
 static int kirch_reserved_slots(const impdar_kirch_plan *p)
 {

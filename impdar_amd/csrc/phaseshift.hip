@@ -1245,6 +1245,8 @@ __global__ __launch_bounds__(256) void ps_dc_kernel(const Cp<T> *__restrict__ F,
     dst->y += (T)(im / (double)snum);
 }
 
+#include "ps_mfma.h"
+
 struct PsPlan {
     int dtype = -1, snum = 0, tnum = 0, nt = 0;
     const impdar_ctx *owner = nullptr;   // plans and buffers live on this context's device and stream
@@ -1252,6 +1254,7 @@ struct PsPlan {
     FftPlan r_time, r_trace;             // Hermitian walk: real-to-complex along time (nt/2 + 1 rows), then over the traces
     bool r_ready = false, c_ready = false;
     DevBuf Xr;                           // ... its real input [tnum][nt]
+    DevBuf d_blocks, d_edge;             // matrix-core path: row-block table; boundary-frequency counts + lists
     DevBuf X, TK, d_kx, d_w, d_vz, d_thr, d_sched, d_rowmap, d_eps;
 };
 static std::mutex g_ps_mu;
@@ -1325,6 +1328,95 @@ static int ps_dispatch(const PsParams &P, hipStream_t st)
     return IMPDAR_OK;
 }
 
+// ---- matrix-core path (ps_mfma.h): eligibility, row-block table, launch ---------------------------------------
+template <int NRB, bool VZ>
+static int ps_mfma_launch(const PsMfmaParams &Q, int tnum, hipStream_t st)
+{
+    auto k = ps_mfma_kernel<NRB, VZ>;
+    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PM_LDS_BYTES));
+    hipLaunchKernelGGL(k, dim3((unsigned)tnum * Q.ngroups), dim3(PM_WAVES * 64), PM_LDS_BYTES, st, Q);
+    IMPDAR_HIP_CHECK(hipGetLastError());
+    return IMPDAR_OK;
+}
+
+// runs: (velocity, first step, length) of every constant-velocity run (one run for a constant velocity).  Returns
+// IMPDAR_OK with *done = true when the frequency sums were produced here; *done = false: not eligible, the vector
+// kernels take the call.
+static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &runs, bool vz, const double *thr, hipStream_t st,
+                       bool *done)
+{
+    *done = false;
+    const char *me = getenv("IMPDAR_PS_MFMA");             // 0: vector kernels only (A/B runs, tests)
+    if (me && atoi(me) == 0) return IMPDAR_OK;
+    const int snum = P.snum, tnum = P.tnum;
+    if (P.nf % PM_CH != 0 || P.nf < 256 || P.nf > 8192 || snum < 256 || runs.empty() || (int)runs.size() > PM_MAX_RUNS) return IMPDAR_OK;
+    if (vz)
+        for (int i = 0; i < snum; ++i)
+            if (!(thr[i] < 1e-10)) return IMPDAR_OK;       // the evanescence test must be the sign of coss off the boundary band
+    // row blocks: 32 tiles of 16 steps of one run; runs of a few steps (a layer boundary smeared over 3-4 steps by
+    // 2 * gradient(z(t))) get none: ps_trans_kernel sums their steps directly
+    std::vector<int2> blocks;
+    int nshort_steps = 0;
+    for (size_t r = 0; r < runs.size(); ++r) {
+        if (vz && runs[r].len <= PM_SHORT) {
+            nshort_steps += runs[r].len;
+            continue;
+        }
+        const int ntile = (runs[r].len + 15) / 16;
+        for (int a0 = 0; a0 < ntile; a0 += 32) blocks.push_back(make_int2((int)r, a0));
+    }
+    const int nb = (int)blocks.size();
+    if (nb == 0 || nshort_steps > 96) return IMPDAR_OK;
+    if ((long long)nb * 512 > (long long)snum * 7 / 4 + 512) return IMPDAR_OK;      // many medium runs: rows mostly padding
+    constexpr int NRB_MAX = 9;
+    const int ngroups = (nb + 2 * NRB_MAX - 1) / (2 * NRB_MAX);
+    const int per_group = (nb + ngroups - 1) / ngroups;
+    const int need = (per_group + 1) / 2;
+    const int nrb = need <= 2 ? 2 : (need <= 4 ? 4 : (need <= 6 ? 6 : NRB_MAX));
+    std::vector<int2> table((size_t)ngroups * 2 * nrb, make_int2(-1, 0));
+    for (int g = 0, at = 0; g < ngroups; ++g) {
+        const int n = std::min(per_group, nb - at), first = (n + 1) / 2;
+        for (int i = 0; i < n; ++i, ++at) {
+            const int half = i < first ? 0 : 1, idx = i < first ? i : i - first;
+            table[((size_t)g * 2 + half) * nrb + idx] = blocks[at];
+        }
+    }
+    PsMfmaParams Q;
+    Q.P = P;
+    Q.nruns = (int)runs.size();
+    for (int r = 0; r < Q.nruns; ++r) Q.runs[r] = runs[r];
+    for (int r = Q.nruns; r < PM_MAX_RUNS; ++r) Q.runs[r] = PsMfmaRun{0.0, 0, 0};
+    Q.ngroups = ngroups;
+    IMPDAR_HIP_CHECK(pl.d_blocks.ensure(table.size() * sizeof(int2)));
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_blocks.p, table.data(), table.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+    Q.blocks = pl.d_blocks.as<int2>();
+    IMPDAR_HIP_CHECK(pl.d_edge.ensure((size_t)tnum * (1 + PM_EMAX) * sizeof(int)));
+    Q.edge_cnt = pl.d_edge.as<int>();
+    Q.edge_list = Q.edge_cnt + tnum;
+    if (vz) IMPDAR_HIP_CHECK(hipMemsetAsync(Q.edge_cnt, 0, (size_t)tnum * sizeof(int), st));
+    int rc;
+    if (vz)
+        rc = nrb == 2 ? ps_mfma_launch<2, true>(Q, tnum, st) : nrb == 4 ? ps_mfma_launch<4, true>(Q, tnum, st)
+           : nrb == 6 ? ps_mfma_launch<6, true>(Q, tnum, st) : ps_mfma_launch<NRB_MAX, true>(Q, tnum, st);
+    else
+        rc = nrb == 2 ? ps_mfma_launch<2, false>(Q, tnum, st) : nrb == 4 ? ps_mfma_launch<4, false>(Q, tnum, st)
+           : nrb == 6 ? ps_mfma_launch<6, false>(Q, tnum, st) : ps_mfma_launch<NRB_MAX, false>(Q, tnum, st);
+    if (rc) return rc;
+    if (vz) {
+        if (nshort_steps > 0) {
+            const size_t lds = (size_t)P.nf * 16 + 4 * 2 * PM_SHORT * sizeof(float);
+            IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_trans_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(ps_trans_kernel, dim3(tnum), dim3(256), lds, st, Q);
+        }
+        hipLaunchKernelGGL(ps_edge_kernel, dim3(tnum), dim3(256), 0, st, Q);
+        IMPDAR_HIP_CHECK(hipGetLastError());
+    }
+    // the host table must outlive its async copy
+    IMPDAR_HIP_CHECK(hipStreamSynchronize(st));
+    *done = true;
+    return IMPDAR_OK;
+}
+
 template <typename T>
 static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int tnum, int nt, const double *kx,
                   const double *ws, double dt, const double *tt_us, double vconst, const double *vmig, int vlen,
@@ -1337,6 +1429,8 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         pl.r_ready = pl.c_ready = false;
         if (pl.owner != ctx) {               // another device / stream: drop everything bound to the old one
             pl.Xr.release();
+            pl.d_blocks.release();
+            pl.d_edge.release();
             pl.X.release(); pl.TK.release(); pl.d_kx.release(); pl.d_w.release(); pl.d_vz.release(); pl.d_thr.release();
             pl.d_sched.release();
             pl.d_rowmap.release();
@@ -1553,11 +1647,30 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             }
         }
     }
-    if ((rc = ps_dispatch<T>(P, st))) return rc;
+    if ((rc = impdar_ctx_ktic(ctx))) return rc;
+    bool mfma_done = false;
+    if constexpr (sizeof(T) == 4) {
+        // float32: the frequency sums on the matrix cores when the depth axis is a few long runs of constant velocity
+        std::vector<PsMfmaRun> mruns;
+        bool ok = true;
+        if (vlen) {
+            for (int i = 0; i < snum && ok; ++i) {
+                ok = std::isfinite(vmig[i]) && vmig[i] != 0.0;
+                if (sched[i]) mruns.push_back(PsMfmaRun{vmig[i], i, 0});
+                if (!mruns.empty()) mruns.back().len += 1;
+                ok = ok && (int)mruns.size() <= PM_MAX_RUNS;
+            }
+        } else {
+            mruns.push_back(PsMfmaRun{vconst, 0, snum});
+        }
+        if (ok && (rc = ps_mfma_run(pl, P, mruns, vlen != 0, thr.data(), st, &mfma_done))) return rc;
+    }
+    if (!mfma_done && (rc = ps_dispatch<T>(P, st))) return rc;
     if (herm)
         for (int k0 : k_zero)
             hipLaunchKernelGGL((ps_dc_kernel<T>), dim3((snum + 255) / 256), dim3(256), 0, st, pl.X.as<Cp<T>>(),
                                pl.TK.as<Cp<T>>(), k0, fstride, snum, w0 * dt);
+    if ((rc = impdar_ctx_ktoc(ctx))) return rc;
     if ((rc = pl.b_trace.exec(pl.TK.p, nullptr))) return rc;
     dim3 bgrid((tnum + 63) / 64, (snum + 63) / 64);
     hipLaunchKernelGGL((ps_real_transpose<T>), bgrid, dim3(256), 0, st, pl.TK.as<Cp<T>>(), (T *)d_out, snum, tnum);

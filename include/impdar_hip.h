@@ -65,6 +65,9 @@ int impdar_ctx_sync(impdar_ctx *ctx);
 /* device-side duration (HIP events on the compute stream, ms) of the kernels of the last impdar_stolt[_dev] /
  * impdar_phaseshift[_dev] call on this context; blocks until they have completed */
 int impdar_ctx_last_ms(impdar_ctx *ctx, float *ms);
+/* ... and of the frequency-sum kernels alone (the rotate-accumulate work of mig_python.py:396-487, without the
+ * transforms and transposes around it) of the last impdar_phaseshift[_dev] call */
+int impdar_ctx_last_kernel_ms(impdar_ctx *ctx, float *ms);
 /* raw device-memory plumbing for resident data (bench, multi-GPU) */
 int impdar_dev_alloc(impdar_ctx *ctx, size_t bytes, void **dptr);
 int impdar_dev_free(impdar_ctx *ctx, void *dptr);

@@ -45,8 +45,30 @@ def main():
     rdv = parallel.Rendezvous(0, 1)
     parallel.init_communicator(ctx, rdv)                           # a 1-rank RCCL communicator
     rng = np.random.default_rng(0)
+    base = {}                      # one-rank step (prep + migrate, pipelined) of the whole radargram, per trace count
+    summary = []
     for case in args.cases:
         tnum, n = CASES[case]
+        if tnum not in base and not args.trace:
+            geo1 = synth.geometry(snum, tnum)
+            p1 = KirchhoffPlan(ctx, np.float32, snum, tnum, geo1['dist'], geo1['travel_time'], vel, False, 'fast', nranks=1)
+            d1 = _hip.DeviceArray.from_host(ctx, rng.standard_normal((snum, tnum)).astype(np.float32))
+            o1 = _hip.DeviceArray(ctx, (snum, tnum), np.float32)
+            for _ in range(3):
+                p1.prep(d1, tnum, 0, tnum)
+                p1.migrate(o1, 0, tnum)
+            p1.sync()
+            t0 = time.perf_counter()
+            K1 = 10 if tnum > 20000 else 20
+            for _ in range(K1):
+                p1.prep(d1, tnum, 0, tnum)
+                p1.migrate(o1, 0, tnum)
+            p1.sync()
+            base[tnum] = (time.perf_counter() - t0) / K1 * 1e3
+            p1.destroy()
+            d1.free()
+            o1.free()
+            print('%d traces on 1 rank: %.3f ms per step' % (tnum, base[tnum]), flush=True)
         geo = synth.geometry(snum, tnum)
         tt = geo['travel_time'] / 1e6
         tnum_pad, shards, blocks, pairs = parallel.plan_blocks(tt, 1.0, vel, tnum, n)
@@ -128,9 +150,20 @@ def main():
             print('   reserve %3d: step without exchange %.3f ms (kernel %.3f) | with exchange %.3f ms (kernel %.3f, '
                   'exchange start->end on its stream %.3f ms) | exposed %.3f ms'
                   % (R, no_ex, k0, with_ex, k1, ex_ms, with_ex - no_ex), flush=True)
+            summary.append((case, n, R, base[tnum], no_ex, with_ex, ex_ms, xgmi_ms))
         plan.destroy()
         d_in.free()
         d_out.free()
+    if summary:
+        print()
+        print('projected strong-scaling efficiency of the busiest rank, T1 / (N x step): kernel side only | with the exchange '
+              'done device-locally | with the exchange taking its xGMI estimate (hidden when it completes under the sum, '
+              'i.e. when its start->end is far below the step; otherwise added to the step)')
+        for case, n, R, t1, no_ex, with_ex, ex_ms, xg in summary:
+            hidden = ex_ms < 0.5 * with_ex
+            proj = max(with_ex, xg) if hidden else with_ex + xg
+            print('   %s reserve %3d: %.3f | %.3f | %.3f  (%s)' % (case, R, t1 / n / no_ex, t1 / n / with_ex, t1 / n / proj,
+                                                                  'exchange runs under the sum' if hidden else 'exchange waits for the sum to end'))
     lib.impdar_ctx_sync(ctx)
 
 

@@ -191,6 +191,67 @@ def test_hermitian_walk_against_the_full_walk_and_the_oracle(hip, monkeypatch, s
     assert measure(outs['1', 'deep'], outs['0', 'deep']) < tol
 
 
+@pytest.mark.parametrize('snum,tnum', [(520, 40), (1000, 33), (2100, 16)])
+@pytest.mark.parametrize('kind', ['const', 'layers', 'uneven_layers', 'boundary'])
+def test_matrix_core_path_against_the_vector_kernels_and_the_oracle(hip, monkeypatch, snum, tnum, kind):
+    """float32 data with a few long runs of constant velocity: the frequency sums run on the matrix cores
+    (ps_mfma_kernel: states x step factors per 16-step tile, float16 hi/lo operands, float32 accumulation) and the
+    boundary frequencies in ps_edge_kernel.  Held to the oracle at the float32 bar, compared with the vector kernels
+    (IMPDAR_PS_MFMA=0), with and without the half walk: sizes whose last tile / row block is ragged, runs that start
+    anywhere, a first layer at 1.68e8 m/s that puts frequencies exactly on the evanescent boundary."""
+    from impdar_amd import synth
+    from impdar_amd.lib.RadarData import RadarData
+    from impdar_amd.lib import migrationlib
+    from oracle import mig_oracle
+    geo = synth.geometry(snum, tnum)
+    data = (synth.noise_radargram(snum, tnum, seed=snum) + 0.5).astype(np.float32)
+    Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+    vel = {'const': 1.69e8,
+           'layers': np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rp], [1.8e8, 0.5 * Rp], [1.9e8, 1.2 * Rp]]),
+           'uneven_layers': np.array([[1.6e8, 0.], [1.6e8, 0.07 * Rp], [1.75e8, 0.61 * Rp], [1.82e8, 0.83 * Rp], [1.9e8, 1.2 * Rp]]),
+           'boundary': np.array([[1.68e8, 0.], [1.68e8, 0.45 * Rp], [1.8e8, 0.7 * Rp], [1.9e8, 1.2 * Rp]])}[kind]
+    want = mig_oracle.phase_shift(data.astype(np.float64), geo['dt'], geo['trace_int'], geo['travel_time'],
+                                  geo['dist'], vel, 20, 30)
+    outs = {}
+    for mfma, herm in (('1', '1'), ('0', '1'), ('1', '0')):
+        monkeypatch.setenv('IMPDAR_PS_MFMA', mfma)
+        monkeypatch.setenv('IMPDAR_PS_HERMITIAN', herm)
+        d = RadarData(None)
+        d.data, d.snum, d.tnum = data.copy(), snum, tnum
+        d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
+        migrationlib.migrationPhaseShift(d, vel=vel, htaper=20, vtaper=30)
+        outs[mfma, herm] = d.data
+        assert rel_l2(d.data, want) < F32_L2, (mfma, herm, rel_l2(d.data, want))
+    print('%s %dx%d: rel L2 vs oracle: matrix cores %.2e, vector kernels %.2e, matrix cores on the full walk %.2e'
+          % (kind, snum, tnum, rel_l2(outs['1', '1'], want), rel_l2(outs['0', '1'], want), rel_l2(outs['1', '0'], want)))
+    assert rel_l2(outs['1', '1'], outs['0', '1']) < F32_L2
+    # the matrix-core result must not be worse than a few times the vector kernels' own float32 error
+    assert rel_l2(outs['1', '1'], want) < max(5.0 * rel_l2(outs['0', '1'], want), 2e-6)
+
+
+def test_matrix_core_path_leaves_many_short_runs_to_the_vector_kernels(hip, monkeypatch):
+    """A table of 40 thin layers (rows of 32 tiles would be mostly padding) and a spectrum too short for the
+    32-frequency chunks keep the vector kernels; the answer is the same either way."""
+    from impdar_amd import synth
+    from impdar_amd.lib.RadarData import RadarData
+    from impdar_amd.lib import migrationlib
+    from oracle import mig_oracle
+    snum, tnum = 700, 24
+    geo = synth.geometry(snum, tnum)
+    data = synth.noise_radargram(snum, tnum, seed=3).astype(np.float32)
+    Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+    vel = np.stack([np.linspace(1.68e8, 1.9e8, 40), np.linspace(0., 1.2 * Rp, 40)], axis=1)
+    want = mig_oracle.phase_shift(data.astype(np.float64), geo['dt'], geo['trace_int'], geo['travel_time'],
+                                  geo['dist'], vel, 20, 30)
+    for mfma in ('1', '0'):
+        monkeypatch.setenv('IMPDAR_PS_MFMA', mfma)
+        d = RadarData(None)
+        d.data, d.snum, d.tnum = data.copy(), snum, tnum
+        d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
+        migrationlib.migrationPhaseShift(d, vel=vel, htaper=20, vtaper=30)
+        assert rel_l2(d.data, want) < F32_L2
+
+
 def test_hermitian_walk_is_refused_when_the_axes_are_not_antisymmetric(hip):
     """The C entry point takes kx and ws from the caller; the half walk needs kx[-k] = -kx[k] and ws[-i] = -ws[i].
     With a wavenumber axis that is not (a caller's own, shifted axis) the library must fall back to all nt frequencies:
