@@ -1349,7 +1349,7 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
     const char *me = getenv("IMPDAR_PS_MFMA");             // 0: vector kernels only (A/B runs, tests)
     if (me && atoi(me) == 0) return IMPDAR_OK;
     const int snum = P.snum, tnum = P.tnum;
-    if (P.nf % PM_CH != 0 || P.nf < 256 || P.nf > 8192 || snum < 256 || runs.empty() || (int)runs.size() > PM_MAX_RUNS) return IMPDAR_OK;
+    if (P.nf % PM_CH != 0 || P.nf < 256 || P.nf > 4096 + 2048 || snum < 256 || runs.empty() || (int)runs.size() > PM_MAX_RUNS) return IMPDAR_OK;
     if (vz)
         for (int i = 0; i < snum; ++i)
             if (!(thr[i] < 1e-10)) return IMPDAR_OK;       // the evanescence test must be the sign of coss off the boundary band
@@ -1404,9 +1404,9 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
     if (rc) return rc;
     if (vz) {
         if (nshort_steps > 0) {
-            const size_t lds = (size_t)P.nf * 16 + 4 * 2 * PM_SHORT * sizeof(float);
+            const size_t lds = (size_t)P.nf * 24 + 8 * 2 * PM_SHORT * sizeof(float);
             IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_trans_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(ps_trans_kernel, dim3(tnum), dim3(256), lds, st, Q);
+            hipLaunchKernelGGL(ps_trans_kernel, dim3(tnum), dim3(512), lds, st, Q);
         }
         hipLaunchKernelGGL(ps_edge_kernel, dim3(tnum), dim3(256), 0, st, Q);
         IMPDAR_HIP_CHECK(hipGetLastError());

@@ -134,14 +134,22 @@ def plan_blocks(tt_sec, dx, vel, tnum, nranks, trace_cost=TRACE_COST_PAIRS, quan
     return tnum_pad, shards, blocks, pairs
 
 
-def plan_exchange(blocks, tnum_pad, nranks, halo, threshold=0.75):
+def plan_exchange(blocks, tnum_pad, nranks, halo, threshold=1.0):
     """Which image rows every rank must receive, and from whom.
 
     Rank r's output block [xlo, xhi) reads input traces [xlo - halo, xhi + halo) (whole 8-trace groups, clipped
-    to the padded profile); rank s owns rows [s*per, (s+1)*per).  Returns a dict with ``mode``: ``'halo'`` when
-    the busiest rank receives at most ``threshold`` of what the all-gather would hand it, else ``'allgather'``;
-    ``need[r]`` = (lo, hi); ``recv[r]`` / ``send[r]`` = lists of (peer, row_lo, row_hi).  Deterministic in its
-    arguments, so every rank derives the same plan without talking."""
+    to the padded profile); rank s owns rows [s*per, (s+1)*per).  Returns a dict with ``mode``: ``'halo'`` (grouped
+    point-to-point transfers of exactly the ranges in ``recv`` / ``send``) when the busiest rank receives at most
+    ``threshold`` of what the all-gather would hand it, else ``'allgather'``; ``need[r]`` = (lo, hi); ``recv[r]`` /
+    ``send[r]`` = lists of (peer, row_lo, row_hi).  Deterministic in its arguments, so every rank derives the same
+    plan without talking.
+
+    The default threshold is 1: point-to-point always.  On a fully connected xGMI node every pair of ranks has a link
+    of its own, so direct transfers of what each rank needs are never slower than a ring, and they are the form whose
+    co-existence with the persistent diffraction-sum kernel was measured (profiles/r03_exchange_overlap.txt: an RCCL
+    send/recv kernel runs underneath the sum once 32 workgroup slots are left free; an all-gather of more than one
+    rank cannot be run on the one-GPU boxes this was built on).  ``exchange='allgather'`` still asks for the
+    collective."""
     per = tnum_pad // nranks
     need, recv, send = [], [[] for _ in range(nranks)], [[] for _ in range(nranks)]
     for r, (xlo, xhi) in enumerate(blocks):

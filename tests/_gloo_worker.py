@@ -91,8 +91,9 @@ def main():
         vel=vel, rdv=rdv, exchange=mode, engine=eng)
     xmode = eng.sk.xplan['mode']
     assert eng.calls == ['prep', 'exchange' if xmode == 'halo' else 'allgather', 'migrate'], eng.calls
-    if xmode == 'halo':
-        # the point of the halo form: strictly less than the whole image arrived
+    if xmode == 'halo' and eng.sk.xplan['rows_received'][rank] < eng.sk.xplan['rows_allgather']:
+        # the point of the halo form: where the aperture does not span the profile, strictly less than the whole image
+        # arrived (point-to-point is the default form also when it does)
         assert (eng.image == POISON).any() or world == 1
     parts = rdv.allgather((xlo, xhi, mine, xmode, eng.sk.xplan['rows_received'][rank]))
     if rank == 0:
