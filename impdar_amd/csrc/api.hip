@@ -125,6 +125,17 @@ void impdar_ps_forget(const impdar_ctx *ctx);      // phaseshift.hip
 void impdar_kirch_forget(const impdar_ctx *ctx);   // kirchhoff.hip
 void impdar_preproc_forget(impdar_ctx *ctx);       // preproc.hip
 
+void impdar_kirch_trim();    // kirchhoff.hip
+void impdar_stolt_trim();    // stolt.hip
+void impdar_ps_trim();       // phaseshift.hip
+
+void impdar_release_caches()
+{
+    impdar_kirch_trim();
+    impdar_stolt_trim();
+    impdar_ps_trim();
+}
+
 void *impdar_ctx_pinned(impdar_ctx *ctx, size_t bytes)
 {
     if (bytes <= ctx->pinned_bytes) return ctx->pinned;

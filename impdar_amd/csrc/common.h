@@ -78,6 +78,19 @@ void impdar_set_error(const char *fmt, ...);
 
 static inline size_t impdar_dtype_size(int dtype) { return dtype == IMPDAR_F64 ? 8 : 4; }
 
+// Drop what the entry points keep between calls -- the one-shot Kirchhoff plan with its images and staging copies
+// (hundreds of MB at config 3), the mig_kirch_loop plan, the Stolt and phase-shift plans with their spectra (GBs at
+// 8192^2) -- except what a call in progress on this thread's stack is using (their mutexes are only tried).  Called by
+// DevBuf::ensure when hipMalloc reports out of memory, before it tries once more: a large call after a large call
+// of another kind must not fail on memory that only a cache is holding.
+void impdar_release_caches();
+// "this thread is inside the entry point that owns cache X": its trim must not even try the (non-recursive) mutex
+struct ImpdarBusy {
+    bool &flag;
+    explicit ImpdarBusy(bool &f) : flag(f) { flag = true; }
+    ~ImpdarBusy() { flag = false; }
+};
+
 // RAII device buffer bound to a context's device.
 struct DevBuf {
     void *p = nullptr;
@@ -92,7 +105,14 @@ struct DevBuf {
         if (n <= bytes) return hipSuccess;
         release();
         hipError_t e = hipMalloc(&p, n);
+        if (e == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            p = nullptr;
+            impdar_release_caches();
+            e = hipMalloc(&p, n);
+        }
         if (e == hipSuccess) bytes = n;
+        else p = nullptr;
         return e;
     }
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }

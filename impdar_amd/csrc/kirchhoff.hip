@@ -3098,6 +3098,7 @@ struct KirchOneShot {
 };
 std::mutex g_k1_mu;
 KirchOneShot *g_k1 = nullptr;
+thread_local bool t_k1_busy = false, t_hook_busy = false;     // this thread is inside impdar_kirchhoff / mig_kirch_loop
 
 std::string kirch_knobs()
 {
@@ -3146,6 +3147,7 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
     };
     const auto t0 = now();
     std::lock_guard<std::mutex> lk(g_k1_mu);
+    ImpdarBusy busy(t_k1_busy);
     if (!g_k1) g_k1 = new KirchOneShot();
     KirchOneShot &c = *g_k1;
     const char *ce = getenv("IMPDAR_KIRCH_ONESHOT_CACHE");
@@ -3250,6 +3252,20 @@ std::mutex g_hook_mu;
 KirchHook g_hook;
 }   // namespace
 
+// impdar_release_caches: out of device memory somewhere -- drop the one-shot and the hook caches unless their entry
+// point is the one running
+void impdar_kirch_trim()
+{
+    if (!t_k1_busy) {
+        std::unique_lock<std::mutex> lk(g_k1_mu, std::try_to_lock);
+        if (lk.owns_lock() && g_k1) g_k1->drop();
+    }
+    if (!t_hook_busy) {
+        std::unique_lock<std::mutex> lk(g_hook_mu, std::try_to_lock);
+        if (lk.owns_lock()) g_hook.drop();
+    }
+}
+
 extern "C" void mig_kirch_loop(double *migdata, int tnum, int snum, double *dist, double *zs, double *zs2,
                                double *tt_sec, double vel, double *gradD, double max_travel_time, int nearfield)
 {
@@ -3265,6 +3281,7 @@ extern "C" void mig_kirch_loop(double *migdata, int tnum, int snum, double *dist
         return fail("the reference prototype carries no data pointer, so the near-field term cannot be formed "
                     "(use impdar_kirchhoff)");
     std::lock_guard<std::mutex> lk(g_hook_mu);
+    ImpdarBusy busy(t_hook_busy);
     KirchHook &c = g_hook;
     if (!c.ctx && impdar_ctx_create(0, &c.ctx) != IMPDAR_OK) {
         c.ctx = nullptr;

@@ -1254,7 +1254,7 @@ struct PsPlan {
     FftPlan r_time, r_trace;             // Hermitian walk: real-to-complex along time (nt/2 + 1 rows), then over the traces
     bool r_ready = false, c_ready = false;
     DevBuf Xr;                           // ... its real input [tnum][nt]
-    DevBuf d_blocks, d_edge;             // matrix-core path: row-block table; boundary-frequency counts + lists
+    DevBuf d_blocks, d_edge, d_runtab;   // matrix-core path: row-block table; boundary-frequency counts + lists; per-run phases
     DevBuf X, TK, d_kx, d_w, d_vz, d_thr, d_sched, d_rowmap, d_eps;
 };
 static std::mutex g_ps_mu;
@@ -1265,6 +1265,18 @@ void impdar_ps_forget(const impdar_ctx *ctx)
 {
     std::lock_guard<std::mutex> lk(g_ps_mu);
     if (g_ps_plan && g_ps_plan->owner == ctx) {
+        delete g_ps_plan;
+        g_ps_plan = nullptr;
+    }
+}
+
+// impdar_release_caches: out of device memory somewhere -- drop the cached plan unless a phase-shift call is using it
+static thread_local bool t_ps_busy = false;
+void impdar_ps_trim()
+{
+    if (t_ps_busy) return;
+    std::unique_lock<std::mutex> lk(g_ps_mu, std::try_to_lock);
+    if (lk.owns_lock() && g_ps_plan) {
         delete g_ps_plan;
         g_ps_plan = nullptr;
     }
@@ -1329,16 +1341,6 @@ static int ps_dispatch(const PsParams &P, hipStream_t st)
 }
 
 // ---- matrix-core path (ps_mfma.h): eligibility, row-block table, launch ---------------------------------------
-template <int NRB, bool VZ>
-static int ps_mfma_launch(const PsMfmaParams &Q, int tnum, hipStream_t st)
-{
-    auto k = ps_mfma_kernel<NRB, VZ>;
-    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PM_LDS_BYTES));
-    hipLaunchKernelGGL(k, dim3((unsigned)tnum * Q.ngroups), dim3(PM_WAVES * 64), PM_LDS_BYTES, st, Q);
-    IMPDAR_HIP_CHECK(hipGetLastError());
-    return IMPDAR_OK;
-}
-
 // runs: (velocity, first step, length) of every constant-velocity run (one run for a constant velocity).  Returns
 // IMPDAR_OK with *done = true when the frequency sums were produced here; *done = false: not eligible, the vector
 // kernels take the call.
@@ -1349,11 +1351,11 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
     const char *me = getenv("IMPDAR_PS_MFMA");             // 0: vector kernels only (A/B runs, tests)
     if (me && atoi(me) == 0) return IMPDAR_OK;
     const int snum = P.snum, tnum = P.tnum;
-    if (P.nf % PM_CH != 0 || P.nf < 256 || P.nf > 4096 + 2048 || snum < 256 || runs.empty() || (int)runs.size() > PM_MAX_RUNS) return IMPDAR_OK;
+    if (P.nf % (PM_CH * PM_NQ) != 0 || P.nf < 256 || P.nf > 4096 + 2048 || snum < 256 || runs.empty() || (int)runs.size() > PM_MAX_RUNS) return IMPDAR_OK;
     if (vz)
         for (int i = 0; i < snum; ++i)
             if (!(thr[i] < 1e-10)) return IMPDAR_OK;       // the evanescence test must be the sign of coss off the boundary band
-    // row blocks: 32 tiles of 16 steps of one run; runs of a few steps (a layer boundary smeared over 3-4 steps by
+    // row blocks: 32 tiles of 64 steps of one run; runs of a few steps (a layer boundary smeared over 3-4 steps by
     // 2 * gradient(z(t))) get none: ps_trans_kernel sums their steps directly
     std::vector<int2> blocks;
     int nshort_steps = 0;
@@ -1362,24 +1364,19 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
             nshort_steps += runs[r].len;
             continue;
         }
-        const int ntile = (runs[r].len + 15) / 16;
+        const int ntile = (runs[r].len + PM_TT - 1) / PM_TT;
         for (int a0 = 0; a0 < ntile; a0 += 32) blocks.push_back(make_int2((int)r, a0));
     }
     const int nb = (int)blocks.size();
-    if (nb == 0 || nshort_steps > 96) return IMPDAR_OK;
-    if ((long long)nb * 512 > (long long)snum * 7 / 4 + 512) return IMPDAR_OK;      // many medium runs: rows mostly padding
-    constexpr int NRB_MAX = 9;
-    const int ngroups = (nb + 2 * NRB_MAX - 1) / (2 * NRB_MAX);
+    if (nb == 0 || nshort_steps > 96 || (int)runs.size() - (vz ? (int)std::count_if(runs.begin(), runs.end(), [](const PsMfmaRun &r) { return r.len <= PM_SHORT; }) : 0) > 8) return IMPDAR_OK;
+    if ((long long)nb * 32 * PM_TT > (long long)snum * 7 / 4 + 32 * PM_TT) return IMPDAR_OK;      // many medium runs: rows mostly padding
+    // groups of up to PM_NRB row blocks (the state tiles a workgroup keeps in LDS), consecutive blocks together
+    const int ngroups = (nb + PM_NRB - 1) / PM_NRB;
     const int per_group = (nb + ngroups - 1) / ngroups;
-    const int need = (per_group + 1) / 2;
-    const int nrb = need <= 2 ? 2 : (need <= 4 ? 4 : (need <= 6 ? 6 : NRB_MAX));
-    std::vector<int2> table((size_t)ngroups * 2 * nrb, make_int2(-1, 0));
+    std::vector<int2> table((size_t)ngroups * PM_NRB, make_int2(-1, 0));
     for (int g = 0, at = 0; g < ngroups; ++g) {
-        const int n = std::min(per_group, nb - at), first = (n + 1) / 2;
-        for (int i = 0; i < n; ++i, ++at) {
-            const int half = i < first ? 0 : 1, idx = i < first ? i : i - first;
-            table[((size_t)g * 2 + half) * nrb + idx] = blocks[at];
-        }
+        const int n = std::min(per_group, nb - at);
+        for (int i = 0; i < n; ++i, ++at) table[(size_t)g * PM_NRB + i] = blocks[at];
     }
     PsMfmaParams Q;
     Q.P = P;
@@ -1394,25 +1391,42 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
     Q.edge_cnt = pl.d_edge.as<int>();
     Q.edge_list = Q.edge_cnt + tnum;
     if (vz) IMPDAR_HIP_CHECK(hipMemsetAsync(Q.edge_cnt, 0, (size_t)tnum * sizeof(int), st));
-    int rc;
-    if (vz)
-        rc = nrb == 2 ? ps_mfma_launch<2, true>(Q, tnum, st) : nrb == 4 ? ps_mfma_launch<4, true>(Q, tnum, st)
-           : nrb == 6 ? ps_mfma_launch<6, true>(Q, tnum, st) : ps_mfma_launch<NRB_MAX, true>(Q, tnum, st);
-    else
-        rc = nrb == 2 ? ps_mfma_launch<2, false>(Q, tnum, st) : nrb == 4 ? ps_mfma_launch<4, false>(Q, tnum, st)
-           : nrb == 6 ? ps_mfma_launch<6, false>(Q, tnum, st) : ps_mfma_launch<NRB_MAX, false>(Q, tnum, st);
-    if (rc) return rc;
-    if (vz) {
-        if (nshort_steps > 0) {
-            const size_t lds = (size_t)P.nf * 24 + 8 * 2 * PM_SHORT * sizeof(float);
-            IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_trans_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(ps_trans_kernel, dim3(tnum), dim3(512), lds, st, Q);
-        }
-        hipLaunchKernelGGL(ps_edge_kernel, dim3(tnum), dim3(256), 0, st, Q);
-        IMPDAR_HIP_CHECK(hipGetLastError());
+    Q.vz = vz ? 1 : 0;
+    Q.nlong = 0;
+    for (int r = 0; r < PM_MAX_RUNS; ++r) Q.long_of[r] = -1;
+    for (int r = 0; r < Q.nruns; ++r)
+        if (!(vz && runs[r].len <= PM_SHORT)) Q.long_of[r] = Q.nlong++;
+    IMPDAR_HIP_CHECK(pl.d_runtab.ensure((size_t)tnum * P.nf * Q.nlong * sizeof(double2)));
+    Q.runtab = pl.d_runtab.as<double2>();
+    {
+        // set-up pass: per-run phases of every (wavenumber, frequency), boundary frequencies, the steps of the short runs
+        const size_t lds = (size_t)P.nf * 24 + 8 * 2 * PM_SHORT * sizeof(float);
+        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_setup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ps_setup_kernel, dim3(tnum), dim3(512), lds, st, Q);
     }
+    Q.stamps = nullptr;
+    DevBuf d_stamps;
+    const bool want_stamps = getenv("IMPDAR_PS_STAMPS") != nullptr;       // diagnostics: phase stamps of one workgroup on stderr
+    if (want_stamps && d_stamps.ensure(16 * PM_WAVES * 6 * sizeof(long long)) == hipSuccess) {
+        IMPDAR_HIP_CHECK(hipMemsetAsync(d_stamps.p, 0, 16 * PM_WAVES * 6 * sizeof(long long), st));
+        Q.stamps = d_stamps.as<long long>();
+    }
+    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PM_LDS_BYTES));
+    hipLaunchKernelGGL(ps_mfma_kernel, dim3((unsigned)tnum * Q.ngroups), dim3(PM_WAVES * 64), PM_LDS_BYTES, st, Q);
+    if (vz) hipLaunchKernelGGL(ps_edge_kernel, dim3(tnum), dim3(256), 0, st, Q);
+    IMPDAR_HIP_CHECK(hipGetLastError());
     // the host table must outlive its async copy
     IMPDAR_HIP_CHECK(hipStreamSynchronize(st));
+    if (Q.stamps) {
+        std::vector<long long> h(16 * PM_WAVES * 6);
+        IMPDAR_HIP_CHECK(hipMemcpy(h.data(), d_stamps.p, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        for (int r = 0; r < 16; ++r)
+            for (int wv = 0; wv < PM_WAVES; ++wv) {
+                const long long *t = &h[(r * PM_WAVES + wv) * 6];
+                fprintf(stderr, "ps_mfma stamps round %2d wave %d: state tile %lld, step factors %lld, barrier %lld, mfma %lld, barrier %lld | round %lld\n",
+                        r, wv, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]);
+            }
+    }
     *done = true;
     return IMPDAR_OK;
 }
@@ -1431,6 +1445,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             pl.Xr.release();
             pl.d_blocks.release();
             pl.d_edge.release();
+            pl.d_runtab.release();
             pl.X.release(); pl.TK.release(); pl.d_kx.release(); pl.d_w.release(); pl.d_vz.release(); pl.d_thr.release();
             pl.d_sched.release();
             pl.d_rowmap.release();
@@ -1697,6 +1712,7 @@ extern "C" int impdar_phaseshift(impdar_ctx *ctx, const void *data, int dtype, i
     IMPDAR_HIP_CHECK(dout.ensure(bytes));
     IMPDAR_HIP_CHECK(hipMemcpyAsync(din.p, data, bytes, hipMemcpyHostToDevice, ctx->stream));
     std::lock_guard<std::mutex> lk(g_ps_mu);
+    ImpdarBusy busy(t_ps_busy);
     if (!g_ps_plan) g_ps_plan = new PsPlan();
     int rc = dtype == IMPDAR_F32 ? ps_run<float>(ctx, *g_ps_plan, din.p, snum, tnum, nt, kx, ws, dt, tt_us, vconst, vmig,
                                                  vmig_len, htaper, vtaper, dout.p)
@@ -1718,6 +1734,7 @@ extern "C" int impdar_phaseshift_dev(impdar_ctx *ctx, const void *d_data, int dt
                      "Interpolated velocity profile is not the length of the number of samples in a trace.");
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
     std::lock_guard<std::mutex> lk(g_ps_mu);
+    ImpdarBusy busy(t_ps_busy);
     if (!g_ps_plan) g_ps_plan = new PsPlan();
     const int rc = dtype == IMPDAR_F32 ? ps_run<float>(ctx, *g_ps_plan, d_data, snum, tnum, nt, kx, ws, dt, tt_us, vconst, vmig,
                                                        vmig_len, htaper, vtaper, d_out)

@@ -1,13 +1,14 @@
 // Phase-shift frequency sum on the matrix cores (float32 data; included by phaseshift.hip).
 //
 // Inside a run of constant velocity every frequency turns by a fixed angle per depth step, so with the steps of the
-// run cut into tiles of 16 (step = start + 16 a + b) the sum the reference accumulates (mig_python.py:418-420, :464, :487)
+// run cut into tiles of 64 (step = start + 64 a + b) the sum the reference accumulates (mig_python.py:418-420, :464, :487)
 // factorises,
-//     TK[start + 16 a + b, k] = sum_w  [ F_w e^{i Phi_w} e^{i 16 a phi_w} ] * [ e^{i (b+1) phi_w} ]  =  sum_w S_w(a) B_w(b),
-// a complex matrix product (tiles x frequencies) . (frequencies x 16 steps) per wavenumber: 1/16 of the rotations
-// remain vector work (the S_w(a), generated by a recurrence over a from an anchor that carries the phase in
-// float64), the contraction over the frequencies -- all of the rotate-accumulate work of ps_kernel / ps_vz32_kernel --
-// goes to v_mfma_f32_32x32x16_f16.  Real form: [C_re C_im] = [S_re S_im] . [[B_re B_im] [-B_im B_re]].
+//     TK[start + 64 a + b, k] = sum_w  [ F_w e^{i Phi_w} e^{i 64 a phi_w} ] * [ e^{i (b+1) phi_w} ]  =  sum_w S_w(a) B_w(b),
+// a complex matrix product (tiles x frequencies) . (frequencies x 64 steps) per wavenumber: 1/64 of the rotations
+// remain vector work for the states S_w(a) (a recurrence over a from an anchor that carries the phase in float64)
+// plus 64 step factors per (frequency, run); the contraction over the frequencies -- all of the rotate-accumulate
+// work of ps_kernel / ps_vz32_kernel -- goes to v_mfma_f32_32x32x16_f16.
+// Real form: [C_re C_im] = [S_re S_im] . [[B_re B_im] [-B_im B_re]].
 //
 // float32 accuracy from float16 operands: every operand is split into two halves (x = hi + lo, 11 + 11 bits) and
 // three products are accumulated in float32, hi.hi + hi.lo + lo.hi (the dropped lo.lo term is 2^-22 of the product).
@@ -16,12 +17,29 @@
 // Phases are float64 on the host side of every anchor (Phi at the start of a run, the increment of the run), and
 // enter float32 as a two-float argument (sincos of the high part, first-order correction by the low part).
 //
-// Work split: one workgroup of 8 waves per (wavenumber, group of row blocks).  A row block is 32 tiles of one run
-// (512 depth steps: the 32 rows of one MFMA accumulator, 16 steps x (re, im) = its 32 columns).  Wave (q, r) takes
-// the frequency chunks c = q mod 4 (32 frequency slots each) and the row blocks of half r of the group: it builds the
-// chunk's step-factor tile B (once per run) and, per row block, the state tile S in its own slice of LDS, then
-// 4 K-steps x 3 MFMAs; nothing is shared between waves until the end, when the four partial sums of a row block are
-// added in a fixed order through LDS (no atomics) and stored, 128 contiguous bytes of TK per half wave.
+// Work split: one workgroup of 8 waves per (wavenumber, group of up to 5 row blocks).  A row block is 32 tiles of one
+// run (2048 depth steps: the 32 rows of an MFMA accumulator).  Wave (q, p) takes the frequency chunks c = q mod 2
+// (32 frequency slots each) and the STEPS 16 p .. 16 p + 15 of every tile (16 steps x (re, im) = the 32 columns of
+// its accumulators), for all row blocks of the group: up to 5 accumulators.  Per round (one chunk per frequency
+// half): wave (q, p) GENERATES the state tile of row block p -- lane (frequency, hh) its rows hh, hh + 2, ..., hh + 30
+// from one float64-phase anchor by S *= e^{i 128 phi} -- into the half's LDS, and its own step-factor tile B;
+// barrier; 5 row blocks x 4 K-steps x 3 MFMAs against the half's state tiles; barrier.  Every state element is
+// generated once per workgroup and used by four waves, every step factor once.  At the end the two frequency halves
+// of every accumulator are added in a fixed order through LDS (no atomics).
+//
+// How it got here (config 5, constant velocity, kernel ms; profiles/r03_ps_mfma_*.txt): 16-step tiles, 8 waves, every
+// wave its own tiles for 8-9 row blocks: 10.8; 16 waves with one row part each, swizzled unpadded tiles, recurrence
+// carried across row blocks: 10.9 -- ablation: 5.1 ms of it generating state rows, 1.0 ms step factors, 1.6 ms MFMA
+// exposed: a row costs ~24 vector-pipe cycles (two float16 pack conversions and two mixed-precision fmas at half
+// rate beside the four rotation ops); 64-step tiles with state tiles shared by the waves of a frequency quarter
+// (16 waves, 16-frequency chunks) generate 1/16 of the rows: 9.35 -- now the per-frequency set-up (two float64
+// divisions, a square root, four phase reductions + sincos) dominated, executed by 16 lanes per frequency; 32-frequency
+// chunks and 8 waves halve that redundancy: 8.7; the float64 set-up moved to its own pass (ps_setup_kernel): 8.55 for
+// constant velocity, 17.1 -> 12.2 for the config-5 table; workgroups of 4 waves (one frequency part, no final
+// reduction), two per CU: 7.8.  In-kernel stamps of that version (IMPDAR_PS_STAMPS, profiles/r03_ps_mfma_stamps.txt): per
+// wave and round ~3000 cycles for the state tile, ~1350 for the step factors, ~2750 for the 48 MFMAs (1536 of pipe
+// time), ~500 at the two barriers; two independent recurrences per lane and operand reads a K-step ahead changed none
+// of them.
 //
 // Runs of up to PM_SHORT steps -- 2 * gradient(z(t)) of a layered table smears every layer boundary over three or
 // four steps, each a "run" of its own -- would waste a whole 512-step row block each: they get none (the frequency
@@ -35,15 +53,18 @@
 typedef _Float16 pm_half8 __attribute__((ext_vector_type(8)));
 typedef float pm_float16 __attribute__((ext_vector_type(16)));
 
+constexpr int PM_TT = 64;                   // depth steps per tile
 constexpr int PM_CH = 32;                   // frequency slots per chunk (lane & 31)
-constexpr int PM_LD = 36;                   // dwords per tile row: 32 + 4 (16 lanes x ds_read_b128 hit 64 distinct banks)
-constexpr int PM_TILE = 32 * PM_LD;         // dwords per tile (hi or lo halves of 32 rows x 32 complex)
-constexpr int PM_WAVES = 8;
+constexpr int PM_ROW = 32;                  // dwords per tile row (32 complex float16 pairs; slots XOR-swizzled, no padding)
+constexpr int PM_TILE = 32 * PM_ROW;        // dwords per tile (hi or lo halves of 32 rows x 32 complex): 4 KB
+constexpr int PM_NQ = 1, PM_NP = 4;         // waves of a workgroup: (one frequency part) x step blocks of 16
+constexpr int PM_NRB = 5;                   // row blocks per group (state tiles per frequency half, accumulators per wave)
+constexpr int PM_WAVES = PM_NQ * PM_NP;
 constexpr int PM_RED_LD = 20;               // dwords per lane in the final reduction image (16 + 4: conflict-free b128)
 constexpr int PM_EMAX = 16;                 // boundary frequencies listed per wavenumber
 constexpr int PM_MAX_RUNS = 32;
 constexpr int PM_SHORT = 8;                 // runs of up to this many steps (the few steps a layer boundary is smeared over) get no row blocks: ps_trans_kernel
-constexpr size_t PM_LDS_BYTES = (size_t)PM_WAVES * 4 * PM_TILE * 4 + 64;
+constexpr size_t PM_LDS_BYTES = ((size_t)PM_NQ * PM_NRB * 2 + (size_t)PM_WAVES * 2) * PM_TILE * 4 + 64;
 
 struct PsMfmaRun {
     double v;               // velocity of the run (v(z)); unused for constant velocity
@@ -54,10 +75,18 @@ struct PsMfmaParams {
     PsParams P;
     PsMfmaRun runs[PM_MAX_RUNS];
     int nruns;
-    const int2 *blocks;     // [ngroups][2][NRB]: (run, first tile inside the run) of every row block; run = -1: none
+    const int2 *blocks;     // [ngroups][PM_NRB]: (run, first tile inside the run) of every row block; run = -1: none
     int ngroups;
     int *edge_cnt;          // [tnum] boundary frequencies found for the wavenumber (v(z))
     int *edge_list;         // [tnum][PM_EMAX] their slots
+    // ps_setup_kernel -> ps_mfma_kernel: per (wavenumber, frequency slot, LONG run) the phase per depth step and the
+    // phase at the start of the run, both float64; the start phase is NaN where the frequency takes no part in the run
+    // (evanescent at or before it, or a boundary frequency)
+    double2 *runtab;        // [tnum][nf][nlong]
+    int nlong;
+    int long_of[PM_MAX_RUNS];   // run -> index among the long runs (-1: short)
+    int vz;
+    long long *stamps;      // diagnostics (IMPDAR_PS_STAMPS): [16 rounds][4 waves][6] cycle stamps of one workgroup, or null
 };
 
 // coss = 1 - (0.5 v kx / w)^2 (mig_python.py:456) with the division by w as a multiplication by rw = 1/w: one
@@ -109,18 +138,16 @@ __device__ __forceinline__ unsigned pm_split(float x, float y, float *rx, float 
 }
 __device__ __forceinline__ unsigned pm_pack(float x, float y) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, y)); }
 
-template <int NRB, bool VZ>
 __global__ __launch_bounds__(PM_WAVES * 64, 2) void ps_mfma_kernel(PsMfmaParams Q)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned pm_lds[];
     const PsParams &P = Q.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q = wave & 3, rhalf = wave >> 2;
+    const int q = wave & (PM_NQ - 1), part = wave / PM_NQ;
     const int g = (int)blockIdx.x % Q.ngroups, k = (int)blockIdx.x / Q.ngroups;
     const int om = lane & 31, hh = lane >> 5;
     const Cp<float> *Frow = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.fstride;
     float *TKrow = reinterpret_cast<float *>(reinterpret_cast<Cp<float> *>(P.TK) + (size_t)k * P.snum);
-    const double kxk = P.kx[k];
 
     // ---- scale of the row: the largest component into [2^11, 2^12)
     float sigma;
@@ -144,227 +171,247 @@ __global__ __launch_bounds__(PM_WAVES * 64, 2) void ps_mfma_kernel(PsMfmaParams 
         sigma = (m > 0.f && m < 3.0e38f) ? ldexpf(1.0f, 12 - e) : 1.0f;
     }
 
-    unsigned *Ahi = pm_lds + (size_t)wave * 4 * PM_TILE, *Alo = Ahi + PM_TILE, *Bhi = Alo + PM_TILE, *Blo = Bhi + PM_TILE;
-    // the row blocks of this wave's half
-    int brun[NRB], ba0[NRB];
+    // ---- tiles (4 KB each: 32 rows of 32 dwords = 32 complex float16 pairs, no padding; the eight 16-byte slots of
+    // row r sit at slot ^ ((r >> 1) & 7), so that the 16 lanes a ds_read_b128 serves together (rows r .. r + 15, one
+    // slot) and the 64 lanes of a generating ds_write_b32 (32 frequencies x the two rows 2 j + hh) each touch all 64
+    // banks once).  Per frequency half q: the state tiles of the group's row blocks, shared by its four waves; one
+    // step-factor tile per wave; hi halves, then lo halves.
+    unsigned *Aq = pm_lds + (size_t)q * PM_NRB * 2 * PM_TILE;                          // [rb][hi, lo]
+    unsigned *Bhi = pm_lds + (size_t)PM_NQ * PM_NRB * 2 * PM_TILE + (size_t)wave * 2 * PM_TILE, *Blo = Bhi + PM_TILE;
+    // generation: this lane writes logical dword `om` of rows 2 j + hh; (row >> 1) & 7 = j & 7
+    int wx[8];
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) {
-        const int2 d = Q.blocks[((size_t)g * 2 + rhalf) * NRB + rb];
+    for (int m = 0; m < 8; ++m) wx[m] = 32 * hh + (om ^ (4 * m));
+    // MFMA operands: row / column lane & 31, K-step s, k-half h = lane >> 5: logical slot 2 s + h; K-step s at rd0 ^ 8 s
+    const int rd0 = (lane & 31) * PM_ROW + ((4 * (lane >> 5)) ^ (4 * (((lane & 31) >> 1) & 7)));
+
+    // the group's row blocks: (run, first tile inside the run); block i is GENERATED by the waves of part i (i < 4;
+    // block 4 by part 0 as well)
+    int brun[PM_NRB], ba0[PM_NRB];
+#pragma unroll
+    for (int rb = 0; rb < PM_NRB; ++rb) {
+        const int2 d = Q.blocks[(size_t)g * PM_NRB + rb];
         brun[rb] = __builtin_amdgcn_readfirstlane(d.x);
         ba0[rb] = __builtin_amdgcn_readfirstlane(d.y);
     }
-    pm_float16 acc[NRB];
+    pm_float16 acc[PM_NRB];
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
+    for (int rb = 0; rb < PM_NRB; ++rb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
 
-    // (Starting the second wave of every SIMD 512 or 1024 cycles late -- the two run the same program on the same
-    // amount of work -- changed nothing: 13.6-13.8 ms either way at config 5, profiles/r03_ps_mfma_variants.txt.)
-    const int nchunk = P.nf / PM_CH;
-    // the next chunk's spectrum and frequency are requested a chunk ahead (a load-and-wait at the top of every chunk
-    // parked the wave for a memory round trip per ~10^4 cycles of work)
-    Cp<float> f_next = ps_load_slot<float>(Frow, P, min(q, nchunk - 1) * PM_CH + om);
-    double w_next = P.w[min(q, nchunk - 1) * PM_CH + om];
-    for (int c = q; c < nchunk; c += 4) {
-        const int slot = c * PM_CH + om;
-        float f0r = f_next.x * sigma, f0i = f_next.y * sigma;
-        const double w = w_next;
+    // this lane's step factors: steps b = 16 part + hh + 2 j of every 64-step tile
+    auto gen_B = [&](double inc) {
+        float e2s, e2c, bs, bc;
+        pm_sincos(pm_wrap(2.0 * inc), &e2s, &e2c);
+        pm_sincos(pm_wrap((double)(16 * part + hh + 1) * inc), &bs, &bc);
+        bs *= 256.f;
+        bc *= 256.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            // column b (re) holds (B_re, -B_im) against (S_re, S_im); column 16 + b (im) holds (B_im, B_re)
+            float rc, rs;
+            const unsigned hc = pm_split(bc, bs, &rc, &rs);
+            const unsigned hcos = hc & 0xffffu, hsin = hc >> 16;
+            const int o = 64 * j + wx[j & 7];
+            Bhi[o] = hcos | ((hsin ^ 0x8000u) << 16);                 // (cos, -sin)
+            Bhi[o + 16 * PM_ROW] = hsin | (hcos << 16);               // (sin, cos)
+            const unsigned lc = pm_pack(rc, rs);
+            const unsigned lcos = lc & 0xffffu, lsin = lc >> 16;
+            Blo[o] = lcos | ((lsin ^ 0x8000u) << 16);
+            Blo[o + 16 * PM_ROW] = lsin | (lcos << 16);
+            const float nc = fmaf(bc, e2c, -(bs * e2s)), ns = fmaf(bc, e2s, bs * e2c);
+            bc = nc;
+            bs = ns;
+        }
+    };
+
+    const int nchunk = P.nf / PM_CH;        // a multiple of PM_NQ (host): every wave makes the same number of rounds
+    // long-run index of every row block (ps_setup_kernel's table)
+    int blong[PM_NRB];
+#pragma unroll
+    for (int rb = 0; rb < PM_NRB; ++rb) blong[rb] = brun[rb] >= 0 ? Q.long_of[brun[rb]] : 0;
+    const double2 *tab = Q.runtab + (size_t)k * P.nf * Q.nlong;
+    // the next round's spectrum and run entries are requested a round ahead
+    Cp<float> f_next = ps_load_slot<float>(Frow, P, q * PM_CH + om);
+    double2 t_next[PM_NRB];
+#pragma unroll
+    for (int rb = 0; rb < PM_NRB; ++rb) t_next[rb] = tab[(size_t)(q * PM_CH + om) * Q.nlong + blong[rb]];
+#define PM_STAMP(pt) \
+    if (Q.stamps && blockIdx.x == gridDim.x / 2 && lane == 0 && c >= 32 && c < 48) \
+        Q.stamps[((c - 32) * PM_WAVES + wave) * 6 + (pt)] = (long long)__builtin_readcyclecounter();
+    for (int c = q; c < nchunk; c += PM_NQ) {
+        PM_STAMP(0)
+        const float f0r = f_next.x * sigma, f0i = f_next.y * sigma;
+        double incs[PM_NRB], phis[PM_NRB];
+#pragma unroll
+        for (int rb = 0; rb < PM_NRB; ++rb) {
+            incs[rb] = t_next[rb].x;
+            phis[rb] = t_next[rb].y;
+        }
         {
-            const int cn = min(c + 4, nchunk - 1);
-            f_next = ps_load_slot<float>(Frow, P, cn * PM_CH + om);
-            w_next = P.w[cn * PM_CH + om];
-        }
-        const double rw = 1.0 / w;
-        double inc = 0.0;           // phase per depth step in the run `cur`
-        double Phi = 0.0;           // phase at the start of the run `cur`
-        int cur = -1;
-        if (VZ) {
-            // a frequency that sits on the evanescent boundary of ANY run is left to ps_edge_kernel for the whole axis
-            bool edge = false;
-            for (int r = 0; r < Q.nruns; ++r) {
-                edge = edge || fabs(pm_coss(Q.runs[r].v, kxk, rw)) < 1e-8;
-            }
-            if (edge) {
-                if (rhalf == 0 && hh == 0 && g == 0) {
-                    const int at = atomicAdd(Q.edge_cnt + k, 1);
-                    if (at < PM_EMAX) Q.edge_list[(size_t)k * PM_EMAX + at] = slot;
-                }
-                f0r = f0i = 0.f;
-            }
-        } else {
-            const double vk = P.vconst * kxk / 2.0;
-            const double vkx2 = vk * vk;                                      // :411
-            if (vkx2 < w * w) inc = w * P.dt * sqrt(1.0 - vkx2 / (w * w));    // :412-415
-            else f0r = f0i = 0.f;                                             // evanescent: dropped
-        }
-        float Ec = 1.f, Es = 0.f;   // e^{i 16 inc}: one tile further
+            const int sn = min(c + PM_NQ, nchunk - 1) * PM_CH + om;
+            f_next = ps_load_slot<float>(Frow, P, sn);
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) {
-            const int run = brun[rb];
-            if (run < 0) continue;                                            // uniform
-            if (run != cur) {
-                if (VZ) {
-                    while (cur < run) {
-                        if (cur >= 0) Phi = pm_wrap(Phi + (double)Q.runs[cur].len * inc);
-                        ++cur;
-                        const double cs = pm_coss(Q.runs[cur].v, kxk, rw);    // :456
-                        if (cs <= 0.0) {
-                            // evanescent at this velocity: zero from here on (:484-485; off the boundary the reference's
-                            // threshold (tau/tt_end/1e6)^2 is the sign of coss)
-                            f0r = f0i = 0.f;
-                            inc = 0.0;
-                        } else {
-                            inc = w * P.dt * sqrt(cs);                        // :458-460
-                        }
-                    }
-                } else {
-                    cur = run;
-                }
-                // ---- the run's step factors: B tile, e^{i (b+1) inc} 2^8 for this lane's steps b = 8 hh .. 8 hh + 7
-                float e1s, e1c, bs, bc;
-                pm_sincos(inc, &e1s, &e1c);                                   // |inc| <= |w| dt <= pi
-                pm_sincos(pm_wrap(16.0 * inc), &Es, &Ec);
-                pm_sincos(pm_wrap((double)(8 * hh + 1) * inc), &bs, &bc);
-                bs *= 256.f;
-                bc *= 256.f;
-                unsigned *bh = Bhi + hh * 16 * PM_LD + om, *bl = Blo + hh * 16 * PM_LD + om;
+            for (int rb = 0; rb < PM_NRB; ++rb) t_next[rb] = tab[(size_t)sn * Q.nlong + blong[rb]];
+        }
+        // ---- phase 1: this wave's state tile(s); the step factors of the first run
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    // column (b, re) holds (B_re, -B_im) against (S_re, S_im); column (b, im) holds (B_im, B_re)
-                    float rc, rs;
-                    const unsigned hc = pm_split(bc, bs, &rc, &rs);
-                    const unsigned hcos = hc & 0xffffu, hsin = hc >> 16;
-                    bh[(2 * j) * PM_LD] = hcos | ((hsin ^ 0x8000u) << 16);            // (cos, -sin)
-                    bh[(2 * j + 1) * PM_LD] = hsin | (hcos << 16);                    // (sin, cos)
-                    const unsigned lc = pm_pack(rc, rs);
-                    const unsigned lcos = lc & 0xffffu, lsin = lc >> 16;
-                    bl[(2 * j) * PM_LD] = lcos | ((lsin ^ 0x8000u) << 16);
-                    bl[(2 * j + 1) * PM_LD] = lsin | (lcos << 16);
-                    const float nc = fmaf(bc, e1c, -(bs * e1s)), ns = fmaf(bc, e1s, bs * e1c);
-                    bc = nc;
-                    bs = ns;
-                }
-            }
-            // ---- the row block's states: S tile, rows 16 hh .. 16 hh + 15 from an anchor with the float64 phase
-            {
-                const int steps0 = 16 * (ba0[rb] + 16 * hh);
-                float s, cph;
-                pm_sincos(pm_wrap(Phi + (double)steps0 * inc), &s, &cph);
-                float sr = fmaf(f0r, cph, -(f0i * s)), si = fmaf(f0r, s, f0i * cph);
-                unsigned *ah = Ahi + hh * 16 * PM_LD + om, *al = Alo + hh * 16 * PM_LD + om;
+        for (int rb = 0; rb < PM_NRB; ++rb) {
+            if (brun[rb] < 0) continue;                                       // uniform
+            if (rb == part || (rb == PM_NP && part == 0)) {
+                // rows hh, hh + 2, ..., hh + 30 = tiles a0 + row of 64 steps each: anchor with the float64 phase, then
+                // S *= e^{i 128 inc} from row to row; a frequency that is out of this run (NaN start phase) contributes zeros
+                const double inc = incs[rb];
+                const bool in = phis[rb] == phis[rb];
+                float s, cph, Es, Ec;
+                pm_sincos(pm_wrap((in ? phis[rb] : 0.0) + (double)(PM_TT * (ba0[rb] + hh)) * inc), &s, &cph);
+                pm_sincos(pm_wrap((double)(2 * PM_TT) * inc), &Es, &Ec);
+                const float gr = in ? f0r : 0.f, gi = in ? f0i : 0.f;
+                float sr = fmaf(gr, cph, -(gi * s)), si = fmaf(gr, s, gi * cph);
+                unsigned *Ahi = Aq + (size_t)rb * 2 * PM_TILE, *Alo = Ahi + PM_TILE;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     float rr, ri;
-                    ah[j * PM_LD] = pm_split(sr, si, &rr, &ri);
-                    al[j * PM_LD] = pm_pack(rr, ri);
+                    const int o = 64 * j + wx[j & 7];
+                    Ahi[o] = pm_split(sr, si, &rr, &ri);
+                    Alo[o] = pm_pack(rr, ri);
                     const float nr = fmaf(sr, Ec, -(si * Es)), ni = fmaf(sr, Es, si * Ec);
                     sr = nr;
                     si = ni;
                 }
             }
+        }
+        PM_STAMP(1)
+        if (brun[0] >= 0) gen_B(incs[0]);
+        PM_STAMP(2)
+        __syncthreads();            // the half's state tiles are complete
+        PM_STAMP(3)
+        // ---- phase 2: every row block of the group against this wave's 16 steps: 32 frequencies = 4 K-steps of 8.  The
+        // operands of step s + 1 are read while the three MFMAs of step s run (a read-wait-compute sequence per step
+        // left the matrix pipe idle for an LDS round trip sixteen times a round).
+#pragma unroll
+        for (int rb = 0; rb < PM_NRB; ++rb) {
+            const int run = brun[rb];
+            if (run < 0) continue;                                            // uniform
+            if (rb > 0 && brun[rb - 1] != run) {
+                __builtin_amdgcn_wave_barrier();
+                gen_B(incs[rb]);                                              // another run: other step factors
+            }
             __builtin_amdgcn_wave_barrier();
-            // ---- 32 frequencies = 4 K-steps of 8: rows / columns on lane & 31, k = 8 (lane >> 5) + j
+            const unsigned *Ahi = Aq + (size_t)rb * 2 * PM_TILE, *Alo = Ahi + PM_TILE;
+            uint4 ra_hi = *reinterpret_cast<const uint4 *>(Ahi + rd0), ra_lo = *reinterpret_cast<const uint4 *>(Alo + rd0);
+            uint4 rb_hi = *reinterpret_cast<const uint4 *>(Bhi + rd0), rb_lo = *reinterpret_cast<const uint4 *>(Blo + rd0);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int o = om * PM_LD + 8 * s + 4 * hh;
-                const pm_half8 a_hi = __builtin_bit_cast(pm_half8, *reinterpret_cast<const uint4 *>(Ahi + o));
-                const pm_half8 a_lo = __builtin_bit_cast(pm_half8, *reinterpret_cast<const uint4 *>(Alo + o));
-                const pm_half8 b_hi = __builtin_bit_cast(pm_half8, *reinterpret_cast<const uint4 *>(Bhi + o));
-                const pm_half8 b_lo = __builtin_bit_cast(pm_half8, *reinterpret_cast<const uint4 *>(Blo + o));
+                const pm_half8 a_hi = __builtin_bit_cast(pm_half8, ra_hi), a_lo = __builtin_bit_cast(pm_half8, ra_lo);
+                const pm_half8 b_hi = __builtin_bit_cast(pm_half8, rb_hi), b_lo = __builtin_bit_cast(pm_half8, rb_lo);
+                if (s < 3) {
+                    const int o = rd0 ^ (8 * (s + 1));
+                    ra_hi = *reinterpret_cast<const uint4 *>(Ahi + o);
+                    ra_lo = *reinterpret_cast<const uint4 *>(Alo + o);
+                    rb_hi = *reinterpret_cast<const uint4 *>(Bhi + o);
+                    rb_lo = *reinterpret_cast<const uint4 *>(Blo + o);
+                }
                 acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[rb], 0, 0, 0);
                 acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[rb], 0, 0, 0);
                 acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[rb], 0, 0, 0);
             }
-            __builtin_amdgcn_wave_barrier();
         }
+        PM_STAMP(4)
+        __syncthreads();            // ... and read by everybody before the next round overwrites them
+        PM_STAMP(5)
     }
 
-    // ---- the four frequency quarters of every row block, added in a fixed order; TK /= snum (:492)
-    __syncthreads();
-    float *red = reinterpret_cast<float *>(pm_lds);
+    // ---- every wave owns its sums outright (all frequencies of its 16 steps): TK /= snum (:492) and store.
+    // accumulator register i of lane l: row (i & 3) + 8 (i >> 2) + 4 (l >> 5), column l & 31 = 16 (im ? 1 : 0) + b
     const float scale = 1.0f / (sigma * 256.0f * (float)P.snum);
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) {
-        float *mine = red + ((size_t)wave * 64 + lane) * PM_RED_LD;
-#pragma unroll
-        for (int i = 0; i < 16; i += 4)
-            *reinterpret_cast<float4 *>(mine + i) = make_float4(acc[rb][i], acc[rb][i + 1], acc[rb][i + 2], acc[rb][i + 3]);
-        __syncthreads();
+    for (int rb = 0; rb < PM_NRB; ++rb) {
         const int run = brun[rb];
-        if (run >= 0) {
-            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (run < 0) continue;
+        const int start = Q.runs[run].start, end = start + Q.runs[run].len;
+        const int col = lane & 31;
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const float4 v = *reinterpret_cast<const float4 *>(red + ((size_t)(rhalf * 4 + qq) * 64 + lane) * PM_RED_LD + 4 * q);
-                sum.x += v.x;
-                sum.y += v.y;
-                sum.z += v.z;
-                sum.w += v.w;
-            }
-            // accumulator register i of lane l: row (i & 3) + 8 (i >> 2) + 4 (l >> 5), column l & 31; here i = 4 q + j
-            const int start = Q.runs[run].start, end = start + Q.runs[run].len;
-            const int col = lane & 31;
-            const int t0 = start + 16 * (ba0[rb] + 8 * q + 4 * hh) + (col >> 1);
-            const float vals[4] = {sum.x, sum.y, sum.z, sum.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int tau = t0 + 16 * j;
-                if (tau < end) TKrow[2 * (size_t)tau + (col & 1)] = vals[j] * scale;
-            }
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            const int tau = start + PM_TT * (ba0[rb] + row) + 16 * part + (col & 15);
+            if (tau < end) TKrow[2 * (size_t)tau + (col >> 4)] = acc[rb][i] * scale;
         }
-        __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------
-// The depth steps of the SHORT runs (len <= PM_SHORT), one workgroup per wavenumber: every frequency's phase is carried
-// through all runs in float64 (LDS), and at a short run each of its steps is summed over the frequencies directly --
-// FK0 e^{i Phi} per (frequency, step), a handful of steps per radargram.  Same rules as ps_mfma_kernel: evanescent at
-// a run's velocity -> zero from there on; boundary frequencies (|coss| < 1e-8 in any run) are ps_edge_kernel's.
-// Stores TK (the row blocks of the long runs do not cover these steps); runs before ps_edge_kernel / ps_dc_kernel.
+// Set-up pass, one workgroup per wavenumber, one thread per frequency at a time: everything that is float64 and per
+// (wavenumber, frequency, run) is done HERE, once, at full lane efficiency, instead of by the 8 lanes per frequency
+// of ps_mfma_kernel in every round (two float64 divisions, a square root and the catch-up over the runs per
+// frequency were the larger part of that kernel's vector work, profiles/r03_ps_mfma_*.txt):
+//   * the phase per step of every run (constant velocity: :411-415; v(z): :456-460) and the phase at the start of every
+//     LONG run -> runtab; a frequency that is evanescent at a run's velocity is out from there on (:484-485: off the
+//     boundary band the reference's threshold (tau/tt_end/1e6)^2 is the sign of coss);
+//   * the boundary frequencies (|coss| < 1e-8 in ANY run: kept or dropped by the reference at every step's own
+//     velocity) take no part in any run and are listed for ps_edge_kernel;
+//   * the depth steps of the SHORT runs (len <= PM_SHORT: a layer boundary smeared over a few steps) are summed over
+//     the frequencies directly -- FK0 e^{i Phi} per (frequency, step) -- and stored to TK (the row blocks of the long
+//     runs do not cover them).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void ps_trans_kernel(PsMfmaParams Q)
+__global__ __launch_bounds__(512) void ps_setup_kernel(PsMfmaParams Q)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned pm_lds[];
     const PsParams &P = Q.P;
     const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *phi = reinterpret_cast<double *>(pm_lds);                       // [nf] phase at the start of the current run
     double *rws = phi + P.nf;                                               // [nf] 1 / w
-    float2 *f0 = reinterpret_cast<float2 *>(rws + P.nf);                    // [nf] spectrum, zero once dead
+    float2 *f0 = reinterpret_cast<float2 *>(rws + P.nf);                    // [nf] spectrum, zero once out
     float *red = reinterpret_cast<float *>(f0 + P.nf);                      // [8][2 * PM_SHORT]
     const Cp<float> *Frow = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.fstride;
     float *TKrow = reinterpret_cast<float *>(reinterpret_cast<Cp<float> *>(P.TK) + (size_t)k * P.snum);
+    double2 *tab = Q.runtab + (size_t)k * P.nf * Q.nlong;
     const double kxk = P.kx[k];
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    if (!Q.vz) {
+        // constant velocity: one run, FK e^{i (tau + 1) phi} for the propagating frequencies (:411-420)
+        for (int slot = tid; slot < P.nf; slot += 512) {
+            const double w = P.w[slot];
+            const double vk = P.vconst * kxk / 2.0;
+            const double vkx2 = vk * vk;                                      // :411
+            const bool prop = vkx2 < w * w;                                   // :412
+            tab[slot] = make_double2(prop ? w * P.dt * sqrt(1.0 - vkx2 / (w * w)) : 0.0, prop ? 0.0 : nan);   // :415
+        }
+        return;
+    }
     for (int slot = tid; slot < P.nf; slot += 512) {
         const Cp<float> f = ps_load_slot<float>(Frow, P, slot);
         const double rw = 1.0 / P.w[slot];
         bool edge = false;
         for (int r = 0; r < Q.nruns; ++r) edge = edge || fabs(pm_coss(Q.runs[r].v, kxk, rw)) < 1e-8;
-        f0[slot] = edge ? make_float2(0.f, 0.f) : make_float2(f.x, f.y);
-        phi[slot] = 0.0;
+        if (edge) {
+            const int at = atomicAdd(Q.edge_cnt + k, 1);
+            if (at < PM_EMAX) Q.edge_list[(size_t)k * PM_EMAX + at] = slot;
+        }
+        // (a frequency whose spectrum value IS zero stays in: f0 only says "out" through the flag below)
+        f0[slot] = make_float2(f.x, f.y);
+        phi[slot] = edge ? nan : 0.0;                                         // NaN phase = out of every run from here on
         rws[slot] = rw;
     }
     for (int r = 0; r < Q.nruns; ++r) {
         const double v = Q.runs[r].v;
         const int len = Q.runs[r].len, start = Q.runs[r].start;
         const bool is_short = len <= PM_SHORT;                                // uniform
+        const int L = Q.long_of[r];
         float acc[2 * PM_SHORT];
 #pragma unroll
         for (int j = 0; j < 2 * PM_SHORT; ++j) acc[j] = 0.f;
         for (int slot = tid; slot < P.nf; slot += 512) {
             const double w = P.w[slot];
             const double cs = pm_coss(v, kxk, rws[slot]);                     // :456
-            double inc = 0.0;
-            float2 f = f0[slot];
-            if (cs <= 0.0) {
-                f = make_float2(0.f, 0.f);                                    // :484-485, for good
-                f0[slot] = f;
-            } else {
-                inc = w * P.dt * sqrt(cs);                                    // :458-460
-            }
             double ph = phi[slot];
-            if (is_short && (f.x != 0.f || f.y != 0.f)) {
+            double inc = 0.0;
+            if (cs <= 0.0) ph = nan;                                          // :484-485, for good
+            else inc = w * P.dt * sqrt(cs);                                   // :458-460
+            if (L >= 0) tab[(size_t)slot * Q.nlong + L] = make_double2(inc, ph);
+            if (is_short && ph == ph) {
+                const float2 f = f0[slot];
 #pragma unroll
                 for (int j = 0; j < PM_SHORT; ++j)
                     if (j < len) {                                            // uniform
@@ -374,7 +421,7 @@ __global__ __launch_bounds__(512) void ps_trans_kernel(PsMfmaParams Q)
                         acc[2 * j + 1] += fmaf(f.x, sn, f.y * c2);
                     }
             }
-            phi[slot] = pm_wrap(ph + (double)len * inc);
+            phi[slot] = pm_wrap(ph + (double)len * inc);                      // NaN stays NaN
         }
         if (is_short) {
 #pragma unroll

@@ -189,6 +189,18 @@ static std::mutex g_stolt_mu;
 static StoltPlan *g_stolt_plan = nullptr;     // last-used plan (sizes repeat across calls)
 
 // called by impdar_ctx_destroy: a cached plan must not outlive the stream it was created on
+// impdar_release_caches: out of device memory somewhere -- drop the cached plan unless a Stolt call is using it
+static thread_local bool t_stolt_busy = false;
+void impdar_stolt_trim()
+{
+    if (t_stolt_busy) return;
+    std::unique_lock<std::mutex> lk(g_stolt_mu, std::try_to_lock);
+    if (lk.owns_lock() && g_stolt_plan) {
+        delete g_stolt_plan;
+        g_stolt_plan = nullptr;
+    }
+}
+
 void impdar_stolt_forget(const impdar_ctx *ctx)
 {
     std::lock_guard<std::mutex> lk(g_stolt_mu);
@@ -304,6 +316,7 @@ extern "C" int impdar_stolt_dev(impdar_ctx *ctx, const void *d_data, int dtype, 
     IMPDAR_ARG_CHECK(vel > 0, "vel must be positive");
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
     std::lock_guard<std::mutex> lk(g_stolt_mu);
+    ImpdarBusy busy(t_stolt_busy);
     if (!g_stolt_plan) g_stolt_plan = new StoltPlan();
     int rc = dtype == IMPDAR_F32
                  ? stolt_run<float>(ctx, *g_stolt_plan, d_data, snum, tnum, kx, ws, vel, htaper, vtaper, d_out)

@@ -65,7 +65,7 @@ def main():
                          'events in the same process\n' % (w + 1, w + k, sum(timed) / k, b['roofline']['kernel_ms']))
     rows, allc = [], {}
     for sub, fn in (('pmc_fetch', 'bench'), ('pmc_write', 'bench'), ('pmc_sq', 'bench'), ('pmc_sq2', 'bench'),
-                    ('paths_sq', 'paths'), ('paths_sq2', 'paths')):
+                    ('paths_sq', 'paths'), ('paths_sq2', 'paths'), ('paths_fetch', 'paths'), ('paths_write', 'paths')):
         c, meta = counters(os.path.join(src, sub))
         for k, cs in c.items():
             for name, v in cs.items():

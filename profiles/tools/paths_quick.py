@@ -3,5 +3,5 @@ environment knobs: run it under different IMPDAR_* settings)."""
 import sys, os, json
 sys.path.insert(0, os.getcwd())
 import bench
-r = bench.path_records(True)
-print(json.dumps({k: {'device_ms': v['device_ms'], 'call_ms': v['call_ms'], 'frac': v['roofline']['frac']} for k, v in r.items()}))
+r = bench.path_records(True, True)
+print(json.dumps({k: {'device_ms': v.get('device_ms', v.get('ms_per_step')), 'kernel_ms': v.get('kernel_ms'), 'frac': v['roofline']['frac']} for k, v in r.items()}))

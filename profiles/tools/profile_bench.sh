@@ -24,5 +24,7 @@ ls -R $O | head -40
 rocprofv3 --kernel-trace --stats -d $O/stats64/run -o x --output-format csv -- python3 bench.py --dtype f64 --mode exact --steps 5 --no-cpu --no-pmc --no-paths --no-e2e > $O/stats64.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/paths/run -o x --output-format csv -- python3 profiles/tools/paths_quick.py > $O/paths.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/paths_sq/run -o x --output-format csv -- python3 profiles/tools/paths_quick.py > $O/paths_sq.log 2>&1
-rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $O/paths_sq2/run -o x --output-format csv -- python3 profiles/tools/paths_quick.py > $O/paths_sq2.log 2>&1
+rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_ACTIVE_INST_LDS -d $O/paths_sq2/run -o x --output-format csv -- python3 profiles/tools/paths_quick.py > $O/paths_sq2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/paths_fetch/run -o x --output-format csv -- python3 profiles/tools/paths_quick.py > $O/paths_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/paths_write/run -o x --output-format csv -- python3 profiles/tools/paths_quick.py > $O/paths_write.log 2>&1
 ls -R $O | head -60

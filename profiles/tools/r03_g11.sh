@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r03n; mkdir -p $O
+timeout 3000 python -m pytest tests -x -q -m gpu > $O/tests_all.txt 2>&1; echo "pytest rc $?" >> $O/tests_all.txt
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc $?" >> $O/smoke.txt
+timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc $?" >> $O/bench.err
+bash profiles/tools/profile_bench.sh prof_r03 > $O/profile.log 2>&1
+tail -n 4 $O/tests_all.txt; tail -n 2 $O/smoke.txt; tail -n 4 $O/bench.err; cat $O/bench.json | cut -c1-400
