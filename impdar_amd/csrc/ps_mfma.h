@@ -100,6 +100,17 @@ __device__ __forceinline__ double pm_coss(double v, double kxk, double rw)
     return 1.0 - a * a;
 }
 
+// sqrt(x) for x in [1e-8, 1]: float32 reciprocal square root as the seed, two Newton steps in float64 (relative
+// error ~1e-16 -- not correctly rounded; the phase per step it feeds tolerates 1e-13).  The IEEE sqrt is ~2.5x the
+// instructions, and ps_setup_kernel takes one per (wavenumber, frequency, run).
+__device__ __forceinline__ double pm_sqrt01(double x)
+{
+    double y = (double)__builtin_amdgcn_rsqf((float)x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return x * y;
+}
+
 __device__ __forceinline__ double pm_wrap(double x) { return x - 6.283185307179586 * rint(x * 0.15915494309189535); }
 
 // sin / cos of a float64 angle in [-pi, pi] as float32: the high float through the polynomial, the low float to first order
@@ -209,17 +220,16 @@ __global__ __launch_bounds__(PM_WAVES * 64, 2) void ps_mfma_kernel(PsMfmaParams 
         bc *= 256.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            // column b (re) holds (B_re, -B_im) against (S_re, S_im); column 16 + b (im) holds (B_im, B_re)
+            // column b (re) holds (B_re, -B_im) against (S_re, S_im); column 16 + b (im) holds (B_im, B_re): four pack
+            // conversions (the negation is a source modifier) instead of shifting and masking two packed pairs apart
             float rc, rs;
-            const unsigned hc = pm_split(bc, bs, &rc, &rs);
-            const unsigned hcos = hc & 0xffffu, hsin = hc >> 16;
+            const unsigned h0 = pm_split(bc, bs, &rc, &rs);          // residuals of (cos, sin)
+            (void)h0;
             const int o = 64 * j + wx[j & 7];
-            Bhi[o] = hcos | ((hsin ^ 0x8000u) << 16);                 // (cos, -sin)
-            Bhi[o + 16 * PM_ROW] = hsin | (hcos << 16);               // (sin, cos)
-            const unsigned lc = pm_pack(rc, rs);
-            const unsigned lcos = lc & 0xffffu, lsin = lc >> 16;
-            Blo[o] = lcos | ((lsin ^ 0x8000u) << 16);
-            Blo[o + 16 * PM_ROW] = lsin | (lcos << 16);
+            Bhi[o] = pm_pack(bc, -bs);                                 // (cos, -sin)
+            Bhi[o + 16 * PM_ROW] = pm_pack(bs, bc);                    // (sin, cos)
+            Blo[o] = pm_pack(rc, -rs);
+            Blo[o + 16 * PM_ROW] = pm_pack(rs, rc);
             const float nc = fmaf(bc, e2c, -(bs * e2s)), ns = fmaf(bc, e2s, bs * e2c);
             bc = nc;
             bs = ns;
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(512) void ps_setup_kernel(PsMfmaParams Q)
             double ph = phi[slot];
             double inc = 0.0;
             if (cs <= 0.0) ph = nan;                                          // :484-485, for good
-            else inc = w * P.dt * sqrt(cs);                                   // :458-460
+            else inc = w * P.dt * pm_sqrt01(cs);                              // :458-460 (off the boundary band: cs >= 1e-8)
             if (L >= 0) tab[(size_t)slot * Q.nlong + L] = make_double2(inc, ph);
             if (is_short && ph == ph) {
                 const float2 f = f0[slot];
