@@ -184,17 +184,21 @@ template <typename F> static void impdar_parallel_for(size_t n, size_t align, F 
 // Device -> pageable host memory in pieces: every piece is DMA-ed into the pinned staging buffer and copied out
 // (or widened to float64) on the host threads while the DMA of the following pieces is still running.
 // elem_out == 0: plain byte copy; elem_out == 8 with elem_in == 4: float32 -> float64.
+// width != 0: the device array is a (n / width) x width block, contiguous, and lands in columns [col0, col0 + width) of a
+// host array with `ld` elements per row (an output-trace block of a sharded or split migration).
 static int impdar_download_piped(impdar_ctx *ctx, void *host_dst, const void *dev_src, size_t n, size_t elem_in,
-                                 bool widen, hipStream_t st)
+                                 bool widen, hipStream_t st, size_t width = 0, size_t ld = 0, size_t col0 = 0)
 {
     const size_t bytes = n * elem_in;
+    const bool block = width != 0 && !(width == ld && col0 == 0);
+    const size_t elem_out = widen ? 8 : elem_in;
     // one staged download per context at a time: the staging buffer is shared (and may be re-allocated) and
     // ctypes callers run without the GIL
     std::lock_guard<std::mutex> lock(ctx->pinned_mu);
     void *stage = bytes >= (1u << 20) ? impdar_ctx_pinned(ctx, bytes) : nullptr;
     std::vector<char> fallback;
     if (!stage) {
-        if (!widen) {
+        if (!widen && !block) {
             IMPDAR_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, st));
             IMPDAR_HIP_CHECK(hipStreamSynchronize(st));
             return IMPDAR_OK;
@@ -206,7 +210,8 @@ static int impdar_download_piped(impdar_ctx *ctx, void *host_dst, const void *de
     const int npiece = (int)std::min<size_t>(8, std::max<size_t>(1, bytes / (48u << 20)));
     hipEvent_t ev[8] = {};
     size_t lo[9];
-    for (int c = 0; c <= npiece; ++c) lo[c] = (n * c / npiece) / 16 * 16;
+    const size_t gran = block ? width : 16;                  // block pieces are whole rows
+    for (int c = 0; c <= npiece; ++c) lo[c] = (n * c / npiece) / gran * gran;
     lo[npiece] = n;
     int rc = IMPDAR_OK, issued = 0;
     for (int c = 0; c < npiece && rc == IMPDAR_OK; ++c) {
@@ -233,7 +238,25 @@ static int impdar_download_piped(impdar_ctx *ctx, void *host_dst, const void *de
         (void)hipEventDestroy(ev[c]);
         if (rc) continue;
         const size_t base = lo[c], cnt = lo[c + 1] - lo[c];
-        if (widen) {
+        if (block) {
+            // rows base / width .. of the block -> host rows of `ld` elements, columns col0 ..
+            const size_t r0 = base / width, nr = cnt / width;
+            const char *sp = reinterpret_cast<const char *>(stage);
+            char *dp = reinterpret_cast<char *>(host_dst);
+            impdar_parallel_for(nr, 1, [=](size_t a, size_t b) {
+                for (size_t r = r0 + a; r < r0 + b; ++r) {
+                    const char *src = sp + r * width * elem_in;
+                    char *dst = dp + (r * ld + col0) * elem_out;
+                    if (widen) {
+                        const float *f = reinterpret_cast<const float *>(src);
+                        double *d = reinterpret_cast<double *>(dst);
+                        for (size_t j = 0; j < width; ++j) d[j] = (double)f[j];
+                    } else {
+                        memcpy(dst, src, width * elem_in);
+                    }
+                }
+            });
+        } else if (widen) {
             const float *f = reinterpret_cast<const float *>(stage) + base;
             double *d = reinterpret_cast<double *>(host_dst) + base;
             impdar_parallel_for(cnt, 16, [=](size_t a, size_t b) { for (size_t i = a; i < b; ++i) d[i] = (double)f[i]; });
@@ -260,6 +283,15 @@ static int impdar_download_piped(impdar_ctx *ctx, void *host_dst, const void *de
 int impdar_download(impdar_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes, hipStream_t st)
 {
     return impdar_download_piped(ctx, host_dst, dev_src, bytes, 1, false, st);
+}
+
+// a (rows x width) device block of `dtype` into columns [col0, col0 + width) of a (rows x ld) float64 host array, on `st`
+int impdar_download_block_f64(impdar_ctx *ctx, double *dst_host, size_t ld, size_t col0, const void *src_dev, int dtype,
+                              size_t rows, size_t width, hipStream_t st)
+{
+    if (rows == 0 || width == 0) return IMPDAR_OK;
+    if (dtype == IMPDAR_F64) return impdar_download_piped(ctx, dst_host, src_dev, rows * width * 8, 1, false, st, width * 8, ld * 8, col0 * 8);
+    return impdar_download_piped(ctx, dst_host, src_dev, rows * width, 4, true, st, width, ld, col0);
 }
 
 extern "C" int impdar_dev_download_f64(impdar_ctx *ctx, double *dst_host, const void *src_dev, int dtype, size_t n)

@@ -55,6 +55,9 @@ void *impdar_ctx_pinned(impdar_ctx *ctx, size_t bytes);
 void impdar_host_copy_f64(double *dst, const void *src, size_t n, bool src_is_f32);
 // device -> host through the pinned staging buffer and a threaded copy (falls back to a plain D2H); synchronises `st`
 int impdar_download(impdar_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes, hipStream_t st);
+// a (rows x width) device block of `dtype` into columns [col0, col0 + width) of a (rows x ld) float64 host array, on `st`
+int impdar_download_block_f64(impdar_ctx *ctx, double *dst_host, size_t ld, size_t col0, const void *src_dev, int dtype,
+                              size_t rows, size_t width, hipStream_t st);
 
 void impdar_set_error(const char *fmt, ...);
 

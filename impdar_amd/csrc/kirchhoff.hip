@@ -3083,6 +3083,7 @@ struct KirchOneShot {
     const impdar_ctx *owner = nullptr;
     impdar_kirch_plan *plan = nullptr;
     DevBuf din, dout;
+    hipEvent_t ev_half = nullptr;    // first output block of a split one-shot call summed (see impdar_kirchhoff)
     int dtype = -1, snum = 0, tnum = 0, nearfield = 0, grad_uniform = 0, mode = 0;
     double vel = 0, grad_h = 0;
     std::vector<double> dist, tt, ga, gb, gc;
@@ -3093,6 +3094,8 @@ struct KirchOneShot {
         plan = nullptr;
         din.release();
         dout.release();
+        if (ev_half) (void)hipEventDestroy(ev_half);
+        ev_half = nullptr;
         owner = nullptr;
     }
 };
@@ -3199,15 +3202,41 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
     }
     const auto t1 = now();
     if ((rc = impdar_kirch_prep(p, c.din.p, tnum, 0, tnum))) return done(rc);
-    if ((rc = impdar_kirch_migrate(p, c.dout.p, 0, tnum))) return done(rc);
     auto t1b = t1;
-    if (timing) {                                             // diagnostic only: the download below waits for the kernel anyway
-        (void)hipStreamSynchronize(ctx->stream);
-        t1b = now();
+    // Large radargrams on the ring kernels: the output traces in two blocks (5/8 and 3/8), two launches, so that the
+    // first block crosses PCIe and is widened on the host while the second is summed (output blocks equal the whole
+    // image bit for bit: every output accumulates its pairs in the same order).  Two launches cost ~10 % more kernel
+    // time than one (each must drain); the download they hide is worth more.  IMPDAR_KIRCH_ONESHOT_SPLIT=0: one launch.
+    const char *se = getenv("IMPDAR_KIRCH_ONESHOT_SPLIT");
+    const int kern = impdar_kirch_plan_kernel(p);
+    const bool split = !(se && atoi(se) == 0) && !timing && tnum >= 4096 && bytes >= ((size_t)64 << 20) &&
+                       (kern == IMPDAR_KERNEL_QUAD || kern == IMPDAR_KERNEL_DQUAD);
+    if (split) {
+        const int mid = ((int)((long long)tnum * 5 / 8) / 8) * 8;
+        char *blk_a = reinterpret_cast<char *>(c.dout.p), *blk_b = blk_a + (size_t)snum * mid * esz;
+        if (!c.ev_half && hipEventCreateWithFlags(&c.ev_half, hipEventDisableTiming) != hipSuccess) {
+            c.ev_half = nullptr;
+            impdar_set_error("hipEventCreate failed");
+            return done(IMPDAR_ERR_HIP);
+        }
+        if ((rc = impdar_kirch_migrate(p, blk_a, 0, mid))) return done(rc);
+        if (hipEventRecord(c.ev_half, ctx->stream) != hipSuccess) return done(IMPDAR_ERR_HIP);
+        if ((rc = impdar_kirch_migrate(p, blk_b, mid, tnum))) return done(rc);
+        // block A leaves on the producer stream (idle since prep) as soon as its launch has finished
+        if (hipStreamWaitEvent(ctx->aux, c.ev_half, 0) != hipSuccess) return done(IMPDAR_ERR_HIP);
+        if ((rc = impdar_download_block_f64(ctx, out, (size_t)tnum, 0, blk_a, dtype, (size_t)snum, (size_t)mid, ctx->aux))) return done(rc);
+        if ((rc = impdar_download_block_f64(ctx, out, (size_t)tnum, (size_t)mid, blk_b, dtype, (size_t)snum, (size_t)(tnum - mid), ctx->stream)))
+            return done(rc);
+    } else {
+        if ((rc = impdar_kirch_migrate(p, c.dout.p, 0, tnum))) return done(rc);
+        if (timing) {                                             // diagnostic only: the download below waits for the kernel anyway
+            (void)hipStreamSynchronize(ctx->stream);
+            t1b = now();
+        }
+        // device -> pinned staging (in pieces) -> the caller's float64 array on several host threads
+        // (mig_python.py:118 returns float64); waits for the diffraction sum on the compute stream
+        if ((rc = impdar_dev_download_f64(ctx, out, c.dout.p, dtype, (size_t)snum * tnum))) return done(rc);
     }
-    // device -> pinned staging (in pieces) -> the caller's float64 array on several host threads
-    // (mig_python.py:118 returns float64); waits for the diffraction sum on the compute stream
-    if ((rc = impdar_dev_download_f64(ctx, out, c.dout.p, dtype, (size_t)snum * tnum))) return done(rc);
     const auto t2 = now();
     rc = done(IMPDAR_OK);
     if (timing)

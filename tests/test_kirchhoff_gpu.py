@@ -204,6 +204,37 @@ def test_native_hook_at_config3_size(hip, tnum):
     assert min(walls) < 0.150
 
 
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_one_shot_in_two_output_blocks_equals_one_launch(hip, monkeypatch, dtype):
+    """Large radargrams through the one-shot entry point (RadarData.migrate on host arrays) are summed in two
+    output-trace blocks so that the first crosses PCIe while the second is computed; the result must equal the
+    single launch bit for bit (IMPDAR_KIRCH_ONESHOT_SPLIT=0), and the oracle on spot traces."""
+    from impdar_amd import synth
+    from impdar_amd.lib.RadarData import RadarData
+    from oracle import c_oracle
+    snum, tnum, vel = 4096, 4104, 1.69e8
+    geo = synth.geometry(snum, tnum)
+    x = synth.diffractor_radargram(snum, tnum, vel=vel, ndiff=16).astype(dtype)
+    outs = {}
+    for split in ('1', '0', '1'):
+        monkeypatch.setenv('IMPDAR_KIRCH_ONESHOT_SPLIT', split)
+        monkeypatch.setenv('IMPDAR_KIRCH_ONESHOT_CACHE', '0')        # a fresh plan per call: the knob is read per call anyway
+        d = RadarData(None)
+        d.data, d.snum, d.tnum = x.copy(), snum, tnum
+        d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
+        d.migrate('kirch', vel=vel)
+        assert d.data.dtype == np.float64 and d.data.shape == (snum, tnum)
+        outs.setdefault(split, []).append(d.data)
+    assert np.array_equal(outs['1'][0], outs['0'][0]) and np.array_equal(outs['1'][0], outs['1'][1])
+    cols = np.array([0, 7, 2559, 2560, 2561, 2567, 4103])            # both sides of the cut (5/8 of 4104, in whole groups of 8: 2560)
+    want = c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], vel, False, traces=cols)
+    got = outs['1'][0][:, cols]
+    if dtype == np.float64:
+        assert rel_max(got, want) < EXACT_TOL
+    else:
+        assert rel_l2(got, want) < FAST_L2
+
+
 def test_reference_fixture_all_zeros(hip):
     """test/test_migrationlib.py:112-114 runs Kirchhoff on 10x20 zeros."""
     from impdar_amd.lib.NoInitRadarData import NoInitRadarData
