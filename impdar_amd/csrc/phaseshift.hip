@@ -1411,8 +1411,10 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
         IMPDAR_HIP_CHECK(hipMemsetAsync(d_stamps.p, 0, 16 * PM_WAVES * 6 * sizeof(long long), st));
         Q.stamps = d_stamps.as<long long>();
     }
-    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PM_LDS_BYTES));
-    hipLaunchKernelGGL(ps_mfma_kernel, dim3((unsigned)tnum * Q.ngroups), dim3(PM_WAVES * 64), PM_LDS_BYTES, st, Q);
+    // (diagnostics: IMPDAR_PS_MFMA_ONE_WG=1 asks for 100 KB of LDS, i.e. one workgroup per CU instead of two)
+    const size_t lds_bytes = getenv("IMPDAR_PS_MFMA_ONE_WG") ? std::max<size_t>(PM_LDS_BYTES, 100 * 1024) : PM_LDS_BYTES;
+    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(ps_mfma_kernel, dim3((unsigned)tnum * Q.ngroups), dim3(PM_WAVES * 64), lds_bytes, st, Q);
     if (vz) hipLaunchKernelGGL(ps_edge_kernel, dim3(tnum), dim3(256), 0, st, Q);
     IMPDAR_HIP_CHECK(hipGetLastError());
     // the host table must outlive its async copy

@@ -54,9 +54,14 @@ typedef _Float16 pm_half8 __attribute__((ext_vector_type(8)));
 typedef float pm_float16 __attribute__((ext_vector_type(16)));
 
 constexpr int PM_TT = 64;                   // depth steps per tile
-constexpr int PM_CH = 32;                   // frequency slots per chunk (lane & 31)
-constexpr int PM_ROW = 32;                  // dwords per tile row (32 complex float16 pairs; slots XOR-swizzled, no padding)
-constexpr int PM_TILE = 32 * PM_ROW;        // dwords per tile (hi or lo halves of 32 rows x 32 complex): 4 KB
+#ifndef PM_CHUNK
+#define PM_CHUNK 32      // 16 (three waves per SIMD, 168 VGPRs) measured 12.1 / 20.2 ms at config 5 against 11.3 / 19.1 ms for 32 (two waves): the per-frequency sincos work doubles
+#endif
+constexpr int PM_CH = PM_CHUNK;             // frequency slots per chunk (16 or 32): lane % PM_CH
+constexpr int PM_NSUB = 64 / PM_CH;         // lanes per frequency: each generates every PM_NSUB-th row / step
+constexpr int PM_ROW = PM_CH;               // dwords per tile row (one complex float16 pair per frequency; slots XOR-swizzled, no padding)
+constexpr int PM_NSLOT = PM_ROW / 4;        // 16-byte slots per row
+constexpr int PM_TILE = 32 * PM_ROW;        // dwords per tile (hi or lo halves of 32 rows): 2 or 4 KB
 constexpr int PM_NQ = 1, PM_NP = 4;         // waves of a workgroup: (one frequency part) x step blocks of 16
 constexpr int PM_NRB = 5;                   // row blocks per group (state tiles per frequency half, accumulators per wave)
 constexpr int PM_WAVES = PM_NQ * PM_NP;
@@ -149,14 +154,14 @@ __device__ __forceinline__ unsigned pm_split(float x, float y, float *rx, float 
 }
 __device__ __forceinline__ unsigned pm_pack(float x, float y) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, y)); }
 
-__global__ __launch_bounds__(PM_WAVES * 64, 2) void ps_mfma_kernel(PsMfmaParams Q)
+__global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_kernel(PsMfmaParams Q)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned pm_lds[];
     const PsParams &P = Q.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = wave & (PM_NQ - 1), part = wave / PM_NQ;
     const int g = (int)blockIdx.x % Q.ngroups, k = (int)blockIdx.x / Q.ngroups;
-    const int om = lane & 31, hh = lane >> 5;
+    const int om = lane % PM_CH, hh = lane / PM_CH;      // frequency of the chunk; which of its PM_NSUB generating lanes
     const Cp<float> *Frow = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.fstride;
     float *TKrow = reinterpret_cast<float *>(reinterpret_cast<Cp<float> *>(P.TK) + (size_t)k * P.snum);
 
@@ -182,19 +187,19 @@ __global__ __launch_bounds__(PM_WAVES * 64, 2) void ps_mfma_kernel(PsMfmaParams 
         sigma = (m > 0.f && m < 3.0e38f) ? ldexpf(1.0f, 12 - e) : 1.0f;
     }
 
-    // ---- tiles (4 KB each: 32 rows of 32 dwords = 32 complex float16 pairs, no padding; the eight 16-byte slots of
-    // row r sit at slot ^ ((r >> 1) & 7), so that the 16 lanes a ds_read_b128 serves together (rows r .. r + 15, one
-    // slot) and the 64 lanes of a generating ds_write_b32 (32 frequencies x the two rows 2 j + hh) each touch all 64
-    // banks once).  Per frequency half q: the state tiles of the group's row blocks, shared by its four waves; one
-    // step-factor tile per wave; hi halves, then lo halves.
+    // ---- tiles (32 rows of PM_ROW dwords = one complex float16 pair per frequency of the chunk, no padding).  A 256-byte
+    // bank line holds PM_NSUB rows; the 16-byte slots of row r sit at slot ^ ((r / PM_NSUB) % PM_NSLOT), so that the 16
+    // lanes a ds_read_b128 serves together (rows r .. r + 15, one slot) and the 64 lanes of a generating ds_write_b32
+    // (PM_CH frequencies x the rows PM_NSUB j + hh) each touch all 64 banks once.  The state tiles of the group's row
+    // blocks are shared by the four waves; one step-factor tile per wave; hi halves, then lo halves.
     unsigned *Aq = pm_lds + (size_t)q * PM_NRB * 2 * PM_TILE;                          // [rb][hi, lo]
     unsigned *Bhi = pm_lds + (size_t)PM_NQ * PM_NRB * 2 * PM_TILE + (size_t)wave * 2 * PM_TILE, *Blo = Bhi + PM_TILE;
-    // generation: this lane writes logical dword `om` of rows 2 j + hh; (row >> 1) & 7 = j & 7
-    int wx[8];
+    // generation: this lane writes logical dword `om` of rows PM_NSUB j + hh; (row / PM_NSUB) % PM_NSLOT = j % PM_NSLOT
+    int wx[PM_NSLOT];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) wx[m] = 32 * hh + (om ^ (4 * m));
+    for (int m = 0; m < PM_NSLOT; ++m) wx[m] = PM_ROW * hh + (om ^ (4 * m));
     // MFMA operands: row / column lane & 31, K-step s, k-half h = lane >> 5: logical slot 2 s + h; K-step s at rd0 ^ 8 s
-    const int rd0 = (lane & 31) * PM_ROW + ((4 * (lane >> 5)) ^ (4 * (((lane & 31) >> 1) & 7)));
+    const int rd0 = (lane & 31) * PM_ROW + ((4 * (lane >> 5)) ^ (4 * (((lane & 31) / PM_NSUB) % PM_NSLOT)));
 
     // the group's row blocks: (run, first tile inside the run); block i is GENERATED by the waves of part i (i < 4;
     // block 4 by part 0 as well)
@@ -211,21 +216,21 @@ __global__ __launch_bounds__(PM_WAVES * 64, 2) void ps_mfma_kernel(PsMfmaParams 
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
 
-    // this lane's step factors: steps b = 16 part + hh + 2 j of every 64-step tile
+    // this lane's step factors: steps b = 16 part + hh + PM_NSUB j of every 64-step tile
     auto gen_B = [&](double inc) {
         float e2s, e2c, bs, bc;
-        pm_sincos(pm_wrap(2.0 * inc), &e2s, &e2c);
+        pm_sincos(pm_wrap((double)PM_NSUB * inc), &e2s, &e2c);
         pm_sincos(pm_wrap((double)(16 * part + hh + 1) * inc), &bs, &bc);
         bs *= 256.f;
         bc *= 256.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 16 / PM_NSUB; ++j) {
             // column b (re) holds (B_re, -B_im) against (S_re, S_im); column 16 + b (im) holds (B_im, B_re): four pack
             // conversions (the negation is a source modifier) instead of shifting and masking two packed pairs apart
             float rc, rs;
             const unsigned h0 = pm_split(bc, bs, &rc, &rs);          // residuals of (cos, sin)
             (void)h0;
-            const int o = 64 * j + wx[j & 7];
+            const int o = 64 * j + wx[j % PM_NSLOT];
             Bhi[o] = pm_pack(bc, -bs);                                 // (cos, -sin)
             Bhi[o + 16 * PM_ROW] = pm_pack(bs, bc);                    // (sin, cos)
             Blo[o] = pm_pack(rc, -rs);
@@ -270,20 +275,20 @@ __global__ __launch_bounds__(PM_WAVES * 64, 2) void ps_mfma_kernel(PsMfmaParams 
         for (int rb = 0; rb < PM_NRB; ++rb) {
             if (brun[rb] < 0) continue;                                       // uniform
             if (rb == part || (rb == PM_NP && part == 0)) {
-                // rows hh, hh + 2, ..., hh + 30 = tiles a0 + row of 64 steps each: anchor with the float64 phase, then
-                // S *= e^{i 128 inc} from row to row; a frequency that is out of this run (NaN start phase) contributes zeros
+                // rows hh, hh + PM_NSUB, ... = tiles a0 + row of 64 steps each: anchor with the float64 phase, then
+                // S *= e^{i 64 PM_NSUB inc} from row to row; a frequency that is out of this run (NaN start phase) contributes zeros
                 const double inc = incs[rb];
                 const bool in = phis[rb] == phis[rb];
                 float s, cph, Es, Ec;
                 pm_sincos(pm_wrap((in ? phis[rb] : 0.0) + (double)(PM_TT * (ba0[rb] + hh)) * inc), &s, &cph);
-                pm_sincos(pm_wrap((double)(2 * PM_TT) * inc), &Es, &Ec);
+                pm_sincos(pm_wrap((double)(PM_NSUB * PM_TT) * inc), &Es, &Ec);
                 const float gr = in ? f0r : 0.f, gi = in ? f0i : 0.f;
                 float sr = fmaf(gr, cph, -(gi * s)), si = fmaf(gr, s, gi * cph);
                 unsigned *Ahi = Aq + (size_t)rb * 2 * PM_TILE, *Alo = Ahi + PM_TILE;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
+                for (int j = 0; j < 32 / PM_NSUB; ++j) {
                     float rr, ri;
-                    const int o = 64 * j + wx[j & 7];
+                    const int o = 64 * j + wx[j % PM_NSLOT];
                     Ahi[o] = pm_split(sr, si, &rr, &ri);
                     Alo[o] = pm_pack(rr, ri);
                     const float nr = fmaf(sr, Ec, -(si * Es)), ni = fmaf(sr, Es, si * Ec);
@@ -313,10 +318,10 @@ __global__ __launch_bounds__(PM_WAVES * 64, 2) void ps_mfma_kernel(PsMfmaParams 
             uint4 ra_hi = *reinterpret_cast<const uint4 *>(Ahi + rd0), ra_lo = *reinterpret_cast<const uint4 *>(Alo + rd0);
             uint4 rb_hi = *reinterpret_cast<const uint4 *>(Bhi + rd0), rb_lo = *reinterpret_cast<const uint4 *>(Blo + rd0);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < PM_CH / 8; ++s) {
                 const pm_half8 a_hi = __builtin_bit_cast(pm_half8, ra_hi), a_lo = __builtin_bit_cast(pm_half8, ra_lo);
                 const pm_half8 b_hi = __builtin_bit_cast(pm_half8, rb_hi), b_lo = __builtin_bit_cast(pm_half8, rb_lo);
-                if (s < 3) {
+                if (s + 1 < PM_CH / 8) {
                     const int o = rd0 ^ (8 * (s + 1));
                     ra_hi = *reinterpret_cast<const uint4 *>(Ahi + o);
                     ra_lo = *reinterpret_cast<const uint4 *>(Alo + o);
