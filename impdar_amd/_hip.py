@@ -67,6 +67,9 @@ SIGNATURES = {
     'impdar_stolt_dev': (_i, [_p, _p, _i, _i, _i, _dp, _dp, _d, _d, _d, _p]),
     'impdar_phaseshift': (_i, [_p, _p, _i, _i, _i, _i, _dp, _dp, _d, _dp, _d, _dp, _i, _d, _d, _p]),
     'impdar_phaseshift_dev': (_i, [_p, _p, _i, _i, _i, _i, _dp, _dp, _d, _dp, _d, _dp, _i, _d, _d, _p]),
+    'impdar_phaseshift_tk_dev': (_i, [_p, _p, _i, _i, _i, _i, _dp, _dp, _d, _dp, _d, _dp, _i, _d, _d, _i, _i, _p]),
+    'impdar_ps_alltoall_dev': (_i, [_p, _p, _i, _i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), _p]),
+    'impdar_phaseshift_finish_dev': (_i, [_p, _p, _i, _i, _i, _p]),
     'impdar_phaseshift_ffd': (_i, [_p, _dp, _i, _i, _i, _dp, _dp, _d, _dp, _dp, _d, _d, _d, _dp]),
     'impdar_taper': (_i, [_p, _p, _i, _i, _i, _d, _d]),
     'impdar_filtfilt': (_i, [_p, _p, _i, _i, _i, _dp, _dp, _i, _dp]),

@@ -38,7 +38,8 @@ def _get_args():
     parser_mig.add_argument('--tmig', type=int, default=0, help='Times for velocity profile')
     parser_mig.add_argument('--verbose', type=int, default=1, help='Print output from SeisUnix migration')
     parser_mig.add_argument('--gpus', type=int, default=0,
-                            help='(extension) shard a Kirchhoff migration over this many MI355X of the node '
+                            help='(extension) shard a Kirchhoff (output-trace blocks) or constant-v / v(z) phase-shift (wavenumber '
+                                 'slabs) migration over this many MI355X of the node '
                                  '(default: $IMPDAR_NGPUS, else one)')
     _add_def_args(parser_mig)
 

@@ -92,6 +92,30 @@ int impdar_exchange_ranges(impdar_ctx *ctx, void *image, int nsend, const int *s
     return IMPDAR_OK;
 }
 
+// Grouped point-to-point exchange between two buffers (the all-to-all of the kx-sharded phase shift): bytes
+// [soff[i], soff[i] + slen[i]) of `sendbuf` go to rank peer[i], bytes [roff[i], roff[i] + rlen[i]) of `recvbuf` come
+// from it; the block for this rank itself travels through RCCL as well (a device-local copy inside the group).
+int impdar_exchange_buffers(impdar_ctx *ctx, const void *sendbuf, void *recvbuf, int npeer, const int *peer, const size_t *soff,
+                            const size_t *slen, const size_t *roff, const size_t *rlen, hipStream_t stream)
+{
+    IMPDAR_ARG_CHECK(ctx && ctx->comm, "communicator not initialised (impdar_comm_init)");
+    ncclComm_t comm = reinterpret_cast<ncclComm_t>(ctx->comm);
+    for (int i = 0; i < npeer; ++i)
+        IMPDAR_ARG_CHECK(peer[i] >= 0 && peer[i] < ctx->nranks, "peer %d outside the communicator", peer[i]);
+    IMPDAR_NCCL_CHECK(ncclGroupStart());
+    ncclResult_t bad = ncclSuccess;
+    for (int i = 0; i < npeer && bad == ncclSuccess; ++i)
+        if (slen[i]) bad = ncclSend(reinterpret_cast<const char *>(sendbuf) + soff[i], slen[i], ncclChar, peer[i], comm, stream);
+    for (int i = 0; i < npeer && bad == ncclSuccess; ++i)
+        if (rlen[i]) bad = ncclRecv(reinterpret_cast<char *>(recvbuf) + roff[i], rlen[i], ncclChar, peer[i], comm, stream);
+    ncclResult_t end = ncclGroupEnd();
+    if (bad != ncclSuccess || end != ncclSuccess) {
+        impdar_set_error("grouped ncclSend/ncclRecv failed: %s", ncclGetErrorString(bad != ncclSuccess ? bad : end));
+        return IMPDAR_ERR_COMM;
+    }
+    return IMPDAR_OK;
+}
+
 extern "C" int impdar_comm_barrier(impdar_ctx *ctx)
 {
     IMPDAR_ARG_CHECK(ctx, "null context");

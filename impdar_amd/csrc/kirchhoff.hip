@@ -2318,7 +2318,10 @@ extern "C" int impdar_kirch_plan_kernel(const impdar_kirch_plan *p)
     return IMPDAR_KERNEL_EXACT_PAIR;
 }
 
-static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int jlo, int nloc, int precomputed)
+// `more`: further input traces of the radargram whose first traces an earlier prep took, AFTER a migrate that reads
+// only those has been enqueued (the pipelined one-shot call): same buffer set, and no wait for that migrate -- it does
+// not read the rows written here.
+static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int jlo, int nloc, int precomputed, bool more = false)
 {
     IMPDAR_ARG_CHECK(p && d_data, "null plan/data");
     IMPDAR_ARG_CHECK(jlo >= 0 && nloc >= 0 && jlo + nloc <= p->tnum_pad && ld >= nloc,
@@ -2326,7 +2329,9 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
                      p->tnum_pad);
     IMPDAR_HIP_CHECK(hipSetDevice(p->ctx->device));
     hipStream_t st = p->ctx->aux;
-    if (p->migrated_since_prep) {
+    if (more) {
+        p->migrated_since_prep = false;
+    } else if (p->migrated_since_prep) {
         // first prep after a migrate: a new radargram -> other buffer set, next event slot
         p->migrated_since_prep = false;
         p->buf ^= 1;
@@ -2337,7 +2342,7 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
     // the buffer set may still be read by the migrate of the radargram before last.  (The
     // input itself must already be complete: the upload entry points are blocking, and the
     // one-shot paths below synchronise their own copy before calling prep.)
-    if (p->free_recorded[b]) IMPDAR_HIP_CHECK(hipStreamWaitEvent(st, p->ev_free[b], 0));
+    if (p->free_recorded[b] && !more) IMPDAR_HIP_CHECK(hipStreamWaitEvent(st, p->ev_free[b], 0));
     // d_data may have been produced by a *_dev step (band pass, re-spacing, cast, another migration).  Those only
     // enqueue on the compute stream and mark the context (impdar_ctx_mark_produced): the producer stream waits
     // for the last such mark.  The mark sits in FRONT of any diffraction sum enqueued since, so the prep of
@@ -3083,7 +3088,7 @@ struct KirchOneShot {
     const impdar_ctx *owner = nullptr;
     impdar_kirch_plan *plan = nullptr;
     DevBuf din, dout;
-    hipEvent_t ev_half = nullptr;    // first output block of a split one-shot call summed (see impdar_kirchhoff)
+    hipEvent_t ev_blk[8] = {};       // output block i of a split one-shot call summed (see impdar_kirchhoff)
     int dtype = -1, snum = 0, tnum = 0, nearfield = 0, grad_uniform = 0, mode = 0;
     double vel = 0, grad_h = 0;
     std::vector<double> dist, tt, ga, gb, gc;
@@ -3094,8 +3099,10 @@ struct KirchOneShot {
         plan = nullptr;
         din.release();
         dout.release();
-        if (ev_half) (void)hipEventDestroy(ev_half);
-        ev_half = nullptr;
+        for (hipEvent_t &e : ev_blk) {
+            if (e) (void)hipEventDestroy(e);
+            e = nullptr;
+        }
         owner = nullptr;
     }
 };
@@ -3195,39 +3202,73 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
         return done(IMPDAR_ERR_HIP);
     }
     const auto t0b = now();
-    if (hipMemcpyAsync(c.din.p, data, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) {      // prep runs on the aux stream
-        impdar_set_error("H2D copy failed");
-        return done(IMPDAR_ERR_HIP);
-    }
-    const auto t1 = now();
-    if ((rc = impdar_kirch_prep(p, c.din.p, tnum, 0, tnum))) return done(rc);
-    auto t1b = t1;
-    // Large radargrams on the ring kernels: the output traces in two blocks (5/8 and 3/8), two launches, so that the
-    // first block crosses PCIe and is widened on the host while the second is summed (output blocks equal the whole
-    // image bit for bit: every output accumulates its pairs in the same order).  Two launches cost ~10 % more kernel
-    // time than one (each must drain); the download they hide is worth more.  IMPDAR_KIRCH_ONESHOT_SPLIT=0: one launch.
+    // Large radargrams on the ring kernels go through in pieces, so that PCIe and the kernels work at the same time.
+    // OUTPUT traces in blocks, one launch each (output blocks equal the whole image bit for bit: every output
+    // accumulates its pairs in the same order): a block crosses PCIe and is widened on the host while the next is
+    // summed.  INPUT traces in column chunks: block i reads the traces up to its right edge + the aperture half width
+    // only (the halo of the multi-GPU plan), so its launch starts when those are on the device and the rest of the
+    // upload runs under it; later chunks are prepared into the same image (kirch_prep_impl's `more`).  Every launch
+    // must drain (~0.3 ms each) -- the copies they hide are worth more.  Four blocks [0, .10, .45, .85, 1] tnum when
+    // the aperture leaves something to overlap (config 3: the first launch needs 45 % of the input), else two (5/8 +
+    // 3/8, download overlap only).  IMPDAR_KIRCH_ONESHOT_SPLIT=0: one upload, one launch, one download.
     const char *se = getenv("IMPDAR_KIRCH_ONESHOT_SPLIT");
     const int kern = impdar_kirch_plan_kernel(p);
     const bool split = !(se && atoi(se) == 0) && !timing && tnum >= 4096 && bytes >= ((size_t)64 << 20) &&
                        (kern == IMPDAR_KERNEL_QUAD || kern == IMPDAR_KERNEL_DQUAD);
+    auto t1 = t0b, t1b = t0b;
     if (split) {
-        const int mid = ((int)((long long)tnum * 5 / 8) / 8) * 8;
-        char *blk_a = reinterpret_cast<char *>(c.dout.p), *blk_b = blk_a + (size_t)snum * mid * esz;
-        if (!c.ev_half && hipEventCreateWithFlags(&c.ev_half, hipEventDisableTiming) != hipSuccess) {
-            c.ev_half = nullptr;
-            impdar_set_error("hipEventCreate failed");
+        const int halo = p->ntab + 16;                 // aperture half width (+ the kernels' staging look-ahead)
+        auto r8 = [](long long x) { return (int)(x / 8 * 8); };
+        std::vector<int> cut;
+        const bool two = se && atoi(se) == 2;          // the round-3 first form, kept for A/B
+        if (!two && (long long)tnum * 45 / 100 + halo < (long long)tnum * 9 / 10)
+            cut = {0, r8((long long)tnum / 10), r8((long long)tnum * 45 / 100), r8((long long)tnum * 85 / 100), tnum};
+        else
+            cut = {0, r8((long long)tnum * 5 / 8), tnum};
+        const int nblk = (int)cut.size() - 1;
+        for (int i = 0; i < nblk; ++i)
+            if (!c.ev_blk[i] && hipEventCreateWithFlags(&c.ev_blk[i], hipEventDisableTiming) != hipSuccess) {
+                c.ev_blk[i] = nullptr;
+                impdar_set_error("hipEventCreate failed");
+                return done(IMPDAR_ERR_HIP);
+            }
+        char *dout = reinterpret_cast<char *>(c.dout.p);
+        int have = 0;                                  // input traces [0, have) are on the device and prepared
+        for (int i = 0; i < nblk; ++i) {
+            const int need = two ? tnum : (int)std::min<long long>(tnum, ((long long)cut[i + 1] + halo + 7) / 8 * 8);
+            if (need > have) {
+                // column block [have, need) of the (snum, tnum) host array; on the producer stream, in front of its prep
+                if (hipMemcpy2DAsync(reinterpret_cast<char *>(c.din.p) + (size_t)have * esz, (size_t)tnum * esz,
+                                     reinterpret_cast<const char *>(data) + (size_t)have * esz, (size_t)tnum * esz,
+                                     (size_t)(need - have) * esz, (size_t)snum, hipMemcpyHostToDevice, ctx->aux) != hipSuccess) {
+                    impdar_set_error("H2D copy failed");
+                    return done(IMPDAR_ERR_HIP);
+                }
+                if ((rc = kirch_prep_impl(p, reinterpret_cast<const char *>(c.din.p) + (size_t)have * esz, tnum, have,
+                                          need - have, 0, have > 0)))
+                    return done(rc);
+                have = need;
+            }
+            if ((rc = impdar_kirch_migrate(p, dout + (size_t)snum * cut[i] * esz, cut[i], cut[i + 1]))) return done(rc);
+            if (hipEventRecord(c.ev_blk[i], ctx->stream) != hipSuccess) return done(IMPDAR_ERR_HIP);
+        }
+        // the blocks leave on the producer stream (idle after the last prep) as their launches finish, the last one
+        // on the compute stream
+        for (int i = 0; i < nblk; ++i) {
+            hipStream_t ds = i + 1 < nblk ? ctx->aux : ctx->stream;
+            if (i + 1 < nblk && hipStreamWaitEvent(ds, c.ev_blk[i], 0) != hipSuccess) return done(IMPDAR_ERR_HIP);
+            if ((rc = impdar_download_block_f64(ctx, out, (size_t)tnum, (size_t)cut[i], dout + (size_t)snum * cut[i] * esz, dtype,
+                                                (size_t)snum, (size_t)(cut[i + 1] - cut[i]), ds)))
+                return done(rc);
+        }
+    } else {
+        if (hipMemcpyAsync(c.din.p, data, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {      // prep runs on the aux stream
+            impdar_set_error("H2D copy failed");
             return done(IMPDAR_ERR_HIP);
         }
-        if ((rc = impdar_kirch_migrate(p, blk_a, 0, mid))) return done(rc);
-        if (hipEventRecord(c.ev_half, ctx->stream) != hipSuccess) return done(IMPDAR_ERR_HIP);
-        if ((rc = impdar_kirch_migrate(p, blk_b, mid, tnum))) return done(rc);
-        // block A leaves on the producer stream (idle since prep) as soon as its launch has finished
-        if (hipStreamWaitEvent(ctx->aux, c.ev_half, 0) != hipSuccess) return done(IMPDAR_ERR_HIP);
-        if ((rc = impdar_download_block_f64(ctx, out, (size_t)tnum, 0, blk_a, dtype, (size_t)snum, (size_t)mid, ctx->aux))) return done(rc);
-        if ((rc = impdar_download_block_f64(ctx, out, (size_t)tnum, (size_t)mid, blk_b, dtype, (size_t)snum, (size_t)(tnum - mid), ctx->stream)))
-            return done(rc);
-    } else {
+        t1 = t1b = now();
+        if ((rc = impdar_kirch_prep(p, c.din.p, tnum, 0, tnum))) return done(rc);
         if ((rc = impdar_kirch_migrate(p, c.dout.p, 0, tnum))) return done(rc);
         if (timing) {                                             // diagnostic only: the download below waits for the kernel anyway
             (void)hipStreamSynchronize(ctx->stream);

@@ -184,6 +184,9 @@ struct PsParams {
     // P.w is indexed by SLOT (the host uploads it in slot order).
     int nf, herm;
     int fstride;            // complex elements between the rows of F (nt; nt/2 + 1 when the time transform is real-to-complex)
+    int nk;                 // wavenumbers in this launch (tnum, or a rank's slab)
+    int k0;                 // first wavenumber of this launch (a rank's slab of a kx-sharded run; 0 otherwise): workgroup b
+                            // works on wavenumber k0 + b and writes row b of TK
 };
 
 // Why half of the frequencies are enough for a real radargram (mig_python.py:268-270, 282, 396-420, 438-487):
@@ -327,10 +330,10 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
     // ([m][thread], each thread reads only what it wrote): 2M registers too many, and recomputing it (fp64
     // divide + square root) at every anchor cost as much as the steps in between
     __shared__ double phd_lds[(VZ && sizeof(T) == 4) ? M * BLOCK : 1];
-    const int k = blockIdx.x;
+    const int k = P.k0 + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Cp<T> *F = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k * P.fstride;
-    Cp<T> *TK = reinterpret_cast<Cp<T> *>(P.TK) + (size_t)k * P.snum;
+    Cp<T> *TK = reinterpret_cast<Cp<T> *>(P.TK) + (size_t)(k - P.k0) * P.snum;
     const double kxk = P.kx[k];
 
     // float32 data: a multiplicative recurrence in fp32 drifts systematically (the rounded rotation is the
@@ -702,10 +705,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 && M == 8) ? IMPDAR_PS_VZ32_M8
     float(*red)[NW][2 * TT] = reinterpret_cast<float(*)[NW][2 * TT]>(ps_smem + (size_t)M * BLOCK * 16);
     // boundary frequencies in quiet tiles (see below): per-step corrections to the frequency sum, double-buffered over tiles
     float *corr = reinterpret_cast<float *>(ps_smem + (size_t)M * BLOCK * 16 + 2 * NW * 2 * TT * sizeof(float));   // [2][2 * TT]
-    const int k = P.rowmap ? P.rowmap[blockIdx.x] : (int)blockIdx.x;
+    const int k = P.rowmap ? P.rowmap[blockIdx.x] : P.k0 + (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Cp<float> *F = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.fstride;
-    Cp<float> *TK = reinterpret_cast<Cp<float> *>(P.TK) + (size_t)k * P.snum;
+    Cp<float> *TK = reinterpret_cast<Cp<float> *>(P.TK) + (size_t)(k - P.k0) * P.snum;
     const double kxk = P.kx[k];
     if (tid < 4 * TT) corr[tid] = 0.f;
 
@@ -1003,10 +1006,10 @@ __global__ __launch_bounds__(BLOCK) void ps_vz64_kernel(PsParams P)
     double *coef = reinterpret_cast<double *>(ps_smem);                                  // [M][BLOCK]
     double(*red)[NW][2 * TT] = reinterpret_cast<double(*)[NW][2 * TT]>(ps_smem + (size_t)M * BLOCK * 8);
     double *corr = reinterpret_cast<double *>(ps_smem + (size_t)M * BLOCK * 8 + 2 * NW * 2 * TT * sizeof(double));   // [2][2 * TT]
-    const int k = P.rowmap ? P.rowmap[blockIdx.x] : (int)blockIdx.x;
+    const int k = P.rowmap ? P.rowmap[blockIdx.x] : P.k0 + (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Cp<double> *F = reinterpret_cast<const Cp<double> *>(P.F) + (size_t)k * P.fstride;
-    Cp<double> *TK = reinterpret_cast<Cp<double> *>(P.TK) + (size_t)k * P.snum;
+    Cp<double> *TK = reinterpret_cast<Cp<double> *>(P.TK) + (size_t)(k - P.k0) * P.snum;
     const double kxk = P.kx[k];
     if (tid < 4 * TT) corr[tid] = 0.0;
 
@@ -1231,8 +1234,8 @@ __global__ __launch_bounds__(BLOCK) void ps_vz64_kernel(PsParams P)
 // step: TK[tau, k0] += FK[0, k0] e^{i (tau + 1) w0 dt} / snum (:415-420, :456-487, :492).  One thread per depth step,
 // after the frequency kernel has stored its sums.
 template <typename T>
-__global__ __launch_bounds__(256) void ps_dc_kernel(const Cp<T> *__restrict__ F, Cp<T> *__restrict__ TK, int k0, int fstride,
-                                                    int snum, double w0dt)
+__global__ __launch_bounds__(256) void ps_dc_kernel(const Cp<T> *__restrict__ F, Cp<T> *__restrict__ TK, int k0, int tk_row,
+                                                    int fstride, int snum, double w0dt)
 {
     const int tau = blockIdx.x * 256 + threadIdx.x;
     if (tau >= snum) return;
@@ -1240,7 +1243,7 @@ __global__ __launch_bounds__(256) void ps_dc_kernel(const Cp<T> *__restrict__ F,
     double sn, cs;
     sincos((double)(tau + 1) * w0dt, &sn, &cs);
     const double re = (double)f.x * cs - (double)f.y * sn, im = (double)f.x * sn + (double)f.y * cs;
-    Cp<T> *dst = TK + (size_t)k0 * snum + tau;
+    Cp<T> *dst = TK + (size_t)tk_row * snum + tau;
     dst->x += (T)(re / (double)snum);
     dst->y += (T)(im / (double)snum);
 }
@@ -1254,6 +1257,10 @@ struct PsPlan {
     FftPlan r_time, r_trace;             // Hermitian walk: real-to-complex along time (nt/2 + 1 rows), then over the traces
     bool r_ready = false, c_ready = false;
     DevBuf Xr;                           // ... its real input [tnum][nt]
+    FftPlan b_slab;                      // kx-sharded run: inverse transform over k of this rank's depth rows
+    int slab_key[3] = {-1, -1, -1};
+    const impdar_ctx *slab_owner = nullptr;
+    DevBuf d_sendbuf;                    // ... packed blocks of the all-to-all
     DevBuf d_blocks, d_edge, d_runtab;   // matrix-core path: row-block table; boundary-frequency counts + lists; per-run phases
     DevBuf X, TK, d_kx, d_w, d_vz, d_thr, d_sched, d_rowmap, d_eps;
 };
@@ -1291,7 +1298,7 @@ static void ps_launch(const PsParams &P, hipStream_t st)
         if (P.vz_mode && P.sched && !old_kernel) {
             auto k = ps_vz32_kernel<BLOCK, M>;
             (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vz32_lds);
-            hipLaunchKernelGGL(k, dim3(P.tnum), dim3(BLOCK), vz32_lds, st, P);
+            hipLaunchKernelGGL(k, dim3(P.nk), dim3(BLOCK), vz32_lds, st, P);
             return;
         }
     }
@@ -1301,14 +1308,14 @@ static void ps_launch(const PsParams &P, hipStream_t st)
         if (P.vz_mode && P.sched && P.eps && !old_kernel64) {
             auto k = ps_vz64_kernel<BLOCK, M>;
             (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vz64_lds);
-            hipLaunchKernelGGL(k, dim3(P.tnum), dim3(BLOCK), vz64_lds, st, P);
+            hipLaunchKernelGGL(k, dim3(P.nk), dim3(BLOCK), vz64_lds, st, P);
             return;
         }
     }
     if (P.vz_mode)
-        hipLaunchKernelGGL((ps_kernel<T, BLOCK, M, true>), dim3(P.tnum), dim3(BLOCK), 0, st, P);
+        hipLaunchKernelGGL((ps_kernel<T, BLOCK, M, true>), dim3(P.nk), dim3(BLOCK), 0, st, P);
     else
-        hipLaunchKernelGGL((ps_kernel<T, BLOCK, M, false>), dim3(P.tnum), dim3(BLOCK), 0, st, P);
+        hipLaunchKernelGGL((ps_kernel<T, BLOCK, M, false>), dim3(P.nk), dim3(BLOCK), 0, st, P);
 }
 
 template <typename T>
@@ -1396,13 +1403,13 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
     for (int r = 0; r < PM_MAX_RUNS; ++r) Q.long_of[r] = -1;
     for (int r = 0; r < Q.nruns; ++r)
         if (!(vz && runs[r].len <= PM_SHORT)) Q.long_of[r] = Q.nlong++;
-    IMPDAR_HIP_CHECK(pl.d_runtab.ensure((size_t)tnum * P.nf * Q.nlong * sizeof(double2)));
+    IMPDAR_HIP_CHECK(pl.d_runtab.ensure((size_t)P.nk * P.nf * Q.nlong * sizeof(double2)));
     Q.runtab = pl.d_runtab.as<double2>();
     {
         // set-up pass: per-run phases of every (wavenumber, frequency), boundary frequencies, the steps of the short runs
         const size_t lds = (size_t)P.nf * 24 + 8 * 2 * PM_SHORT * sizeof(float);
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_setup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(ps_setup_kernel, dim3(tnum), dim3(512), lds, st, Q);
+        hipLaunchKernelGGL(ps_setup_kernel, dim3(P.nk), dim3(512), lds, st, Q);
     }
     Q.stamps = nullptr;
     DevBuf d_stamps;
@@ -1414,8 +1421,8 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
     // (diagnostics: IMPDAR_PS_MFMA_ONE_WG=1 asks for 100 KB of LDS, i.e. one workgroup per CU instead of two)
     const size_t lds_bytes = getenv("IMPDAR_PS_MFMA_ONE_WG") ? std::max<size_t>(PM_LDS_BYTES, 100 * 1024) : PM_LDS_BYTES;
     IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(ps_mfma_kernel, dim3((unsigned)tnum * Q.ngroups), dim3(PM_WAVES * 64), lds_bytes, st, Q);
-    if (vz) hipLaunchKernelGGL(ps_edge_kernel, dim3(tnum), dim3(256), 0, st, Q);
+    hipLaunchKernelGGL(ps_mfma_kernel, dim3((unsigned)P.nk * Q.ngroups), dim3(PM_WAVES * 64), lds_bytes, st, Q);
+    if (vz) hipLaunchKernelGGL(ps_edge_kernel, dim3(P.nk), dim3(256), 0, st, Q);
     IMPDAR_HIP_CHECK(hipGetLastError());
     // the host table must outlive its async copy
     IMPDAR_HIP_CHECK(hipStreamSynchronize(st));
@@ -1436,8 +1443,11 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
 template <typename T>
 static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int tnum, int nt, const double *kx,
                   const double *ws, double dt, const double *tt_us, double vconst, const double *vmig, int vlen,
-                  double htaper, double vtaper, void *d_out)
+                  double htaper, double vtaper, void *d_out, int k0 = 0, int nk = -1, void *tk_out = nullptr)
 {
+    // tk_out != null: a rank of a kx-sharded run -- the transforms (replicated on every rank) and the frequency sums of
+    // wavenumbers [k0, k0 + nk) only, written to tk_out [nk][snum]; no inverse transform (impdar_phaseshift_finish_dev)
+    if (nk < 0) nk = tnum;
     hipStream_t st = ctx->stream;
     const bool dbl = sizeof(T) == 8;
     if (pl.owner != ctx || pl.dtype != (dbl ? IMPDAR_F64 : IMPDAR_F32) || pl.snum != snum || pl.tnum != tnum || pl.nt != nt) {
@@ -1448,6 +1458,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             pl.d_blocks.release();
             pl.d_edge.release();
             pl.d_runtab.release();
+            pl.d_sendbuf.release();
             pl.X.release(); pl.TK.release(); pl.d_kx.release(); pl.d_w.release(); pl.d_vz.release(); pl.d_thr.release();
             pl.d_sched.release();
             pl.d_rowmap.release();
@@ -1562,7 +1573,9 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     PsParams P;
     P.F = pl.X.p;
     P.fstride = fstride;
-    P.TK = pl.TK.p;
+    P.k0 = k0;
+    P.nk = nk;
+    P.TK = tk_out ? tk_out : pl.TK.p;
     P.kx = pl.d_kx.as<double>();
     P.w = pl.d_w.as<double>();
     P.vz = pl.d_vz.as<double>();
@@ -1635,7 +1648,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
                 if (sched[i]) runs.emplace_back(vmig[i], 0);
                 runs.back().second += 1;
             }
-            if (runs.size() <= 64 && tnum >= 512) {
+            if (runs.size() <= 64 && tnum >= 512 && nk == tnum) {      // (a slab of a sharded run keeps the natural order)
                 std::vector<double> aw(nt);
                 for (int j = 0; j < nt; ++j) aw[j] = std::fabs(ws[j] == 0.0 ? 1e-10 / dt : ws[j]);
                 std::sort(aw.begin(), aw.end());
@@ -1684,10 +1697,17 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     }
     if (!mfma_done && (rc = ps_dispatch<T>(P, st))) return rc;
     if (herm)
-        for (int k0 : k_zero)
-            hipLaunchKernelGGL((ps_dc_kernel<T>), dim3((snum + 255) / 256), dim3(256), 0, st, pl.X.as<Cp<T>>(),
-                               pl.TK.as<Cp<T>>(), k0, fstride, snum, w0 * dt);
+        for (int kz : k_zero)
+            if (kz >= k0 && kz < k0 + nk)
+                hipLaunchKernelGGL((ps_dc_kernel<T>), dim3((snum + 255) / 256), dim3(256), 0, st, pl.X.as<Cp<T>>(),
+                                   reinterpret_cast<Cp<T> *>(P.TK), kz, kz - k0, fstride, snum, w0 * dt);
     if ((rc = impdar_ctx_ktoc(ctx))) return rc;
+    if (tk_out) {
+        IMPDAR_HIP_CHECK(hipGetLastError());
+        if ((rc = impdar_ctx_toc(ctx))) return rc;
+        IMPDAR_HIP_CHECK(hipStreamSynchronize(st));
+        return IMPDAR_OK;
+    }
     if ((rc = pl.b_trace.exec(pl.TK.p, nullptr))) return rc;
     dim3 bgrid((tnum + 63) / 64, (snum + 63) / 64);
     hipLaunchKernelGGL((ps_real_transpose<T>), bgrid, dim3(256), 0, st, pl.TK.as<Cp<T>>(), (T *)d_out, snum, tnum);
@@ -1743,6 +1763,143 @@ extern "C" int impdar_phaseshift_dev(impdar_ctx *ctx, const void *d_data, int dt
                                        : ps_run<double>(ctx, *g_ps_plan, d_data, snum, tnum, nt, kx, ws, dt, tt_us, vconst, vmig,
                                                         vmig_len, htaper, vtaper, d_out);
     return rc ? rc : impdar_ctx_mark_produced(ctx);
+}
+
+// ---------------------------------------------------------------------------
+// Sharding over the wavenumbers (optional row): every wavenumber is independent in phaseShift
+// (mig_python.py:396-487), so rank r computes TK for its slab of k -- the cheap forward transforms are replicated on
+// every rank from the whole radargram --, the slabs are redistributed into depth-row slabs by one all-to-all, and
+// every rank finishes its rows with the inverse transform over k (:282).  Three calls per rank:
+//   impdar_phaseshift_tk_dev      d_tk [nk][snum] complex: frequency sums of wavenumbers [k0, k0 + nk)
+//   impdar_ps_alltoall_dev        d_tk -> d_t2 [tnum][tw] complex: ALL wavenumbers, this rank's depth rows [tau0, tau0 + tw)
+//   impdar_phaseshift_finish_dev  d_t2 -> d_out (tw, tnum) real: ifft over k, real part
+// ---------------------------------------------------------------------------
+extern "C" int impdar_phaseshift_tk_dev(impdar_ctx *ctx, const void *d_data, int dtype, int snum, int tnum, int nt,
+                                        const double *kx, const double *ws, double dt, const double *tt_us, double vconst,
+                                        const double *vmig, int vmig_len, double htaper, double vtaper, int k0, int nk,
+                                        void *d_tk)
+{
+    IMPDAR_ARG_CHECK(ctx && d_data && d_tk && kx && ws && tt_us, "null argument");
+    IMPDAR_ARG_CHECK(dtype == IMPDAR_F32 || dtype == IMPDAR_F64, "dtype must be 0 (f32) or 1 (f64)");
+    IMPDAR_ARG_CHECK(snum >= 1 && tnum >= 1 && nt >= snum, "bad sizes snum %d tnum %d nt %d", snum, tnum, nt);
+    IMPDAR_ARG_CHECK(k0 >= 0 && nk >= 0 && k0 + nk <= tnum, "wavenumber slab [%d, %d) outside [0, %d)", k0, k0 + nk, tnum);
+    IMPDAR_ARG_CHECK(vmig_len == 0 || (vmig_len == snum && vmig),
+                     "Interpolated velocity profile is not the length of the number of samples in a trace.");
+    if (nk == 0) return IMPDAR_OK;
+    IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> lk(g_ps_mu);
+    ImpdarBusy busy(t_ps_busy);
+    if (!g_ps_plan) g_ps_plan = new PsPlan();
+    const int rc = dtype == IMPDAR_F32 ? ps_run<float>(ctx, *g_ps_plan, d_data, snum, tnum, nt, kx, ws, dt, tt_us, vconst, vmig,
+                                                       vmig_len, htaper, vtaper, nullptr, k0, nk, d_tk)
+                                       : ps_run<double>(ctx, *g_ps_plan, d_data, snum, tnum, nt, kx, ws, dt, tt_us, vconst, vmig,
+                                                        vmig_len, htaper, vtaper, nullptr, k0, nk, d_tk);
+    return rc ? rc : impdar_ctx_mark_produced(ctx);
+}
+
+// rows [0, nk) x columns [tau0, tau0 + tw) of a [nk][snum] complex array -> contiguous [nk][tw]
+template <typename T>
+__global__ __launch_bounds__(256) void ps_pack_kernel(const Cp<T> *__restrict__ src, Cp<T> *__restrict__ dst, int nk, int snum,
+                                                      int tau0, int tw)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)nk * tw) return;
+    const size_t r = i / tw, j = i % tw;
+    dst[i] = src[r * snum + tau0 + j];
+}
+
+// defined in comm.hip
+int impdar_exchange_buffers(impdar_ctx *ctx, const void *sendbuf, void *recvbuf, int npeer, const int *peer, const size_t *soff,
+                            const size_t *slen, const size_t *roff, const size_t *rlen, hipStream_t stream);
+
+// `tau_edges` / `k_edges`: nranks + 1 edges of the depth-row and wavenumber slabs (the same on every rank).  Rank r
+// sends block (its k slab) x (depth slab of s) to every rank s and receives (k slab of s) x (its depth slab), which
+// lands at row k_edges[s] of d_t2 [tnum][tw]: the k-major layout the inverse transform wants, no unpacking.
+extern "C" int impdar_ps_alltoall_dev(impdar_ctx *ctx, const void *d_tk, int dtype, int snum, int tnum, int nranks, int rank,
+                                      const int *tau_edges, const int *k_edges, void *d_t2)
+{
+    IMPDAR_ARG_CHECK(ctx && d_tk && d_t2 && tau_edges && k_edges, "null argument");
+    IMPDAR_ARG_CHECK(dtype == IMPDAR_F32 || dtype == IMPDAR_F64, "dtype must be 0 (f32) or 1 (f64)");
+    IMPDAR_ARG_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d of %d", rank, nranks);
+    IMPDAR_ARG_CHECK(tau_edges[0] == 0 && tau_edges[nranks] == snum && k_edges[0] == 0 && k_edges[nranks] == tnum,
+                     "slab edges must run from 0 to snum / tnum");
+    for (int s = 0; s < nranks; ++s)
+        IMPDAR_ARG_CHECK(tau_edges[s + 1] >= tau_edges[s] && k_edges[s + 1] >= k_edges[s], "slab edges must not decrease");
+    IMPDAR_ARG_CHECK(nranks == 1 || (ctx->comm && ctx->nranks == nranks), "communicator of %d ranks needed", nranks);
+    IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t esz = 2 * impdar_dtype_size(dtype);
+    const int nk = k_edges[rank + 1] - k_edges[rank], tw = tau_edges[rank + 1] - tau_edges[rank];
+    std::lock_guard<std::mutex> lk(g_ps_mu);
+    ImpdarBusy busy(t_ps_busy);
+    if (!g_ps_plan) g_ps_plan = new PsPlan();
+    PsPlan &pl = *g_ps_plan;
+    IMPDAR_HIP_CHECK(pl.d_sendbuf.ensure(std::max<size_t>((size_t)nk * snum * esz, 16)));
+    std::vector<int> peer(nranks);
+    std::vector<size_t> soff(nranks), slen(nranks), roff(nranks), rlen(nranks);
+    size_t at = 0;
+    for (int s = 0; s < nranks; ++s) {
+        const int tws = tau_edges[s + 1] - tau_edges[s], nks = k_edges[s + 1] - k_edges[s];
+        peer[s] = s;
+        soff[s] = at;
+        slen[s] = (size_t)nk * tws * esz;
+        roff[s] = (size_t)k_edges[s] * tw * esz;
+        rlen[s] = (size_t)nks * tw * esz;
+        if (nk > 0 && tws > 0) {
+            const unsigned grid = (unsigned)(((size_t)nk * tws + 255) / 256);
+            if (dtype == IMPDAR_F32)
+                hipLaunchKernelGGL((ps_pack_kernel<float>), dim3(grid), dim3(256), 0, st, (const Cp<float> *)d_tk,
+                                   reinterpret_cast<Cp<float> *>(pl.d_sendbuf.as<char>() + at), nk, snum, tau_edges[s], tws);
+            else
+                hipLaunchKernelGGL((ps_pack_kernel<double>), dim3(grid), dim3(256), 0, st, (const Cp<double> *)d_tk,
+                                   reinterpret_cast<Cp<double> *>(pl.d_sendbuf.as<char>() + at), nk, snum, tau_edges[s], tws);
+        }
+        at += slen[s];
+    }
+    IMPDAR_HIP_CHECK(hipGetLastError());
+    int rc;
+    if (ctx->comm) {
+        if ((rc = impdar_exchange_buffers(ctx, pl.d_sendbuf.p, d_t2, nranks, peer.data(), soff.data(), slen.data(), roff.data(),
+                                          rlen.data(), st)))
+            return rc;
+    } else {
+        // one rank, no communicator: the only block goes to itself
+        IMPDAR_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(d_t2) + roff[0], pl.d_sendbuf.as<char>() + soff[0], slen[0],
+                                        hipMemcpyDeviceToDevice, st));
+    }
+    IMPDAR_HIP_CHECK(hipStreamSynchronize(st));
+    return impdar_ctx_mark_produced(ctx);
+}
+
+extern "C" int impdar_phaseshift_finish_dev(impdar_ctx *ctx, void *d_t2, int dtype, int tw, int tnum, void *d_out)
+{
+    IMPDAR_ARG_CHECK(ctx && d_t2 && d_out, "null argument");
+    IMPDAR_ARG_CHECK(dtype == IMPDAR_F32 || dtype == IMPDAR_F64, "dtype must be 0 (f32) or 1 (f64)");
+    IMPDAR_ARG_CHECK(tw >= 0 && tnum >= 1, "bad sizes tw %d tnum %d", tw, tnum);
+    if (tw == 0) return IMPDAR_OK;
+    IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> lk(g_ps_mu);
+    ImpdarBusy busy(t_ps_busy);
+    if (!g_ps_plan) g_ps_plan = new PsPlan();
+    PsPlan &pl = *g_ps_plan;
+    const bool dbl = dtype == IMPDAR_F64;
+    hipStream_t st = ctx->stream;
+    int rc;
+    if (pl.slab_key[0] != dtype || pl.slab_key[1] != tw || pl.slab_key[2] != tnum || pl.slab_owner != ctx) {
+        const rocfft_array_type ci = rocfft_array_type_complex_interleaved;
+        if ((rc = pl.b_slab.create(rocfft_transform_type_complex_inverse, dbl, true, tnum, tw, ci, ci, tw, 1, tw, 1, 1.0 / tnum, st)))
+            return rc;
+        pl.slab_key[0] = dtype, pl.slab_key[1] = tw, pl.slab_key[2] = tnum;
+        pl.slab_owner = ctx;
+    }
+    if ((rc = pl.b_slab.exec(d_t2, nullptr))) return rc;                  // ifft over k (:282)
+    dim3 bgrid((tnum + 63) / 64, (tw + 63) / 64);
+    if (dbl)
+        hipLaunchKernelGGL((ps_real_transpose<double>), bgrid, dim3(256), 0, st, (const Cp<double> *)d_t2, (double *)d_out, tw, tnum);
+    else
+        hipLaunchKernelGGL((ps_real_transpose<float>), bgrid, dim3(256), 0, st, (const Cp<float> *)d_t2, (float *)d_out, tw, tnum);
+    IMPDAR_HIP_CHECK(hipGetLastError());
+    return impdar_ctx_mark_produced(ctx);
 }
 
 // ===========================================================================

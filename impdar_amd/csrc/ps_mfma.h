@@ -160,10 +160,10 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
     const PsParams &P = Q.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = wave & (PM_NQ - 1), part = wave / PM_NQ;
-    const int g = (int)blockIdx.x % Q.ngroups, k = (int)blockIdx.x / Q.ngroups;
+    const int g = (int)blockIdx.x % Q.ngroups, kb = (int)blockIdx.x / Q.ngroups, k = P.k0 + kb;
     const int om = lane % PM_CH, hh = lane / PM_CH;      // frequency of the chunk; which of its PM_NSUB generating lanes
     const Cp<float> *Frow = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.fstride;
-    float *TKrow = reinterpret_cast<float *>(reinterpret_cast<Cp<float> *>(P.TK) + (size_t)k * P.snum);
+    float *TKrow = reinterpret_cast<float *>(reinterpret_cast<Cp<float> *>(P.TK) + (size_t)kb * P.snum);
 
     // ---- scale of the row: the largest component into [2^11, 2^12)
     float sigma;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
     int blong[PM_NRB];
 #pragma unroll
     for (int rb = 0; rb < PM_NRB; ++rb) blong[rb] = brun[rb] >= 0 ? Q.long_of[brun[rb]] : 0;
-    const double2 *tab = Q.runtab + (size_t)k * P.nf * Q.nlong;
+    const double2 *tab = Q.runtab + (size_t)kb * P.nf * Q.nlong;
     // the next round's spectrum and run entries are requested a round ahead
     Cp<float> f_next = ps_load_slot<float>(Frow, P, q * PM_CH + om);
     double2 t_next[PM_NRB];
@@ -374,14 +374,14 @@ __global__ __launch_bounds__(512) void ps_setup_kernel(PsMfmaParams Q)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned pm_lds[];
     const PsParams &P = Q.P;
-    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = P.k0 + (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *phi = reinterpret_cast<double *>(pm_lds);                       // [nf] phase at the start of the current run
     double *rws = phi + P.nf;                                               // [nf] 1 / w
     float2 *f0 = reinterpret_cast<float2 *>(rws + P.nf);                    // [nf] spectrum, zero once out
     float *red = reinterpret_cast<float *>(f0 + P.nf);                      // [8][2 * PM_SHORT]
     const Cp<float> *Frow = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.fstride;
-    float *TKrow = reinterpret_cast<float *>(reinterpret_cast<Cp<float> *>(P.TK) + (size_t)k * P.snum);
-    double2 *tab = Q.runtab + (size_t)k * P.nf * Q.nlong;
+    float *TKrow = reinterpret_cast<float *>(reinterpret_cast<Cp<float> *>(P.TK) + (size_t)(k - P.k0) * P.snum);
+    double2 *tab = Q.runtab + (size_t)(k - P.k0) * P.nf * Q.nlong;
     const double kxk = P.kx[k];
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     if (!Q.vz) {
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(512) void ps_setup_kernel(PsMfmaParams Q)
 __global__ __launch_bounds__(256) void ps_edge_kernel(PsMfmaParams Q)
 {
     const PsParams &P = Q.P;
-    const int k = blockIdx.x, tid = threadIdx.x;
+    const int k = P.k0 + (int)blockIdx.x, tid = threadIdx.x;
     int n = Q.edge_cnt[k];
     if (n <= 0) return;
     n = min(n, PM_EMAX);
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void ps_edge_kernel(PsMfmaParams Q)
     }
     __syncthreads();
     const Cp<float> *Frow = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.fstride;
-    Cp<float> *TKrow = reinterpret_cast<Cp<float> *>(P.TK) + (size_t)k * P.snum;
+    Cp<float> *TKrow = reinterpret_cast<Cp<float> *>(P.TK) + (size_t)(k - P.k0) * P.snum;
     const double kxk = P.kx[k];
     const int seg = (P.snum + 255) / 256;
     const int lo = min(tid * seg, P.snum), hi = min(lo + seg, P.snum);

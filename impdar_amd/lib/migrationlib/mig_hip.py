@@ -188,15 +188,18 @@ def migrationStolt(dat, vel=1.68e8, htaper=100, vtaper=1000):
 # ---------------------------------------------------------------------------
 # phase shift
 # ---------------------------------------------------------------------------
-def migrationPhaseShift(dat, vel=1.69e8, vel_fn=None, htaper=100, vtaper=1000, **genfromtxt_kwargs):
+def migrationPhaseShift(dat, vel=1.69e8, vel_fn=None, htaper=100, vtaper=1000, ngpus=None, **genfromtxt_kwargs):
     """Phase-shift (Gazdag) migration (mig_python.py:211-287; kernel semantics
     :361-493).  Constant ``vel``, a 2-column (v, z) table or a 3-column
     (v, z, x) table / ``vel_fn`` file; the last runs the 2-D v(x, z) Fourier
-    finite-difference branch (:428-432, 448-487, 496-540) in float64."""
-    return _phase_shift(dat, vel, vel_fn, htaper, vtaper, genfromtxt_kwargs, None)
+    finite-difference branch (:428-432, 448-487, 496-540) in float64.
+
+    ``ngpus`` (extension; default ``$IMPDAR_NGPUS``): above 1 the constant-velocity and v(z) forms are sharded
+    over the wavenumbers on that many GPUs (``impdar_amd.parallel.run_sharded_phaseshift``)."""
+    return _phase_shift(dat, vel, vel_fn, htaper, vtaper, genfromtxt_kwargs, None, ngpus)
 
 
-def _phase_shift(dat, vel, vel_fn, htaper, vtaper, genfromtxt_kwargs, dev):
+def _phase_shift(dat, vel, vel_fn, htaper, vtaper, genfromtxt_kwargs, dev, ngpus=None):
     """``dev``: None -> ``dat.data`` (host); a resident DeviceArray -> migrated where it is, the result
     replaces ``dat._dev`` (constant v and 1-D v(z); the 2-D branch goes through the host)."""
     print('Phase-Shift Migration of %.0fx%.0f matrix' % (dat.snum, dat.tnum))
@@ -212,8 +215,12 @@ def _phase_shift(dat, vel, vel_fn, htaper, vtaper, genfromtxt_kwargs, dev):
         # the reference's in-place ``dat.data *= H*V`` (:258) cannot cast float -> int
         raise TypeError("Cannot cast ufunc 'multiply' output from dtype('float64') to dtype('%s') "
                         "with casting rule 'same_kind'" % src_dtype)
-    lib = _hip.load()
-    ctx = _hip.context() if dev is None else dev.ctx
+    from ... import parallel
+    ngpus = (parallel.ngpus_requested() if ngpus is None else int(ngpus)) if dev is None else 0
+    lib = None if ngpus > 1 else _hip.load()
+    # with ngpus > 1 the ranks are child processes, one per device: this process stays off the GPU until it is
+    # known that the run is not sharded (the 2-D branch)
+    ctx = None if ngpus > 1 else (_hip.context() if dev is None else dev.ctx)
     if dev is None:
         data, code = _device_data(dat.data)
     else:
@@ -244,6 +251,8 @@ def _phase_shift(dat, vel, vel_fn, htaper, vtaper, genfromtxt_kwargs, dev):
                 raise ValueError('2-D velocity array must have shape (snum, tnum)')
             if dev is not None:
                 dat.from_device()
+            lib = _hip.load()
+            ctx = _hip.context() if ctx is None else ctx
             d64 = np.ascontiguousarray(dat.data, dtype=np.float64)
             out = np.empty((dat.snum, dat.tnum), dtype=np.float64)
             tt_us, p_tt = _hip.as_dp(dat.travel_time)
@@ -264,6 +273,13 @@ def _phase_shift(dat, vel, vel_fn, htaper, vtaper, genfromtxt_kwargs, dev):
         vconst = 0.0
         vm, p_vm = _hip.as_dp(vmig)
         vlen = dat.snum
+    if ngpus > 1:
+        dat.data = parallel.run_sharded_phaseshift(data, nt, kx, ws, float(dat.dt), dat.travel_time, vconst, vm,
+                                                   htaper, vtaper, ngpus=ngpus)
+        print('')
+        print('Phase-Shift Migration of %.0fx%.0f matrix complete in %.2f seconds on %d GPUs'
+              % (dat.snum, dat.tnum, time.time() - start, ngpus))
+        return dat
     tt_us, p_tt = _hip.as_dp(dat.travel_time)
     _, p_kx = _hip.as_dp(kx)
     _, p_ws = _hip.as_dp(ws)

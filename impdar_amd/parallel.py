@@ -544,6 +544,130 @@ HipEngine.run_once = _hip_run_once
 
 
 # ---------------------------------------------------------------------------------------------------------
+# phase shift sharded over the wavenumbers
+# ---------------------------------------------------------------------------------------------------------
+def slab_edges(n, nranks):
+    """``nranks + 1`` edges of near-equal contiguous slabs of ``range(n)`` (the wavenumber and the depth-row
+    slabs of the sharded phase shift: every wavenumber costs the same, mig_python.py:396-487)."""
+    return [n * r // nranks for r in range(nranks + 1)]
+
+
+def alltoall_layout(tau_edges, k_edges, rank, itemsize):
+    """Byte layout of one rank's all-to-all (what ``impdar_ps_alltoall_dev`` does on the device; the CPU stand-in
+    of the tests follows the same table).  Rank ``r`` holds TK rows of its wavenumbers ``[k_edges[r], k_edges[r+1])``
+    over ALL depth rows; it sends to rank ``s`` the columns of s's depth slab, packed one block per peer, and
+    receives from ``s`` the rows ``[k_edges[s], k_edges[s+1])`` of its own [tnum][tw] array: k-major, ready for
+    the inverse transform over k (:282).  Returns ``(send, recv)``: lists of ``(peer, offset, nbytes)``."""
+    nranks = len(k_edges) - 1
+    nk = k_edges[rank + 1] - k_edges[rank]
+    tw = tau_edges[rank + 1] - tau_edges[rank]
+    send, recv, at = [], [], 0
+    for s in range(nranks):
+        n = nk * (tau_edges[s + 1] - tau_edges[s]) * itemsize
+        send.append((s, at, n))
+        at += n
+        recv.append((s, k_edges[s] * tw * itemsize, (k_edges[s + 1] - k_edges[s]) * tw * itemsize))
+    return send, recv
+
+
+class ShardedPhaseShift(object):
+    """One rank of a phase-shift (Gazdag) migration sharded over the wavenumbers on ``world`` GPUs.  Every rank
+    holds the whole radargram (the forward transforms are a few percent of the work and are replicated), sums the
+    frequencies of its wavenumber slab, the slabs are redistributed into depth-row slabs by one all-to-all and
+    every rank finishes rows ``[tau_lo, tau_hi)`` of the image.  Constant velocity and v(z) (mig_python.py:396-446);
+    the 2-D v(x, z) branch is not sharded."""
+
+    def __init__(self, ctx, snum, tnum, nt, kx, ws, dt, travel_time_us, vconst, vmig, htaper, vtaper, rank, world,
+                 dtype=np.float32, engine=None):
+        self.rank, self.world = int(rank), int(world)
+        self.snum, self.tnum, self.nt, self.dtype = int(snum), int(tnum), int(nt), np.dtype(dtype)
+        self.k_edges = slab_edges(self.tnum, self.world)
+        self.tau_edges = slab_edges(self.snum, self.world)
+        self.k_lo, self.k_hi = self.k_edges[self.rank], self.k_edges[self.rank + 1]
+        self.tau_lo, self.tau_hi = self.tau_edges[self.rank], self.tau_edges[self.rank + 1]
+        self.args = dict(kx=np.ascontiguousarray(kx, dtype=np.float64), ws=np.ascontiguousarray(ws, dtype=np.float64),
+                         dt=float(dt), travel_time=np.ascontiguousarray(travel_time_us, dtype=np.float64),
+                         vconst=float(vconst),
+                         vmig=None if vmig is None else np.ascontiguousarray(vmig, dtype=np.float64),
+                         htaper=float(htaper), vtaper=float(vtaper))
+        if self.args['vmig'] is not None and len(self.args['vmig']) != self.snum:
+            raise ValueError('Interpolated velocity profile is not the length of the number of samples in a trace.')
+        self.engine = engine if engine is not None else HipPhaseShiftEngine(ctx)
+
+    def run(self, data):
+        """``data``: the whole (snum, tnum) radargram.  Returns this rank's rows ``[tau_lo, tau_hi)`` of the
+        migrated image, (tau_hi - tau_lo, tnum) in ``data``'s dtype."""
+        data = np.ascontiguousarray(data)
+        if data.shape != (self.snum, self.tnum):
+            raise ValueError('The input array must be of size (snum, tnum)')
+        return self.engine.run(self, data)
+
+
+class HipPhaseShiftEngine(object):
+    """The device side of ``ShardedPhaseShift``: ``impdar_phaseshift_tk_dev`` -> ``impdar_ps_alltoall_dev`` (grouped
+    RCCL send/recv inside the library) -> ``impdar_phaseshift_finish_dev``."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def run(self, sp, data):
+        import ctypes as C
+        from . import _hip
+        lib = _hip.load()
+        ctx, a = self.ctx, sp.args
+        code = _hip.dtype_code(sp.dtype)
+        cdt = np.complex64 if sp.dtype == np.float32 else np.complex128
+        nk, tw = sp.k_hi - sp.k_lo, sp.tau_hi - sp.tau_lo
+        d_in = _hip.DeviceArray.from_host(ctx, data.astype(sp.dtype, copy=False))
+        d_tk = _hip.DeviceArray(ctx, (max(nk, 1), sp.snum), cdt)
+        d_t2 = _hip.DeviceArray(ctx, (sp.tnum, max(tw, 1)), cdt)
+        d_out = _hip.DeviceArray(ctx, (max(tw, 1), sp.tnum), sp.dtype)
+        try:
+            p_vm = _hip.as_dp(a['vmig'])[1] if a['vmig'] is not None else None
+            rc = lib.impdar_phaseshift_tk_dev(ctx, d_in.ptr, code, sp.snum, sp.tnum, sp.nt, _hip.as_dp(a['kx'])[1],
+                                              _hip.as_dp(a['ws'])[1], a['dt'], _hip.as_dp(a['travel_time'])[1],
+                                              a['vconst'], p_vm, 0 if a['vmig'] is None else sp.snum, a['htaper'],
+                                              a['vtaper'], sp.k_lo, nk, d_tk.ptr)
+            _hip.check(rc, 'impdar_phaseshift_tk_dev')
+            ia = (C.c_int * (sp.world + 1))
+            rc = lib.impdar_ps_alltoall_dev(ctx, d_tk.ptr, code, sp.snum, sp.tnum, sp.world, sp.rank,
+                                            ia(*sp.tau_edges), ia(*sp.k_edges), d_t2.ptr)
+            _hip.check(rc, 'impdar_ps_alltoall_dev')
+            rc = lib.impdar_phaseshift_finish_dev(ctx, d_t2.ptr, code, tw, sp.tnum, d_out.ptr)
+            _hip.check(rc, 'impdar_phaseshift_finish_dev')
+            _hip.check(lib.impdar_ctx_sync(ctx), 'impdar_ctx_sync')
+            return d_out.to_host()[:tw]
+        finally:
+            for d in (d_in, d_tk, d_t2, d_out):
+                d.free()
+
+
+def migrate_phaseshift_sharded(data, geometry, vconst=1.69e8, vmig=None, htaper=100, vtaper=1000, rdv=None, ctx=None,
+                               engine=None):
+    """Collective: every rank calls this with the WHOLE (snum, tnum) radargram and gets back
+    ``(tau_lo, tau_hi, rows)``: the depth rows of the migrated image it owns, in ``data``'s dtype.
+
+    ``geometry``: dict(snum, tnum, nt, kx, ws, dt, travel_time [us]) as migrationPhaseShift builds them
+    (mig_python.py:246-263).  ``vmig``: None (constant ``vconst``) or the (snum,) profile of getVelocityProfile."""
+    from . import _hip
+    own_rdv = rdv is None
+    rdv = Rendezvous() if rdv is None else rdv
+    if engine is None:
+        _hip.load()
+        ctx = _hip.context() if ctx is None else ctx
+        if rdv.world > 1 and not _hip.load().impdar_comm_size(ctx) == rdv.world:
+            init_communicator(ctx, rdv)
+    g = geometry
+    sp = ShardedPhaseShift(ctx, g['snum'], g['tnum'], g['nt'], g['kx'], g['ws'], g['dt'], g['travel_time'], vconst, vmig,
+                           htaper, vtaper, rdv.rank, rdv.world, np.asarray(data).dtype, engine)
+    rows = sp.run(data)
+    rdv.barrier()
+    if own_rdv:
+        rdv.close()
+    return sp.tau_lo, sp.tau_hi, rows
+
+
+# ---------------------------------------------------------------------------------------------------------
 # single-process front door: one worker per GPU
 # ---------------------------------------------------------------------------------------------------------
 def ngpus_requested():
@@ -602,34 +726,58 @@ def shard_timeout():
         return 1800.0
 
 
-def run_sharded(data, dist_km, travel_time_us, vel=1.69e8, nearfield=False, ngpus=2, mode='auto', timeout=None):
-    """Migrate a host radargram on ``ngpus`` GPUs from a single process: the radargram and the result live in a
-    private (mode 0700, ``mkdtemp``) directory of /dev/shm, one worker process per GPU
-    (``impdar_amd._shard_worker``) runs ``migrate_kirchhoff_sharded`` on its shard.  A worker that fails (among
-    others: ``ngpus`` larger than the number of visible GPUs) or a job that exceeds ``timeout`` seconds raises here
-    instead of hanging.  Returns the float64 migrated array like migrationKirchhoff (mig_python.py:118)."""
-    data = np.ascontiguousarray(data)
-    if data.dtype not in (np.float32, np.float64):
-        data = data.astype(np.float64)
+def _run_workers(kind, data, arrays, meta, ngpus, timeout):
+    """The job directory of ``run_sharded`` / ``run_sharded_phaseshift``: a private (mode 0700, ``mkdtemp``)
+    directory of /dev/shm holding the radargram, the geometry arrays (plain ``.npy``), ``meta.json`` and the
+    float64 result the workers fill; one worker process per GPU (``impdar_amd._shard_worker``)."""
     snum, tnum = data.shape
     ngpus = int(ngpus)
     if ngpus < 1:
         raise ValueError('ngpus must be at least 1, got %d' % ngpus)
     shm = '/dev/shm' if os.path.isdir('/dev/shm') else tempfile.gettempdir()
     base = tempfile.mkdtemp(prefix='impdar_shard_', dir=shm)
-    f_in, f_out, f_meta = os.path.join(base, 'in.npy'), os.path.join(base, 'out.npy'), os.path.join(base, 'meta.json')
+    f_out = os.path.join(base, 'out.npy')
     try:
-        np.save(f_in, data)
-        np.save(os.path.join(base, 'dist.npy'), np.asarray(dist_km, dtype=np.float64))
-        np.save(os.path.join(base, 'travel_time.npy'), np.asarray(travel_time_us, dtype=np.float64))
+        np.save(os.path.join(base, 'in.npy'), data)
+        for name, a in arrays.items():
+            np.save(os.path.join(base, name + '.npy'), np.asarray(a, dtype=np.float64))
         out = np.lib.format.open_memmap(f_out, mode='w+', dtype=np.float64, shape=(snum, tnum))
         del out
-        with open(f_meta, 'w') as fo:
-            json.dump(dict(snum=snum, tnum=tnum, vel=float(vel), nearfield=bool(nearfield), mode=str(mode)), fo)
+        with open(os.path.join(base, 'meta.json'), 'w') as fo:
+            json.dump(dict(meta, kind=kind, snum=snum, tnum=tnum), fo)
         codes = spawn_ranks([sys.executable, '-m', 'impdar_amd._shard_worker', base], ngpus,
                             timeout=shard_timeout() if timeout is None else timeout)
         if any(codes):
-            raise RuntimeError('sharded Kirchhoff migration failed: worker exit codes %s' % codes)
+            raise RuntimeError('sharded %s migration failed: worker exit codes %s' % (kind, codes))
         return np.array(np.load(f_out, mmap_mode='r', allow_pickle=False))
     finally:
         shutil.rmtree(base, ignore_errors=True)
+
+
+def _host_radargram(data):
+    data = np.ascontiguousarray(data)
+    if data.dtype not in (np.float32, np.float64):
+        data = data.astype(np.float64)
+    return data
+
+
+def run_sharded(data, dist_km, travel_time_us, vel=1.69e8, nearfield=False, ngpus=2, mode='auto', timeout=None):
+    """Migrate a host radargram on ``ngpus`` GPUs from a single process: one worker process per GPU runs
+    ``migrate_kirchhoff_sharded`` on its shard (``_run_workers``).  A worker that fails (among others: ``ngpus``
+    larger than the number of visible GPUs) or a job that exceeds ``timeout`` seconds raises here instead of
+    hanging.  Returns the float64 migrated array like migrationKirchhoff (mig_python.py:118)."""
+    return _run_workers('Kirchhoff', _host_radargram(data), dict(dist=dist_km, travel_time=travel_time_us),
+                        dict(vel=float(vel), nearfield=bool(nearfield), mode=str(mode)), ngpus, timeout)
+
+
+def run_sharded_phaseshift(data, nt, kx, ws, dt, travel_time_us, vconst=1.69e8, vmig=None, htaper=100, vtaper=1000,
+                           ngpus=2, timeout=None):
+    """Phase-shift migration of a host radargram on ``ngpus`` GPUs from a single process: one worker per GPU runs
+    ``migrate_phaseshift_sharded`` (wavenumber slabs -> all-to-all -> depth-row slabs).  Returns the float64
+    migrated array like migrationPhaseShift (mig_python.py:282)."""
+    arrays = dict(kx=kx, ws=ws, travel_time=travel_time_us)
+    if vmig is not None:
+        arrays['vmig'] = vmig
+    return _run_workers('phase-shift', _host_radargram(data), arrays,
+                        dict(nt=int(nt), dt=float(dt), vconst=float(vconst), has_vmig=vmig is not None,
+                             htaper=float(htaper), vtaper=float(vtaper)), ngpus, timeout)

@@ -187,6 +187,18 @@ int impdar_phaseshift_dev(impdar_ctx *ctx, const void *d_data, int dtype, int sn
                           int nt, const double *kx, const double *ws, double dt,
                           const double *tt_us, double vconst, const double *vmig, int vmig_len,
                           double htaper, double vtaper, void *d_out);
+/* Phase shift sharded over the wavenumbers (every k is independent in phaseShift, mig_python.py:396-487):
+ * a rank calls, on the whole radargram resident on its device,
+ *   impdar_phaseshift_tk_dev      -> d_tk [nk][snum] complex: TK (already / snum, :492) of wavenumbers [k0, k0 + nk)
+ *   impdar_ps_alltoall_dev        -> d_t2 [tnum][tw] complex: all wavenumbers, its own depth rows (grouped RCCL
+ *                                    send/recv; tau_edges / k_edges: nranks + 1 slab edges, the same on every rank)
+ *   impdar_phaseshift_finish_dev  -> d_out (tw, tnum) real: ifft over k, real part (:282); d_t2 is overwritten */
+int impdar_phaseshift_tk_dev(impdar_ctx *ctx, const void *d_data, int dtype, int snum, int tnum, int nt,
+                             const double *kx, const double *ws, double dt, const double *tt_us, double vconst,
+                             const double *vmig, int vmig_len, double htaper, double vtaper, int k0, int nk, void *d_tk);
+int impdar_ps_alltoall_dev(impdar_ctx *ctx, const void *d_tk, int dtype, int snum, int tnum, int nranks, int rank,
+                           const int *tau_edges, const int *k_edges, void *d_t2);
+int impdar_phaseshift_finish_dev(impdar_ctx *ctx, void *d_t2, int dtype, int tw, int tnum, void *d_out);
 
 /* ---- phase shift, 2-D v(x,z): Fourier finite-difference branch ----------
  * Replaces the `hasattr(vmig[itau], "__len__")` path of phaseShift

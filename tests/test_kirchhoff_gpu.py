@@ -204,29 +204,38 @@ def test_native_hook_at_config3_size(hip, tnum):
     assert min(walls) < 0.150
 
 
+@pytest.mark.parametrize('dx', [1.0, 4.0])
 @pytest.mark.parametrize('dtype', [np.float32, np.float64])
-def test_one_shot_in_two_output_blocks_equals_one_launch(hip, monkeypatch, dtype):
-    """Large radargrams through the one-shot entry point (RadarData.migrate on host arrays) are summed in two
-    output-trace blocks so that the first crosses PCIe while the second is computed; the result must equal the
-    single launch bit for bit (IMPDAR_KIRCH_ONESHOT_SPLIT=0), and the oracle on spot traces."""
+def test_one_shot_in_pieces_equals_one_launch(hip, monkeypatch, dtype, dx):
+    """Large radargrams through the one-shot entry point (RadarData.migrate on host arrays) go through in pieces:
+    output-trace blocks, one launch each, so that a block crosses PCIe while the next is computed, and -- when the
+    aperture is narrow enough to leave something (dx = 4 m here: four blocks, three input chunks; dx = 1 m: the
+    aperture spans the profile, two blocks, one upload) -- input-trace chunks uploaded under the launches that do not
+    need them.  The result must equal the single upload / launch / download bit for bit
+    (IMPDAR_KIRCH_ONESHOT_SPLIT=0) and the two-block form (=2), and the oracle on spot traces."""
     from impdar_amd import synth
     from impdar_amd.lib.RadarData import RadarData
     from oracle import c_oracle
     snum, tnum, vel = 4096, 4104, 1.69e8
-    geo = synth.geometry(snum, tnum)
-    x = synth.diffractor_radargram(snum, tnum, vel=vel, ndiff=16).astype(dtype)
+    geo = synth.geometry(snum, tnum, dx=dx)
+    x = synth.diffractor_radargram(snum, tnum, vel=vel, ndiff=16, dx=dx).astype(dtype)
     outs = {}
-    for split in ('1', '0', '1'):
+    for split in ('1', '0', '2', '1'):
         monkeypatch.setenv('IMPDAR_KIRCH_ONESHOT_SPLIT', split)
-        monkeypatch.setenv('IMPDAR_KIRCH_ONESHOT_CACHE', '0')        # a fresh plan per call: the knob is read per call anyway
+        # a fresh plan for the first three calls (the knob is read per call anyway), the cached one for the last
+        monkeypatch.setenv('IMPDAR_KIRCH_ONESHOT_CACHE', '0' if len(outs) < 2 else '1')
         d = RadarData(None)
         d.data, d.snum, d.tnum = x.copy(), snum, tnum
         d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
         d.migrate('kirch', vel=vel)
         assert d.data.dtype == np.float64 and d.data.shape == (snum, tnum)
         outs.setdefault(split, []).append(d.data)
+    monkeypatch.setenv('IMPDAR_KIRCH_ONESHOT_CACHE', '0')
     assert np.array_equal(outs['1'][0], outs['0'][0]) and np.array_equal(outs['1'][0], outs['1'][1])
-    cols = np.array([0, 7, 2559, 2560, 2561, 2567, 4103])            # both sides of the cut (5/8 of 4104, in whole groups of 8: 2560)
+    assert np.array_equal(outs['2'][0], outs['0'][0])
+    # both sides of the output cuts (dx 4: 408, 1840, 3488; dx 1: 5/8 of 4104 in whole groups of 8 = 2560) and of the
+    # input chunk edges of the dx = 4 run (408 / 1840 + the 865-trace aperture + margin, in groups of 8)
+    cols = np.array([0, 7, 407, 408, 1296, 1839, 1840, 2559, 2560, 2561, 2728, 3487, 3488, 4103])
     want = c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], vel, False, traces=cols)
     got = outs['1'][0][:, cols]
     if dtype == np.float64:

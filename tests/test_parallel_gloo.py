@@ -49,6 +49,56 @@ def test_sharded_kirchhoff_gloo_spawned(world, mode, tnum, dx, capfd):
         assert ('mode=halo' if mode == 'auto' else 'mode=allgather') in out.out
 
 
+PS_WORKER = os.path.join(ROOT, 'tests', '_gloo_ps_worker.py')
+
+
+def test_sharded_phase_shift_gloo_under_torchrun():
+    """Wavenumber slabs -> all-to-all -> depth-row slabs at world size 2, launched like bench.py."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
+    env.pop('IMPDAR_RDV_JOB', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), PS_WORKER, 'vz', '64', '45']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert 'GLOO_PS_OK world=2 kind=vz' in out.stdout
+
+
+@pytest.mark.parametrize('world,kind,snum,tnum', [(3, 'const', 50, 37), (3, 'vz', 64, 90), (4, 'vz', 33, 3)])
+def test_sharded_phase_shift_gloo_spawned(world, kind, snum, tnum, capfd):
+    """... and at 3 and 4 ranks from the product's spawner; 3 wavenumbers on 4 ranks leaves one rank an empty
+    wavenumber slab (it still finishes its depth rows)."""
+    codes = parallel.spawn_ranks([sys.executable, PS_WORKER, kind, str(snum), str(tnum)], world,
+                                 env_extra=dict(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
+                                                OMP_NUM_THREADS='1'), timeout=600)
+    out = capfd.readouterr()
+    assert codes == [0] * world, out.out[-2000:] + out.err[-4000:]
+    assert 'GLOO_PS_OK world=%d kind=%s' % (world, kind) in out.out
+
+
+def test_alltoall_layout_is_a_permutation_of_the_blocks():
+    """Every (wavenumber slab) x (depth slab) block is sent once and received once, sizes agree pairwise, and each
+    rank's send and receive buffers are covered exactly."""
+    for snum, tnum, world in ((50, 37, 3), (7, 2, 4), (4096, 4096, 8), (1, 1, 2)):
+        te, ke = parallel.slab_edges(snum, world), parallel.slab_edges(tnum, world)
+        assert te[0] == 0 and te[-1] == snum and ke[0] == 0 and ke[-1] == tnum
+        assert max(np.diff(te)) - min(np.diff(te)) <= 1 and max(np.diff(ke)) - min(np.diff(ke)) <= 1
+        plans = [parallel.alltoall_layout(te, ke, r, 8) for r in range(world)]
+        for r, (send, recv) in enumerate(plans):
+            assert [p for p, _, _ in send] == list(range(world)) == [p for p, _, _ in recv]
+            at = 0
+            for _, off, n in send:
+                assert off == at
+                at += n
+            assert at == (ke[r + 1] - ke[r]) * snum * 8
+            at = 0
+            for _, off, n in recv:
+                assert off == at
+                at += n
+            assert at == tnum * (te[r + 1] - te[r]) * 8
+            for s in range(world):
+                assert send[s][2] == plans[s][1][r][2]
+
+
 def test_exchange_plan_properties():
     """plan_exchange: every row a block's aperture reaches is either the rank's own or received exactly once;
     point-to-point ranges by default (config 4 on 8 GPUs receives a third of the image, config 3 on 8 GPUs nearly
