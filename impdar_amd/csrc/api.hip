@@ -294,6 +294,99 @@ int impdar_download_block_f64(impdar_ctx *ctx, double *dst_host, size_t ld, size
     return impdar_download_piped(ctx, dst_host, src_dev, rows * width, 4, true, st, width, ld, col0);
 }
 
+// Several (rows x width[i]) device blocks of `dtype` into columns [col0[i], col0[i] + width[i]) of ONE (rows x ld) float64
+// host array, each as soon as `after[i]` (the event behind the kernel that produces it) has passed: all copies are
+// enqueued on `st` at once, in pieces, and the host threads widen piece k while the DMA of piece k + 1 (of this block
+// or the next) runs -- the pipelined one-shot Kirchhoff call's way out.
+int impdar_download_blocks_f64(impdar_ctx *ctx, double *dst_host, size_t ld, size_t rows, int dtype, int nblk,
+                               const size_t *col0, const size_t *width, const void *const *src, const hipEvent_t *after,
+                               hipStream_t st)
+{
+    const size_t elem_in = impdar_dtype_size(dtype);
+    const bool widen = dtype == IMPDAR_F32;
+    size_t total = 0;
+    for (int i = 0; i < nblk; ++i) total += rows * width[i] * elem_in;
+    if (total == 0) return IMPDAR_OK;
+    std::unique_lock<std::mutex> lock(ctx->pinned_mu);
+    char *stage = reinterpret_cast<char *>(impdar_ctx_pinned(ctx, total));
+    if (!stage) {
+        // no pinned memory: block by block through the single-block path
+        lock.unlock();
+        for (int i = 0; i < nblk; ++i) {
+            if (after[i]) IMPDAR_HIP_CHECK(hipStreamWaitEvent(st, after[i], 0));
+            const int rc = impdar_download_block_f64(ctx, dst_host, ld, col0[i], src[i], dtype, rows, width[i], st);
+            if (rc) return rc;
+        }
+        return IMPDAR_OK;
+    }
+    struct Piece {
+        int blk;
+        size_t r0, nr, off;
+        hipEvent_t ev;
+    };
+    std::vector<Piece> pieces;
+    int rc = IMPDAR_OK;
+    size_t off = 0;
+    for (int i = 0; i < nblk && rc == IMPDAR_OK; ++i) {
+        if (width[i] == 0) continue;
+        const size_t bytes = rows * width[i] * elem_in;
+        // pieces of >= 16 MB, at most 4 per block: every piece costs a start of the host threads
+        const size_t np = std::min<size_t>(4, std::max<size_t>(1, bytes / ((size_t)16 << 20)));
+        if (after[i] && hipStreamWaitEvent(st, after[i], 0) != hipSuccess) rc = IMPDAR_ERR_HIP;
+        for (size_t c = 0; c < np && rc == IMPDAR_OK; ++c) {
+            Piece q;
+            q.blk = i;
+            q.r0 = rows * c / np;
+            q.nr = rows * (c + 1) / np - q.r0;
+            q.off = off;
+            q.ev = nullptr;
+            const size_t pb = q.nr * width[i] * elem_in;
+            if (hipEventCreateWithFlags(&q.ev, hipEventDisableTiming) != hipSuccess) {
+                rc = IMPDAR_ERR_HIP;
+                break;
+            }
+            pieces.push_back(q);
+            if (hipMemcpyAsync(stage + off, reinterpret_cast<const char *>(src[i]) + q.r0 * width[i] * elem_in, pb,
+                               hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipEventRecord(q.ev, st) != hipSuccess)
+                rc = IMPDAR_ERR_HIP;
+            off += pb;
+        }
+    }
+    for (const Piece &q : pieces) {
+        if (rc == IMPDAR_OK && hipEventSynchronize(q.ev) != hipSuccess) rc = IMPDAR_ERR_HIP;
+        if (rc == IMPDAR_OK) {
+            const size_t w = width[q.blk], c0 = col0[q.blk], r0 = q.r0;
+            const char *sp = stage + q.off;
+            impdar_parallel_for(q.nr, 1, [=](size_t a, size_t b) {
+                for (size_t r = a; r < b; ++r) {
+                    const char *s = sp + r * w * elem_in;
+                    double *d = dst_host + (r0 + r) * ld + c0;
+                    if (widen) {
+                        const float *f = reinterpret_cast<const float *>(s);
+                        for (size_t j = 0; j < w; ++j) d[j] = (double)f[j];
+                    } else {
+                        memcpy(d, s, w * 8);
+                    }
+                }
+            });
+        }
+    }
+    if (rc) {
+        // no DMA into the staging buffer may still be in flight when it is handed to the next caller
+        (void)hipStreamSynchronize(st);
+        impdar_set_error("device -> host copy failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    for (const Piece &q : pieces)
+        if (q.ev) (void)hipEventDestroy(q.ev);
+    if (ctx->pinned_bytes > ((size_t)1 << 30)) {
+        (void)hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+    }
+    return rc;
+}
+
 extern "C" int impdar_dev_download_f64(impdar_ctx *ctx, double *dst_host, const void *src_dev, int dtype, size_t n)
 {
     IMPDAR_ARG_CHECK(ctx && dst_host && src_dev, "impdar_dev_download_f64: null argument");

@@ -59,6 +59,11 @@ int impdar_download(impdar_ctx *ctx, void *host_dst, const void *dev_src, size_t
 int impdar_download_block_f64(impdar_ctx *ctx, double *dst_host, size_t ld, size_t col0, const void *src_dev, int dtype,
                               size_t rows, size_t width, hipStream_t st);
 
+// several output-trace blocks of one image, each after its own event, copies and host widening pipelined across blocks
+int impdar_download_blocks_f64(impdar_ctx *ctx, double *dst_host, size_t ld, size_t rows, int dtype, int nblk,
+                               const size_t *col0, const size_t *width, const void *const *src, const hipEvent_t *after,
+                               hipStream_t st);
+
 void impdar_set_error(const char *fmt, ...);
 
 #define IMPDAR_HIP_CHECK(expr)                                                        \

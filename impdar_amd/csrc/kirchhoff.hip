@@ -3208,12 +3208,13 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
     // summed.  INPUT traces in column chunks: block i reads the traces up to its right edge + the aperture half width
     // only (the halo of the multi-GPU plan), so its launch starts when those are on the device and the rest of the
     // upload runs under it; later chunks are prepared into the same image (kirch_prep_impl's `more`).  Every launch
-    // must drain (~0.3 ms each) -- the copies they hide are worth more.  Four blocks [0, .10, .45, .85, 1] tnum when
-    // the aperture leaves something to overlap (config 3: the first launch needs 45 % of the input), else two (5/8 +
-    // 3/8, download overlap only).  IMPDAR_KIRCH_ONESHOT_SPLIT=0: one upload, one launch, one download.
+    // must drain (~0.3 ms each) -- the copies they hide are worth more.  Four blocks [0, .10, .40, .70, 1] tnum when
+    // the aperture leaves something to overlap (config 3: the first launch needs 45 % of the input; a sweep of the
+    // cuts is in profiles/r03_oneshot_pipeline.txt), else two (5/8 + 3/8, download overlap only).
+    // IMPDAR_KIRCH_ONESHOT_SPLIT=0: one upload, one launch, one download; =2: one upload, two launches.
     const char *se = getenv("IMPDAR_KIRCH_ONESHOT_SPLIT");
     const int kern = impdar_kirch_plan_kernel(p);
-    const bool split = !(se && atoi(se) == 0) && !timing && tnum >= 4096 && bytes >= ((size_t)64 << 20) &&
+    const bool split = !(se && atoi(se) == 0) && (!timing || getenv("IMPDAR_TIMING_SPLIT")) && tnum >= 4096 && bytes >= ((size_t)64 << 20) &&
                        (kern == IMPDAR_KERNEL_QUAD || kern == IMPDAR_KERNEL_DQUAD);
     auto t1 = t0b, t1b = t0b;
     if (split) {
@@ -3221,10 +3222,28 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
         auto r8 = [](long long x) { return (int)(x / 8 * 8); };
         std::vector<int> cut;
         const bool two = se && atoi(se) == 2;          // the round-3 first form, kept for A/B
-        if (!two && (long long)tnum * 45 / 100 + halo < (long long)tnum * 9 / 10)
-            cut = {0, r8((long long)tnum / 10), r8((long long)tnum * 45 / 100), r8((long long)tnum * 85 / 100), tnum};
-        else
+        // IMPDAR_KIRCH_ONESHOT_CUTS="10,40,70": the interior cuts in percent of tnum (tuning knob; up to 7 blocks)
+        std::vector<int> pct = {10, 40, 70};
+        if (const char *ce2 = getenv("IMPDAR_KIRCH_ONESHOT_CUTS")) {
+            std::vector<int> q;
+            for (const char *c = ce2; *c;) {
+                char *end = nullptr;
+                const long v = strtol(c, &end, 10);
+                if (end == c) break;
+                q.push_back((int)v);
+                c = *end == ',' ? end + 1 : end;
+            }
+            bool ok = !q.empty() && q.size() <= 6 && q.front() > 0 && q.back() < 100;
+            for (size_t i = 1; i < q.size(); ++i) ok = ok && q[i] > q[i - 1];
+            if (ok) pct = q;
+        }
+        if (!two && (long long)tnum * pct[pct.size() > 1 ? 1 : 0] / 100 + halo < (long long)tnum * 9 / 10) {
+            cut = {0};
+            for (int q : pct) cut.push_back(r8((long long)tnum * q / 100));
+            cut.push_back(tnum);
+        } else {
             cut = {0, r8((long long)tnum * 5 / 8), tnum};
+        }
         const int nblk = (int)cut.size() - 1;
         for (int i = 0; i < nblk; ++i)
             if (!c.ev_blk[i] && hipEventCreateWithFlags(&c.ev_blk[i], hipEventDisableTiming) != hipSuccess) {
@@ -3234,6 +3253,13 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
             }
         char *dout = reinterpret_cast<char *>(c.dout.p);
         int have = 0;                                  // input traces [0, have) are on the device and prepared
+        std::string trace;                             // IMPDAR_TIMING: host time at which each stage's call returned
+        auto stamp = [&](const char *what, int i) {
+            if (!timing) return;
+            char buf[64];
+            snprintf(buf, sizeof buf, " %s%d %.2f", what, i, ms(t0b, now()));
+            trace += buf;
+        };
         for (int i = 0; i < nblk; ++i) {
             const int need = two ? tnum : (int)std::min<long long>(tnum, ((long long)cut[i + 1] + halo + 7) / 8 * 8);
             if (need > have) {
@@ -3248,19 +3274,29 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
                                           need - have, 0, have > 0)))
                     return done(rc);
                 have = need;
+                stamp("up", i);
             }
             if ((rc = impdar_kirch_migrate(p, dout + (size_t)snum * cut[i] * esz, cut[i], cut[i + 1]))) return done(rc);
             if (hipEventRecord(c.ev_blk[i], ctx->stream) != hipSuccess) return done(IMPDAR_ERR_HIP);
+            stamp("launch", i);
         }
-        // the blocks leave on the producer stream (idle after the last prep) as their launches finish, the last one
-        // on the compute stream
-        for (int i = 0; i < nblk; ++i) {
-            hipStream_t ds = i + 1 < nblk ? ctx->aux : ctx->stream;
-            if (i + 1 < nblk && hipStreamWaitEvent(ds, c.ev_blk[i], 0) != hipSuccess) return done(IMPDAR_ERR_HIP);
-            if ((rc = impdar_download_block_f64(ctx, out, (size_t)tnum, (size_t)cut[i], dout + (size_t)snum * cut[i] * esz, dtype,
-                                                (size_t)snum, (size_t)(cut[i + 1] - cut[i]), ds)))
+        // the blocks leave on the producer stream (idle after the last prep) as their launches finish: all copies
+        // enqueued at once, the host widens what has arrived
+        {
+            std::vector<size_t> col0(nblk), width(nblk);
+            std::vector<const void *> src(nblk);
+            for (int i = 0; i < nblk; ++i) {
+                col0[i] = (size_t)cut[i];
+                width[i] = (size_t)(cut[i + 1] - cut[i]);
+                src[i] = dout + (size_t)snum * cut[i] * esz;
+            }
+            if ((rc = impdar_download_blocks_f64(ctx, out, (size_t)tnum, (size_t)snum, dtype, nblk, col0.data(), width.data(),
+                                                 src.data(), c.ev_blk, ctx->aux)))
                 return done(rc);
+            stamp("down", nblk - 1);
         }
+        if (timing) fprintf(stderr, "impdar_kirchhoff pieces (ms since the first copy):%s\n", trace.c_str());
+        t1 = t1b = now();
     } else {
         if (hipMemcpyAsync(c.din.p, data, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) {      // prep runs on the aux stream
@@ -3281,8 +3317,8 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
     const auto t2 = now();
     rc = done(IMPDAR_OK);
     if (timing)
-        fprintf(stderr, "impdar_kirchhoff: %s, plan+alloc %.2f ms, H2D %.2f ms, prep+migrate %.2f ms, D2H+convert %.2f ms, release %.2f ms\n",
-                hit ? "cached plan" : "new plan", ms(t0, t0b), ms(t0b, t1), ms(t1, t1b), ms(t1b, t2), ms(t2, now()));
+        fprintf(stderr, "impdar_kirchhoff: %s, plan+alloc %.2f ms, H2D %.2f ms, prep+migrate %.2f ms, D2H+convert %.2f ms, release %.2f ms, call %.2f ms\n",
+                hit ? "cached plan" : "new plan", ms(t0, t0b), ms(t0b, t1), ms(t1, t1b), ms(t1b, t2), ms(t2, now()), ms(t0, now()));
     return rc;
 }
 
