@@ -91,6 +91,38 @@ __global__ __launch_bounds__(256) void ps_taper_inplace(T *__restrict__ d, int s
 }
 
 // Z[tnum][snum] complex -> out (snum,tnum) real part
+// out[c][r] = in[r][c] for a (rows x cols) complex array: the transforms over the traces / wavenumbers run on
+// contiguous rows of the transposed array.  rocFFT's own strided plans for the same transform (stride = row length,
+// distance 1) take 1.77 ms at 8192 x 8192 complex64 where this transpose + a contiguous plan take 0.25 + 0.23 ms
+// (profiles/r03_fft_strided_probe.txt).
+template <typename T, int TS>
+__global__ __launch_bounds__(256) void ps_transpose_c(const Cp<T> *__restrict__ in, Cp<T> *__restrict__ out, int rows, int cols)
+{
+    __shared__ Cp<T> tile[TS][TS + 1];
+    const int c0 = blockIdx.x * TS, r0 = blockIdx.y * TS;
+    const int tx = threadIdx.x % TS, ty = threadIdx.x / TS;
+    for (int r = ty; r < TS; r += 256 / TS)
+        if (r0 + r < rows && c0 + tx < cols) tile[r][tx] = in[(size_t)(r0 + r) * cols + c0 + tx];
+    __syncthreads();
+    for (int c = ty; c < TS; c += 256 / TS)
+        if (c0 + c < cols && r0 + tx < rows) out[(size_t)(c0 + c) * rows + r0 + tx] = tile[tx][c];
+}
+
+template <typename T> static void ps_launch_transpose(const void *in, void *out, int rows, int cols, hipStream_t st)
+{
+    constexpr int TS = sizeof(T) == 4 ? 64 : 32;
+    hipLaunchKernelGGL((ps_transpose_c<T, TS>), dim3((cols + TS - 1) / TS, (rows + TS - 1) / TS), dim3(256), 0, st,
+                       reinterpret_cast<const Cp<T> *>(in), reinterpret_cast<Cp<T> *>(out), rows, cols);
+}
+
+// out[i] = Re Z[i] (mig_python.py:282 keeps the real part of the inverse transform)
+template <typename T>
+__global__ __launch_bounds__(256) void ps_real_part(const Cp<T> *__restrict__ Z, T *__restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = Z[i].x;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void ps_real_transpose(const Cp<T> *__restrict__ Z, T *__restrict__ out, int snum,
                                                          int tnum)
@@ -1254,13 +1286,14 @@ struct PsPlan {
     int dtype = -1, snum = 0, tnum = 0, nt = 0;
     const impdar_ctx *owner = nullptr;   // plans and buffers live on this context's device and stream
     FftPlan f_time, f_trace, b_trace;
+    bool rows_form = true;               // b_trace / r_trace / b_slab run on contiguous rows of transposed arrays (else rocFFT's strided plans)
     FftPlan r_time, r_trace;             // Hermitian walk: real-to-complex along time (nt/2 + 1 rows), then over the traces
     bool r_ready = false, c_ready = false;
     DevBuf Xr;                           // ... its real input [tnum][nt]
     FftPlan b_slab;                      // kx-sharded run: inverse transform over k of this rank's depth rows
     int slab_key[3] = {-1, -1, -1};
     const impdar_ctx *slab_owner = nullptr;
-    DevBuf d_sendbuf;                    // ... packed blocks of the all-to-all
+    DevBuf d_sendbuf, d_slab;            // ... packed blocks of the all-to-all; the transposed slab
     DevBuf d_blocks, d_edge, d_runtab;   // matrix-core path: row-block table; boundary-frequency counts + lists; per-run phases
     DevBuf X, TK, d_kx, d_w, d_vz, d_thr, d_sched, d_rowmap, d_eps;
 };
@@ -1450,7 +1483,12 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     if (nk < 0) nk = tnum;
     hipStream_t st = ctx->stream;
     const bool dbl = sizeof(T) == 8;
-    if (pl.owner != ctx || pl.dtype != (dbl ? IMPDAR_F64 : IMPDAR_F32) || pl.snum != snum || pl.tnum != tnum || pl.nt != nt) {
+    // IMPDAR_PS_FFT=strided: the transforms over the traces / wavenumbers as rocFFT's strided plans on the arrays as
+    // they lie (rounds 1-3a); default: transpose, contiguous plan, transpose (see ps_transpose_c)
+    const char *fe = getenv("IMPDAR_PS_FFT");
+    const bool rows_form = !(fe && strcmp(fe, "strided") == 0);
+    if (pl.owner != ctx || pl.dtype != (dbl ? IMPDAR_F64 : IMPDAR_F32) || pl.snum != snum || pl.tnum != tnum || pl.nt != nt ||
+        pl.rows_form != rows_form) {
         pl.dtype = -1;
         pl.r_ready = pl.c_ready = false;
         if (pl.owner != ctx) {               // another device / stream: drop everything bound to the old one
@@ -1459,6 +1497,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             pl.d_edge.release();
             pl.d_runtab.release();
             pl.d_sendbuf.release();
+            pl.d_slab.release();
             pl.X.release(); pl.TK.release(); pl.d_kx.release(); pl.d_w.release(); pl.d_vz.release(); pl.d_thr.release();
             pl.d_sched.release();
             pl.d_rowmap.release();
@@ -1468,8 +1507,11 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         int rc;
         const rocfft_array_type ci = rocfft_array_type_complex_interleaved;
         pl.c_ready = false;              // the forward transforms are made on first use (below): which pair depends on the walk
-        if ((rc = pl.b_trace.create(rocfft_transform_type_complex_inverse, dbl, true, tnum, snum, ci, ci, snum, 1, snum, 1,
-                                    1.0 / tnum, st)))
+        pl.rows_form = rows_form;
+        if ((rc = rows_form ? pl.b_trace.create(rocfft_transform_type_complex_inverse, dbl, true, tnum, snum, ci, ci, 1, tnum, 1, tnum,
+                                                1.0 / tnum, st)
+                            : pl.b_trace.create(rocfft_transform_type_complex_inverse, dbl, true, tnum, snum, ci, ci, snum, 1, snum, 1,
+                                                1.0 / tnum, st)))
             return rc;
         IMPDAR_HIP_CHECK(pl.X.ensure((size_t)tnum * nt * 2 * sizeof(T)));
         IMPDAR_HIP_CHECK(pl.TK.ensure((size_t)tnum * snum * 2 * sizeof(T)));
@@ -1530,8 +1572,10 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             if ((rc = pl.r_time.create(rocfft_transform_type_real_forward, dbl, false, nt, tnum, rocfft_array_type_real,
                                        rocfft_array_type_hermitian_interleaved, 1, nt, 1, fstride, 1.0, st)))
                 return rc;
-            if ((rc = pl.r_trace.create(rocfft_transform_type_complex_forward, dbl, true, tnum, fstride, ci, ci, fstride, 1,
-                                        fstride, 1, 1.0, st)))
+            if ((rc = pl.rows_form ? pl.r_trace.create(rocfft_transform_type_complex_forward, dbl, true, tnum, fstride, ci, ci, 1, tnum,
+                                                       1, tnum, 1.0, st)
+                                   : pl.r_trace.create(rocfft_transform_type_complex_forward, dbl, true, tnum, fstride, ci, ci, fstride, 1,
+                                                       fstride, 1, 1.0, st)))
                 return rc;
             pl.r_ready = true;
         }
@@ -1563,7 +1607,16 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         hipLaunchKernelGGL((ps_taper_pad_transpose_real<T>), tgrid, dim3(256), 0, st, (const T *)d_data, pl.Xr.as<T>(), snum,
                            tnum, nt, htaper, vtaper);
         if ((rc = pl.r_time.exec(pl.Xr.p, pl.X.p))) return rc;
-        if ((rc = pl.r_trace.exec(pl.X.p, nullptr))) return rc;
+        if (pl.rows_form) {
+            // over the traces on contiguous rows: X [x][fstride] -> [fstride][x] (pl.TK is free until the frequency sums
+            // write it, and large enough: snum > nt / 2), transform, and back -> X [k][fstride]
+            ps_launch_transpose<T>(pl.X.p, pl.TK.p, tnum, fstride, st);
+            if ((rc = pl.r_trace.exec(pl.TK.p, nullptr))) return rc;
+            ps_launch_transpose<T>(pl.TK.p, pl.X.p, fstride, tnum, st);
+            IMPDAR_HIP_CHECK(hipGetLastError());
+        } else if ((rc = pl.r_trace.exec(pl.X.p, nullptr))) {
+            return rc;
+        }
     } else {
         hipLaunchKernelGGL((ps_taper_pad_transpose<T>), tgrid, dim3(256), 0, st, (const T *)d_data, pl.X.as<Cp<T>>(), snum,
                            tnum, nt, htaper, vtaper);
@@ -1708,9 +1761,18 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         IMPDAR_HIP_CHECK(hipStreamSynchronize(st));
         return IMPDAR_OK;
     }
-    if ((rc = pl.b_trace.exec(pl.TK.p, nullptr))) return rc;
-    dim3 bgrid((tnum + 63) / 64, (snum + 63) / 64);
-    hipLaunchKernelGGL((ps_real_transpose<T>), bgrid, dim3(256), 0, st, pl.TK.as<Cp<T>>(), (T *)d_out, snum, tnum);
+    if (pl.rows_form) {
+        // inverse over k on contiguous rows: TK [k][tau] -> [tau][k] (pl.X: the spectrum is not needed any more, and
+        // nt >= snum), transform, real part (:282) -- already (snum, tnum)
+        ps_launch_transpose<T>(pl.TK.p, pl.X.p, tnum, snum, st);
+        if ((rc = pl.b_trace.exec(pl.X.p, nullptr))) return rc;
+        const size_t n = (size_t)snum * tnum;
+        hipLaunchKernelGGL((ps_real_part<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pl.X.as<Cp<T>>(), (T *)d_out, n);
+    } else {
+        if ((rc = pl.b_trace.exec(pl.TK.p, nullptr))) return rc;
+        dim3 bgrid((tnum + 63) / 64, (snum + 63) / 64);
+        hipLaunchKernelGGL((ps_real_transpose<T>), bgrid, dim3(256), 0, st, pl.TK.as<Cp<T>>(), (T *)d_out, snum, tnum);
+    }
     IMPDAR_HIP_CHECK(hipGetLastError());
     if ((rc = impdar_ctx_toc(ctx))) return rc;
     // host staging vectors (w, thr) must outlive the async copies
@@ -1887,17 +1949,23 @@ extern "C" int impdar_phaseshift_finish_dev(impdar_ctx *ctx, void *d_t2, int dty
     int rc;
     if (pl.slab_key[0] != dtype || pl.slab_key[1] != tw || pl.slab_key[2] != tnum || pl.slab_owner != ctx) {
         const rocfft_array_type ci = rocfft_array_type_complex_interleaved;
-        if ((rc = pl.b_slab.create(rocfft_transform_type_complex_inverse, dbl, true, tnum, tw, ci, ci, tw, 1, tw, 1, 1.0 / tnum, st)))
+        if ((rc = pl.b_slab.create(rocfft_transform_type_complex_inverse, dbl, true, tnum, tw, ci, ci, 1, tnum, 1, tnum, 1.0 / tnum, st)))
             return rc;
         pl.slab_key[0] = dtype, pl.slab_key[1] = tw, pl.slab_key[2] = tnum;
         pl.slab_owner = ctx;
     }
-    if ((rc = pl.b_slab.exec(d_t2, nullptr))) return rc;                  // ifft over k (:282)
-    dim3 bgrid((tnum + 63) / 64, (tw + 63) / 64);
+    // ifft over k (:282) on contiguous rows: [k][tau] -> [tau][k], transform, real part
+    const size_t n = (size_t)tw * tnum;
+    IMPDAR_HIP_CHECK(pl.d_slab.ensure(n * 2 * impdar_dtype_size(dtype)));
+    if (dbl) ps_launch_transpose<double>(d_t2, pl.d_slab.p, tnum, tw, st);
+    else ps_launch_transpose<float>(d_t2, pl.d_slab.p, tnum, tw, st);
+    if ((rc = pl.b_slab.exec(pl.d_slab.p, nullptr))) return rc;
     if (dbl)
-        hipLaunchKernelGGL((ps_real_transpose<double>), bgrid, dim3(256), 0, st, (const Cp<double> *)d_t2, (double *)d_out, tw, tnum);
+        hipLaunchKernelGGL((ps_real_part<double>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pl.d_slab.as<Cp<double>>(),
+                           (double *)d_out, n);
     else
-        hipLaunchKernelGGL((ps_real_transpose<float>), bgrid, dim3(256), 0, st, (const Cp<float> *)d_t2, (float *)d_out, tw, tnum);
+        hipLaunchKernelGGL((ps_real_part<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pl.d_slab.as<Cp<float>>(),
+                           (float *)d_out, n);
     IMPDAR_HIP_CHECK(hipGetLastError());
     return impdar_ctx_mark_produced(ctx);
 }
