@@ -1691,45 +1691,51 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
                 IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_eps.p, epsum.data(), epsum.size() * sizeof(double), hipMemcpyHostToDevice, st));
                 P.eps = pl.d_eps.as<double>();
             }
-            // Launch order.  A wavenumber that holds a frequency on the evanescent boundary of a run walks it in
-            // fp64 in every tile of that run (~2x the tile time); spread over the launch, the last such rows finish
-            // alone after everything else (2 ms at config 5).  They go first, longest first.  The test here only
-            // orders the launch -- generous tolerance, the kernel decides for itself: |0.5 v kx| within 1e-7 of
-            // some |w|.
-            std::vector<std::pair<double, int>> runs;      // (velocity, steps) of every run
-            for (int i = 0; i < snum; ++i) {
-                if (sched[i]) runs.emplace_back(vmig[i], 0);
-                runs.back().second += 1;
-            }
-            if (runs.size() <= 64 && tnum >= 512 && nk == tnum) {      // (a slab of a sharded run keeps the natural order)
-                std::vector<double> aw(nt);
-                for (int j = 0; j < nt; ++j) aw[j] = std::fabs(ws[j] == 0.0 ? 1e-10 / dt : ws[j]);
-                std::sort(aw.begin(), aw.end());
-                std::vector<std::pair<int, int>> score(tnum);      // (-steps spent walking, row)
-                int flagged = 0;
-                for (int k = 0; k < tnum; ++k) {
-                    int steps = 0;
-                    for (const auto &r : runs) {
-                        const double target = 0.5 * r.first * std::fabs(kx[k]);
-                        const auto it = std::lower_bound(aw.begin(), aw.end(), target);
-                        const double hi = it != aw.end() ? *it : aw.back(), lo = it != aw.begin() ? *(it - 1) : aw.front();
-                        const double band = dbl ? 2e-6 : 1e-7;
-                        if (std::fabs(hi - target) <= band * target || std::fabs(lo - target) <= band * target) steps += r.second;
-                    }
-                    score[k] = std::make_pair(-steps, k);
-                    flagged += steps > 0;
-                }
-                if (flagged > 0 && flagged < tnum) {
-                    std::stable_sort(score.begin(), score.end());
-                    rowmap.resize(tnum);
-                    for (int b = 0; b < tnum; ++b) rowmap[b] = score[b].second;
-                    IMPDAR_HIP_CHECK(pl.d_rowmap.ensure((size_t)tnum * sizeof(int)));
-                    IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_rowmap.p, rowmap.data(), (size_t)tnum * sizeof(int), hipMemcpyHostToDevice, st));
-                    P.rowmap = pl.d_rowmap.as<int>();
-                }
-            }
         }
     }
+    // (only the runs kernels of the vector path use it, and it costs ~2 ms of host time at config 5 with the GPU idle:
+    // made when they are about to be launched, not when the matrix-core path takes the call)
+    auto order_rows = [&]() -> int {
+        // Launch order.  A wavenumber that holds a frequency on the evanescent boundary of a run walks it in
+        // fp64 in every tile of that run (~2x the tile time); spread over the launch, the last such rows finish
+        // alone after everything else (2 ms at config 5).  They go first, longest first.  The test here only
+        // orders the launch -- generous tolerance, the kernel decides for itself: |0.5 v kx| within 1e-7 of
+        // some |w|.
+        std::vector<std::pair<double, int>> runs;      // (velocity, steps) of every run
+        for (int i = 0; i < snum; ++i) {
+            if (sched[i]) runs.emplace_back(vmig[i], 0);
+            runs.back().second += 1;
+        }
+        if (runs.size() <= 64 && tnum >= 512 && nk == tnum) {      // (a slab of a sharded run keeps the natural order)
+            std::vector<double> aw(nt);
+            for (int j = 0; j < nt; ++j) aw[j] = std::fabs(ws[j] == 0.0 ? 1e-10 / dt : ws[j]);
+            std::sort(aw.begin(), aw.end());
+            std::vector<std::pair<int, int>> score(tnum);      // (-steps spent walking, row)
+            int flagged = 0;
+            for (int k = 0; k < tnum; ++k) {
+                int steps = 0;
+                for (const auto &r : runs) {
+                    const double target = 0.5 * r.first * std::fabs(kx[k]);
+                    const auto it = std::lower_bound(aw.begin(), aw.end(), target);
+                    const double hi = it != aw.end() ? *it : aw.back(), lo = it != aw.begin() ? *(it - 1) : aw.front();
+                    const double band = dbl ? 2e-6 : 1e-7;
+                    if (std::fabs(hi - target) <= band * target || std::fabs(lo - target) <= band * target) steps += r.second;
+                }
+                score[k] = std::make_pair(-steps, k);
+                flagged += steps > 0;
+            }
+            if (flagged > 0 && flagged < tnum) {
+                std::stable_sort(score.begin(), score.end());
+                rowmap.resize(tnum);
+                for (int b = 0; b < tnum; ++b) rowmap[b] = score[b].second;
+                IMPDAR_HIP_CHECK(pl.d_rowmap.ensure((size_t)tnum * sizeof(int)));
+                IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_rowmap.p, rowmap.data(), (size_t)tnum * sizeof(int), hipMemcpyHostToDevice, st));
+                P.rowmap = pl.d_rowmap.as<int>();
+            }
+        }
+        return IMPDAR_OK;
+    };
+    if (sizeof(T) == 8 && P.sched && (rc = order_rows())) return rc;       // float64: always the vector kernels
     if ((rc = impdar_ctx_ktic(ctx))) return rc;
     bool mfma_done = false;
     if constexpr (sizeof(T) == 4) {
@@ -1748,6 +1754,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         }
         if (ok && (rc = ps_mfma_run(pl, P, mruns, vlen != 0, thr.data(), st, &mfma_done))) return rc;
     }
+    if (sizeof(T) == 4 && !mfma_done && P.sched && (rc = order_rows())) return rc;
     if (!mfma_done && (rc = ps_dispatch<T>(P, st))) return rc;
     if (herm)
         for (int kz : k_zero)
