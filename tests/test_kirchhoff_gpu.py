@@ -204,19 +204,21 @@ def test_native_hook_at_config3_size(hip, tnum):
     assert min(walls) < 0.150
 
 
-@pytest.mark.parametrize('dx', [1.0, 4.0])
-@pytest.mark.parametrize('dtype', [np.float32, np.float64])
-def test_one_shot_in_pieces_equals_one_launch(hip, monkeypatch, dtype, dx):
+@pytest.mark.parametrize('dtype,dx,tnum,nearfield', [(np.float32, 1.0, 4104, False), (np.float64, 1.0, 4104, False),
+                                                     (np.float32, 4.0, 4104, False), (np.float64, 4.0, 4104, False),
+                                                     (np.float32, 4.0, 4101, True)])
+def test_one_shot_in_pieces_equals_one_launch(hip, monkeypatch, dtype, dx, tnum, nearfield):
     """Large radargrams through the one-shot entry point (RadarData.migrate on host arrays) go through in pieces:
     output-trace blocks, one launch each, so that a block crosses PCIe while the next is computed, and -- when the
     aperture is narrow enough to leave something (dx = 4 m here: four blocks, three input chunks; dx = 1 m: the
     aperture spans the profile, two blocks, one upload) -- input-trace chunks uploaded under the launches that do not
     need them.  The result must equal the single upload / launch / download bit for bit
-    (IMPDAR_KIRCH_ONESHOT_SPLIT=0) and the two-block form (=2), and the oracle on spot traces."""
+    (IMPDAR_KIRCH_ONESHOT_SPLIT=0) and the two-block form (=2), and the oracle on spot traces.  The last case: a trace
+    count that is not a whole number of 8-trace groups, near-field term (two images are prepared chunk by chunk)."""
     from impdar_amd import synth
     from impdar_amd.lib.RadarData import RadarData
     from oracle import c_oracle
-    snum, tnum, vel = 4096, 4104, 1.69e8
+    snum, vel = 4096, 1.69e8
     geo = synth.geometry(snum, tnum, dx=dx)
     x = synth.diffractor_radargram(snum, tnum, vel=vel, ndiff=16, dx=dx).astype(dtype)
     outs = {}
@@ -227,16 +229,17 @@ def test_one_shot_in_pieces_equals_one_launch(hip, monkeypatch, dtype, dx):
         d = RadarData(None)
         d.data, d.snum, d.tnum = x.copy(), snum, tnum
         d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
-        d.migrate('kirch', vel=vel)
+        d.migrate('kirch', vel=vel, nearfield=nearfield)
         assert d.data.dtype == np.float64 and d.data.shape == (snum, tnum)
         outs.setdefault(split, []).append(d.data)
     monkeypatch.setenv('IMPDAR_KIRCH_ONESHOT_CACHE', '0')
     assert np.array_equal(outs['1'][0], outs['0'][0]) and np.array_equal(outs['1'][0], outs['1'][1])
     assert np.array_equal(outs['2'][0], outs['0'][0])
-    # both sides of the output cuts (dx 4: 408, 1840, 3488; dx 1: 5/8 of 4104 in whole groups of 8 = 2560) and of the
-    # input chunk edges of the dx = 4 run (408 / 1840 + the 865-trace aperture + margin, in groups of 8)
-    cols = np.array([0, 7, 407, 408, 1296, 1839, 1840, 2559, 2560, 2561, 2728, 3487, 3488, 4103])
-    want = c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], vel, False, traces=cols)
+    # both sides of the output cuts (dx 1: 5/8 of 4104 in whole groups of 8 = 2560) and of the input chunk edges of the
+    # dx = 4 runs (cut + the 865-trace aperture + margin, in groups of 8)
+    # (cuts at 10 / 40 / 70 % of the traces in whole groups of 8: 408, 1640, 2872 for 4104; 408, 1640, 2864 for 4101)
+    cols = np.array([0, 7, 407, 408, 1296, 1639, 1640, 2528, 2559, 2560, 2561, 2863, 2864, 2871, 2872, 3760, tnum - 1])
+    want = c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], vel, nearfield, traces=cols)
     got = outs['1'][0][:, cols]
     if dtype == np.float64:
         assert rel_max(got, want) < EXACT_TOL
