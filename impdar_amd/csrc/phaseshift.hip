@@ -1443,9 +1443,10 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
     Q.runtab = pl.d_runtab.as<double2>();
     {
         // set-up pass: per-run phases of every (wavenumber, frequency), boundary frequencies, the steps of the short runs
-        const size_t lds = (size_t)P.nf * 24 + 8 * 2 * PM_SHORT * sizeof(float);
-        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_setup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(ps_setup_kernel, dim3(P.nk), dim3(512), lds, st, Q);
+        const size_t lds = 8 * 2 * PM_SHORT * sizeof(float);
+        if (P.nf <= 2048) hipLaunchKernelGGL(ps_setup_kernel<4>, dim3(P.nk), dim3(512), lds, st, Q);
+        else if (P.nf <= 4096) hipLaunchKernelGGL(ps_setup_kernel<8>, dim3(P.nk), dim3(512), lds, st, Q);
+        else hipLaunchKernelGGL(ps_setup_kernel<12>, dim3(P.nk), dim3(512), lds, st, Q);
     }
     Q.stamps = nullptr;
     DevBuf d_stamps;

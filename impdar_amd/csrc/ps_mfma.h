@@ -370,15 +370,13 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
 //     the frequencies directly -- FK0 e^{i Phi} per (frequency, step) -- and stored to TK (the row blocks of the long
 //     runs do not cover them).
 // ---------------------------------------------------------------------------
+template <int PM_SM>      // frequencies per thread: nf <= 512 PM_SM
 __global__ __launch_bounds__(512) void ps_setup_kernel(PsMfmaParams Q)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned pm_lds[];
     const PsParams &P = Q.P;
     const int k = P.k0 + (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double *phi = reinterpret_cast<double *>(pm_lds);                       // [nf] phase at the start of the current run
-    double *rws = phi + P.nf;                                               // [nf] 1 / w
-    float2 *f0 = reinterpret_cast<float2 *>(rws + P.nf);                    // [nf] spectrum, zero once out
-    float *red = reinterpret_cast<float *>(f0 + P.nf);                      // [8][2 * PM_SHORT]
+    float *red = reinterpret_cast<float *>(pm_lds);                         // [8][2 * PM_SHORT]
     const Cp<float> *Frow = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.fstride;
     float *TKrow = reinterpret_cast<float *>(reinterpret_cast<Cp<float> *>(P.TK) + (size_t)(k - P.k0) * P.snum);
     double2 *tab = Q.runtab + (size_t)(k - P.k0) * P.nf * Q.nlong;
@@ -395,19 +393,28 @@ __global__ __launch_bounds__(512) void ps_setup_kernel(PsMfmaParams Q)
         }
         return;
     }
-    for (int slot = tid; slot < P.nf; slot += 512) {
-        const Cp<float> f = ps_load_slot<float>(Frow, P, slot);
-        const double rw = 1.0 / P.w[slot];
+    // Every thread keeps its frequencies (slot = tid + 512 m) in registers and walks the runs with the m loop unrolled:
+    // no LDS round trips (the first form kept phase / 1/w / spectrum in 24 nf bytes of LDS: 2.08 ms at config 5, this one
+    // 1.83; a branch-free body -- selects instead of the two ifs -- measured no better: the pass is bound by its ~450
+    // instructions per (wavenumber, frequency) of the nine runs of that table, six of them one-step runs with a sincos each).
+    double ph[PM_SM], rw[PM_SM], wv[PM_SM];
+    float2 fv[PM_SM];
+#pragma unroll
+    for (int m = 0; m < PM_SM; ++m) {
+        const int slot = tid + 512 * m;
+        const bool in = slot < P.nf;
+        const Cp<float> f = in ? ps_load_slot<float>(Frow, P, slot) : Cp<float>{0.f, 0.f};
+        wv[m] = in ? P.w[slot] : 1.0;
+        rw[m] = 1.0 / wv[m];
         bool edge = false;
-        for (int r = 0; r < Q.nruns; ++r) edge = edge || fabs(pm_coss(Q.runs[r].v, kxk, rw)) < 1e-8;
-        if (edge) {
+        for (int r = 0; r < Q.nruns; ++r) edge = edge || fabs(pm_coss(Q.runs[r].v, kxk, rw[m])) < 1e-8;
+        if (edge && in) {
             const int at = atomicAdd(Q.edge_cnt + k, 1);
             if (at < PM_EMAX) Q.edge_list[(size_t)k * PM_EMAX + at] = slot;
         }
-        // (a frequency whose spectrum value IS zero stays in: f0 only says "out" through the flag below)
-        f0[slot] = make_float2(f.x, f.y);
-        phi[slot] = edge ? nan : 0.0;                                         // NaN phase = out of every run from here on
-        rws[slot] = rw;
+        // (a frequency whose spectrum value IS zero stays in: only the NaN phase says "out")
+        fv[m] = make_float2(f.x, f.y);
+        ph[m] = (edge || !in) ? nan : 0.0;                                    // NaN phase = out of every run from here on
     }
     for (int r = 0; r < Q.nruns; ++r) {
         const double v = Q.runs[r].v;
@@ -417,26 +424,25 @@ __global__ __launch_bounds__(512) void ps_setup_kernel(PsMfmaParams Q)
         float acc[2 * PM_SHORT];
 #pragma unroll
         for (int j = 0; j < 2 * PM_SHORT; ++j) acc[j] = 0.f;
-        for (int slot = tid; slot < P.nf; slot += 512) {
-            const double w = P.w[slot];
-            const double cs = pm_coss(v, kxk, rws[slot]);                     // :456
-            double ph = phi[slot];
+#pragma unroll
+        for (int m = 0; m < PM_SM; ++m) {
+            const int slot = tid + 512 * m;
+            const double cs = pm_coss(v, kxk, rw[m]);                         // :456
             double inc = 0.0;
-            if (cs <= 0.0) ph = nan;                                          // :484-485, for good
-            else inc = w * P.dt * pm_sqrt01(cs);                              // :458-460 (off the boundary band: cs >= 1e-8)
-            if (L >= 0) tab[(size_t)slot * Q.nlong + L] = make_double2(inc, ph);
-            if (is_short && ph == ph) {
-                const float2 f = f0[slot];
+            if (cs <= 0.0) ph[m] = nan;                                       // :484-485, for good
+            else inc = wv[m] * P.dt * pm_sqrt01(cs);                          // :458-460 (off the boundary band: cs >= 1e-8)
+            if (L >= 0 && slot < P.nf) tab[(size_t)slot * Q.nlong + L] = make_double2(inc, ph[m]);
+            if (is_short && ph[m] == ph[m]) {
 #pragma unroll
                 for (int j = 0; j < PM_SHORT; ++j)
                     if (j < len) {                                            // uniform
                         float sn, c2;
-                        pm_sincos(pm_wrap(ph + (double)(j + 1) * inc), &sn, &c2);
-                        acc[2 * j] += fmaf(f.x, c2, -(f.y * sn));            // :464, :487
-                        acc[2 * j + 1] += fmaf(f.x, sn, f.y * c2);
+                        pm_sincos(pm_wrap(ph[m] + (double)(j + 1) * inc), &sn, &c2);
+                        acc[2 * j] += fmaf(fv[m].x, c2, -(fv[m].y * sn));    // :464, :487
+                        acc[2 * j + 1] += fmaf(fv[m].x, sn, fv[m].y * c2);
                     }
             }
-            phi[slot] = pm_wrap(ph + (double)len * inc);                      // NaN stays NaN
+            ph[m] = pm_wrap(ph[m] + (double)len * inc);                       // NaN stays NaN
         }
         if (is_short) {
 #pragma unroll
