@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 && M == 8) ? IMPDAR_PS_VZ32_M8
 //    (float64 LDS atomics), exactly as in ps_vz32_kernel.
 // ---------------------------------------------------------------------------
 template <int BLOCK, int M>
-__global__ __launch_bounds__(BLOCK) void ps_vz64_kernel(PsParams P)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void ps_vz64_kernel(PsParams P)
 {
     constexpr int TT = 16;
     constexpr int NW = BLOCK / 64;

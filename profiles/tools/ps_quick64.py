@@ -16,7 +16,8 @@ x = rng.standard_normal((n, n))
 Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
 tab = np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rp], [1.8e8, 0.5 * Rp], [1.9e8, 1.2 * Rp]])
 out = {}
-for name, vel in (('const', 1.69e8), ('vz', tab)):
+flat = np.array([[1.69e8, 0.], [1.69e8, 10. * Rp]])      # one constant-velocity run through the v(z) kernel
+for name, vel in (('const', 1.69e8), ('vz', tab), ('vz_flat', flat)):
     ms = []
     for i in range(reps + 1):
         d = RadarData(None)
@@ -28,7 +29,10 @@ for name, vel in (('const', 1.69e8), ('vz', tab)):
         v = C.c_float()
         _hip.check(lib.impdar_ctx_last_ms(ctx, C.byref(v)), 'impdar_ctx_last_ms')
         ms.append(v.value)
+        kv = C.c_float()
+        _hip.check(lib.impdar_ctx_last_kernel_ms(ctx, C.byref(kv)), 'impdar_ctx_last_kernel_ms')
+        kms = kv.value
         d._dev.free()
         d._dev = None
-    out[name] = {'device_ms': float(np.median(ms[1:])), 'all': [round(m, 2) for m in ms]}
+    out[name] = {'device_ms': float(np.median(ms[1:])), 'kernel_ms': round(kms, 2), 'all': [round(m, 2) for m in ms]}
 print(json.dumps({'n': n, 'dtype': 'float64', **out}))
