@@ -3194,6 +3194,12 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
     const size_t esz = impdar_dtype_size(dtype);
     const size_t bytes = (size_t)snum * tnum * esz;
     auto done = [&](int code) {
+        if (code != IMPDAR_OK) {
+            // the uploads of the pipelined form read the caller's array asynchronously: nothing may still be in flight
+            // when an error hands the array back
+            (void)hipStreamSynchronize(ctx->aux);
+            (void)hipStreamSynchronize(ctx->stream);
+        }
         if (code != IMPDAR_OK || !keep) c.drop();
         return code;
     };

@@ -42,6 +42,48 @@ int main()
         CK(hipStreamSynchronize(st));
         printf("whole 1-D pageable D2H: %.2f ms (%.1f GB/s)\n", ms(t0, now()), bytes / ms(t0, now()) / 1e6);
     }
+    // device -> pageable, trace (column) blocks
+    for (int rep = 0; rep < 3; ++rep)
+        for (int b = 0; b < 3; ++b) {
+            const size_t j0 = cuts[b], w = (cuts[b + 1] - cuts[b]) * esz;
+            auto t0 = now();
+            CK(hipMemcpy2DAsync(h2 + j0 * esz, tnum * esz, d + j0 * esz, tnum * esz, w, snum, hipMemcpyDeviceToHost, st));
+            CK(hipStreamSynchronize(st));
+            printf("2-D pageable D2H traces [%zu, %zu): %.2f ms (%.1f GB/s)\n", cuts[b], cuts[b + 1], ms(t0, now()),
+                   w * snum / ms(t0, now()) / 1e6);
+        }
+    // a compact (snum x width) device block into columns of the host array (what an output block of the split call is)
+    for (int rep = 0; rep < 3; ++rep) {
+        const size_t j0 = 4000, wcols = 3000, w = wcols * esz;
+        auto t0 = now();
+        CK(hipMemcpy2DAsync(h2 + j0 * esz, tnum * esz, d, w, w, snum, hipMemcpyDeviceToHost, st));
+        CK(hipStreamSynchronize(st));
+        printf("2-D pageable D2H compact block -> columns [4000, 7000): %.2f ms (%.1f GB/s)\n", ms(t0, now()), w * snum / ms(t0, now()) / 1e6);
+    }
+    // into FRESH pageable memory (first touch by the copy), as a result array just made by numpy.empty is
+    for (int rep = 0; rep < 2; ++rep) {
+        char *h3 = (char *)malloc(bytes);
+        auto t0 = now();
+        CK(hipMemcpyAsync(h3, d, bytes, hipMemcpyDeviceToHost, st));
+        CK(hipStreamSynchronize(st));
+        printf("whole 1-D D2H into untouched pageable memory: %.2f ms (%.1f GB/s)\n", ms(t0, now()), bytes / ms(t0, now()) / 1e6);
+        free(h3);
+    }
+    // device -> PINNED staging buffers of different sizes (hipHostMalloc), 54.6 MB pieces
+    for (size_t mb : {164, 328, 656}) {
+        char *pin = nullptr;
+        auto ta = now();
+        CK(hipHostMalloc((void **)&pin, mb << 20, hipHostMallocDefault));
+        const double alloc_ms = ms(ta, now());
+        for (int rep = 0; rep < 3; ++rep) {
+            auto t0 = now();
+            CK(hipMemcpyAsync(pin + (size_t)rep * (54u << 20), d, (size_t)54 << 20, hipMemcpyDeviceToHost, st));
+            CK(hipStreamSynchronize(st));
+            printf("D2H 54 MB into a %zu MB hipHostMalloc buffer (allocated in %.1f ms): %.2f ms (%.1f GB/s)\n", mb, alloc_ms, ms(t0, now()),
+                   (double)((size_t)54 << 20) / ms(t0, now()) / 1e6);
+        }
+        CK(hipHostFree(pin));
+    }
     // row slabs (contiguous): pieces of 1/4 of the rows
     for (int rep = 0; rep < 2; ++rep)
         for (int b = 3; b >= 0; --b) {
