@@ -1519,7 +1519,9 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
                                                 1.0 / tnum, st)))
             return rc;
         IMPDAR_HIP_CHECK(pl.X.ensure((size_t)tnum * nt * 2 * sizeof(T)));
-        IMPDAR_HIP_CHECK(pl.TK.ensure((size_t)tnum * snum * 2 * sizeof(T)));
+        // (TK doubles as the scratch of the transposed forward transform: nt / 2 + 1 rows of tnum -- more than snum rows
+        // when the caller pads the time axis beyond the next power of two)
+        IMPDAR_HIP_CHECK(pl.TK.ensure((size_t)tnum * std::max(snum, nt / 2 + 1) * 2 * sizeof(T)));
         IMPDAR_HIP_CHECK(pl.d_kx.ensure((size_t)tnum * 8));
         IMPDAR_HIP_CHECK(pl.d_w.ensure((size_t)nt * 8));
         IMPDAR_HIP_CHECK(pl.d_vz.ensure((size_t)snum * 8));

@@ -280,6 +280,39 @@ def test_hermitian_walk_is_refused_when_the_axes_are_not_antisymmetric(hip):
     assert rel_max(out, want) < F64_TOL, rel_max(out, want)
 
 
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_time_axis_padded_far_beyond_the_samples(hip, dtype):
+    """The C entry point takes nt from the caller (any nt >= snum; the package passes the next power of two,
+    mig_python.py:262): with nt = 1024 for 100 samples the half spectrum (nt / 2 + 1 rows) is larger than the image,
+    which the scratch buffers of the transposed transforms must allow for.  Antisymmetric axes: the half walk runs."""
+    import ctypes as C
+    from impdar_amd import _hip, synth
+    from oracle import mig_oracle
+    lib, ctx = _hip.load(), _hip.context()
+    snum, tnum, nt = 100, 48, 1024
+    geo = synth.geometry(snum, tnum)
+    data = synth.noise_radargram(snum, tnum, seed=5).astype(dtype)
+    kx = mig_oracle._kx(tnum, geo['trace_int'], geo['dist'])
+    ws = 2. * np.pi * np.fft.fftfreq(nt, d=geo['dt'])
+    out = np.empty((snum, tnum), dtype=dtype)
+    tt = np.ascontiguousarray(geo['travel_time'], dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    vm = np.where(np.arange(snum) < 40, 1.69e8, 2.0e8).astype(np.float64)
+    for vlen in (0, snum):
+        _hip.check(lib.impdar_phaseshift(ctx, data.ctypes.data_as(C.c_void_p), _hip.dtype_code(dtype), snum, tnum, nt,
+                                         kx.ctypes.data_as(dp), ws.ctypes.data_as(dp), C.c_double(geo['dt']),
+                                         tt.ctypes.data_as(dp), C.c_double(1.69e8), vm.ctypes.data_as(dp) if vlen else None, vlen,
+                                         C.c_double(5.), C.c_double(7.), out.ctypes.data_as(C.c_void_p)), 'impdar_phaseshift')
+        tap = mig_oracle._apply_taper(data.astype(np.float64), 5, 7, inplace_form=True)
+        FK = np.fft.fft2(tap, (nt, tnum))
+        TK = mig_oracle.phase_shift_tk(FK, vm if vlen else 1.69e8, kx, ws, geo['dt'], geo['travel_time'], snum, tnum)
+        want = np.fft.ifft(TK).real
+        if dtype == np.float64:
+            assert rel_max(out, want) < F64_TOL, rel_max(out, want)
+        else:
+            assert rel_l2(out, want) < F32_L2, rel_l2(out, want)
+
+
 def test_velocity_file_and_errors(hip, tmp_path):
     """test/test_migrationlib.py:120-131: constant, layered from a file,
     TypeError for an unreadable file."""
