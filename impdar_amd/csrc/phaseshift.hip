@@ -1307,7 +1307,7 @@ static PsPlan *g_ps_plan = nullptr;
 void impdar_ps_forget(const impdar_ctx *ctx)
 {
     std::lock_guard<std::mutex> lk(g_ps_mu);
-    if (g_ps_plan && g_ps_plan->owner == ctx) {
+    if (g_ps_plan && (g_ps_plan->owner == ctx || g_ps_plan->slab_owner == ctx)) {      // (the sharded calls' plan and buffers too)
         delete g_ps_plan;
         g_ps_plan = nullptr;
     }
