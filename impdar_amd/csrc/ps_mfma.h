@@ -305,6 +305,11 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
         // ---- phase 2: every row block of the group against this wave's 16 steps: 32 frequencies = 4 K-steps of 8.  The
         // operands of step s + 1 are read while the three MFMAs of step s run (a read-wait-compute sequence per step
         // left the matrix pipe idle for an LDS round trip sixteen times a round).
+        // The step factors of a run stay in registers for all of its row blocks (4 K-steps x (hi, lo) = 8 x 16 bytes per
+        // lane): with them re-read from LDS for every block the phase moved 16 KB per wave and block through a 256 B/clk
+        // port for 384 cycles of matrix pipe -- 341 B/clk with eight waves on a CU: the LDS read port, not the pipe, set
+        // its length (~2750 cycles a round against 1536-1920 of MFMA).
+        uint4 bh[PM_CH / 8], bl[PM_CH / 8];
 #pragma unroll
         for (int rb = 0; rb < PM_NRB; ++rb) {
             const int run = brun[rb];
@@ -314,19 +319,24 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
                 gen_B(incs[rb]);                                              // another run: other step factors
             }
             __builtin_amdgcn_wave_barrier();
+            if (rb == 0 || brun[rb - 1] != run) {
+#pragma unroll
+                for (int s = 0; s < PM_CH / 8; ++s) {
+                    const int o = rd0 ^ (8 * s);
+                    bh[s] = *reinterpret_cast<const uint4 *>(Bhi + o);
+                    bl[s] = *reinterpret_cast<const uint4 *>(Blo + o);
+                }
+            }
             const unsigned *Ahi = Aq + (size_t)rb * 2 * PM_TILE, *Alo = Ahi + PM_TILE;
             uint4 ra_hi = *reinterpret_cast<const uint4 *>(Ahi + rd0), ra_lo = *reinterpret_cast<const uint4 *>(Alo + rd0);
-            uint4 rb_hi = *reinterpret_cast<const uint4 *>(Bhi + rd0), rb_lo = *reinterpret_cast<const uint4 *>(Blo + rd0);
 #pragma unroll
             for (int s = 0; s < PM_CH / 8; ++s) {
                 const pm_half8 a_hi = __builtin_bit_cast(pm_half8, ra_hi), a_lo = __builtin_bit_cast(pm_half8, ra_lo);
-                const pm_half8 b_hi = __builtin_bit_cast(pm_half8, rb_hi), b_lo = __builtin_bit_cast(pm_half8, rb_lo);
+                const pm_half8 b_hi = __builtin_bit_cast(pm_half8, bh[s]), b_lo = __builtin_bit_cast(pm_half8, bl[s]);
                 if (s + 1 < PM_CH / 8) {
                     const int o = rd0 ^ (8 * (s + 1));
                     ra_hi = *reinterpret_cast<const uint4 *>(Ahi + o);
                     ra_lo = *reinterpret_cast<const uint4 *>(Alo + o);
-                    rb_hi = *reinterpret_cast<const uint4 *>(Bhi + o);
-                    rb_lo = *reinterpret_cast<const uint4 *>(Blo + o);
                 }
                 acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[rb], 0, 0, 0);
                 acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[rb], 0, 0, 0);
