@@ -274,19 +274,23 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
 #pragma unroll
         for (int rb = 0; rb < PM_NRB; ++rb) {
             if (brun[rb] < 0) continue;                                       // uniform
-            if (rb == part || (rb == PM_NP && part == 0)) {
+            // block rb < 4: all 32 rows by the waves of part rb; the fifth block: a quarter of the rows by every part (with
+            // it on part 0 alone that wave generated two tiles a round and the other three waited at the barrier)
+            const bool whole = rb == part, quarter = rb == PM_NP;
+            if (whole || quarter) {
                 // rows hh, hh + PM_NSUB, ... = tiles a0 + row of 64 steps each: anchor with the float64 phase, then
                 // S *= e^{i 64 PM_NSUB inc} from row to row; a frequency that is out of this run (NaN start phase) contributes zeros
+                constexpr int NJ = 32 / PM_NSUB, NJQ = NJ / PM_NP;
+                const int j0 = quarter ? NJQ * part : 0;
                 const double inc = incs[rb];
                 const bool in = phis[rb] == phis[rb];
                 float s, cph, Es, Ec;
-                pm_sincos(pm_wrap((in ? phis[rb] : 0.0) + (double)(PM_TT * (ba0[rb] + hh)) * inc), &s, &cph);
+                pm_sincos(pm_wrap((in ? phis[rb] : 0.0) + (double)(PM_TT * (ba0[rb] + PM_NSUB * j0 + hh)) * inc), &s, &cph);
                 pm_sincos(pm_wrap((double)(PM_NSUB * PM_TT) * inc), &Es, &Ec);
                 const float gr = in ? f0r : 0.f, gi = in ? f0i : 0.f;
                 float sr = fmaf(gr, cph, -(gi * s)), si = fmaf(gr, s, gi * cph);
                 unsigned *Ahi = Aq + (size_t)rb * 2 * PM_TILE, *Alo = Ahi + PM_TILE;
-#pragma unroll
-                for (int j = 0; j < 32 / PM_NSUB; ++j) {
+                auto row = [&](int j) {
                     float rr, ri;
                     const int o = 64 * j + wx[j % PM_NSLOT];
                     Ahi[o] = pm_split(sr, si, &rr, &ri);
@@ -294,6 +298,19 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
                     const float nr = fmaf(sr, Ec, -(si * Es)), ni = fmaf(sr, Es, si * Ec);
                     sr = nr;
                     si = ni;
+                };
+                if (whole) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) row(j);
+                } else {
+                    // (the quarter is uniform per wave but not a compile-time constant: unrolled over the four parts so that
+                    // the slot pattern wx[j % PM_NSLOT] keeps constant indices)
+#pragma unroll
+                    for (int p4 = 0; p4 < PM_NP; ++p4)
+                        if (p4 == part) {                                     // uniform
+#pragma unroll
+                            for (int jj = 0; jj < NJQ; ++jj) row(NJQ * p4 + jj);
+                        }
                 }
             }
         }
