@@ -129,6 +129,9 @@ __device__ __forceinline__ void pm_sincos(double x, float *s, float *c)
     *c = fmaf(-sh, xl, ch);
 }
 
+// Timing-only ablations for profiles/tools/variant_build.sh (SRC=phaseshift): results are WRONG with any of them set.
+//   PM_ABL_NOSTATE  no state tiles    PM_ABL_NOB  no step-factor tiles    PM_ABL_NOMFMA  operand reads, no MFMAs
+//   PM_ABL_NOREAD   MFMAs on whatever the operand registers hold, no LDS reads in the product phase
 #ifndef PM_FMAMIX
 #define PM_FMAMIX 1         // residuals by v_fma_mix_f32 (float16 half x -1 + float32, one instruction) instead of convert + subtract
 #endif
@@ -277,7 +280,11 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
             // block rb < 4: all 32 rows by the waves of part rb; the fifth block: a quarter of the rows by every part (with
             // it on part 0 alone that wave generated two tiles a round and the other three waited at the barrier)
             const bool whole = rb == part, quarter = rb == PM_NP;
+#ifdef PM_ABL_NOSTATE
+            if (false) {
+#else
             if (whole || quarter) {
+#endif
                 // rows hh, hh + PM_NSUB, ... = tiles a0 + row of 64 steps each: anchor with the float64 phase, then
                 // S *= e^{i 64 PM_NSUB inc} from row to row; a frequency that is out of this run (NaN start phase) contributes zeros
                 constexpr int NJ = 32 / PM_NSUB, NJQ = NJ / PM_NP;
@@ -315,7 +322,9 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
             }
         }
         PM_STAMP(1)
+#ifndef PM_ABL_NOB
         if (brun[0] >= 0) gen_B(incs[0]);
+#endif
         PM_STAMP(2)
         __syncthreads();            // the half's state tiles are complete
         PM_STAMP(3)
@@ -333,9 +342,12 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
             if (run < 0) continue;                                            // uniform
             if (rb > 0 && brun[rb - 1] != run) {
                 __builtin_amdgcn_wave_barrier();
+#ifndef PM_ABL_NOB
                 gen_B(incs[rb]);                                              // another run: other step factors
+#endif
             }
             __builtin_amdgcn_wave_barrier();
+#ifndef PM_ABL_NOREAD
             if (rb == 0 || brun[rb - 1] != run) {
 #pragma unroll
                 for (int s = 0; s < PM_CH / 8; ++s) {
@@ -344,20 +356,38 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
                     bl[s] = *reinterpret_cast<const uint4 *>(Blo + o);
                 }
             }
+#else
+            if (rb == 0 && c == q)
+#pragma unroll
+                for (int s = 0; s < PM_CH / 8; ++s) bh[s] = bl[s] = make_uint4(lane, s, lane, s);
+#endif
             const unsigned *Ahi = Aq + (size_t)rb * 2 * PM_TILE, *Alo = Ahi + PM_TILE;
+#ifndef PM_ABL_NOREAD
             uint4 ra_hi = *reinterpret_cast<const uint4 *>(Ahi + rd0), ra_lo = *reinterpret_cast<const uint4 *>(Alo + rd0);
+#else
+            uint4 ra_hi = make_uint4(lane, rb, lane, rb), ra_lo = ra_hi;
+            (void)Ahi;
+            (void)Alo;
+#endif
 #pragma unroll
             for (int s = 0; s < PM_CH / 8; ++s) {
                 const pm_half8 a_hi = __builtin_bit_cast(pm_half8, ra_hi), a_lo = __builtin_bit_cast(pm_half8, ra_lo);
                 const pm_half8 b_hi = __builtin_bit_cast(pm_half8, bh[s]), b_lo = __builtin_bit_cast(pm_half8, bl[s]);
+#ifndef PM_ABL_NOREAD
                 if (s + 1 < PM_CH / 8) {
                     const int o = rd0 ^ (8 * (s + 1));
                     ra_hi = *reinterpret_cast<const uint4 *>(Ahi + o);
                     ra_lo = *reinterpret_cast<const uint4 *>(Alo + o);
                 }
+#endif
+#ifndef PM_ABL_NOMFMA
                 acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[rb], 0, 0, 0);
                 acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[rb], 0, 0, 0);
                 acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[rb], 0, 0, 0);
+#else
+                // keep the operand reads alive
+                asm volatile("" ::"v"(a_hi), "v"(a_lo), "v"(b_hi), "v"(b_lo));
+#endif
             }
         }
         PM_STAMP(4)
