@@ -1414,12 +1414,33 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
     if (nb == 0 || nshort_steps > 96 || (int)runs.size() - (vz ? (int)std::count_if(runs.begin(), runs.end(), [](const PsMfmaRun &r) { return r.len <= PM_SHORT; }) : 0) > 8) return IMPDAR_OK;
     if ((long long)nb * 32 * PM_TT > (long long)snum * 7 / 4 + 32 * PM_TT) return IMPDAR_OK;      // many medium runs: rows mostly padding
     // groups of up to PM_NRB row blocks (the state tiles a workgroup keeps in LDS), consecutive blocks together
-    const int ngroups = (nb + PM_NRB - 1) / PM_NRB;
+    int ngroups = (nb + PM_NRB - 1) / PM_NRB;
     const int per_group = (nb + ngroups - 1) / ngroups;
     std::vector<int2> table((size_t)ngroups * PM_NRB, make_int2(-1, 0));
     for (int g = 0, at = 0; g < ngroups; ++g) {
         const int n = std::min(per_group, nb - at);
         for (int i = 0; i < n; ++i, ++at) table[(size_t)g * PM_NRB + i] = blocks[at];
+    }
+    // IMPDAR_PS_MFMA_SPEC=1: the kernel with producer and consumer waves (ps_mfma_spec_kernel); its groups hold blocks of
+    // ONE run each
+    const char *spe = getenv("IMPDAR_PS_MFMA_SPEC");
+    const bool spec = spe && atoi(spe) != 0;
+    if (spec) {
+        table.clear();
+        for (int at = 0; at < nb;) {
+            int n = 1;
+            while (at + n < nb && n < PM_NRB && blocks[at + n].x == blocks[at].x) ++n;
+            // a run of 6+ blocks: near-equal groups
+            int same = n;
+            while (at + same < nb && blocks[at + same].x == blocks[at].x) ++same;
+            const int parts = (same + PM_NRB - 1) / PM_NRB;
+            n = std::min(n, (same + parts - 1) / parts);
+            const size_t base = table.size();
+            table.resize(base + PM_NRB, make_int2(-1, 0));
+            for (int i = 0; i < n; ++i) table[base + i] = blocks[at + i];
+            at += n;
+        }
+        ngroups = (int)(table.size() / PM_NRB);
     }
     PsMfmaParams Q;
     Q.P = P;
@@ -1458,7 +1479,13 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
     // (diagnostics: IMPDAR_PS_MFMA_ONE_WG=1 asks for 100 KB of LDS, i.e. one workgroup per CU instead of two)
     const size_t lds_bytes = getenv("IMPDAR_PS_MFMA_ONE_WG") ? std::max<size_t>(PM_LDS_BYTES, 100 * 1024) : PM_LDS_BYTES;
     IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(ps_mfma_kernel, dim3((unsigned)P.nk * Q.ngroups), dim3(PM_WAVES * 64), lds_bytes, st, Q);
+    if (spec) {
+        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_mfma_spec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)PS_SPEC_LDS_BYTES));
+        hipLaunchKernelGGL(ps_mfma_spec_kernel, dim3((unsigned)P.nk * Q.ngroups), dim3(PS_SPEC_WAVES * 64), PS_SPEC_LDS_BYTES, st, Q);
+    } else {
+        hipLaunchKernelGGL(ps_mfma_kernel, dim3((unsigned)P.nk * Q.ngroups), dim3(PM_WAVES * 64), lds_bytes, st, Q);
+    }
     if (vz) hipLaunchKernelGGL(ps_edge_kernel, dim3(P.nk), dim3(256), 0, st, Q);
     IMPDAR_HIP_CHECK(hipGetLastError());
     // the host table must outlive its async copy

@@ -414,6 +414,201 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
 }
 
 // ---------------------------------------------------------------------------
+// The same sum with SPECIALISED waves (round 3, late; IMPDAR_PS_MFMA_SPEC=1).  profiles/r03_ps_mfma_ablation2.txt: in
+// ps_mfma_kernel the generation of the tiles, the products and the rest ADD UP (3.05 + 3.2 + 1.8 ms at constant
+// velocity): the two workgroups of a CU run in step, nothing of one hides under the other.  Here one workgroup of
+// eight waves owns the CU: waves 4..7 (producers) generate the state and step-factor tiles of round r + 1 into the other
+// of two tile sets while waves 0..3 (consumers) multiply round r -- one producer and one consumer per SIMD, the vector
+// pipe and the matrix pipe busy at the same time by construction, one barrier a round.  144 KB of LDS (two sets of
+// five state tiles + four step-factor tiles, hi and lo halves).  All row blocks of a group belong to ONE run (the host
+// forms the groups that way for this kernel): one step-factor tile per part and round.
+// ---------------------------------------------------------------------------
+constexpr int PS_SPEC_WAVES = 8;
+constexpr size_t PS_SPEC_SET = ((size_t)PM_NRB * 2 + (size_t)PM_NP * 2) * PM_TILE;      // dwords per tile set
+constexpr size_t PS_SPEC_LDS_BYTES = 2 * PS_SPEC_SET * 4 + 64;
+
+__global__ __launch_bounds__(PS_SPEC_WAVES * 64, 1) void ps_mfma_spec_kernel(PsMfmaParams Q)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned pm_lds[];
+    const PsParams &P = Q.P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= PM_NP;               // uniform per wave
+    const int part = wave & (PM_NP - 1);
+    const int g = (int)blockIdx.x % Q.ngroups, kb = (int)blockIdx.x / Q.ngroups, k = P.k0 + kb;
+    const int om = lane % PM_CH, hh = lane / PM_CH;
+    const Cp<float> *Frow = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.fstride;
+    float *TKrow = reinterpret_cast<float *>(reinterpret_cast<Cp<float> *>(P.TK) + (size_t)kb * P.snum);
+
+    float sigma;
+    {
+        float m = 0.f;
+        for (int slot = tid; slot < P.nf; slot += PS_SPEC_WAVES * 64) {
+            const Cp<float> f = ps_load_slot<float>(Frow, P, slot);
+            m = fmaxf(m, fmaxf(fabsf(f.x), fabsf(f.y)));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float *mx = reinterpret_cast<float *>(pm_lds);
+        if (lane == 0) mx[wave] = m;
+        __syncthreads();
+        m = mx[0];
+#pragma unroll
+        for (int i = 1; i < PS_SPEC_WAVES; ++i) m = fmaxf(m, mx[i]);
+        __syncthreads();
+        int e = 0;
+        (void)frexpf(m, &e);
+        sigma = (m > 0.f && m < 3.0e38f) ? ldexpf(1.0f, 12 - e) : 1.0f;
+    }
+
+    int wx[PM_NSLOT];
+#pragma unroll
+    for (int m = 0; m < PM_NSLOT; ++m) wx[m] = PM_ROW * hh + (om ^ (4 * m));
+    const int rd0 = (lane & 31) * PM_ROW + ((4 * (lane >> 5)) ^ (4 * (((lane & 31) / PM_NSUB) % PM_NSLOT)));
+
+    int brun[PM_NRB], ba0[PM_NRB];
+#pragma unroll
+    for (int rb = 0; rb < PM_NRB; ++rb) {
+        const int2 d = Q.blocks[(size_t)g * PM_NRB + rb];
+        brun[rb] = __builtin_amdgcn_readfirstlane(d.x);
+        ba0[rb] = __builtin_amdgcn_readfirstlane(d.y);
+    }
+    const int run = brun[0];                            // the group's run (host: every block of the group)
+    const int L = run >= 0 ? Q.long_of[run] : 0;
+    const int nchunk = P.nf / PM_CH;
+    const double2 *tab = Q.runtab + (size_t)kb * P.nf * Q.nlong;
+
+    if (producer) {
+        // ---- tiles of round c into set c & 1: state tile of block `part` (and a quarter of the fifth), step factors of part `part`
+        Cp<float> f_next = ps_load_slot<float>(Frow, P, om);
+        double2 t_next = tab[(size_t)om * Q.nlong + L];
+        for (int c = 0; c <= nchunk; ++c) {
+            if (c < nchunk) {
+                unsigned *set = pm_lds + (size_t)(c & 1) * PS_SPEC_SET;
+                unsigned *Bhi = set + (size_t)PM_NRB * 2 * PM_TILE + (size_t)part * 2 * PM_TILE, *Blo = Bhi + PM_TILE;
+                const float f0r = f_next.x * sigma, f0i = f_next.y * sigma;
+                const double inc = t_next.x, phi = t_next.y;
+                {
+                    const int sn = min(c + 1, nchunk - 1) * PM_CH + om;
+                    f_next = ps_load_slot<float>(Frow, P, sn);
+                    t_next = tab[(size_t)sn * Q.nlong + L];
+                }
+                const bool in = phi == phi;
+                float Es, Ec;
+                pm_sincos(pm_wrap((double)(PM_NSUB * PM_TT) * inc), &Es, &Ec);
+                const float gr = in ? f0r : 0.f, gi = in ? f0i : 0.f;
+#pragma unroll
+                for (int rb = 0; rb < PM_NRB; ++rb) {
+                    if (brun[rb] < 0) continue;                               // uniform
+                    const bool whole = rb == part, quarter = rb == PM_NP;
+                    if (!(whole || quarter)) continue;
+                    constexpr int NJ = 32 / PM_NSUB, NJQ = NJ / PM_NP;
+                    const int j0 = quarter ? NJQ * part : 0;
+                    float s, cph;
+                    pm_sincos(pm_wrap((in ? phi : 0.0) + (double)(PM_TT * (ba0[rb] + PM_NSUB * j0 + hh)) * inc), &s, &cph);
+                    float sr = fmaf(gr, cph, -(gi * s)), si = fmaf(gr, s, gi * cph);
+                    unsigned *Ahi = set + (size_t)rb * 2 * PM_TILE, *Alo = Ahi + PM_TILE;
+                    auto row = [&](int j) {
+                        float rr, ri;
+                        const int o = 64 * j + wx[j % PM_NSLOT];
+                        Ahi[o] = pm_split(sr, si, &rr, &ri);
+                        Alo[o] = pm_pack(rr, ri);
+                        const float nr = fmaf(sr, Ec, -(si * Es)), ni = fmaf(sr, Es, si * Ec);
+                        sr = nr;
+                        si = ni;
+                    };
+                    if (whole) {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) row(j);
+                    } else {
+#pragma unroll
+                        for (int p4 = 0; p4 < PM_NP; ++p4)
+                            if (p4 == part) {                                 // uniform
+#pragma unroll
+                                for (int jj = 0; jj < NJQ; ++jj) row(NJQ * p4 + jj);
+                            }
+                    }
+                }
+                if (run >= 0) {
+                    // step factors b = 16 part + hh + PM_NSUB j of the 64-step tile (see ps_mfma_kernel's gen_B)
+                    float e2s, e2c, bs, bc;
+                    pm_sincos(pm_wrap((double)PM_NSUB * inc), &e2s, &e2c);
+                    pm_sincos(pm_wrap((double)(16 * part + hh + 1) * inc), &bs, &bc);
+                    bs *= 256.f;
+                    bc *= 256.f;
+#pragma unroll
+                    for (int j = 0; j < 16 / PM_NSUB; ++j) {
+                        float rc, rs;
+                        (void)pm_split(bc, bs, &rc, &rs);
+                        const int o = 64 * j + wx[j % PM_NSLOT];
+                        Bhi[o] = pm_pack(bc, -bs);
+                        Bhi[o + 16 * PM_ROW] = pm_pack(bs, bc);
+                        Blo[o] = pm_pack(rc, -rs);
+                        Blo[o + 16 * PM_ROW] = pm_pack(rs, rc);
+                        const float nc = fmaf(bc, e2c, -(bs * e2s)), ns = fmaf(bc, e2s, bs * e2c);
+                        bc = nc;
+                        bs = ns;
+                    }
+                }
+            }
+            __syncthreads();        // set c & 1 complete; the consumers are done with it (they read it two rounds ago)
+        }
+        return;
+    }
+
+    // ---- consumers: every row block of the group against this wave's 16 steps
+    pm_float16 acc[PM_NRB];
+#pragma unroll
+    for (int rb = 0; rb < PM_NRB; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
+    __syncthreads();                // round 0's tiles
+    for (int c = 0; c < nchunk; ++c) {
+        const unsigned *set = pm_lds + (size_t)(c & 1) * PS_SPEC_SET;
+        const unsigned *Bhi = set + (size_t)PM_NRB * 2 * PM_TILE + (size_t)part * 2 * PM_TILE, *Blo = Bhi + PM_TILE;
+        uint4 bh[PM_CH / 8], bl[PM_CH / 8];
+#pragma unroll
+        for (int s = 0; s < PM_CH / 8; ++s) {
+            const int o = rd0 ^ (8 * s);
+            bh[s] = *reinterpret_cast<const uint4 *>(Bhi + o);
+            bl[s] = *reinterpret_cast<const uint4 *>(Blo + o);
+        }
+#pragma unroll
+        for (int rb = 0; rb < PM_NRB; ++rb) {
+            if (brun[rb] < 0) continue;                                       // uniform
+            const unsigned *Ahi = set + (size_t)rb * 2 * PM_TILE, *Alo = Ahi + PM_TILE;
+            uint4 ra_hi = *reinterpret_cast<const uint4 *>(Ahi + rd0), ra_lo = *reinterpret_cast<const uint4 *>(Alo + rd0);
+#pragma unroll
+            for (int s = 0; s < PM_CH / 8; ++s) {
+                const pm_half8 a_hi = __builtin_bit_cast(pm_half8, ra_hi), a_lo = __builtin_bit_cast(pm_half8, ra_lo);
+                const pm_half8 b_hi = __builtin_bit_cast(pm_half8, bh[s]), b_lo = __builtin_bit_cast(pm_half8, bl[s]);
+                if (s + 1 < PM_CH / 8) {
+                    const int o = rd0 ^ (8 * (s + 1));
+                    ra_hi = *reinterpret_cast<const uint4 *>(Ahi + o);
+                    ra_lo = *reinterpret_cast<const uint4 *>(Alo + o);
+                }
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[rb], 0, 0, 0);
+            }
+        }
+        __syncthreads();            // this set may be overwritten (round c + 2); round c + 1's set is complete
+    }
+    const float scale = 1.0f / (sigma * 256.0f * (float)P.snum);
+#pragma unroll
+    for (int rb = 0; rb < PM_NRB; ++rb) {
+        if (brun[rb] < 0) continue;
+        const int start = Q.runs[brun[rb]].start, end = start + Q.runs[brun[rb]].len;
+        const int col = lane & 31;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            const int tau = start + PM_TT * (ba0[rb] + row) + 16 * part + (col & 15);
+            if (tau < end) TKrow[2 * (size_t)tau + (col >> 4)] = acc[rb][i] * scale;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Set-up pass, one workgroup per wavenumber, one thread per frequency at a time: everything that is float64 and per
 // (wavenumber, frequency, run) is done HERE, once, at full lane efficiency, instead of by the 8 lanes per frequency
 // of ps_mfma_kernel in every round (two float64 divisions, a square root and the catch-up over the runs per
