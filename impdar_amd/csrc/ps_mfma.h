@@ -623,7 +623,7 @@ __global__ __launch_bounds__(PS_SPEC_WAVES * 64, 1) void ps_mfma_spec_kernel(PsM
 //     runs do not cover them).
 // ---------------------------------------------------------------------------
 template <int PM_SM>      // frequencies per thread: nf <= 512 PM_SM
-__global__ __launch_bounds__(512) void ps_setup_kernel(PsMfmaParams Q)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(PM_SM <= 8 ? 4 : 2))) void ps_setup_kernel(PsMfmaParams Q)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned pm_lds[];
     const PsParams &P = Q.P;
