@@ -775,6 +775,10 @@ def run_sharded_phaseshift(data, nt, kx, ws, dt, travel_time_us, vconst=1.69e8, 
     """Phase-shift migration of a host radargram on ``ngpus`` GPUs from a single process: one worker per GPU runs
     ``migrate_phaseshift_sharded`` (wavenumber slabs -> all-to-all -> depth-row slabs).  Returns the float64
     migrated array like migrationPhaseShift (mig_python.py:282)."""
+    if not np.issubdtype(np.asarray(data).dtype, np.floating):
+        # as migrationPhaseShift: the reference's in-place taper cannot cast float -> int (mig_python.py:258)
+        raise TypeError("Cannot cast ufunc 'multiply' output from dtype('float64') to dtype('%s') with casting rule "
+                        "'same_kind'" % np.asarray(data).dtype)
     arrays = dict(kx=kx, ws=ws, travel_time=travel_time_us)
     if vmig is not None:
         arrays['vmig'] = vmig
