@@ -1,5 +1,5 @@
 """Three constant-velocity and three v(z) calls of the config-5 phase shift through the library given as argv[1]
-(timing-only ablation builds of ps_mfma_kernel: profiles/tools/variant_build.sh, r03_g37.sh)."""
+(timing-only ablation builds of ps_mfma_kernel: profiles/tools/variant_build.sh, r03_runs/r03_g37.sh)."""
 import os, sys, io, contextlib
 os.environ['IMPDAR_HIP_LIB'] = sys.argv[1]
 sys.path.insert(0, os.getcwd())
