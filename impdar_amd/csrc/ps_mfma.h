@@ -132,6 +132,9 @@ __device__ __forceinline__ void pm_sincos(double x, float *s, float *c)
 // Timing-only ablations for profiles/tools/variant_build.sh (SRC=phaseshift): results are WRONG with any of them set.
 //   PM_ABL_NOSTATE  no state tiles    PM_ABL_NOB  no step-factor tiles    PM_ABL_NOMFMA  operand reads, no MFMAs
 //   PM_ABL_NOREAD   MFMAs on whatever the operand registers hold, no LDS reads in the product phase
+#ifndef PM_BPIPE
+#define PM_BPIPE 0        // 1: the next step-factor tile is generated in slices between the MFMAs of the current run (measured: no gain, profiles/r03_ps_mfma_ablation2.txt)
+#endif
 #ifndef PM_FMAMIX
 #define PM_FMAMIX 1         // residuals by v_fma_mix_f32 (float16 half x -1 + float32, one instruction) instead of convert + subtract
 #endif
@@ -244,6 +247,30 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
         }
     };
 
+    // The same in slices, for generating the NEXT step-factor tile underneath the products of the current run
+    // (PM_BPIPE): the tile's LDS scratch is free once the current run's factors sit in registers (bh / bl below), the
+    // matrix pipe works for 32 cycles per MFMA, and the vector instructions of a slice issue in between.
+    float gb_e2s = 0.f, gb_e2c = 1.f, gb_bs = 0.f, gb_bc = 0.f;
+    auto B_begin = [&](double inc) {
+        pm_sincos(pm_wrap((double)PM_NSUB * inc), &gb_e2s, &gb_e2c);
+        pm_sincos(pm_wrap((double)(16 * part + hh + 1) * inc), &gb_bs, &gb_bc);
+        gb_bs *= 256.f;
+        gb_bc *= 256.f;
+    };
+    auto B_row = [&](int j) {
+        float rc, rs;
+        (void)pm_split(gb_bc, gb_bs, &rc, &rs);
+        const int o = 64 * j + wx[j % PM_NSLOT];
+        Bhi[o] = pm_pack(gb_bc, -gb_bs);
+        Bhi[o + 16 * PM_ROW] = pm_pack(gb_bs, gb_bc);
+        Blo[o] = pm_pack(rc, -rs);
+        Blo[o + 16 * PM_ROW] = pm_pack(rs, rc);
+        const float nc = fmaf(gb_bc, gb_e2c, -(gb_bs * gb_e2s)), ns = fmaf(gb_bc, gb_e2s, gb_bs * gb_e2c);
+        gb_bc = nc;
+        gb_bs = ns;
+    };
+    static_assert((PM_CH == 32 && 16 / PM_NSUB <= 9) || !PM_BPIPE, "three K-steps of three rows carry the rows of a step-factor tile");
+
     const int nchunk = P.nf / PM_CH;        // a multiple of PM_NQ (host): every wave makes the same number of rounds
     // long-run index of every row block (ps_setup_kernel's table)
     int blong[PM_NRB];
@@ -255,6 +282,9 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
     double2 t_next[PM_NRB];
 #pragma unroll
     for (int rb = 0; rb < PM_NRB; ++rb) t_next[rb] = tab[(size_t)(q * PM_CH + om) * Q.nlong + blong[rb]];
+#if PM_BPIPE
+    if (brun[0] >= 0) gen_B(t_next[0].x);                                     // the first round's first run
+#endif
 #define PM_STAMP(pt) \
     if (Q.stamps && blockIdx.x == gridDim.x / 2 && lane == 0 && c >= 32 && c < 48) \
         Q.stamps[((c - 32) * PM_WAVES + wave) * 6 + (pt)] = (long long)__builtin_readcyclecounter();
@@ -322,7 +352,7 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
             }
         }
         PM_STAMP(1)
-#ifndef PM_ABL_NOB
+#if !defined(PM_ABL_NOB) && !PM_BPIPE
         if (brun[0] >= 0) gen_B(incs[0]);
 #endif
         PM_STAMP(2)
@@ -340,13 +370,30 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
         for (int rb = 0; rb < PM_NRB; ++rb) {
             const int run = brun[rb];
             if (run < 0) continue;                                            // uniform
+#if !PM_BPIPE
             if (rb > 0 && brun[rb - 1] != run) {
                 __builtin_amdgcn_wave_barrier();
 #ifndef PM_ABL_NOB
                 gen_B(incs[rb]);                                              // another run: other step factors
 #endif
             }
+#endif
             __builtin_amdgcn_wave_barrier();
+            // PM_BPIPE: at the first block of a run the scratch holds this run's factors (made during the previous run's
+            // products, or the previous round's); once they are in registers the NEXT tile -- the group's next run, or the
+            // first run of the next round -- is generated in slices behind the MFMAs of this block
+            const bool run_start = rb == 0 || brun[rb - 1] != run;            // uniform
+            double inc_nextB = 0.0;
+            bool pipe_here = false;
+#if PM_BPIPE && !defined(PM_ABL_NOB)
+            if (run_start) {
+                pipe_here = true;
+                inc_nextB = t_next[0].x;                                      // no later run in the group: next round's first
+#pragma unroll
+                for (int r2 = PM_NRB - 1; r2 > rb; --r2)
+                    if (brun[r2] >= 0 && brun[r2] != brun[r2 - 1]) inc_nextB = incs[r2];   // the FIRST change after rb wins
+            }
+#endif
 #ifndef PM_ABL_NOREAD
             if (rb == 0 || brun[rb - 1] != run) {
 #pragma unroll
@@ -387,6 +434,18 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
 #else
                 // keep the operand reads alive
                 asm volatile("" ::"v"(a_hi), "v"(a_lo), "v"(b_hi), "v"(b_lo));
+#endif
+#if PM_BPIPE && !defined(PM_ABL_NOB)
+                if (pipe_here) {                                              // uniform
+                    // slices of the next step-factor tile: the two sincos behind the first K-step's MFMAs, three rows
+                    // behind each of the others
+                    if (s == 0) {
+                        B_begin(inc_nextB);
+                    } else {
+#pragma unroll
+                        for (int j = 3 * (s - 1); j < 3 * s && j < 16 / PM_NSUB; ++j) B_row(j);
+                    }
+                }
 #endif
             }
         }
