@@ -269,6 +269,8 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
         gb_bc = nc;
         gb_bs = ns;
     };
+    (void)B_begin;
+    (void)B_row;
     static_assert((PM_CH == 32 && 16 / PM_NSUB <= 9) || !PM_BPIPE, "three K-steps of three rows carry the rows of a step-factor tile");
 
     const int nchunk = P.nf / PM_CH;        // a multiple of PM_NQ (host): every wave makes the same number of rounds
@@ -385,6 +387,9 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
             const bool run_start = rb == 0 || brun[rb - 1] != run;            // uniform
             double inc_nextB = 0.0;
             bool pipe_here = false;
+            (void)run_start;
+            (void)inc_nextB;
+            (void)pipe_here;
 #if PM_BPIPE && !defined(PM_ABL_NOB)
             if (run_start) {
                 pipe_here = true;
