@@ -132,6 +132,9 @@ __device__ __forceinline__ void pm_sincos(double x, float *s, float *c)
 // Timing-only ablations for profiles/tools/variant_build.sh (SRC=phaseshift): results are WRONG with any of them set.
 //   PM_ABL_NOSTATE  no state tiles    PM_ABL_NOB  no step-factor tiles    PM_ABL_NOMFMA  operand reads, no MFMAs
 //   PM_ABL_NOREAD   MFMAs on whatever the operand registers hold, no LDS reads in the product phase
+#ifndef PM_FUSEGEN
+#define PM_FUSEGEN 1      // phase 1 as one straight-line loop over three independent recurrences (0: the separate loops)
+#endif
 #ifndef PM_BPIPE
 #define PM_BPIPE 0        // 1: the next step-factor tile is generated in slices between the MFMAs of the current run (measured: no gain, profiles/r03_ps_mfma_ablation2.txt)
 #endif
@@ -305,6 +308,94 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
 #pragma unroll
             for (int rb = 0; rb < PM_NRB; ++rb) t_next[rb] = tab[(size_t)sn * Q.nlong + blong[rb]];
         }
+#if PM_FUSEGEN && !defined(PM_ABL_NOSTATE) && !defined(PM_ABL_NOB) && !PM_BPIPE
+        // ---- phase 1, fused: the state tile of this wave's own block as TWO recurrences (rows 0..15 and 16..31 of the tile,
+        // each from its own float64-phase anchor) and the step-factor tile, advanced together in one straight-line loop.
+        // A wave's vector instructions issue ~7 cycles apart when each depends on the one before and 4 apart when they
+        // do not (profiles/tools/mfma_valu_probe.hip); the separate loops (below) were three dependent chains one after
+        // the other, with the stamps' branches between them.  The block's parameters are picked by the (uniform) part
+        // index without branching; a wave whose block does not exist fills a tile nobody reads.
+        {
+            double inc_o = incs[0], phi_o = phis[0];
+            int a0_o = ba0[0];
+#pragma unroll
+            for (int rb = 1; rb < PM_NP; ++rb) {
+                const bool me = rb == part;
+                inc_o = me ? incs[rb] : inc_o;
+                phi_o = me ? phis[rb] : phi_o;
+                a0_o = me ? ba0[rb] : a0_o;
+            }
+            const bool in_o = phi_o == phi_o;
+            const double ph0 = in_o ? phi_o : 0.0;
+            constexpr int NJ = 32 / PM_NSUB, NJH = NJ / 2;
+            float sx, cx, sy, cy, Es, Ec, e2s, e2c, bs, bc;
+            pm_sincos(pm_wrap(ph0 + (double)(PM_TT * (a0_o + hh)) * inc_o), &sx, &cx);
+            pm_sincos(pm_wrap(ph0 + (double)(PM_TT * (a0_o + PM_NSUB * NJH + hh)) * inc_o), &sy, &cy);
+            pm_sincos(pm_wrap((double)(PM_NSUB * PM_TT) * inc_o), &Es, &Ec);
+            pm_sincos(pm_wrap((double)PM_NSUB * incs[0]), &e2s, &e2c);
+            pm_sincos(pm_wrap((double)(16 * part + hh + 1) * incs[0]), &bs, &bc);
+            bs *= 256.f;
+            bc *= 256.f;
+            const float gr = in_o ? f0r : 0.f, gi = in_o ? f0i : 0.f;
+            float xr = fmaf(gr, cx, -(gi * sx)), xi = fmaf(gr, sx, gi * cx);
+            float yr = fmaf(gr, cy, -(gi * sy)), yi = fmaf(gr, sy, gi * cy);
+            unsigned *Ahi = Aq + (size_t)part * 2 * PM_TILE, *Alo = Ahi + PM_TILE;
+#pragma unroll
+            for (int j = 0; j < NJH; ++j) {
+                float rr, ri, qr, qi, rc, rs;
+                const int ox = 64 * j + wx[j % PM_NSLOT], oy = 64 * (j + NJH) + wx[(j + NJH) % PM_NSLOT];
+                const unsigned hx = pm_split(xr, xi, &rr, &ri), hy = pm_split(yr, yi, &qr, &qi);
+                (void)pm_split(bc, bs, &rc, &rs);
+                Ahi[ox] = hx;
+                Ahi[oy] = hy;
+                Alo[ox] = pm_pack(rr, ri);
+                Alo[oy] = pm_pack(qr, qi);
+                const int ob = 64 * j + wx[j % PM_NSLOT];
+                Bhi[ob] = pm_pack(bc, -bs);
+                Bhi[ob + 16 * PM_ROW] = pm_pack(bs, bc);
+                Blo[ob] = pm_pack(rc, -rs);
+                Blo[ob + 16 * PM_ROW] = pm_pack(rs, rc);
+                const float nxr = fmaf(xr, Ec, -(xi * Es)), nxi = fmaf(xr, Es, xi * Ec);
+                const float nyr = fmaf(yr, Ec, -(yi * Es)), nyi = fmaf(yr, Es, yi * Ec);
+                const float nc = fmaf(bc, e2c, -(bs * e2s)), ns = fmaf(bc, e2s, bs * e2c);
+                xr = nxr;
+                xi = nxi;
+                yr = nyr;
+                yi = nyi;
+                bc = nc;
+                bs = ns;
+            }
+            static_assert(16 / PM_NSUB == 32 / PM_NSUB / 2, "the step-factor tile has as many rows per lane as half a state tile");
+        }
+        // the fifth block of a full group: a quarter of its rows by every wave
+        if (brun[PM_NRB - 1] >= 0) {                                          // uniform
+            constexpr int rb = PM_NRB - 1, NJQ = 32 / PM_NSUB / PM_NP;
+            const double inc = incs[rb];
+            const bool in = phis[rb] == phis[rb];
+            float s, cph, Es, Ec;
+            pm_sincos(pm_wrap((in ? phis[rb] : 0.0) + (double)(PM_TT * (ba0[rb] + PM_NSUB * NJQ * part + hh)) * inc), &s, &cph);
+            pm_sincos(pm_wrap((double)(PM_NSUB * PM_TT) * inc), &Es, &Ec);
+            const float gr = in ? f0r : 0.f, gi = in ? f0i : 0.f;
+            float sr = fmaf(gr, cph, -(gi * s)), si = fmaf(gr, s, gi * cph);
+            unsigned *Ahi = Aq + (size_t)rb * 2 * PM_TILE, *Alo = Ahi + PM_TILE;
+#pragma unroll
+            for (int p4 = 0; p4 < PM_NP; ++p4)
+                if (p4 == part) {                                             // uniform
+#pragma unroll
+                    for (int jj = 0; jj < NJQ; ++jj) {
+                        const int j = NJQ * p4 + jj;
+                        float rr, ri;
+                        const int o = 64 * j + wx[j % PM_NSLOT];
+                        Ahi[o] = pm_split(sr, si, &rr, &ri);
+                        Alo[o] = pm_pack(rr, ri);
+                        const float nr = fmaf(sr, Ec, -(si * Es)), ni = fmaf(sr, Es, si * Ec);
+                        sr = nr;
+                        si = ni;
+                    }
+                }
+        }
+        PM_STAMP(1)
+#else
         // ---- phase 1: this wave's state tile(s); the step factors of the first run
 #pragma unroll
         for (int rb = 0; rb < PM_NRB; ++rb) {
@@ -356,6 +447,7 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
         PM_STAMP(1)
 #if !defined(PM_ABL_NOB) && !PM_BPIPE
         if (brun[0] >= 0) gen_B(incs[0]);
+#endif
 #endif
         PM_STAMP(2)
         __syncthreads();            // the half's state tiles are complete
