@@ -132,6 +132,11 @@ __device__ __forceinline__ void pm_sincos(double x, float *s, float *c)
 // Timing-only ablations for profiles/tools/variant_build.sh (SRC=phaseshift): results are WRONG with any of them set.
 //   PM_ABL_NOSTATE  no state tiles    PM_ABL_NOB  no step-factor tiles    PM_ABL_NOMFMA  operand reads, no MFMAs
 //   PM_ABL_NOREAD   MFMAs on whatever the operand registers hold, no LDS reads in the product phase
+//   PM_ABL_NOBAR    no workgroup barriers in the round loop    PM_ABL_NOLOAD  no spectrum / run-table loads in the round loop (and what depends on them
+//   is hoisted: not a measure of the loads)    PM_ABL_HOTLOAD  the loads of every round hit the same cached entries
+#ifndef PM_LDSBAR
+#define PM_LDSBAR 0       // 1: the round loop barriers wait for LDS only, not for the global loads in flight (measured: no difference)
+#endif
 #ifndef PM_FUSEGEN
 #define PM_FUSEGEN 1      // phase 1 as one straight-line loop over three independent recurrences (0: the separate loops)
 #endif
@@ -162,6 +167,16 @@ __device__ __forceinline__ unsigned pm_split(float x, float y, float *rx, float 
     return hb;
 }
 __device__ __forceinline__ unsigned pm_pack(float x, float y) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, y)); }
+
+// Workgroup barrier for data exchanged through LDS only: every wave's LDS operations are complete (lgkmcnt 0) before it
+// arrives, but its global loads stay in flight (__syncthreads() also waits for those, vmcnt 0).  Tried because the
+// loads of a round always hitting the same cached entries (PM_ABL_HOTLOAD) made the kernel 14 % faster; this barrier
+// changed nothing, so that gain is the data's (the same low, mostly evanescent frequencies every round), not the loads'.
+#if PM_LDSBAR
+__device__ __forceinline__ void pm_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#else
+__device__ __forceinline__ void pm_lds_barrier() { __syncthreads(); }
+#endif
 
 __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_kernel(PsMfmaParams Q)
 {
@@ -302,12 +317,19 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
             incs[rb] = t_next[rb].x;
             phis[rb] = t_next[rb].y;
         }
+#ifndef PM_ABL_NOLOAD
         {
+#ifdef PM_ABL_HOTLOAD
+            int sn = q * PM_CH + om;                      // the same (cached) entries every round; opaque, so nothing is hoisted
+            asm volatile("" : "+v"(sn));
+#else
             const int sn = min(c + PM_NQ, nchunk - 1) * PM_CH + om;
+#endif
             f_next = ps_load_slot<float>(Frow, P, sn);
 #pragma unroll
             for (int rb = 0; rb < PM_NRB; ++rb) t_next[rb] = tab[(size_t)sn * Q.nlong + blong[rb]];
         }
+#endif
 #if PM_FUSEGEN && !defined(PM_ABL_NOSTATE) && !defined(PM_ABL_NOB) && !PM_BPIPE
         // ---- phase 1, fused: the state tile of this wave's own block as TWO recurrences (rows 0..15 and 16..31 of the tile,
         // each from its own float64-phase anchor) and the step-factor tile, advanced together in one straight-line loop.
@@ -450,7 +472,9 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
 #endif
 #endif
         PM_STAMP(2)
-        __syncthreads();            // the half's state tiles are complete
+#ifndef PM_ABL_NOBAR
+        pm_lds_barrier();           // the half's state tiles are complete
+#endif
         PM_STAMP(3)
         // ---- phase 2: every row block of the group against this wave's 16 steps: 32 frequencies = 4 K-steps of 8.  The
         // operands of step s + 1 are read while the three MFMAs of step s run (a read-wait-compute sequence per step
@@ -547,7 +571,9 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
             }
         }
         PM_STAMP(4)
-        __syncthreads();            // ... and read by everybody before the next round overwrites them
+#ifndef PM_ABL_NOBAR
+        pm_lds_barrier();           // ... and read by everybody before the next round overwrites them
+#endif
         PM_STAMP(5)
     }
 
