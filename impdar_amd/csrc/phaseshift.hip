@@ -1411,8 +1411,15 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
         for (int a0 = 0; a0 < ntile; a0 += 32) blocks.push_back(make_int2((int)r, a0));
     }
     const int nb = (int)blocks.size();
-    if (nb == 0 || nshort_steps > 96 || (int)runs.size() - (vz ? (int)std::count_if(runs.begin(), runs.end(), [](const PsMfmaRun &r) { return r.len <= PM_SHORT; }) : 0) > 8) return IMPDAR_OK;
-    if ((long long)nb * 32 * PM_TT > (long long)snum * 7 / 4 + 32 * PM_TT) return IMPDAR_OK;      // many medium runs: rows mostly padding
+    // limits of the matrix-core path (IMPDAR_PS_MFMA_LONG / _PAD / _SHORT override them for experiments): long runs, row
+    // padding (blocks x 2048 steps against the record), steps in short runs.  A row block costs ~2.4 ms at 8192^2 and the
+    // vector runs kernels ~40-50 ms for the whole record: 16 runs / 3 x padding is where the two meet (a 21-row table of
+    // equal layers: 44.5 -> 38.1 ms; 8 / 1.75 / 96 until late in round 3, profiles/r03_ps_layers.txt)
+    static const int max_long = getenv("IMPDAR_PS_MFMA_LONG") ? atoi(getenv("IMPDAR_PS_MFMA_LONG")) : 16;
+    static const double max_pad = getenv("IMPDAR_PS_MFMA_PAD") ? atof(getenv("IMPDAR_PS_MFMA_PAD")) : 3.0;
+    static const int max_short = getenv("IMPDAR_PS_MFMA_SHORT") ? atoi(getenv("IMPDAR_PS_MFMA_SHORT")) : 200;
+    if (nb == 0 || nshort_steps > max_short || (int)runs.size() - (vz ? (int)std::count_if(runs.begin(), runs.end(), [](const PsMfmaRun &r) { return r.len <= PM_SHORT; }) : 0) > max_long) return IMPDAR_OK;
+    if ((double)nb * 32 * PM_TT > (double)snum * max_pad + 32 * PM_TT) return IMPDAR_OK;      // many medium runs: rows mostly padding
     // groups of up to PM_NRB row blocks (the state tiles a workgroup keeps in LDS), consecutive blocks together
     int ngroups = (nb + PM_NRB - 1) / PM_NRB;
     const int per_group = (nb + ngroups - 1) / ngroups;

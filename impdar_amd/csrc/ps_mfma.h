@@ -67,7 +67,7 @@ constexpr int PM_NRB = 5;                   // row blocks per group (state tiles
 constexpr int PM_WAVES = PM_NQ * PM_NP;
 constexpr int PM_RED_LD = 20;               // dwords per lane in the final reduction image (16 + 4: conflict-free b128)
 constexpr int PM_EMAX = 16;                 // boundary frequencies listed per wavenumber
-constexpr int PM_MAX_RUNS = 32;
+constexpr int PM_MAX_RUNS = 96;
 constexpr int PM_SHORT = 8;                 // runs of up to this many steps (the few steps a layer boundary is smeared over) get no row blocks: ps_trans_kernel
 constexpr size_t PM_LDS_BYTES = ((size_t)PM_NQ * PM_NRB * 2 + (size_t)PM_WAVES * 2) * PM_TILE * 4 + 64;
 
