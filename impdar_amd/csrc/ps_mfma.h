@@ -167,6 +167,11 @@ __device__ __forceinline__ unsigned pm_split(float x, float y, float *rx, float 
     return hb;
 }
 __device__ __forceinline__ unsigned pm_pack(float x, float y) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, y)); }
+// from the packed pair (x, y): (x, -y) and (y, x) -- exact: rounding toward zero is symmetric in the sign, so these are the
+// words pm_pack(x, -y) and pm_pack(y, x) would give, for one conversion instead of three (the conversion is a half-rate
+// instruction; the kernel is bound by vector issue)
+__device__ __forceinline__ unsigned pm_conj(unsigned h) { return h ^ 0x80000000u; }
+__device__ __forceinline__ unsigned pm_swap(unsigned h) { return __builtin_amdgcn_alignbit(h, h, 16); }
 
 // Workgroup barrier for data exchanged through LDS only: every wave's LDS operations are complete (lgkmcnt 0) before it
 // arrives, but its global loads stay in flight (__syncthreads() also waits for those, vmcnt 0).  Tried because the
@@ -252,13 +257,12 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
             // column b (re) holds (B_re, -B_im) against (S_re, S_im); column 16 + b (im) holds (B_im, B_re): four pack
             // conversions (the negation is a source modifier) instead of shifting and masking two packed pairs apart
             float rc, rs;
-            const unsigned h0 = pm_split(bc, bs, &rc, &rs);          // residuals of (cos, sin)
-            (void)h0;
+            const unsigned h0 = pm_split(bc, bs, &rc, &rs), l0 = pm_pack(rc, rs);      // (cos, sin): high halves, residuals
             const int o = 64 * j + wx[j % PM_NSLOT];
-            Bhi[o] = pm_pack(bc, -bs);                                 // (cos, -sin)
-            Bhi[o + 16 * PM_ROW] = pm_pack(bs, bc);                    // (sin, cos)
-            Blo[o] = pm_pack(rc, -rs);
-            Blo[o + 16 * PM_ROW] = pm_pack(rs, rc);
+            Bhi[o] = pm_conj(h0);                                      // (cos, -sin)
+            Bhi[o + 16 * PM_ROW] = pm_swap(h0);                        // (sin, cos)
+            Blo[o] = pm_conj(l0);
+            Blo[o + 16 * PM_ROW] = pm_swap(l0);
             const float nc = fmaf(bc, e2c, -(bs * e2s)), ns = fmaf(bc, e2s, bs * e2c);
             bc = nc;
             bs = ns;
@@ -277,12 +281,12 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
     };
     auto B_row = [&](int j) {
         float rc, rs;
-        (void)pm_split(gb_bc, gb_bs, &rc, &rs);
+        const unsigned h0 = pm_split(gb_bc, gb_bs, &rc, &rs), l0 = pm_pack(rc, rs);
         const int o = 64 * j + wx[j % PM_NSLOT];
-        Bhi[o] = pm_pack(gb_bc, -gb_bs);
-        Bhi[o + 16 * PM_ROW] = pm_pack(gb_bs, gb_bc);
-        Blo[o] = pm_pack(rc, -rs);
-        Blo[o + 16 * PM_ROW] = pm_pack(rs, rc);
+        Bhi[o] = pm_conj(h0);
+        Bhi[o + 16 * PM_ROW] = pm_swap(h0);
+        Blo[o] = pm_conj(l0);
+        Blo[o + 16 * PM_ROW] = pm_swap(l0);
         const float nc = fmaf(gb_bc, gb_e2c, -(gb_bs * gb_e2s)), ns = fmaf(gb_bc, gb_e2s, gb_bs * gb_e2c);
         gb_bc = nc;
         gb_bs = ns;
@@ -367,16 +371,16 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
                 float rr, ri, qr, qi, rc, rs;
                 const int ox = 64 * j + wx[j % PM_NSLOT], oy = 64 * (j + NJH) + wx[(j + NJH) % PM_NSLOT];
                 const unsigned hx = pm_split(xr, xi, &rr, &ri), hy = pm_split(yr, yi, &qr, &qi);
-                (void)pm_split(bc, bs, &rc, &rs);
+                const unsigned hb = pm_split(bc, bs, &rc, &rs), lb = pm_pack(rc, rs);
                 Ahi[ox] = hx;
                 Ahi[oy] = hy;
                 Alo[ox] = pm_pack(rr, ri);
                 Alo[oy] = pm_pack(qr, qi);
                 const int ob = 64 * j + wx[j % PM_NSLOT];
-                Bhi[ob] = pm_pack(bc, -bs);
-                Bhi[ob + 16 * PM_ROW] = pm_pack(bs, bc);
-                Blo[ob] = pm_pack(rc, -rs);
-                Blo[ob + 16 * PM_ROW] = pm_pack(rs, rc);
+                Bhi[ob] = pm_conj(hb);
+                Bhi[ob + 16 * PM_ROW] = pm_swap(hb);
+                Blo[ob] = pm_conj(lb);
+                Blo[ob + 16 * PM_ROW] = pm_swap(lb);
                 const float nxr = fmaf(xr, Ec, -(xi * Es)), nxi = fmaf(xr, Es, xi * Ec);
                 const float nyr = fmaf(yr, Ec, -(yi * Es)), nyi = fmaf(yr, Es, yi * Ec);
                 const float nc = fmaf(bc, e2c, -(bs * e2s)), ns = fmaf(bc, e2s, bs * e2c);
@@ -720,12 +724,12 @@ __global__ __launch_bounds__(PS_SPEC_WAVES * 64, 1) void ps_mfma_spec_kernel(PsM
 #pragma unroll
                     for (int j = 0; j < 16 / PM_NSUB; ++j) {
                         float rc, rs;
-                        (void)pm_split(bc, bs, &rc, &rs);
+                        const unsigned h0 = pm_split(bc, bs, &rc, &rs), l0 = pm_pack(rc, rs);
                         const int o = 64 * j + wx[j % PM_NSLOT];
-                        Bhi[o] = pm_pack(bc, -bs);
-                        Bhi[o + 16 * PM_ROW] = pm_pack(bs, bc);
-                        Blo[o] = pm_pack(rc, -rs);
-                        Blo[o + 16 * PM_ROW] = pm_pack(rs, rc);
+                        Bhi[o] = pm_conj(h0);
+                        Bhi[o + 16 * PM_ROW] = pm_swap(h0);
+                        Blo[o] = pm_conj(l0);
+                        Blo[o + 16 * PM_ROW] = pm_swap(l0);
                         const float nc = fmaf(bc, e2c, -(bs * e2s)), ns = fmaf(bc, e2s, bs * e2c);
                         bc = nc;
                         bs = ns;
