@@ -55,6 +55,7 @@ SIGNATURES = {
     'impdar_kirch_plan_destroy': (None, [_p]),
     'impdar_kirch_plan_mode': (_i, [_p]),
     'impdar_kirch_plan_tnum_pad': (_i, [_p]),
+    'impdar_kirch_plan_xnoise': (_d, [_p]),
     'impdar_kirch_plan_kernel': (_i, [_p]),
     'impdar_kirch_prep': (_i, [_p, _p, _i, _i, _i]),
     'impdar_kirch_allgather': (_i, [_p]),

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libimpdar_hip.so')
-SOURCES = ['api.hip', 'comm.hip', 'kirchhoff.hip', 'stolt.hip', 'phaseshift.hip', 'preproc.hip']
+SOURCES = ['api.hip', 'comm.hip', 'kirchhoff.hip', 'kirch_gen.hip', 'stolt.hip', 'phaseshift.hip', 'preproc.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off',
          '-fno-slp-vectorize', '-Wall', '-Wno-unused-function']
 
@@ -19,16 +19,30 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
+def _headers(path, seen=None):
+    """The local headers a source includes (transitively) + the public header: its rebuild triggers."""
+    import re
+    seen = set() if seen is None else seen
+    with open(path) as f:
+        names = re.findall(r'^\s*#\s*include\s+"([^"]+)"', f.read(), flags=re.M)
+    for n in names:
+        h = os.path.join(CSRC, n)
+        if not os.path.exists(h):
+            h = os.path.join(HERE, '..', 'include', os.path.basename(n))
+        if os.path.exists(h) and h not in seen:
+            seen.add(h)
+            _headers(h, seen)
+    return sorted(seen)
+
+
 def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + sorted(os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith('.h')) + \
-        [os.path.join(HERE, '..', 'include', 'impdar_hip.h')]
     objs, jobs = [], []
     for s in srcs:
         o = s[:-4] + '.o'
         objs.append(o)
-        if force or _newer(s, o) or any(_newer(d, o) for d in deps[len(srcs):]):
+        if force or _newer(s, o) or any(_newer(d, o) for d in _headers(s)):
             cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)

@@ -23,15 +23,13 @@
 //                        same idea with a trace-major ring, ds_read_b32 and an fp32 weight table,
 //                        for geometries whose moveout does not fit the quad ring.
 #include "common.h"
+#include "kirch_plan.h"
 #include <limits>
 #include <cmath>
 #include <algorithm>
 #include <chrono>
 #include <thread>
 
-#define KF_THREADS 256
-#define KF_W 512            // LDS floats per ring slot (circular window)
-#define KF_PAD_ROWS 128      // zero traces kept on both sides of the image (loops are clipped to the profile)
 
 // ===========================================================================
 // prep: gradient + transpose
@@ -1739,90 +1737,6 @@ __global__ __launch_bounds__(256) void kirch_combine_kernel(const T *__restrict_
 // ===========================================================================
 // host side
 // ===========================================================================
-struct impdar_kirch_plan {
-    impdar_ctx *ctx = nullptr;
-    int dtype = IMPDAR_F32, snum = 0, tnum = 0, tnum_pad = 0, nranks = 1;
-    int nearfield = 0, mode = IMPDAR_KIRCH_EXACT;
-    int grad_uniform = 0;
-    double grad_h = 1.0, vel = 0, tmax = 0, dt = 1, dx = 1, tt0 = 0, alpha = 1;
-    bool uniform = false;
-    bool dist_sorted = false;
-    // exact path on uniform grids: fp64 pick / weight tables (built at the first migrate)
-    DevBuf d_XK, d_XW, d_XW2, d_xhmax;
-    int xntab = 0;
-    bool xtab_ready = false, xtab_off = false;
-    int diag_tables_built = 0;
-    bool table_built[2] = {false, false};   // ring kernels: the geometry-only pick table of buffer set b exists
-    // device tables
-    DevBuf d_dist, d_tt, d_zs, d_zs2, d_ga, d_gb, d_gc;
-    // Everything a prep produces is double-buffered: prep / table / all-gather of radargram
-    // s+1 run on the context's aux stream while the diffraction sum of radargram s runs on
-    // the compute stream.  `buf` flips at the first prep after a migrate.
-    DevBuf GT[2], DT[2];           // images with KF_PAD_ROWS all-zero rows before row 0 and after row tnum_pad-1
-    int buf = 0;
-    bool migrated_since_prep = false;
-    const void *last_out = nullptr;   // output of the last migrate (a prep that reads it must wait for that kernel)
-    int last_out_buf = 0;
-    hipEvent_t ev_ready[2] = {nullptr, nullptr};   // image + table of buffer b complete (aux stream)
-    hipEvent_t ev_free[2] = {nullptr, nullptr};    // last migrate reading buffer b done (compute stream)
-    bool free_recorded[2] = {false, false};
-    DevBuf d_hmax, d_klo, d_khi;
-    DevBuf d_TK[2], d_TW[2], d_TW2[2], d_c1, d_c2, d_fin, d_WIN;
-    int nrows = 0, mrow0 = 0;   // quad kernel: step-block table rows (see FastParams)
-    int quadSH = 0;             // table entries are LDS byte offsets >> quadSH
-    DevBuf d_stamps;               // diagnostic builds only
-    int nb = 0, ntab = 0;
-    bool quad = false;          // sample-major LDS ring (kirch_quad_kernel)
-    std::vector<int> h_hmax;    // host copy of the per-chunk aperture half widths (tile cost model)
-    DevBuf d_queue;             // quad kernel, persistent workgroups: per-XCD item counters
-    int slots = 0;              // ... and how many of them are resident at once (occupancy query, cached)
-    int walk_parts_log2 = 0;    // every tile's aperture walk as 1, 2 or 4 queue items (plans of 4+ / 8+ ranks)
-    DevBuf d_partial;           // ... and the partial images of the pieces
-    DevBuf d_tilemap;           // ring kernels: (chunk, slot, XCD) -> output tile, balanced over the XCDs
-    std::vector<short> h_tilemap;
-    int tm_key[5] = {-1, -1, -1, -1, -1};   // (xlo, xhi, tile width, G, tiles_per_xcd) the cached map was built for
-    int nh = 1;                 // quad kernel: output tiles per workgroup sharing one ring (256 nh threads)
-    int lk = 0;                 // ... and extra ring groups = blocks of additional staging lookahead (nh >= 2 only)
-    bool dquad = false;         // the same ring in float64 (kirch_dquad_kernel): exact mode, float64 data, uniform grids
-    double xnoise = 0;          // position noise of dist[j] - dist[xi] in units of dx (see plan creation)
-    bool tie_ambiguous = false; // more rounding-noise ties than the list holds: per-pair kernel only
-    int ntie_groups = 0;        // samples with flagged offsets (kirch_tiefix_kernel after every table-driven diffraction sum)
-    DevBuf d_tie_ti, d_tie_off, d_tie_n;
-    DevBuf d_c1d, d_c2d, d_find;
-    int quadW = 0;              // samples per ring slot in that layout
-    // host copies for pair counting
-    std::vector<int> h_half;       // exact aperture half-width per sample (uniform grids)
-    int nchunks = 0;
-    // ring of HIP-event sets so a timed loop can read per-step kernel
-    // durations afterwards without synchronising inside the loop
-    static constexpr int NSLOT = 64;
-    hipEvent_t evs[NSLOT][6] = {};
-    bool haves[NSLOT][3] = {};
-    int slot = 0;
-    int xb = 24;                   // fast-kernel trace tile (24: quad ring, 16: tab ring)
-
-    ~impdar_kirch_plan()
-    {
-        for (hipEvent_t e : {ev_ready[0], ev_ready[1], ev_free[0], ev_free[1]})
-            if (e) (void)hipEventDestroy(e);
-        for (int s = 0; s < NSLOT; ++s)
-            for (int i = 0; i < 6; ++i)
-                if (evs[s][i]) (void)hipEventDestroy(evs[s][i]);
-    }
-};
-
-static inline char *img_row0(const impdar_kirch_plan *p, const DevBuf &b)  // b = GT[buf] / DT[buf]
-{
-    return reinterpret_cast<char *>(b.p) + (size_t)KF_PAD_ROWS * p->snum * impdar_dtype_size(p->dtype);
-}
-
-static int upload(DevBuf &b, const void *src, size_t bytes)
-{
-    IMPDAR_HIP_CHECK(b.ensure(bytes ? bytes : 8));
-    if (bytes) IMPDAR_HIP_CHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
-    return IMPDAR_OK;
-}
-
 // set by mig_kirch_loop around its plan creation: the time limit t > t_max drops a pair at (mig_python.py:52) is the
 // caller's argument there, not max(tt)
 static thread_local const double *g_tmax_override = nullptr;
@@ -1973,16 +1887,43 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     const bool fast_ok = dtype == IMPDAR_F32 && p->uniform && window_ok && snum < 65536 &&
                          std::fabs(tmax / dt) / sa < 65000.0 && span_ok;
 
+    // float32 data on a profile whose spacing is NOT uniform (mig_python.py:44 takes any dist[]): kirch_gen_kernel
+    // computes every pair's pick from the positions.  It needs a uniform time axis, a sorted dist[] (the staging windows
+    // and the input range of a tile come from bisections) and, per 32 consecutive output traces, a moveout that fits
+    // its LDS slots: W >= 264 + (extent of the 32 traces in samples).  IMPDAR_KIRCH_IMPL=gen takes it on uniform
+    // profiles too (A/B against the ring kernels).
+    int gen_w = 0;
+    bool gen_ok = false;
+    bool uni_t11 = uni_t;          // the float64 re-decision of a pick takes tt[k] = tt[0] + k dt: to 1e-11 dt here
+    for (int k = 0; k < snum && uni_t11; ++k)
+        if (std::fabs(tt_sec[k] - (tt_sec[0] + k * dt)) > 1e-11 * dt) uni_t11 = false;
+    if (dtype == IMPDAR_F32 && uni_t11 && p->dist_sorted && tnum >= 2 && snum >= 4 && snum < (1 << 22) && !g_tmax_override &&
+        (double)tnum * snum * 4.0 < 2147483648.0) {
+        double ext = 0.0;
+        for (int j = 0; j < tnum; ++j) ext = std::max(ext, dist_m[std::min(j + 31, tnum - 1)] - dist_m[j]);
+        const double need = 264.0 + std::ceil(ext * 2.0 / (vel * dt));
+        if (need <= 1024.0) {
+            gen_w = ((int)need + 255) / 256 * 256;
+            if (gen_w < 512) gen_w = 512;
+            gen_ok = true;
+        }
+    }
+    const char *impl_env = getenv("IMPDAR_KIRCH_IMPL");
+    const bool gen_forced = gen_ok && impl_env && !strcmp(impl_env, "gen") && mode != IMPDAR_KIRCH_EXACT;
     const int requested_mode = mode;
-    if (mode == IMPDAR_KIRCH_AUTO) mode = fast_ok ? IMPDAR_KIRCH_FAST : IMPDAR_KIRCH_EXACT;
-    if (mode == IMPDAR_KIRCH_FAST && !fast_ok) {
+    const bool gen = gen_forced || (gen_ok && !fast_ok && mode != IMPDAR_KIRCH_EXACT);
+    if (mode == IMPDAR_KIRCH_AUTO) mode = (fast_ok || gen) ? IMPDAR_KIRCH_FAST : IMPDAR_KIRCH_EXACT;
+    if (mode == IMPDAR_KIRCH_FAST && !fast_ok && !gen) {
         delete p;
-        impdar_set_error("fast Kirchhoff kernel needs float32 data on uniform dist/travel_time grids "
-                         "with moveout 2dx/(v dt) <= %.1f samples per trace (got %.2f)",
+        impdar_set_error("the float32 Kirchhoff kernels need float32 data on a uniform travel_time axis and either a "
+                         "uniform dist with moveout 2dx/(v dt) <= %.1f samples per trace (got %.2f) or a sorted dist "
+                         "whose 32-trace windows span <= 760 samples of moveout",
                          (KF_W - KF_THREADS - 8.0) / 15.0, sa);
         return IMPDAR_ERR_UNSUPPORTED;
     }
     p->mode = mode;
+    p->gen = gen && mode == IMPDAR_KIRCH_FAST;
+    p->genW = gen_w;
     {
         // One full-aperture walk of a shallow chunk takes ~1.2 ms at config 3 -- as long as the whole step of a rank of
         // an 8-GPU run should be, and such a rank's block has fewer items than the chip has workgroup slots.  Plans
@@ -1996,20 +1937,22 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         const char *ie = getenv("IMPDAR_KIRCH_IMPL");       // tuning knob: "tab" forces the b32 ring
         p->quadW = wq;
         p->quadSH = ((size_t)(wq / 32) * kq_ps <= 65535) ? 0 : 4;
-        p->quad = (mode == IMPDAR_KIRCH_FAST) && quad_ok && !(ie && !strcmp(ie, "tab") && tab_ok);
-        p->xb = p->quad ? xbq : 16;
+        p->quad = (mode == IMPDAR_KIRCH_FAST) && !p->gen && quad_ok && !(ie && !strcmp(ie, "tab") && tab_ok);
+        p->xb = p->gen ? 32 : (p->quad ? xbq : 16);
     }
     // float64 data in exact mode on uniform grids: the same ring in float64 (20 or 16 output traces per lane,
     // step blocks of 4) when its window fits; otherwise (and for IMPDAR_KIRCH_EXACT_IMPL = tab | pair) the
     // global-memory kernels
     // The table-driven float64 kernels weight a pair by its trace OFFSET (n dx); the reference by dist[j] - dist[xi].
     // On a profile whose positions are noisy against the grid (a first trace tens of kilometres along the line:
-    // ulp(dist) / dx ~ 1e-10; spacing that is uniform only to 1e-9) the weights differ by that much, and the stated
-    // 1e-12 of the float64 path no longer holds (measured 2.5e-12 with the near-field term at xnoise 1e-10): such
-    // profiles keep the per-pair kernel in exact mode.  40000 traces of 1 m from 0 have xnoise 1.8e-11.
-    const bool noisy_x = p->xnoise > 3e-11;
-    if (mode == IMPDAR_KIRCH_EXACT && noisy_x && !getenv("IMPDAR_KIRCH_EXACT_IMPL")) p->xtab_off = true;
-    if (mode == IMPDAR_KIRCH_EXACT && dtype == IMPDAR_F64 && p->uniform && !noisy_x && snum < 65536 &&
+    // ulp(dist) / dx ~ 1e-10; 100000 traces from 0: 4.5e-11) the two weights differ by that much relative, and the
+    // result differs from the reference's by up to ~0.03 xnoise of the image maximum (measured 2.5e-12 at 1e-10 with
+    // the near-field term).  Rounds 2-3 sent every profile with xnoise > 3e-11 to the per-pair kernel to hold a flat
+    // 1e-12 -- 45-100x slower on ordinary long traverses.  The ring (and the tabulated kernel) now stay; the stated bar
+    // of the float64 path is  max(1e-12, 0.1 xnoise)  of the image maximum (impdar_kirch_plan_xnoise reports xnoise;
+    // picks are not affected: every pick within the noise of a tie is re-done pair by pair, kirch_tiefix_kernel).
+    // IMPDAR_KIRCH_EXACT_IMPL=pair still forces the reference's arithmetic pair by pair.
+    if (mode == IMPDAR_KIRCH_EXACT && dtype == IMPDAR_F64 && p->uniform && snum < 65536 &&
         std::fabs(tmax / dt) / sa < 65000.0 && (2.0 * hest + 400.0) / 4.0 * (double)snum * 32.0 < 2147483648.0 &&
         !getenv("IMPDAR_KIRCH_EXACT_IMPL")) {
         const char *ne = getenv("IMPDAR_KIRCH_NHD");        // tuning knob: tiles per workgroup, 1 | 2
@@ -2065,7 +2008,9 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
             zs[k] = vel * tt_sec[k] / 2.0;          // mig_python.py:101
             zs2[k] = zs[k] * zs[k];                 // :102
         }
-        if ((rc = upload(p->d_dist, dist_m, (size_t)tnum * 8)) || (rc = upload(p->d_tt, tt_sec, (size_t)snum * 8)) ||
+        std::vector<double> dpad(dist_m, dist_m + tnum);
+        dpad.resize((size_t)tnum + 64, dist_m[tnum - 1]);      // kirch_gen_kernel reads up to 31 entries past a tile's end
+        if ((rc = upload(p->d_dist, dpad.data(), dpad.size() * 8)) || (rc = upload(p->d_tt, tt_sec, (size_t)snum * 8)) ||
             (rc = upload(p->d_zs, zs.data(), (size_t)snum * 8)) || (rc = upload(p->d_zs2, zs2.data(), (size_t)snum * 8)))
             return fail(rc);
     }
@@ -2081,7 +2026,7 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     }
     // ---- picks that rounding noise decides (see kirch_tiescan_kernel): the table-driven kernels would break those
     // ties one way per offset, the reference breaks them pair by pair
-    if (p->uniform && (mode == IMPDAR_KIRCH_FAST || p->dquad || !getenv("IMPDAR_KIRCH_EXACT_IMPL") ||
+    if (p->uniform && !gen_forced && (mode == IMPDAR_KIRCH_FAST || p->dquad || !getenv("IMPDAR_KIRCH_EXACT_IMPL") ||
                        strcmp(getenv("IMPDAR_KIRCH_EXACT_IMPL"), "pair"))) {
         int hg = 0;
         for (int k = 0; k < snum; ++k) hg = std::max(hg, p->h_half[k] + 1);
@@ -2115,6 +2060,21 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
             hipStreamSynchronize(ctx->stream) != hipSuccess) {
             impdar_set_error("tie scan failed: %s", hipGetErrorString(hipGetLastError()));
             return fail(IMPDAR_ERR_HIP);
+        }
+        if (p->gen && count > 0) {
+            // kirch_gen_kernel on a UNIFORM profile (steep moveout: the ring kernels' windows do not fit) decides a pick
+            // that sits on a half-way point by exact arithmetic; the reference by the rounding noise of its own
+            // sqrt / divide, pair by pair (see kirch_tiescan_kernel).  A rational moveout has such entries: those
+            // profiles keep the float64 kernels, which re-do them the reference's way.
+            if (requested_mode == IMPDAR_KIRCH_FAST) {
+                impdar_set_error("the float32 Kirchhoff kernels cannot reproduce the %d picks that rounding noise "
+                                 "decides on this uniform profile (moveout %.4f samples per trace); use mode auto / exact",
+                                 count, sa);
+                return fail(IMPDAR_ERR_UNSUPPORTED);
+            }
+            p->gen = false;
+            mode = p->mode = IMPDAR_KIRCH_EXACT;
+            p->xb = 16;
         }
         const bool no_fix = getenv("IMPDAR_KIRCH_TIEFIX") && !strcmp(getenv("IMPDAR_KIRCH_TIEFIX"), "0");   // diagnostic
         if (count > 0 && count <= TIE_CAP && !no_fix) {
@@ -2152,8 +2112,27 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
             p->xtab_off = true;
         }
     }
+    if (p->gen) {
+        // per-sample float32 factors, the squared half-way radii of the float64 re-decision, per-chunk bounds
+        const int nch = (snum + KF_THREADS - 1) / KF_THREADS;
+        p->nchunks = nch;
+        std::vector<float> a(snum), a2(snum), alo2(nch, 3.0e38f);
+        p->h_zs2min.assign(nch, 1e300);
+        for (int k = 0; k < snum; ++k) {
+            const double ak = tt_sec[k] / dt;
+            a[k] = (float)ak;
+            a2[k] = (float)(ak * ak);
+            alo2[k / KF_THREADS] = std::min(alo2[k / KF_THREADS], (float)(ak * ak) * (1.0f - 1.0e-6f));
+            const double zs = vel * tt_sec[k] / 2.0;
+            p->h_zs2min[k / KF_THREADS] = std::min(p->h_zs2min[k / KF_THREADS], zs * zs);
+        }
+        p->h_dist.assign(dist_m, dist_m + tnum);
+        if ((rc = upload(p->d_ga32, a.data(), snum * 4)) || (rc = upload(p->d_ga2_32, a2.data(), snum * 4)) ||
+            (rc = upload(p->d_alo2, alo2.data(), nch * 4)))
+            return fail(rc);
+    }
     const int ringS = p->dquad ? 4 : 8;            // steps per block of the ring kernels (traces per 32-byte row)
-    if (mode == IMPDAR_KIRCH_FAST || p->dquad) {
+    if ((mode == IMPDAR_KIRCH_FAST && !p->gen) || p->dquad) {
         const int nch = (snum + KF_THREADS - 1) / KF_THREADS;
         p->nchunks = nch;
         std::vector<int> hmax(nch, 0);
@@ -2306,11 +2285,13 @@ extern "C" void impdar_kirch_plan_destroy(impdar_kirch_plan *p)
 }
 
 extern "C" int impdar_kirch_plan_mode(const impdar_kirch_plan *p) { return p ? p->mode : IMPDAR_ERR_ARG; }
+extern "C" double impdar_kirch_plan_xnoise(const impdar_kirch_plan *p) { return p ? p->xnoise : -1.0; }
 extern "C" int impdar_kirch_plan_tnum_pad(const impdar_kirch_plan *p) { return p ? p->tnum_pad : IMPDAR_ERR_ARG; }
 
 extern "C" int impdar_kirch_plan_kernel(const impdar_kirch_plan *p)
 {
     if (!p) return IMPDAR_ERR_ARG;
+    if (p->gen) return IMPDAR_KERNEL_GEN;
     if (p->mode == IMPDAR_KIRCH_FAST) return p->quad ? IMPDAR_KERNEL_QUAD : IMPDAR_KERNEL_TAB;
     if (p->dquad) return IMPDAR_KERNEL_DQUAD;
     const char *e = getenv("IMPDAR_KIRCH_EXACT_IMPL");
@@ -2416,7 +2397,7 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
         else
             hipLaunchKernelGGL(kirch_tableq_kernel, dim3((p->snum + 255) / 256, na), dim3(256), 0, st, T);
         IMPDAR_HIP_CHECK(hipGetLastError());
-    } else if (p->mode == IMPDAR_KIRCH_FAST) {
+    } else if (p->mode == IMPDAR_KIRCH_FAST && !p->gen) {
         // geometry-only pick/weight table, rebuilt with every prep (counted in prep time)
         TableParams T;
         T.TK = p->d_TK[b].as<unsigned short>();
@@ -2732,7 +2713,10 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
     IMPDAR_HIP_CHECK(hipStreamWaitEvent(st, p->ev_ready[b], 0));      // image + table of this radargram
     if (!p->haves[p->slot][2]) IMPDAR_HIP_CHECK(hipEventRecord(ev[4], st));
     const int nx = xhi - xlo;
-    if (nx > 0 && (p->mode == IMPDAR_KIRCH_FAST || p->dquad)) {
+    if (nx > 0 && p->gen) {
+        const int grc = kirch_launch_gen(p, d_out, xlo, xhi, st);
+        if (grc) return grc;
+    } else if (nx > 0 && (p->mode == IMPDAR_KIRCH_FAST || p->dquad)) {
         FastParams P;
         P.GT = reinterpret_cast<const float *>(img_row0(p, p->GT[b]));
         P.DT = p->nearfield ? reinterpret_cast<const float *>(img_row0(p, p->DT[b])) : nullptr;

@@ -9,7 +9,7 @@ from .lib.migrationlib.mig_hip import gradient_coefficients
 
 MODE_NAMES = {_hip.KIRCH_EXACT: 'exact', _hip.KIRCH_FAST: 'fast'}
 KERNEL_NAMES = {0: 'kirch_exact_kernel', 1: 'kirch_exact_tab_kernel', 2: 'kirch_dquad_kernel', 3: 'kirch_quad_kernel',
-                4: 'kirch_tab_kernel'}
+                4: 'kirch_tab_kernel', 5: 'kirch_gen_kernel'}
 
 
 class KirchhoffPlan(object):
@@ -33,6 +33,8 @@ class KirchhoffPlan(object):
         self.mode = MODE_NAMES[self.lib.impdar_kirch_plan_mode(self.h)]
         self.tnum_pad = self.lib.impdar_kirch_plan_tnum_pad(self.h)
         self.kernel = KERNEL_NAMES[self.lib.impdar_kirch_plan_kernel(self.h)]
+        # position noise of the profile in units of dx; the float64 table-driven kernels meet max(1e-12, 0.1 xnoise)
+        self.xnoise = float(self.lib.impdar_kirch_plan_xnoise(self.h))
 
     def prep(self, d_data, ld, jlo, nloc):
         """Gradient + transpose of a local column block (device array)."""

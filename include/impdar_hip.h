@@ -129,13 +129,18 @@ int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, int tnum,
 void impdar_kirch_plan_destroy(impdar_kirch_plan *plan);
 int impdar_kirch_plan_mode(const impdar_kirch_plan *plan);      /* resolved mode */
 int impdar_kirch_plan_tnum_pad(const impdar_kirch_plan *plan);
+/* Position noise of the profile in units of the trace spacing: how far dist[j] - dist[xi] can be from (j - xi) dx
+ * (deviation from the fitted grid + rounding of the largest |dist|).  The float64 kernels that weight a pair by its
+ * trace offset (ring, tabulated) meet  max(1e-12, 0.1 xnoise)  of the image maximum against mig_python.py:44-60. */
+double impdar_kirch_plan_xnoise(const impdar_kirch_plan *plan);
 /* which diffraction-sum kernel the plan will launch */
 typedef enum impdar_kirch_kernel {
     IMPDAR_KERNEL_EXACT_PAIR = 0,   /* per-pair fp64 arithmetic in the reference's order: any geometry            */
     IMPDAR_KERNEL_EXACT_TAB = 1,    /* fp64 picks/weights tabulated per (sample, |offset|), global-memory gather  */
     IMPDAR_KERNEL_DQUAD = 2,        /* float64 LDS ring (the float64 default on uniform grids)                    */
     IMPDAR_KERNEL_QUAD = 3,         /* float32 LDS ring, ds_read_b128 (the fast path)                             */
-    IMPDAR_KERNEL_TAB = 4           /* float32 LDS ring, trace-major, for steep moveout                           */
+    IMPDAR_KERNEL_TAB = 4,          /* float32 LDS ring, trace-major, for steep moveout                           */
+    IMPDAR_KERNEL_GEN = 5           /* float32, non-uniform (sorted) dist: picks computed per pair, LDS-staged     */
 } impdar_kirch_kernel;
 int impdar_kirch_plan_kernel(const impdar_kirch_plan *plan);
 int impdar_kirch_prep(impdar_kirch_plan *plan, const void *d_data, int ld, int jlo, int nloc);
