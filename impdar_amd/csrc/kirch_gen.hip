@@ -14,23 +14,38 @@
 //       k   = rint(s)                            nearest sample (ties: below)
 //       cos = a / sqrt(a^2 + D^2)                (:47)
 //   per pair: q = a^2 + D^2 (D^2 is the same for all lanes: read from a small LDS table the workgroup fills in
-//   float64 a block ahead), r = v_rsq(q), s = fma(q, r, -u0), clamp to the slot, round by adding 1.5 * 2^23 (the
-//   integer lands in the mantissa), one shift-add makes the LDS address, ds_read_b32, acc += r * g; the factor
-//   a / (2 pi v) is applied once at the end.  11 vector instructions per pair.
+//   float64 a block ahead), r = v_rsq(q), the position normalised to the slot p = clamp01((q r - u0 - kmin) / (W - 1))
+//   in one fma, rounded by adding 1.5 * 2^23 (the integer lands in the mantissa), one shift-add makes the LDS
+//   address, ds_read_b32, acc += r * g; the factor a / (2 pi v) is applied once at the end.  9 vector instructions
+//   per pair, chosen by their measured issue cost (see kirch_gen_kernel).  A wave skips the traces that reach none of
+//   its 64 samples.
 //
-// Parity.  A float32 s is good to ~3.5e-7 s (4 ulp) -- a pick within that of a half-way point could round either
-// way, and 0.2 % of all picks are that close: on white noise that alone would be 6 % of error.  Every pair whose
-// rounded position lies within the bound of a tie is therefore decided again in float64 WITHOUT a square root:
-// the pair (m, m + 1) of candidate samples is known, and  k = m + 1  <=>  dx^2 + zs^2 > (v (tt[m] + tt[m+1]) / 4)^2
-// (dx, zs2 and the operation order of mig_python.py:44; the right side tabulated from the real tt[]).  One uniform
-// branch per pair step, taken by ~9 % of the wave steps.  The result then has the reference's picks except where
-// the reference's own float64 rounding of sqrt / divide decides (relative 1e-16: never on a jittered profile).
+// Parity.  A float32 position is good to ~4 ulp (2.4e-7 s) -- a pick within that of a half-way point could round
+// either way, and 0.2 % of all picks are that close: on white noise that alone would be 6 % of error.  Every pair
+// whose rounded position lies within the bound of a tie is therefore decided again in float64 WITHOUT a square root:
+// the pair (m, m + 1) of candidate samples is known, and  k = m + 1  <=>  D^2 + a^2 > (m + 1/2 + tt[0]/dt)^2  in
+// units of samples (:44,:49 squared; tt[m] = tt[0] + m dt, which the plan checks to 1e-11 dt).  One uniform branch
+// per pair step, out of line, taken by ~10 % of the wave steps.  The result then has the reference's picks except
+// where the reference's own float64 rounding of sqrt / divide decides (relative 1e-16: never on a jittered profile;
+// a UNIFORM profile with a rational moveout has such pairs -- the plan's tie scan finds them and keeps those profiles
+// on the float64 kernels).
 //
 // The end of the time axis.  The reference drops a pair with t > max(tt) (:52); sample snum - 1 therefore owns only
 // the lower half of its cell.  Rather than testing every pair, the staged copy of every trace holds zeros from
 // sample snum - 1 on -- the loop needs no time-limit test at all -- and kirch_gen_shell_kernel adds the pairs that
-// pick sample snum - 1 (a shell half a sample thick: a few traces per output sample, found by bisection on the sorted
-// dist[]) in the reference's float64 arithmetic afterwards.
+// pick sample snum - 1 (a shell half a sample thick: a few traces per output sample, found by a guess-and-gallop
+// search on the sorted dist[]) in the reference's float64 arithmetic afterwards -- including its rounding of
+// 2 rs / vel against max(tt), which decides the pairs at zero offset in the last row.
+//
+// Measured at 10000 x 4096, +-0.3 dx jitter (profiles/r04_gen_*.txt; 0.77 s on the per-pair kernel): 89.5 ms for the
+// first correct version; re-decision path without global loads and out of line 72.5; issue-cost-aware step + per-wave
+// aperture skip + sums pinned behind their reads (the compiler had sunk all 32 below the last read and spilled) 61.7.
+// Then: a^2 / (W-1)^2 rounded once (error bound 5 -> 4 ulp: fewer flagged steps) and the re-decision in units of
+// samples (21 -> 18 instructions): 58.8-61.0 ms by box.  Timing-only runs with the flag threshold moved
+// (profiles/r04_gen_flag_cost.txt): never flagged 50.2 ms, always flagged 129 ms -- the re-decision path (a whole
+// wave for ~1 flagged lane in 11 % of the steps) costs 8.6 ms; the vector-issue model of the step (28 cycles) gives
+// 36 ms, the per-block work (tables, staging, barrier: ~250 instructions per 256 pair steps) and the launch's tail
+// are the rest.
 #include "kirch_plan.h"
 #include <algorithm>
 #include <cmath>
@@ -39,9 +54,6 @@ typedef float kq_f4 __attribute__((ext_vector_type(4)));
 typedef unsigned kq_u4 __attribute__((ext_vector_type(4)));
 
 #define KG_S 8                      // input traces per block
-#ifndef KG_QUADFLAG
-#define KG_QUADFLAG 0               // 1: one branch per four pairs (measured slower/faster: see profiles/r04_gen_variants.txt)
-#endif
 #define KG_MAGIC 12582912.0f        // 1.5 * 2^23: x + KG_MAGIC has rint(x) in its low mantissa bits (0 <= x < 2^22)
 #define KG_MAGIC_BITS 0x4B400000u
 
@@ -52,13 +64,14 @@ struct GenParams {
     int snum, tnum, xlo, xhi;
     const double *dist;         // metres [tnum + 64], non-decreasing; the last 64 repeat dist[tnum - 1]
     const double *zs, *zs2;     // [snum] (mig_python.py:101-102)
-    const float *a, *a2;        // [snum] tt/dt and its square
+    const float *a, *a2;        // [snum] tt/dt, and (tt/dt)^2 / (W - 1)^2 rounded once
     const int2 *jr;             // [nchunks][ntiles] first / last input trace inside any aperture of (chunk, tile)
     const float *alo2;          // [nchunks] smallest a^2 of the chunk's samples
     double cscale;              // 2 / (vel dt): metres -> samples
     double r2lim;               // (vel max(tt) / 2)^2
     double tmax;                // max(tt), seconds
     double tt0, dt;             // the time axis: tt[k] = tt0 + k dt (to 1e-11 dt, checked by the plan)
+    double hh;                  // 1/2 + tt0 / dt
     double vel;
     float nu0;                  // -tt[0]/dt
     float fin;                  // 1 / (2 pi vel)
@@ -68,12 +81,12 @@ struct GenParams {
     int nchunks, ntiles, tiles_per_xcd, G;
 };
 
-// Squared radius of the time half-way between samples m and m + 1: a pair picks m + 1 iff dx^2 + zs^2 exceeds it.
-__device__ static inline double kg_halfway_r2(int m, const GenParams &P)
+// (Position of the time half-way between samples m and m + 1, in samples from t = 0)^2: a pair picks m + 1 iff
+// D^2 + a^2 exceeds it.
+__device__ static inline double kg_halfway_s2(double m, const GenParams &P)
 {
-    const double tsum = (double)(2 * m + 1) * P.dt + 2.0 * P.tt0;     // tt[m] + tt[m + 1]
-    const double r = (P.vel * 0.25) * tsum;
-    return r * r;
+    const double t = m + P.hh;
+    return t * t;
 }
 
 __host__ __device__ constexpr unsigned kg_lds_bytes(int w, bool near)
@@ -93,7 +106,7 @@ __host__ __device__ constexpr unsigned kg_lds_bytes(int w, bool near)
 //     v_add q'   v_rsq r'   v_fma p (clamp)   v_fmaak f = p (W-1) + 1.5 2^23   v_add kf = f - 1.5 2^23
 //     v_fma df = p (W-1) - kf   v_lshl_add addr   v_cmp |df| > thr   ds_read_b32   v_fma acc += r' g
 // = 6 x 2 + 2 x 4 + 8 = 28 cycles (31 before).
-template <int XB, int WR, bool NEAR, int QF>
+template <int XB, int WR, bool NEAR>
 __global__ __launch_bounds__(256, 4) void kirch_gen_kernel(GenParams P)
 {
     static_assert(XB == 32, "thread (i, jj) roles below assume 256 = 32 x 8");
@@ -138,13 +151,12 @@ __global__ __launch_bounds__(256, 4) void kirch_gen_kernel(GenParams P)
     const int jb = jr.x, jhi = jr.y;
     const int nblocks = jhi >= jb ? (jhi - jb + S) / S : 0;
 
-    constexpr float INV_WM2 = 1.0f / (WM * WM);
-    const float a2raw = P.a2[ti];
-    float a2n = a2raw * INV_WM2;                     // a^2 / (W - 1)^2
+    constexpr double INV_WM2 = 1.0 / ((double)(W - 1) * (double)(W - 1));
+    float a2n = P.a2[ti];                            // a^2 / (W - 1)^2
     float wm_v = WM;
     asm volatile("" : "+v"(a2n), "+v"(wm_v));        // VGPRs, not literals / scalars (an SGPR operand halves the issue rate)
-    const double zs2d = P.zs2[ti];
-    float cnn = P.cn * INV_WM2;                      // near field: r'^2 = (W - 1)^2 r^2
+    const double a2s = P.zs2[ti] * (P.cscale * P.cscale);      // a^2 in float64, for the re-decision
+    float cnn = P.cn * (float)INV_WM2;                      // near field: r'^2 = (W - 1)^2 r^2
     asm volatile("" : "+v"(cnn));
     float acc[XB];
 #pragma unroll
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(256, 4) void kirch_gen_kernel(GenParams P)
             const double xj = P.dist[min(j, tnum - 1)];
             const double D = (xj - dxi) * P.cscale;
             const int slot3 = blk % 3;
-            d2tab[(slot3 * S + rj) * XB + ri] = valid ? (float)(D * D * (double)INV_WM2) : 1.0e30f;
+            d2tab[(slot3 * S + rj) * XB + ri] = valid ? (float)(D * D * INV_WM2) : 1.0e30f;
             if (ri == 0) {
                 // smallest position any pair of (chunk, tile, j) can have: closest output trace, shallowest sample
                 const double dmin = fmax(fmax(xL - xj, xj - xR), 0.0) * P.cscale;
@@ -229,7 +241,7 @@ __global__ __launch_bounds__(256, 4) void kirch_gen_kernel(GenParams P)
                 }
         };
 
-        if (tid < XB) xtile[tid] = P.dist[x0 + tid];
+        if (tid < XB) xtile[tid] = P.dist[x0 + tid] * P.cscale;      // positions in samples, float64
         tables(0);
         tables(1);
         __syncthreads();
@@ -251,18 +263,19 @@ __global__ __launch_bounds__(256, 4) void kirch_gen_kernel(GenParams P)
                 float cj = __uint_as_float(m.y), thr = __uint_as_float(m.z);
                 const unsigned d2row = D2_OFF + (unsigned)((slot3 * S + jj) * XB) * 4u;
                 const int kmin_j = kmintab[slot3 * S + jj];
-                const double xj_d = P.dist[min(jb + blk * S + jj, tnum - 1)];
+                const double xj_s = P.dist[min(jb + blk * S + jj, tnum - 1)] * P.cscale;
+                const float kmin_f = (float)kmin_j, smax2_f = (float)(snum - 2);
                 float g_prev = 0.f, r_prev = 0.f, gd_prev = 0.f;
                 // a flagged pair: within the float32 error of a half-way point.  Decide between the two candidate samples
                 // (m, m + 1) in float64, by squares (see the header); the other lanes keep their address.  Out of line:
                 // the branch is uniform and rarely taken.
                 auto fix = [&](int i, bool flag, float kf, float df, unsigned addr) -> unsigned {
                     if (flag) {
-                        int mlo = kmin_j + (int)kf - (df > 0.f ? 0 : 1);          // kf counts from the slot's first sample
-                        mlo = min(max(mlo, 0), snum - 2);
-                        const double dx = xj_d - *(lds_dp)(uintptr_t)(XT_OFF + 8u * (unsigned)i);
-                        const double qd = dx * dx + zs2d;                            // mig_python.py:44
-                        const int pick = qd > kg_halfway_r2(mlo, P) ? mlo + 1 : mlo;    // :49, ties to the lower sample
+                        // kf counts from the slot's first sample; candidates (m, m + 1), m clamped like argmin's index
+                        const float mlo = fminf(fmaxf(kf + (df > 0.f ? kmin_f : kmin_f - 1.0f), 0.f), smax2_f);
+                        const double ds = xj_s - *(lds_dp)(uintptr_t)(XT_OFF + 8u * (unsigned)i);
+                        const double qs = ds * ds + a2s;                              // mig_python.py:44 in samples^2
+                        const float pick = mlo + (qs > kg_halfway_s2((double)mlo, P) ? 1.0f : 0.0f);    // :49, ties below
                         addr = base_k + 4u * (unsigned)pick;
                     }
                     return addr;
@@ -338,7 +351,8 @@ __global__ __launch_bounds__(256) void kirch_gen_shell_kernel(GenParams P)
     const double z = P.zs[ti], z2 = P.zs2[ti];
     const double qhi = P.r2lim * (1.0 + 1e-9);            // candidates only: the reference's own test decides below
     if (z == 0.0 || !(qhi >= z2)) return;
-    const double qlo = kg_halfway_r2(snum - 2, P);      // the main kernel's own rule for picking the last sample
+    // the main kernel's own rule for picking the last sample, in metres^2
+    const double qlo = kg_halfway_s2((double)(snum - 2), P) / (P.cscale * P.cscale);
     const double dhi = sqrt(qhi - z2) * (1.0 + 1e-12);
     const double dlo = qlo > z2 ? sqrt(qlo - z2) * (1.0 - 1e-12) : -1.0;
     const double x = P.dist[xi];
@@ -463,17 +477,18 @@ int kirch_launch_gen(impdar_kirch_plan *p, void *d_out, int xlo, int xhi, hipStr
     P.tmax = p->tmax;
     P.tt0 = p->tt0;
     P.dt = p->dt;
+    P.hh = 0.5 + p->tt0 / p->dt;
     P.vel = p->vel;
     P.nu0 = (float)(-p->tt0 / p->dt);
     P.fin = (float)(1.0 / (2.0 * M_PI * p->vel));
     const double half = p->vel * p->dt / 2.0;
     P.cn = (float)(p->vel / (half * half));
-    // error of the float32 position (kirch_gen_kernel: p (W - 1) = q' r' (W - 1) - u0 - kmin), with u = 2^-24: a^2, D^2
-    // and their sum are rounded once each (|dq| <= 2 u q, i.e. u s), v_rsq is good to 1 ulp (2 u s), the constant
-    // (u0 + kmin) / (W - 1) and the fma round once each (u (u0 + kmin) and < u W): < 5 u s = 3.0e-7 s at the slot's
-    // end; e0 covers the 1e-11 dt the time axis may be off a grid
+    // error of the float32 position (kirch_gen_kernel: p (W - 1) = q' r' (W - 1) - u0 - kmin), with u = 2^-24: a^2 / (W-1)^2
+    // and D^2 / (W-1)^2 are rounded once each, their sum once (|dq| <= 2 u q, i.e. u s), v_rsq is good to 1 ulp (2 u s),
+    // the constant (u0 + kmin) / (W - 1) and the fma round once each (u (u0 + kmin) and < u W): < 4 u s = 2.4e-7 s at
+    // the slot's end; e0 covers the 1e-11 dt the time axis may be off a grid
     P.e0 = 2.0e-6f;
-    P.e1 = 3.3e-7f;
+    P.e1 = 2.65e-7f;
     P.W = p->genW;
     P.nchunks = nch;
     P.ntiles = ntiles;
@@ -485,25 +500,14 @@ int kirch_launch_gen(impdar_kirch_plan *p, void *d_out, int xlo, int xhi, hipStr
     const size_t shmem = kg_lds_bytes(p->genW, p->nearfield != 0);
 #define KG_LAUNCH(WR, NEAR)                                                                                      \
     do {                                                                                                          \
-        auto k = kirch_gen_kernel<XB, WR, NEAR, QF>;                                                                  \
+        auto k = kirch_gen_kernel<XB, WR, NEAR>;                                                                  \
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
         hipLaunchKernelGGL(k, dim3(nblk), dim3(256), shmem, st, P);                                               \
     } while (0)
-    static const bool qf = getenv("IMPDAR_KIRCH_GEN_QF") && atoi(getenv("IMPDAR_KIRCH_GEN_QF")) == 1;    // A/B, temporary
-    if (qf) {
-        constexpr int QF = 1;
-        if (p->nearfield) {
-            if (wr == 2) KG_LAUNCH(2, true); else if (wr == 3) KG_LAUNCH(3, true); else KG_LAUNCH(4, true);
-        } else {
-            if (wr == 2) KG_LAUNCH(2, false); else if (wr == 3) KG_LAUNCH(3, false); else KG_LAUNCH(4, false);
-        }
+    if (p->nearfield) {
+        if (wr == 2) KG_LAUNCH(2, true); else if (wr == 3) KG_LAUNCH(3, true); else KG_LAUNCH(4, true);
     } else {
-        constexpr int QF = 0;
-        if (p->nearfield) {
-            if (wr == 2) KG_LAUNCH(2, true); else if (wr == 3) KG_LAUNCH(3, true); else KG_LAUNCH(4, true);
-        } else {
-            if (wr == 2) KG_LAUNCH(2, false); else if (wr == 3) KG_LAUNCH(3, false); else KG_LAUNCH(4, false);
-        }
+        if (wr == 2) KG_LAUNCH(2, false); else if (wr == 3) KG_LAUNCH(3, false); else KG_LAUNCH(4, false);
     }
 #undef KG_LAUNCH
     IMPDAR_HIP_CHECK(hipGetLastError());

@@ -2121,7 +2121,7 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         for (int k = 0; k < snum; ++k) {
             const double ak = tt_sec[k] / dt;
             a[k] = (float)ak;
-            a2[k] = (float)(ak * ak);
+            a2[k] = (float)(ak * ak / ((double)(gen_w - 1) * (double)(gen_w - 1)));    // normalised to the slot (kirch_gen_kernel)
             alo2[k / KF_THREADS] = std::min(alo2[k / KF_THREADS], (float)(ak * ak) * (1.0f - 1.0e-6f));
             const double zs = vel * tt_sec[k] / 2.0;
             p->h_zs2min[k / KF_THREADS] = std::min(p->h_zs2min[k / KF_THREADS], zs * zs);
