@@ -246,6 +246,19 @@ def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None):
             return float(np.median(ms[1:])), float(np.median(wall[1:])), fin, float(np.median(kms[1:]))
         return float(np.median(ms[1:])), float(np.median(wall[1:])), fin
 
+    def host_call_ms(run, make, reps=3):
+        """Host arrays in, float64 image out (what RadarData.migrate on a loaded file does): median wall of `reps`
+        calls after one warm-up call, PCIe both ways and the widening to float64 included."""
+        wall = []
+        for _ in range(reps + 1):
+            d = make()
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                run(d)
+            wall.append(time.perf_counter() - t0)
+            assert d.data.dtype == np.float64 or d.data.dtype == np.float32
+        return float(np.median(wall[1:])) * 1e3
+
     # ---- config 2: Stolt f-k, 4096 x 4096 float32
     n = 4096
     geo = synth.geometry(n, n)
@@ -257,6 +270,10 @@ def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None):
            "roofline": {"bound": "hbm", "achieved": algo / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": algo,
                         "fused_floor_bytes": 8 * n * n}}
+    e2e = host_call_ms(lambda d: d.migrate('stolt', vel=1.68e8, htaper=100, vtaper=1000), lambda: dat_of(x, geo))
+    rec["end_to_end"] = {"wall_ms": e2e, "value": n / (e2e * 1e-3), "unit": "traces/s",
+                         "note": "RadarData.migrate('stolt') on a host float32 array: H2D + the device path + D2H (the "
+                                 "reference returns float32 for float32 input under NumPy >= 2); median of 3 calls"}
     if not no_cpu:
         from oracle import mig_oracle
         t0 = time.perf_counter()
@@ -304,12 +321,20 @@ def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None):
                         "mfma_flop_executed": 3.0 * flop,
                         "frac_executed": 3.0 * tf / FP16_MFMA_PEAK_TF,
                         "x_fp32_vector_peak": tf / FP32_VECTOR_PEAK_TF,
+                        "frac_device_ms": flop / (ms * 1e-3) / 1e12 / FP16_MFMA_PEAK_TF,
+                        "x_fp32_vector_peak_device_ms": flop / (ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TF,
                         "note": "kernel_ms = the frequency-sum kernels (ps_mfma_kernel + boundary frequencies + zero-frequency "
                                 "row); achieved = 8 flop per needed complex rotate-accumulate (half walk) over kernel_ms, "
                                 "against the dense float16 MFMA peak; the kernel executes three float16 products per "
                                 "float32 product (hi.hi + hi.lo + lo.hi) plus 1/16 of the rotations on the vector "
                                 "units; device_ms also holds the real-to-complex and trace transforms, the inverse "
-                                "transform and the transposes"}}
+                                "transform and the transposes; kernel_ms includes ps_setup_kernel and the host-side "
+                                "synchronisation inside the matrix-core path; frac_device_ms / x_fp32_vector_peak_device_ms "
+                                "are the same flop over device_ms (the basis rounds 1-2 reported)"}}
+    e2e = host_call_ms(lambda d: d.migrate('phsh', vel=tab, htaper=100, vtaper=1000), lambda: dat_of(x, geo), reps=2)
+    rec["end_to_end"] = {"wall_ms": e2e, "value": n / (e2e * 1e-3), "unit": "traces/s",
+                         "note": "RadarData.migrate('phsh', vel=table) on a host float32 array: getVelocityProfile + H2D + "
+                                 "the device path + D2H widened to the float64 the reference returns; median of 2 calls"}
     if not no_cpu:
         from oracle import mig_oracle
         m = 512
@@ -373,6 +398,98 @@ def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None):
     d_in.free()
     d_out.free()
     out["kirchhoff_f64_config3"] = rec
+
+    # ---- config 3's size on a NON-UNIFORM profile (+-0.3 dx jitter, the recipe of golden K3): kirch_gen_kernel
+    jit = np.random.default_rng(3).uniform(-0.3, 0.3, tnum)
+    distj = (np.arange(tnum) + jit) * 1.0e-3
+    x32 = full_data.astype(np.float32) if (full_data is not None and full_data.shape == (snum, tnum)) else \
+        rng.standard_normal((snum, tnum)).astype(np.float32)
+    plan = KirchhoffPlan(ctx, np.float32, snum, tnum, distj, g3['travel_time'], vel, False, 'auto')
+    d_in = _hip.DeviceArray.from_host(ctx, x32)
+    d_out = _hip.DeviceArray(ctx, (snum, tnum), np.float32)
+    for _ in range(4):
+        plan.prep(d_in, tnum, 0, tnum)
+        plan.migrate(d_out, 0, tnum)
+    plan.sync()
+    kms = float(np.mean([plan.history_ms(b)[2] for b in range(3)]))
+    rec = {"workload": "Kirchhoff diffraction sum, 10000 traces x 4096 samples, float32, trace positions jittered by "
+                       "+-0.3 dx (non-uniform dist: mig_python.py:44 takes any), resident in HBM",
+           "kernel": plan.kernel, "kernel_ms": kms, "traces_per_s": tnum / (kms * 1e-3),
+           "note": "picks computed per pair from the positions; 0.77 s on the per-pair float64 kernel in rounds 1-3; "
+                   "bound by vector issue (28 cycles per wave pair step), not by LDS or HBM"}
+    if not no_cpu:
+        from oracle import c_oracle
+        cols = np.unique(np.linspace(0, tnum - 1, 8).round().astype(np.int32))
+        want = c_oracle.kirchhoff(x32, g3['travel_time'], distj, vel, False, traces=cols)
+        got = d_out.to_host()[:, cols].astype(np.float64)
+        rec["parity_rel_l2"] = float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-300))
+        rec["parity_cols"] = int(len(cols))
+        rec["parity_bar"] = PARITY_BAR
+        if not rec["parity_rel_l2"] <= PARITY_BAR:
+            rec["error"] = "general-geometry output differs from the C oracle"
+    plan.destroy()
+    d_in.free()
+    d_out.free()
+    out["kirchhoff_jittered_config3"] = rec
+    return out
+
+
+def first_call_child(kind):
+    """`bench.py --first-call kirch|stolt|phsh`: a fresh process, as `impproc migrate file.mat` is -- import, context,
+    the FIRST migration call of the process on a host array, then a second call for contrast.  One JSON line."""
+    import contextlib
+    import io
+    t_imp = time.perf_counter()
+    from impdar_amd import _hip, synth
+    from impdar_amd.lib.RadarData import RadarData
+    import_ms = (time.perf_counter() - t_imp) * 1e3
+    vel = 1.69e8
+    if kind == 'kirch':
+        snum, tnum = 4096, 10000
+        geo = synth.geometry(snum, tnum)
+        x = synth.diffractor_radargram(snum, tnum, vel=vel, dtype=np.float32, chunk=128, threads=host_threads())
+        run = lambda d: d.migrate('kirch', vel=vel)
+    elif kind == 'stolt':
+        snum = tnum = 4096
+        geo = synth.geometry(snum, tnum)
+        x = np.random.default_rng(0).standard_normal((snum, tnum)).astype(np.float32)
+        run = lambda d: d.migrate('stolt', vel=1.68e8, htaper=100, vtaper=1000)
+    else:
+        snum = tnum = 8192
+        geo = synth.geometry(snum, tnum)
+        x = np.random.default_rng(0).standard_normal((snum, tnum)).astype(np.float32)
+        Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+        tab = np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rp], [1.8e8, 0.5 * Rp], [1.9e8, 1.2 * Rp]])
+        run = lambda d: d.migrate('phsh', vel=tab, htaper=100, vtaper=1000)
+    t0 = time.perf_counter()
+    _hip.load()
+    _hip.context()
+    ctx_ms = (time.perf_counter() - t0) * 1e3
+    walls = []
+    for _ in range(2):
+        d = RadarData(None)
+        d.data, d.snum, d.tnum = x, snum, tnum
+        d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            run(d)
+        walls.append((time.perf_counter() - t0) * 1e3)
+    print(json.dumps({"kind": kind, "import_ms": import_ms, "context_ms": ctx_ms, "first_call_ms": walls[0],
+                      "second_call_ms": walls[1], "finite": bool(np.isfinite(d.data).all())}))
+
+
+def first_call_records():
+    """Run the three first-call children (must happen before this process touches the GPU)."""
+    import subprocess
+    out = {}
+    for kind in ('kirch', 'stolt', 'phsh'):
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--first-call', kind], capture_output=True,
+                               text=True, timeout=240)
+            line = [l for l in r.stdout.splitlines() if l.startswith('{"kind"')]
+            out[kind] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]}
+        except Exception as exc:
+            out[kind] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     return out
 
 
@@ -396,12 +513,16 @@ def main():
     ap.add_argument('--no-paths', action='store_true', help='skip the config-2 / config-5 sub-records')
     ap.add_argument('--no-e2e', action='store_true', help='skip the PCIe-inclusive one-shot figure')
     ap.add_argument('--cpu-budget', type=float, default=15.0)
+    ap.add_argument('--first-call', default=None, choices=['kirch', 'stolt', 'phsh'], help=argparse.SUPPRESS)
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--pmc-child-path', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--data-child', default='zeros', choices=['zeros', 'synthetic'], help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child_path:
         pmc_child_path(args.pmc_child_path, args.steps)
+        return
+    if args.first_call:
+        first_call_child(args.first_call)
         return
 
     # ---- `python bench.py --gpus N` without a launcher: start the N ranks here, BEFORE anything touches the GPU
@@ -421,6 +542,14 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     args.gpus = world
+
+    # the FIRST call of a process (what `impproc migrate file.mat` is), measured in fresh child processes started
+    # before this one touches the GPU
+    first_calls = None
+    if rank == 0 and world == 1 and not args.no_e2e and not args.pmc_child and not os.environ.get('IMPDAR_BENCH_FORCE_DIST'):
+        t0 = time.time()
+        first_calls = first_call_records()
+        log('[bench] first-call children took %.1f s' % (time.time() - t0))
 
     from impdar_amd import _hip, parallel, synth
     np_dtype = np.float32 if args.dtype == 'f32' else np.float64
@@ -506,6 +635,26 @@ def main():
     out_host = d_out.to_host()[:, :xhi - xlo]
     finite = bool(np.isfinite(out_host).all())
 
+    # ---- what every rank did, gathered on rank 0: its block, the rows RCCL handed it, its own event times, four
+    # columns of its timed output (rank 0 holds them to the C oracle below), and what RCCL itself says about the
+    # communicator -- an N > 1 record then proves on its own that N ranks exchanged and migrated
+    import ctypes as C
+    rccl = None
+    if multi:
+        vals = [C.c_int(-1) for _ in range(4)]
+        if _hip.load().impdar_comm_info(ctx, *[C.byref(v) for v in vals]) == 0:
+            rccl = dict(ranks=vals[0].value, rank=vals[1].value, device=vals[2].value, version=vals[3].value)
+    pcols = np.unique(np.linspace(xlo, max(xhi - 1, xlo), 4).round().astype(np.int64)) if xhi > xlo else np.zeros(0, np.int64)
+    mine = dict(rank=rank, device=local % ndev, output_block=[int(xlo), int(xhi)], input_shard=[int(jlo), int(jhi)],
+                rows_received=int(sk.xplan['rows_received'][rank]) if world > 1 else 0,
+                prep_ms=float(np.mean(prep_ms)) if prep_ms else None,
+                exchange_ms=float(np.mean(gather_ms)) if gather_ms else None,
+                migrate_ms=float(np.mean(kernel_ms)) if kernel_ms else None,
+                pairs=int(sk.pairs[rank]), rccl=rccl, finite=finite,
+                cols=[int(c) for c in pcols],
+                colvals=np.ascontiguousarray(out_host[:, pcols - xlo], dtype=np.float64) if len(pcols) else np.zeros((snum, 0)))
+    everyone = rdv.allgather(mine)
+
     res = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -535,7 +684,13 @@ def main():
                                             "migrate_ms": s_mig,
                                             "note": "one radargram on an idle device: prep + exchange are exposed here; "
                                                     "the timed steps overlap them with the previous diffraction sum"},
-                       "output_finite": finite},
+                       "rccl": ({"ranks": everyone[0]['rccl']['ranks'], "version": everyone[0]['rccl']['version'],
+                                 "ranks_seen_by_every_rank": [e['rccl']['ranks'] if e['rccl'] else None for e in everyone]}
+                                if everyone[0]['rccl'] else None),
+                       "ranks": [{k: e[k] for k in ('rank', 'device', 'output_block', 'input_shard', 'rows_received',
+                                                    'prep_ms', 'exchange_ms', 'migrate_ms', 'pairs', 'finite')}
+                                 for e in everyone],
+                       "output_finite": bool(all(e['finite'] for e in everyone))},
             # the binding roof: every pair's sample is one 4-byte lane of a ds_read_b128, so the LDS read port
             # (256 B/clk/CU) bounds the diffraction sum; HBM only sees the compulsory image + output bytes
             "roofline": {"bound": "lds", "achieved": achieved, "peak": LDS_PEAK_GBS, "unit": "GB/s",
@@ -571,6 +726,18 @@ def main():
         res["parity_bar"] = PARITY_BAR if args.dtype == 'f32' else 1e-12
         if not rel <= res["parity_bar"]:
             res["error"] = "timed output differs from the oracle: rel L2 %.3e on %d columns" % (rel, len(cols))
+        # every rank's own four columns against the C oracle
+        from oracle import c_oracle as _co
+        for e, rec in zip(everyone, res["config"]["ranks"]):
+            if not e['cols']:
+                rec["parity_rel_l2"] = None
+                continue
+            w = _co.kirchhoff(full_data, geo['travel_time'], geo['dist'], vel, False, traces=np.asarray(e['cols'], dtype=np.int32))
+            r = float(np.linalg.norm(np.asarray(e['colvals']) - w) / max(np.linalg.norm(w), 1e-300))
+            rec["parity_cols"] = e['cols']
+            rec["parity_rel_l2"] = r
+            if not r <= res["parity_bar"]:
+                res["error"] = "rank %d: timed output differs from the oracle: rel L2 %.3e" % (e['rank'], r)
         log('[bench] cpu legs + parity took %.1f s (parity rel L2 %.2e on %d columns)' % (time.time() - t0, rel, len(cols)))
     elif rank == 0:
         res["cpu_baseline"] = None
@@ -614,7 +781,12 @@ def main():
                                  "note": "RadarData.migrate('kirch') on a host float32 array: plan + tables + H2D + prep + "
                                          "diffraction sum + D2H + widening to the float64 the reference returns; median of 3 "
                                          "calls on the same array (its pages stay registered with the runtime after the first "
-                                         "upload); wall_ms_fresh_array: median of 3 calls on arrays uploaded for the first time"}
+                                         "upload); wall_ms_fresh_array: median of 3 calls on arrays uploaded for the first time; "
+                                         "first_call_ms: the first call of a fresh process after its context exists "
+                                         "(first_call has the three paths, with import and context creation beside them)"}
+            if first_calls:
+                res["end_to_end"]["first_call_ms"] = first_calls.get('kirch', {}).get('first_call_ms')
+                res["end_to_end"]["first_call"] = first_calls
         # ---- HBM-side traffic of the dominant kernel, counted in child runs of this command
         if not args.no_pmc and kname in ('kirch_quad_kernel', 'kirch_dquad_kernel'):
             t0 = time.time()

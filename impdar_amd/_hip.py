@@ -42,6 +42,7 @@ SIGNATURES = {
     'impdar_ctx_sync': (_i, [_p]),
     'impdar_ctx_last_ms': (_i, [_p, C.POINTER(C.c_float)]),
     'impdar_ctx_last_kernel_ms': (_i, [_p, C.POINTER(C.c_float)]),
+    'impdar_ctx_last_metrics': (_i, [_p, C.c_char_p, C.c_size_t]),
     'impdar_dev_alloc': (_i, [_p, C.c_size_t, C.POINTER(_p)]),
     'impdar_dev_free': (_i, [_p, _p]),
     'impdar_dev_upload': (_i, [_p, _p, _p, C.c_size_t]),
@@ -84,6 +85,7 @@ SIGNATURES = {
     'impdar_comm_init': (_i, [_p, C.c_char_p, _i, _i]),
     'impdar_comm_rank': (_i, [_p]),
     'impdar_comm_size': (_i, [_p]),
+    'impdar_comm_info': (_i, [_p, _ip, _ip, _ip, _ip]),
     'impdar_comm_barrier': (_i, [_p]),
 }
 

@@ -43,11 +43,7 @@ extern "C" int impdar_ctx_create(int device, impdar_ctx **out)
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi);
-    {
-        const char *pe = getenv("IMPDAR_AUX_PRIO");   // tuning knob: lo (default) / hi
-        const int pa = (pe && !strcmp(pe, "hi")) ? prio_hi : prio_lo;
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, pa);
-    }
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio_lo);
     if (e != hipSuccess) {
         delete c;
         impdar_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -115,6 +111,30 @@ extern "C" int impdar_ctx_last_kernel_ms(impdar_ctx *ctx, float *ms)
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
     IMPDAR_HIP_CHECK(hipEventSynchronize(ctx->ev_ktoc));
     IMPDAR_HIP_CHECK(hipEventElapsedTime(ms, ctx->ev_ktic, ctx->ev_ktoc));
+    return IMPDAR_OK;
+}
+
+// One JSON object about the last migration entry point that ran on this context ("emit a JSON
+// line per run beside the print"; the reference only prints 'complete in N seconds', mig_python.py:121-122,206-207,
+// 285-286).  The Python entry points add the sizes, traces per second and the device count and print the line on
+// stderr when IMPDAR_METRICS is set.
+extern "C" int impdar_ctx_last_metrics(impdar_ctx *ctx, char *json, size_t cap)
+{
+    IMPDAR_ARG_CHECK(ctx && json && cap > 0, "null context/buffer");
+    IMPDAR_ARG_CHECK(ctx->m_entry, "no migration entry point has run on this context");
+    float dev_ms = -1.f, k_ms = ctx->m_kernel_ms;
+    IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->timed && hipEventSynchronize(ctx->ev_toc) == hipSuccess) (void)hipEventElapsedTime(&dev_ms, ctx->ev_tic, ctx->ev_toc);
+    if (k_ms < 0.f && ctx->ktimed && hipEventSynchronize(ctx->ev_ktoc) == hipSuccess)
+        (void)hipEventElapsedTime(&k_ms, ctx->ev_ktic, ctx->ev_ktoc);
+    (void)hipGetLastError();
+    int n = snprintf(json, cap, "{\"entry\": \"%s\", \"kernel\": \"%s\", \"device\": %d", ctx->m_entry,
+                     ctx->m_kernel ? ctx->m_kernel : "", ctx->device);
+    if (n > 0 && (size_t)n < cap && k_ms >= 0.f) n += snprintf(json + n, cap - n, ", \"kernel_ms\": %.4f", k_ms);
+    if (n > 0 && (size_t)n < cap && dev_ms >= 0.f) n += snprintf(json + n, cap - n, ", \"device_ms\": %.4f", dev_ms);
+    if (n > 0 && (size_t)n < cap && ctx->m_extra[0]) n += snprintf(json + n, cap - n, ", %s", ctx->m_extra);
+    if (n > 0 && (size_t)n < cap) n += snprintf(json + n, cap - n, "}");
+    IMPDAR_ARG_CHECK(n > 0 && (size_t)n < cap, "buffer of %zu bytes is too small for the metrics object", cap);
     return IMPDAR_OK;
 }
 

@@ -53,6 +53,24 @@ void impdar_comm_destroy(impdar_ctx *ctx)
 extern "C" int impdar_comm_rank(const impdar_ctx *ctx) { return ctx ? ctx->rank : IMPDAR_ERR_ARG; }
 extern "C" int impdar_comm_size(const impdar_ctx *ctx) { return ctx ? ctx->nranks : IMPDAR_ERR_ARG; }
 
+// What RCCL itself says about the communicator (not what the caller passed to impdar_comm_init): ranks in it, this
+// process's rank, the device it is bound to, and the library version -- so that a bench record of an N-GPU run can
+// show that the exchange really ran over an N-rank RCCL communicator.
+extern "C" int impdar_comm_info(const impdar_ctx *ctx, int *ranks, int *rank, int *device, int *version)
+{
+    IMPDAR_ARG_CHECK(ctx && ctx->comm, "communicator not initialised (impdar_comm_init)");
+    ncclComm_t c = reinterpret_cast<ncclComm_t>(ctx->comm);
+    int v = 0;
+    if (ranks) IMPDAR_NCCL_CHECK(ncclCommCount(c, ranks));
+    if (rank) IMPDAR_NCCL_CHECK(ncclCommUserRank(c, rank));
+    if (device) IMPDAR_NCCL_CHECK(ncclCommCuDevice(c, device));
+    if (version) {
+        IMPDAR_NCCL_CHECK(ncclGetVersion(&v));
+        *version = v;
+    }
+    return IMPDAR_OK;
+}
+
 // In-place all-gather: rank r owns bytes [r*per, (r+1)*per) of `image`.
 int impdar_allgather_rows(impdar_ctx *ctx, void *image, size_t bytes_per_rank, hipStream_t stream)
 {

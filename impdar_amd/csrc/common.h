@@ -36,6 +36,12 @@ struct impdar_ctx {
     // ... and of its dominant kernel alone (the frequency sum of a phase-shift call: impdar_ctx_last_kernel_ms)
     hipEvent_t ev_ktic = nullptr, ev_ktoc = nullptr;
     bool ktimed = false;
+    // what the last migration entry point on this context did (impdar_ctx_last_metrics): its name, the kernel that did
+    // the sums, that kernel's time when the entry point measured it itself (< 0: read ev_ktic / ev_ktoc), and further
+    // "key": value pairs of JSON
+    const char *m_entry = nullptr, *m_kernel = nullptr;
+    float m_kernel_ms = -1.f;
+    char m_extra[320] = "";
 };
 
 // bracket the device work of one call on ctx->stream (read back by impdar_ctx_last_ms)
@@ -116,7 +122,11 @@ struct DevBuf {
         if (e == hipErrorOutOfMemory) {
             (void)hipGetLastError();
             p = nullptr;
+            // the trims destroy cached plans of other contexts and set THEIR device while doing so: come back to ours
+            int dev = -1;
+            const bool have_dev = hipGetDevice(&dev) == hipSuccess;
             impdar_release_caches();
+            if (have_dev) (void)hipSetDevice(dev);
             e = hipMalloc(&p, n);
         }
         if (e == hipSuccess) bytes = n;

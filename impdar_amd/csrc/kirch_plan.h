@@ -39,7 +39,6 @@ struct impdar_kirch_plan {
     DevBuf d_TK[2], d_TW[2], d_TW2[2], d_c1, d_c2, d_fin, d_WIN;
     int nrows = 0, mrow0 = 0;   // quad kernel: step-block table rows (see FastParams)
     int quadSH = 0;             // table entries are LDS byte offsets >> quadSH
-    DevBuf d_stamps;               // diagnostic builds only
     int nb = 0, ntab = 0;
     bool quad = false;          // sample-major LDS ring (kirch_quad_kernel)
     std::vector<int> h_hmax;    // host copy of the per-chunk aperture half widths (tile cost model)

@@ -72,6 +72,29 @@ def _kx(dat):
     return 2. * np.pi * np.fft.fftfreq(dat.tnum, d=np.mean(trace_int))
 
 
+def _emit_metrics(dat, seconds, ngpus=1, ctx=None):
+    """SURVEY section 5 "metrics": one JSON line per migration beside the reference's 'complete in N seconds' print
+    (mig_python.py:121-122,206-207,285-286), on stderr, when ``$IMPDAR_METRICS`` is set: what ran (entry point, kernel,
+    kernel and device milliseconds from HIP events: ``impdar_ctx_last_metrics``), the sizes, traces per second of the
+    whole call and the device count."""
+    if not os.environ.get('IMPDAR_METRICS'):
+        return
+    import json
+    import sys
+    rec = {}
+    if ctx is not None:
+        buf = C.create_string_buffer(1024)
+        if _hip.load().impdar_ctx_last_metrics(ctx, buf, len(buf)) == 0:
+            rec = json.loads(buf.value.decode())
+    data = dat.__dict__.get('data', None)          # (a resident radargram has no host array: do not fetch it for this)
+    rec.update(impdar_metrics=1, snum=int(dat.snum), tnum=int(dat.tnum),
+               dtype=str(data.dtype) if hasattr(data, 'dtype') else 'resident',
+               wall_s=round(float(seconds), 6), traces_per_s=round(float(dat.tnum) / max(float(seconds), 1e-9), 3),
+               devices=int(ngpus))
+    sys.stderr.write(json.dumps(rec) + '\n')
+    sys.stderr.flush()
+
+
 # ---------------------------------------------------------------------------
 # Kirchhoff
 # ---------------------------------------------------------------------------
@@ -110,6 +133,7 @@ def migrationKirchhoff(dat, vel=1.69e8, nearfield=False, mode=None, ngpus=None):
         print('')
         print('Kirchhoff Migration of %.0fx%.0f matrix complete in %.2f seconds on %d GPUs'
               % (dat.snum, dat.tnum, time.time() - start, ngpus))
+        _emit_metrics(dat, time.time() - start, ngpus)
         return dat
     lib = _hip.load()
     ctx = _hip.context()
@@ -133,6 +157,7 @@ def migrationKirchhoff(dat, vel=1.69e8, nearfield=False, mode=None, ngpus=None):
     print('')
     print('Kirchhoff Migration of %.0fx%.0f matrix complete in %.2f seconds'
           % (dat.snum, dat.tnum, time.time() - start))
+    _emit_metrics(dat, time.time() - start, 1, ctx)
     return dat
 
 
@@ -182,6 +207,7 @@ def migrationStolt(dat, vel=1.68e8, htaper=100, vtaper=1000):
     print('')
     print('Stolt Migration of %.0fx%.0f matrix complete in %.2f seconds'
           % (dat.snum, dat.tnum, time.time() - start))
+    _emit_metrics(dat, time.time() - start, 1, ctx)
     return dat
 
 
@@ -268,6 +294,7 @@ def _phase_shift(dat, vel, vel_fn, htaper, vtaper, genfromtxt_kwargs, dev, ngpus
             print('')
             print('Phase-Shift Migration of %.0fx%.0f matrix complete in %.2f seconds'
                   % (dat.snum, dat.tnum, time.time() - start))
+            _emit_metrics(dat, time.time() - start, 1, ctx)
             return dat
         print('1-D velocity structure, Gazdag Migration')
         vconst = 0.0
@@ -279,6 +306,7 @@ def _phase_shift(dat, vel, vel_fn, htaper, vtaper, genfromtxt_kwargs, dev, ngpus
         print('')
         print('Phase-Shift Migration of %.0fx%.0f matrix complete in %.2f seconds on %d GPUs'
               % (dat.snum, dat.tnum, time.time() - start, ngpus))
+        _emit_metrics(dat, time.time() - start, ngpus)
         return dat
     tt_us, p_tt = _hip.as_dp(dat.travel_time)
     _, p_kx = _hip.as_dp(kx)
@@ -310,6 +338,7 @@ def _phase_shift(dat, vel, vel_fn, htaper, vtaper, genfromtxt_kwargs, dev, ngpus
     print('')
     print('Phase-Shift Migration of %.0fx%.0f matrix complete in %.2f seconds'
           % (dat.snum, dat.tnum, time.time() - start))
+    _emit_metrics(dat, time.time() - start, 1, ctx)
     return dat
 
 
@@ -336,6 +365,7 @@ def migrationTimeWavenumber(dat, vel=1.69e8, vel_fn=None, htaper=100, vtaper=100
     print('')
     print('Time-Wavenumber Migration of %.0fx%.0f matrix complete in %.2f seconds'
           % (dat.snum, dat.tnum, time.time() - start))
+    _emit_metrics(dat, time.time() - start, 1, ctx)
     return dat
 
 

@@ -691,6 +691,10 @@ def spawn_ranks(argv, world, env_extra=None, timeout=None):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), IMPDAR_RDV_JOB=job,
                    IMPDAR_RDV_SECRET=secret)
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        # the parent's device choice is not the ranks': _hip.context() prefers IMPDAR_DEVICE over LOCAL_RANK, so an
+        # inherited value would put every rank on one GPU (and an inherited IMPDAR_NGPUS would make the workers spawn)
+        env.pop('IMPDAR_DEVICE', None)
+        env.pop('IMPDAR_NGPUS', None)
         env.update(env_extra or {})
         procs.append(subprocess.Popen(argv, env=env))
     deadline = None if timeout is None else time.time() + timeout

@@ -68,6 +68,12 @@ int impdar_ctx_last_ms(impdar_ctx *ctx, float *ms);
 /* ... and of the frequency-sum kernels alone (the rotate-accumulate work of mig_python.py:396-487, without the
  * transforms and transposes around it) of the last impdar_phaseshift[_dev] call */
 int impdar_ctx_last_kernel_ms(impdar_ctx *ctx, float *ms);
+/* One JSON object about the last migration entry point that ran on this context (impdar_kirchhoff, impdar_stolt,
+ * impdar_phaseshift[_ffd], impdar_taper): {"entry", "kernel" (the kernel that did the sums), "device", "kernel_ms",
+ * "device_ms", and per entry point e.g. "plan": "new" | "cached", "launches"}.  SURVEY.md section 5 "metrics": the
+ * reference prints 'complete in N seconds' only (mig_python.py:121-122,206-207,285-286); the Python entry points add
+ * sizes, traces per second and the device count and print the line on stderr when IMPDAR_METRICS is set. */
+int impdar_ctx_last_metrics(impdar_ctx *ctx, char *json, size_t cap);
 /* raw device-memory plumbing for resident data (bench, multi-GPU) */
 int impdar_dev_alloc(impdar_ctx *ctx, size_t bytes, void **dptr);
 int impdar_dev_free(impdar_ctx *ctx, void *dptr);
@@ -264,6 +270,9 @@ int impdar_comm_unique_id(char id[IMPDAR_UNIQUE_ID_BYTES]);
 int impdar_comm_init(impdar_ctx *ctx, const char id[IMPDAR_UNIQUE_ID_BYTES], int rank, int nranks);
 int impdar_comm_rank(const impdar_ctx *ctx);
 int impdar_comm_size(const impdar_ctx *ctx);
+/* RCCL's own view of the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion); any
+ * pointer may be null */
+int impdar_comm_info(const impdar_ctx *ctx, int *ranks, int *rank, int *device, int *version);
 int impdar_comm_barrier(impdar_ctx *ctx);
 
 #ifdef __cplusplus

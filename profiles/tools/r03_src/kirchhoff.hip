@@ -23,13 +23,15 @@
 //                        same idea with a trace-major ring, ds_read_b32 and an fp32 weight table,
 //                        for geometries whose moveout does not fit the quad ring.
 #include "common.h"
-#include "kirch_plan.h"
 #include <limits>
 #include <cmath>
 #include <algorithm>
 #include <chrono>
 #include <thread>
 
+#define KF_THREADS 256
+#define KF_W 512            // LDS floats per ring slot (circular window)
+#define KF_PAD_ROWS 128      // zero traces kept on both sides of the image (loops are clipped to the profile)
 
 // ===========================================================================
 // prep: gradient + transpose
@@ -495,6 +497,7 @@ struct FastParams {
     const int2 *WIN;               // [nchunks][nrows] staging window of the 8 traces a block adds:
                                    //   x = kmin | (kmin mod W) << 16, y = kmax
     int nrows, mrow0;
+    unsigned long long *stamps;    // diagnostic builds only (-DKQ_STAMP): per-workgroup {start, end, hw id, chunk|steps}
     int ntab;                      // tab kernel: table rows; the last row is all zero (|n| beyond every aperture)
 };
 
@@ -886,6 +889,7 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
     // chunk) -- one walk of a shallow chunk is as long as such a rank's whole step should be.  A piece writes its
     // sums to its own partial image; kirch_combine_kernel adds the pieces in a fixed order.
     int part = 0;
+    unsigned stamp_slot = blockIdx.x;
     if (P.queue) {
         __syncthreads();                       // every wave is done with the previous item (ring reads, the slot)
         if (threadIdx.x == 0) {
@@ -903,6 +907,7 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
                     const int t = (int)P.tilemap[(size_t)i * 8 + x];
                     if (t >= 0 && t < P.nxt) {
                         it = ((i / P.tiles_per_xcd) << 16) | t;
+                        item_slot[1] = i * 8 + x;
                         break;
                     }
                 }
@@ -911,6 +916,7 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
         }
         __syncthreads();
         const int it = item_slot[0];
+        stamp_slot = (unsigned)item_slot[1];
         part = item_slot[2];
         if (it < 0) break;
         chunk = it >> 16;
@@ -925,6 +931,9 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
                        : ((qx / P.G) * 8 + xcd) * P.G + (qx % P.G);
         if (xt < 0 || xt >= P.nxt) return;
     }
+#ifdef KQ_STAMP
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
     const int s0 = chunk * KF_THREADS;
     const int x0w = (P.xlo & ~7) + xt * (XB * NH);   // workgroup's first output trace: a multiple of 8 (outputs left of xlo are not stored)
     const int x0 = x0w + half * XB;
@@ -978,9 +987,13 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
     auto row_of = [&](int blk) { return min(mrow + blk, P.nrows - 1); };
     // this tile's pick rows: half * XB offsets behind the clock (the table keeps 8 all-dropped rows at its start)
     const int mrow_h = mrow - half * (XB / 8);
+#ifdef KQ_DIAG_PICKHOT      // diagnostic build: every pick load hits the same 16 table rows (L2-hot); results invalid
+    auto prow_of = [&](int blk) { return (mrow_h + blk) & 15; };
+#else
     // (blocks past the walk -- the padding of the last ring revolution -- read the table's last, all-dropped row: after
     // a piece of a walk they would otherwise be offsets that the next piece owns)
     auto prow_of = [&](int blk) { return blk >= nblocks ? P.nrows - 1 : max(min(mrow_h + blk, P.nrows - 1), 0); };
+#endif
 
     // Staging window of the 8 traces block `blk_for` adds: one 8-byte lookup, issued ONE BLOCK EARLIER
     // than its use: s_waitcnt vmcnt counts in order, so waiting for a lookup issued in the same block
@@ -1043,10 +1056,15 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
     // 0.74 ms faster at config 3).  The wait in front of the barrier then leaves the two youngest loads (the
     // pick row and the staging window issued at the top of the block) in flight: s_waitcnt vmcnt counts in
     // order, so vmcnt(2) still retires the staging DMA issued behind the previous barrier.
+#ifndef KQ_PICK_AHEAD
+#define KQ_PICK_AHEAD 2
+#endif
     kq_u4 tkc = picks(0);                          // picks of the current block
+#if KQ_PICK_AHEAD == 2
     kq_u4 tkp[PD + 1];                             // ... of the next one (tkp[0]) and of those behind it
 #pragma unroll
     for (int j = 0; j < PD; ++j) tkp[j] = picks(1 + j);
+#endif
 
     // accumulators in quads: the ordering pin below takes them as XB/4 operands of ONE asm statement
     kq_f4 acc4[XB / 4];
@@ -1078,11 +1096,19 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
     auto dma_issue = [&](int blk_for, int wa) {     // traces that block `blk_for` adds to the ring
         const int kmin = wa & 0xffff, kmod = (int)((unsigned)wa >> 16);
         const int gidx = ((blk_for + G0) % NB + NB) % NB;      // ring group of these traces
+#ifdef KQ_DIAG_STAGEHOT     // diagnostic build: the staging DMA re-reads the same 8 image groups (L2-hot)
+        const unsigned so = (unsigned)((blk_for + G0) & 7) * grp_bytes;
+#else
         const unsigned so = (unsigned)(blk_for + G0) * grp_bytes;     // image group of trace jbase + q0
+#endif
         for (int pc = wv; pc < npieces; pc += 4 * NH) {
             int t = pc * 32 + rl - kmod;
             t += (t < 0) ? W : 0;
+#ifdef KQ_DIAG_STAGEONE     // diagnostic build: every DMA lane reads the same 32 bytes of its image group
+            const int c = 0;
+#else
             const int c = min(kmin + t, snum - 1);
+#endif
             const unsigned vo = (unsigned)c * 32u + hsel;
             dma16((unsigned)(pc * KQ_PS + gidx * KQ_GS), vo, gdesc, so);
             if (NEAR) dma16(img_bytes + (unsigned)(pc * KQ_PS + gidx * KQ_GS), vo, ddesc, so);
@@ -1133,7 +1159,11 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
                 // must stay a whole ds_read_b128 also for the partly used quads at the ends of
                 // the window: fma_step marks the unused components as used (empty asm)
                 const unsigned src = ((qd & 1) ? a1 : a0) + (qd >> 1) * KQ_GS;
+#ifdef KQ_DIAG_NOLDS        // diagnostic build: no LDS reads (VALU-only time of the loop)
+                asm volatile("" : "=v"(v[qd].x), "=v"(v[qd].y), "=v"(v[qd].z), "=v"(v[qd].w) : "v"(src));
+#else
                 v[qd] = *(lds_f4p)(uintptr_t)src;
+#endif
                 if (NEAR) u[qd] = *(lds_f4p)(uintptr_t)(src + img_bytes);
             }
     };
@@ -1151,6 +1181,9 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
                 // components of an edge quad that serve no output are handed to an empty asm: the
                 // load stays a whole ds_read_b128 (split into b32 pieces it bank-conflicts 4-way)
                 // at no instruction cost
+#ifdef KQ_DIAG_NOFMA        // diagnostic build: reads only (LDS-only time of the loop)
+#define KQ_COMP(ix, c) asm volatile("" ::"v"(v[qd].c));
+#else
 #define KQ_COMP(ix, c)                                                              \
     if (ix < XB) {                                                                  \
         KQ_ACC(ix < XB ? ix : 0) = fmaf(w, v[qd].c, KQ_ACC(ix < XB ? ix : 0));            \
@@ -1159,6 +1192,7 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
         asm volatile("" ::"v"(v[qd].c));                                            \
         if (NEAR) asm volatile("" ::"v"(u[qd].c));                                  \
     }
+#endif
                 KQ_COMP(i0, x)
                 KQ_COMP(i1, y)
                 KQ_COMP(i2, z)
@@ -1199,9 +1233,17 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
             // ---- loads: the next block's table entries and, by DMA, its 8 new traces.  Their ring group
             // held traces last read at step 6 of the previous block, and every wave is past that block's
             // barrier, which sits after step 6: no wave can still be reading them.
+#ifdef KQ_DIAG_NOPICK
+            tkp[PD] = tkc;
+#elif KQ_PICK_AHEAD == 2
             tkp[PD] = picks(blk + PD + 1);
+#else
+            const kq_u4 tkn = picks(blk + 1);
+#endif
             int wn = 0;
+#if !defined(KQ_DIAG_NOSTAGE)
             fetch_for(blk + 2 + LK + PD, wn, wb);      // staging window of a DMA issued PD blocks from now
+#endif
             // obliquity cos(theta) of this block's steps
             float twc[S], tw2c[NEAR ? S : 1];
 #pragma unroll
@@ -1233,7 +1275,9 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
             // ---- barrier after step 6.  The new traces are first read by step 0 of the next block, whose
             // reads are issued below; each wave retires its own DMA (and the pick load) first.  The LDS
             // reads of step 7 stay in flight across the barrier, so the read pipeline never drains.
+#ifndef KQ_DIAG_NODMAWAIT
             // a builtin so that hipcc's own wait counting sees it
+#if KQ_PICK_AHEAD == 2 && !defined(KQ_DIAG_NOSTAGE) && !defined(KQ_DIAG_NOPICK)
             if (LK == 0) {
                 __builtin_amdgcn_s_waitcnt(0x0F72);    // vmcnt(2): all but this block's pick row + window lookup
             } else if (blk < LK || dma_c == 0) {
@@ -1243,21 +1287,35 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
             } else {
                 __builtin_amdgcn_s_waitcnt(0x0F76);    // vmcnt(6): ... and two DMAs
             }
+#else
+            __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) only
+#endif
+#endif
+#ifndef KQ_DIAG_NOBAR
             asm volatile("s_barrier" ::: "memory");
+#endif
+#if !defined(KQ_DIAG_NOSTAGE)
             // every wave is past step 6 of this block: the ring group of the traces last read there is free
             dma_issue(blk + 2 + LK, wp[0]);
 #pragma unroll
             for (int j = 0; j + 1 < PD; ++j) wp[j] = wp[j + 1];
             wp[PD - 1] = wn;
+#endif
+#if KQ_PICK_AHEAD == 2
 #define KQ_NEXT tkp[0]
+#else
+#define KQ_NEXT tkn
+#endif
             KQ_STEP(((pm0 + 8) % RG, KQ_TK(KQ_NEXT, 0), va, ua), (pm0 + 7, twc[7], KQ_W2(7), vb, ub));
 #undef KQ_W2
 #undef KQ_STEP
 #undef KQ_UNPACK
             tkc = KQ_NEXT;
 #undef KQ_NEXT
+#if KQ_PICK_AHEAD == 2
 #pragma unroll
             for (int j = 0; j < PD; ++j) tkp[j] = tkp[j + 1];
+#endif
         }
     }
 #undef KQ_PIN
@@ -1273,6 +1331,20 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
             if (x0 + i >= P.xlo && x0 + i < P.xhi) o[i] = KQ_ACC(i) * fin;
     }
 #undef KQ_ACC
+#ifdef KQ_STAMP
+    // diagnostic build (build/stamp_run.py): workgroup residency timeline, us per step per chunk
+    if (tid == 0 && P.stamps) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *o = P.stamps + ((size_t)stamp_slot * NH + half) * 4;
+        o[0] = t_start;
+        o[1] = __builtin_amdgcn_s_memrealtime();
+        o[2] = ((unsigned long long)xcc << 32) | hwid;
+        o[3] = ((unsigned long long)chunk << 32) | (unsigned)nsteps;
+    }
+#endif
+    (void)stamp_slot;
     if (!P.queue) break;
     }   // item loop
 }
@@ -1667,6 +1739,90 @@ __global__ __launch_bounds__(256) void kirch_combine_kernel(const T *__restrict_
 // ===========================================================================
 // host side
 // ===========================================================================
+struct impdar_kirch_plan {
+    impdar_ctx *ctx = nullptr;
+    int dtype = IMPDAR_F32, snum = 0, tnum = 0, tnum_pad = 0, nranks = 1;
+    int nearfield = 0, mode = IMPDAR_KIRCH_EXACT;
+    int grad_uniform = 0;
+    double grad_h = 1.0, vel = 0, tmax = 0, dt = 1, dx = 1, tt0 = 0, alpha = 1;
+    bool uniform = false;
+    bool dist_sorted = false;
+    // exact path on uniform grids: fp64 pick / weight tables (built at the first migrate)
+    DevBuf d_XK, d_XW, d_XW2, d_xhmax;
+    int xntab = 0;
+    bool xtab_ready = false, xtab_off = false;
+    int diag_tables_built = 0;
+    bool table_built[2] = {false, false};   // ring kernels: the geometry-only pick table of buffer set b exists
+    // device tables
+    DevBuf d_dist, d_tt, d_zs, d_zs2, d_ga, d_gb, d_gc;
+    // Everything a prep produces is double-buffered: prep / table / all-gather of radargram
+    // s+1 run on the context's aux stream while the diffraction sum of radargram s runs on
+    // the compute stream.  `buf` flips at the first prep after a migrate.
+    DevBuf GT[2], DT[2];           // images with KF_PAD_ROWS all-zero rows before row 0 and after row tnum_pad-1
+    int buf = 0;
+    bool migrated_since_prep = false;
+    const void *last_out = nullptr;   // output of the last migrate (a prep that reads it must wait for that kernel)
+    int last_out_buf = 0;
+    hipEvent_t ev_ready[2] = {nullptr, nullptr};   // image + table of buffer b complete (aux stream)
+    hipEvent_t ev_free[2] = {nullptr, nullptr};    // last migrate reading buffer b done (compute stream)
+    bool free_recorded[2] = {false, false};
+    DevBuf d_hmax, d_klo, d_khi;
+    DevBuf d_TK[2], d_TW[2], d_TW2[2], d_c1, d_c2, d_fin, d_WIN;
+    int nrows = 0, mrow0 = 0;   // quad kernel: step-block table rows (see FastParams)
+    int quadSH = 0;             // table entries are LDS byte offsets >> quadSH
+    DevBuf d_stamps;               // diagnostic builds only
+    int nb = 0, ntab = 0;
+    bool quad = false;          // sample-major LDS ring (kirch_quad_kernel)
+    std::vector<int> h_hmax;    // host copy of the per-chunk aperture half widths (tile cost model)
+    DevBuf d_queue;             // quad kernel, persistent workgroups: per-XCD item counters
+    int slots = 0;              // ... and how many of them are resident at once (occupancy query, cached)
+    int walk_parts_log2 = 0;    // every tile's aperture walk as 1, 2 or 4 queue items (plans of 4+ / 8+ ranks)
+    DevBuf d_partial;           // ... and the partial images of the pieces
+    DevBuf d_tilemap;           // ring kernels: (chunk, slot, XCD) -> output tile, balanced over the XCDs
+    std::vector<short> h_tilemap;
+    int tm_key[5] = {-1, -1, -1, -1, -1};   // (xlo, xhi, tile width, G, tiles_per_xcd) the cached map was built for
+    int nh = 1;                 // quad kernel: output tiles per workgroup sharing one ring (256 nh threads)
+    int lk = 0;                 // ... and extra ring groups = blocks of additional staging lookahead (nh >= 2 only)
+    bool dquad = false;         // the same ring in float64 (kirch_dquad_kernel): exact mode, float64 data, uniform grids
+    double xnoise = 0;          // position noise of dist[j] - dist[xi] in units of dx (see plan creation)
+    bool tie_ambiguous = false; // more rounding-noise ties than the list holds: per-pair kernel only
+    int ntie_groups = 0;        // samples with flagged offsets (kirch_tiefix_kernel after every table-driven diffraction sum)
+    DevBuf d_tie_ti, d_tie_off, d_tie_n;
+    DevBuf d_c1d, d_c2d, d_find;
+    int quadW = 0;              // samples per ring slot in that layout
+    // host copies for pair counting
+    std::vector<int> h_half;       // exact aperture half-width per sample (uniform grids)
+    int nchunks = 0;
+    // ring of HIP-event sets so a timed loop can read per-step kernel
+    // durations afterwards without synchronising inside the loop
+    static constexpr int NSLOT = 64;
+    hipEvent_t evs[NSLOT][6] = {};
+    bool haves[NSLOT][3] = {};
+    int slot = 0;
+    int xb = 24;                   // fast-kernel trace tile (24: quad ring, 16: tab ring)
+
+    ~impdar_kirch_plan()
+    {
+        for (hipEvent_t e : {ev_ready[0], ev_ready[1], ev_free[0], ev_free[1]})
+            if (e) (void)hipEventDestroy(e);
+        for (int s = 0; s < NSLOT; ++s)
+            for (int i = 0; i < 6; ++i)
+                if (evs[s][i]) (void)hipEventDestroy(evs[s][i]);
+    }
+};
+
+static inline char *img_row0(const impdar_kirch_plan *p, const DevBuf &b)  // b = GT[buf] / DT[buf]
+{
+    return reinterpret_cast<char *>(b.p) + (size_t)KF_PAD_ROWS * p->snum * impdar_dtype_size(p->dtype);
+}
+
+static int upload(DevBuf &b, const void *src, size_t bytes)
+{
+    IMPDAR_HIP_CHECK(b.ensure(bytes ? bytes : 8));
+    if (bytes) IMPDAR_HIP_CHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return IMPDAR_OK;
+}
+
 // set by mig_kirch_loop around its plan creation: the time limit t > t_max drops a pair at (mig_python.py:52) is the
 // caller's argument there, not max(tt)
 static thread_local const double *g_tmax_override = nullptr;
@@ -1817,43 +1973,16 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     const bool fast_ok = dtype == IMPDAR_F32 && p->uniform && window_ok && snum < 65536 &&
                          std::fabs(tmax / dt) / sa < 65000.0 && span_ok;
 
-    // float32 data on a profile whose spacing is NOT uniform (mig_python.py:44 takes any dist[]): kirch_gen_kernel
-    // computes every pair's pick from the positions.  It needs a uniform time axis, a sorted dist[] (the staging windows
-    // and the input range of a tile come from bisections) and, per 32 consecutive output traces, a moveout that fits
-    // its LDS slots: W >= 264 + (extent of the 32 traces in samples).  IMPDAR_KIRCH_IMPL=gen takes it on uniform
-    // profiles too (A/B against the ring kernels).
-    int gen_w = 0;
-    bool gen_ok = false;
-    bool uni_t11 = uni_t;          // the float64 re-decision of a pick takes tt[k] = tt[0] + k dt: to 1e-11 dt here
-    for (int k = 0; k < snum && uni_t11; ++k)
-        if (std::fabs(tt_sec[k] - (tt_sec[0] + k * dt)) > 1e-11 * dt) uni_t11 = false;
-    if (dtype == IMPDAR_F32 && uni_t11 && p->dist_sorted && tnum >= 2 && snum >= 4 && snum < (1 << 22) && !g_tmax_override &&
-        (double)tnum * snum * 4.0 < 2147483648.0) {
-        double ext = 0.0;
-        for (int j = 0; j < tnum; ++j) ext = std::max(ext, dist_m[std::min(j + 31, tnum - 1)] - dist_m[j]);
-        const double need = 264.0 + std::ceil(ext * 2.0 / (vel * dt));
-        if (need <= 1024.0) {
-            gen_w = ((int)need + 255) / 256 * 256;
-            if (gen_w < 512) gen_w = 512;
-            gen_ok = true;
-        }
-    }
-    const char *impl_env = getenv("IMPDAR_KIRCH_IMPL");
-    const bool gen_forced = gen_ok && impl_env && !strcmp(impl_env, "gen") && mode != IMPDAR_KIRCH_EXACT;
     const int requested_mode = mode;
-    const bool gen = gen_forced || (gen_ok && !fast_ok && mode != IMPDAR_KIRCH_EXACT);
-    if (mode == IMPDAR_KIRCH_AUTO) mode = (fast_ok || gen) ? IMPDAR_KIRCH_FAST : IMPDAR_KIRCH_EXACT;
-    if (mode == IMPDAR_KIRCH_FAST && !fast_ok && !gen) {
+    if (mode == IMPDAR_KIRCH_AUTO) mode = fast_ok ? IMPDAR_KIRCH_FAST : IMPDAR_KIRCH_EXACT;
+    if (mode == IMPDAR_KIRCH_FAST && !fast_ok) {
         delete p;
-        impdar_set_error("the float32 Kirchhoff kernels need float32 data on a uniform travel_time axis and either a "
-                         "uniform dist with moveout 2dx/(v dt) <= %.1f samples per trace (got %.2f) or a sorted dist "
-                         "whose 32-trace windows span <= 760 samples of moveout",
+        impdar_set_error("fast Kirchhoff kernel needs float32 data on uniform dist/travel_time grids "
+                         "with moveout 2dx/(v dt) <= %.1f samples per trace (got %.2f)",
                          (KF_W - KF_THREADS - 8.0) / 15.0, sa);
         return IMPDAR_ERR_UNSUPPORTED;
     }
     p->mode = mode;
-    p->gen = gen && mode == IMPDAR_KIRCH_FAST;
-    p->genW = gen_w;
     {
         // One full-aperture walk of a shallow chunk takes ~1.2 ms at config 3 -- as long as the whole step of a rank of
         // an 8-GPU run should be, and such a rank's block has fewer items than the chip has workgroup slots.  Plans
@@ -1867,22 +1996,20 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
         const char *ie = getenv("IMPDAR_KIRCH_IMPL");       // tuning knob: "tab" forces the b32 ring
         p->quadW = wq;
         p->quadSH = ((size_t)(wq / 32) * kq_ps <= 65535) ? 0 : 4;
-        p->quad = (mode == IMPDAR_KIRCH_FAST) && !p->gen && quad_ok && !(ie && !strcmp(ie, "tab") && tab_ok);
-        p->xb = p->gen ? 32 : (p->quad ? xbq : 16);
+        p->quad = (mode == IMPDAR_KIRCH_FAST) && quad_ok && !(ie && !strcmp(ie, "tab") && tab_ok);
+        p->xb = p->quad ? xbq : 16;
     }
     // float64 data in exact mode on uniform grids: the same ring in float64 (20 or 16 output traces per lane,
     // step blocks of 4) when its window fits; otherwise (and for IMPDAR_KIRCH_EXACT_IMPL = tab | pair) the
     // global-memory kernels
     // The table-driven float64 kernels weight a pair by its trace OFFSET (n dx); the reference by dist[j] - dist[xi].
     // On a profile whose positions are noisy against the grid (a first trace tens of kilometres along the line:
-    // ulp(dist) / dx ~ 1e-10; 100000 traces from 0: 4.5e-11) the two weights differ by that much relative, and the
-    // result differs from the reference's by up to ~0.03 xnoise of the image maximum (measured 2.5e-12 at 1e-10 with
-    // the near-field term).  Rounds 2-3 sent every profile with xnoise > 3e-11 to the per-pair kernel to hold a flat
-    // 1e-12 -- 45-100x slower on ordinary long traverses.  The ring (and the tabulated kernel) now stay; the stated bar
-    // of the float64 path is  max(1e-12, 0.1 xnoise)  of the image maximum (impdar_kirch_plan_xnoise reports xnoise;
-    // picks are not affected: every pick within the noise of a tie is re-done pair by pair, kirch_tiefix_kernel).
-    // IMPDAR_KIRCH_EXACT_IMPL=pair still forces the reference's arithmetic pair by pair.
-    if (mode == IMPDAR_KIRCH_EXACT && dtype == IMPDAR_F64 && p->uniform && snum < 65536 &&
+    // ulp(dist) / dx ~ 1e-10; spacing that is uniform only to 1e-9) the weights differ by that much, and the stated
+    // 1e-12 of the float64 path no longer holds (measured 2.5e-12 with the near-field term at xnoise 1e-10): such
+    // profiles keep the per-pair kernel in exact mode.  40000 traces of 1 m from 0 have xnoise 1.8e-11.
+    const bool noisy_x = p->xnoise > 3e-11;
+    if (mode == IMPDAR_KIRCH_EXACT && noisy_x && !getenv("IMPDAR_KIRCH_EXACT_IMPL")) p->xtab_off = true;
+    if (mode == IMPDAR_KIRCH_EXACT && dtype == IMPDAR_F64 && p->uniform && !noisy_x && snum < 65536 &&
         std::fabs(tmax / dt) / sa < 65000.0 && (2.0 * hest + 400.0) / 4.0 * (double)snum * 32.0 < 2147483648.0 &&
         !getenv("IMPDAR_KIRCH_EXACT_IMPL")) {
         const char *ne = getenv("IMPDAR_KIRCH_NHD");        // tuning knob: tiles per workgroup, 1 | 2
@@ -1938,9 +2065,7 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
             zs[k] = vel * tt_sec[k] / 2.0;          // mig_python.py:101
             zs2[k] = zs[k] * zs[k];                 // :102
         }
-        std::vector<double> dpad(dist_m, dist_m + tnum);
-        dpad.resize((size_t)tnum + 64, dist_m[tnum - 1]);      // kirch_gen_kernel reads up to 31 entries past a tile's end
-        if ((rc = upload(p->d_dist, dpad.data(), dpad.size() * 8)) || (rc = upload(p->d_tt, tt_sec, (size_t)snum * 8)) ||
+        if ((rc = upload(p->d_dist, dist_m, (size_t)tnum * 8)) || (rc = upload(p->d_tt, tt_sec, (size_t)snum * 8)) ||
             (rc = upload(p->d_zs, zs.data(), (size_t)snum * 8)) || (rc = upload(p->d_zs2, zs2.data(), (size_t)snum * 8)))
             return fail(rc);
     }
@@ -1956,7 +2081,7 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     }
     // ---- picks that rounding noise decides (see kirch_tiescan_kernel): the table-driven kernels would break those
     // ties one way per offset, the reference breaks them pair by pair
-    if (p->uniform && !gen_forced && (mode == IMPDAR_KIRCH_FAST || p->dquad || !getenv("IMPDAR_KIRCH_EXACT_IMPL") ||
+    if (p->uniform && (mode == IMPDAR_KIRCH_FAST || p->dquad || !getenv("IMPDAR_KIRCH_EXACT_IMPL") ||
                        strcmp(getenv("IMPDAR_KIRCH_EXACT_IMPL"), "pair"))) {
         int hg = 0;
         for (int k = 0; k < snum; ++k) hg = std::max(hg, p->h_half[k] + 1);
@@ -1990,21 +2115,6 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
             hipStreamSynchronize(ctx->stream) != hipSuccess) {
             impdar_set_error("tie scan failed: %s", hipGetErrorString(hipGetLastError()));
             return fail(IMPDAR_ERR_HIP);
-        }
-        if (p->gen && count > 0) {
-            // kirch_gen_kernel on a UNIFORM profile (steep moveout: the ring kernels' windows do not fit) decides a pick
-            // that sits on a half-way point by exact arithmetic; the reference by the rounding noise of its own
-            // sqrt / divide, pair by pair (see kirch_tiescan_kernel).  A rational moveout has such entries: those
-            // profiles keep the float64 kernels, which re-do them the reference's way.
-            if (requested_mode == IMPDAR_KIRCH_FAST) {
-                impdar_set_error("the float32 Kirchhoff kernels cannot reproduce the %d picks that rounding noise "
-                                 "decides on this uniform profile (moveout %.4f samples per trace); use mode auto / exact",
-                                 count, sa);
-                return fail(IMPDAR_ERR_UNSUPPORTED);
-            }
-            p->gen = false;
-            mode = p->mode = IMPDAR_KIRCH_EXACT;
-            p->xb = 16;
         }
         const bool no_fix = getenv("IMPDAR_KIRCH_TIEFIX") && !strcmp(getenv("IMPDAR_KIRCH_TIEFIX"), "0");   // diagnostic
         if (count > 0 && count <= TIE_CAP && !no_fix) {
@@ -2042,27 +2152,8 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
             p->xtab_off = true;
         }
     }
-    if (p->gen) {
-        // per-sample float32 factors, the squared half-way radii of the float64 re-decision, per-chunk bounds
-        const int nch = (snum + KF_THREADS - 1) / KF_THREADS;
-        p->nchunks = nch;
-        std::vector<float> a(snum), a2(snum), alo2(nch, 3.0e38f);
-        p->h_zs2min.assign(nch, 1e300);
-        for (int k = 0; k < snum; ++k) {
-            const double ak = tt_sec[k] / dt;
-            a[k] = (float)ak;
-            a2[k] = (float)(ak * ak / ((double)(gen_w - 1) * (double)(gen_w - 1)));    // normalised to the slot (kirch_gen_kernel)
-            alo2[k / KF_THREADS] = std::min(alo2[k / KF_THREADS], (float)(ak * ak) * (1.0f - 1.0e-6f));
-            const double zs = vel * tt_sec[k] / 2.0;
-            p->h_zs2min[k / KF_THREADS] = std::min(p->h_zs2min[k / KF_THREADS], zs * zs);
-        }
-        p->h_dist.assign(dist_m, dist_m + tnum);
-        if ((rc = upload(p->d_ga32, a.data(), snum * 4)) || (rc = upload(p->d_ga2_32, a2.data(), snum * 4)) ||
-            (rc = upload(p->d_alo2, alo2.data(), nch * 4)))
-            return fail(rc);
-    }
     const int ringS = p->dquad ? 4 : 8;            // steps per block of the ring kernels (traces per 32-byte row)
-    if ((mode == IMPDAR_KIRCH_FAST && !p->gen) || p->dquad) {
+    if (mode == IMPDAR_KIRCH_FAST || p->dquad) {
         const int nch = (snum + KF_THREADS - 1) / KF_THREADS;
         p->nchunks = nch;
         std::vector<int> hmax(nch, 0);
@@ -2215,13 +2306,11 @@ extern "C" void impdar_kirch_plan_destroy(impdar_kirch_plan *p)
 }
 
 extern "C" int impdar_kirch_plan_mode(const impdar_kirch_plan *p) { return p ? p->mode : IMPDAR_ERR_ARG; }
-extern "C" double impdar_kirch_plan_xnoise(const impdar_kirch_plan *p) { return p ? p->xnoise : -1.0; }
 extern "C" int impdar_kirch_plan_tnum_pad(const impdar_kirch_plan *p) { return p ? p->tnum_pad : IMPDAR_ERR_ARG; }
 
 extern "C" int impdar_kirch_plan_kernel(const impdar_kirch_plan *p)
 {
     if (!p) return IMPDAR_ERR_ARG;
-    if (p->gen) return IMPDAR_KERNEL_GEN;
     if (p->mode == IMPDAR_KIRCH_FAST) return p->quad ? IMPDAR_KERNEL_QUAD : IMPDAR_KERNEL_TAB;
     if (p->dquad) return IMPDAR_KERNEL_DQUAD;
     const char *e = getenv("IMPDAR_KIRCH_EXACT_IMPL");
@@ -2282,7 +2371,8 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
         P.clean = (p->mode == IMPDAR_KIRCH_FAST) ? 1 : (p->dquad ? 2 : 0);
         P.i8 = (p->quad || p->dquad) ? 1 : 0;
         dim3 grid((nloc + 63) / 64, (p->snum + 63) / 64);
-        if (p->dtype == IMPDAR_F32 && P.i8)
+        static const bool force_tile = getenv("IMPDAR_KIRCH_PREP_TILE") != nullptr;   // tuning knob: LDS-tile transpose
+        if (p->dtype == IMPDAR_F32 && P.i8 && !force_tile)
             hipLaunchKernelGGL((kirch_prep_direct_kernel<float, 8>), dim3((nloc + 255) / 256, p->snum), dim3(256), 0, st, P);
         else if (p->dquad)
             hipLaunchKernelGGL((kirch_prep_direct_kernel<double, 4>), dim3((nloc + 255) / 256, p->snum), dim3(256), 0, st, P);
@@ -2294,8 +2384,10 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
     }
     // The pick table depends on the plan's geometry only (like an FFT plan's twiddles): it is built by the first prep
     // into each of the two buffer sets and kept.  (Round 1 rebuilt it with every prep -- 0.06-0.13 ms on the producer
-    // stream, hidden behind a whole-radargram diffraction sum but a tenth of the step of an 8-rank block.)
-    if (((p->mode == IMPDAR_KIRCH_FAST && p->quad) || p->dquad) && p->table_built[b]) {
+    // stream, hidden behind a whole-radargram diffraction sum but a tenth of the step of an 8-rank block;
+    // IMPDAR_KIRCH_TABLE_EVERY_PREP=1 restores that.)
+    static const bool table_every_prep = getenv("IMPDAR_KIRCH_TABLE_EVERY_PREP") != nullptr;
+    if (((p->mode == IMPDAR_KIRCH_FAST && p->quad) || p->dquad) && !table_every_prep && p->table_built[b]) {
         // this buffer set's table is in place
     } else if ((p->mode == IMPDAR_KIRCH_FAST && p->quad) || p->dquad) {
         p->table_built[b] = true;
@@ -2324,7 +2416,7 @@ static int kirch_prep_impl(impdar_kirch_plan *p, const void *d_data, int ld, int
         else
             hipLaunchKernelGGL(kirch_tableq_kernel, dim3((p->snum + 255) / 256, na), dim3(256), 0, st, T);
         IMPDAR_HIP_CHECK(hipGetLastError());
-    } else if (p->mode == IMPDAR_KIRCH_FAST && !p->gen) {
+    } else if (p->mode == IMPDAR_KIRCH_FAST) {
         // geometry-only pick/weight table, rebuilt with every prep (counted in prep time)
         TableParams T;
         T.TK = p->d_TK[b].as<unsigned short>();
@@ -2373,8 +2465,9 @@ int impdar_kirch_prep_precomputed(impdar_kirch_plan *p, const void *d_grad, int 
 static int build_tilemap(impdar_kirch_plan *p, FastParams &P, int tile_w, int align_mask, int ring_blocks, int step_block,
                          hipStream_t st)
 {
+    static const bool off = getenv("IMPDAR_KIRCH_TILEMAP") && !strcmp(getenv("IMPDAR_KIRCH_TILEMAP"), "0");
     P.tilemap = nullptr;
-    if ((int)p->h_hmax.size() != P.nchunks) return IMPDAR_OK;
+    if (off || (int)p->h_hmax.size() != P.nchunks) return IMPDAR_OK;
     const int key[5] = {P.xlo, P.xhi, tile_w, P.G, P.tiles_per_xcd};
     const size_t n = (size_t)P.nchunks * P.tiles_per_xcd * 8;
     if (memcmp(key, p->tm_key, sizeof(key)) != 0 || p->h_tilemap.size() != n) {
@@ -2448,10 +2541,12 @@ static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipSt
     const int ntiles = (P.xhi - (P.xlo & ~7) + XB * NH - 1) / (XB * NH);      // workgroup tiles start at a multiple of 8
     P.nxt = ntiles;
     {
+        const char *ge = getenv("IMPDAR_KIRCH_G");        // tuning knob: adjacent trace tiles per XCD group
         // groups of 4 adjacent tiles per XCD share staging lines in L2 (same-box A/B at config 3: 1.2-1.6 %
-        // faster than 1, L2 misses -36 %; 6 / 8 / 12 are slower), but the XCDs only stay balanced when each gets many
-        // groups: with the 45-70 tiles of an 8-rank block groups of 4 leave half of the XCDs with twice the work (-16 %).
-        P.G = ntiles >= 256 ? 4 : 1;
+        // faster than 1, L2 misses -36 %), but the XCDs only stay balanced when each gets many groups: with
+        // the 45-70 tiles of an 8-rank block G = 4 leaves half of the XCDs with twice the work (-16 %).
+        const int g = ge ? atoi(ge) : (ntiles >= 256 ? 4 : 1);
+        P.G = (g >= 1 && g <= 64) ? g : 1;
     }
     const int per = 8 * P.G;
     const int nxt_pad = ((ntiles + per - 1) / per) * per;
@@ -2471,7 +2566,8 @@ static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipSt
         auto k = kirch_quad_kernel<XB, false, OCC, SH, NH, LK>;
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         int grid = nblk;
-        if (P.tilemap) {
+        static const bool no_queue = getenv("IMPDAR_KIRCH_QUEUE") && !strcmp(getenv("IMPDAR_KIRCH_QUEUE"), "0");
+        if (P.tilemap && !no_queue) {
             // persistent workgroups: as many as are resident at once, each pulling items from the per-XCD queues
             if (p->slots <= 0) {        // resident workgroups of this plan's kernel on this device: asked once
                 int per_cu = 0, ncu = 0;
@@ -2527,7 +2623,9 @@ static int launch_dquad(impdar_kirch_plan *p, const FastParams &P0, hipStream_t 
     const int ntiles = (P.xhi - (P.xlo & ~3) + XB * NH - 1) / (XB * NH);      // workgroup tiles start at a multiple of 4
     P.nxt = ntiles;
     {
-        P.G = ntiles >= 256 ? 4 : 1;
+        const char *ge = getenv("IMPDAR_KIRCH_G");
+        const int g = ge ? atoi(ge) : (ntiles >= 256 ? 4 : 1);
+        P.G = (g >= 1 && g <= 64) ? g : 1;
     }
     const int per = 8 * P.G;
     const int nxt_pad = ((ntiles + per - 1) / per) * per;
@@ -2547,7 +2645,8 @@ static int launch_dquad(impdar_kirch_plan *p, const FastParams &P0, hipStream_t 
         auto k = kirch_dquad_kernel<XB, false, (NH > 1 ? 4 : 2), SH, NH>;
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         int grid = nblk;
-        if (P.tilemap) {
+        static const bool no_queue = getenv("IMPDAR_KIRCH_QUEUE") && !strcmp(getenv("IMPDAR_KIRCH_QUEUE"), "0");
+        if (P.tilemap && !no_queue) {
             if (p->slots <= 0) {        // resident workgroups of this plan's kernel on this device: asked once
                 int per_cu = 0, ncu = 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, KF_THREADS * NH, shmem) == hipSuccess &&
@@ -2633,10 +2732,7 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
     IMPDAR_HIP_CHECK(hipStreamWaitEvent(st, p->ev_ready[b], 0));      // image + table of this radargram
     if (!p->haves[p->slot][2]) IMPDAR_HIP_CHECK(hipEventRecord(ev[4], st));
     const int nx = xhi - xlo;
-    if (nx > 0 && p->gen) {
-        const int grc = kirch_launch_gen(p, d_out, xlo, xhi, st);
-        if (grc) return grc;
-    } else if (nx > 0 && (p->mode == IMPDAR_KIRCH_FAST || p->dquad)) {
+    if (nx > 0 && (p->mode == IMPDAR_KIRCH_FAST || p->dquad)) {
         FastParams P;
         P.GT = reinterpret_cast<const float *>(img_row0(p, p->GT[b]));
         P.DT = p->nearfield ? reinterpret_cast<const float *>(img_row0(p, p->DT[b])) : nullptr;
@@ -2666,12 +2762,21 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         P.WIN = p->d_WIN.as<int2>();
         P.nrows = p->nrows;
         P.mrow0 = p->mrow0;
+        P.stamps = nullptr;
         P.tilemap = nullptr;
         P.queue = nullptr;
         P.parts_log2 = 0;
         P.partial = nullptr;
         P.part_stride = 0;
+#ifdef KQ_STAMP
+        if (p->d_stamps.ensure((size_t)1 << 22) == hipSuccess) {
+            (void)hipMemsetAsync(p->d_stamps.p, 0, (size_t)1 << 22, st);
+            P.stamps = p->d_stamps.as<unsigned long long>();
+        }
+#endif
         int rc;
+        const char *oe0 = getenv("IMPDAR_KIRCH_OCC");      // tuning knob: min waves per SIMD to compile for
+        const int occ0 = oe0 ? atoi(oe0) : 0;
         if (p->dquad && p->nh == 2 && p->quadSH == 4)
             rc = p->xb == 20 ? launch_dquad<20, 4, 2>(p, P, st) : launch_dquad<16, 4, 2>(p, P, st);
         else if (p->dquad)
@@ -2680,7 +2785,7 @@ extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, 
         else if (p->quad && p->quadSH == 0)
             rc = p->xb == 40 ? launch_quad<40, 2, 0>(p, P, nx, st)
                  : p->xb == 32 ? launch_quad<32, 2, 0>(p, P, nx, st)
-                               : launch_quad<24, 3, 0>(p, P, nx, st);
+                 : (occ0 == 2) ? launch_quad<24, 2, 0>(p, P, nx, st) : launch_quad<24, 3, 0>(p, P, nx, st);
         else if (p->quad && p->nh == 2 && p->xb == 32)
             rc = launch_quad<32, 4, 4, 2, 0>(p, P, nx, st);      // 70 KB of LDS: two workgroups of 8 waves per CU
         else if (p->quad && p->nh == 2 && p->xb == 40)
@@ -2945,6 +3050,16 @@ extern "C" int impdar_kirch_last_ms(impdar_kirch_plan *p, float *prep_ms, float 
     return impdar_kirch_history_ms(p, 0, prep_ms, gather_ms, migrate_ms);
 }
 
+#ifdef KQ_STAMP
+extern "C" int impdar_kirch_debug_stamps(impdar_kirch_plan *p, unsigned long long *host, size_t bytes)
+{
+    if (!p || !p->d_stamps.p) return IMPDAR_ERR_ARG;
+    IMPDAR_HIP_CHECK(hipSetDevice(p->ctx->device));
+    IMPDAR_HIP_CHECK(hipDeviceSynchronize());
+    IMPDAR_HIP_CHECK(hipMemcpy(host, p->d_stamps.p, bytes, hipMemcpyDeviceToHost));
+    return IMPDAR_OK;
+}
+#endif
 
 extern "C" long long impdar_kirch_count_pairs(const impdar_kirch_plan *p, int xlo, int xhi)
 {
@@ -2997,9 +3112,11 @@ thread_local bool t_k1_busy = false, t_hook_busy = false;     // this thread is 
 
 std::string kirch_knobs()
 {
-    static const char *names[] = {"IMPDAR_KIRCH_EXACT_IMPL", "IMPDAR_KIRCH_IMPL", "IMPDAR_KIRCH_LK", "IMPDAR_KIRCH_NH",
-                                  "IMPDAR_KIRCH_NHD", "IMPDAR_KIRCH_PARTS", "IMPDAR_KIRCH_TIEFIX", "IMPDAR_KIRCH_XB",
-                                  "IMPDAR_KIRCH_XBD", "IMPDAR_KIRCH_MODE"};
+    static const char *names[] = {"IMPDAR_KIRCH_EXACT_IMPL", "IMPDAR_KIRCH_G", "IMPDAR_KIRCH_IMPL", "IMPDAR_KIRCH_LK",
+                                  "IMPDAR_KIRCH_NH", "IMPDAR_KIRCH_NHD", "IMPDAR_KIRCH_OCC", "IMPDAR_KIRCH_PARTS",
+                                  "IMPDAR_KIRCH_PREP_TILE", "IMPDAR_KIRCH_QUEUE", "IMPDAR_KIRCH_TABLE_EVERY_PREP",
+                                  "IMPDAR_KIRCH_TIEFIX", "IMPDAR_KIRCH_TILEMAP", "IMPDAR_KIRCH_XB", "IMPDAR_KIRCH_XBD",
+                                  "IMPDAR_KIRCH_MODE"};
     std::string k;
     for (const char *n : names) {
         const char *v = getenv(n);
@@ -3033,6 +3150,7 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
                                 const double *gc, int mode, double *out)
 {
     IMPDAR_ARG_CHECK(ctx && data && out, "null context/data/output");
+    const bool timing = getenv("IMPDAR_TIMING") != nullptr;      // diagnostic: phase times of the one-shot call on stderr
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
@@ -3102,15 +3220,29 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
     // IMPDAR_KIRCH_ONESHOT_SPLIT=0: one upload, one launch, one download; =2: one upload, two launches.
     const char *se = getenv("IMPDAR_KIRCH_ONESHOT_SPLIT");
     const int kern = impdar_kirch_plan_kernel(p);
-    const bool split = !(se && atoi(se) == 0) && tnum >= 4096 && bytes >= ((size_t)64 << 20) &&
+    const bool split = !(se && atoi(se) == 0) && (!timing || getenv("IMPDAR_TIMING_SPLIT")) && tnum >= 4096 && bytes >= ((size_t)64 << 20) &&
                        (kern == IMPDAR_KERNEL_QUAD || kern == IMPDAR_KERNEL_DQUAD);
-    int nlaunch = 1;
+    auto t1 = t0b, t1b = t0b;
     if (split) {
         const int halo = p->ntab + 16;                 // aperture half width (+ the kernels' staging look-ahead)
         auto r8 = [](long long x) { return (int)(x / 8 * 8); };
         std::vector<int> cut;
         const bool two = se && atoi(se) == 2;          // the round-3 first form, kept for A/B
-        const std::vector<int> pct = {10, 40, 70};         // interior cuts in percent of tnum (sweep: profiles/r03_oneshot_pipeline.txt)
+        // IMPDAR_KIRCH_ONESHOT_CUTS="10,40,70": the interior cuts in percent of tnum (tuning knob; up to 7 blocks)
+        std::vector<int> pct = {10, 40, 70};
+        if (const char *ce2 = getenv("IMPDAR_KIRCH_ONESHOT_CUTS")) {
+            std::vector<int> q;
+            for (const char *c = ce2; *c;) {
+                char *end = nullptr;
+                const long v = strtol(c, &end, 10);
+                if (end == c) break;
+                q.push_back((int)v);
+                c = *end == ',' ? end + 1 : end;
+            }
+            bool ok = !q.empty() && q.size() <= 6 && q.front() > 0 && q.back() < 100;
+            for (size_t i = 1; i < q.size(); ++i) ok = ok && q[i] > q[i - 1];
+            if (ok) pct = q;
+        }
         if (!two && (long long)tnum * pct[pct.size() > 1 ? 1 : 0] / 100 + halo < (long long)tnum * 9 / 10) {
             cut = {0};
             for (int q : pct) cut.push_back(r8((long long)tnum * q / 100));
@@ -3119,7 +3251,6 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
             cut = {0, r8((long long)tnum * 5 / 8), tnum};
         }
         const int nblk = (int)cut.size() - 1;
-        nlaunch = nblk;
         for (int i = 0; i < nblk; ++i)
             if (!c.ev_blk[i] && hipEventCreateWithFlags(&c.ev_blk[i], hipEventDisableTiming) != hipSuccess) {
                 c.ev_blk[i] = nullptr;
@@ -3128,6 +3259,13 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
             }
         char *dout = reinterpret_cast<char *>(c.dout.p);
         int have = 0;                                  // input traces [0, have) are on the device and prepared
+        std::string trace;                             // IMPDAR_TIMING: host time at which each stage's call returned
+        auto stamp = [&](const char *what, int i) {
+            if (!timing) return;
+            char buf[64];
+            snprintf(buf, sizeof buf, " %s%d %.2f", what, i, ms(t0b, now()));
+            trace += buf;
+        };
         for (int i = 0; i < nblk; ++i) {
             const int need = two ? tnum : (int)std::min<long long>(tnum, ((long long)cut[i + 1] + halo + 7) / 8 * 8);
             if (need > have) {
@@ -3142,9 +3280,11 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
                                           need - have, 0, have > 0)))
                     return done(rc);
                 have = need;
+                stamp("up", i);
             }
             if ((rc = impdar_kirch_migrate(p, dout + (size_t)snum * cut[i] * esz, cut[i], cut[i + 1]))) return done(rc);
             if (hipEventRecord(c.ev_blk[i], ctx->stream) != hipSuccess) return done(IMPDAR_ERR_HIP);
+            stamp("launch", i);
         }
         // the blocks leave on the producer stream (idle after the last prep) as their launches finish: all copies
         // enqueued at once, the host widens what has arrived
@@ -3159,36 +3299,32 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
             if ((rc = impdar_download_blocks_f64(ctx, out, (size_t)tnum, (size_t)snum, dtype, nblk, col0.data(), width.data(),
                                                  src.data(), c.ev_blk, ctx->aux)))
                 return done(rc);
+            stamp("down", nblk - 1);
         }
+        if (timing) fprintf(stderr, "impdar_kirchhoff pieces (ms since the first copy):%s\n", trace.c_str());
+        t1 = t1b = now();
     } else {
         if (hipMemcpyAsync(c.din.p, data, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) {      // prep runs on the aux stream
             impdar_set_error("H2D copy failed");
             return done(IMPDAR_ERR_HIP);
         }
+        t1 = t1b = now();
         if ((rc = impdar_kirch_prep(p, c.din.p, tnum, 0, tnum))) return done(rc);
         if ((rc = impdar_kirch_migrate(p, c.dout.p, 0, tnum))) return done(rc);
+        if (timing) {                                             // diagnostic only: the download below waits for the kernel anyway
+            (void)hipStreamSynchronize(ctx->stream);
+            t1b = now();
+        }
         // device -> pinned staging (in pieces) -> the caller's float64 array on several host threads
         // (mig_python.py:118 returns float64); waits for the diffraction sum on the compute stream
         if ((rc = impdar_dev_download_f64(ctx, out, c.dout.p, dtype, (size_t)snum * tnum))) return done(rc);
     }
-    // what this call did, for impdar_ctx_last_metrics (the downloads above have synchronised the streams)
-    float kms = -1.f;
-    {
-        float a = 0.f, b = 0.f, c2 = 0.f;
-        if (impdar_kirch_last_ms(p, &a, &b, &c2) == IMPDAR_OK) kms = c2;       // first launch's start to last launch's end
-        (void)hipGetLastError();
-    }
-    static const char *kernel_names[] = {"kirch_exact_kernel", "kirch_exact_tab_kernel", "kirch_dquad_kernel", "kirch_quad_kernel",
-                                         "kirch_tab_kernel", "kirch_gen_kernel"};
-    ctx->m_entry = "impdar_kirchhoff";
-    ctx->m_kernel = (kern >= 0 && kern < 6) ? kernel_names[kern] : "";
-    ctx->m_kernel_ms = kms;
-    ctx->timed = false;
     const auto t2 = now();
-    snprintf(ctx->m_extra, sizeof ctx->m_extra, "\"plan\": \"%s\", \"launches\": %d, \"plan_ms\": %.3f, \"call_ms\": %.3f",
-             hit ? "cached" : "new", nlaunch, ms(t0, t0b), ms(t0, t2));
     rc = done(IMPDAR_OK);
+    if (timing)
+        fprintf(stderr, "impdar_kirchhoff: %s, plan+alloc %.2f ms, H2D %.2f ms, prep+migrate %.2f ms, D2H+convert %.2f ms, release %.2f ms, call %.2f ms\n",
+                hit ? "cached plan" : "new plan", ms(t0, t0b), ms(t0b, t1), ms(t1, t1b), ms(t1b, t2), ms(t2, now()), ms(t0, now()));
     return rc;
 }
 

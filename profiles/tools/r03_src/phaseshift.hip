@@ -147,6 +147,15 @@ template <typename T> __device__ inline void sincos_t(T x, T *s, T *c);
 // about 20 VALU instructions, no slow path.
 template <> __device__ inline void sincos_t<float>(float x, float *s, float *c)
 {
+#ifdef IMPDAR_PS_HWSINCOS
+    // hardware v_sin_f32 / v_cos_f32 (argument in revolutions) + one Newton step back onto the
+    // unit circle, so the amplitude error does not compound over thousands of depth steps
+    const float r = x * 0.15915494309189535f;
+    float ss = __builtin_amdgcn_sinf(r), cc = __builtin_amdgcn_cosf(r);
+    const float k = fmaf(-0.5f, fmaf(cc, cc, ss * ss), 1.5f);
+    *s = ss * k;
+    *c = cc * k;
+#else
     const float q = rintf(x * 0.636619772f);
     float r = fmaf(q, -1.5707963705062866f, x);
     r = fmaf(q, 4.37113900018624283e-8f, r);
@@ -159,6 +168,7 @@ template <> __device__ inline void sincos_t<float>(float x, float *s, float *c)
     const float cc = (qi & 1) ? sp : cp;
     *s = (qi & 2) ? -ss : ss;
     *c = ((qi + 1) & 2) ? -cc : cc;
+#endif
 }
 template <> __device__ inline void sincos_t<double>(double x, double *s, double *c) { sincos(x, s, c); }
 
@@ -172,7 +182,19 @@ template <> __device__ inline void sincos_t<double>(double x, double *s, double 
 #endif
 constexpr int PS_ANCHOR = IMPDAR_PS_ANCHOR;
 
+#ifdef IMPDAR_PS_DIAG_STAMPS
+// diagnostics build: core-clock stamps of one workgroup's tiles 100..115 (5 points per tile, waves 0 and 7)
+__device__ long long ps_dbg_stamps[2 * 16 * 5];
+#define PS_STAMP(point) \
+    if (blockIdx.x == 300 && (tid == 0 || tid == 448) && tile >= 100 && tile < 116) \
+        ps_dbg_stamps[((tid ? 1 : 0) * 16 + (tile - 100)) * 5 + (point)] = (long long)__builtin_readcyclecounter();
+extern "C" int impdar_ps_debug_stamps(long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ps_dbg_stamps), sizeof(long long) * 2 * 16 * 5) == hipSuccess ? 0 : 1;
+}
+#else
 #define PS_STAMP(point)
+#endif
 
 struct PsParams {
     const void *F;          // [tnum][nt] complex
@@ -228,7 +250,11 @@ template <typename T> __device__ __forceinline__ Cp<T> ps_load_slot(const Cp<T> 
 // workgroup reduce at the same moment, so nothing hides it)
 template <typename T, int MASK> __device__ __forceinline__ T lane_xor(T v)
 {
+#ifdef IMPDAR_PS_DIAG_SHFL
+    constexpr bool DPP = false;
+#else
     constexpr bool DPP = true;
+#endif
     auto dpp32 = [](unsigned u) {
         unsigned x;
         if constexpr (MASK == 1) x = __builtin_amdgcn_update_dpp(0u, u, 0xB1, 0xf, 0xf, false);        // quad_perm:[1,0,3,2]
@@ -252,7 +278,11 @@ template <typename T, int MASK> __device__ __forceinline__ T lane_xor(T v)
 template <typename T, int HALF, int MASK, int NV>
 __device__ __forceinline__ void wrs_halve(T (&v)[NV], int lane)
 {
+#ifdef IMPDAR_PS_DIAG_SHFL
+    constexpr bool SWAP = false;
+#else
     constexpr bool SWAP = true;
+#endif
     if constexpr (SWAP && sizeof(T) == 4 && (MASK == 32 || MASK == 16)) {
         // gfx950 v_permlane32_swap / v_permlane16_swap: the upper half (odd rows) of the first operand trades places
         // with the lower half (even rows) of the second -- afterwards every lane holds the value it keeps and the one
@@ -627,6 +657,13 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
             }
         }
         // ---- sum over frequencies: wave butterfly, then across waves via LDS
+#ifdef IMPDAR_PS_DIAG_NOREDUCE
+        { T z = 0;
+#pragma unroll
+          for (int i = 0; i < 2 * PS_TT; ++i) z += acc[i];
+          if (z == (T)12345.678) reinterpret_cast<T *>(TK)[tile] = z;
+          continue; }
+#endif
         PS_STAMP(1)
         wave_reduce_scatter<T, 2 * PS_TT>(acc, lane);
         T (*buf)[2 * PS_TT] = red[tile & 1];
@@ -874,6 +911,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 && M == 8) ? IMPDAR_PS_VZ32_M8
             }
         }
         // ---- sum over frequencies: wave butterfly, then across waves via LDS
+#ifdef IMPDAR_PS_DIAG_NOREDUCE
+        { float z = 0;
+#pragma unroll
+          for (int i = 0; i < 2 * TT; ++i) z += acc[i];
+          if (z == 12345.678f) reinterpret_cast<float *>(TK)[tile] = z;
+          return; }
+#endif
         PS_STAMP(1)
         wave_reduce_scatter<float, 2 * TT>(acc, lane);
         float(*buf)[2 * TT] = red[tile & 1];
@@ -1281,32 +1325,29 @@ void impdar_ps_trim()
     }
 }
 
-static thread_local const char *t_ps_kernel = "";       // the frequency-sum kernel of the call in progress (metrics)
-
 template <typename T, int BLOCK, int M>
 static void ps_launch(const PsParams &P, hipStream_t st)
 {
     constexpr size_t vz32_lds = (size_t)M * BLOCK * 16 + 2 * (BLOCK / 64) * 32 * sizeof(float) + 2 * 32 * sizeof(float);
     if constexpr (sizeof(T) == 4 && vz32_lds <= 160 * 1024) {
-        if (P.vz_mode && P.sched) {
+        static const bool old_kernel = getenv("IMPDAR_PS_VZ_OLD") != nullptr;     // tuning knob: the per-step kernel
+        if (P.vz_mode && P.sched && !old_kernel) {
             auto k = ps_vz32_kernel<BLOCK, M>;
             (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vz32_lds);
             hipLaunchKernelGGL(k, dim3(P.nk), dim3(BLOCK), vz32_lds, st, P);
-            t_ps_kernel = "ps_vz32_kernel";
             return;
         }
     }
     constexpr size_t vz64_lds = (size_t)M * BLOCK * 8 + 2 * (BLOCK / 64) * 32 * sizeof(double) + 2 * 32 * sizeof(double);
     if constexpr (sizeof(T) == 8 && vz64_lds <= 160 * 1024 && M <= 16) {
-        if (P.vz_mode && P.sched && P.eps) {
+        static const bool old_kernel64 = getenv("IMPDAR_PS_VZ_OLD") != nullptr;
+        if (P.vz_mode && P.sched && P.eps && !old_kernel64) {
             auto k = ps_vz64_kernel<BLOCK, M>;
             (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vz64_lds);
             hipLaunchKernelGGL(k, dim3(P.nk), dim3(BLOCK), vz64_lds, st, P);
-            t_ps_kernel = "ps_vz64_kernel";
             return;
         }
     }
-    t_ps_kernel = P.vz_mode ? "ps_kernel (per step)" : "ps_kernel (constant velocity)";
     if (P.vz_mode)
         hipLaunchKernelGGL((ps_kernel<T, BLOCK, M, true>), dim3(P.nk), dim3(BLOCK), 0, st, P);
     else
@@ -1320,10 +1361,11 @@ static int ps_dispatch(const PsParams &P, hipStream_t st)
     // Workgroup shape.  "deep": 16 frequencies per lane and as few waves as that takes (the reduce-scatter and the
     // tile barrier are a fixed cost per wave and tile, the rotate-accumulate body scales with the frequencies per
     // lane; smaller workgroups also put two or more on a CU, so one's barrier wait overlaps another's body).
-    // "wide": 512 threads as soon as there are 512 frequencies (round 1-2 shape).
+    // "wide": 512 threads as soon as there are 512 frequencies (round 1-2 shape).  IMPDAR_PS_SHAPE=wide|deep.
+    const char *shape_env = getenv("IMPDAR_PS_SHAPE");
     // Measured at 8192^2 with the half walk (4096 frequencies per wavenumber; profiles/r03_ps_shapes.txt): float32 constant
     // v 35.0 (wide) / 41.6 (deep) ms, v(z) 43.4 / 44.9; float64 constant v 63.6 / 56.8, v(z) 72.6 / 70.7.
-    const bool deep = sizeof(T) == 8;
+    const bool deep = shape_env ? (strcmp(shape_env, "deep") == 0) : (sizeof(T) == 8);
     if (nt <= 64) ps_launch<T, 64, 1>(P, st);
     else if (nt <= 128) ps_launch<T, 128, 1>(P, st);
     else if (nt <= 256) ps_launch<T, 256, 1>(P, st);
@@ -1369,11 +1411,13 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
         for (int a0 = 0; a0 < ntile; a0 += 32) blocks.push_back(make_int2((int)r, a0));
     }
     const int nb = (int)blocks.size();
-    // limits of the matrix-core path: long runs, row padding (blocks x 2048 steps against the record), steps in short
-    // runs.  A row block costs ~2.4 ms at 8192^2 and the vector runs kernels ~40-50 ms for the whole record: 16 runs /
-    // 3 x padding is where the two meet (a 21-row table of equal layers: 44.5 -> 38.1 ms; profiles/r03_ps_layers.txt)
-    constexpr int max_long = 16, max_short = 200;
-    constexpr double max_pad = 3.0;
+    // limits of the matrix-core path (IMPDAR_PS_MFMA_LONG / _PAD / _SHORT override them for experiments): long runs, row
+    // padding (blocks x 2048 steps against the record), steps in short runs.  A row block costs ~2.4 ms at 8192^2 and the
+    // vector runs kernels ~40-50 ms for the whole record: 16 runs / 3 x padding is where the two meet (a 21-row table of
+    // equal layers: 44.5 -> 38.1 ms; 8 / 1.75 / 96 until late in round 3, profiles/r03_ps_layers.txt)
+    static const int max_long = getenv("IMPDAR_PS_MFMA_LONG") ? atoi(getenv("IMPDAR_PS_MFMA_LONG")) : 16;
+    static const double max_pad = getenv("IMPDAR_PS_MFMA_PAD") ? atof(getenv("IMPDAR_PS_MFMA_PAD")) : 3.0;
+    static const int max_short = getenv("IMPDAR_PS_MFMA_SHORT") ? atoi(getenv("IMPDAR_PS_MFMA_SHORT")) : 200;
     if (nb == 0 || nshort_steps > max_short || (int)runs.size() - (vz ? (int)std::count_if(runs.begin(), runs.end(), [](const PsMfmaRun &r) { return r.len <= PM_SHORT; }) : 0) > max_long) return IMPDAR_OK;
     if ((double)nb * 32 * PM_TT > (double)snum * max_pad + 32 * PM_TT) return IMPDAR_OK;      // many medium runs: rows mostly padding
     // groups of up to PM_NRB row blocks (the state tiles a workgroup keeps in LDS), consecutive blocks together
@@ -1384,37 +1428,46 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
         const int n = std::min(per_group, nb - at);
         for (int i = 0; i < n; ++i, ++at) table[(size_t)g * PM_NRB + i] = blocks[at];
     }
+    // IMPDAR_PS_MFMA_SPEC=1: the kernel with producer and consumer waves (ps_mfma_spec_kernel); its groups hold blocks of
+    // ONE run each
+    const char *spe = getenv("IMPDAR_PS_MFMA_SPEC");
+    const bool spec = spe && atoi(spe) != 0;
+    if (spec) {
+        table.clear();
+        for (int at = 0; at < nb;) {
+            int n = 1;
+            while (at + n < nb && n < PM_NRB && blocks[at + n].x == blocks[at].x) ++n;
+            // a run of 6+ blocks: near-equal groups
+            int same = n;
+            while (at + same < nb && blocks[at + same].x == blocks[at].x) ++same;
+            const int parts = (same + PM_NRB - 1) / PM_NRB;
+            n = std::min(n, (same + parts - 1) / parts);
+            const size_t base = table.size();
+            table.resize(base + PM_NRB, make_int2(-1, 0));
+            for (int i = 0; i < n; ++i) table[base + i] = blocks[at + i];
+            at += n;
+        }
+        ngroups = (int)(table.size() / PM_NRB);
+    }
     PsMfmaParams Q;
     Q.P = P;
     Q.nruns = (int)runs.size();
     for (int r = 0; r < Q.nruns; ++r) Q.runs[r] = runs[r];
     for (int r = Q.nruns; r < PM_MAX_RUNS; ++r) Q.runs[r] = PsMfmaRun{0.0, 0, 0};
     Q.ngroups = ngroups;
-    // The path's own buffers (runtab: 16 bytes per wavenumber, frequency and long run -- 8.6 GB for 16 runs at
-    // 8192 x 4096).  Not getting them is not an error: the vector kernels need none of it and take the call.
-    Q.nlong = 0;
-    for (int r = 0; r < PM_MAX_RUNS; ++r) Q.long_of[r] = -1;
-    for (int r = 0; r < Q.nruns; ++r)
-        if (!(vz && runs[r].len <= PM_SHORT)) Q.long_of[r] = Q.nlong++;
-    {
-        const size_t rt_bytes = (size_t)P.nk * P.nf * Q.nlong * sizeof(double2);
-        size_t free_b = 0, total_b = 0;
-        if (rt_bytes > pl.d_runtab.bytes && hipMemGetInfo(&free_b, &total_b) == hipSuccess && rt_bytes > free_b / 2) {
-            (void)hipGetLastError();
-            return IMPDAR_OK;                  // would take more than half of what is free: leave it to the vector kernels
-        }
-        if (pl.d_blocks.ensure(table.size() * sizeof(int2)) != hipSuccess ||
-            pl.d_edge.ensure((size_t)tnum * (1 + PM_EMAX) * sizeof(int)) != hipSuccess || pl.d_runtab.ensure(rt_bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            return IMPDAR_OK;
-        }
-    }
+    IMPDAR_HIP_CHECK(pl.d_blocks.ensure(table.size() * sizeof(int2)));
     IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_blocks.p, table.data(), table.size() * sizeof(int2), hipMemcpyHostToDevice, st));
     Q.blocks = pl.d_blocks.as<int2>();
+    IMPDAR_HIP_CHECK(pl.d_edge.ensure((size_t)tnum * (1 + PM_EMAX) * sizeof(int)));
     Q.edge_cnt = pl.d_edge.as<int>();
     Q.edge_list = Q.edge_cnt + tnum;
     if (vz) IMPDAR_HIP_CHECK(hipMemsetAsync(Q.edge_cnt, 0, (size_t)tnum * sizeof(int), st));
     Q.vz = vz ? 1 : 0;
+    Q.nlong = 0;
+    for (int r = 0; r < PM_MAX_RUNS; ++r) Q.long_of[r] = -1;
+    for (int r = 0; r < Q.nruns; ++r)
+        if (!(vz && runs[r].len <= PM_SHORT)) Q.long_of[r] = Q.nlong++;
+    IMPDAR_HIP_CHECK(pl.d_runtab.ensure((size_t)P.nk * P.nf * Q.nlong * sizeof(double2)));
     Q.runtab = pl.d_runtab.as<double2>();
     {
         // set-up pass: per-run phases of every (wavenumber, frequency), boundary frequencies, the steps of the short runs
@@ -1423,23 +1476,36 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
         else if (P.nf <= 4096) hipLaunchKernelGGL(ps_setup_kernel<8>, dim3(P.nk), dim3(512), lds, st, Q);
         else hipLaunchKernelGGL(ps_setup_kernel<12>, dim3(P.nk), dim3(512), lds, st, Q);
     }
-    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PM_LDS_BYTES));
-    hipLaunchKernelGGL(ps_mfma_kernel, dim3((unsigned)P.nk * Q.ngroups), dim3(PM_WAVES * 64), PM_LDS_BYTES, st, Q);
+    Q.stamps = nullptr;
+    DevBuf d_stamps;
+    const bool want_stamps = getenv("IMPDAR_PS_STAMPS") != nullptr;       // diagnostics: phase stamps of one workgroup on stderr
+    if (want_stamps && d_stamps.ensure(16 * PM_WAVES * 6 * sizeof(long long)) == hipSuccess) {
+        IMPDAR_HIP_CHECK(hipMemsetAsync(d_stamps.p, 0, 16 * PM_WAVES * 6 * sizeof(long long), st));
+        Q.stamps = d_stamps.as<long long>();
+    }
+    // (diagnostics: IMPDAR_PS_MFMA_ONE_WG=1 asks for 100 KB of LDS, i.e. one workgroup per CU instead of two)
+    const size_t lds_bytes = getenv("IMPDAR_PS_MFMA_ONE_WG") ? std::max<size_t>(PM_LDS_BYTES, 100 * 1024) : PM_LDS_BYTES;
+    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (spec) {
+        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_mfma_spec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)PS_SPEC_LDS_BYTES));
+        hipLaunchKernelGGL(ps_mfma_spec_kernel, dim3((unsigned)P.nk * Q.ngroups), dim3(PS_SPEC_WAVES * 64), PS_SPEC_LDS_BYTES, st, Q);
+    } else {
+        hipLaunchKernelGGL(ps_mfma_kernel, dim3((unsigned)P.nk * Q.ngroups), dim3(PM_WAVES * 64), lds_bytes, st, Q);
+    }
     if (vz) hipLaunchKernelGGL(ps_edge_kernel, dim3(P.nk), dim3(256), 0, st, Q);
     IMPDAR_HIP_CHECK(hipGetLastError());
     // the host table must outlive its async copy
     IMPDAR_HIP_CHECK(hipStreamSynchronize(st));
-    if (vz) {
-        // ps_setup_kernel takes every boundary frequency out of the matrix-core sums but lists only the first PM_EMAX per
-        // wavenumber for ps_edge_kernel (more needs a table of many runs on a rational grid).  The counter keeps
-        // counting: an overflow means contributions are missing from TK -- the result is discarded and the vector
-        // kernels, which walk every boundary frequency themselves, produce it.
-        std::vector<int> cnt((size_t)P.nk);
-        IMPDAR_HIP_CHECK(hipMemcpy(cnt.data(), Q.edge_cnt + P.k0, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
-        int worst = 0;
-        for (int c : cnt) worst = std::max(worst, c);
-        const bool force_overflow = getenv("IMPDAR_PS_TEST_EDGE_OVERFLOW") != nullptr;      // test hook (read per call)
-        if (worst > PM_EMAX || force_overflow) return IMPDAR_OK;           // *done stays false
+    if (Q.stamps) {
+        std::vector<long long> h(16 * PM_WAVES * 6);
+        IMPDAR_HIP_CHECK(hipMemcpy(h.data(), d_stamps.p, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        for (int r = 0; r < 16; ++r)
+            for (int wv = 0; wv < PM_WAVES; ++wv) {
+                const long long *t = &h[(r * PM_WAVES + wv) * 6];
+                fprintf(stderr, "ps_mfma stamps round %2d wave %d: state tile %lld, step factors %lld, barrier %lld, mfma %lld, barrier %lld | round %lld\n",
+                        r, wv, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]);
+            }
     }
     *done = true;
     return IMPDAR_OK;
@@ -1487,6 +1553,9 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
                                                 1.0 / tnum, st)))
             return rc;
         IMPDAR_HIP_CHECK(pl.X.ensure((size_t)tnum * nt * 2 * sizeof(T)));
+        // (TK doubles as the scratch of the transposed forward transform: nt / 2 + 1 rows of tnum -- more than snum rows
+        // when the caller pads the time axis beyond the next power of two)
+        IMPDAR_HIP_CHECK(pl.TK.ensure((size_t)tnum * std::max(snum, nt / 2 + 1) * 2 * sizeof(T)));
         IMPDAR_HIP_CHECK(pl.d_kx.ensure((size_t)tnum * 8));
         IMPDAR_HIP_CHECK(pl.d_w.ensure((size_t)nt * 8));
         IMPDAR_HIP_CHECK(pl.d_vz.ensure((size_t)snum * 8));
@@ -1535,14 +1604,6 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     const int fstride = herm ? nt / 2 + 1 : nt;
     if (herm) {
         w[0] = ws[nt / 2];                  // slot order: Nyquist first, then rows 1..nt/2-1 (already in place)
-    }
-    {
-        // TK: the frequency sums [tnum][snum] of an unsharded call, and the scratch of the transposed forward transform
-        // (nt / 2 + 1 rows of tnum -- more than snum rows when the caller pads the time axis beyond the next power of
-        // two).  A rank of a kx-sharded run writes its sums to the caller's slab: it only needs the scratch.
-        const size_t scratch_rows = (herm && pl.rows_form) ? (size_t)(nt / 2 + 1) : 0;
-        const size_t rows = tk_out ? scratch_rows : std::max<size_t>((size_t)snum, scratch_rows);
-        if (rows) IMPDAR_HIP_CHECK(pl.TK.ensure((size_t)tnum * rows * 2 * sizeof(T)));
     }
     {
         int rc;
@@ -1621,7 +1682,10 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     P.nf = nf;
     P.herm = herm ? 1 : 0;
     P.vz_mode = vlen ? 1 : 0;
-    P.vtol = dbl ? 1e-11 : 1e-10;
+    {
+        const char *e = getenv("IMPDAR_PS_VTOL");     // diagnostic knob
+        P.vtol = e ? atof(e) : (dbl ? 1e-11 : 1e-10);
+    }
     P.sched = P.tsched = P.rowmap = nullptr;
     P.eps = nullptr;
     std::vector<int> sched, rowmap;
@@ -1653,8 +1717,9 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         // per-step kernel is faster for float32 (2048^2, 40 / 80 / 160 layers: 4.6 / 7.5 / 12.2 ms against
         // 5.5 / 6.8 / 9.5 ms); the float64 runs kernel stays ahead until every tile holds a change (10.1 / 16.6 /
         // 27.5 ms against 26.4 ms throughout: its per-step tiles pay the square root and sincos at the changes
-        // only).  profiles/tools/ps_dirty.py.
-        const double dirty_max = dbl ? 0.9 : 0.5;
+        // only).  profiles/tools/ps_dirty.py; IMPDAR_PS_DIRTY_MAX overrides the share.
+        const char *dm = getenv("IMPDAR_PS_DIRTY_MAX");
+        const double dirty_max = dm ? atof(dm) : (dbl ? 0.9 : 0.5);
         bool vfinite = true;                // a velocity profile with NaN / inf entries takes the per-step kernel
         for (int i = 0; i < snum; ++i) vfinite = vfinite && std::isfinite(vmig[i]) && vmig[i] != 0.0;
         if (vfinite && ((double)ndirty <= dirty_max * ntile || snum <= 64)) {
@@ -1746,10 +1811,6 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     }
     if (sizeof(T) == 4 && !mfma_done && P.sched && (rc = order_rows())) return rc;
     if (!mfma_done && (rc = ps_dispatch<T>(P, st))) return rc;
-    ctx->m_entry = tk_out ? "impdar_phaseshift_tk_dev" : "impdar_phaseshift";
-    ctx->m_kernel = mfma_done ? "ps_mfma_kernel" : t_ps_kernel;
-    ctx->m_kernel_ms = -1.f;                 // (bracketed by ktic / ktoc)
-    snprintf(ctx->m_extra, sizeof ctx->m_extra, "\"hermitian_walk\": %s, \"frequencies\": %d", herm ? "true" : "false", nf);
     if (herm)
         for (int kz : k_zero)
             if (kz >= k0 && kz < k0 + nk)
@@ -2480,11 +2541,6 @@ extern "C" int impdar_phaseshift_ffd(impdar_ctx *ctx, const double *data, int sn
         IMPDAR_HIP_CHECK(hipGetLastError());
         IMPDAR_HIP_CHECK(hipMemcpyAsync(out, dout.p, nreal * 8, hipMemcpyDeviceToHost, st));
         IMPDAR_HIP_CHECK(hipStreamSynchronize(st));      // the staging vectors above live until here
-        ctx->m_entry = "impdar_phaseshift_ffd";
-        ctx->m_kernel = "ffd_chain_kernel";
-        ctx->m_kernel_ms = -1.f;
-        ctx->timed = ctx->ktimed = false;
-        ctx->m_extra[0] = 0;
         return IMPDAR_OK;
     }
 
@@ -2540,11 +2596,6 @@ extern "C" int impdar_phaseshift_ffd(impdar_ctx *ctx, const double *data, int sn
     IMPDAR_HIP_CHECK(hipGetLastError());
     IMPDAR_HIP_CHECK(hipMemcpyAsync(out, dout.p, nreal * 8, hipMemcpyDeviceToHost, st));
     IMPDAR_HIP_CHECK(hipStreamSynchronize(st));
-    ctx->m_entry = "impdar_phaseshift_ffd";
-    ctx->m_kernel = "ffd_post_pre + rocFFT + ffd_mid per (step, frequency)";
-    ctx->m_kernel_ms = -1.f;
-    ctx->timed = ctx->ktimed = false;
-    ctx->m_extra[0] = 0;
     return IMPDAR_OK;
 }
 
@@ -2569,10 +2620,5 @@ extern "C" int impdar_taper(impdar_ctx *ctx, void *data_inout, int dtype, int sn
     IMPDAR_HIP_CHECK(hipGetLastError());
     IMPDAR_HIP_CHECK(hipMemcpyAsync(data_inout, d.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     IMPDAR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    ctx->m_entry = "impdar_taper";
-    ctx->m_kernel = "ps_taper_inplace";
-    ctx->m_kernel_ms = -1.f;
-    ctx->timed = ctx->ktimed = false;
-    ctx->m_extra[0] = 0;
     return IMPDAR_OK;
 }

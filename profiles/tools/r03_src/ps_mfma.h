@@ -91,6 +91,7 @@ struct PsMfmaParams {
     int nlong;
     int long_of[PM_MAX_RUNS];   // run -> index among the long runs (-1: short)
     int vz;
+    long long *stamps;      // diagnostics (IMPDAR_PS_STAMPS): [16 rounds][4 waves][6] cycle stamps of one workgroup, or null
 };
 
 // coss = 1 - (0.5 v kx / w)^2 (mig_python.py:456) with the division by w as a multiplication by rw = 1/w: one
@@ -128,11 +129,29 @@ __device__ __forceinline__ void pm_sincos(double x, float *s, float *c)
     *c = fmaf(-sh, xl, ch);
 }
 
+// Timing-only ablations for profiles/tools/variant_build.sh (SRC=phaseshift): results are WRONG with any of them set.
+//   PM_ABL_NOSTATE  no state tiles    PM_ABL_NOB  no step-factor tiles    PM_ABL_NOMFMA  operand reads, no MFMAs
+//   PM_ABL_NOREAD   MFMAs on whatever the operand registers hold, no LDS reads in the product phase
+//   PM_ABL_NOBAR    no workgroup barriers in the round loop    PM_ABL_NOLOAD  no spectrum / run-table loads in the round loop (and what depends on them
+//   is hoisted: not a measure of the loads)    PM_ABL_HOTLOAD  the loads of every round hit the same cached entries
+#ifndef PM_LDSBAR
+#define PM_LDSBAR 0       // 1: the round loop barriers wait for LDS only, not for the global loads in flight (measured: no difference)
+#endif
+#ifndef PM_FUSEGEN
+#define PM_FUSEGEN 1      // phase 1 as one straight-line loop over three independent recurrences (0: the separate loops)
+#endif
+#ifndef PM_BPIPE
+#define PM_BPIPE 0        // 1: the next step-factor tile is generated in slices between the MFMAs of the current run (measured: no gain, profiles/r03_ps_mfma_ablation2.txt)
+#endif
+#ifndef PM_FMAMIX
+#define PM_FMAMIX 1         // residuals by v_fma_mix_f32 (float16 half x -1 + float32, one instruction) instead of convert + subtract
+#endif
 // (x, y) -> the float16 pair nearest towards zero as one dword, and what is left of x and y
 __device__ __forceinline__ unsigned pm_split(float x, float y, float *rx, float *ry)
 {
     const auto h = __builtin_amdgcn_cvt_pkrtz(x, y);
     const unsigned hb = __builtin_bit_cast(unsigned, h);
+#if PM_FMAMIX
     // x - (float)h.lo and y - (float)h.hi, each one mixed-precision fma: the float16 half is source 0 (op_sel_hi bit 0),
     // its low or high word picked by op_sel bit 0
     const float m1 = -1.0f;
@@ -141,6 +160,10 @@ __device__ __forceinline__ unsigned pm_split(float x, float y, float *rx, float 
     asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(b) : "v"(hb), "v"(m1), "v"(y));
     *rx = a;
     *ry = b;
+#else
+    *rx = __builtin_fmaf((float)h[0], -1.0f, x);
+    *ry = __builtin_fmaf((float)h[1], -1.0f, y);
+#endif
     return hb;
 }
 __device__ __forceinline__ unsigned pm_pack(float x, float y) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, y)); }
@@ -154,7 +177,11 @@ __device__ __forceinline__ unsigned pm_swap(unsigned h) { return __builtin_amdgc
 // arrives, but its global loads stay in flight (__syncthreads() also waits for those, vmcnt 0).  Tried because the
 // loads of a round always hitting the same cached entries (PM_ABL_HOTLOAD) made the kernel 14 % faster; this barrier
 // changed nothing, so that gain is the data's (the same low, mostly evanescent frequencies every round), not the loads'.
+#if PM_LDSBAR
+__device__ __forceinline__ void pm_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#else
 __device__ __forceinline__ void pm_lds_barrier() { __syncthreads(); }
+#endif
 
 __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_kernel(PsMfmaParams Q)
 {
@@ -242,6 +269,32 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
         }
     };
 
+    // The same in slices, for generating the NEXT step-factor tile underneath the products of the current run
+    // (PM_BPIPE): the tile's LDS scratch is free once the current run's factors sit in registers (bh / bl below), the
+    // matrix pipe works for 32 cycles per MFMA, and the vector instructions of a slice issue in between.
+    float gb_e2s = 0.f, gb_e2c = 1.f, gb_bs = 0.f, gb_bc = 0.f;
+    auto B_begin = [&](double inc) {
+        pm_sincos(pm_wrap((double)PM_NSUB * inc), &gb_e2s, &gb_e2c);
+        pm_sincos(pm_wrap((double)(16 * part + hh + 1) * inc), &gb_bs, &gb_bc);
+        gb_bs *= 256.f;
+        gb_bc *= 256.f;
+    };
+    auto B_row = [&](int j) {
+        float rc, rs;
+        const unsigned h0 = pm_split(gb_bc, gb_bs, &rc, &rs), l0 = pm_pack(rc, rs);
+        const int o = 64 * j + wx[j % PM_NSLOT];
+        Bhi[o] = pm_conj(h0);
+        Bhi[o + 16 * PM_ROW] = pm_swap(h0);
+        Blo[o] = pm_conj(l0);
+        Blo[o + 16 * PM_ROW] = pm_swap(l0);
+        const float nc = fmaf(gb_bc, gb_e2c, -(gb_bs * gb_e2s)), ns = fmaf(gb_bc, gb_e2s, gb_bs * gb_e2c);
+        gb_bc = nc;
+        gb_bs = ns;
+    };
+    (void)B_begin;
+    (void)B_row;
+    static_assert((PM_CH == 32 && 16 / PM_NSUB <= 9) || !PM_BPIPE, "three K-steps of three rows carry the rows of a step-factor tile");
+
     const int nchunk = P.nf / PM_CH;        // a multiple of PM_NQ (host): every wave makes the same number of rounds
     // long-run index of every row block (ps_setup_kernel's table)
     int blong[PM_NRB];
@@ -253,7 +306,14 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
     double2 t_next[PM_NRB];
 #pragma unroll
     for (int rb = 0; rb < PM_NRB; ++rb) t_next[rb] = tab[(size_t)(q * PM_CH + om) * Q.nlong + blong[rb]];
+#if PM_BPIPE
+    if (brun[0] >= 0) gen_B(t_next[0].x);                                     // the first round's first run
+#endif
+#define PM_STAMP(pt) \
+    if (Q.stamps && blockIdx.x == gridDim.x / 2 && lane == 0 && c >= 32 && c < 48) \
+        Q.stamps[((c - 32) * PM_WAVES + wave) * 6 + (pt)] = (long long)__builtin_readcyclecounter();
     for (int c = q; c < nchunk; c += PM_NQ) {
+        PM_STAMP(0)
         const float f0r = f_next.x * sigma, f0i = f_next.y * sigma;
         double incs[PM_NRB], phis[PM_NRB];
 #pragma unroll
@@ -261,12 +321,20 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
             incs[rb] = t_next[rb].x;
             phis[rb] = t_next[rb].y;
         }
+#ifndef PM_ABL_NOLOAD
         {
+#ifdef PM_ABL_HOTLOAD
+            int sn = q * PM_CH + om;                      // the same (cached) entries every round; opaque, so nothing is hoisted
+            asm volatile("" : "+v"(sn));
+#else
             const int sn = min(c + PM_NQ, nchunk - 1) * PM_CH + om;
+#endif
             f_next = ps_load_slot<float>(Frow, P, sn);
 #pragma unroll
             for (int rb = 0; rb < PM_NRB; ++rb) t_next[rb] = tab[(size_t)sn * Q.nlong + blong[rb]];
         }
+#endif
+#if PM_FUSEGEN && !defined(PM_ABL_NOSTATE) && !defined(PM_ABL_NOB) && !PM_BPIPE
         // ---- phase 1, fused: the state tile of this wave's own block as TWO recurrences (rows 0..15 and 16..31 of the tile,
         // each from its own float64-phase anchor) and the step-factor tile, advanced together in one straight-line loop.
         // A wave's vector instructions issue ~7 cycles apart when each depends on the one before and 4 apart when they
@@ -352,7 +420,66 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
                     }
                 }
         }
+        PM_STAMP(1)
+#else
+        // ---- phase 1: this wave's state tile(s); the step factors of the first run
+#pragma unroll
+        for (int rb = 0; rb < PM_NRB; ++rb) {
+            if (brun[rb] < 0) continue;                                       // uniform
+            // block rb < 4: all 32 rows by the waves of part rb; the fifth block: a quarter of the rows by every part (with
+            // it on part 0 alone that wave generated two tiles a round and the other three waited at the barrier)
+            const bool whole = rb == part, quarter = rb == PM_NP;
+#ifdef PM_ABL_NOSTATE
+            if (false) {
+#else
+            if (whole || quarter) {
+#endif
+                // rows hh, hh + PM_NSUB, ... = tiles a0 + row of 64 steps each: anchor with the float64 phase, then
+                // S *= e^{i 64 PM_NSUB inc} from row to row; a frequency that is out of this run (NaN start phase) contributes zeros
+                constexpr int NJ = 32 / PM_NSUB, NJQ = NJ / PM_NP;
+                const int j0 = quarter ? NJQ * part : 0;
+                const double inc = incs[rb];
+                const bool in = phis[rb] == phis[rb];
+                float s, cph, Es, Ec;
+                pm_sincos(pm_wrap((in ? phis[rb] : 0.0) + (double)(PM_TT * (ba0[rb] + PM_NSUB * j0 + hh)) * inc), &s, &cph);
+                pm_sincos(pm_wrap((double)(PM_NSUB * PM_TT) * inc), &Es, &Ec);
+                const float gr = in ? f0r : 0.f, gi = in ? f0i : 0.f;
+                float sr = fmaf(gr, cph, -(gi * s)), si = fmaf(gr, s, gi * cph);
+                unsigned *Ahi = Aq + (size_t)rb * 2 * PM_TILE, *Alo = Ahi + PM_TILE;
+                auto row = [&](int j) {
+                    float rr, ri;
+                    const int o = 64 * j + wx[j % PM_NSLOT];
+                    Ahi[o] = pm_split(sr, si, &rr, &ri);
+                    Alo[o] = pm_pack(rr, ri);
+                    const float nr = fmaf(sr, Ec, -(si * Es)), ni = fmaf(sr, Es, si * Ec);
+                    sr = nr;
+                    si = ni;
+                };
+                if (whole) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) row(j);
+                } else {
+                    // (the quarter is uniform per wave but not a compile-time constant: unrolled over the four parts so that
+                    // the slot pattern wx[j % PM_NSLOT] keeps constant indices)
+#pragma unroll
+                    for (int p4 = 0; p4 < PM_NP; ++p4)
+                        if (p4 == part) {                                     // uniform
+#pragma unroll
+                            for (int jj = 0; jj < NJQ; ++jj) row(NJQ * p4 + jj);
+                        }
+                }
+            }
+        }
+        PM_STAMP(1)
+#if !defined(PM_ABL_NOB) && !PM_BPIPE
+        if (brun[0] >= 0) gen_B(incs[0]);
+#endif
+#endif
+        PM_STAMP(2)
+#ifndef PM_ABL_NOBAR
         pm_lds_barrier();           // the half's state tiles are complete
+#endif
+        PM_STAMP(3)
         // ---- phase 2: every row block of the group against this wave's 16 steps: 32 frequencies = 4 K-steps of 8.  The
         // operands of step s + 1 are read while the three MFMAs of step s run (a read-wait-compute sequence per step
         // left the matrix pipe idle for an LDS round trip sixteen times a round).
@@ -365,11 +492,34 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
         for (int rb = 0; rb < PM_NRB; ++rb) {
             const int run = brun[rb];
             if (run < 0) continue;                                            // uniform
+#if !PM_BPIPE
             if (rb > 0 && brun[rb - 1] != run) {
                 __builtin_amdgcn_wave_barrier();
+#ifndef PM_ABL_NOB
                 gen_B(incs[rb]);                                              // another run: other step factors
+#endif
             }
+#endif
             __builtin_amdgcn_wave_barrier();
+            // PM_BPIPE: at the first block of a run the scratch holds this run's factors (made during the previous run's
+            // products, or the previous round's); once they are in registers the NEXT tile -- the group's next run, or the
+            // first run of the next round -- is generated in slices behind the MFMAs of this block
+            const bool run_start = rb == 0 || brun[rb - 1] != run;            // uniform
+            double inc_nextB = 0.0;
+            bool pipe_here = false;
+            (void)run_start;
+            (void)inc_nextB;
+            (void)pipe_here;
+#if PM_BPIPE && !defined(PM_ABL_NOB)
+            if (run_start) {
+                pipe_here = true;
+                inc_nextB = t_next[0].x;                                      // no later run in the group: next round's first
+#pragma unroll
+                for (int r2 = PM_NRB - 1; r2 > rb; --r2)
+                    if (brun[r2] >= 0 && brun[r2] != brun[r2 - 1]) inc_nextB = incs[r2];   // the FIRST change after rb wins
+            }
+#endif
+#ifndef PM_ABL_NOREAD
             if (rb == 0 || brun[rb - 1] != run) {
 #pragma unroll
                 for (int s = 0; s < PM_CH / 8; ++s) {
@@ -378,23 +528,57 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
                     bl[s] = *reinterpret_cast<const uint4 *>(Blo + o);
                 }
             }
+#else
+            if (rb == 0 && c == q)
+#pragma unroll
+                for (int s = 0; s < PM_CH / 8; ++s) bh[s] = bl[s] = make_uint4(lane, s, lane, s);
+#endif
             const unsigned *Ahi = Aq + (size_t)rb * 2 * PM_TILE, *Alo = Ahi + PM_TILE;
+#ifndef PM_ABL_NOREAD
             uint4 ra_hi = *reinterpret_cast<const uint4 *>(Ahi + rd0), ra_lo = *reinterpret_cast<const uint4 *>(Alo + rd0);
+#else
+            uint4 ra_hi = make_uint4(lane, rb, lane, rb), ra_lo = ra_hi;
+            (void)Ahi;
+            (void)Alo;
+#endif
 #pragma unroll
             for (int s = 0; s < PM_CH / 8; ++s) {
                 const pm_half8 a_hi = __builtin_bit_cast(pm_half8, ra_hi), a_lo = __builtin_bit_cast(pm_half8, ra_lo);
                 const pm_half8 b_hi = __builtin_bit_cast(pm_half8, bh[s]), b_lo = __builtin_bit_cast(pm_half8, bl[s]);
+#ifndef PM_ABL_NOREAD
                 if (s + 1 < PM_CH / 8) {
                     const int o = rd0 ^ (8 * (s + 1));
                     ra_hi = *reinterpret_cast<const uint4 *>(Ahi + o);
                     ra_lo = *reinterpret_cast<const uint4 *>(Alo + o);
                 }
+#endif
+#ifndef PM_ABL_NOMFMA
                 acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[rb], 0, 0, 0);
                 acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[rb], 0, 0, 0);
                 acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[rb], 0, 0, 0);
+#else
+                // keep the operand reads alive
+                asm volatile("" ::"v"(a_hi), "v"(a_lo), "v"(b_hi), "v"(b_lo));
+#endif
+#if PM_BPIPE && !defined(PM_ABL_NOB)
+                if (pipe_here) {                                              // uniform
+                    // slices of the next step-factor tile: the two sincos behind the first K-step's MFMAs, three rows
+                    // behind each of the others
+                    if (s == 0) {
+                        B_begin(inc_nextB);
+                    } else {
+#pragma unroll
+                        for (int j = 3 * (s - 1); j < 3 * s && j < 16 / PM_NSUB; ++j) B_row(j);
+                    }
+                }
+#endif
             }
         }
+        PM_STAMP(4)
+#ifndef PM_ABL_NOBAR
         pm_lds_barrier();           // ... and read by everybody before the next round overwrites them
+#endif
+        PM_STAMP(5)
     }
 
     // ---- every wave owns its sums outright (all frequencies of its 16 steps): TK /= snum (:492) and store.
@@ -415,6 +599,200 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same sum with SPECIALISED waves (round 3, late; IMPDAR_PS_MFMA_SPEC=1).  profiles/r03_ps_mfma_ablation2.txt: in
+// ps_mfma_kernel the generation of the tiles, the products and the rest ADD UP (3.05 + 3.2 + 1.8 ms at constant
+// velocity): the two workgroups of a CU run in step, nothing of one hides under the other.  Here one workgroup of
+// eight waves owns the CU: waves 4..7 (producers) generate the state and step-factor tiles of round r + 1 into the other
+// of two tile sets while waves 0..3 (consumers) multiply round r -- one producer and one consumer per SIMD, the vector
+// pipe and the matrix pipe busy at the same time by construction, one barrier a round.  144 KB of LDS (two sets of
+// five state tiles + four step-factor tiles, hi and lo halves).  All row blocks of a group belong to ONE run (the host
+// forms the groups that way for this kernel): one step-factor tile per part and round.
+// ---------------------------------------------------------------------------
+constexpr int PS_SPEC_WAVES = 8;
+constexpr size_t PS_SPEC_SET = ((size_t)PM_NRB * 2 + (size_t)PM_NP * 2) * PM_TILE;      // dwords per tile set
+constexpr size_t PS_SPEC_LDS_BYTES = 2 * PS_SPEC_SET * 4 + 64;
+
+__global__ __launch_bounds__(PS_SPEC_WAVES * 64, 1) void ps_mfma_spec_kernel(PsMfmaParams Q)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned pm_lds[];
+    const PsParams &P = Q.P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= PM_NP;               // uniform per wave
+    const int part = wave & (PM_NP - 1);
+    const int g = (int)blockIdx.x % Q.ngroups, kb = (int)blockIdx.x / Q.ngroups, k = P.k0 + kb;
+    const int om = lane % PM_CH, hh = lane / PM_CH;
+    const Cp<float> *Frow = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.fstride;
+    float *TKrow = reinterpret_cast<float *>(reinterpret_cast<Cp<float> *>(P.TK) + (size_t)kb * P.snum);
+
+    float sigma;
+    {
+        float m = 0.f;
+        for (int slot = tid; slot < P.nf; slot += PS_SPEC_WAVES * 64) {
+            const Cp<float> f = ps_load_slot<float>(Frow, P, slot);
+            m = fmaxf(m, fmaxf(fabsf(f.x), fabsf(f.y)));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float *mx = reinterpret_cast<float *>(pm_lds);
+        if (lane == 0) mx[wave] = m;
+        __syncthreads();
+        m = mx[0];
+#pragma unroll
+        for (int i = 1; i < PS_SPEC_WAVES; ++i) m = fmaxf(m, mx[i]);
+        __syncthreads();
+        int e = 0;
+        (void)frexpf(m, &e);
+        sigma = (m > 0.f && m < 3.0e38f) ? ldexpf(1.0f, 12 - e) : 1.0f;
+    }
+
+    int wx[PM_NSLOT];
+#pragma unroll
+    for (int m = 0; m < PM_NSLOT; ++m) wx[m] = PM_ROW * hh + (om ^ (4 * m));
+    const int rd0 = (lane & 31) * PM_ROW + ((4 * (lane >> 5)) ^ (4 * (((lane & 31) / PM_NSUB) % PM_NSLOT)));
+
+    int brun[PM_NRB], ba0[PM_NRB];
+#pragma unroll
+    for (int rb = 0; rb < PM_NRB; ++rb) {
+        const int2 d = Q.blocks[(size_t)g * PM_NRB + rb];
+        brun[rb] = __builtin_amdgcn_readfirstlane(d.x);
+        ba0[rb] = __builtin_amdgcn_readfirstlane(d.y);
+    }
+    const int run = brun[0];                            // the group's run (host: every block of the group)
+    const int L = run >= 0 ? Q.long_of[run] : 0;
+    const int nchunk = P.nf / PM_CH;
+    const double2 *tab = Q.runtab + (size_t)kb * P.nf * Q.nlong;
+
+    if (producer) {
+        // ---- tiles of round c into set c & 1: state tile of block `part` (and a quarter of the fifth), step factors of part `part`
+        Cp<float> f_next = ps_load_slot<float>(Frow, P, om);
+        double2 t_next = tab[(size_t)om * Q.nlong + L];
+        for (int c = 0; c <= nchunk; ++c) {
+            if (c < nchunk) {
+                unsigned *set = pm_lds + (size_t)(c & 1) * PS_SPEC_SET;
+                unsigned *Bhi = set + (size_t)PM_NRB * 2 * PM_TILE + (size_t)part * 2 * PM_TILE, *Blo = Bhi + PM_TILE;
+                const float f0r = f_next.x * sigma, f0i = f_next.y * sigma;
+                const double inc = t_next.x, phi = t_next.y;
+                {
+                    const int sn = min(c + 1, nchunk - 1) * PM_CH + om;
+                    f_next = ps_load_slot<float>(Frow, P, sn);
+                    t_next = tab[(size_t)sn * Q.nlong + L];
+                }
+                const bool in = phi == phi;
+                float Es, Ec;
+                pm_sincos(pm_wrap((double)(PM_NSUB * PM_TT) * inc), &Es, &Ec);
+                const float gr = in ? f0r : 0.f, gi = in ? f0i : 0.f;
+#pragma unroll
+                for (int rb = 0; rb < PM_NRB; ++rb) {
+                    if (brun[rb] < 0) continue;                               // uniform
+                    const bool whole = rb == part, quarter = rb == PM_NP;
+                    if (!(whole || quarter)) continue;
+                    constexpr int NJ = 32 / PM_NSUB, NJQ = NJ / PM_NP;
+                    const int j0 = quarter ? NJQ * part : 0;
+                    float s, cph;
+                    pm_sincos(pm_wrap((in ? phi : 0.0) + (double)(PM_TT * (ba0[rb] + PM_NSUB * j0 + hh)) * inc), &s, &cph);
+                    float sr = fmaf(gr, cph, -(gi * s)), si = fmaf(gr, s, gi * cph);
+                    unsigned *Ahi = set + (size_t)rb * 2 * PM_TILE, *Alo = Ahi + PM_TILE;
+                    auto row = [&](int j) {
+                        float rr, ri;
+                        const int o = 64 * j + wx[j % PM_NSLOT];
+                        Ahi[o] = pm_split(sr, si, &rr, &ri);
+                        Alo[o] = pm_pack(rr, ri);
+                        const float nr = fmaf(sr, Ec, -(si * Es)), ni = fmaf(sr, Es, si * Ec);
+                        sr = nr;
+                        si = ni;
+                    };
+                    if (whole) {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) row(j);
+                    } else {
+#pragma unroll
+                        for (int p4 = 0; p4 < PM_NP; ++p4)
+                            if (p4 == part) {                                 // uniform
+#pragma unroll
+                                for (int jj = 0; jj < NJQ; ++jj) row(NJQ * p4 + jj);
+                            }
+                    }
+                }
+                if (run >= 0) {
+                    // step factors b = 16 part + hh + PM_NSUB j of the 64-step tile (see ps_mfma_kernel's gen_B)
+                    float e2s, e2c, bs, bc;
+                    pm_sincos(pm_wrap((double)PM_NSUB * inc), &e2s, &e2c);
+                    pm_sincos(pm_wrap((double)(16 * part + hh + 1) * inc), &bs, &bc);
+                    bs *= 256.f;
+                    bc *= 256.f;
+#pragma unroll
+                    for (int j = 0; j < 16 / PM_NSUB; ++j) {
+                        float rc, rs;
+                        const unsigned h0 = pm_split(bc, bs, &rc, &rs), l0 = pm_pack(rc, rs);
+                        const int o = 64 * j + wx[j % PM_NSLOT];
+                        Bhi[o] = pm_conj(h0);
+                        Bhi[o + 16 * PM_ROW] = pm_swap(h0);
+                        Blo[o] = pm_conj(l0);
+                        Blo[o + 16 * PM_ROW] = pm_swap(l0);
+                        const float nc = fmaf(bc, e2c, -(bs * e2s)), ns = fmaf(bc, e2s, bs * e2c);
+                        bc = nc;
+                        bs = ns;
+                    }
+                }
+            }
+            __syncthreads();        // set c & 1 complete; the consumers are done with it (they read it two rounds ago)
+        }
+        return;
+    }
+
+    // ---- consumers: every row block of the group against this wave's 16 steps
+    pm_float16 acc[PM_NRB];
+#pragma unroll
+    for (int rb = 0; rb < PM_NRB; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
+    __syncthreads();                // round 0's tiles
+    for (int c = 0; c < nchunk; ++c) {
+        const unsigned *set = pm_lds + (size_t)(c & 1) * PS_SPEC_SET;
+        const unsigned *Bhi = set + (size_t)PM_NRB * 2 * PM_TILE + (size_t)part * 2 * PM_TILE, *Blo = Bhi + PM_TILE;
+        uint4 bh[PM_CH / 8], bl[PM_CH / 8];
+#pragma unroll
+        for (int s = 0; s < PM_CH / 8; ++s) {
+            const int o = rd0 ^ (8 * s);
+            bh[s] = *reinterpret_cast<const uint4 *>(Bhi + o);
+            bl[s] = *reinterpret_cast<const uint4 *>(Blo + o);
+        }
+#pragma unroll
+        for (int rb = 0; rb < PM_NRB; ++rb) {
+            if (brun[rb] < 0) continue;                                       // uniform
+            const unsigned *Ahi = set + (size_t)rb * 2 * PM_TILE, *Alo = Ahi + PM_TILE;
+            uint4 ra_hi = *reinterpret_cast<const uint4 *>(Ahi + rd0), ra_lo = *reinterpret_cast<const uint4 *>(Alo + rd0);
+#pragma unroll
+            for (int s = 0; s < PM_CH / 8; ++s) {
+                const pm_half8 a_hi = __builtin_bit_cast(pm_half8, ra_hi), a_lo = __builtin_bit_cast(pm_half8, ra_lo);
+                const pm_half8 b_hi = __builtin_bit_cast(pm_half8, bh[s]), b_lo = __builtin_bit_cast(pm_half8, bl[s]);
+                if (s + 1 < PM_CH / 8) {
+                    const int o = rd0 ^ (8 * (s + 1));
+                    ra_hi = *reinterpret_cast<const uint4 *>(Ahi + o);
+                    ra_lo = *reinterpret_cast<const uint4 *>(Alo + o);
+                }
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[rb], 0, 0, 0);
+            }
+        }
+        __syncthreads();            // this set may be overwritten (round c + 2); round c + 1's set is complete
+    }
+    const float scale = 1.0f / (sigma * 256.0f * (float)P.snum);
+#pragma unroll
+    for (int rb = 0; rb < PM_NRB; ++rb) {
+        if (brun[rb] < 0) continue;
+        const int start = Q.runs[brun[rb]].start, end = start + Q.runs[brun[rb]].len;
+        const int col = lane & 31;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            const int tau = start + PM_TT * (ba0[rb] + row) + 16 * part + (col & 15);
+            if (tau < end) TKrow[2 * (size_t)tau + (col >> 4)] = acc[rb][i] * scale;
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------
 // Set-up pass, one workgroup per wavenumber, one thread per frequency at a time: everything that is float64 and per

@@ -123,6 +123,46 @@ __global__ __launch_bounds__(256) void stolt_stretch(const Cx<T> *__restrict__ F
     K[(size_t)xi * m + zj] = o;
 }
 
+// The same on a frequency-major spectrum F[w][kx] (element (w, kx) at w * tnum + kx), the layout rocFFT's 2-D real
+// transform has its data in before its last transpose: xi is the fast thread index (kx and the output row are read
+// and written contiguously; the two knots of a lane sit in rows i0(kx) that move slowly along a wave).
+template <typename T>
+__global__ __launch_bounds__(256) void stolt_stretch_wmajor(const Cx<T> *__restrict__ F, Cx<T> *__restrict__ K,
+                                                            const double *__restrict__ kx, const double *__restrict__ ws,
+                                                            int m, int nz, int tnum, double vel)
+{
+    const int xi = blockIdx.x * 256 + threadIdx.x;
+    const int zj = blockIdx.y;
+    if (xi >= tnum) return;
+    Cx<T> o;
+    o.x = 0;
+    o.y = 0;
+    if (zj < nz) {
+        const double kxi = kx[xi];
+        const double kz = ws[zj] * 2.0 / vel;                       // :180
+        const double kk = sqrt(kz * kz + kxi * kxi);                // :188 and :196 (kx^2 + kz^2: the same sum)
+        double wq = vel / 2.0 * kk;
+        const double wlast = ws[m - 1];
+        if (wq > wlast) wq = wlast;                                 // FITPACK clamps to the last knot
+        const double dw = ws[1] - ws[0];
+        int i0 = (int)floor(wq / dw);
+        i0 = min(max(i0, 0), m - 2);
+        while (i0 > 0 && ws[i0] > wq) --i0;
+        while (i0 < m - 2 && ws[i0 + 1] <= wq) ++i0;
+        const double w = (wq - ws[i0]) / (ws[i0 + 1] - ws[i0]);
+        const Cx<T> a = F[(size_t)i0 * tnum + xi], b = F[(size_t)(i0 + 1) * tnum + xi];
+        const T re = (T)((1.0 - w) * (double)a.x + w * (double)b.x);       // :190, rounded into the complex array
+        const T im = (T)((1.0 - w) * (double)a.y + w * (double)b.y);
+        const double sc = kz / kk;                                  // :196
+        o.x = (T)((double)re * sc);                                 // :198, scaled in place in double
+        o.y = (T)((double)im * sc);
+        if (zj == 0 && xi == 0) {                                   // :200
+            o.x = 0;
+            o.y = 0;
+        }
+    }
+    K[(size_t)zj * tnum + xi] = o;
+}
 
 // C2R ignores the imaginary part of the DC and Nyquist bins (numpy irfft):
 // clear them so any Hermitian-assuming backend agrees.
@@ -141,6 +181,7 @@ struct StoltPlan {
     FftPlan r2c, c2c_f, c2c_b, c2r;     // separate passes (IMPDAR_STOLT_FFT=1d)
     FftPlan fwd2d, inv2d;               // the same two pairs as 2-D real transforms (default)
     bool use2d = true;
+    bool wmajor = false;                // 2-D plans hand over / take the spectrum frequency-major (IMPDAR_STOLT_LAYOUT=wmajor)
     DevBuf X, F, K, Y, d_kx, d_ws;
 };
 
@@ -191,14 +232,18 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
         // irfft2 (:202) = complex inverse over the traces, then C2R over time.  rocFFT's 2-D real plans do
         // exactly these two passes each, with its own blocked column kernels instead of a strided batch.
         if (pl.use2d) {
-            // (asking rocFFT for the spectrum frequency-major -- its layout before the plan's last transpose -- removes two
-            // transposes but makes it pick slower kernels: 0.76 ms against 0.37 ms at 4096 x 4096 float32, round 2)
+            // tuning knob: "wmajor" takes the spectrum frequency-major from rocFFT (its layout before the plan's last
+            // transpose) and hands it back that way.  Measured at 4096 x 4096 float32: the two transposes go, but
+            // rocFFT picks slower kernels for those strides (0.76 ms instead of 0.37 ms), so trace-major stays.
+            const char *le = getenv("IMPDAR_STOLT_LAYOUT");
+            pl.wmajor = le && !strcmp(le, "wmajor");
+            const size_t col = pl.wmajor ? (size_t)tnum : 0, dist = pl.wmajor ? (size_t)m * tnum : 0;
             if ((rc = pl.fwd2d.create2d(rocfft_transform_type_real_forward, dbl, false, snum, tnum, rocfft_array_type_real,
-                                        rocfft_array_type_hermitian_interleaved, snum, m, 1.0, st)))
+                                        rocfft_array_type_hermitian_interleaved, snum, m, 1.0, st, 0, col, 0, dist)))
                 return rc;
             if ((rc = pl.inv2d.create2d(rocfft_transform_type_real_inverse, dbl, false, nout, tnum,
                                         rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, m, nout,
-                                        1.0 / ((double)nout * tnum), st)))
+                                        1.0 / ((double)nout * tnum), st, col, 0, dist, 0)))
                 return rc;
         }
         if ((rc = pl.r2c.create(rocfft_transform_type_real_forward, dbl, false, snum, tnum, rocfft_array_type_real,
@@ -243,8 +288,12 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
         if ((rc = pl.r2c.exec(pl.X.p, pl.F.p))) return rc;
         if ((rc = pl.c2c_f.exec(pl.F.p, nullptr))) return rc;
     }
-    hipLaunchKernelGGL((stolt_stretch<T>), dim3((m + 255) / 256, tnum), dim3(256), 0, st, pl.F.as<Cx<T>>(),
-                       pl.K.as<Cx<T>>(), pl.d_kx.as<double>(), pl.d_ws.as<double>(), m, nz, tnum, vel);
+    if (pl.use2d && pl.wmajor)
+        hipLaunchKernelGGL((stolt_stretch_wmajor<T>), dim3((tnum + 255) / 256, m), dim3(256), 0, st, pl.F.as<Cx<T>>(),
+                           pl.K.as<Cx<T>>(), pl.d_kx.as<double>(), pl.d_ws.as<double>(), m, nz, tnum, vel);
+    else
+        hipLaunchKernelGGL((stolt_stretch<T>), dim3((m + 255) / 256, tnum), dim3(256), 0, st, pl.F.as<Cx<T>>(),
+                           pl.K.as<Cx<T>>(), pl.d_kx.as<double>(), pl.d_ws.as<double>(), m, nz, tnum, vel);
     if (pl.use2d) {
         if ((rc = pl.inv2d.exec(pl.K.p, pl.Y.p))) return rc;
     } else {
@@ -255,11 +304,6 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
     dim3 bgrid((tnum + 63) / 64, (nout + 63) / 64);
     hipLaunchKernelGGL((stolt_transpose_back<T>), bgrid, dim3(256), 0, st, pl.Y.as<T>(), (T *)d_out, nout, tnum);
     IMPDAR_HIP_CHECK(hipGetLastError());
-    ctx->m_entry = "impdar_stolt";
-    ctx->m_kernel = "stolt_stretch (+ rocFFT 2-D real transforms)";
-    ctx->m_kernel_ms = -1.f;
-    ctx->ktimed = false;
-    ctx->m_extra[0] = 0;
     return impdar_ctx_toc(ctx);
 }
 

@@ -34,6 +34,23 @@ def test_binding_table_covers_header():
     assert sorted(_hip.SIGNATURES) == header_symbols()
 
 
+def test_every_knob_is_documented_and_tested():
+    """Every environment variable read inside impdar_amd/csrc/ has a row in INTEGRATION.md section 4 and is set by at
+    least one GPU test; at most 20 of them (round 3 had 40)."""
+    import glob
+    src = ''.join(open(f).read() for f in glob.glob(os.path.join(ROOT, 'impdar_amd', 'csrc', '*.h*')))
+    knobs = sorted(set(re.findall(r'getenv\("(IMPDAR_[A-Z0-9_]+)"\)', src)))
+    assert 0 < len(knobs) <= 20, knobs
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    table = doc[doc.index('## 4. Environment variables'):doc.index('## 5. CLI')]
+    tests = ''.join(open(f).read() for f in glob.glob(os.path.join(ROOT, 'tests', 'test_*_gpu.py')))
+    for k in knobs:
+        assert '`%s`' % k in table, '%s is read by the library but has no row in INTEGRATION.md' % k
+        assert "'%s'" % k in tests, '%s is not set by any GPU test' % k
+    documented = set(re.findall(r'^\| `(IMPDAR_[A-Z0-9_]+)`', table[:table.index('Read by the Python host side')], flags=re.M))
+    assert documented == set(knobs), sorted(documented ^ set(knobs))
+
+
 def test_no_device_fails_loudly():
     from impdar_amd import _hip
     _hip.load()

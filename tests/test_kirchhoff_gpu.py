@@ -142,6 +142,36 @@ def test_general_geometry_kernel_random_profiles(hip, kind):
         d_in.free()
 
 
+def test_general_geometry_kernel_against_the_ring_on_a_uniform_profile(hip, monkeypatch):
+    """IMPDAR_KIRCH_IMPL=gen sends a UNIFORM profile through kirch_gen_kernel (A/B against the ring kernels): same
+    picks (both are held to the reference's), sums rounded differently.  A rational moveout whose ties the reference
+    decides by rounding noise is a profile the general kernel must not take by itself: steep enough for the ring
+    kernels' windows not to fit, the plan keeps the float64 kernels in auto mode and refuses 'fast'."""
+    from impdar_amd import synth
+    from impdar_amd.kirchhoff import KirchhoffPlan, migrate_resident
+    from oracle import c_oracle
+    ctx = hip.context()
+    snum, tnum, vel = 900, 420, 1.69e8
+    geo = synth.geometry(snum, tnum)
+    x = synth.noise_radargram(snum, tnum, seed=12).astype(np.float32)
+    want = c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], vel, False)
+    ring, _, _ = migrate_resident(ctx, x, geo['dist'], geo['travel_time'], vel, False, 'auto')
+    monkeypatch.setenv('IMPDAR_KIRCH_IMPL', 'gen')
+    plan = KirchhoffPlan(ctx, np.float32, snum, tnum, geo['dist'], geo['travel_time'], vel, False, 'auto')
+    assert plan.kernel == 'kirch_gen_kernel'
+    plan.destroy()
+    gen, _, _ = migrate_resident(ctx, x, geo['dist'], geo['travel_time'], vel, False, 'auto')
+    monkeypatch.delenv('IMPDAR_KIRCH_IMPL')
+    assert rel_l2(gen, want) < FAST_L2 and rel_l2(ring, want) < FAST_L2 and rel_l2(gen, ring) < 1e-5
+    # 25 samples of moveout per trace exactly: (2 a)^2 + (50 n)^2 is an odd square for whole families of (a, n)
+    geo = synth.geometry(600, 200, dt=2e-9, dx=5.0)
+    auto = KirchhoffPlan(ctx, np.float32, 600, 200, geo['dist'], geo['travel_time'], 2.0e8, False, 'auto')
+    assert auto.mode == 'exact' and auto.kernel != 'kirch_gen_kernel', (auto.mode, auto.kernel)
+    auto.destroy()
+    with pytest.raises(NotImplementedError):
+        KirchhoffPlan(ctx, np.float32, 600, 200, geo['dist'], geo['travel_time'], 2.0e8, False, 'fast')
+
+
 def test_general_geometry_kernel_at_config3_size(hip):
     """A jittered 10000 x 4096 float32 profile (the K3 recipe: +-0.3 dx): 0.77 s on the per-pair kernel in rounds 1-3;
     kirch_gen_kernel + shell kernel 58.8-61.0 ms depending on the box (devices differ by +-3 %; the review's target is
@@ -955,7 +985,7 @@ def test_several_tiles_per_workgroup_on_one_ring(hip, xb, nh, lk, monkeypatch):
 
 def test_one_shot_entry_point_reuses_its_plan(hip, monkeypatch, capfd):
     """impdar_kirchhoff keeps its last plan and device buffers: a second radargram of the same geometry (a cache hit,
-    reported by IMPDAR_TIMING) must come out exactly as with a plan of its own (IMPDAR_KIRCH_ONESHOT_CACHE=0), and a
+    reported by the IMPDAR_METRICS line) must come out exactly as with a plan of its own (IMPDAR_KIRCH_ONESHOT_CACHE=0), and a
     change of geometry or velocity must not reuse anything."""
     from impdar_amd import synth
     from impdar_amd.lib.RadarData import RadarData
@@ -973,21 +1003,26 @@ def test_one_shot_entry_point_reuses_its_plan(hip, monkeypatch, capfd):
         migrationlib.migrationKirchhoff(d, vel=vel)
         return d.data
 
-    monkeypatch.setenv('IMPDAR_TIMING', '1')
+    import json
+
+    def plans(err):
+        return [json.loads(l)['plan'] for l in err.splitlines() if l.startswith('{') and '"impdar_metrics"' in l]
+
+    monkeypatch.setenv('IMPDAR_METRICS', '1')
     monkeypatch.delenv('IMPDAR_KIRCH_ONESHOT_CACHE', raising=False)
     capfd.readouterr()
     kept = [run(x) for x in xs]
     err = capfd.readouterr().err
-    assert err.count('impdar_kirchhoff: new plan') == 1 and err.count('impdar_kirchhoff: cached plan') == 1, err
+    assert plans(err) == ['new', 'cached'], err
     other = run(xs[0], vel=1.8e8)                       # same sizes, another velocity: a plan of its own
     geo2 = synth.geometry(snum, tnum, dx=2.0)
     wide = run(xs[0], g=geo2)                           # another trace spacing
     err = capfd.readouterr().err
-    assert err.count('new plan') == 2 and 'cached plan' not in err, err
+    assert plans(err) == ['new', 'new'], err
     monkeypatch.setenv('IMPDAR_KIRCH_ONESHOT_CACHE', '0')
     fresh = [run(x) for x in xs]
     err = capfd.readouterr().err
-    assert err.count('new plan') == 2 and 'cached plan' not in err, err
+    assert plans(err) == ['new', 'new'], err
     for a, b, x in zip(kept, fresh, xs):
         assert np.array_equal(a, b)
         assert rel_l2(a, c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], 1.69e8, False)) < FAST_L2

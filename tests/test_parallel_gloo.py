@@ -49,6 +49,22 @@ def test_sharded_kirchhoff_gloo_spawned(world, mode, tnum, dx, capfd):
         assert ('mode=halo' if mode == 'auto' else 'mode=allgather') in out.out
 
 
+BYTES_WORKER = os.path.join(ROOT, 'tests', '_gloo_bytes_worker.py')
+
+
+@pytest.mark.parametrize('world,tnum,dx', [(2, 200, 4.0), (3, 430, 4.0), (4, 1000, 2.0)])
+def test_halo_exchange_moves_the_bytes_of_the_grouped_image(world, tnum, dx, capfd):
+    """What RCCL moves between two GPUs is byte ranges of the 8-trace-grouped float32 image (PrepParams::i8), at the
+    offsets impdar_kirch_exchange derives from plan_exchange's row ranges.  The same bytes over gloo: every row a
+    rank's output block reads holds the whole-radargram image afterwards, nothing else was touched."""
+    codes = parallel.spawn_ranks([sys.executable, BYTES_WORKER, str(tnum), str(dx)], world,
+                                 env_extra=dict(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
+                                                OMP_NUM_THREADS='1'), timeout=600)
+    out = capfd.readouterr()
+    assert codes == [0] * world, out.out[-2000:] + out.err[-4000:]
+    assert 'GLOO_BYTES_OK world=%d mode=halo' % world in out.out
+
+
 PS_WORKER = os.path.join(ROOT, 'tests', '_gloo_ps_worker.py')
 
 

@@ -163,7 +163,7 @@ def test_hermitian_walk_against_the_full_walk_and_the_oracle(hip, monkeypatch, s
     the zero-frequency row at kx = 0 (mig_python.py:268-270, 282: FK Hermitian, only ifft(TK).real kept);
     IMPDAR_PS_HERMITIAN=0 walks all nt two-sided frequencies as the reference does.  Both against the oracle at the
     stated bars and against each other; even and odd trace counts (with and without a wavenumber Nyquist row), a
-    radargram with a large mean (the zero-frequency row carries it), both workgroup shapes."""
+    radargram with a large mean (the zero-frequency row carries it)."""
     from impdar_amd import synth
     from impdar_amd.lib.RadarData import RadarData
     from impdar_amd.lib import migrationlib
@@ -179,16 +179,15 @@ def test_hermitian_walk_against_the_full_walk_and_the_oracle(hip, monkeypatch, s
                                   geo['dist'], vel, 5, 7)
     tol, measure = (F64_TOL, rel_max) if dtype == np.float64 else (F32_L2, rel_l2)
     outs = {}
-    for herm, shape in (('1', 'deep'), ('0', 'deep'), ('1', 'wide'), ('0', 'wide')):
+    for herm in ('1', '0'):
         monkeypatch.setenv('IMPDAR_PS_HERMITIAN', herm)
-        monkeypatch.setenv('IMPDAR_PS_SHAPE', shape)
         d = RadarData(None)
         d.data, d.snum, d.tnum = data.copy(), snum, tnum
         d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
         migrationlib.migrationPhaseShift(d, vel=vel, htaper=5, vtaper=7)
-        outs[herm, shape] = d.data
-        assert measure(d.data, want) < tol, (herm, shape, measure(d.data, want))
-    assert measure(outs['1', 'deep'], outs['0', 'deep']) < tol
+        outs[herm] = d.data
+        assert measure(d.data, want) < tol, (herm, measure(d.data, want))
+    assert measure(outs['1'], outs['0']) < tol
 
 
 @pytest.mark.parametrize('snum,tnum', [(520, 40), (1000, 33), (2100, 16)])
@@ -250,6 +249,39 @@ def test_matrix_core_path_leaves_many_short_runs_to_the_vector_kernels(hip, monk
         d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
         migrationlib.migrationPhaseShift(d, vel=vel, htaper=20, vtaper=30)
         assert rel_l2(d.data, want) < F32_L2
+
+
+def test_matrix_core_path_hands_over_when_a_wavenumber_has_more_boundary_frequencies_than_it_lists(hip, monkeypatch):
+    """ps_setup_kernel takes every boundary frequency out of the matrix-core sums and lists the first 16 per wavenumber
+    for ps_edge_kernel; beyond that contributions would be missing from TK.  The host reads the counters back after the
+    launch and, on an overflow, discards the result and lets the vector kernels produce it (they walk every boundary
+    frequency themselves).  Forced here by the test hook on the 'boundary' table (a first layer at 1.68e8 m/s puts
+    frequencies exactly on the evanescent boundary): same answer as the vector kernels asked for by name, bit for bit."""
+    from impdar_amd import synth
+    from impdar_amd.lib.RadarData import RadarData
+    from impdar_amd.lib import migrationlib
+    from oracle import mig_oracle
+    snum, tnum = 1030, 100
+    geo = synth.geometry(snum, tnum)
+    data = (synth.noise_radargram(snum, tnum, seed=snum) + 0.5).astype(np.float32)
+    Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+    vel = np.array([[1.68e8, 0.], [1.68e8, 0.45 * Rp], [1.8e8, 0.7 * Rp], [1.9e8, 1.2 * Rp]])
+    want = mig_oracle.phase_shift(data.astype(np.float64), geo['dt'], geo['trace_int'], geo['travel_time'],
+                                  geo['dist'], vel, 20, 30)
+    outs = {}
+    for name, env in (('mfma', {}), ('overflow', {'IMPDAR_PS_TEST_EDGE_OVERFLOW': '1'}), ('vector', {'IMPDAR_PS_MFMA': '0'})):
+        for k in ('IMPDAR_PS_TEST_EDGE_OVERFLOW', 'IMPDAR_PS_MFMA'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        d = RadarData(None)
+        d.data, d.snum, d.tnum = data.copy(), snum, tnum
+        d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
+        migrationlib.migrationPhaseShift(d, vel=vel, htaper=20, vtaper=30)
+        outs[name] = d.data
+        assert rel_l2(d.data, want) < F32_L2, (name, rel_l2(d.data, want))
+    assert np.array_equal(outs['overflow'], outs['vector'])
+    assert not np.array_equal(outs['mfma'], outs['vector'])          # (the matrix-core sums round differently)
 
 
 def test_hermitian_walk_is_refused_when_the_axes_are_not_antisymmetric(hip):
