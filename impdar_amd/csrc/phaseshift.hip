@@ -1313,6 +1313,8 @@ static void ps_launch(const PsParams &P, hipStream_t st)
         hipLaunchKernelGGL((ps_kernel<T, BLOCK, M, false>), dim3(P.nk), dim3(BLOCK), 0, st, P);
 }
 
+#include "ps_smooth.h"      // v(z) that changes at every step: carried square roots and rotations
+
 template <typename T>
 static int ps_dispatch(const PsParams &P, hipStream_t st)
 {
@@ -1745,7 +1747,18 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         if (ok && (rc = ps_mfma_run(pl, P, mruns, vlen != 0, thr.data(), st, &mfma_done))) return rc;
     }
     if (sizeof(T) == 4 && !mfma_done && P.sched && (rc = order_rows())) return rc;
-    if (!mfma_done && (rc = ps_dispatch<T>(P, st))) return rc;
+    bool smooth_done = false;
+    if (!mfma_done && vlen && !P.sched) {
+        // no runs of constant velocity to live on (the velocity changes in most 16-step tiles): ps_smooth_kernel
+        bool ok = true;
+        for (int i = 0; i < snum && ok; ++i) ok = std::isfinite(vmig[i]) && vmig[i] != 0.0 && thr[i] < 1e-10;
+        if (ok && ps_smooth_launch<T>(P, st)) {
+            IMPDAR_HIP_CHECK(hipGetLastError());
+            t_ps_kernel = "ps_smooth_kernel";
+            smooth_done = true;
+        }
+    }
+    if (!mfma_done && !smooth_done && (rc = ps_dispatch<T>(P, st))) return rc;
     ctx->m_entry = tk_out ? "impdar_phaseshift_tk_dev" : "impdar_phaseshift";
     ctx->m_kernel = mfma_done ? "ps_mfma_kernel" : t_ps_kernel;
     ctx->m_kernel_ms = -1.f;                 // (bracketed by ktic / ktoc)

@@ -261,14 +261,17 @@ def test_matrix_core_path_hands_over_when_a_wavenumber_has_more_boundary_frequen
     from impdar_amd.lib.RadarData import RadarData
     from impdar_amd.lib import migrationlib
     from oracle import mig_oracle
-    snum, tnum = 1030, 100
+    import ctypes as C
+    import json
+    from impdar_amd import _hip
+    snum, tnum = 2100, 16
     geo = synth.geometry(snum, tnum)
     data = (synth.noise_radargram(snum, tnum, seed=snum) + 0.5).astype(np.float32)
     Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
     vel = np.array([[1.68e8, 0.], [1.68e8, 0.45 * Rp], [1.8e8, 0.7 * Rp], [1.9e8, 1.2 * Rp]])
     want = mig_oracle.phase_shift(data.astype(np.float64), geo['dt'], geo['trace_int'], geo['travel_time'],
                                   geo['dist'], vel, 20, 30)
-    outs = {}
+    outs, kernels = {}, {}
     for name, env in (('mfma', {}), ('overflow', {'IMPDAR_PS_TEST_EDGE_OVERFLOW': '1'}), ('vector', {'IMPDAR_PS_MFMA': '0'})):
         for k in ('IMPDAR_PS_TEST_EDGE_OVERFLOW', 'IMPDAR_PS_MFMA'):
             monkeypatch.delenv(k, raising=False)
@@ -280,8 +283,11 @@ def test_matrix_core_path_hands_over_when_a_wavenumber_has_more_boundary_frequen
         migrationlib.migrationPhaseShift(d, vel=vel, htaper=20, vtaper=30)
         outs[name] = d.data
         assert rel_l2(d.data, want) < F32_L2, (name, rel_l2(d.data, want))
+        buf = C.create_string_buffer(1024)
+        _hip.check(_hip.load().impdar_ctx_last_metrics(_hip.context(), buf, len(buf)), 'metrics')
+        kernels[name] = json.loads(buf.value.decode())['kernel']
+    assert kernels['mfma'] == 'ps_mfma_kernel' and kernels['overflow'] == kernels['vector'] != 'ps_mfma_kernel', kernels
     assert np.array_equal(outs['overflow'], outs['vector'])
-    assert not np.array_equal(outs['mfma'], outs['vector'])          # (the matrix-core sums round differently)
 
 
 def test_hermitian_walk_is_refused_when_the_axes_are_not_antisymmetric(hip):
@@ -310,6 +316,53 @@ def test_hermitian_walk_is_refused_when_the_axes_are_not_antisymmetric(hip):
     TK = mig_oracle.phase_shift_tk(FK, 1.69e8, kx, ws, geo['dt'], geo['travel_time'], snum, tnum)
     want = np.fft.ifft(TK).real
     assert rel_max(out, want) < F64_TOL, rel_max(out, want)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('profile', ['gradient', 'gradient_with_jumps', 'slowing', 'wavy', 'noisy_steps'])
+@pytest.mark.parametrize('snum,tnum', [(700, 48), (1100, 20), (130, 33)])
+def test_velocity_that_changes_at_every_step(hip, dtype, profile, snum, tnum, capfd, monkeypatch):
+    """A per-step velocity profile handed to the C entry point (what getVelocityProfile returns for anything but a few
+    thick layers): no runs of constant velocity, so ps_smooth_kernel carries sqrt(coss) and the rotation from step
+    to step (Newton / second-order updates, float64 anchors) and re-does the frequencies near the evanescent boundary
+    -- and every frequency at a velocity jump -- from scratch in the reference's rounding.  Against the oracle's
+    literal per-step loop (mig_python.py:438-487) at the stated bars; the metrics line names the kernel."""
+    import ctypes as C
+    import json
+    from impdar_amd import _hip, synth
+    from oracle import mig_oracle
+    lib, ctx = _hip.load(), _hip.context()
+    nt = 1 << int(np.ceil(np.log2(snum)))
+    geo = synth.geometry(snum, tnum)
+    rng = np.random.default_rng(snum + tnum)
+    data = (rng.standard_normal((snum, tnum)) + 0.3).astype(dtype)
+    u = np.linspace(0., 1., snum)
+    vm = {'gradient': 1.69e8 + 0.5e8 * u,
+          'gradient_with_jumps': 1.69e8 + 0.3e8 * u + 0.05e8 * (u > 0.3) + 0.08e8 * (u > 0.7),
+          'slowing': 2.1e8 - 0.4e8 * u,
+          'wavy': 1.8e8 + 0.15e8 * np.sin(7. * u) + 0.1e8 * u,
+          'noisy_steps': 1.69e8 + 0.4e8 * u + 2.0e4 * rng.standard_normal(snum)}[profile]
+    vm = np.ascontiguousarray(vm, dtype=np.float64)
+    kx = mig_oracle._kx(tnum, geo['trace_int'], geo['dist'])
+    ws = 2. * np.pi * np.fft.fftfreq(nt, d=geo['dt'])
+    out = np.empty((snum, tnum), dtype=dtype)
+    tt = np.ascontiguousarray(geo['travel_time'], dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    _hip.check(lib.impdar_phaseshift(ctx, data.ctypes.data_as(C.c_void_p), _hip.dtype_code(dtype), snum, tnum, nt,
+                                     kx.ctypes.data_as(dp), ws.ctypes.data_as(dp), C.c_double(geo['dt']),
+                                     tt.ctypes.data_as(dp), C.c_double(0.0), vm.ctypes.data_as(dp), snum, C.c_double(5.),
+                                     C.c_double(7.), out.ctypes.data_as(C.c_void_p)), 'impdar_phaseshift')
+    buf = C.create_string_buffer(1024)
+    _hip.check(lib.impdar_ctx_last_metrics(ctx, buf, len(buf)), 'metrics')
+    assert json.loads(buf.value.decode())['kernel'] == 'ps_smooth_kernel'
+    tap = mig_oracle._apply_taper(data.astype(np.float64), 5, 7, inplace_form=True)
+    FK = np.fft.fft2(tap, (nt, tnum))
+    TK = mig_oracle.phase_shift_tk(FK, vm, kx, ws, geo['dt'], geo['travel_time'], snum, tnum)
+    want = np.fft.ifft(TK).real
+    if dtype == np.float32:
+        assert rel_l2(out, want) < F32_L2, (profile, rel_l2(out, want))
+    else:
+        assert rel_max(out, want) < F64_TOL, (profile, rel_max(out, want))
 
 
 @pytest.mark.parametrize('dtype', [np.float32, np.float64])
