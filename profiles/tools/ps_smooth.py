@@ -3,7 +3,7 @@ velocity -- ps_smooth_kernel since round 4, the per-step kernels before), float3
 usage: ps_smooth.py [n]"""
 import sys, os, json
 import ctypes as C
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from impdar_amd import _hip, synth
 lib, ctx = _hip.load(), _hip.context()
