@@ -33,6 +33,7 @@
 // the carried values are good to 6e-6 (float32: two Newton steps, third-order rotation) / 2e-8 (float64: three steps,
 // sixth-order rotation) there and to rounding everywhere else.
 #define PSS_BAND 10.0
+#define PSS_NARROW 0.01     // bands up to this take the short way through the exact branch
 
 template <typename T, int BLOCK, int M>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void ps_smooth_kernel(PsParams P)
@@ -52,6 +53,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
     Cp<T> *f0_lds = reinterpret_cast<Cp<T> *>(pss_smem);
     Cp<T> *part = reinterpret_cast<Cp<T> *>(pss_smem + (size_t)(F32 ? M : 0) * BLOCK * sizeof(Cp<T>));
     T(*red)[NW][2 * TT] = reinterpret_cast<T(*)[NW][2 * TT]>(reinterpret_cast<char *>(part) + (size_t)TT * BLOCK * sizeof(Cp<T>));
+    // [2][TT] per-step constants {c = v^2, band, threshold, v}: written by 16 lanes a tile ahead, read by every lane as one
+    // broadcast (they were ~10 uniform float64 instructions and two vector loads per step and wave)
+    double4 *stepc = reinterpret_cast<double4 *>(reinterpret_cast<char *>(red) + (size_t)2 * NW * 2 * TT * sizeof(T));
     const int k = P.k0 + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Cp<T> *F = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k * P.fstride;
@@ -62,6 +66,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
     // the sum of y since the last anchor and the phase at that anchor
     double x[M], wdt[M], y[M], g[M], ysum[F32 ? M : 1], Phi[F32 ? M : 1];
     T sr_[M], si_[M], rc[M], rs[M];                       // state FK and rotation R = exp(i phi)
+    T wdtT[F32 ? M : 1];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const int slot = tid + m * BLOCK;
@@ -75,6 +80,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
         const double a0 = 0.5 * kxk / w;
         x[m] = slot < P.nf ? a0 * a0 : 0.0;
         wdt[m] = w * P.dt;
+        if (F32) wdtT[F32 ? m : 0] = (T)wdt[m];
         y[m] = 1.0;
         g[m] = 0.5;
         if (F32) {
@@ -87,8 +93,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
         rc[m] = 1;
         rs[m] = 0;
     }
-    double c_prev = 0.0;
-    double vz_next = P.vz[0], thr_next = P.thr[0];
+    auto step_constants = [&](int tile) {                 // lanes 0..15: the constants of tile `tile`
+        const int tau = tile * TT + tid;
+        if (tid < TT && tau < P.snum) {
+            const double vd = P.vz[tau], c = vd * vd;
+            double csb = 4.0;                             // step 0: every lane from scratch
+            if (tau > 0) {
+                const double vp = P.vz[tau - 1];
+                // band: coss below this moved too much relative to itself for the carried values
+                csb = BAND * fabs(c - vp * vp) / c + 1.0e-9;
+            }
+            stepc[(tile & 1) * TT + tid] = make_double4(c, csb, P.thr[tau], vd);
+        }
+    };
+    step_constants(0);
+    __syncthreads();
     unsigned dead = 0;                                    // bit m: frequency m of this lane has turned evanescent
     const int ntile = (P.snum + TT - 1) / TT;
     for (int tile = 0; tile < ntile; ++tile) {
@@ -128,109 +147,113 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
             const int tau = tau0 + t;
             T psr = 0, psi = 0;
             if (tau < P.snum) {                                   // uniform
-                // this step's velocity and threshold were requested a step ago
-                const double vd = vz_next, thr = thr_next;
-                const int tn = tau + 1 < P.snum ? tau + 1 : tau;
-                vz_next = P.vz[tn];
-                thr_next = P.thr[tn];
-                const double c = vd * vd;
-                // band: coss below this moved too much relative to itself for the carried values (every lane at step 0).
-                // (1 / c from the float reciprocal: a float64 division here is ~40 instructions per step and wave)
-                const double csb = tau == 0 ? 4.0 : BAND * fabs(c - c_prev) * (double)__builtin_amdgcn_rcpf((float)c) + 1.0e-9;
-                c_prev = c;
+                const double4 sc = stepc[(tile & 1) * TT + t];
+                const double c = sc.x, csb = sc.y;
 #define PSS_EACH for (int j = 0, m = m0; j < G; ++j, ++m)
-#define PSS_PIN(a)                                                                   \
+#define PSS_PIN(f)                                                                   \
     do {                                                                             \
-        if constexpr (G == 2) asm volatile("" : "+v"(a[0]), "+v"(a[G > 1 ? 1 : 0])); \
-        else asm volatile("" : "+v"(a[0]));                                         \
+        if constexpr (G == 2) asm volatile("" : "+v"(q[0].f), "+v"(q[G > 1 ? 1 : 0].f)); \
+        else asm volatile("" : "+v"(q[0].f));                                        \
     } while (0)
 #pragma unroll
                 for (int m0 = 0; m0 < M; m0 += G) {
                     if ((gdead >> m0) & 1u) continue;             // uniform
-                    double csg[G], e1g[G], y1g[G], rg[G], e2g[G], y2g[G], gng[G], ddg[G];
-                    T dg[G], hd2g[G], urg[G], uig[G], m1g[G], m2g[G], ncrg[G], nsrg[G];
-                    bool bandg[G];
+                    // (a struct per frequency, not an array per quantity: arrays of two floats become <2 x float> and
+                    // the packed instructions that follows -- same rate as two plain ones -- cost moves to pack and unpack)
+                    struct {
+                        double cs, e1, y1, r, e2, y2, gn, dd;
+                        T d, hd2, ur, ui, m1, m2, ncr, nsr;
+                        bool band;
+                    } q[G];
                     bool any = false;
                     // stage by stage across the group (the pins keep the scheduler from putting the chains back one after
                     // the other to save registers)
 #pragma unroll
-                    PSS_EACH csg[j] = fma(-c, x[m], 1.0);
-                    PSS_PIN(csg);
+                    PSS_EACH q[j].cs = fma(-c, x[m], 1.0);
+                    PSS_PIN(cs);
                     // Newton steps for y = sqrt(cs) from the previous step's y, g ~ 1 / (2 y).  (g is refreshed BETWEEN
                     // the steps: with the previous step's g in both, the second step only gains a factor rho -- rho^3
                     // left, 7e-8 on a float64 image of 700 steps; refreshed from y1 it is a true Newton step: rho^4)
 #pragma unroll
-                    PSS_EACH e1g[j] = fma(-y[m], y[m], csg[j]);
-                    PSS_PIN(e1g);
+                    PSS_EACH q[j].e1 = fma(-y[m], y[m], q[j].cs);
+                    PSS_PIN(e1);
 #pragma unroll
-                    PSS_EACH y1g[j] = fma(e1g[j], g[m], y[m]);
-                    PSS_PIN(y1g);
+                    PSS_EACH q[j].y1 = fma(q[j].e1, g[m], y[m]);
+                    PSS_PIN(y1);
 #pragma unroll
                     PSS_EACH {
-                        rg[j] = fma(-(y1g[j] + y1g[j]), g[m], 1.0);
-                        e2g[j] = fma(-y1g[j], y1g[j], csg[j]);
+                        q[j].r = fma(-(q[j].y1 + q[j].y1), g[m], 1.0);
+                        q[j].e2 = fma(-q[j].y1, q[j].y1, q[j].cs);
                     }
-                    PSS_PIN(rg);
-                    PSS_PIN(e2g);
+                    PSS_PIN(r);
+                    PSS_PIN(e2);
 #pragma unroll
-                    PSS_EACH gng[j] = fma(g[m], rg[j], g[m]);
-                    PSS_PIN(gng);
+                    PSS_EACH q[j].gn = fma(g[m], q[j].r, g[m]);
+                    PSS_PIN(gn);
 #pragma unroll
-                    PSS_EACH y2g[j] = fma(e2g[j], gng[j], y1g[j]);
-                    PSS_PIN(y2g);
+                    PSS_EACH q[j].y2 = fma(q[j].e2, q[j].gn, q[j].y1);
+                    PSS_PIN(y2);
                     if (!F32) {
                         // float64 data: a third step (rho^4 = 2e-12 per step at the band's edge adds up over a record)
 #pragma unroll
-                        PSS_EACH e1g[j] = fma(-y2g[j], y2g[j], csg[j]);
-                        PSS_PIN(e1g);
+                        PSS_EACH q[j].e1 = fma(-q[j].y2, q[j].y2, q[j].cs);
+                        PSS_PIN(e1);
 #pragma unroll
-                        PSS_EACH y2g[j] = fma(e1g[j], gng[j], y2g[j]);
-                        PSS_PIN(y2g);
+                        PSS_EACH q[j].y2 = fma(q[j].e1, q[j].gn, q[j].y2);
+                        PSS_PIN(y2);
                     }
                     // R *= exp(i d), d = phi - phi_previous = w dt (y2 - y).  float32: 1 - d^2/2 + i d (re-anchored every
                     // 64 steps; d^3/6 < 1e-12 but at the band's edge); float64: cos to d^6, sin to d^5 (with
                     // 1 - d^2/2 + i (d - d^3/6) the modulus is 1 - d^4/24: a systematic loss, 6e-9 over 700 steps; at the
                     // band's edge d reaches 0.03)
 #pragma unroll
-                    PSS_EACH ddg[j] = y2g[j] - y[m];
-                    PSS_PIN(ddg);
+                    PSS_EACH q[j].dd = q[j].y2 - y[m];
+                    PSS_PIN(dd);
 #pragma unroll
-                    PSS_EACH dg[j] = F32 ? (T)ddg[j] * (T)wdt[m] : (T)(ddg[j] * wdt[m]);
-                    PSS_PIN(dg);
+                    PSS_EACH q[j].d = F32 ? (T)q[j].dd * wdtT[F32 ? m : 0] : (T)(q[j].dd * wdt[m]);
+                    PSS_PIN(d);
 #pragma unroll
-                    PSS_EACH hd2g[j] = dg[j] * dg[j] * (T)0.5;
-                    PSS_PIN(hd2g);
+                    PSS_EACH q[j].hd2 = q[j].d * q[j].d * (T)0.5;
+                    PSS_PIN(hd2);
 #pragma unroll
                     PSS_EACH {
                         // with h = d^2 / 2:  cos d = 1 - h + h^2/6 - h^3/90,  sin d = d (1 - h/3 + h^2/30)
-                        const T h = hd2g[j];
-                        urg[j] = F32 ? (T)1 - h : fma(h, fma(h, fma(h, (T)(-1.0 / 90.0), (T)(1.0 / 6.0)), (T)-1), (T)1);
-                        uig[j] = F32 ? dg[j] : dg[j] * fma(h, fma(h, (T)(1.0 / 30.0), (T)(-1.0 / 3.0)), (T)1);
+                        const T h = q[j].hd2;
+                        q[j].ur = F32 ? (T)1 - h : fma(h, fma(h, fma(h, (T)(-1.0 / 90.0), (T)(1.0 / 6.0)), (T)-1), (T)1);
+                        q[j].ui = F32 ? q[j].d : q[j].d * fma(h, fma(h, (T)(1.0 / 30.0), (T)(-1.0 / 3.0)), (T)1);
                     }
-                    PSS_PIN(urg);
+                    PSS_PIN(ur);
 #pragma unroll
                     PSS_EACH {
-                        m1g[j] = rs[m] * uig[j];
-                        m2g[j] = rs[m] * urg[j];
+                        q[j].m1 = rs[m] * q[j].ui;
+                        q[j].m2 = rs[m] * q[j].ur;
                     }
-                    PSS_PIN(m1g);
-                    PSS_PIN(m2g);
+                    PSS_PIN(m1);
+                    PSS_PIN(m2);
 #pragma unroll
                     PSS_EACH {
-                        ncrg[j] = fma(rc[m], urg[j], -m1g[j]);
-                        nsrg[j] = fma(rc[m], uig[j], m2g[j]);
-                        bandg[j] = csg[j] < csb;
-                        any = any || bandg[j];
+                        q[j].ncr = fma(rc[m], q[j].ur, -q[j].m1);
+                        q[j].nsr = fma(rc[m], q[j].ui, q[j].m2);
+                        q[j].band = q[j].cs < csb;
+                        any = any || q[j].band;
                     }
                     if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) != 0, 0)) {
+                        // (one or two frequencies of every wavenumber are in the band at any step of a smooth profile: this
+                        // branch is taken by one wave of the workgroup at almost every step, and what it costs counts)
+                        const double thr = sc.z, vd = sc.w;
+                        const bool narrow = csb <= PSS_NARROW;    // uniform
 #pragma unroll
                         PSS_EACH {
-                            if (bandg[j]) {
-                                // this step from scratch, in the reference's own rounding (:456-460, :484-485)
+                            if (q[j].band) {
                                 const int slot = tid + m * BLOCK;
-                                const double wx = slot < P.nf ? P.w[slot] : 1.0;
-                                const double a = ((0.5 * vd) * kxk) / wx;
-                                const double cr = 1.0 - a * a;
+                                double cr = q[j].cs;
+                                const bool cheap = narrow && fabs(cr - thr) > 1.0e-13;
+                                if (!cheap) {
+                                    // coss in the reference's own rounding (:456-460): what decides at the threshold
+                                    const double wx = slot < P.nf ? P.w[slot] : 1.0;
+                                    const double a = ((0.5 * vd) * kxk) / wx;
+                                    cr = 1.0 - a * a;
+                                }
                                 if (cr <= thr || !(slot < P.nf) || ((dead >> m) & 1u)) {
                                     // evanescent: zero from here on (:484-485 zero the spectrum itself: once out, out for
                                     // good -- a velocity that falls again must not revive the carried values of such a
@@ -244,30 +267,70 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
                                         f0_lds[m * BLOCK + tid] = z;
                                     }
                                     x[m] = 0.0;
-                                    y2g[j] = 1.0;
-                                    gng[j] = 0.5;
-                                    ncrg[j] = 1;
-                                    nsrg[j] = 0;
+                                    q[j].y2 = 1.0;
+                                    q[j].gn = 0.5;
+                                    q[j].ncr = 1;
+                                    q[j].nsr = 0;
+                                } else if (cheap) {
+                                    // y = sqrt(coss) from the hardware's reciprocal square root and two Newton steps that
+                                    // carry h ~ 1 / (2 y) along (coss in [1e-13, 0.01]: no scaling); the phase w dt y is
+                                    // below 0.32: sine and cosine from their series
+                                    const double r0 = __builtin_amdgcn_rsq(cr);
+                                    double y0 = cr * r0, h = 0.5 * r0;
+#pragma unroll
+                                    for (int it = 0; it < 2; ++it) {
+                                        y0 = fma(fma(-y0, y0, cr), h, y0);
+                                        h = fma(h, fma(-(y0 + y0), h, 1.0), h);
+                                    }
+                                    y0 = fma(fma(-y0, y0, cr), h, y0);
+                                    q[j].y2 = y0;
+                                    q[j].gn = h;
+                                    const T ph = (T)(wdt[m] * y0), s2 = ph * ph;
+                                    T pc, ps;
+                                    if (F32) {
+                                        pc = fma(s2, fma(s2, fma(s2, fma(s2, (T)(1.0 / 40320), (T)(-1.0 / 720)), (T)(1.0 / 24)), (T)-0.5), (T)1);
+                                        ps = fma(s2, fma(s2, fma(s2, fma(s2, (T)(1.0 / 362880), (T)(-1.0 / 5040)), (T)(1.0 / 120)), (T)(-1.0 / 6)), (T)1);
+                                    } else {
+                                        pc = (T)(1.0 / 87178291200.0);                       // 1/14!
+                                        ps = (T)(1.0 / 1307674368000.0);                     // 1/15!
+                                        pc = fma(s2, -pc, (T)(1.0 / 479001600.0));           // 1/12!
+                                        ps = fma(s2, -ps, (T)(1.0 / 6227020800.0));          // 1/13!
+                                        pc = fma(s2, -pc, (T)(1.0 / 3628800.0));
+                                        ps = fma(s2, -ps, (T)(1.0 / 39916800.0));
+                                        pc = fma(s2, -pc, (T)(1.0 / 40320.0));
+                                        ps = fma(s2, -ps, (T)(1.0 / 362880.0));
+                                        pc = fma(s2, -pc, (T)(1.0 / 720.0));
+                                        ps = fma(s2, -ps, (T)(1.0 / 5040.0));
+                                        pc = fma(s2, -pc, (T)(1.0 / 24.0));
+                                        ps = fma(s2, -ps, (T)(1.0 / 120.0));
+                                        pc = fma(s2, -pc, (T)0.5);
+                                        ps = fma(s2, -ps, (T)(1.0 / 6.0));
+                                        pc = fma(s2, -pc, (T)1);
+                                        ps = fma(s2, -ps, (T)1);
+                                    }
+                                    q[j].ncr = pc;
+                                    q[j].nsr = ps * ph;
                                 } else {
-                                    y2g[j] = sqrt(cr);
-                                    gng[j] = 0.5 / y2g[j];
+                                    // this step from scratch (:456-464)
+                                    q[j].y2 = sqrt(cr);
+                                    q[j].gn = 0.5 / q[j].y2;
                                     T sn, cn;
-                                    sincos_t<T>((T)(wdt[m] * y2g[j]), &sn, &cn);
-                                    ncrg[j] = cn;
-                                    nsrg[j] = sn;
+                                    sincos_t<T>((T)(wdt[m] * q[j].y2), &sn, &cn);
+                                    q[j].ncr = cn;
+                                    q[j].nsr = sn;
                                 }
                             }
                         }
                     }
 #pragma unroll
                     PSS_EACH {
-                        y[m] = y2g[j];
-                        g[m] = gng[j];
-                        if (F32) ysum[F32 ? m : 0] += y2g[j];
-                        rc[m] = ncrg[j];
-                        rs[m] = nsrg[j];
-                        const T nr = fma(sr_[m], ncrg[j], -(si_[m] * nsrg[j]));     // FK *= exp(i phi), :464
-                        const T ni = fma(sr_[m], nsrg[j], si_[m] * ncrg[j]);
+                        y[m] = q[j].y2;
+                        g[m] = q[j].gn;
+                        if (F32) ysum[F32 ? m : 0] += q[j].y2;
+                        rc[m] = q[j].ncr;
+                        rs[m] = q[j].nsr;
+                        const T nr = fma(sr_[m], q[j].ncr, -(si_[m] * q[j].nsr));     // FK *= exp(i phi), :464
+                        const T ni = fma(sr_[m], q[j].nsr, si_[m] * q[j].ncr);
                         sr_[m] = nr;
                         si_[m] = ni;
                         psr += nr;                                                  // :487
@@ -294,6 +357,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
         wave_reduce_scatter<T, 2 * TT>(acc, lane);
         T(*buf)[2 * TT] = red[tile & 1];
         if ((lane & 1) == 0) buf[wave][lane >> 1] = acc[0];
+        step_constants(tile + 1);                         // (the other half of the table: last read a tile ago)
         __syncthreads();
         if (tid < 2 * TT) {
             T s = 0;
@@ -312,7 +376,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
 template <typename T, int BLOCK, int M> static size_t ps_smooth_lds()
 {
     return (size_t)(sizeof(T) == 4 ? M : 0) * BLOCK * sizeof(Cp<T>) + (size_t)16 * BLOCK * sizeof(Cp<T>) +
-           2 * (BLOCK / 64) * 32 * sizeof(T);
+           2 * (BLOCK / 64) * 32 * sizeof(T) + 2 * 16 * sizeof(double4);
 }
 
 template <typename T, int BLOCK, int M> static void ps_smooth_launch_one(const PsParams &P, hipStream_t st)
