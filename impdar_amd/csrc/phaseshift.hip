@@ -186,6 +186,9 @@ struct PsParams {
     const int *sched;       // float32 v(z), ps_vz32_kernel: [snum] 1 where a new constant-velocity run starts
     const int *tsched;      // ... [ceil(ntile/32)] bit t of word t/32 set where 16-step tile t holds such a step
     const int *rowmap;      // ... [tnum] wavenumber of workgroup b (rows holding boundary frequencies first), or null
+    const double *sm_step, *sm_tile;   // float32, ps_smooth32_kernel: the tables of ps_smooth_tables
+    void *sm_part;          // ps_smooth kernels: [sm_nchunks][nk][snum] complex partial images (more than one chunk)
+    int sm_nchunks;
     const double *eps;      // float64 v(z), ps_vz64_kernel: [ceil(snum/16)] sum over the tile's steps of v / v_run - 1
     int snum, tnum, nt, vz_mode;
     // Frequency slots a workgroup walks.  Full walk: nf = nt, slot i = row i of F.  Hermitian walk (herm = 1, real
@@ -1254,7 +1257,8 @@ struct PsPlan {
     const impdar_ctx *slab_owner = nullptr;
     DevBuf d_sendbuf, d_slab;            // ... packed blocks of the all-to-all; the transposed slab
     DevBuf d_blocks, d_edge, d_runtab;   // matrix-core path: row-block table; boundary-frequency counts + lists; per-run phases
-    DevBuf X, TK, d_kx, d_w, d_vz, d_thr, d_sched, d_rowmap, d_eps;
+    DevBuf X, TK, d_kx, d_w, d_vz, d_thr, d_sched, d_rowmap, d_eps, d_sm, d_part;
+    std::vector<double> h_sm_step, h_sm_tile;
 };
 static std::mutex g_ps_mu;
 static PsPlan *g_ps_plan = nullptr;
@@ -1473,7 +1477,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             pl.d_runtab.release();
             pl.d_sendbuf.release();
             pl.d_slab.release();
-            pl.X.release(); pl.TK.release(); pl.d_kx.release(); pl.d_w.release(); pl.d_vz.release(); pl.d_thr.release();
+            pl.X.release(); pl.TK.release(); pl.d_kx.release(); pl.d_w.release(); pl.d_vz.release(); pl.d_thr.release(); pl.d_sm.release(); pl.d_part.release();
             pl.d_sched.release();
             pl.d_rowmap.release();
             pl.d_eps.release();
@@ -1626,6 +1630,9 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     P.vtol = dbl ? 1e-11 : 1e-10;
     P.sched = P.tsched = P.rowmap = nullptr;
     P.eps = nullptr;
+    P.sm_step = P.sm_tile = nullptr;
+    P.sm_part = nullptr;
+    P.sm_nchunks = 1;
     std::vector<int> sched, rowmap;
     std::vector<double> epsum;
     if (vlen) {
@@ -1752,10 +1759,30 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         // no runs of constant velocity to live on (the velocity changes in most 16-step tiles): ps_smooth_kernel
         bool ok = true;
         for (int i = 0; i < snum && ok; ++i) ok = std::isfinite(vmig[i]) && vmig[i] != 0.0 && thr[i] < 1e-10;
-        if (ok && ps_smooth_launch<T>(P, st)) {
-            IMPDAR_HIP_CHECK(hipGetLastError());
-            t_ps_kernel = "ps_smooth_kernel";
-            smooth_done = true;
+        if (ok) {
+            P.sm_nchunks = ps_smooth_chunks(nf);
+            const size_t part_bytes = P.sm_nchunks > 1 ? (size_t)P.sm_nchunks * nk * snum * sizeof(Cp<T>) : 0;
+            std::vector<double> &sm_step = pl.h_sm_step, &sm_tile = pl.h_sm_tile;     // (alive until the next call: async copies)
+            if (sizeof(T) == 4) ps_smooth_tables(vmig, thr.data(), snum, sm_step, sm_tile);
+            // (no room for the partial images: the per-step kernels below)
+            if (pl.d_sm.ensure((sm_step.size() + sm_tile.size()) * 8 + 64) == hipSuccess &&
+                (!part_bytes || pl.d_part.ensure(part_bytes) == hipSuccess)) {
+                if (sizeof(T) == 4) {
+                    IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_sm.p, sm_step.data(), sm_step.size() * 8, hipMemcpyHostToDevice, st));
+                    IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_sm.as<double>() + sm_step.size(), sm_tile.data(), sm_tile.size() * 8,
+                                                    hipMemcpyHostToDevice, st));
+                    P.sm_step = pl.d_sm.as<double>();
+                    P.sm_tile = pl.d_sm.as<double>() + sm_step.size();
+                }
+                P.sm_part = pl.d_part.p;
+                ps_smooth_launch<T>(P, st);
+                IMPDAR_HIP_CHECK(hipGetLastError());
+                t_ps_kernel = sizeof(T) == 4 ? "ps_smooth32_kernel" : "ps_smooth_kernel";
+                smooth_done = true;
+            } else {
+                (void)hipGetLastError();
+                P.sm_nchunks = 1;
+            }
         }
     }
     if (!mfma_done && !smooth_done && (rc = ps_dispatch<T>(P, st))) return rc;

@@ -2,152 +2,160 @@
 // gradient: what getVelocityProfile's 2 * gradient(z(t)) gives for anything but a few thick layers.
 // (included by phaseshift.hip)
 //
-// Reference: mig_python.py:438-487.  Per depth step tau and frequency w (wavenumber kx fixed per workgroup):
+// Reference: mig_python.py:438-487.  Per depth step tau and frequency w (wavenumber kx):
 //     coss = 1 - (0.5 v_tau kx / w)^2;   FK[w] *= exp(i w dt sqrt(coss));   FK[w] = 0 for good once coss <= thr_tau;
 //     TK[tau] += FK[w]
 // The runs kernels (ps_vz32_kernel / ps_vz64_kernel, ps_mfma.h) live on runs of constant velocity, where the rotation
 // per step is fixed.  Without runs the per-step kernel paid a float64 divide, square root and a sincos per
 // (tau, w): 917 ms (float32) / 834 ms (float64) at 8192^2 against 15 / 60 ms for a four-layer table.
 //
-// Here the velocity is assumed to move LITTLE per step (it may still do anything: see the band below), and every
-// per-step quantity is carried forward instead of recomputed:
-//   * y = sqrt(coss) by two Newton steps from the previous step's y, with g = 1 / (2 y) carried by its own Newton
-//     step between them: 7 float64 fma, no divide, no square root.  Two steps from a relative offset rho leave rho^4.
-//   * the per-step rotation R = exp(i phi), phi = w dt y, by R *= 1 + i d - d^2 / 2 (- i d^3 / 6 + d^4 / 24 in float64) with
-//     d = phi - phi_previous: a rotation OF the rotation, no sincos;
-//   * float32 data: the state is re-anchored to FK0 exp(i Phi) with the float64 phase sum Phi every 64 steps, and R
-//     to exp(i phi), as the runs kernels do (the recurrences drift, the anchors do not).
+// Work units.  ONE WAVE per (wavenumber, chunk of 64 M frequencies), a workgroup of its own: no barrier anywhere.  The
+// frequencies below v kx / 2 are evanescent -- 40-55 % of the (kx, w) plane at 1 m / 10 ns / 1.69e8 m/s -- and the few
+// next to that edge need an exact, expensive branch at every step (the band, below).  With a workgroup per wavenumber
+// (rounds 4a-c) the wave that held the band ran twice as long as its seven neighbours, which waited at the tile's
+// barrier with their compute unit: 190 ms where the instruction count said 80.  As waves of their own the all-evanescent
+// chunks leave at once, the band's wave takes its time alone, and the hardware fills the slots.  Each wave writes the
+// step sums of ITS frequencies to its own row of a partial image [chunk][k][tau]; ps_smooth_sum_kernel adds the
+// chunks in order (deterministic) and divides by snum (:492).  9 GB of extra traffic at 8192^2: 2.5 ms.
+//
+// float64 data (ps_smooth_kernel): every per-step quantity is carried forward instead of recomputed:
+//   * y = sqrt(coss) by three Newton steps from the previous step's y, with g = 1 / (2 y) carried by its own Newton
+//     step between them: 10 float64 fma, no divide, no square root;
+//   * the per-step rotation R = exp(i phi), phi = w dt y, by R *= exp(i d), d = phi - phi_previous, cos to d^6 and sin
+//     to d^5: a rotation OF the rotation, no sincos.
 // The band.  Newton from the previous value needs coss to move little RELATIVE to itself: rho = |d coss| / (2 coss).
 // A frequency about to turn evanescent (coss -> 0) violates that, and so does every frequency at a step where the
-// velocity jumps.  Lanes with coss < 10 |d(v^2)| / v^2 (rho > 0.05; all lanes at step 0) take the exact path for
-// that step: coss in the reference's own rounding (the evanescence test coss <= thr is decided there and only
-// there), a real square root, a real sincos.  As v grows with depth the cut-off frequency v kx / 2 sweeps upwards:
-// the frequencies in the band are a handful of NEIGHBOURS, i.e. lanes of one wave -- the exact path runs for about
-// one (wave, frequency slot) pair per step.
+// velocity jumps.  Lanes with coss < 60 |d(v^2)| / v^2 (all lanes at step 0) take the exact path for that step: coss
+// in the reference's own rounding where it is within 1e-13 of the threshold (the evanescence test coss <= thr is
+// decided there and only there), a real square root, a real sincos -- or, for narrow bands, the hardware's reciprocal
+// root + Newton and the series of sine and cosine (the phase is small where coss is).
+// float32 data (ps_smooth32_kernel): see there.
 #pragma once
 
-// Band: coss < PSS_BAND |d(v^2)| / v^2, i.e. rho = |d coss| / (2 coss) > 1 / (2 PSS_BAND).  250 (rho > 0.002) held every
-// carried value to its bar on every frequency and made the exact path a bottleneck: the frequencies in the band are
-// neighbours, so ONE wave of the workgroup ran it step after step (~750 cycles a time) while seven waited at the tile
-// barrier.  A frequency spends a few steps at the band's edge and is one of thousands in the sum: with rho up to 0.05
-// the carried values are good to 6e-6 (float32: two Newton steps, third-order rotation) / 2e-8 (float64: three steps,
-// sixth-order rotation) there and to rounding everywhere else.
-#define PSS_BAND 10.0
+#define PSS_BAND 60.0
 #define PSS_NARROW 0.01     // bands up to this take the short way through the exact branch
+#define PSS_TT 16           // steps per tile
 
-template <typename T, int BLOCK, int M>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void ps_smooth_kernel(PsParams P)
+// what a wave of either kernel starts with
+struct PssWave {
+    int k, chunk, lane;
+    double kxk;
+};
+
+// [chunk][k][tau] partial images -> TK = sum over chunks / snum (:492); n = nk * snum elements
+template <typename T> __global__ void ps_smooth_sum_kernel(const Cp<T> *__restrict__ part, Cp<T> *__restrict__ TK, int nchunks, size_t n, int snum)
 {
-    constexpr int TT = 16;
-    constexpr int NW = BLOCK / 64;
-    constexpr bool F32 = sizeof(T) == 4;
-    constexpr int ANCHOR_TILES = 4;                       // float32: anchors every 64 steps
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Cp<T> s = part[i];
+    for (int c = 1; c < nchunks; ++c) {
+        const Cp<T> v = part[(size_t)c * n + i];
+        s.x += v.x;
+        s.y += v.y;
+    }
+    s.x = s.x / (T)snum;
+    s.y = s.y / (T)snum;
+    TK[i] = s;
+}
+
+// the tile's 16 step sums of this lane's frequencies (acc[2 t], acc[2 t + 1]) -> summed over the wave -> row `out`
+template <typename T> __device__ __forceinline__ void pss_write_tile(T (&acc)[2 * PSS_TT], int lane, Cp<T> *out, int tau0, int snum, bool final_scale)
+{
+    wave_reduce_scatter<T, 2 * PSS_TT>(acc, lane);        // lane 2 i holds value i
+    const int tau = tau0 + (lane >> 2);
+    if ((lane & 1) == 0 && tau < snum) {
+        T *dst = reinterpret_cast<T *>(out + tau) + ((lane >> 1) & 1);
+        *dst = final_scale ? acc[0] / (T)snum : acc[0];
+    }
+}
+
+template <int M>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps_smooth_kernel(PsParams P)
+{
+    using T = double;
+    constexpr int TT = PSS_TT;
     // frequencies per group: their chains are independent (a wave that issues one dependent float64 operation after the
-    // other waits ~16 cycles for each), ONE branch per group for the band, and a group whose 64 G lanes-and-slots have
-    // all turned evanescent is skipped by its wave
+    // other waits ~16 cycles for each), ONE branch per group for the band, and a group whose frequencies have turned
+    // evanescent in all 64 lanes is skipped
     constexpr int G = M < 2 ? M : 2;
-    constexpr double BAND = F32 ? PSS_BAND : 6.0 * PSS_BAND;
-    extern __shared__ __attribute__((aligned(16))) char pss_smem[];
-    // [M][BLOCK] original spectrum (float32: the anchors rotate it) | [TT][BLOCK] per-step partial sums of a lane's
-    // frequencies | [2][NW][2 TT] wave sums
-    Cp<T> *f0_lds = reinterpret_cast<Cp<T> *>(pss_smem);
-    Cp<T> *part = reinterpret_cast<Cp<T> *>(pss_smem + (size_t)(F32 ? M : 0) * BLOCK * sizeof(Cp<T>));
-    T(*red)[NW][2 * TT] = reinterpret_cast<T(*)[NW][2 * TT]>(reinterpret_cast<char *>(part) + (size_t)TT * BLOCK * sizeof(Cp<T>));
-    // [2][TT] per-step constants {c = v^2, band, threshold, v}: written by 16 lanes a tile ahead, read by every lane as one
-    // broadcast (they were ~10 uniform float64 instructions and two vector loads per step and wave)
-    double4 *stepc = reinterpret_cast<double4 *>(reinterpret_cast<char *>(red) + (size_t)2 * NW * 2 * TT * sizeof(T));
-    const int k = P.k0 + blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ Cp<T> part[TT][64];                        // per-step partial sums of a lane's frequencies
+    __shared__ double4 stepc[2][TT];                      // the steps' {c = v^2, band, threshold, v}
+    const int k = P.k0 + blockIdx.x, chunk = gridDim.y - 1 - blockIdx.y;     // (the high, busy chunks first)
+    const int lane = threadIdx.x;
     const Cp<T> *F = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k * P.fstride;
-    Cp<T> *TK = reinterpret_cast<Cp<T> *>(P.TK) + (size_t)(k - P.k0) * P.snum;
+    Cp<T> *out = reinterpret_cast<Cp<T> *>(P.sm_nchunks > 1 ? P.sm_part : P.TK) +
+                 ((size_t)(P.sm_nchunks > 1 ? chunk : 0) * P.nk + (k - P.k0)) * P.snum;
+    const bool final_scale = P.sm_nchunks == 1;
     const double kxk = P.kx[k];
 
-    // per owned frequency: x = (kx / 2w)^2, w dt, y = sqrt(coss) and g ~ 1 / (2 y) of the last step; float32 data also
-    // the sum of y since the last anchor and the phase at that anchor
-    double x[M], wdt[M], y[M], g[M], ysum[F32 ? M : 1], Phi[F32 ? M : 1];
+    // per owned frequency: x = (kx / 2w)^2, w dt, y = sqrt(coss) and g ~ 1 / (2 y) of the last step
+    double x[M], wdt[M], y[M], g[M];
     T sr_[M], si_[M], rc[M], rs[M];                       // state FK and rotation R = exp(i phi)
-    T wdtT[F32 ? M : 1];
+    unsigned dead = 0;                                    // bit m: frequency m of this lane has turned evanescent
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-        const int slot = tid + m * BLOCK;
+        const int slot = (chunk * M + m) * 64 + lane;
         Cp<T> f;
         f.x = f.y = 0;
         double w = 1.0;
         if (slot < P.nf) {
             f = ps_load_slot<T>(F, P, slot);
             w = P.w[slot];
+        } else {
+            dead |= 1u << m;
         }
         const double a0 = 0.5 * kxk / w;
         x[m] = slot < P.nf ? a0 * a0 : 0.0;
         wdt[m] = w * P.dt;
-        if (F32) wdtT[F32 ? m : 0] = (T)wdt[m];
         y[m] = 1.0;
         g[m] = 0.5;
-        if (F32) {
-            ysum[F32 ? m : 0] = 0.0;
-            Phi[F32 ? m : 0] = 0.0;
-            f0_lds[m * BLOCK + tid] = f;
-        }
         sr_[m] = f.x;
         si_[m] = f.y;
         rc[m] = 1;
         rs[m] = 0;
     }
     auto step_constants = [&](int tile) {                 // lanes 0..15: the constants of tile `tile`
-        const int tau = tile * TT + tid;
-        if (tid < TT && tau < P.snum) {
+        const int tau = tile * TT + lane;
+        if (lane < TT && tau < P.snum) {
             const double vd = P.vz[tau], c = vd * vd;
             double csb = 4.0;                             // step 0: every lane from scratch
             if (tau > 0) {
                 const double vp = P.vz[tau - 1];
                 // band: coss below this moved too much relative to itself for the carried values
-                csb = BAND * fabs(c - vp * vp) / c + 1.0e-9;
+                csb = PSS_BAND * fabs(c - vp * vp) / c + 1.0e-9;
             }
-            stepc[(tile & 1) * TT + tid] = make_double4(c, csb, P.thr[tau], vd);
+            stepc[tile & 1][lane] = make_double4(c, csb, P.thr[tau], vd);
         }
     };
     step_constants(0);
-    __syncthreads();
-    unsigned dead = 0;                                    // bit m: frequency m of this lane has turned evanescent
     const int ntile = (P.snum + TT - 1) / TT;
     for (int tile = 0; tile < ntile; ++tile) {
         const int tau0 = tile * TT;
-        if (F32 && tile > 0 && tile % ANCHOR_TILES == 0) {
-            // anchor: the state from the ORIGINAL spectrum and the float64 phase, the rotation from its own phase
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
-                double ph = fma(wdt[m], ysum[F32 ? m : 0], Phi[F32 ? m : 0]);
-                ph -= 6.283185307179586 * rint(ph * 0.15915494309189535);
-                Phi[F32 ? m : 0] = ph;
-                ysum[F32 ? m : 0] = 0.0;
-                T sn, cs;
-                sincos_t<T>((T)ph, &sn, &cs);
-                const Cp<T> f0 = f0_lds[m * BLOCK + tid];
-                sr_[m] = fma(f0.x, cs, -(f0.y * sn));
-                si_[m] = fma(f0.x, sn, f0.y * cs);
-                sincos_t<T>((T)(wdt[m] * y[m]), &sn, &cs);
-                rc[m] = cs;
-                rs[m] = sn;
-                asm volatile("" : "+v"(sr_[m]), "+v"(si_[m]), "+v"(rc[m]), "+v"(rs[m]));
-            }
-        }
-        // groups all of whose frequencies, in all 64 lanes of this wave, are out: nothing to carry, nothing to add (the
-        // evanescent region v kx / 2 > w is a contiguous block of slots: 40 % of the plane at 1 m / 10 ns / 1.69e8 m/s)
+        __syncthreads();                                  // (one wave: orders the table's writes and reads)
+        step_constants(tile + 1);
+        // groups all of whose frequencies, in all 64 lanes, are out: nothing to carry, nothing to add
         unsigned gdead = 0;
+        bool all_out = true;
 #pragma unroll
         for (int m0 = 0; m0 < M; m0 += G) {
             bool alive = false;
 #pragma unroll
             for (int j = 0; j < G; ++j) alive = alive || !((dead >> (m0 + j)) & 1u);
             if (__builtin_amdgcn_ballot_w64(alive) == 0) gdead |= 1u << m0;
+            else all_out = false;
         }
-        gdead = __builtin_amdgcn_readfirstlane(gdead);
+        if (all_out) {                                    // uniform: zeros from here to the end of the record
+            Cp<T> z;
+            z.x = z.y = 0;
+            for (int tau = tau0 + lane; tau < P.snum; tau += 64) out[tau] = z;
+            return;
+        }
 #pragma unroll 1
         for (int t = 0; t < TT; ++t) {
             const int tau = tau0 + t;
             T psr = 0, psi = 0;
             if (tau < P.snum) {                                   // uniform
-                const double4 sc = stepc[(tile & 1) * TT + t];
+                const double4 sc = stepc[tile & 1][t];
                 const double c = sc.x, csb = sc.y;
 #define PSS_EACH for (int j = 0, m = m0; j < G; ++j, ++m)
 #define PSS_PIN(f)                                                                   \
@@ -158,8 +166,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
 #pragma unroll
                 for (int m0 = 0; m0 < M; m0 += G) {
                     if ((gdead >> m0) & 1u) continue;             // uniform
-                    // (a struct per frequency, not an array per quantity: arrays of two floats become <2 x float> and
-                    // the packed instructions that follows -- same rate as two plain ones -- cost moves to pack and unpack)
                     struct {
                         double cs, e1, y1, r, e2, y2, gn, dd;
                         T d, hd2, ur, ui, m1, m2, ncr, nsr;
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
                     PSS_PIN(cs);
                     // Newton steps for y = sqrt(cs) from the previous step's y, g ~ 1 / (2 y).  (g is refreshed BETWEEN
                     // the steps: with the previous step's g in both, the second step only gains a factor rho -- rho^3
-                    // left, 7e-8 on a float64 image of 700 steps; refreshed from y1 it is a true Newton step: rho^4)
+                    // left, 7e-8 on an image of 700 steps; refreshed from y1 it is a true Newton step: rho^4)
 #pragma unroll
                     PSS_EACH q[j].e1 = fma(-y[m], y[m], q[j].cs);
                     PSS_PIN(e1);
@@ -193,34 +199,31 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
 #pragma unroll
                     PSS_EACH q[j].y2 = fma(q[j].e2, q[j].gn, q[j].y1);
                     PSS_PIN(y2);
-                    if (!F32) {
-                        // float64 data: a third step (rho^4 = 2e-12 per step at the band's edge adds up over a record)
+                    // a third step (rho^4 = 2e-12 per step at the band's edge adds up over a record)
 #pragma unroll
-                        PSS_EACH q[j].e1 = fma(-q[j].y2, q[j].y2, q[j].cs);
-                        PSS_PIN(e1);
+                    PSS_EACH q[j].e1 = fma(-q[j].y2, q[j].y2, q[j].cs);
+                    PSS_PIN(e1);
 #pragma unroll
-                        PSS_EACH q[j].y2 = fma(q[j].e1, q[j].gn, q[j].y2);
-                        PSS_PIN(y2);
-                    }
-                    // R *= exp(i d), d = phi - phi_previous = w dt (y2 - y).  float32: 1 - d^2/2 + i d (re-anchored every
-                    // 64 steps; d^3/6 < 1e-12 but at the band's edge); float64: cos to d^6, sin to d^5 (with
+                    PSS_EACH q[j].y2 = fma(q[j].e1, q[j].gn, q[j].y2);
+                    PSS_PIN(y2);
+                    // R *= exp(i d), d = phi - phi_previous = w dt (y2 - y): cos to d^6, sin to d^5 (with
                     // 1 - d^2/2 + i (d - d^3/6) the modulus is 1 - d^4/24: a systematic loss, 6e-9 over 700 steps; at the
                     // band's edge d reaches 0.03)
 #pragma unroll
                     PSS_EACH q[j].dd = q[j].y2 - y[m];
                     PSS_PIN(dd);
 #pragma unroll
-                    PSS_EACH q[j].d = F32 ? (T)q[j].dd * wdtT[F32 ? m : 0] : (T)(q[j].dd * wdt[m]);
+                    PSS_EACH q[j].d = q[j].dd * wdt[m];
                     PSS_PIN(d);
 #pragma unroll
-                    PSS_EACH q[j].hd2 = q[j].d * q[j].d * (T)0.5;
+                    PSS_EACH q[j].hd2 = q[j].d * q[j].d * 0.5;
                     PSS_PIN(hd2);
 #pragma unroll
                     PSS_EACH {
                         // with h = d^2 / 2:  cos d = 1 - h + h^2/6 - h^3/90,  sin d = d (1 - h/3 + h^2/30)
                         const T h = q[j].hd2;
-                        q[j].ur = F32 ? (T)1 - h : fma(h, fma(h, fma(h, (T)(-1.0 / 90.0), (T)(1.0 / 6.0)), (T)-1), (T)1);
-                        q[j].ui = F32 ? q[j].d : q[j].d * fma(h, fma(h, (T)(1.0 / 30.0), (T)(-1.0 / 3.0)), (T)1);
+                        q[j].ur = fma(h, fma(h, fma(h, -1.0 / 90.0, 1.0 / 6.0), -1.0), 1.0);
+                        q[j].ui = q[j].d * fma(h, fma(h, 1.0 / 30.0, -1.0 / 3.0), 1.0);
                     }
                     PSS_PIN(ur);
 #pragma unroll
@@ -238,14 +241,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
                         any = any || q[j].band;
                     }
                     if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) != 0, 0)) {
-                        // (one or two frequencies of every wavenumber are in the band at any step of a smooth profile: this
-                        // branch is taken by one wave of the workgroup at almost every step, and what it costs counts)
                         const double thr = sc.z, vd = sc.w;
                         const bool narrow = csb <= PSS_NARROW;    // uniform
 #pragma unroll
                         PSS_EACH {
                             if (q[j].band) {
-                                const int slot = tid + m * BLOCK;
+                                const int slot = (chunk * M + m) * 64 + lane;
                                 double cr = q[j].cs;
                                 const bool cheap = narrow && fabs(cr - thr) > 1.0e-13;
                                 if (!cheap) {
@@ -254,18 +255,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
                                     const double a = ((0.5 * vd) * kxk) / wx;
                                     cr = 1.0 - a * a;
                                 }
-                                if (cr <= thr || !(slot < P.nf) || ((dead >> m) & 1u)) {
+                                if (cr <= thr || ((dead >> m) & 1u)) {
                                     // evanescent: zero from here on (:484-485 zero the spectrum itself: once out, out for
                                     // good -- a velocity that falls again must not revive the carried values of such a
                                     // lane, which are parked where they stay finite)
                                     dead |= 1u << m;
                                     sr_[m] = 0;
                                     si_[m] = 0;
-                                    if (F32) {
-                                        Cp<T> z;
-                                        z.x = z.y = 0;
-                                        f0_lds[m * BLOCK + tid] = z;
-                                    }
                                     x[m] = 0.0;
                                     q[j].y2 = 1.0;
                                     q[j].gn = 0.5;
@@ -285,29 +281,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
                                     y0 = fma(fma(-y0, y0, cr), h, y0);
                                     q[j].y2 = y0;
                                     q[j].gn = h;
-                                    const T ph = (T)(wdt[m] * y0), s2 = ph * ph;
-                                    T pc, ps;
-                                    if (F32) {
-                                        pc = fma(s2, fma(s2, fma(s2, fma(s2, (T)(1.0 / 40320), (T)(-1.0 / 720)), (T)(1.0 / 24)), (T)-0.5), (T)1);
-                                        ps = fma(s2, fma(s2, fma(s2, fma(s2, (T)(1.0 / 362880), (T)(-1.0 / 5040)), (T)(1.0 / 120)), (T)(-1.0 / 6)), (T)1);
-                                    } else {
-                                        pc = (T)(1.0 / 87178291200.0);                       // 1/14!
-                                        ps = (T)(1.0 / 1307674368000.0);                     // 1/15!
-                                        pc = fma(s2, -pc, (T)(1.0 / 479001600.0));           // 1/12!
-                                        ps = fma(s2, -ps, (T)(1.0 / 6227020800.0));          // 1/13!
-                                        pc = fma(s2, -pc, (T)(1.0 / 3628800.0));
-                                        ps = fma(s2, -ps, (T)(1.0 / 39916800.0));
-                                        pc = fma(s2, -pc, (T)(1.0 / 40320.0));
-                                        ps = fma(s2, -ps, (T)(1.0 / 362880.0));
-                                        pc = fma(s2, -pc, (T)(1.0 / 720.0));
-                                        ps = fma(s2, -ps, (T)(1.0 / 5040.0));
-                                        pc = fma(s2, -pc, (T)(1.0 / 24.0));
-                                        ps = fma(s2, -ps, (T)(1.0 / 120.0));
-                                        pc = fma(s2, -pc, (T)0.5);
-                                        ps = fma(s2, -ps, (T)(1.0 / 6.0));
-                                        pc = fma(s2, -pc, (T)1);
-                                        ps = fma(s2, -ps, (T)1);
-                                    }
+                                    const T ph = wdt[m] * y0, s2 = ph * ph;
+                                    T pc = 1.0 / 87178291200.0;                          // 1/14!
+                                    T ps = 1.0 / 1307674368000.0;                        // 1/15!
+                                    pc = fma(s2, -pc, 1.0 / 479001600.0);                // 1/12!
+                                    ps = fma(s2, -ps, 1.0 / 6227020800.0);               // 1/13!
+                                    pc = fma(s2, -pc, 1.0 / 3628800.0);
+                                    ps = fma(s2, -ps, 1.0 / 39916800.0);
+                                    pc = fma(s2, -pc, 1.0 / 40320.0);
+                                    ps = fma(s2, -ps, 1.0 / 362880.0);
+                                    pc = fma(s2, -pc, 1.0 / 720.0);
+                                    ps = fma(s2, -ps, 1.0 / 5040.0);
+                                    pc = fma(s2, -pc, 1.0 / 24.0);
+                                    ps = fma(s2, -ps, 1.0 / 120.0);
+                                    pc = fma(s2, -pc, 0.5);
+                                    ps = fma(s2, -ps, 1.0 / 6.0);
+                                    pc = fma(s2, -pc, 1.0);
+                                    ps = fma(s2, -ps, 1.0);
                                     q[j].ncr = pc;
                                     q[j].nsr = ps * ph;
                                 } else {
@@ -315,7 +305,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
                                     q[j].y2 = sqrt(cr);
                                     q[j].gn = 0.5 / q[j].y2;
                                     T sn, cn;
-                                    sincos_t<T>((T)(wdt[m] * q[j].y2), &sn, &cn);
+                                    sincos_t<T>(wdt[m] * q[j].y2, &sn, &cn);
                                     q[j].ncr = cn;
                                     q[j].nsr = sn;
                                 }
@@ -326,7 +316,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
                     PSS_EACH {
                         y[m] = q[j].y2;
                         g[m] = q[j].gn;
-                        if (F32) ysum[F32 ? m : 0] += q[j].y2;
                         rc[m] = q[j].ncr;
                         rs[m] = q[j].nsr;
                         const T nr = fma(sr_[m], q[j].ncr, -(si_[m] * q[j].nsr));     // FK *= exp(i phi), :464
@@ -344,60 +333,409 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
             Cp<T> pv;
             pv.x = psr;
             pv.y = psi;
-            part[t * BLOCK + tid] = pv;                   // (each lane reads back only what it wrote)
+            part[t][lane] = pv;                           // (each lane reads back only what it wrote)
         }
-        // ---- sum over frequencies: the tile's 16 step sums of this lane, wave butterfly, then across waves via LDS
         T acc[2 * TT];
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
-            const Cp<T> pv = part[t * BLOCK + tid];
+            const Cp<T> pv = part[t][lane];
             acc[2 * t] = pv.x;
             acc[2 * t + 1] = pv.y;
         }
-        wave_reduce_scatter<T, 2 * TT>(acc, lane);
-        T(*buf)[2 * TT] = red[tile & 1];
-        if ((lane & 1) == 0) buf[wave][lane >> 1] = acc[0];
-        step_constants(tile + 1);                         // (the other half of the table: last read a tile ago)
-        __syncthreads();
-        if (tid < 2 * TT) {
-            T s = 0;
-#pragma unroll
-            for (int q = 0; q < NW; ++q) s += buf[q][tid];
-            const int tau = tau0 + (tid >> 1);
-            if (tau < P.snum) {
-                T *dst = reinterpret_cast<T *>(TK + tau) + (tid & 1);
-                *dst = s / (T)P.snum;                                   // TK /= snum, :492
-            }
-        }
-        // red[] is double-buffered: the next tile writes the other buffer and the barrier of that tile orders it
+        pss_write_tile<T>(acc, lane, out, tau0, P.snum, final_scale);
     }
 }
 
-template <typename T, int BLOCK, int M> static size_t ps_smooth_lds()
+// ---------------------------------------------------------------------------------------------------------------
+// float32 data: expansion about one velocity per 16-step tile.
+//
+// The kernel above spends 14 of its ~32 instructions per (step, frequency) to carry y = sqrt(coss) in float64.  A float32
+// image needs float64 only where errors ADD UP: in the phase sum Phi that the anchors rotate the original spectrum by.
+// Both are taken from an expansion about the tile's middle velocity, c_a = (min + max)/2 of c = v^2 over the tile,
+// delta_t = c_t - c_a, per frequency xi = x / coss_a, u_t = xi delta_t:
+//     y_t = y_a sqrt(1 - u_t)
+//   * the phase sum of the whole tile at once, in float64, at the tile's start:
+//         sum_t y_t = y_a sum_p b_p xi^p S_p,   S_p = sum_t delta_t^p,  b_p the binomial series of sqrt(1 - u)
+//     -- S_p is the same for every frequency and wavenumber: the HOST folds Q_p = b_p S_p into a table
+//     (ps_smooth_tables), the kernel runs a 9-term Horner in xi per frequency and tile (|u| <= 0.1: 1e-11 left);
+//   * the step's rotation in float32: exp(i phi_t) = R_a exp(i psi_t), R_a = exp(i w dt y_a),
+//     psi_t = w dt y_a (sqrt(1 - u_t) - 1) from the hardware square root (absolute error 1e-7 w dt y_a: it does not add
+//     up, every step starts again from R_a), |psi| < 0.15: its sine and cosine from the series.  19 float32 instructions
+//     and the square root per (step, frequency); per (tile, frequency) ~40 float64 ones for y_a (hardware reciprocal root +
+//     two Newton steps), xi, the Horner, and the turn of R_a to the new tile's velocity.
+// Frequencies with |u| > 0.1 somewhere in the tile, or within reach of the threshold, are the band of this kernel:
+// they take the exact branch for all steps of the tile.  State anchors every 64 steps.
+#define PSS32_UMAX 0.1
+#define PSS32_NQ 9              // Q_0 .. Q_8
+#define PSS32_NARROW 0.02       // band lanes with coss up to this: phase < 0.45, sine and cosine from their series
+#define PSS32_TILE_DOUBLES 16   // per tile: Q_0..Q_8, [9] c_a, [10] max |delta|, [11] max threshold, [12] narrow
+
+// the per-step / per-tile tables of ps_smooth32_kernel (host, float64): step[4 tau + {0,1,2,3}] = {c, thr, v, delta}
+static void ps_smooth_tables(const double *vz, const double *thr, int snum, std::vector<double> &step, std::vector<double> &tile)
 {
-    return (size_t)(sizeof(T) == 4 ? M : 0) * BLOCK * sizeof(Cp<T>) + (size_t)16 * BLOCK * sizeof(Cp<T>) +
-           2 * (BLOCK / 64) * 32 * sizeof(T) + 2 * 16 * sizeof(double4);
+    const int ntile = (snum + 15) / 16;
+    step.assign((size_t)ntile * 16 * 4, 0.0);
+    tile.assign((size_t)ntile * PSS32_TILE_DOUBLES, 0.0);
+    for (int t = 0; t < ntile; ++t) {
+        const int t0 = t * 16, n = std::min(16, snum - t0);
+        double cmin = vz[t0] * vz[t0], cmax = cmin, thrmax = thr[t0];
+        for (int i = 1; i < n; ++i) {
+            const double c = vz[t0 + i] * vz[t0 + i];
+            cmin = std::min(cmin, c);
+            cmax = std::max(cmax, c);
+            thrmax = std::max(thrmax, thr[t0 + i]);
+        }
+        const double ca = 0.5 * (cmin + cmax);
+        double *q = &tile[(size_t)t * PSS32_TILE_DOUBLES];
+        double dmax = 0.0, pw[16];
+        for (int i = 0; i < 16; ++i) {
+            const int tau = t0 + std::min(i, n - 1);
+            const double c = vz[tau] * vz[tau];
+            double *sp = &step[(size_t)(t0 + i) * 4];
+            sp[0] = c;
+            sp[1] = thr[tau];
+            sp[2] = vz[tau];
+            sp[3] = c - ca;
+            if (i < n) dmax = std::max(dmax, std::fabs(c - ca));
+            pw[i] = 1.0;
+        }
+        double b = 1.0;
+        for (int p = 0; p < PSS32_NQ; ++p) {
+            if (p == 1) b = -0.5;
+            if (p >= 2) b *= (2.0 * p - 3.0) / (2.0 * p);
+            double sum = 0.0;
+            for (int i = 0; i < n; ++i) {
+                sum += pw[i];
+                pw[i] *= step[(size_t)(t0 + i) * 4 + 3];
+            }
+            q[p] = b * sum;
+        }
+        q[9] = ca;
+        q[10] = dmax;
+        q[11] = thrmax;
+        // the band's lanes: coss_a < x dmax / UMAX (+ the threshold's reach), coss_t <= coss_a + x dmax, x <= 1 / cmin while
+        // the lane propagates
+        q[12] = ((1.0 / PSS32_UMAX + 1.0) * dmax / cmin + 2.0 * thrmax + 1e-12 <= PSS32_NARROW) ? 1.0 : 0.0;
+    }
 }
 
-template <typename T, int BLOCK, int M> static void ps_smooth_launch_one(const PsParams &P, hipStream_t st)
+// four uniform doubles through the scalar cache (load and wait in one statement, see scalar_load_2f64)
+__device__ __forceinline__ void pss_scalar_load_4f64(const double *p, double *a, double *b, double *c, double *d)
 {
-    auto k = ps_smooth_kernel<T, BLOCK, M>;
-    const size_t lds = ps_smooth_lds<T, BLOCK, M>();
-    (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(P.nk), dim3(BLOCK), lds, st, P);
+    double x, y, z, w;
+    asm volatile("s_load_dwordx2 %0, %4, 0x0\n\ts_load_dwordx2 %1, %4, 0x8\n\ts_load_dwordx2 %2, %4, 0x10\n\t"
+                 "s_load_dwordx2 %3, %4, 0x18\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(x), "=&s"(y), "=&s"(z), "=&s"(w)
+                 : "s"(p)
+                 : "memory");
+    *a = x;
+    *b = y;
+    *c = z;
+    *d = w;
 }
 
-// true when a kernel was launched (frequency counts it is instantiated for)
-template <typename T> static bool ps_smooth_launch(const PsParams &P, hipStream_t st)
+template <int M>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps_smooth32_kernel(PsParams P)
 {
-    const int nf = P.nf;
-    if (nf <= 64) ps_smooth_launch_one<T, 64, 1>(P, st);
-    else if (nf <= 128) ps_smooth_launch_one<T, 128, 1>(P, st);
-    else if (nf <= 256) ps_smooth_launch_one<T, 256, 1>(P, st);
-    else if (nf <= 512) ps_smooth_launch_one<T, 512, 1>(P, st);
-    else if (nf <= 1024) ps_smooth_launch_one<T, 512, 2>(P, st);
-    else if (nf <= 2048) ps_smooth_launch_one<T, 512, 4>(P, st);
-    else if (nf <= 4096) ps_smooth_launch_one<T, 512, 8>(P, st);
-    else return false;
-    return true;
+    using T = float;
+    constexpr int TT = PSS_TT;
+    constexpr int ANCHOR_TILES = 4;
+    constexpr int G = M < 2 ? M : 2;
+    __shared__ Cp<T> f0_lds[M][64];                       // original spectrum (the anchors rotate it)
+    __shared__ Cp<T> part[TT][64];                        // per-step partial sums of a lane's frequencies
+    __shared__ double4 stepc[2][TT];                      // the steps' {c, thr, v, delta}
+    const int k = P.k0 + blockIdx.x, chunk = gridDim.y - 1 - blockIdx.y;     // (the high, busy chunks first)
+    const int lane = threadIdx.x;
+    const Cp<T> *F = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k * P.fstride;
+    Cp<T> *out = reinterpret_cast<Cp<T> *>(P.sm_nchunks > 1 ? P.sm_part : P.TK) +
+                 ((size_t)(P.sm_nchunks > 1 ? chunk : 0) * P.nk + (k - P.k0)) * P.snum;
+    const bool final_scale = P.sm_nchunks == 1;
+    const double kxk = P.kx[k];
+    const double4 *gstep = reinterpret_cast<const double4 *>(P.sm_step);
+
+    double x[M], wdt[M], Phi[M], Kp[M];                   // (kx / 2w)^2, w dt, phase at the END of the tile, w dt y_a
+    T sr_[M], si_[M], ca[M], sa[M], xi[M], Kf[M];         // state FK, R_a = exp(i w dt y_a), x / coss_a, w dt y_a
+    unsigned dead = 0;                                    // bit m: frequency m of this lane has turned evanescent
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int slot = (chunk * M + m) * 64 + lane;
+        Cp<T> f;
+        f.x = f.y = 0;
+        double w = 1.0;
+        if (slot < P.nf) {
+            f = ps_load_slot<T>(F, P, slot);
+            w = P.w[slot];
+        } else {
+            dead |= 1u << m;
+        }
+        const double a0 = 0.5 * kxk / w;
+        x[m] = slot < P.nf ? a0 * a0 : 0.0;
+        wdt[m] = w * P.dt;
+        Phi[m] = 0.0;
+        Kp[m] = 0.0;
+        f0_lds[m][lane] = f;
+        sr_[m] = f.x;
+        si_[m] = f.y;
+        ca[m] = 1;
+        sa[m] = 0;
+        xi[m] = 0;
+        Kf[m] = 0;
+    }
+    if (lane < TT) stepc[0][lane] = gstep[lane];
+    const int ntile = (P.snum + TT - 1) / TT;
+    for (int tile = 0; tile < ntile; ++tile) {
+        const int tau0 = tile * TT;
+        const bool anchor = tile % ANCHOR_TILES == 0;
+        __syncthreads();                                  // (one wave: orders the table's writes and reads)
+        if (lane < TT && tile + 1 < ntile) stepc[(tile + 1) & 1][lane] = gstep[(size_t)(tile + 1) * TT + lane];
+        if (anchor && tile > 0) {
+            // the state from the ORIGINAL spectrum and the float64 phase (which stands at the end of the last tile)
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                double ph = Phi[m];
+                ph -= 6.283185307179586 * rint(ph * 0.15915494309189535);
+                Phi[m] = ph;
+                T sn, cs;
+                sincos_t<T>((T)ph, &sn, &cs);
+                const Cp<T> f0 = f0_lds[m][lane];
+                sr_[m] = fma(f0.x, cs, -(f0.y * sn));
+                si_[m] = fma(f0.x, sn, f0.y * cs);
+                asm volatile("" : "+v"(sr_[m]), "+v"(si_[m]));
+            }
+        }
+        // ---- this tile's expansion
+        double tq[PSS32_TILE_DOUBLES];
+        {
+            const double *gt = P.sm_tile + (size_t)tile * PSS32_TILE_DOUBLES;
+#pragma unroll
+            for (int i = 0; i < 12; i += 4) pss_scalar_load_4f64(gt + i, &tq[i], &tq[i + 1], &tq[i + 2], &tq[i + 3]);
+            tq[12] = gt[12];
+        }
+        const double c_a = tq[9], dmax = tq[10], thrmax = tq[11];
+        const bool narrow = tq[12] != 0.0;
+        unsigned bandm = 0;                               // bit m: frequency m of this lane takes the exact branch this tile
+        unsigned gdead = 0, gband = 0;                    // (uniform) bit m0: group all out / has a lane in the band
+        bool all_out = true;
+#pragma unroll
+        for (int m0 = 0; m0 < M; m0 += G) {
+            bool alive = false;
+#pragma unroll
+            for (int j = 0; j < G; ++j) alive = alive || !((dead >> (m0 + j)) & 1u);
+            if (__builtin_amdgcn_ballot_w64(alive) == 0) {         // uniform
+                gdead |= 1u << m0;
+                continue;
+            }
+            all_out = false;
+            bool anyband = false;
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int m = m0 + j;
+                const double cs_a = fma(-c_a, x[m], 1.0);
+                const bool band = !(cs_a * PSS32_UMAX > x[m] * dmax) || !(cs_a * 0.75 > thrmax + 1.0e-13);
+                if (band) bandm |= 1u << m;
+                anyband = anyband || band;
+                const double csu = band ? 1.0 : cs_a;     // (band lanes: any finite stand-in, they overwrite what it gives)
+                const double r0 = __builtin_amdgcn_rsq(csu);
+                double y0 = csu * r0, h = 0.5 * r0;
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    y0 = fma(fma(-y0, y0, csu), h, y0);
+                    h = fma(h, fma(-(y0 + y0), h, 1.0), h);
+                }
+                y0 = fma(fma(-y0, y0, csu), h, y0);
+                const double t2 = h + h, xid = t2 * t2 * x[m];     // x / coss_a
+                double H = tq[PSS32_NQ - 1];
+#pragma unroll
+                for (int p = PSS32_NQ - 2; p >= 0; --p) H = fma(H, xid, tq[p]);
+                const double K = wdt[m] * y0;
+                if (!band) Phi[m] = fma(K, H, Phi[m]);     // the whole tile's phase (band lanes add theirs step by step)
+                xi[m] = (T)xid;
+                const T K32 = (T)K;
+                Kf[m] = K32;
+                // R_a: turned from the last tile's by the series in dK, from scratch at the anchors and after jumps
+                const T dK = (T)(K - Kp[m]);
+                Kp[m] = K;
+                if (anchor || !(fabsf(dK) <= 0.2f)) {
+                    const T klo = (T)(K - (double)K32);
+                    T sn, cn;
+                    sincos_t<T>(K32, &sn, &cn);
+                    ca[m] = fma(-sn, klo, cn);
+                    sa[m] = fma(cn, klo, sn);
+                } else {
+                    const T s2 = dK * dK;
+                    const T ec = fma(s2, fma(s2, fma(s2, (T)(-1.0 / 720), (T)(1.0 / 24)), (T)-0.5), (T)1);
+                    const T es = dK * fma(s2, fma(s2, (T)(1.0 / 120), (T)(-1.0 / 6)), (T)1);
+                    const T nc = fma(ca[m], ec, -(sa[m] * es));
+                    const T ns = fma(ca[m], es, sa[m] * ec);
+                    ca[m] = nc;
+                    sa[m] = ns;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(anyband) != 0) gband |= 1u << m0;
+        }
+        if (all_out) {                                    // uniform: zeros from here to the end of the record
+            Cp<T> z;
+            z.x = z.y = 0;
+            for (int tau = tau0 + lane; tau < P.snum; tau += 64) out[tau] = z;
+            return;
+        }
+        gdead = __builtin_amdgcn_readfirstlane(gdead);
+        gband = __builtin_amdgcn_readfirstlane(gband);
+#pragma unroll 1
+        for (int t = 0; t < TT; ++t) {
+            const int tau = tau0 + t;
+            T psr = 0, psi = 0;
+            if (tau < P.snum) {                                   // uniform
+                const double4 sc = stepc[tile & 1][t];
+                const T dl = (T)sc.w;
+#define PSS_EACH for (int j = 0, m = m0; j < G; ++j, ++m)
+#define PSS_PIN(f)                                                                   \
+    do {                                                                             \
+        if constexpr (G == 2) asm volatile("" : "+v"(q[0].f), "+v"(q[G > 1 ? 1 : 0].f)); \
+        else asm volatile("" : "+v"(q[0].f));                                        \
+    } while (0)
+#pragma unroll
+                for (int m0 = 0; m0 < M; m0 += G) {
+                    if ((gdead >> m0) & 1u) continue;             // uniform
+                    struct {
+                        T w, s, psi, s2, ec, es, m1, m2, ncr, nsr;
+                    } q[G];
+#pragma unroll
+                    PSS_EACH q[j].w = fma(-xi[m], dl, (T)1);
+                    PSS_PIN(w);
+#pragma unroll
+                    PSS_EACH q[j].s = __builtin_amdgcn_sqrtf(q[j].w);
+                    PSS_PIN(s);
+#pragma unroll
+                    PSS_EACH q[j].psi = fma(Kf[m], q[j].s, -Kf[m]);
+                    PSS_PIN(psi);
+#pragma unroll
+                    PSS_EACH q[j].s2 = q[j].psi * q[j].psi;
+                    PSS_PIN(s2);
+#pragma unroll
+                    PSS_EACH {
+                        q[j].ec = fma(q[j].s2, (T)(1.0 / 24), (T)-0.5);
+                        q[j].es = fma(q[j].s2, (T)(1.0 / 120), (T)(-1.0 / 6));
+                    }
+                    PSS_PIN(ec);
+                    PSS_PIN(es);
+#pragma unroll
+                    PSS_EACH {
+                        q[j].ec = fma(q[j].s2, q[j].ec, (T)1);
+                        q[j].es = fma(q[j].s2, q[j].es, (T)1);
+                    }
+                    PSS_PIN(ec);
+                    PSS_PIN(es);
+#pragma unroll
+                    PSS_EACH q[j].es = q[j].es * q[j].psi;
+                    PSS_PIN(es);
+#pragma unroll
+                    PSS_EACH {
+                        q[j].m1 = sa[m] * q[j].es;
+                        q[j].m2 = sa[m] * q[j].ec;
+                    }
+                    PSS_PIN(m1);
+                    PSS_PIN(m2);
+#pragma unroll
+                    PSS_EACH {
+                        q[j].ncr = fma(ca[m], q[j].ec, -q[j].m1);
+                        q[j].nsr = fma(ca[m], q[j].es, q[j].m2);
+                    }
+                    if (__builtin_expect((gband >> m0) & 1u, 0)) {       // uniform
+                        const double c = sc.x, thr = sc.y, vd = sc.z;
+#pragma unroll
+                        PSS_EACH {
+                            if ((bandm >> m) & 1u) {
+                                const int slot = (chunk * M + m) * 64 + lane;
+                                double cr = fma(-c, x[m], 1.0);
+                                const bool cheap = narrow && cr < PSS32_NARROW && fabs(cr - thr) > 1.0e-13;
+                                if (!cheap) {
+                                    // coss in the reference's own rounding (:456-460): what decides at the threshold
+                                    const double wx = slot < P.nf ? P.w[slot] : 1.0;
+                                    const double a = ((0.5 * vd) * kxk) / wx;
+                                    cr = 1.0 - a * a;
+                                }
+                                if (cr <= thr || ((dead >> m) & 1u)) {
+                                    // evanescent: zero from here on (:484-485 zero the spectrum itself: once out, out for good)
+                                    dead |= 1u << m;
+                                    sr_[m] = 0;
+                                    si_[m] = 0;
+                                    Cp<T> z;
+                                    z.x = z.y = 0;
+                                    f0_lds[m][lane] = z;
+                                    x[m] = 0.0;
+                                    q[j].ncr = 1;
+                                    q[j].nsr = 0;
+                                } else if (cheap) {
+                                    // the phase w dt sqrt(coss) < 0.45: float32 is enough for this step's rotation AND for the
+                                    // phase sum (relative 1e-7 of a small phase, over the few dozen steps a frequency
+                                    // spends in the band: 1e-6 rad)
+                                    const T y32 = __builtin_amdgcn_sqrtf((T)cr);
+                                    const T ph = (T)wdt[m] * y32, s2 = ph * ph;
+                                    Phi[m] += (double)ph;
+                                    q[j].ncr = fma(s2, fma(s2, fma(s2, fma(s2, (T)(1.0 / 40320), (T)(-1.0 / 720)), (T)(1.0 / 24)), (T)-0.5), (T)1);
+                                    q[j].nsr = ph * fma(s2, fma(s2, fma(s2, fma(s2, (T)(1.0 / 362880), (T)(-1.0 / 5040)), (T)(1.0 / 120)), (T)(-1.0 / 6)), (T)1);
+                                } else {
+                                    const double phd = wdt[m] * sqrt(cr);            // :456-464
+                                    Phi[m] += phd;
+                                    T sn, cn;
+                                    sincos_t<T>((T)phd, &sn, &cn);
+                                    q[j].ncr = cn;
+                                    q[j].nsr = sn;
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    PSS_EACH {
+                        const T nr = fma(sr_[m], q[j].ncr, -(si_[m] * q[j].nsr));     // FK *= exp(i phi), :464
+                        const T ni = fma(sr_[m], q[j].nsr, si_[m] * q[j].ncr);
+                        sr_[m] = nr;
+                        si_[m] = ni;
+                        psr += nr;                                                  // :487
+                        psi += ni;
+                    }
+                    asm volatile("" : "+v"(psr), "+v"(psi));
+                }
+#undef PSS_PIN
+#undef PSS_EACH
+            }
+            Cp<T> pv;
+            pv.x = psr;
+            pv.y = psi;
+            part[t][lane] = pv;                           // (each lane reads back only what it wrote)
+        }
+        T acc[2 * TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const Cp<T> pv = part[t][lane];
+            acc[2 * t] = pv.x;
+            acc[2 * t + 1] = pv.y;
+        }
+        pss_write_tile<T>(acc, lane, out, tau0, P.snum, final_scale);
+    }
+}
+
+// frequencies per wave: 64 M.  One chunk while the frequencies fit a wave (M up to 8), chunks of 512 beyond.
+template <typename T, int M> static void ps_smooth_launch_one(const PsParams &P, int nchunks, hipStream_t st)
+{
+    if constexpr (sizeof(T) == 4) hipLaunchKernelGGL(ps_smooth32_kernel<M>, dim3(P.nk, nchunks), dim3(64), 0, st, P);
+    else hipLaunchKernelGGL(ps_smooth_kernel<M>, dim3(P.nk, nchunks), dim3(64), 0, st, P);
+}
+
+static int ps_smooth_chunks(int nf) { return nf <= 512 ? 1 : (nf + 511) / 512; }
+
+// P.sm_nchunks (and, beyond one chunk, P.sm_part: [chunks][nk][snum] complex) set by the caller
+template <typename T> static void ps_smooth_launch(const PsParams &P, hipStream_t st)
+{
+    const int nf = P.nf, nchunks = P.sm_nchunks;
+    if (nf <= 64) ps_smooth_launch_one<T, 1>(P, 1, st);
+    else if (nf <= 128) ps_smooth_launch_one<T, 2>(P, 1, st);
+    else if (nf <= 256) ps_smooth_launch_one<T, 4>(P, 1, st);
+    else ps_smooth_launch_one<T, 8>(P, nchunks, st);
+    if (nchunks > 1) {
+        const size_t n = (size_t)P.nk * P.snum;
+        hipLaunchKernelGGL((ps_smooth_sum_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<const Cp<T> *>(P.sm_part), reinterpret_cast<Cp<T> *>(P.TK), nchunks, n, P.snum);
+    }
 }
