@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """One-off sweep of the pipelined one-shot Kirchhoff call (GPU box; not part of the pytest suites): random large
 geometries -- trace counts off the 8-trace groups, apertures from a tenth of the profile to all of it, float32 and
-float64, far and near field -- migrated with IMPDAR_KIRCH_ONESHOT_SPLIT=1 (upload in trace chunks, several launches,
-downloads underneath) and =0 (one upload, one launch, one download): the two must be BIT-EQUAL.
+float64, far and near field -- migrated in pieces (the default: upload in trace chunks, several launches, downloads
+underneath), as ONE persistent launch that waits for its input on the device (IMPDAR_KIRCH_ONESHOT_SPLIT=persistent) and
+with =0 (one upload, one launch, one download): the three must be BIT-EQUAL.
 
     python tests/tools/fuzz_oneshot_pieces.py [ncases] [seed]
 """
@@ -19,12 +20,11 @@ from impdar_amd import synth                                    # noqa: E402
 from impdar_amd.lib.RadarData import RadarData                  # noqa: E402
 
 
-def run(x, geo, snum, tnum, vel, nearfield, split, cuts):
-    os.environ['IMPDAR_KIRCH_ONESHOT_SPLIT'] = split
-    if cuts:
-        os.environ['IMPDAR_KIRCH_ONESHOT_CUTS'] = cuts
+def run(x, geo, snum, tnum, vel, nearfield, split):
+    if split:
+        os.environ['IMPDAR_KIRCH_ONESHOT_SPLIT'] = split
     else:
-        os.environ.pop('IMPDAR_KIRCH_ONESHOT_CUTS', None)
+        os.environ.pop('IMPDAR_KIRCH_ONESHOT_SPLIT', None)
     d = RadarData(None)
     d.data, d.snum, d.tnum = x, snum, tnum
     d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
@@ -47,15 +47,15 @@ def main():
         dt = float(rng.choice([1e-8, 5e-9]))
         vel = float(rng.choice([1.69e8, 1.68e8, 2.0e8]))
         nearfield = bool(rng.random() < 0.25)
-        cuts = str(rng.choice(['', '', '5,30,60', '20,50', '10,25,45,70,90']))
         geo = synth.geometry(snum, tnum, dt=dt, dx=dx)
         x = synth.noise_radargram(snum, tnum, seed=int(rng.integers(1 << 30))).astype(dtype)
-        a = run(x, geo, snum, tnum, vel, nearfield, '1', cuts)
-        b = run(x, geo, snum, tnum, vel, nearfield, '0', '')
-        ok = np.array_equal(a, b) and np.isfinite(a).all() and a.any()
+        a = run(x, geo, snum, tnum, vel, nearfield, '')
+        c = run(x, geo, snum, tnum, vel, nearfield, 'persistent')
+        b = run(x, geo, snum, tnum, vel, nearfield, '0')
+        ok = np.array_equal(a, b) and np.array_equal(c, b) and np.isfinite(a).all() and a.any()
         bad += 0 if ok else 1
-        print('%3d %s snum %4d tnum %5d dx %4.1f dt %.0e vel %.3g near %d cuts %-14s %s'
-              % (case, np.dtype(dtype).name, snum, tnum, dx, dt, vel, nearfield, cuts or 'default', 'bit-equal' if ok else 'MISS'), flush=True)
+        print('%3d %s snum %4d tnum %5d dx %4.1f dt %.0e vel %.3g near %d %s'
+              % (case, np.dtype(dtype).name, snum, tnum, dx, dt, vel, nearfield, 'bit-equal' if ok else 'MISS'), flush=True)
     print('cases %d, misses %d, %.0f s' % (ncases, bad, time.time() - t_start))
     sys.exit(1 if bad else 0)
 
