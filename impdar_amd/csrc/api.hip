@@ -156,8 +156,47 @@ void impdar_release_caches()
     impdar_ps_trim();
 }
 
+static void pinned_adopt(impdar_ctx *ctx)
+{
+    if (ctx->pin_thread.joinable()) ctx->pin_thread.join();
+    if (ctx->pin_next) {
+        if (ctx->pin_next_bytes > ctx->pinned_bytes) {
+            if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+            ctx->pinned = ctx->pin_next;
+            ctx->pinned_bytes = ctx->pin_next_bytes;
+        } else {
+            (void)hipHostFree(ctx->pin_next);
+        }
+        ctx->pin_next = nullptr;
+        ctx->pin_next_bytes = 0;
+    }
+}
+
+void impdar_ctx_pinned_prefetch(impdar_ctx *ctx, size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(ctx->pinned_mu);
+    if (bytes < ((size_t)1 << 20) || bytes <= ctx->pinned_bytes || bytes > ((size_t)1 << 30)) return;
+    if (ctx->pin_thread.joinable()) {
+        if (ctx->pin_next_bytes >= bytes) return;          // one on its way that will do
+        pinned_adopt(ctx);
+        if (bytes <= ctx->pinned_bytes) return;
+    }
+    ctx->pin_next_bytes = bytes;
+    const int device = ctx->device;
+    ctx->pin_thread = std::thread([ctx, device, bytes] {
+        void *p = nullptr;
+        if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+        }
+        ctx->pin_next = p;          // (read after the join)
+    });
+}
+
+// (callers hold ctx->pinned_mu)
 void *impdar_ctx_pinned(impdar_ctx *ctx, size_t bytes)
 {
+    pinned_adopt(ctx);
     if (bytes <= ctx->pinned_bytes) return ctx->pinned;
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     ctx->pinned = nullptr;
@@ -327,8 +366,13 @@ int impdar_download_blocks_f64(impdar_ctx *ctx, double *dst_host, size_t ld, siz
     size_t total = 0;
     for (int i = 0; i < nblk; ++i) total += rows * width[i] * elem_in;
     if (total == 0) return IMPDAR_OK;
+    // The staging buffer is a RING of at most 64 MB (round 4; the whole image before): pinning costs 0.22 ms per MB, and
+    // the 164 MB of a config-3 image were the largest term of a process's first call.  Pieces of <= 16 MB go round it:
+    // the copy of a piece is enqueued as soon as the ring has room, i.e. once the host has widened the piece that held
+    // that room; up to four are in flight.
+    const size_t cap = std::min(total, IMPDAR_STAGE_RING_BYTES);
     std::unique_lock<std::mutex> lock(ctx->pinned_mu);
-    char *stage = reinterpret_cast<char *>(impdar_ctx_pinned(ctx, total));
+    char *stage = reinterpret_cast<char *>(impdar_ctx_pinned(ctx, cap));
     if (!stage) {
         // no pinned memory: block by block through the single-block path
         lock.unlock();
@@ -341,39 +385,35 @@ int impdar_download_blocks_f64(impdar_ctx *ctx, double *dst_host, size_t ld, siz
     }
     struct Piece {
         int blk;
-        size_t r0, nr, off;
+        size_t r0, nr, off, bytes;
         hipEvent_t ev;
     };
     std::vector<Piece> pieces;
-    int rc = IMPDAR_OK;
-    size_t off = 0;
-    for (int i = 0; i < nblk && rc == IMPDAR_OK; ++i) {
+    for (int i = 0; i < nblk; ++i) {
         if (width[i] == 0) continue;
         const size_t bytes = rows * width[i] * elem_in;
-        // pieces of >= 16 MB, at most 4 per block: every piece costs a start of the host threads
-        const size_t np = std::min<size_t>(4, std::max<size_t>(1, bytes / ((size_t)16 << 20)));
-        if (after[i] && hipStreamWaitEvent(st, after[i], 0) != hipSuccess) rc = IMPDAR_ERR_HIP;
-        for (size_t c = 0; c < np && rc == IMPDAR_OK; ++c) {
+        const size_t np = std::min(rows, std::max<size_t>(1, (bytes + (cap / 4) - 1) / (cap / 4)));
+        for (size_t c = 0; c < np; ++c) {
             Piece q;
             q.blk = i;
             q.r0 = rows * c / np;
             q.nr = rows * (c + 1) / np - q.r0;
-            q.off = off;
+            q.off = 0;
+            q.bytes = q.nr * width[i] * elem_in;
             q.ev = nullptr;
-            const size_t pb = q.nr * width[i] * elem_in;
-            if (hipEventCreateWithFlags(&q.ev, hipEventDisableTiming) != hipSuccess) {
-                rc = IMPDAR_ERR_HIP;
-                break;
+            if (q.bytes > cap) {                              // (a single row wider than the ring: cannot happen below 64 MB per row)
+                lock.unlock();
+                impdar_set_error("download: a piece of %zu bytes does not fit the staging ring", q.bytes);
+                return IMPDAR_ERR_ARG;
             }
             pieces.push_back(q);
-            if (hipMemcpyAsync(stage + off, reinterpret_cast<const char *>(src[i]) + q.r0 * width[i] * elem_in, pb,
-                               hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipEventRecord(q.ev, st) != hipSuccess)
-                rc = IMPDAR_ERR_HIP;
-            off += pb;
         }
     }
-    for (const Piece &q : pieces) {
+    int rc = IMPDAR_OK;
+    size_t head = 0, inflight = 0, done_k = 0;          // ring write offset, bytes enqueued and not yet widened, next piece to widen
+    int last_waited = -1;
+    auto widen_next = [&]() {
+        Piece &q = pieces[done_k++];
         if (rc == IMPDAR_OK && hipEventSynchronize(q.ev) != hipSuccess) rc = IMPDAR_ERR_HIP;
         if (rc == IMPDAR_OK) {
             const size_t w = width[q.blk], c0 = col0[q.blk], r0 = q.r0;
@@ -391,7 +431,49 @@ int impdar_download_blocks_f64(impdar_ctx *ctx, double *dst_host, size_t ld, siz
                 }
             });
         }
+        inflight -= q.bytes;
+    };
+    for (size_t k = 0; k < pieces.size() && rc == IMPDAR_OK; ++k) {
+        Piece &q = pieces[k];
+        // room: contiguous from `head`, else from the ring's start once everything in flight has been widened past it
+        for (;;) {
+            if (head + q.bytes <= cap && inflight + q.bytes <= cap) {
+                // (pieces are widened in order, so what lies at [head, head + bytes) is either free or belongs to a piece
+                // still in flight further round: the second condition keeps the total inside the ring, and a wrap below
+                // only happens onto widened pieces)
+                bool clash = false;
+                for (size_t j = done_k; j < k; ++j)
+                    if (pieces[j].off < head + q.bytes && head < pieces[j].off + pieces[j].bytes) clash = true;
+                if (!clash) break;
+            } else if (head + q.bytes > cap) {
+                head = 0;
+                continue;
+            }
+            if (done_k >= k) {                                // nothing left to free: cannot happen (q.bytes <= cap)
+                rc = IMPDAR_ERR_HIP;
+                break;
+            }
+            widen_next();
+        }
+        if (rc) break;
+        if (after[q.blk] && last_waited != q.blk) {
+            if (hipStreamWaitEvent(st, after[q.blk], 0) != hipSuccess) rc = IMPDAR_ERR_HIP;
+            last_waited = q.blk;
+        }
+        q.off = head;
+        if (rc == IMPDAR_OK && hipEventCreateWithFlags(&q.ev, hipEventDisableTiming) != hipSuccess) {
+            q.ev = nullptr;
+            rc = IMPDAR_ERR_HIP;
+        }
+        if (rc == IMPDAR_OK &&
+            (hipMemcpyAsync(stage + q.off, reinterpret_cast<const char *>(src[q.blk]) + q.r0 * width[q.blk] * elem_in, q.bytes,
+                            hipMemcpyDeviceToHost, st) != hipSuccess ||
+             hipEventRecord(q.ev, st) != hipSuccess))
+            rc = IMPDAR_ERR_HIP;
+        head += q.bytes;
+        inflight += q.bytes;
     }
+    while (rc == IMPDAR_OK && done_k < pieces.size() && pieces[done_k].ev) widen_next();
     if (rc) {
         // no DMA into the staging buffer may still be in flight when it is handed to the next caller
         (void)hipStreamSynchronize(st);
@@ -399,11 +481,6 @@ int impdar_download_blocks_f64(impdar_ctx *ctx, double *dst_host, size_t ld, siz
     }
     for (const Piece &q : pieces)
         if (q.ev) (void)hipEventDestroy(q.ev);
-    if (ctx->pinned_bytes > ((size_t)1 << 30)) {
-        (void)hipHostFree(ctx->pinned);
-        ctx->pinned = nullptr;
-        ctx->pinned_bytes = 0;
-    }
     return rc;
 }
 
@@ -427,6 +504,7 @@ extern "C" void impdar_ctx_destroy(impdar_ctx *ctx)
     impdar_ps_forget(ctx);
     impdar_kirch_forget(ctx);
     impdar_preproc_forget(ctx);
+    pinned_adopt(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->ev_produced) (void)hipEventDestroy(ctx->ev_produced);
     if (ctx->ev_tic) (void)hipEventDestroy(ctx->ev_tic);

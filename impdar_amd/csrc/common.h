@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 #include "../../include/impdar_hip.h"
@@ -26,6 +27,11 @@ struct impdar_ctx {
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
     std::mutex pinned_mu;           // held for a whole staged download (the buffer may be re-allocated by the next one)
+    // a staging buffer on its way: allocated by a thread of its own while the call that will need it plans, uploads and
+    // computes (hipHostMalloc pins ~4.5 GB/s: 36 ms for the 164 MB of a config-3 image -- the largest term of a first call)
+    std::thread pin_thread;
+    void *pin_next = nullptr;
+    size_t pin_next_bytes = 0;
     // last work enqueued on `stream` by a *_dev entry point that WRITES a caller-visible device array; consumers
     // on the producer stream (impdar_kirch_prep) wait for it
     hipEvent_t ev_produced = nullptr;
@@ -44,6 +50,10 @@ struct impdar_ctx {
     char m_extra[320] = "";
 };
 
+// the staging ring of impdar_download_blocks_f64
+constexpr size_t IMPDAR_STAGE_RING_BYTES = (size_t)64 << 20;
+// start allocating a pinned staging buffer of `bytes` unless the context has one (impdar_ctx_pinned adopts it)
+void impdar_ctx_pinned_prefetch(impdar_ctx *ctx, size_t bytes);
 // bracket the device work of one call on ctx->stream (read back by impdar_ctx_last_ms)
 int impdar_ctx_tic(impdar_ctx *ctx);
 int impdar_ctx_toc(impdar_ctx *ctx);

@@ -3358,6 +3358,9 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
     impdar_kirch_plan *p = c.plan;
     const size_t esz = impdar_dtype_size(dtype);
     const size_t bytes = (size_t)snum * tnum * esz;
+    // the download's staging ring, pinned by a thread of its own while this call uploads and sums (started behind the
+    // plan: beside it the two contend for the runtime -- plan 18 -> 40 ms)
+    impdar_ctx_pinned_prefetch(ctx, std::min(bytes, IMPDAR_STAGE_RING_BYTES));
     auto done = [&](int code) {
         if (code != IMPDAR_OK) {
             // the uploads of the pipelined form read the caller's array asynchronously: nothing may still be in flight

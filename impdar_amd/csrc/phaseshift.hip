@@ -1832,6 +1832,7 @@ extern "C" int impdar_phaseshift(impdar_ctx *ctx, const void *data, int dtype, i
                      "Interpolated velocity profile is not the length of the number of samples in a trace.");
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t bytes = (size_t)snum * tnum * impdar_dtype_size(dtype);
+    impdar_ctx_pinned_prefetch(ctx, bytes);      // the download's staging buffer, pinned while the call works
     DevBuf din, dout;
     IMPDAR_HIP_CHECK(din.ensure(bytes));
     IMPDAR_HIP_CHECK(dout.ensure(bytes));

@@ -176,17 +176,19 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
     const int m = snum / 2 + 1, nz = snum / 2, nout = 2 * (snum / 2);
     hipStream_t st = ctx->stream;
     const bool dbl = sizeof(T) == 8;
-    if (pl.owner != ctx || pl.dtype != (dbl ? IMPDAR_F64 : IMPDAR_F32) || pl.snum != snum || pl.tnum != tnum) {
+    bool want2d = true;
+    {
+        const char *e = getenv("IMPDAR_STOLT_FFT");          // tuning knob: "1d" = four 1-D passes
+        want2d = !(e && !strcmp(e, "1d"));
+    }
+    if (pl.owner != ctx || pl.dtype != (dbl ? IMPDAR_F64 : IMPDAR_F32) || pl.snum != snum || pl.tnum != tnum || pl.use2d != want2d) {
         pl.dtype = -1;
         if (pl.owner != ctx) {               // another device / stream: drop everything bound to the old one
             pl.X.release(); pl.F.release(); pl.K.release(); pl.Y.release(); pl.d_kx.release(); pl.d_ws.release();
             pl.owner = ctx;
         }
         int rc;
-        {
-            const char *e = getenv("IMPDAR_STOLT_FFT");          // tuning knob: "1d" = four 1-D passes
-            pl.use2d = !(e && !strcmp(e, "1d"));
-        }
+        pl.use2d = want2d;
         // rfft2(axes=(1,0)) (:159) = real transform over time (contiguous here), complex over the traces (rows);
         // irfft2 (:202) = complex inverse over the traces, then C2R over time.  rocFFT's 2-D real plans do
         // exactly these two passes each, with its own blocked column kernels instead of a strided batch.
@@ -201,21 +203,24 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
                                         1.0 / ((double)nout * tnum), st)))
                 return rc;
         }
-        if ((rc = pl.r2c.create(rocfft_transform_type_real_forward, dbl, false, snum, tnum, rocfft_array_type_real,
-                                rocfft_array_type_hermitian_interleaved, 1, snum, 1, m, 1.0, st)))
-            return rc;
-        if ((rc = pl.c2c_f.create(rocfft_transform_type_complex_forward, dbl, true, tnum, m,
-                                  rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, m, 1,
-                                  m, 1, 1.0, st)))
-            return rc;
-        if ((rc = pl.c2c_b.create(rocfft_transform_type_complex_inverse, dbl, true, tnum, m,
-                                  rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, m, 1,
-                                  m, 1, 1.0 / tnum, st)))
-            return rc;
-        if ((rc = pl.c2r.create(rocfft_transform_type_real_inverse, dbl, false, nout, tnum,
-                                rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, 1, m, 1, nout,
-                                1.0 / nout, st)))
-            return rc;
+        if (!pl.use2d) {
+            // (round 3 built these four beside the 2-D pair on every new size: four run-time compilations nobody ran)
+            if ((rc = pl.r2c.create(rocfft_transform_type_real_forward, dbl, false, snum, tnum, rocfft_array_type_real,
+                                    rocfft_array_type_hermitian_interleaved, 1, snum, 1, m, 1.0, st)))
+                return rc;
+            if ((rc = pl.c2c_f.create(rocfft_transform_type_complex_forward, dbl, true, tnum, m,
+                                      rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, m, 1,
+                                      m, 1, 1.0, st)))
+                return rc;
+            if ((rc = pl.c2c_b.create(rocfft_transform_type_complex_inverse, dbl, true, tnum, m,
+                                      rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, m, 1,
+                                      m, 1, 1.0 / tnum, st)))
+                return rc;
+            if ((rc = pl.c2r.create(rocfft_transform_type_real_inverse, dbl, false, nout, tnum,
+                                    rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, 1, m, 1, nout,
+                                    1.0 / nout, st)))
+                return rc;
+        }
         IMPDAR_HIP_CHECK(pl.X.ensure((size_t)tnum * snum * sizeof(T)));
         IMPDAR_HIP_CHECK(pl.F.ensure((size_t)tnum * m * 2 * sizeof(T)));
         IMPDAR_HIP_CHECK(pl.K.ensure((size_t)tnum * m * 2 * sizeof(T)));
@@ -292,6 +297,7 @@ extern "C" int impdar_stolt(impdar_ctx *ctx, const void *data, int dtype, int sn
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t esz = impdar_dtype_size(dtype);
     const size_t inb = (size_t)snum * tnum * esz, outb = (size_t)(2 * (snum / 2)) * tnum * esz;
+    impdar_ctx_pinned_prefetch(ctx, outb);       // the download's staging buffer, pinned while the call works
     DevBuf din, dout;
     IMPDAR_HIP_CHECK(din.ensure(inb));
     IMPDAR_HIP_CHECK(dout.ensure(outb ? outb : 8));
