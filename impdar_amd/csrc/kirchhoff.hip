@@ -1975,16 +1975,19 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     if (mode == IMPDAR_KIRCH_EXACT && dtype == IMPDAR_F64 && p->uniform && snum < 65536 &&
         std::fabs(tmax / dt) / sa < 65000.0 && (2.0 * hest + 400.0) / 4.0 * (double)snum * 32.0 < 2147483648.0 &&
         !getenv("IMPDAR_KIRCH_EXACT_IMPL")) {
-        const char *ne = getenv("IMPDAR_KIRCH_NHD");        // tuning knob: tiles per workgroup, 1 | 2
-        int nhd = ne ? atoi(ne) : KD_DEFAULT_NH;
-        if (nhd != 2 || nearfield) nhd = 1;
         auto rows_for = [&](int xb, int nh) { return ((KF_THREADS + (int)std::ceil(sa * (xb * nh + 4 - 2)) + 8 + 31) / 32) * 32; };
-        const char *xe = getenv("IMPDAR_KIRCH_XBD");        // tuning knob: 16 | 20
-        int xbd = (xe && atoi(xe) == 16) ? 16 : ((xe && atoi(xe) == 20) ? 20 : (nhd == 2 ? KD_DEFAULT_XB2 : 20));
         auto fits = [&](int xb, int nh) {
             const size_t b = (size_t)(rows_for(xb, nh) / 32) * kd_piece_bytes(xb);
             return b <= 80 * 1024 && (nh == 1 || b > 65535);
         };
+        // Whole radargrams: TWO tiles of 20 traces per workgroup on one ring when that ring fits half a CU's LDS, as the
+        // float32 kernel does (round 4, same-box A/B at config 3: 17.71 -> 16.91 ms; two tiles of 16: 19.2; a rank's
+        // block of under ~8000 traces keeps one tile, as there)
+        const char *ne = getenv("IMPDAR_KIRCH_NHD");        // tuning knob: tiles per workgroup, 1 | 2
+        const char *xe = getenv("IMPDAR_KIRCH_XBD");        // tuning knob: 16 | 20
+        int nhd = ne ? atoi(ne) : ((!xe && fits(20, 2) && (long long)tnum >= 8000LL * nranks) ? 2 : KD_DEFAULT_NH);
+        if (nhd != 2 || nearfield) nhd = 1;
+        int xbd = (xe && atoi(xe) == 16) ? 16 : ((xe && atoi(xe) == 20) ? 20 : ((nhd == 2 && ne) ? KD_DEFAULT_XB2 : 20));
         if (nhd == 2 && !fits(xbd, 2)) nhd = 1;
         if (!fits(xbd, nhd)) xbd = 16;
         if (fits(xbd, nhd)) {

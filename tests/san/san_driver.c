@@ -35,9 +35,9 @@ int main(void)
     void *fake = calloc(1, 4096);
     impdar_ctx *fctx = (impdar_ctx *)fake;
     enum { SNUM = 64, TNUM = 40 };
-    double tt[SNUM], dist[TNUM], bad_tt[SNUM], jit[TNUM];
+    double tt[SNUM], dist[TNUM], bad_tt[SNUM], jit[TNUM], zig[TNUM];
     for (int k = 0; k < SNUM; ++k) { tt[k] = k * 1e-8; bad_tt[k] = (k == 7 ? 3 : k) * 1e-8; }
-    for (int j = 0; j < TNUM; ++j) { dist[j] = j * 1.0; jit[j] = j * 1.0 + (j % 3) * 0.2; }
+    for (int j = 0; j < TNUM; ++j) { dist[j] = j * 1.0; jit[j] = j * 1.0 + (j % 3) * 0.2; zig[j] = j * 1.0 + (j % 2) * 2.5; }
     impdar_kirch_plan *plan = NULL;
     /* argument checks */
     EXPECT(impdar_kirch_plan_create(NULL, IMPDAR_F32, SNUM, TNUM, dist, tt, 1.69e8, 0, 1, 1e-8, 0, 0, 0, 0, 1, &plan) == IMPDAR_ERR_ARG, "null ctx");
@@ -51,8 +51,12 @@ int main(void)
     /* host geometry analysis (runs before the first HIP call) */
     EXPECT(impdar_kirch_plan_create(fctx, IMPDAR_F32, SNUM, TNUM, dist, bad_tt, 1.69e8, 0, 1, 1e-8, 0, 0, 0, 0, 1, &plan) == IMPDAR_ERR_ARG
            && strstr(impdar_last_error(), "increasing"), "non-monotonic travel_time");
-    EXPECT(impdar_kirch_plan_create(fctx, IMPDAR_F32, SNUM, TNUM, jit, tt, 1.69e8, 0, 1, 1e-8, 0, 0, 0, IMPDAR_KIRCH_FAST, 1, &plan) == IMPDAR_ERR_UNSUPPORTED,
-           "fast kernel on a non-uniform trace spacing");
+    /* (round 4: float32 data on a sorted non-uniform spacing has a fast kernel of its own, kirch_gen_kernel -- the plan
+       gets as far as the device; a spacing that is not sorted has none) */
+    EXPECT(impdar_kirch_plan_create(fctx, IMPDAR_F32, SNUM, TNUM, jit, tt, 1.69e8, 0, 1, 1e-8, 0, 0, 0, IMPDAR_KIRCH_FAST, 1, &plan) == IMPDAR_ERR_HIP,
+           "fast kernel on a sorted non-uniform trace spacing: as far as the first HIP call");
+    EXPECT(impdar_kirch_plan_create(fctx, IMPDAR_F32, SNUM, TNUM, zig, tt, 1.69e8, 0, 1, 1e-8, 0, 0, 0, IMPDAR_KIRCH_FAST, 1, &plan) == IMPDAR_ERR_UNSUPPORTED,
+           "fast kernel on an unsorted trace spacing");
     EXPECT(impdar_kirch_plan_create(fctx, IMPDAR_F64, SNUM, TNUM, dist, tt, 1.69e8, 0, 1, 1e-8, 0, 0, 0, IMPDAR_KIRCH_FAST, 1, &plan) == IMPDAR_ERR_UNSUPPORTED,
            "fast kernel on float64 data");
     /* a valid plan gets as far as the device and fails there, releasing what it built */

@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT
 
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-SOURCES = ['api.hip', 'comm.hip', 'kirchhoff.hip', 'stolt.hip', 'phaseshift.hip', 'preproc.hip']
+SOURCES = ['api.hip', 'comm.hip', 'kirchhoff.hip', 'kirch_gen.hip', 'stolt.hip', 'phaseshift.hip', 'preproc.hip']
 
 
 def _gpu_present():
