@@ -117,15 +117,28 @@ __device__ __forceinline__ double pm_sqrt01(double x)
 
 __device__ __forceinline__ double pm_wrap(double x) { return x - 6.283185307179586 * rint(x * 0.15915494309189535); }
 
-// sin / cos of a float64 angle in [-pi, pi] as float32: the high float through the polynomial, the low float to first order
+// sin / cos of a float64 angle (any size the phases of a record reach) as float32.  The reduction is done in float64 --
+// t = x 2/pi, n = rint(t), r = (t - n) pi/2 in [-pi/4, pi/4], exact to ~1e-12 -- so the float32 argument of the
+// polynomials carries no more than its own rounding (3e-8), and the quadrant is n mod 4: 6 float64-rate and 17 float32
+// instructions.  (Rounds 2-3: wrap to [-pi, pi] in float64, split into a high and a low float, the library's sincosf
+// on the high one -- its own reduction and both polynomials, ~50 instructions -- and a first-order correction by the
+// low one; five of these per lane and round were a third of the kernel's vector instructions.)  Polynomials: the
+// single-precision kernels of Cephes on [-pi/4, pi/4], below 1 ulp.
 __device__ __forceinline__ void pm_sincos(double x, float *s, float *c)
 {
-    const float xh = (float)x;
-    const float xl = (float)(x - (double)xh);
-    float sh, ch;
-    sincos_t<float>(xh, &sh, &ch);
-    *s = fmaf(ch, xl, sh);
-    *c = fmaf(-sh, xl, ch);
+    const double t = x * 0.6366197723675814;              // 2 / pi
+    const double n = rint(t);
+    const float r = (float)((t - n) * 1.5707963267948966);
+    const int q = (int)n;
+    const float z = r * r;
+    const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+    const float cp = fmaf(z * z, fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f),
+                          fmaf(-0.5f, z, 1.0f));
+    const bool odd = q & 1;
+    const float sv = odd ? cp : sp, cv = odd ? sp : cp;
+    // quadrant 0: (s, c); 1: (c, -s); 2: (-s, -c); 3: (-c, s)
+    *s = (q & 2) ? -sv : sv;
+    *c = ((q + 1) & 2) ? -cv : cv;
 }
 
 // (x, y) -> the float16 pair nearest towards zero as one dword, and what is left of x and y
@@ -221,8 +234,8 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
     // this lane's step factors: steps b = 16 part + hh + PM_NSUB j of every 64-step tile
     auto gen_B = [&](double inc) {
         float e2s, e2c, bs, bc;
-        pm_sincos(pm_wrap((double)PM_NSUB * inc), &e2s, &e2c);
-        pm_sincos(pm_wrap((double)(16 * part + hh + 1) * inc), &bs, &bc);
+        pm_sincos((double)PM_NSUB * inc, &e2s, &e2c);
+        pm_sincos((double)(16 * part + hh + 1) * inc, &bs, &bc);
         bs *= 256.f;
         bc *= 256.f;
 #pragma unroll
@@ -287,11 +300,11 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
             const double ph0 = in_o ? phi_o : 0.0;
             constexpr int NJ = 32 / PM_NSUB, NJH = NJ / 2;
             float sx, cx, sy, cy, Es, Ec, e2s, e2c, bs, bc;
-            pm_sincos(pm_wrap(ph0 + (double)(PM_TT * (a0_o + hh)) * inc_o), &sx, &cx);
-            pm_sincos(pm_wrap(ph0 + (double)(PM_TT * (a0_o + PM_NSUB * NJH + hh)) * inc_o), &sy, &cy);
-            pm_sincos(pm_wrap((double)(PM_NSUB * PM_TT) * inc_o), &Es, &Ec);
-            pm_sincos(pm_wrap((double)PM_NSUB * incs[0]), &e2s, &e2c);
-            pm_sincos(pm_wrap((double)(16 * part + hh + 1) * incs[0]), &bs, &bc);
+            pm_sincos(ph0 + (double)(PM_TT * (a0_o + hh)) * inc_o, &sx, &cx);
+            pm_sincos(ph0 + (double)(PM_TT * (a0_o + PM_NSUB * NJH + hh)) * inc_o, &sy, &cy);
+            pm_sincos((double)(PM_NSUB * PM_TT) * inc_o, &Es, &Ec);
+            pm_sincos((double)PM_NSUB * incs[0], &e2s, &e2c);
+            pm_sincos((double)(16 * part + hh + 1) * incs[0], &bs, &bc);
             bs *= 256.f;
             bc *= 256.f;
             const float gr = in_o ? f0r : 0.f, gi = in_o ? f0i : 0.f;
@@ -331,8 +344,8 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
             const double inc = incs[rb];
             const bool in = phis[rb] == phis[rb];
             float s, cph, Es, Ec;
-            pm_sincos(pm_wrap((in ? phis[rb] : 0.0) + (double)(PM_TT * (ba0[rb] + PM_NSUB * NJQ * part + hh)) * inc), &s, &cph);
-            pm_sincos(pm_wrap((double)(PM_NSUB * PM_TT) * inc), &Es, &Ec);
+            pm_sincos((in ? phis[rb] : 0.0) + (double)(PM_TT * (ba0[rb] + PM_NSUB * NJQ * part + hh)) * inc, &s, &cph);
+            pm_sincos((double)(PM_NSUB * PM_TT) * inc, &Es, &Ec);
             const float gr = in ? f0r : 0.f, gi = in ? f0i : 0.f;
             float sr = fmaf(gr, cph, -(gi * s)), si = fmaf(gr, s, gi * cph);
             unsigned *Ahi = Aq + (size_t)rb * 2 * PM_TILE, *Alo = Ahi + PM_TILE;
@@ -497,7 +510,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(PM_SM <= 8 
                 for (int j = 0; j < PM_SHORT; ++j)
                     if (j < len) {                                            // uniform
                         float sn, c2;
-                        pm_sincos(pm_wrap(ph[m] + (double)(j + 1) * inc), &sn, &c2);
+                        pm_sincos(ph[m] + (double)(j + 1) * inc, &sn, &c2);
                         acc[2 * j] += fmaf(fv[m].x, c2, -(fv[m].y * sn));    // :464, :487
                         acc[2 * j + 1] += fmaf(fv[m].x, sn, fv[m].y * c2);
                     }

@@ -4,4 +4,4 @@ import sys, os, json
 sys.path.insert(0, os.getcwd())
 import bench
 r = bench.path_records(True, True)
-print(json.dumps({k: {'device_ms': v.get('device_ms', v.get('ms_per_step')), 'kernel_ms': v.get('kernel_ms'), 'frac': v['roofline']['frac']} for k, v in r.items()}))
+print(json.dumps({k: {'device_ms': v.get('device_ms', v.get('ms_per_step')), 'kernel_ms': v.get('kernel_ms'), 'frac': (v.get('roofline') or {}).get('frac'), 'e2e': (v.get('end_to_end') or {}).get('host_call_ms')} for k, v in r.items()}))
