@@ -2049,7 +2049,7 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     }
     // ---- picks that rounding noise decides (see kirch_tiescan_kernel): the table-driven kernels would break those
     // ties one way per offset, the reference breaks them pair by pair
-    if (p->uniform && !gen_forced && (mode == IMPDAR_KIRCH_FAST || p->dquad || !getenv("IMPDAR_KIRCH_EXACT_IMPL") ||
+    if (p->uniform && (mode == IMPDAR_KIRCH_FAST || p->dquad || !getenv("IMPDAR_KIRCH_EXACT_IMPL") ||
                        strcmp(getenv("IMPDAR_KIRCH_EXACT_IMPL"), "pair"))) {
         int hg = 0;
         for (int k = 0; k < snum; ++k) hg = std::max(hg, p->h_half[k] + 1);

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
 //
 // The kernel above spends 14 of its ~32 instructions per (step, frequency) to carry y = sqrt(coss) in float64.  A float32
 // image needs float64 only where errors ADD UP: in the phase sum Phi that the anchors rotate the original spectrum by.
-// Both are taken from an expansion about the tile's middle velocity, c_a = (min + max)/2 of c = v^2 over the tile,
+// Both are taken from an expansion about the middle velocity of 32 steps (two tiles), c_a = (min + max)/2 of c = v^2 over them,
 // delta_t = c_t - c_a, per frequency xi = x / coss_a, u_t = xi delta_t:
 //     y_t = y_a sqrt(1 - u_t)
 //   * the phase sum of the whole tile at once, in float64, at the tile's start:
@@ -368,16 +368,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
 #define PSS32_UMAX 0.1
 #define PSS32_NQ 9              // Q_0 .. Q_8
 #define PSS32_NARROW 0.02       // band lanes with coss up to this: phase < 0.45, sine and cosine from their series
-#define PSS32_TILE_DOUBLES 16   // per tile: Q_0..Q_8, [9] c_a, [10] max |delta|, [11] max threshold, [12] narrow
+#define PSS32_TILE_DOUBLES 16   // per expansion: Q_0..Q_8, [9] c_a, [10] max |delta|, [11] max threshold, [12] narrow
+#define PSS32_XTILES 2          // 16-step tiles per expansion (one per tile: 15 % of the kernel's instructions went into it)
 
 // the per-step / per-tile tables of ps_smooth32_kernel (host, float64): step[4 tau + {0,1,2,3}] = {c, thr, v, delta}
 static void ps_smooth_tables(const double *vz, const double *thr, int snum, std::vector<double> &step, std::vector<double> &tile)
 {
-    const int ntile = (snum + 15) / 16;
-    step.assign((size_t)ntile * 16 * 4, 0.0);
-    tile.assign((size_t)ntile * PSS32_TILE_DOUBLES, 0.0);
-    for (int t = 0; t < ntile; ++t) {
-        const int t0 = t * 16, n = std::min(16, snum - t0);
+    constexpr int XS = PSS32_XTILES * PSS_TT;              // steps per expansion
+    const int nint = (snum + XS - 1) / XS;
+    step.assign((size_t)nint * XS * 4, 0.0);
+    tile.assign((size_t)nint * PSS32_TILE_DOUBLES, 0.0);
+    for (int t = 0; t < nint; ++t) {
+        const int t0 = t * XS, n = std::min(XS, snum - t0);
         double cmin = vz[t0] * vz[t0], cmax = cmin, thrmax = thr[t0];
         for (int i = 1; i < n; ++i) {
             const double c = vz[t0 + i] * vz[t0 + i];
@@ -387,8 +389,8 @@ static void ps_smooth_tables(const double *vz, const double *thr, int snum, std:
         }
         const double ca = 0.5 * (cmin + cmax);
         double *q = &tile[(size_t)t * PSS32_TILE_DOUBLES];
-        double dmax = 0.0, pw[16];
-        for (int i = 0; i < 16; ++i) {
+        double dmax = 0.0, pw[XS];
+        for (int i = 0; i < XS; ++i) {
             const int tau = t0 + std::min(i, n - 1);
             const double c = vz[tau] * vz[tau];
             double *sp = &step[(size_t)(t0 + i) * 4];
@@ -483,9 +485,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
     }
     if (lane < TT) stepc[0][lane] = gstep[lane];
     const int ntile = (P.snum + TT - 1) / TT;
+    static_assert(ANCHOR_TILES % PSS32_XTILES == 0, "anchors fall on expansion starts");
+    unsigned bandm = 0;                                   // bit m: frequency m of this lane takes the exact branch this expansion
+    unsigned gband = 0;                                   // (uniform) bit m0: the group has a lane in the band
+    bool narrow = false;
     for (int tile = 0; tile < ntile; ++tile) {
         const int tau0 = tile * TT;
         const bool anchor = tile % ANCHOR_TILES == 0;
+        const bool expand = tile % PSS32_XTILES == 0;
         __syncthreads();                                  // (one wave: orders the table's writes and reads)
         if (lane < TT && tile + 1 < ntile) stepc[(tile + 1) & 1][lane] = gstep[(size_t)(tile + 1) * TT + lane];
         if (anchor && tile > 0) {
@@ -503,75 +510,82 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
                 asm volatile("" : "+v"(sr_[m]), "+v"(si_[m]));
             }
         }
-        // ---- this tile's expansion
-        double tq[PSS32_TILE_DOUBLES];
-        {
-            const double *gt = P.sm_tile + (size_t)tile * PSS32_TILE_DOUBLES;
-#pragma unroll
-            for (int i = 0; i < 12; i += 4) pss_scalar_load_4f64(gt + i, &tq[i], &tq[i + 1], &tq[i + 2], &tq[i + 3]);
-            tq[12] = gt[12];
-        }
-        const double c_a = tq[9], dmax = tq[10], thrmax = tq[11];
-        const bool narrow = tq[12] != 0.0;
-        unsigned bandm = 0;                               // bit m: frequency m of this lane takes the exact branch this tile
-        unsigned gdead = 0, gband = 0;                    // (uniform) bit m0: group all out / has a lane in the band
+        // groups all of whose frequencies, in all 64 lanes, are out
+        unsigned gdead = 0;
         bool all_out = true;
 #pragma unroll
         for (int m0 = 0; m0 < M; m0 += G) {
             bool alive = false;
 #pragma unroll
             for (int j = 0; j < G; ++j) alive = alive || !((dead >> (m0 + j)) & 1u);
-            if (__builtin_amdgcn_ballot_w64(alive) == 0) {         // uniform
-                gdead |= 1u << m0;
-                continue;
+            if (__builtin_amdgcn_ballot_w64(alive) == 0) gdead |= 1u << m0;
+            else all_out = false;
+        }
+        gdead = __builtin_amdgcn_readfirstlane(gdead);
+        // ---- the expansion of the next PSS32_XTILES tiles
+        if (expand && !all_out) {                         // uniform
+            double tq[PSS32_TILE_DOUBLES];
+            {
+                const double *gt = P.sm_tile + (size_t)(tile / PSS32_XTILES) * PSS32_TILE_DOUBLES;
+#pragma unroll
+                for (int i = 0; i < 12; i += 4) pss_scalar_load_4f64(gt + i, &tq[i], &tq[i + 1], &tq[i + 2], &tq[i + 3]);
+                tq[12] = gt[12];
             }
-            all_out = false;
-            bool anyband = false;
+            const double c_a = tq[9], dmax = tq[10], thrmax = tq[11];
+            narrow = tq[12] != 0.0;
+            bandm = 0;
+            gband = 0;
 #pragma unroll
-            for (int j = 0; j < G; ++j) {
-                const int m = m0 + j;
-                const double cs_a = fma(-c_a, x[m], 1.0);
-                const bool band = !(cs_a * PSS32_UMAX > x[m] * dmax) || !(cs_a * 0.75 > thrmax + 1.0e-13);
-                if (band) bandm |= 1u << m;
-                anyband = anyband || band;
-                const double csu = band ? 1.0 : cs_a;     // (band lanes: any finite stand-in, they overwrite what it gives)
-                const double r0 = __builtin_amdgcn_rsq(csu);
-                double y0 = csu * r0, h = 0.5 * r0;
+            for (int m0 = 0; m0 < M; m0 += G) {
+                if ((gdead >> m0) & 1u) continue;             // uniform
+                bool anyband = false;
 #pragma unroll
-                for (int it = 0; it < 2; ++it) {
+                for (int j = 0; j < G; ++j) {
+                    const int m = m0 + j;
+                    const double cs_a = fma(-c_a, x[m], 1.0);
+                    const bool band = !(cs_a * PSS32_UMAX > x[m] * dmax) || !(cs_a * 0.75 > thrmax + 1.0e-13);
+                    if (band) bandm |= 1u << m;
+                    anyband = anyband || band;
+                    const double csu = band ? 1.0 : cs_a;     // (band lanes: any finite stand-in, they overwrite what it gives)
+                    const double r0 = __builtin_amdgcn_rsq(csu);
+                    double y0 = csu * r0, h = 0.5 * r0;
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        y0 = fma(fma(-y0, y0, csu), h, y0);
+                        h = fma(h, fma(-(y0 + y0), h, 1.0), h);
+                    }
                     y0 = fma(fma(-y0, y0, csu), h, y0);
-                    h = fma(h, fma(-(y0 + y0), h, 1.0), h);
-                }
-                y0 = fma(fma(-y0, y0, csu), h, y0);
-                const double t2 = h + h, xid = t2 * t2 * x[m];     // x / coss_a
-                double H = tq[PSS32_NQ - 1];
+                    const double t2 = h + h, xid = t2 * t2 * x[m];     // x / coss_a
+                    double H = tq[PSS32_NQ - 1];
 #pragma unroll
-                for (int p = PSS32_NQ - 2; p >= 0; --p) H = fma(H, xid, tq[p]);
-                const double K = wdt[m] * y0;
-                if (!band) Phi[m] = fma(K, H, Phi[m]);     // the whole tile's phase (band lanes add theirs step by step)
-                xi[m] = (T)xid;
-                const T K32 = (T)K;
-                Kf[m] = K32;
-                // R_a: turned from the last tile's by the series in dK, from scratch at the anchors and after jumps
-                const T dK = (T)(K - Kp[m]);
-                Kp[m] = K;
-                if (anchor || !(fabsf(dK) <= 0.2f)) {
-                    const T klo = (T)(K - (double)K32);
-                    T sn, cn;
-                    sincos_t<T>(K32, &sn, &cn);
-                    ca[m] = fma(-sn, klo, cn);
-                    sa[m] = fma(cn, klo, sn);
-                } else {
-                    const T s2 = dK * dK;
-                    const T ec = fma(s2, fma(s2, fma(s2, (T)(-1.0 / 720), (T)(1.0 / 24)), (T)-0.5), (T)1);
-                    const T es = dK * fma(s2, fma(s2, (T)(1.0 / 120), (T)(-1.0 / 6)), (T)1);
-                    const T nc = fma(ca[m], ec, -(sa[m] * es));
-                    const T ns = fma(ca[m], es, sa[m] * ec);
-                    ca[m] = nc;
-                    sa[m] = ns;
+                    for (int p = PSS32_NQ - 2; p >= 0; --p) H = fma(H, xid, tq[p]);
+                    const double K = wdt[m] * y0;
+                    if (!band) Phi[m] = fma(K, H, Phi[m]);     // the whole expansion's phase (band lanes add theirs step by step)
+                    xi[m] = (T)xid;
+                    const T K32 = (T)K;
+                    Kf[m] = K32;
+                    // R_a: turned from the last expansion's by the series in dK, from scratch at the anchors and after jumps
+                    const T dK = (T)(K - Kp[m]);
+                    Kp[m] = K;
+                    if (anchor || !(fabsf(dK) <= 0.2f)) {
+                        const T klo = (T)(K - (double)K32);
+                        T sn, cn;
+                        sincos_t<T>(K32, &sn, &cn);
+                        ca[m] = fma(-sn, klo, cn);
+                        sa[m] = fma(cn, klo, sn);
+                    } else {
+                        const T s2 = dK * dK;
+                        const T ec = fma(s2, fma(s2, fma(s2, (T)(-1.0 / 720), (T)(1.0 / 24)), (T)-0.5), (T)1);
+                        const T es = dK * fma(s2, fma(s2, (T)(1.0 / 120), (T)(-1.0 / 6)), (T)1);
+                        const T nc = fma(ca[m], ec, -(sa[m] * es));
+                        const T ns = fma(ca[m], es, sa[m] * ec);
+                        ca[m] = nc;
+                        sa[m] = ns;
+                    }
                 }
+                if (__builtin_amdgcn_ballot_w64(anyband) != 0) gband |= 1u << m0;
             }
-            if (__builtin_amdgcn_ballot_w64(anyband) != 0) gband |= 1u << m0;
+            gband = __builtin_amdgcn_readfirstlane(gband);
         }
         if (all_out) {                                    // uniform: zeros from here to the end of the record
             Cp<T> z;
@@ -579,8 +593,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
             for (int tau = tau0 + lane; tau < P.snum; tau += 64) out[tau] = z;
             return;
         }
-        gdead = __builtin_amdgcn_readfirstlane(gdead);
-        gband = __builtin_amdgcn_readfirstlane(gband);
 #pragma unroll 1
         for (int t = 0; t < TT; ++t) {
             const int tau = tau0 + t;

@@ -33,9 +33,20 @@ def main():
         dx = float(rng.choice([1.0, 0.5, 2.0, 2.5, 4.0]))
         geo = synth.geometry(snum, tnum, dt=dt, dx=dx)
         Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
-        kind = rng.integers(0, 4)
+        kind = rng.integers(0, 5)
         if kind == 0:
             vel = float(rng.choice([1.68e8, 1.69e8, 2.0e8, 1.5e8]))
+        elif kind == 4:
+            # "per-step": a dense table (a row per few samples, gradient + wobble + small noise, rising or falling), so
+            # that the interpolated velocity changes at EVERY depth step (ps_smooth_kernel / ps_smooth32_kernel)
+            nl = int(min(max(snum // int(rng.choice([1, 2, 3])), 8), 700))
+            v0 = float(rng.choice([1.68e8, 1.69e8, 2.0e8, 1.6e8]))
+            u = np.linspace(0., 1., nl)
+            vs = v0 * (1.0 + float(rng.uniform(-0.15, 0.3)) * u + 0.03 * np.sin(float(rng.uniform(2., 12.)) * u)
+                       + float(rng.choice([0., 1e-4])) * rng.standard_normal(nl))
+            Rv = vs.max() * geo['travel_time'][-1] * 1e-6 / 2.
+            zs = np.linspace(0., 1.3 * Rv, nl)
+            vel = np.stack([vs, zs], axis=1)
         else:
             nl = int(rng.choice([2, 3, 4, 7, 40])) if kind < 3 else int(rng.integers(50, 90))
             v0 = float(rng.choice([1.68e8, 1.69e8, 2.0e8, 1.6e8]))
@@ -80,7 +91,7 @@ def main():
         worst[dtype] = max(worst[dtype], err)
         print('%3d %s snum %4d tnum %3d dt %.3g dx %.3g vel %s %s err %.3g %s'
               % (case, 'f32' if dtype == np.float32 else 'f64', snum, tnum, dt, dx,
-                 'const %.3g' % vel if np.isscalar(vel) else '%d layers from %.3g' % (len(vel), vel[0, 0]),
+                 'const %.3g' % vel if np.isscalar(vel) else '%s%d layers from %.3g' % ('per-step ' if kind == 4 else '', len(vel), vel[0, 0]),
                  '', err, 'ok' if ok else 'MISS'), flush=True)
     print('cases %d, misses %d, worst float32 rel-L2 %.3g (bar 2e-4), worst float64 rel-max %.3g (bar 1e-9), %.0f s'
           % (ncases, bad, worst[np.float32], worst[np.float64], time.time() - t_start))
