@@ -1,5 +1,9 @@
 // Small RAII wrapper over rocFFT plans (used by stolt.hip and phaseshift.hip).
 #pragma once
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
 #include "common.h"
 #include <rocfft/rocfft.h>
 
@@ -104,6 +108,37 @@ struct FftPlan {
         return IMPDAR_OK;
     }
 };
+
+// Several rocFFT plans created at the same time, each by a thread of its own (the first by the caller): the plans of a
+// new size are compiled at run time -- 0.2-0.6 s each on a machine that has not seen the size -- and a first Stolt or
+// phase-shift call needs two or three.  Returns the first failure (its message becomes this thread's last error).
+static int impdar_parallel_plans(int device, std::vector<std::function<int()>> makers)
+{
+    std::vector<int> rcs(makers.size(), 0);
+    std::vector<std::string> msgs(makers.size());
+    std::vector<std::thread> pool;
+    for (size_t i = 1; i < makers.size(); ++i)
+        pool.emplace_back([&, i] {
+            if (hipSetDevice(device) != hipSuccess) {
+                rcs[i] = IMPDAR_ERR_HIP;
+                msgs[i] = "hipSetDevice failed in a plan thread";
+                return;
+            }
+            rcs[i] = makers[i]();
+            if (rcs[i]) msgs[i] = impdar_last_error();
+        });
+    if (!makers.empty()) {
+        rcs[0] = makers[0]();
+        if (rcs[0]) msgs[0] = impdar_last_error();
+    }
+    for (auto &t : pool) t.join();
+    for (size_t i = 0; i < makers.size(); ++i)
+        if (rcs[i]) {
+            impdar_set_error("%s", msgs[i].c_str());
+            return rcs[i];
+        }
+    return IMPDAR_OK;
+}
 
 // edge taper weight, reference mig_python.py:152-156: min(i, n-1-i)/taper clipped to 1
 __host__ __device__ static inline double impdar_taper_w(int i, int n, double taper)

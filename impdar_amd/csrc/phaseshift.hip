@@ -1259,6 +1259,7 @@ struct PsPlan {
     DevBuf d_blocks, d_edge, d_runtab;   // matrix-core path: row-block table; boundary-frequency counts + lists; per-run phases
     DevBuf X, TK, d_kx, d_w, d_vz, d_thr, d_sched, d_rowmap, d_eps, d_sm, d_part;
     std::vector<double> h_sm_step, h_sm_tile;
+    bool b_ready = false;
 };
 static std::mutex g_ps_mu;
 static PsPlan *g_ps_plan = nullptr;
@@ -1483,15 +1484,9 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             pl.d_eps.release();
             pl.owner = ctx;
         }
-        int rc;
-        const rocfft_array_type ci = rocfft_array_type_complex_interleaved;
         pl.c_ready = false;              // the forward transforms are made on first use (below): which pair depends on the walk
         pl.rows_form = rows_form;
-        if ((rc = rows_form ? pl.b_trace.create(rocfft_transform_type_complex_inverse, dbl, true, tnum, snum, ci, ci, 1, tnum, 1, tnum,
-                                                1.0 / tnum, st)
-                            : pl.b_trace.create(rocfft_transform_type_complex_inverse, dbl, true, tnum, snum, ci, ci, snum, 1, snum, 1,
-                                                1.0 / tnum, st)))
-            return rc;
+        pl.b_ready = false;              // the inverse transform over the traces: made below, beside the forward pair
         IMPDAR_HIP_CHECK(pl.X.ensure((size_t)tnum * nt * 2 * sizeof(T)));
         IMPDAR_HIP_CHECK(pl.d_kx.ensure((size_t)tnum * 8));
         IMPDAR_HIP_CHECK(pl.d_w.ensure((size_t)nt * 8));
@@ -1553,24 +1548,38 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     {
         int rc;
         const rocfft_array_type ci = rocfft_array_type_complex_interleaved;
+        // the plans this call still lacks, created side by side (run-time compilation: impdar_parallel_plans)
+        std::vector<std::function<int()>> makers;
+        const bool rows_form_b = pl.rows_form;
+        if (!pl.b_ready)
+            makers.push_back([&] {
+                return rows_form_b ? pl.b_trace.create(rocfft_transform_type_complex_inverse, dbl, true, tnum, snum, ci, ci, 1, tnum, 1, tnum,
+                                                       1.0 / tnum, st)
+                                   : pl.b_trace.create(rocfft_transform_type_complex_inverse, dbl, true, tnum, snum, ci, ci, snum, 1, snum, 1,
+                                                       1.0 / tnum, st);
+            });
         if (herm && !pl.r_ready) {
             IMPDAR_HIP_CHECK(pl.Xr.ensure((size_t)tnum * nt * sizeof(T)));
-            if ((rc = pl.r_time.create(rocfft_transform_type_real_forward, dbl, false, nt, tnum, rocfft_array_type_real,
-                                       rocfft_array_type_hermitian_interleaved, 1, nt, 1, fstride, 1.0, st)))
-                return rc;
-            if ((rc = pl.rows_form ? pl.r_trace.create(rocfft_transform_type_complex_forward, dbl, true, tnum, fstride, ci, ci, 1, tnum,
-                                                       1, tnum, 1.0, st)
-                                   : pl.r_trace.create(rocfft_transform_type_complex_forward, dbl, true, tnum, fstride, ci, ci, fstride, 1,
-                                                       fstride, 1, 1.0, st)))
-                return rc;
-            pl.r_ready = true;
+            makers.push_back([&] {
+                return pl.r_time.create(rocfft_transform_type_real_forward, dbl, false, nt, tnum, rocfft_array_type_real,
+                                        rocfft_array_type_hermitian_interleaved, 1, nt, 1, fstride, 1.0, st);
+            });
+            makers.push_back([&] {
+                return pl.rows_form ? pl.r_trace.create(rocfft_transform_type_complex_forward, dbl, true, tnum, fstride, ci, ci, 1, tnum,
+                                                        1, tnum, 1.0, st)
+                                    : pl.r_trace.create(rocfft_transform_type_complex_forward, dbl, true, tnum, fstride, ci, ci, fstride, 1,
+                                                        fstride, 1, 1.0, st);
+            });
         }
         if (!herm && !pl.c_ready) {
-            if ((rc = pl.f_time.create(rocfft_transform_type_complex_forward, dbl, true, nt, tnum, ci, ci, 1, nt, 1, nt, 1.0, st)))
-                return rc;
-            if ((rc = pl.f_trace.create(rocfft_transform_type_complex_forward, dbl, true, tnum, nt, ci, ci, nt, 1, nt, 1, 1.0, st)))
-                return rc;
-            pl.c_ready = true;
+            makers.push_back([&] { return pl.f_time.create(rocfft_transform_type_complex_forward, dbl, true, nt, tnum, ci, ci, 1, nt, 1, nt, 1.0, st); });
+            makers.push_back([&] { return pl.f_trace.create(rocfft_transform_type_complex_forward, dbl, true, tnum, nt, ci, ci, nt, 1, nt, 1, 1.0, st); });
+        }
+        if (!makers.empty()) {
+            if ((rc = impdar_parallel_plans(ctx->device, makers))) return rc;
+            pl.b_ready = true;
+            if (herm) pl.r_ready = true;
+            else pl.c_ready = true;
         }
     }
     if (vlen)
