@@ -196,6 +196,7 @@ void impdar_ctx_pinned_prefetch(impdar_ctx *ctx, size_t bytes)
 // (callers hold ctx->pinned_mu)
 void *impdar_ctx_pinned(impdar_ctx *ctx, size_t bytes)
 {
+    if (bytes <= ctx->pinned_bytes) return ctx->pinned;      // (a larger one on its way is not waited for)
     pinned_adopt(ctx);
     if (bytes <= ctx->pinned_bytes) return ctx->pinned;
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -370,6 +371,9 @@ int impdar_download_blocks_f64(impdar_ctx *ctx, double *dst_host, size_t ld, siz
     // the 164 MB of a config-3 image were the largest term of a process's first call.  Pieces of <= 16 MB go round it:
     // the copy of a piece is enqueued as soon as the ring has room, i.e. once the host has widened the piece that held
     // that room; up to four are in flight.
+    // (same-box A/B of the steady call at config 3, ring 32 / 64 / 96 / 128 MB / whole image: 16.4 / 13.2 / 12.9 / 13.0 / 13.0 ms;
+    // the first call of a process: 52 ms with 64 MB, 66 ms with 96 MB -- more than the call can pin behind its plan
+    // before the first block is ready to leave.  64 MB.)
     const size_t cap = std::min(total, IMPDAR_STAGE_RING_BYTES);
     std::unique_lock<std::mutex> lock(ctx->pinned_mu);
     char *stage = reinterpret_cast<char *>(impdar_ctx_pinned(ctx, cap));

@@ -8,22 +8,6 @@
 #define KF_W 512            // LDS floats per ring slot (circular window)
 #define KF_PAD_ROWS 128      // zero traces kept on both sides of the image (loops are clipped to the profile)
 
-// The pipelined one-shot call (impdar_kirchhoff): output blocks, what each needs of the input, and the words the one
-// persistent launch and the streams around it talk through (FastParams::items).
-struct KirchPipe {
-    int nblk = 0;
-    int cut[9] = {};            // block b = output traces [cut[b], cut[b + 1])
-    int need[8] = {};           // ... reads input traces [0, need[b])
-    int nitems[8] = {};         // ... in this many (chunk, tile) items (filled by the launch)
-    unsigned *in_ready = nullptr, *abort_flag = nullptr;    // device
-    unsigned *done = nullptr;   // pinned host, 16 words per block
-    long long spin_limit = 0;
-    // the preps of the later chunks need the slots the launch leaves free; once they are through, a second, small launch
-    // of the same kernel joins the first (same item lists and counters) on all but a few of those slots
-    bool join = false;
-    int items_per_xcd = 0;
-};
-
 struct impdar_kirch_plan {
     impdar_ctx *ctx = nullptr;
     int dtype = IMPDAR_F32, snum = 0, tnum = 0, tnum_pad = 0, nranks = 1;
@@ -58,27 +42,13 @@ struct impdar_kirch_plan {
     int nb = 0, ntab = 0;
     bool quad = false;          // sample-major LDS ring (kirch_quad_kernel)
     std::vector<int> h_hmax;    // host copy of the per-chunk aperture half widths (tile cost model)
-    // Launch lanes.  A diffraction sum over an output block uses one lane's tile map and queue counters; the blocks of
-    // a pipelined one-shot call are launched on two streams and overlap (the next block's workgroups take the slots the
-    // last one's leave), so each has its own.  Lane 0: everything else.
-    static constexpr int NLANE = 8;
-    int lane = 0;               // lane of the launch being set up
-    KirchPipe *pipe = nullptr;  // ... the launch of a pipelined one-shot call: slots are left free for the prep kernels of
-                                // later chunks, the tie fixes and whatever else runs beside it
-    DevBuf d_items;
-    std::vector<int> h_items;
-    DevBuf d_queue_l[NLANE];    // quad kernel, persistent workgroups: per-XCD item counters
+    DevBuf d_queue;             // quad kernel, persistent workgroups: per-XCD item counters
     int slots = 0;              // ... and how many of them are resident at once (occupancy query, cached)
     int walk_parts_log2 = 0;    // every tile's aperture walk as 1, 2 or 4 queue items (plans of 4+ / 8+ ranks)
     DevBuf d_partial;           // ... and the partial images of the pieces
-    DevBuf d_tilemap_l[NLANE];  // ring kernels: (chunk, slot, XCD) -> output tile, balanced over the XCDs
-    std::vector<short> h_tilemap_l[NLANE];
-    int tm_key_l[NLANE][5];     // (xlo, xhi, tile width, G, tiles_per_xcd) the lane's cached map was built for
-    impdar_kirch_plan()
-    {
-        for (auto &k : tm_key_l)
-            for (int &v : k) v = -1;
-    }
+    DevBuf d_tilemap;           // ring kernels: (chunk, slot, XCD) -> output tile, balanced over the XCDs
+    std::vector<short> h_tilemap;
+    int tm_key[5] = {-1, -1, -1, -1, -1};   // (xlo, xhi, tile width, G, tiles_per_xcd) the cached map was built for
     int nh = 1;                 // quad kernel: output tiles per workgroup sharing one ring (256 nh threads)
     int lk = 0;                 // ... and extra ring groups = blocks of additional staging lookahead (nh >= 2 only)
     bool dquad = false;         // the same ring in float64 (kirch_dquad_kernel): exact mode, float64 data, uniform grids

@@ -496,63 +496,7 @@ struct FastParams {
                                    //   x = kmin | (kmin mod W) << 16, y = kmax
     int nrows, mrow0;
     int ntab;                      // tab kernel: table rows; the last row is all zero (|n| beyond every aperture)
-    // Ring kernels, the pipelined one-shot call (impdar_kirchhoff): ONE persistent launch walks all output blocks in
-    // order while the input is still arriving.  items != null: per-XCD item lists [items_per_xcd][8], block by block,
-    // item = tile inside the block | chunk << 16 | block << 28 (-1: none).  Before an item of block b starts, lane 0
-    // waits until *in_ready >= pipe_need[b] (input traces uploaded and prepared so far, written behind every prep by a
-    // stream write); after it, it adds 1 to done[16 b] (pinned host memory: a stream wait on that count releases the
-    // block's tie fix and download).  A wait that outlasts spin_limit (100 MHz ticks) sets *abort: every workgroup
-    // leaves at its next item and the host reports the failure.  Block b = output traces [pipe_xlo[b], pipe_xhi[b]),
-    // stored compact (snum x width) at out + snum * pipe_xlo[b].
-    const int *items;
-    int items_per_xcd;
-    int pipe_xlo[8], pipe_xhi[8], pipe_need[8];
-    const unsigned *in_ready;
-    unsigned *done, *abort;
-    long long spin_limit;
 };
-
-// lane 0 of a persistent workgroup of the pipelined launch: the previous item is finished (signal its block), take the
-// next one from the per-XCD lists and wait for its input.  Returns the item or -1.
-__device__ __forceinline__ int kirch_pipe_next(const FastParams &P, int prev_blk)
-{
-    if (prev_blk >= 0) {
-        __threadfence_system();                // the item's outputs (every wave stored them before the barrier) ...
-        atomicAdd(P.done + prev_blk * 16, 1u); // ... before the count a stream is waiting on
-    }
-    if (__atomic_load_n(P.abort, __ATOMIC_RELAXED)) return -1;
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    int it = -1;
-    for (int v = 0; v < 8 && it < 0; ++v) {
-        const int x = (int)((xcc + v) & 7u);
-        for (;;) {
-            const int i = atomicAdd(P.queue + x * 16, 1);
-            if (i >= P.items_per_xcd) break;
-            const int t = P.items[(size_t)i * 8 + x];
-            if (t >= 0) {
-                it = t;
-                break;
-            }
-        }
-    }
-    if (it < 0) return -1;
-    const unsigned need = (unsigned)P.pipe_need[it >> 28];
-    const long long t0 = wall_clock64();
-    while (__atomic_load_n(P.in_ready, __ATOMIC_RELAXED) < need) {
-        if (__atomic_load_n(P.abort, __ATOMIC_RELAXED)) return -1;
-        if (wall_clock64() - t0 > P.spin_limit) {
-            // give up: every workgroup leaves at its next item, and every stream waiting for a block's count is let go
-            // (the host reads the flag and reports the call as failed)
-            atomicExch(P.abort, 1u);
-            for (int b = 0; b < 8; ++b) atomicExch(P.done + 16 * b, 1u << 30);
-            return -1;
-        }
-        __builtin_amdgcn_s_sleep(64);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // the image columns another kernel wrote while this one ran
-    return it;
-}
 
 // ---------------------------------------------------------------------------
 // pick / weight table.  For a uniform trace spacing the sample picked by the
@@ -934,7 +878,6 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
     // speed on this loop and blocks are dealt to them statically, so with one item per block the slowest XCD set
     // the kernel's end; the queue also closes the gaps between workgroups and shortens the tail.
     bool first_item = true;
-    int pipe_prev = -1;                       // pipelined launch: block of the item just finished
     int *item_slot = reinterpret_cast<int *>(lds) + (size_t)(img_bytes / 4) * (NEAR ? 2 : 1);
     for (;;) {
     int chunk, xt;
@@ -943,23 +886,7 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
     // chunk) -- one walk of a shallow chunk is as long as such a rank's whole step should be.  A piece writes its
     // sums to its own partial image; kirch_combine_kernel adds the pieces in a fixed order.
     int part = 0;
-    int xlo_i = P.xlo, xhi_i = P.xhi, ldo_i = P.ldo;       // this item's output block (the launch's, but for pipelined items)
-    size_t out_off = 0;
-    if (P.items) {
-        __syncthreads();                       // every wave is done with the previous item (ring reads, the slot, its stores)
-        if (threadIdx.x == 0) item_slot[0] = kirch_pipe_next(P, pipe_prev);
-        __syncthreads();
-        const int it = item_slot[0];
-        if (it < 0) break;
-        const int blk = it >> 28;
-        pipe_prev = blk;
-        chunk = (it >> 16) & 0xfff;
-        xt = it & 0xffff;
-        xlo_i = P.pipe_xlo[blk];
-        xhi_i = P.pipe_xhi[blk];
-        ldo_i = xhi_i - xlo_i;
-        out_off = (size_t)P.snum * xlo_i;
-    } else if (P.queue) {
+    if (P.queue) {
         __syncthreads();                       // every wave is done with the previous item (ring reads, the slot)
         if (threadIdx.x == 0) {
             unsigned xcc;
@@ -999,7 +926,7 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
         if (xt < 0 || xt >= P.nxt) return;
     }
     const int s0 = chunk * KF_THREADS;
-    const int x0w = (xlo_i & ~7) + xt * (XB * NH);   // workgroup's first output trace: a multiple of 8 (outputs left of xlo are not stored)
+    const int x0w = (P.xlo & ~7) + xt * (XB * NH);   // workgroup's first output trace: a multiple of 8 (outputs left of xlo are not stored)
     const int x0 = x0w + half * XB;
     const int snum = P.snum, tnum = P.tnum;
     // ds_read_b128 is serviced in four groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31},
@@ -1339,11 +1266,11 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_quad_kernel(FastPa
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // the look-ahead DMA must land before the LDS is released
 
     if (ti_raw < snum) {
-        float *o = (P.parts_log2 ? reinterpret_cast<float *>(P.partial) + (size_t)part * P.part_stride : P.out + out_off) +
-                   (size_t)ti_raw * ldo_i + (x0 - xlo_i);
+        float *o = (P.parts_log2 ? reinterpret_cast<float *>(P.partial) + (size_t)part * P.part_stride : P.out) +
+                   (size_t)ti_raw * P.ldo + (x0 - P.xlo);
 #pragma unroll
         for (int i = 0; i < XB; ++i)
-            if (x0 + i >= xlo_i && x0 + i < xhi_i) o[i] = KQ_ACC(i) * fin;
+            if (x0 + i >= P.xlo && x0 + i < P.xhi) o[i] = KQ_ACC(i) * fin;
     }
 #undef KQ_ACC
     if (!P.queue) break;
@@ -1435,28 +1362,11 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_dquad_kernel(FastP
     const int half = NH > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
     // persistent workgroups pulling (chunk, tile) items from per-XCD queues: see kirch_quad_kernel
     bool first_item = true;
-    int pipe_prev = -1;                       // pipelined launch: block of the item just finished
     int *item_slot = reinterpret_cast<int *>(lds) + (size_t)(img_bytes / 4) * (NEAR ? 2 : 1);
     for (;;) {
     int chunk, xt;
     int part = 0;            // see kirch_quad_kernel: which piece of the tile's aperture walk (plans of 4+ ranks)
-    int xlo_i = P.xlo, xhi_i = P.xhi, ldo_i = P.ldo;       // this item's output block (see kirch_quad_kernel)
-    size_t out_off = 0;
-    if (P.items) {
-        __syncthreads();
-        if (threadIdx.x == 0) item_slot[0] = kirch_pipe_next(P, pipe_prev);
-        __syncthreads();
-        const int it = item_slot[0];
-        if (it < 0) break;
-        const int blk = it >> 28;
-        pipe_prev = blk;
-        chunk = (it >> 16) & 0xfff;
-        xt = it & 0xffff;
-        xlo_i = P.pipe_xlo[blk];
-        xhi_i = P.pipe_xhi[blk];
-        ldo_i = xhi_i - xlo_i;
-        out_off = (size_t)P.snum * xlo_i;
-    } else if (P.queue) {
+    if (P.queue) {
         __syncthreads();
         if (threadIdx.x == 0) {
             unsigned xcc;
@@ -1496,7 +1406,7 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_dquad_kernel(FastP
         if (xt < 0 || xt >= P.nxt) return;
     }
     const int s0 = chunk * KF_THREADS;
-    const int x0w = (xlo_i & ~3) + xt * (XB * NH);   // workgroup tiles start at a multiple of 4 (outputs left of xlo are not stored)
+    const int x0w = (P.xlo & ~3) + xt * (XB * NH);   // workgroup tiles start at a multiple of 4 (outputs left of xlo are not stored)
     const int x0 = x0w + half * XB;
     const int snum = P.snum, tnum = P.tnum;
     // lane -> sample permutation: the 16 lanes a ds_read_b128 services together hold 16 consecutive samples
@@ -1733,10 +1643,10 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_dquad_kernel(FastP
 
     if (ti_raw < snum) {
         double *o = (P.parts_log2 ? reinterpret_cast<double *>(P.partial) + (size_t)part * P.part_stride
-                                  : reinterpret_cast<double *>(P.out) + out_off) + (size_t)ti_raw * ldo_i + (x0 - xlo_i);
+                                  : reinterpret_cast<double *>(P.out)) + (size_t)ti_raw * P.ldo + (x0 - P.xlo);
 #pragma unroll
         for (int i = 0; i < XB; ++i)
-            if (x0 + i >= xlo_i && x0 + i < xhi_i) o[i] = (fin == 0.0) ? 0.0 : KD_ACC(i) * fin;
+            if (x0 + i >= P.xlo && x0 + i < P.xhi) o[i] = (fin == 0.0) ? 0.0 : KD_ACC(i) * fin;
     }
 #undef KD_ACC
     if (!P.queue) break;
@@ -2470,10 +2380,7 @@ static int build_tilemap(impdar_kirch_plan *p, FastParams &P, int tile_w, int al
     if ((int)p->h_hmax.size() != P.nchunks) return IMPDAR_OK;
     const int key[5] = {P.xlo, P.xhi, tile_w, P.G, P.tiles_per_xcd};
     const size_t n = (size_t)P.nchunks * P.tiles_per_xcd * 8;
-    int *tm_key = p->tm_key_l[p->lane];
-    std::vector<short> &h_tilemap = p->h_tilemap_l[p->lane];
-    DevBuf &d_tilemap = p->d_tilemap_l[p->lane];
-    if (memcmp(key, tm_key, sizeof(key)) != 0 || h_tilemap.size() != n) {
+    if (memcmp(key, p->tm_key, sizeof(key)) != 0 || p->h_tilemap.size() != n) {
         std::vector<short> map(n, (short)-1);
         const int x00 = P.xlo & ~align_mask;
         const int G = P.G, units = (P.nxt + G - 1) / G, cap = P.tiles_per_xcd / G;
@@ -2509,111 +2416,12 @@ static int build_tilemap(impdar_kirch_plan *p, FastParams &P, int tile_w, int al
             }
         }
         if (P.nxt > 32767) return IMPDAR_OK;
-        h_tilemap.swap(map);
-        memcpy(tm_key, key, sizeof(key));
-        IMPDAR_HIP_CHECK(d_tilemap.ensure(n * sizeof(short)));
-        IMPDAR_HIP_CHECK(hipMemcpyAsync(d_tilemap.p, h_tilemap.data(), n * sizeof(short), hipMemcpyHostToDevice, st));
+        p->h_tilemap.swap(map);
+        memcpy(p->tm_key, key, sizeof(key));
+        IMPDAR_HIP_CHECK(p->d_tilemap.ensure(n * sizeof(short)));
+        IMPDAR_HIP_CHECK(hipMemcpyAsync(p->d_tilemap.p, p->h_tilemap.data(), n * sizeof(short), hipMemcpyHostToDevice, st));
     }
-    P.tilemap = d_tilemap.as<short>();
-    return IMPDAR_OK;
-}
-
-// The item lists of the pipelined launch (FastParams::items): block by block, inside a block the deep chunks (long
-// walks) first, groups of G adjacent tiles to the XCD with the least accumulated walk (as build_tilemap does per launch).
-static int build_pipe_items(impdar_kirch_plan *p, FastParams &P, int tile_w, int ring_blocks, int step_block, hipStream_t st)
-{
-    KirchPipe &pp = *p->pipe;
-    auto words = [&] {
-        for (int b = 0; b < pp.nblk; ++b) {
-            P.pipe_xlo[b] = pp.cut[b];
-            P.pipe_xhi[b] = pp.cut[b + 1];
-            P.pipe_need[b] = pp.need[b];
-        }
-        P.items = p->d_items.as<int>();
-        P.items_per_xcd = pp.items_per_xcd;
-        P.in_ready = pp.in_ready;
-        P.abort = pp.abort_flag;
-        P.done = pp.done;
-        P.spin_limit = pp.spin_limit;
-    };
-    if (pp.join) {           // the second launch: the lists are on the device
-        words();
-        return IMPDAR_OK;
-    }
-    if ((int)p->h_hmax.size() != P.nchunks || P.nchunks > 4095 || pp.nblk < 1 || pp.nblk > 8) {
-        impdar_set_error("pipelined launch: plan without per-chunk aperture widths");
-        return IMPDAR_ERR_UNSUPPORTED;
-    }
-    // Order.  A block is done when its LAST item is: with 300 items a block and 480 workgroups all items of a block
-    // start together and the block is done one deep-chunk walk (2.7 ms) later -- the downloads of the last blocks (and
-    // the host's widening of them) then all fall behind the end of the launch.  So the deep chunks of a block (the
-    // chunks that hold ~70 % of the walk) are handed out LEAD blocks ahead of its shallow ones:
-    //     D(0) .. D(LEAD), S(0), D(LEAD + 1), S(1), ...
-    // and a block completes with its (short) shallow items, in order, spread over the launch.
-    constexpr int LEAD = 2;
-    std::vector<double> ccost(P.nchunks, 0.0);
-    double ctotal = 0;
-    for (int c = 0; c < P.nchunks; ++c) {
-        const int hm = p->h_hmax[c];
-        ccost[c] = 2.0 * hm + 8 * step_block;
-        ctotal += ccost[c];
-    }
-    int csplit = P.nchunks;          // chunks >= csplit are "deep"
-    {
-        double acc = 0;
-        while (csplit > 1 && acc + ccost[csplit - 1] <= 0.72 * ctotal) acc += ccost[--csplit];
-        if (csplit == P.nchunks) csplit = P.nchunks - 1;
-    }
-    std::vector<int> list[8];
-    double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto deal = [&](int b, int clo, int chi) {          // the items of block b's chunks [clo, chi), deep ones first
-        const int x00 = pp.cut[b], ntiles = (pp.cut[b + 1] - pp.cut[b] + tile_w - 1) / tile_w;
-        const int G = ntiles >= 32 ? 4 : 1, units = (ntiles + G - 1) / G;
-        std::vector<std::pair<double, int>> cost(units);
-        for (int c = chi - 1; c >= clo; --c) {
-            const int hm = p->h_hmax[c];
-            for (int u = 0; u < units; ++u) {
-                double w = 0;
-                for (int t = u * G; t < std::min((u + 1) * G, ntiles); ++t) {
-                    const int x0 = x00 + t * tile_w;
-                    const int nlo = std::max(-hm, -(x0 + tile_w - 1)), nhi = std::min(hm, p->tnum - 1 - x0);
-                    const int blocks = std::max(0, nhi - nlo + step_block) / step_block;
-                    w += ((blocks + ring_blocks - 1) / ring_blocks) * ring_blocks + 8;
-                }
-                cost[u] = {w, u};
-            }
-            std::sort(cost.begin(), cost.end(), [](const std::pair<double, int> &a, const std::pair<double, int> &b2) {
-                return a.first > b2.first || (a.first == b2.first && a.second < b2.second);
-            });
-            for (const auto &cu : cost) {
-                int best = 0;
-                for (int x = 1; x < 8; ++x)
-                    if (load[x] < load[best]) best = x;
-                for (int t = cu.second * G; t < std::min((cu.second + 1) * G, ntiles); ++t) list[best].push_back(t | (c << 16) | (b << 28));
-                load[best] += cu.first;
-            }
-        }
-    };
-    for (int b = 0; b < pp.nblk; ++b) {
-        const int ntiles = (pp.cut[b + 1] - pp.cut[b] + tile_w - 1) / tile_w;
-        if (ntiles > 65535) return IMPDAR_ERR_UNSUPPORTED;
-        pp.nitems[b] = ntiles * P.nchunks;
-    }
-    for (int b = 0; b <= std::min(LEAD, pp.nblk - 1); ++b) deal(b, csplit, P.nchunks);
-    for (int b = 0; b < pp.nblk; ++b) {
-        deal(b, 0, csplit);
-        if (b + LEAD + 1 < pp.nblk) deal(b + LEAD + 1, csplit, P.nchunks);
-    }
-    size_t per = 0;
-    for (const auto &l : list) per = std::max(per, l.size());
-    std::vector<int> &flat = p->h_items;
-    flat.assign(per * 8, -1);
-    for (int x = 0; x < 8; ++x)
-        for (size_t i = 0; i < list[x].size(); ++i) flat[i * 8 + x] = list[x][i];
-    IMPDAR_HIP_CHECK(p->d_items.ensure(flat.size() * sizeof(int) + 64));
-    IMPDAR_HIP_CHECK(hipMemcpyAsync(p->d_items.p, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    pp.items_per_xcd = (int)per;
-    words();
+    P.tilemap = p->d_tilemap.as<short>();
     return IMPDAR_OK;
 }
 
@@ -2632,7 +2440,7 @@ static int build_pipe_items(impdar_kirch_plan *p, FastParams &P, int tile_w, int
 static int kirch_reserved_slots(const impdar_kirch_plan *p)
 {
     const char *re = getenv("IMPDAR_KIRCH_RESERVE");
-    const int r = re ? atoi(re) : ((p->nranks > 1 || p->pipe) ? KQ_DEFAULT_RESERVE : 0);
+    const int r = re ? atoi(re) : (p->nranks > 1 ? KQ_DEFAULT_RESERVE : 0);
     return std::min(std::max(r, 0), 256);
 }
 
@@ -2654,8 +2462,7 @@ static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipSt
     const int nblk = P.nchunks * nxt_pad;
     const int W = p->quadW;
     {
-        const int trc = p->pipe ? build_pipe_items(p, P, XB * NH, (kq_ring_slots(XB) + 8 * LK) / 8, 8, st)
-                                : build_tilemap(p, P, XB * NH, 7, (kq_ring_slots(XB) + 8 * LK) / 8, 8, st);
+        const int trc = build_tilemap(p, P, XB * NH, 7, (kq_ring_slots(XB) + 8 * LK) / 8, 8, st);
         if (trc) return trc;
     }
     const size_t shmem = (size_t)(W / 32) * kq_piece_bytes_lk(XB, LK) * (p->nearfield ? 2 : 1) + 16;   // + the item slot
@@ -2667,27 +2474,7 @@ static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipSt
         auto k = kirch_quad_kernel<XB, false, OCC, SH, NH, LK>;
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         int grid = nblk;
-        if (P.items) {
-            // the pipelined one-shot call: ONE persistent launch over all blocks
-            if (p->slots <= 0) {
-                int per_cu = 0, ncu = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, KF_THREADS * NH, shmem) == hipSuccess &&
-                    hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->ctx->device) == hipSuccess &&
-                    per_cu > 0 && ncu > 0)
-                    p->slots = per_cu * ncu;
-                else
-                    (void)hipGetLastError();
-            }
-            if (p->slots <= 0 || p->d_queue_l[p->lane].ensure(8 * 64) != hipSuccess) {
-                impdar_set_error("pipelined launch: no occupancy figure / queue counters");
-                return IMPDAR_ERR_HIP;
-            }
-            if (!p->pipe->join) IMPDAR_HIP_CHECK(hipMemsetAsync(p->d_queue_l[p->lane].p, 0, 8 * 64, st));
-            P.queue = p->d_queue_l[p->lane].as<int>();
-            grid = (int)std::min<long long>(std::max(p->slots - kirch_reserved_slots(p), 1), (long long)P.items_per_xcd * 8);
-            if (p->pipe->join) grid = std::max(kirch_reserved_slots(p) - 4, 0);      // (tie fixes and stream waits keep four)
-            if (grid == 0) return IMPDAR_OK;
-        } else if (P.tilemap) {
+        if (P.tilemap) {
             // persistent workgroups: as many as are resident at once, each pulling items from the per-XCD queues
             if (p->slots <= 0) {        // resident workgroups of this plan's kernel on this device: asked once
                 int per_cu = 0, ncu = 0;
@@ -2702,9 +2489,9 @@ static int launch_quad(impdar_kirch_plan *p, const FastParams &P0, int nx, hipSt
             const int pl2 = NH == 1 ? p->walk_parts_log2 : 0;
             const size_t nout = (size_t)P.snum * P.ldo, esz = impdar_dtype_size(p->dtype);
             const bool pieces = pl2 > 0 && p->slots > 0 && p->d_partial.ensure((nout << pl2) * esz) == hipSuccess;
-            if (p->slots > 0 && (p->slots < nblk || pieces) && p->d_queue_l[p->lane].ensure(8 * 64) == hipSuccess) {
-                IMPDAR_HIP_CHECK(hipMemsetAsync(p->d_queue_l[p->lane].p, 0, 8 * 64, st));
-                P.queue = p->d_queue_l[p->lane].as<int>();
+            if (p->slots > 0 && (p->slots < nblk || pieces) && p->d_queue.ensure(8 * 64) == hipSuccess) {
+                IMPDAR_HIP_CHECK(hipMemsetAsync(p->d_queue.p, 0, 8 * 64, st));
+                P.queue = p->d_queue.as<int>();
                 if (pieces) {
                     P.parts_log2 = pl2;
                     P.partial = p->d_partial.p;
@@ -2751,8 +2538,7 @@ static int launch_dquad(impdar_kirch_plan *p, const FastParams &P0, hipStream_t 
     const int nblk = P.nchunks * nxt_pad;
     const int W = p->quadW;
     {
-        const int trc = p->pipe ? build_pipe_items(p, P, XB * NH, kd_ring_slots(XB) / 4, 4, st)
-                                : build_tilemap(p, P, XB * NH, 3, kd_ring_slots(XB) / 4, 4, st);
+        const int trc = build_tilemap(p, P, XB * NH, 3, kd_ring_slots(XB) / 4, 4, st);
         if (trc) return trc;
     }
     const size_t shmem = (size_t)(W / 32) * kd_piece_bytes(XB) * (p->nearfield ? 2 : 1) + 16;      // + the item slot
@@ -2764,27 +2550,7 @@ static int launch_dquad(impdar_kirch_plan *p, const FastParams &P0, hipStream_t 
         auto k = kirch_dquad_kernel<XB, false, (NH > 1 ? 4 : 2), SH, NH>;
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         int grid = nblk;
-        if (P.items) {
-            // the pipelined one-shot call: ONE persistent launch over all blocks
-            if (p->slots <= 0) {
-                int per_cu = 0, ncu = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, KF_THREADS * NH, shmem) == hipSuccess &&
-                    hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->ctx->device) == hipSuccess &&
-                    per_cu > 0 && ncu > 0)
-                    p->slots = per_cu * ncu;
-                else
-                    (void)hipGetLastError();
-            }
-            if (p->slots <= 0 || p->d_queue_l[p->lane].ensure(8 * 64) != hipSuccess) {
-                impdar_set_error("pipelined launch: no occupancy figure / queue counters");
-                return IMPDAR_ERR_HIP;
-            }
-            if (!p->pipe->join) IMPDAR_HIP_CHECK(hipMemsetAsync(p->d_queue_l[p->lane].p, 0, 8 * 64, st));
-            P.queue = p->d_queue_l[p->lane].as<int>();
-            grid = (int)std::min<long long>(std::max(p->slots - kirch_reserved_slots(p), 1), (long long)P.items_per_xcd * 8);
-            if (p->pipe->join) grid = std::max(kirch_reserved_slots(p) - 4, 0);      // (tie fixes and stream waits keep four)
-            if (grid == 0) return IMPDAR_OK;
-        } else if (P.tilemap) {
+        if (P.tilemap) {
             if (p->slots <= 0) {        // resident workgroups of this plan's kernel on this device: asked once
                 int per_cu = 0, ncu = 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, KF_THREADS * NH, shmem) == hipSuccess &&
@@ -2798,9 +2564,9 @@ static int launch_dquad(impdar_kirch_plan *p, const FastParams &P0, hipStream_t 
             const int pl2 = NH == 1 ? p->walk_parts_log2 : 0;
             const size_t nout = (size_t)P.snum * P.ldo, esz = impdar_dtype_size(p->dtype);
             const bool pieces = pl2 > 0 && p->slots > 0 && p->d_partial.ensure((nout << pl2) * esz) == hipSuccess;
-            if (p->slots > 0 && (p->slots < nblk || pieces) && p->d_queue_l[p->lane].ensure(8 * 64) == hipSuccess) {
-                IMPDAR_HIP_CHECK(hipMemsetAsync(p->d_queue_l[p->lane].p, 0, 8 * 64, st));
-                P.queue = p->d_queue_l[p->lane].as<int>();
+            if (p->slots > 0 && (p->slots < nblk || pieces) && p->d_queue.ensure(8 * 64) == hipSuccess) {
+                IMPDAR_HIP_CHECK(hipMemsetAsync(p->d_queue.p, 0, 8 * 64, st));
+                P.queue = p->d_queue.as<int>();
                 if (pieces) {
                     P.parts_log2 = pl2;
                     P.partial = p->d_partial.p;
@@ -2858,64 +2624,17 @@ static int launch_tab(impdar_kirch_plan *p, const FastParams &P0, int nx, hipStr
     return IMPDAR_OK;
 }
 
-// the (sample, offset) entries whose pick rounding noise decides, pair by pair, on the compact block d_out of output
-// traces [xlo, xhi) (kirch_tiefix_kernel): behind every table-driven diffraction sum
-static int kirch_tiefix_on(impdar_kirch_plan *p, void *d_out, int xlo, int xhi, hipStream_t st)
-{
-    const int nx = xhi - xlo;
-    const int b = p->buf;
-    if (nx > 0 && p->ntie_groups > 0 && impdar_kirch_plan_kernel(p) != IMPDAR_KERNEL_EXACT_PAIR) {
-        // the (sample, offset) entries whose pick rounding noise decides, pair by pair (kirch_tiefix_kernel)
-        const int kern = impdar_kirch_plan_kernel(p);
-        TieFixParams F;
-        F.GT = img_row0(p, p->GT[b]);
-        F.DT = p->nearfield ? img_row0(p, p->DT[b]) : nullptr;
-        F.out = d_out;
-        F.ldo = nx;
-        F.snum = p->snum;
-        F.tnum = p->tnum;
-        F.xlo = xlo;
-        F.xhi = xhi;
-        F.grp = kern == IMPDAR_KERNEL_QUAD ? 8 : (kern == IMPDAR_KERNEL_DQUAD ? 4 : 0);
-        F.near = p->nearfield;
-        F.dist = p->d_dist.as<double>();
-        F.zs = p->d_zs.as<double>();
-        F.zs2 = p->d_zs2.as<double>();
-        F.tt = p->d_tt.as<double>();
-        F.dx = p->dx;
-        F.vel = p->vel;
-        F.tmax = p->tmax;
-        F.inv_dt = 1.0 / p->dt;
-        F.tt0 = p->tt0;
-        F.g_ti = p->d_tie_ti.as<int>();
-        F.g_off = p->d_tie_off.as<int>();
-        F.g_n = p->d_tie_n.as<int>();
-        const bool xtab = kern == IMPDAR_KERNEL_EXACT_TAB;
-        F.hmax = xtab ? p->d_xhmax.as<int>() : p->d_hmax.as<int>();
-        F.nmax = xtab ? p->xntab : p->ntab - 1;
-        const dim3 grid((nx + 255) / 256, p->ntie_groups);
-        if (p->dtype == IMPDAR_F32)
-            hipLaunchKernelGGL(kirch_tiefix_kernel<float>, grid, dim3(256), 0, st, F);
-        else
-            hipLaunchKernelGGL(kirch_tiefix_kernel<double>, grid, dim3(256), 0, st, F);
-        IMPDAR_HIP_CHECK(hipGetLastError());
-    }
-    return IMPDAR_OK;
-}
-
-// the diffraction sum of output traces [xlo, xhi) on stream st, with launch lane `lane` (see impdar_kirch_plan::lane)
-static int kirch_migrate_on(impdar_kirch_plan *p, void *d_out, int xlo, int xhi, hipStream_t st, int lane)
+extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, int xhi)
 {
     IMPDAR_ARG_CHECK(p && d_out, "null plan/output");
     IMPDAR_ARG_CHECK(0 <= xlo && xlo <= xhi && xhi <= p->tnum, "bad output trace range [%d,%d) for tnum %d", xlo,
                      xhi, p->tnum);
     IMPDAR_HIP_CHECK(hipSetDevice(p->ctx->device));
-    p->lane = lane;
+    hipStream_t st = p->ctx->stream;
     hipEvent_t *ev = p->evs[p->slot];
     const int b = p->buf;
-    const bool join = p->pipe && p->pipe->join;      // a launch that joins the pipelined one: no events of its own
     IMPDAR_HIP_CHECK(hipStreamWaitEvent(st, p->ev_ready[b], 0));      // image + table of this radargram
-    if (!p->haves[p->slot][2] && !join) IMPDAR_HIP_CHECK(hipEventRecord(ev[4], st));
+    if (!p->haves[p->slot][2]) IMPDAR_HIP_CHECK(hipEventRecord(ev[4], st));
     const int nx = xhi - xlo;
     if (nx > 0 && p->gen) {
         const int grc = kirch_launch_gen(p, d_out, xlo, xhi, st);
@@ -2952,11 +2671,6 @@ static int kirch_migrate_on(impdar_kirch_plan *p, void *d_out, int xlo, int xhi,
         P.mrow0 = p->mrow0;
         P.tilemap = nullptr;
         P.queue = nullptr;
-        P.items = nullptr;
-        P.items_per_xcd = 0;
-        P.in_ready = nullptr;
-        P.done = P.abort = nullptr;
-        P.spin_limit = 0;
         P.parts_log2 = 0;
         P.partial = nullptr;
         P.part_stride = 0;
@@ -3089,11 +2803,42 @@ static int kirch_migrate_on(impdar_kirch_plan *p, void *d_out, int xlo, int xhi,
         }
         IMPDAR_HIP_CHECK(hipGetLastError());
     }
-    if (!p->pipe) {          // (the pipelined launch: block by block, behind each block's items -- impdar_kirchhoff)
-        const int trc = kirch_tiefix_on(p, d_out, xlo, xhi, st);
-        if (trc) return trc;
+    if (nx > 0 && p->ntie_groups > 0 && impdar_kirch_plan_kernel(p) != IMPDAR_KERNEL_EXACT_PAIR) {
+        // the (sample, offset) entries whose pick rounding noise decides, pair by pair (kirch_tiefix_kernel)
+        const int kern = impdar_kirch_plan_kernel(p);
+        TieFixParams F;
+        F.GT = img_row0(p, p->GT[b]);
+        F.DT = p->nearfield ? img_row0(p, p->DT[b]) : nullptr;
+        F.out = d_out;
+        F.ldo = nx;
+        F.snum = p->snum;
+        F.tnum = p->tnum;
+        F.xlo = xlo;
+        F.xhi = xhi;
+        F.grp = kern == IMPDAR_KERNEL_QUAD ? 8 : (kern == IMPDAR_KERNEL_DQUAD ? 4 : 0);
+        F.near = p->nearfield;
+        F.dist = p->d_dist.as<double>();
+        F.zs = p->d_zs.as<double>();
+        F.zs2 = p->d_zs2.as<double>();
+        F.tt = p->d_tt.as<double>();
+        F.dx = p->dx;
+        F.vel = p->vel;
+        F.tmax = p->tmax;
+        F.inv_dt = 1.0 / p->dt;
+        F.tt0 = p->tt0;
+        F.g_ti = p->d_tie_ti.as<int>();
+        F.g_off = p->d_tie_off.as<int>();
+        F.g_n = p->d_tie_n.as<int>();
+        const bool xtab = kern == IMPDAR_KERNEL_EXACT_TAB;
+        F.hmax = xtab ? p->d_xhmax.as<int>() : p->d_hmax.as<int>();
+        F.nmax = xtab ? p->xntab : p->ntab - 1;
+        const dim3 grid((nx + 255) / 256, p->ntie_groups);
+        if (p->dtype == IMPDAR_F32)
+            hipLaunchKernelGGL(kirch_tiefix_kernel<float>, grid, dim3(256), 0, st, F);
+        else
+            hipLaunchKernelGGL(kirch_tiefix_kernel<double>, grid, dim3(256), 0, st, F);
+        IMPDAR_HIP_CHECK(hipGetLastError());
     }
-    if (join) return IMPDAR_OK;
     IMPDAR_HIP_CHECK(hipEventRecord(ev[5], st));
     IMPDAR_HIP_CHECK(hipEventRecord(p->ev_free[b], st));
     p->free_recorded[b] = true;
@@ -3102,12 +2847,6 @@ static int kirch_migrate_on(impdar_kirch_plan *p, void *d_out, int xlo, int xhi,
     p->migrated_since_prep = true;
     p->haves[p->slot][2] = true;
     return IMPDAR_OK;
-}
-
-extern "C" int impdar_kirch_migrate(impdar_kirch_plan *p, void *d_out, int xlo, int xhi)
-{
-    IMPDAR_ARG_CHECK(p && d_out, "null plan/output");
-    return kirch_migrate_on(p, d_out, xlo, xhi, p->ctx->stream, 0);
 }
 
 // defined in comm.hip
@@ -3238,11 +2977,6 @@ struct KirchOneShot {
     impdar_kirch_plan *plan = nullptr;
     DevBuf din, dout;
     hipEvent_t ev_blk[8] = {};       // output block i of a split one-shot call summed (see impdar_kirchhoff)
-    hipStream_t st2 = nullptr;       // the stream that waits for a block's count, fixes its ties and releases its download
-    unsigned *h_done = nullptr;      // pinned: items done per block (16 words apart), see FastParams::items
-    hipStream_t st3 = nullptr;       // the uploads of the pipelined call (the producer stream's preps run beside them)
-    hipEvent_t ev_up[8] = {};        // ... chunk i has arrived
-    DevBuf d_sync;                   // device: [0] input traces ready, [32] a workgroup gave up waiting
     int dtype = -1, snum = 0, tnum = 0, nearfield = 0, grad_uniform = 0, mode = 0;
     double vel = 0, grad_h = 0;
     std::vector<double> dist, tt, ga, gb, gc;
@@ -3257,23 +2991,6 @@ struct KirchOneShot {
             if (e) (void)hipEventDestroy(e);
             e = nullptr;
         }
-        if (st2) {
-            (void)hipStreamSynchronize(st2);
-            (void)hipStreamDestroy(st2);
-            st2 = nullptr;
-        }
-        if (st3) {
-            (void)hipStreamSynchronize(st3);
-            (void)hipStreamDestroy(st3);
-            st3 = nullptr;
-        }
-        for (hipEvent_t &e : ev_up) {
-            if (e) (void)hipEventDestroy(e);
-            e = nullptr;
-        }
-        if (h_done) (void)hipHostFree(h_done);
-        h_done = nullptr;
-        d_sync.release();
         owner = nullptr;
     }
 };
@@ -3370,8 +3087,6 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
             // when an error hands the array back
             (void)hipStreamSynchronize(ctx->aux);
             (void)hipStreamSynchronize(ctx->stream);
-            if (c.st2) (void)hipStreamSynchronize(c.st2);
-            if (c.st3) (void)hipStreamSynchronize(c.st3);
         }
         if (code != IMPDAR_OK || !keep) c.drop();
         return code;
@@ -3386,161 +3101,56 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
     // accumulates its pairs in the same order): a block crosses PCIe and is widened on the host while the next is
     // summed.  INPUT traces in column chunks: block i reads the traces up to its right edge + the aperture half width
     // only (the halo of the multi-GPU plan), so its launch starts when those are on the device and the rest of the
-    // upload runs under it; later chunks are prepared into the same image (kirch_prep_impl's `more`).
-    // Every launch must drain (a launch ends with its slowest workgroup: 10.2 ms of kernels in four launches against 7.6
-    // in one) -- the copies they hide are worth more.  Four blocks [0, .10, .40, .70, 1] tnum when the aperture leaves
-    // something to overlap (config 3: the first launch needs 45 % of the input; a sweep of the cuts is in
-    // profiles/r03_oneshot_pipeline.txt), else two (5/8 + 3/8, download overlap only).
-    // IMPDAR_KIRCH_ONESHOT_SPLIT=0: one upload, one launch, one download.
-    // =persistent (round 4, measured slower, kept for the record and under test: profiles/r04_oneshot_pipeline.txt): ONE
-    // persistent launch for all blocks.  Its workgroups pull the items of all blocks (eight, in whole tiles) from
-    // per-XCD lists; an item waits (lane 0, bounded) until the input it reads has been uploaded AND prepared -- a count
-    // the producer stream writes behind every prep (hipStreamWriteValue32) -- and adds one to its block's count when it
-    // is done; a third stream waits for that count (hipStreamWaitValue32), runs the block's tie fix and lets its
-    // download go.  32 of the 512 workgroup slots stay free for the preps (28 join the sum behind the last prep).  No
-    // launch drains but the last -- and the blocks finish LATE: a block of 300 items on 480 workgroups is done one deep
-    // walk after it starts, the downloads and the host's widening of the last 40 % fall behind the launch's end.
+    // upload runs under it; later chunks are prepared into the same image (kirch_prep_impl's `more`).  Every launch
+    // must drain (~0.3 ms each) -- the copies they hide are worth more.  Four blocks [0, .10, .40, .70, 1] tnum when
+    // the aperture leaves something to overlap (config 3: the first launch needs 45 % of the input; a sweep of the
+    // cuts is in profiles/r03_oneshot_pipeline.txt), else two (5/8 + 3/8, download overlap only).
+    // IMPDAR_KIRCH_ONESHOT_SPLIT=0: one upload, one launch, one download; =2: one upload, two launches.
     const char *se = getenv("IMPDAR_KIRCH_ONESHOT_SPLIT");
     const int kern = impdar_kirch_plan_kernel(p);
-    const bool split = !(se && !strcmp(se, "0")) && tnum >= 4096 && bytes >= ((size_t)64 << 20) &&
+    const bool split = !(se && atoi(se) == 0) && tnum >= 4096 && bytes >= ((size_t)64 << 20) &&
                        (kern == IMPDAR_KERNEL_QUAD || kern == IMPDAR_KERNEL_DQUAD);
-    // (near-field plans: their ring kernels have no persistent form)
-    // (=stall, tests: the persistent form with the last chunk's count never written -- the launch must give up and the
-    // call must fail)
-    const bool stall = split && se && !strcmp(se, "stall") && !nearfield;
-    const bool persistent = split && se && (!strcmp(se, "persistent") || stall) && !nearfield;
     int nlaunch = 1;
     if (split) {
         const int halo = p->ntab + 16;                 // aperture half width (+ the kernels' staging look-ahead)
-        // cuts on whole workgroup tiles (and on the 8-trace groups of the image)
-        int unit = std::max(1, p->xb * p->nh);
-        while (unit % 8) unit *= 2;
-        auto ru = [unit](long long x) { return (int)(x / unit * unit); };
+        auto r8 = [](long long x) { return (int)(x / 8 * 8); };
         std::vector<int> cut;
-        // interior cuts in percent of tnum
-        const std::vector<int> pct = persistent ? std::vector<int>{5, 16, 32, 50, 68, 84, 93} : std::vector<int>{10, 40, 70};
-        if ((long long)tnum * pct[1] / 100 + halo < (long long)tnum * 9 / 10) {
+        const bool two = se && atoi(se) == 2;          // the round-3 first form, kept for A/B
+        const std::vector<int> pct = {10, 40, 70};         // interior cuts in percent of tnum (sweep: profiles/r03_oneshot_pipeline.txt)
+        if (!two && (long long)tnum * pct[pct.size() > 1 ? 1 : 0] / 100 + halo < (long long)tnum * 9 / 10) {
             cut = {0};
-            for (int q : pct) {
-                const int x = ru((long long)tnum * q / 100);
-                if (x > cut.back()) cut.push_back(x);
-            }
+            for (int q : pct) cut.push_back(r8((long long)tnum * q / 100));
             cut.push_back(tnum);
         } else {
-            cut = {0, ru((long long)tnum * 5 / 8), tnum};
+            cut = {0, r8((long long)tnum * 5 / 8), tnum};
         }
         const int nblk = (int)cut.size() - 1;
-        nlaunch = persistent ? 1 : nblk;
+        nlaunch = nblk;
         for (int i = 0; i < nblk; ++i)
             if (!c.ev_blk[i] && hipEventCreateWithFlags(&c.ev_blk[i], hipEventDisableTiming) != hipSuccess) {
                 c.ev_blk[i] = nullptr;
                 impdar_set_error("hipEventCreate failed");
                 return done(IMPDAR_ERR_HIP);
             }
-        KirchPipe pipe;
-        if (persistent) {
-            if (!c.st2) {
-                int prio_lo = 0, prio_hi = 0;
-                (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-                if (hipStreamCreateWithPriority(&c.st2, hipStreamNonBlocking, prio_hi) != hipSuccess) {
-                    c.st2 = nullptr;
-                    impdar_set_error("hipStreamCreate failed");
-                    return done(IMPDAR_ERR_HIP);
-                }
-            }
-            if (!c.st3 && hipStreamCreateWithFlags(&c.st3, hipStreamNonBlocking) != hipSuccess) {
-                c.st3 = nullptr;
-                impdar_set_error("hipStreamCreate failed");
-                return done(IMPDAR_ERR_HIP);
-            }
-            for (int i = 0; i < nblk; ++i)
-                if (!c.ev_up[i] && hipEventCreateWithFlags(&c.ev_up[i], hipEventDisableTiming) != hipSuccess) {
-                    c.ev_up[i] = nullptr;
-                    impdar_set_error("hipEventCreate failed");
-                    return done(IMPDAR_ERR_HIP);
-                }
-            if (!c.h_done && hipHostMalloc(reinterpret_cast<void **>(&c.h_done), 8 * 64, hipHostMallocMapped) != hipSuccess) {
-                c.h_done = nullptr;
-                impdar_set_error("hipHostMalloc of the block counters failed");
-                return done(IMPDAR_ERR_HIP);
-            }
-            if (c.d_sync.ensure(256) != hipSuccess) {
-                impdar_set_error("hipMalloc of the pipeline words failed");
-                return done(IMPDAR_ERR_HIP);
-            }
-            // (nothing of an earlier call is in flight: every call ends with its downloads, which wait for all of it)
-            memset(c.h_done, 0, 8 * 64);
-            if (hipMemsetAsync(c.d_sync.p, 0, 256, ctx->aux) != hipSuccess) return done(IMPDAR_ERR_HIP);
-            pipe.nblk = nblk;
-            for (int i = 0; i <= nblk; ++i) pipe.cut[i] = cut[i];
-            for (int i = 0; i < nblk; ++i) pipe.need[i] = (int)std::min<long long>(tnum, ((long long)cut[i + 1] + halo + 7) / 8 * 8);
-            pipe.in_ready = c.d_sync.as<unsigned>();
-            pipe.abort_flag = c.d_sync.as<unsigned>() + 32;
-            pipe.done = c.h_done;
-            pipe.spin_limit = stall ? 20000000LL : 200000000LL;      // 2 s of the 100 MHz clock: an upload that takes longer has failed
-        }
         char *dout = reinterpret_cast<char *>(c.dout.p);
         int have = 0;                                  // input traces [0, have) are on the device and prepared
-        auto bring = [&](int i) -> int {               // input chunk of block i: upload and prep
-            const int need = (int)std::min<long long>(tnum, ((long long)cut[i + 1] + halo + 7) / 8 * 8);
+        for (int i = 0; i < nblk; ++i) {
+            const int need = two ? tnum : (int)std::min<long long>(tnum, ((long long)cut[i + 1] + halo + 7) / 8 * 8);
             if (need > have) {
-                // column block [have, need) of the (snum, tnum) host array, in front of its prep on the producer stream.
-                // (The persistent form copies on a stream of its own: the preps run on the few slots the launch leaves
-                // free, 0.6-0.75 ms a chunk, and behind them on one stream the last chunk arrived at 5.5 ms instead of 2.9.)
-                hipStream_t ups = persistent ? c.st3 : ctx->aux;
+                // column block [have, need) of the (snum, tnum) host array; on the producer stream, in front of its prep
                 if (hipMemcpy2DAsync(reinterpret_cast<char *>(c.din.p) + (size_t)have * esz, (size_t)tnum * esz,
                                      reinterpret_cast<const char *>(data) + (size_t)have * esz, (size_t)tnum * esz,
-                                     (size_t)(need - have) * esz, (size_t)snum, hipMemcpyHostToDevice, ups) != hipSuccess) {
+                                     (size_t)(need - have) * esz, (size_t)snum, hipMemcpyHostToDevice, ctx->aux) != hipSuccess) {
                     impdar_set_error("H2D copy failed");
-                    return IMPDAR_ERR_HIP;
-                }
-                if (persistent && (hipEventRecord(c.ev_up[i], c.st3) != hipSuccess ||
-                                   hipStreamWaitEvent(ctx->aux, c.ev_up[i], 0) != hipSuccess)) {
-                    impdar_set_error("H2D copy failed");
-                    return IMPDAR_ERR_HIP;
-                }
-                const int prc = kirch_prep_impl(p, reinterpret_cast<const char *>(c.din.p) + (size_t)have * esz, tnum, have,
-                                                need - have, 0, have > 0);
-                if (prc) return prc;
-                have = need;
-                if (persistent && !(stall && have == tnum) && hipStreamWriteValue32(ctx->aux, pipe.in_ready, (uint32_t)have, 0) != hipSuccess) {
-                    impdar_set_error("hipStreamWriteValue32 failed");
-                    return IMPDAR_ERR_HIP;
-                }
-            }
-            return IMPDAR_OK;
-        };
-        if (persistent) {
-            if ((rc = bring(0))) return done(rc);
-            p->pipe = &pipe;
-            rc = kirch_migrate_on(p, dout, 0, tnum, ctx->stream, 0);
-            p->pipe = nullptr;
-            if (rc) return done(rc);
-            for (int i = 1; i < nblk; ++i)
-                if ((rc = bring(i))) return done(rc);
-            // the preps are through (the launch below waits for the last one): most of the slots they needed join in
-            pipe.join = true;
-            p->pipe = &pipe;
-            rc = kirch_migrate_on(p, dout, 0, tnum, c.st3, 0);
-            p->pipe = nullptr;
-            pipe.join = false;
-            if (rc) return done(rc);
-            p->migrated_since_prep = true;         // (the preps of the later chunks came after the launch)
-            for (int i = 0; i < nblk; ++i) {
-                // block i: all of its items done -> its tie fix -> its download may start
-                if (hipStreamWaitValue32(c.st2, pipe.done + 16 * i, (uint32_t)pipe.nitems[i], hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) {
-                    impdar_set_error("hipStreamWaitValue32 failed");
                     return done(IMPDAR_ERR_HIP);
                 }
-                if ((rc = kirch_tiefix_on(p, dout + (size_t)snum * cut[i] * esz, cut[i], cut[i + 1], c.st2))) return done(rc);
-                if (hipEventRecord(c.ev_blk[i], c.st2) != hipSuccess) return done(IMPDAR_ERR_HIP);
+                if ((rc = kirch_prep_impl(p, reinterpret_cast<const char *>(c.din.p) + (size_t)have * esz, tnum, have,
+                                          need - have, 0, have > 0)))
+                    return done(rc);
+                have = need;
             }
-        } else {
-            for (int i = 0; i < nblk; ++i) {
-                if ((rc = bring(i))) return done(rc);
-                if ((rc = kirch_migrate_on(p, dout + (size_t)snum * cut[i] * esz, cut[i], cut[i + 1], ctx->stream, i))) return done(rc);
-                if (hipEventRecord(c.ev_blk[i], ctx->stream) != hipSuccess) return done(IMPDAR_ERR_HIP);
-            }
+            if ((rc = impdar_kirch_migrate(p, dout + (size_t)snum * cut[i] * esz, cut[i], cut[i + 1]))) return done(rc);
+            if (hipEventRecord(c.ev_blk[i], ctx->stream) != hipSuccess) return done(IMPDAR_ERR_HIP);
         }
         // the blocks leave on the producer stream (idle after the last prep) as their launches finish: all copies
         // enqueued at once, the host widens what has arrived
@@ -3555,20 +3165,6 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
             if ((rc = impdar_download_blocks_f64(ctx, out, (size_t)tnum, (size_t)snum, dtype, nblk, col0.data(), width.data(),
                                                  src.data(), c.ev_blk, ctx->aux)))
                 return done(rc);
-        }
-        if (persistent) {
-            // a workgroup that gave up waiting for its input released every count: the image is not a result
-            unsigned gave_up = 0;
-            if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
-                hipMemcpy(&gave_up, pipe.abort_flag, 4, hipMemcpyDeviceToHost) != hipSuccess) {
-                impdar_set_error("pipelined launch: %s", hipGetErrorString(hipGetLastError()));
-                return done(IMPDAR_ERR_HIP);
-            }
-            if (gave_up) {
-                impdar_set_error("pipelined launch: a workgroup waited %.1f s for its input traces and gave up",
-                                 (double)pipe.spin_limit / 1e8);
-                return done(IMPDAR_ERR_HIP);
-            }
         }
     } else {
         if (hipMemcpyAsync(c.din.p, data, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||

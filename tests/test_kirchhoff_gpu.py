@@ -336,25 +336,18 @@ def test_one_shot_in_pieces_equals_one_launch(hip, monkeypatch, dtype, dx, tnum,
     output-trace blocks, one launch each, so that a block crosses PCIe while the next is computed, and -- when the
     aperture is narrow enough to leave something (dx = 4 m here: four blocks, three input chunks; dx = 1 m: the
     aperture spans the profile, two blocks, one upload) -- input-trace chunks uploaded under the launches that do not
-    need them.  IMPDAR_KIRCH_ONESHOT_SPLIT=persistent: ONE persistent launch walks all blocks (eight): its items wait
-    for the input count the producer stream writes, and a third stream waits for each block's item count before it
-    fixes the block's ties and lets its download go (near-field plans have no such form: one launch per block).  All
-    must equal the single upload / launch / download (=0) bit for bit, and the oracle on spot traces.  The last case: a
-    trace count that is not a whole number of 8-trace groups, near-field term (two images are prepared chunk by chunk)."""
-    import ctypes as C
-    import json
-    from impdar_amd import _hip, synth
+    need them.  The result must equal the single upload / launch / download bit for bit
+    (IMPDAR_KIRCH_ONESHOT_SPLIT=0) and the two-block form (=2), and the oracle on spot traces.  The last case: a trace
+    count that is not a whole number of 8-trace groups, near-field term (two images are prepared chunk by chunk)."""
+    from impdar_amd import synth
     from impdar_amd.lib.RadarData import RadarData
     from oracle import c_oracle
     snum, vel = 4096, 1.69e8
     geo = synth.geometry(snum, tnum, dx=dx)
     x = synth.diffractor_radargram(snum, tnum, vel=vel, ndiff=16, dx=dx).astype(dtype)
-    outs, launches = {}, {}
-    for split in (None, '0', 'persistent', None):
-        if split is None:
-            monkeypatch.delenv('IMPDAR_KIRCH_ONESHOT_SPLIT', raising=False)
-        else:
-            monkeypatch.setenv('IMPDAR_KIRCH_ONESHOT_SPLIT', split)
+    outs = {}
+    for split in ('1', '0', '2', '1'):
+        monkeypatch.setenv('IMPDAR_KIRCH_ONESHOT_SPLIT', split)
         # a fresh plan for the first three calls (the knob is read per call anyway), the cached one for the last
         monkeypatch.setenv('IMPDAR_KIRCH_ONESHOT_CACHE', '0' if len(outs) < 2 else '1')
         d = RadarData(None)
@@ -363,55 +356,19 @@ def test_one_shot_in_pieces_equals_one_launch(hip, monkeypatch, dtype, dx, tnum,
         d.migrate('kirch', vel=vel, nearfield=nearfield)
         assert d.data.dtype == np.float64 and d.data.shape == (snum, tnum)
         outs.setdefault(split, []).append(d.data)
-        buf = C.create_string_buffer(1024)
-        _hip.check(hip.load().impdar_ctx_last_metrics(hip.context(), buf, len(buf)), 'metrics')
-        launches[split] = json.loads(buf.value.decode())['launches']
     monkeypatch.setenv('IMPDAR_KIRCH_ONESHOT_CACHE', '0')
-    monkeypatch.delenv('IMPDAR_KIRCH_ONESHOT_SPLIT', raising=False)
-    assert np.array_equal(outs[None][0], outs['0'][0]) and np.array_equal(outs[None][0], outs[None][1])
-    assert np.array_equal(outs['persistent'][0], outs['0'][0])
-    nblk = 4 if dx == 4.0 else 2
-    assert launches['0'] == 1 and launches[None] == nblk and launches['persistent'] == (nblk if nearfield else 1), launches
-    # spot traces all along the profile, and both sides of every whole percent of it (the output cuts are whole tiles
-    # just below 10 / 40 / 70 % (5 / 16 / 32 / 50 / 68 / 84 / 93 % in the persistent form), or 5/8, of the traces; the
-    # input chunks end an aperture beyond them)
-    cols = np.unique(np.concatenate([[0, 7, tnum - 1], np.arange(5, tnum, 293),
-                                     [c for q in (5, 10, 16, 32, 40, 50, 62.5, 68, 70, 84, 93) for c in
-                                      (int(tnum * q / 100) // 8 * 8 - 1, int(tnum * q / 100) // 8 * 8)]])).astype(np.int64)
+    assert np.array_equal(outs['1'][0], outs['0'][0]) and np.array_equal(outs['1'][0], outs['1'][1])
+    assert np.array_equal(outs['2'][0], outs['0'][0])
+    # both sides of the output cuts (dx 1: 5/8 of 4104 in whole groups of 8 = 2560) and of the input chunk edges of the
+    # dx = 4 runs (cut + the 865-trace aperture + margin, in groups of 8)
+    # (cuts at 10 / 40 / 70 % of the traces in whole groups of 8: 408, 1640, 2872 for 4104; 408, 1640, 2864 for 4101)
+    cols = np.array([0, 7, 407, 408, 1296, 1639, 1640, 2528, 2559, 2560, 2561, 2863, 2864, 2871, 2872, 3760, tnum - 1])
     want = c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], vel, nearfield, traces=cols)
-    got = outs[None][0][:, cols]
+    got = outs['1'][0][:, cols]
     if dtype == np.float64:
         assert rel_max(got, want) < EXACT_TOL
     else:
         assert rel_l2(got, want) < FAST_L2
-
-
-def test_pipelined_launch_gives_up_when_its_input_never_arrives(hip, monkeypatch):
-    """The workgroups of the persistent one-shot launch (IMPDAR_KIRCH_ONESHOT_SPLIT=persistent) wait for their input on
-    the device -- bounded: 2 s (0.2 s in this test) after which the launch gives up, lets go of every stream that waits
-    for a block, and the call FAILS.  =stall is that form with the count of the last input chunk withheld.  The next
-    call works."""
-    from impdar_amd import synth
-    from impdar_amd.lib.RadarData import RadarData
-    snum, tnum, vel, dx = 4096, 4104, 1.69e8, 4.0
-    geo = synth.geometry(snum, tnum, dx=dx)
-    x = synth.diffractor_radargram(snum, tnum, vel=vel, ndiff=8, dx=dx).astype(np.float32)
-
-    def run():
-        d = RadarData(None)
-        d.data, d.snum, d.tnum = x.copy(), snum, tnum
-        d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
-        d.migrate('kirch', vel=vel)
-        return d.data
-    monkeypatch.setenv('IMPDAR_KIRCH_ONESHOT_SPLIT', 'stall')
-    with pytest.raises(RuntimeError, match='gave up'):
-        run()
-    monkeypatch.setenv('IMPDAR_KIRCH_ONESHOT_SPLIT', 'persistent')
-    a = run()
-    monkeypatch.setenv('IMPDAR_KIRCH_ONESHOT_SPLIT', '0')
-    b = run()
-    monkeypatch.delenv('IMPDAR_KIRCH_ONESHOT_SPLIT')
-    assert np.array_equal(a, b)
 
 
 def test_reference_fixture_all_zeros(hip):

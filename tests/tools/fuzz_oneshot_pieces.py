@@ -2,8 +2,8 @@
 """One-off sweep of the pipelined one-shot Kirchhoff call (GPU box; not part of the pytest suites): random large
 geometries -- trace counts off the 8-trace groups, apertures from a tenth of the profile to all of it, float32 and
 float64, far and near field -- migrated in pieces (the default: upload in trace chunks, several launches, downloads
-underneath), as ONE persistent launch that waits for its input on the device (IMPDAR_KIRCH_ONESHOT_SPLIT=persistent) and
-with =0 (one upload, one launch, one download): the three must be BIT-EQUAL.
+underneath), with IMPDAR_KIRCH_ONESHOT_SPLIT=2 (one upload, two launches) and =0 (one upload, one launch, one download):
+the three must be BIT-EQUAL.
 
     python tests/tools/fuzz_oneshot_pieces.py [ncases] [seed]
 """
@@ -50,7 +50,7 @@ def main():
         geo = synth.geometry(snum, tnum, dt=dt, dx=dx)
         x = synth.noise_radargram(snum, tnum, seed=int(rng.integers(1 << 30))).astype(dtype)
         a = run(x, geo, snum, tnum, vel, nearfield, '')
-        c = run(x, geo, snum, tnum, vel, nearfield, 'persistent')
+        c = run(x, geo, snum, tnum, vel, nearfield, '2')
         b = run(x, geo, snum, tnum, vel, nearfield, '0')
         ok = np.array_equal(a, b) and np.array_equal(c, b) and np.isfinite(a).all() and a.any()
         bad += 0 if ok else 1
