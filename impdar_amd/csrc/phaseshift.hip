@@ -452,17 +452,28 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
                     asm volatile("" : "+v"(fr[m]), "+v"(fi[m]));
                 }
             }
+            // (pairs of frequencies that are zero in all 64 lanes -- the evanescent band, masked once at the start,
+            // :404-412 -- are skipped: see ps_vz32_kernel; exact zeros, the order of the other terms kept)
+            constexpr int QG = M >= 2 ? 2 : 1;
 #pragma unroll
-            for (int t = 0; t < PS_TT; ++t) {
+            for (int m0 = 0; m0 < M; m0 += QG) {
+                bool nz = false;
 #pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    const T nr = fma(fr[m], pa[m], -(fi[m] * pb[m]));   // FFK *= cp, :418
-                    const T ni = fma(fr[m], pb[m], fi[m] * pa[m]);
-                    fr[m] = nr;
-                    fi[m] = ni;
-                    acc[2 * t] += nr;                                   // TK[itau] += FFK, :420
-                    acc[2 * t + 1] += ni;
-                    asm volatile("" : "+v"(fr[m]), "+v"(fi[m]), "+v"(acc[2 * t]), "+v"(acc[2 * t + 1]));
+                for (int j = 0; j < QG; ++j) nz = nz || fr[m0 + j] != (T)0 || fi[m0 + j] != (T)0;
+                if (__builtin_amdgcn_ballot_w64(nz) == 0) continue;     // uniform
+#pragma unroll
+                for (int t = 0; t < PS_TT; ++t) {
+#pragma unroll
+                    for (int j = 0; j < QG; ++j) {
+                        const int m = m0 + j;
+                        const T nr = fma(fr[m], pa[m], -(fi[m] * pb[m]));   // FFK *= cp, :418
+                        const T ni = fma(fr[m], pb[m], fi[m] * pa[m]);
+                        fr[m] = nr;
+                        fi[m] = ni;
+                        acc[2 * t] += nr;                                   // TK[itau] += FFK, :420
+                        acc[2 * t + 1] += ni;
+                        asm volatile("" : "+v"(fr[m]), "+v"(fi[m]), "+v"(acc[2 * t]), "+v"(acc[2 * t + 1]));
+                    }
                 }
             }
         } else if (F32) {
@@ -764,17 +775,30 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 && M == 8) ? IMPDAR_PS_VZ32_M8
                 anchor(nrec);
                 nrec = 0;
             }
+            // Pairs of frequencies whose state is zero in all 64 lanes of the wave are skipped (round 4): once evanescent,
+            // zero for good (:484-485), and the frequencies below v kx / 2 are a contiguous band -- 42 % of the (kx, w)
+            // plane at config 5, whole waves' worth of slots.  A skipped term is an exact zero and the order of the
+            // others is kept (for every step: frequencies in rising order): the sums are bit for bit what they were.
+            constexpr int QG = M >= 2 ? 2 : 1;
 #pragma unroll
-            for (int t = 0; t < TT; ++t) {
+            for (int m0 = 0; m0 < M; m0 += QG) {
+                bool nz = false;
 #pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    const float nr = fmaf(gr[m], pc[m], -(gi[m] * ps[m]));     // FK *= exp(i w dt sqrt(coss)), :464
-                    const float ni = fmaf(gr[m], ps[m], gi[m] * pc[m]);
-                    gr[m] = nr;
-                    gi[m] = ni;
-                    acc[2 * t] += nr;                                           // TK[itau] += FK, :487
-                    acc[2 * t + 1] += ni;
-                    asm volatile("" : "+v"(gr[m]), "+v"(gi[m]), "+v"(acc[2 * t]), "+v"(acc[2 * t + 1]));
+                for (int j = 0; j < QG; ++j) nz = nz || gr[m0 + j] != 0.f || gi[m0 + j] != 0.f;
+                if (__builtin_amdgcn_ballot_w64(nz) == 0) continue;             // uniform
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+#pragma unroll
+                    for (int j = 0; j < QG; ++j) {
+                        const int m = m0 + j;
+                        const float nr = fmaf(gr[m], pc[m], -(gi[m] * ps[m]));     // FK *= exp(i w dt sqrt(coss)), :464
+                        const float ni = fmaf(gr[m], ps[m], gi[m] * pc[m]);
+                        gr[m] = nr;
+                        gi[m] = ni;
+                        acc[2 * t] += nr;                                           // TK[itau] += FK, :487
+                        acc[2 * t + 1] += ni;
+                        asm volatile("" : "+v"(gr[m]), "+v"(gi[m]), "+v"(acc[2 * t]), "+v"(acc[2 * t + 1]));
+                    }
                 }
             }
             nrec += TT;
@@ -1046,17 +1070,27 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
         for (int i = 0; i < 2 * TT; ++i) acc[i] = 0.0;
         const int tau0 = tile * TT;
         if constexpr (quiet) {
+            // (pairs of frequencies that are zero in all 64 lanes are skipped: see ps_vz32_kernel)
+            constexpr int QG = M >= 2 ? 2 : 1;
 #pragma unroll
-            for (int t = 0; t < TT; ++t) {
+            for (int m0 = 0; m0 < M; m0 += QG) {
+                bool nz = false;
 #pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    const double nr = fma(gr[m], pc[m], -(gi[m] * ps[m]));      // FK *= exp(i w dt sqrt(coss)), :464
-                    const double ni = fma(gr[m], ps[m], gi[m] * pc[m]);
-                    gr[m] = nr;
-                    gi[m] = ni;
-                    acc[2 * t] += nr;                                           // TK[itau] += FK, :487
-                    acc[2 * t + 1] += ni;
-                    asm volatile("" : "+v"(gr[m]), "+v"(gi[m]), "+v"(acc[2 * t]), "+v"(acc[2 * t + 1]));
+                for (int j = 0; j < QG; ++j) nz = nz || gr[m0 + j] != 0.0 || gi[m0 + j] != 0.0;
+                if (__builtin_amdgcn_ballot_w64(nz) == 0) continue;             // uniform
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+#pragma unroll
+                    for (int j = 0; j < QG; ++j) {
+                        const int m = m0 + j;
+                        const double nr = fma(gr[m], pc[m], -(gi[m] * ps[m]));      // FK *= exp(i w dt sqrt(coss)), :464
+                        const double ni = fma(gr[m], ps[m], gi[m] * pc[m]);
+                        gr[m] = nr;
+                        gi[m] = ni;
+                        acc[2 * t] += nr;                                           // TK[itau] += FK, :487
+                        acc[2 * t + 1] += ni;
+                        asm volatile("" : "+v"(gr[m]), "+v"(gi[m]), "+v"(acc[2 * t]), "+v"(acc[2 * t + 1]));
+                    }
                 }
             }
         } else {
