@@ -280,6 +280,17 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
 #pragma unroll
             for (int rb = 0; rb < PM_NRB; ++rb) t_next[rb] = tab[(size_t)sn * Q.nlong + blong[rb]];
         }
+        // A chunk none of whose 16 frequencies takes part in any of the group's runs adds nothing: the round is skipped
+        // (round 4).  The frequencies below v kx / 2 are evanescent -- out for good, NaN start phase in the run table --
+        // and they are a contiguous band of slots: 42 % of the (kx, w) plane at config 5, i.e. 42 % of the rounds.  Every
+        // wave sees the same 16 frequencies x PM_NRB entries (lane % PM_CH), so all four decide alike and none meets a barrier.
+        {
+            bool takes_part = false;
+#pragma unroll
+            for (int rb = 0; rb < PM_NRB; ++rb) takes_part = takes_part || (brun[rb] >= 0 && phis[rb] == phis[rb]);
+            takes_part = takes_part && (f0r != 0.f || f0i != 0.f);
+            if (__builtin_amdgcn_ballot_w64(takes_part) == 0) continue;      // uniform over the workgroup
+        }
         // ---- phase 1, fused: the state tile of this wave's own block as TWO recurrences (rows 0..15 and 16..31 of the tile,
         // each from its own float64-phase anchor) and the step-factor tile, advanced together in one straight-line loop.
         // A wave's vector instructions issue ~7 cycles apart when each depends on the one before and 4 apart when they
