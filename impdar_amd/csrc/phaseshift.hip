@@ -819,6 +819,17 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 && M == 8) ? IMPDAR_PS_VZ32_M8
 #pragma unroll
                     for (int m = 0; m < M; ++m) {
                         const int iw = tid_here + m * BLOCK;
+                        {
+                            // (a frequency that is out -- original spectrum zeroed -- in all 64 lanes has nothing to turn:
+                            // the divide, square root and sincos of a run's start are skipped for it, round 4)
+                            const float2 f0c = f0_lds[m * BLOCK + tid];
+                            if (__builtin_amdgcn_ballot_w64(f0c.x != 0.f || f0c.y != 0.f) == 0) {      // uniform
+                                pc[m] = 1.f;
+                                ps[m] = 0.f;
+                                phd_lds[m * BLOCK + tid] = 0.0;
+                                continue;
+                            }
+                        }
                         if (nrec > 0) {   // the steps since the last anchor turned by the OLD increment
                             const double ph = Phi[m] + (double)nrec * phd_lds[m * BLOCK + tid];
                             Phi[m] = ph - 6.283185307179586 * rint(ph * 0.15915494309189535);
@@ -1109,7 +1120,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
                     for (int m = 0; m < M; ++m) {
                         const int iw = tid_here + m * BLOCK;
                         double c2 = 1.0, sn = 0.0, cf = 0.0;
-                        if (iw < P.nf) {
+                        // (a frequency whose state is zero in all 64 lanes is out for good: nothing to compute for it)
+                        const bool wave_out = __builtin_amdgcn_ballot_w64(gr[m] != 0.0 || gi[m] != 0.0) == 0;      // uniform
+                        if (iw < P.nf && !wave_out) {
                             const double w = P.w[iw];
                             const double a = 0.5 * vd * kxk / w;                 // :456
                             const double cs = 1.0 - a * a;
