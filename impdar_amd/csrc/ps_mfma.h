@@ -284,12 +284,15 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
         // (round 4).  The frequencies below v kx / 2 are evanescent -- out for good, NaN start phase in the run table --
         // and they are a contiguous band of slots: 42 % of the (kx, w) plane at config 5, i.e. 42 % of the rounds.  Every
         // wave sees the same 16 frequencies x PM_NRB entries (lane % PM_CH), so all four decide alike and none meets a barrier.
+        // ... and a row block whose RUN none of them takes part in (the band widens from run to run as the velocity
+        // rises) is left out of phase 2, with its step factors.
+        unsigned rb_in = 0;                                                  // uniform over the workgroup
         {
-            bool takes_part = false;
+            const bool any_f = f0r != 0.f || f0i != 0.f;
 #pragma unroll
-            for (int rb = 0; rb < PM_NRB; ++rb) takes_part = takes_part || (brun[rb] >= 0 && phis[rb] == phis[rb]);
-            takes_part = takes_part && (f0r != 0.f || f0i != 0.f);
-            if (__builtin_amdgcn_ballot_w64(takes_part) == 0) continue;      // uniform over the workgroup
+            for (int rb = 0; rb < PM_NRB; ++rb)
+                if (brun[rb] >= 0 && __builtin_amdgcn_ballot_w64(any_f && phis[rb] == phis[rb]) != 0) rb_in |= 1u << rb;
+            if (rb_in == 0) continue;
         }
         // ---- phase 1, fused: the state tile of this wave's own block as TWO recurrences (rows 0..15 and 16..31 of the tile,
         // each from its own float64-phase anchor) and the step-factor tile, advanced together in one straight-line loop.
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
             static_assert(16 / PM_NSUB == 32 / PM_NSUB / 2, "the step-factor tile has as many rows per lane as half a state tile");
         }
         // the fifth block of a full group: a quarter of its rows by every wave
-        if (brun[PM_NRB - 1] >= 0) {                                          // uniform
+        if ((rb_in >> (PM_NRB - 1)) & 1u) {                                   // uniform
             constexpr int rb = PM_NRB - 1, NJQ = 32 / PM_NSUB / PM_NP;
             const double inc = incs[rb];
             const bool in = phis[rb] == phis[rb];
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
 #pragma unroll
         for (int rb = 0; rb < PM_NRB; ++rb) {
             const int run = brun[rb];
-            if (run < 0) continue;                                            // uniform
+            if (run < 0 || !((rb_in >> rb) & 1u)) continue;                   // uniform
             if (rb > 0 && brun[rb - 1] != run) {
                 __builtin_amdgcn_wave_barrier();
                 gen_B(incs[rb]);                                              // another run: other step factors
