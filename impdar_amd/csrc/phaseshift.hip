@@ -322,6 +322,16 @@ __device__ __forceinline__ void wave_reduce_scatter(T (&v)[NV], int lane)
     }
 }
 
+// Frequency slot of (thread, m) in the vector kernels: PAIRS of owned frequencies are 64 slots apart (a wave's pair covers
+// 128 consecutive slots, the waves of a workgroup interleave at that grain).  The kernels skip a pair that is zero in all
+// 64 lanes, and the evanescent frequencies are a contiguous band of slots: with the pair's two frequencies a whole
+// workgroup width apart (tid + m BLOCK, rounds 1-3) a pair went out only 512 slots after its first half did.
+template <int BLOCK, int M> __device__ __forceinline__ int ps_slot(int tid, int m)
+{
+    if constexpr (M >= 2 && M % 2 == 0) return (m >> 1) * (2 * BLOCK) + ((tid >> 6) << 7) + ((m & 1) << 6) + (tid & 63);
+    else return tid + m * BLOCK;
+}
+
 template <typename T, int BLOCK, int M, bool VZ>
 __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
 {
@@ -362,7 +372,7 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
     T pw[FD ? M : 1];                 // fp64 v(z): w (pa holds 1/w)
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-        const int iw = tid + m * BLOCK;
+        const int iw = ps_slot<BLOCK, M>(tid, m);
         fr[m] = fi[m] = pa[m] = pb[m] = 0;
         if (FD) pw[FD ? m : 0] = 0;
         if (F32 && !VZ) phd[F32 && !VZ ? m : 0] = 0.0;
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
     auto rot32 = [](double ph, T *s, T *c) { sincos_t<T>((T)ph, s, c); };
     // F32 v(z): fp64 phase increment w dt sqrt(coss) of owned frequency m at velocity v (0 past the end of the axis)
     auto incr = [&](int m, double v, double *cs_out) -> double {
-        const int iw = tid + m * BLOCK;
+        const int iw = ps_slot<BLOCK, M>(tid, m);
         double inc = 0.0, cs = 1.0;
         if (iw < P.nf) {
             const double w = P.w[iw];
@@ -571,7 +581,7 @@ __global__ __launch_bounds__(BLOCK) void ps_kernel(PsParams P)
 #pragma unroll
                         for (int m = 0; m < M; ++m)
                             if ((edge >> m) & 1u) {
-                                const double w = P.w[tid + m * BLOCK];
+                                const double w = P.w[ps_slot<BLOCK, M>(tid, m)];
                                 const double a = 0.5 * vd * kxk / w;
                                 const double cs = 1.0 - a * a;
                                 pa[m] = (T)cs;
@@ -726,7 +736,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 && M == 8) ? IMPDAR_PS_VZ32_M8
     double Phi[M];           // accumulated phase at the last anchor, kept in [-pi, pi]
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-        const int iw = tid + m * BLOCK;
+        const int iw = ps_slot<BLOCK, M>(tid, m);
         float2 f = make_float2(0.f, 0.f);
         if (iw < P.nf) {
             const Cp<float> c = ps_load_slot<float>(F, P, iw);
@@ -818,7 +828,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 && M == 8) ? IMPDAR_PS_VZ32_M8
                     asm volatile("" : "+v"(tid_here));
 #pragma unroll
                     for (int m = 0; m < M; ++m) {
-                        const int iw = tid_here + m * BLOCK;
+                        const int iw = ps_slot<BLOCK, M>(tid_here, m);
                         {
                             // (a frequency that is out -- original spectrum zeroed -- in all 64 lanes has nothing to turn:
                             // the divide, square root and sincos of a run's start are skipped for it, round 4)
@@ -879,7 +889,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 && M == 8) ? IMPDAR_PS_VZ32_M8
 #pragma unroll
                     for (int m = 0; m < M; ++m)
                         if ((edge >> m) & 1u) {
-                            const double w = P.w[tid_here + m * BLOCK];
+                            const double w = P.w[ps_slot<BLOCK, M>(tid_here, m)];
                             const double a = 0.5 * vd * kxk / w;
                             const double cs = 1.0 - a * a;
                             double ph = Phi[m] + w * P.dt * (cs > 0.0 ? sqrt(cs) : 0.0);
@@ -946,7 +956,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 512 && M == 8) ? IMPDAR_PS_VZ32_M8
                         hr = gr[q];
                         hi = gi[q];
                     }
-                const double w = P.w[tid_here + m * BLOCK];
+                const double w = P.w[ps_slot<BLOCK, M>(tid_here, m)];
                 float2 f = f0_lds[m * BLOCK + tid];
                 float sr = hr, si = hi;
 #pragma unroll 1
@@ -1043,7 +1053,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
     double pc[M], ps[M];     // exp(i increment) of the current run (identity for boundary and dead frequencies)
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-        const int iw = tid + m * BLOCK;
+        const int iw = ps_slot<BLOCK, M>(tid, m);
         gr[m] = gi[m] = ps[m] = 0.0;
         pc[m] = 1.0;
         if (iw < P.nf) {
@@ -1118,7 +1128,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
                     unsigned new_edge = 0;
 #pragma unroll
                     for (int m = 0; m < M; ++m) {
-                        const int iw = tid_here + m * BLOCK;
+                        const int iw = ps_slot<BLOCK, M>(tid_here, m);
                         double c2 = 1.0, sn = 0.0, cf = 0.0;
                         // (a frequency whose state is zero in all 64 lanes is out for good: nothing to compute for it)
                         const bool wave_out = __builtin_amdgcn_ballot_w64(gr[m] != 0.0 || gi[m] != 0.0) == 0;      // uniform
@@ -1170,7 +1180,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
                     // boundary frequencies: this step's increment from this step's velocity (their pc/ps are the identity)
 #pragma unroll
                     for (int m = 0; m < M; ++m)
-                        if ((edge >> m) & 1u) edge_step(P.w[tid_here + m * BLOCK], vd, thr, gr[m], gi[m]);
+                        if ((edge >> m) & 1u) edge_step(P.w[ps_slot<BLOCK, M>(tid_here, m)], vd, thr, gr[m], gi[m]);
                 }
                 double pr[4] = {0, 0, 0, 0}, pi[4] = {0, 0, 0, 0};              // :487
 #pragma unroll
@@ -1223,7 +1233,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void
                             hr = gr[q];
                             hi = gi[q];
                         }
-                    const double w = P.w[tid_here + m * BLOCK];
+                    const double w = P.w[ps_slot<BLOCK, M>(tid_here, m)];
                     double sr = hr, si = hi;
 #pragma unroll 1
                     for (int t = 0; t < TT; ++t) {
