@@ -36,6 +36,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # LDS read port: 256 B/clk/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md, LDS section: "aggregate ~150 TB/s")
 LDS_PEAK_GBS = 256 * 256 * 2.4
 FP32_VECTOR_PEAK_TF = 157.3
+FP64_VECTOR_PEAK_TF = 78.6   # v_fma_f64: 4 cycles per wave instruction, measured (profiles/r04_valu_rates.txt): 64 x 2 / 4 x 1024 SIMDs x 2.4 GHz
 FP16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 PARITY_BAR = 1e-4         # relative L2 of the fast (float32) kernel against the float64 oracle, DESIGN.md section 2
 
@@ -350,6 +351,21 @@ def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None):
                                "sample": "NumPy closed form on a 512x512 radargram, %.2f s, scaled x%d "
                                          "(work = snum*nt*tnum) to the full size" % (el, scale)}
     out["gazdag_config5"] = rec
+    # ... and on float64 data (what a float64 .mat file gets: the vector runs kernel ps_vz64_kernel, no matrix cores)
+    x64 = x.astype(np.float64)
+    ms64, wall64, fin64, kms64 = device_ms(lambda d: d.migrate('phsh', vel=tab, htaper=100, vtaper=1000), lambda: dat_of(x64, geo),
+                                           reps=2, kernel=True)
+    tf64 = flop / (kms64 * 1e-3) / 1e12
+    out["gazdag_f64_config5"] = {
+        "workload": "phase-shift (Gazdag) migration, 1-D v(z) table, 8192x8192 float64 data (BASELINE config 5 in the "
+                    "reference's own arithmetic), resident in HBM",
+        "device_ms": ms64, "kernel_ms": kms64, "call_ms": wall64 * 1e3, "traces_per_s": n / (ms64 * 1e-3), "output_finite": fin64,
+        "steps_executed": steps,
+        "roofline": {"bound": "fp64 vector", "achieved": tf64, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": tf64 / FP64_VECTOR_PEAK_TF, "algorithmic_flop": flop,
+                     "note": "8 flop per needed complex rotate-accumulate (half walk) over kernel_ms against the float64 "
+                             "vector peak; 42 % of the (kx, w) plane is evanescent and skipped pair-wise (DESIGN 11.7)"}}
+    del x64
     del x
 
     # ---- config 3 in the reference's own arithmetic: float64 data, kirch_dquad_kernel (mig_python.py:53,118 sum in float64)
