@@ -15,6 +15,27 @@ void impdar_set_error(const char *fmt, ...)
 
 extern "C" const char *impdar_last_error(void) { return g_err; }
 
+#include <chrono>
+bool impdar_trace_on()
+{
+    const char *e = getenv("IMPDAR_TRACE");          // read per call (a handful of trace points per migration)
+    return e && atoi(e) != 0;
+}
+void impdar_trace(const char *fmt, ...)
+{
+    if (!impdar_trace_on()) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    static std::mutex mu;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    std::lock_guard<std::mutex> lk(mu);
+    fprintf(stderr, "[impdar +%9.2f ms] %s\n", ms, buf);
+}
+
 extern "C" int impdar_device_count(void)
 {
     int n = 0;
@@ -28,6 +49,7 @@ extern "C" int impdar_device_count(void)
 extern "C" int impdar_ctx_create(int device, impdar_ctx **out)
 {
     IMPDAR_ARG_CHECK(out, "null output pointer");
+    impdar_trace("ctx_create: enter");
     int n = impdar_device_count();
     if (n <= 0) {
         impdar_set_error("no HIP device visible (hipGetDeviceCount = %d)", n);
@@ -50,6 +72,7 @@ extern "C" int impdar_ctx_create(int device, impdar_ctx **out)
         return IMPDAR_ERR_HIP;
     }
     *out = c;
+    impdar_trace("ctx_create: device %d set, two streams made", device);
     return IMPDAR_OK;
 }
 
@@ -185,10 +208,12 @@ void impdar_ctx_pinned_prefetch(impdar_ctx *ctx, size_t bytes)
     const int device = ctx->device;
     ctx->pin_thread = std::thread([ctx, device, bytes] {
         void *p = nullptr;
+        impdar_trace("pinned prefetch thread: hipHostMalloc of %zu MB: start", bytes >> 20);
         if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
             p = nullptr;
         }
+        impdar_trace("pinned prefetch thread: done");
         ctx->pin_next = p;          // (read after the join)
     });
 }
@@ -203,10 +228,12 @@ void *impdar_ctx_pinned(impdar_ctx *ctx, size_t bytes)
     ctx->pinned = nullptr;
     ctx->pinned_bytes = 0;
     void *p = nullptr;
+    impdar_trace("impdar_ctx_pinned: synchronous hipHostMalloc of %zu MB", bytes >> 20);
     if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
+    impdar_trace("impdar_ctx_pinned: done");
     ctx->pinned = p;
     ctx->pinned_bytes = bytes;
     return p;

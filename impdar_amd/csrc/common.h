@@ -81,6 +81,10 @@ int impdar_download_blocks_f64(impdar_ctx *ctx, double *dst_host, size_t ld, siz
                                hipStream_t st);
 
 void impdar_set_error(const char *fmt, ...);
+// IMPDAR_TRACE=1: one line on stderr per milestone of a call ("[impdar +12.3 ms] stolt: plans ready"), the time since the
+// library's first trace point -- where a first call's time goes (profiles/r05_first_call.txt).  A no-op otherwise.
+bool impdar_trace_on();
+void impdar_trace(const char *fmt, ...);
 
 #define IMPDAR_HIP_CHECK(expr)                                                        \
     do {                                                                              \

@@ -44,9 +44,11 @@ struct FftPlan {
         rocfft_status s = rocfft_plan_description_set_data_layout(desc, in_t, out_t, nullptr, nullptr, 1, &in_stride,
                                                                   in_dist, 1, &out_stride, out_dist);
         if (s == rocfft_status_success && scale != 1.0) s = rocfft_plan_description_set_scale_factor(desc, scale);
+        impdar_trace("rocfft_plan_create 1-D type %d length %zu batch %zu strides %zu/%zu: start", (int)type, length, batch, in_stride, out_stride);
         if (s == rocfft_status_success)
             s = rocfft_plan_create(&plan, inplace ? rocfft_placement_inplace : rocfft_placement_notinplace, type,
                                    dbl ? rocfft_precision_double : rocfft_precision_single, 1, &length, batch, desc);
+        impdar_trace("rocfft_plan_create 1-D type %d length %zu batch %zu: done", (int)type, length, batch);
         rocfft_plan_description_destroy(desc);
         if (s != rocfft_status_success) {
             impdar_set_error("rocFFT plan creation failed (length %zu, batch %zu, status %d)", length, batch, (int)s);
@@ -82,9 +84,11 @@ struct FftPlan {
                                                                   out_dist ? out_dist : out_row * len1);
         if (s == rocfft_status_success && scale != 1.0) s = rocfft_plan_description_set_scale_factor(desc, scale);
         size_t lengths[2] = {len0, len1};
+        impdar_trace("rocfft_plan_create 2-D type %d %zu x %zu: start", (int)type, len0, len1);
         if (s == rocfft_status_success)
             s = rocfft_plan_create(&plan, inplace ? rocfft_placement_inplace : rocfft_placement_notinplace, type,
                                    dbl ? rocfft_precision_double : rocfft_precision_single, 2, lengths, 1, desc);
+        impdar_trace("rocfft_plan_create 2-D type %d %zu x %zu: done", (int)type, len0, len1);
         rocfft_plan_description_destroy(desc);
         if (s != rocfft_status_success) {
             impdar_set_error("rocFFT 2-D plan creation failed (%zu x %zu, status %d)", len0, len1, (int)s);
@@ -117,6 +121,16 @@ static int impdar_parallel_plans(int device, std::vector<std::function<int()>> m
     std::vector<int> rcs(makers.size(), 0);
     std::vector<std::string> msgs(makers.size());
     std::vector<std::thread> pool;
+    {
+        const char *te = getenv("IMPDAR_TRACE");           // IMPDAR_TRACE=2: the trace, and the plans one after the other (diagnosis)
+        if (te && atoi(te) >= 2) {
+            for (auto &m : makers) {
+                const int rc = m();
+                if (rc) return rc;
+            }
+            return IMPDAR_OK;
+        }
+    }
     for (size_t i = 1; i < makers.size(); ++i)
         pool.emplace_back([&, i] {
             if (hipSetDevice(device) != hipSuccess) {

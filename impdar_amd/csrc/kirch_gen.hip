@@ -64,6 +64,7 @@ struct GenParams {
     int snum, tnum, xlo, xhi;
     const double *dist;         // metres [tnum + 64], non-decreasing; the last 64 repeat dist[tnum - 1]
     const double *zs, *zs2;     // [snum] (mig_python.py:101-102)
+    const double *tt;           // [snum] travel time, seconds (the reference's own axis: kg_ref_upper)
     const float *a, *a2;        // [snum] tt/dt, and (tt/dt)^2 / (W - 1)^2 rounded once
     const int2 *jr;             // [nchunks][ntiles] first / last input trace inside any aperture of (chunk, tile)
     const float *alo2;          // [nchunks] smallest a^2 of the chunk's samples
@@ -72,6 +73,7 @@ struct GenParams {
     double tmax;                // max(tt), seconds
     double tt0, dt;             // the time axis: tt[k] = tt0 + k dt (to 1e-11 dt, checked by the plan)
     double hh;                  // 1/2 + tt0 / dt
+    double tie2;                // see kg_near_tie
     double vel;
     float nu0;                  // -tt[0]/dt
     float fin;                  // 1 / (2 pi vel)
@@ -88,6 +90,28 @@ __device__ static inline double kg_halfway_s2(double m, const GenParams &P)
     const double t = m + P.hh;
     return t * t;
 }
+
+// A pick that sits ON a half-way point (to KG_TIE_EPS samples -- far wider than any float64 rounding, far rarer than
+// the float32 flags): the reference decides it by the rounding noise of its own sqrt / divide / subtract
+// (mig_python.py:44,:49: argmin |tt[k] - 2 rs / vel|, first minimum), pair by pair.  Lattice positions with a rational
+// moveout (an evenly spaced survey with dropped traces) are full of such pairs; a jittered profile has none.  Those
+// pairs repeat the reference's operations literally -- metres, seconds, IEEE sqrt and divide, its own tt[] -- between
+// the two candidate samples (m, m + 1): true = m + 1.
+#define KG_TIE_EPS 1.0e-9
+#ifndef KG_TIE_FN
+#define KG_TIE_FN __device__ static __attribute__((noinline))
+#endif
+KG_TIE_FN bool kg_ref_upper(const double *__restrict__ dist, const double *__restrict__ zs2,
+                            const double *__restrict__ tt, double vel, int j, int xi, int ti, int m)
+{
+    const double dx = dist[j] - dist[xi];
+    const double rs = sqrt(dx * dx + zs2[ti]);                         // :44
+    const double t = 2.0 * rs / vel;                                   // :49
+    return fabs(tt[m + 1] - t) < fabs(tt[m] - t);                      // argmin keeps the first of two equal distances
+}
+// |s^2 - h^2| <= tie2  with  tie2 = 2 KG_TIE_EPS (largest |h| of the record + 1): at least KG_TIE_EPS samples around every
+// half-way point (wider around the shallow ones; a false positive costs one literal evaluation)
+__device__ static inline bool kg_near_tie(double q, double h2, double tie2) { return fabs(q - h2) <= tie2; }
 
 __host__ __device__ constexpr unsigned kg_lds_bytes(int w, bool near)
 {
@@ -275,7 +299,11 @@ __global__ __launch_bounds__(256, 4) void kirch_gen_kernel(GenParams P)
                         const float mlo = fminf(fmaxf(kf + (df > 0.f ? kmin_f : kmin_f - 1.0f), 0.f), smax2_f);
                         const double ds = xj_s - *(lds_dp)(uintptr_t)(XT_OFF + 8u * (unsigned)i);
                         const double qs = ds * ds + a2s;                              // mig_python.py:44 in samples^2
-                        const float pick = mlo + (qs > kg_halfway_s2((double)mlo, P) ? 1.0f : 0.0f);    // :49, ties below
+                        const double h2 = kg_halfway_s2((double)mlo, P);
+                        bool up = qs > h2;                                            // :49
+                        if (__builtin_expect(kg_near_tie(qs, h2, P.tie2), 0))         // ... a tie: the reference's own rounding decides
+                            up = kg_ref_upper(P.dist, P.zs2, P.tt, P.vel, min(jb + blk * S + jj, tnum - 1), min(x0 + i, tnum - 1), ti, (int)mlo);
+                        const float pick = mlo + (up ? 1.0f : 0.0f);
                         addr = base_k + 4u * (unsigned)pick;
                     }
                     return addr;
@@ -352,7 +380,8 @@ __global__ __launch_bounds__(256) void kirch_gen_shell_kernel(GenParams P)
     const double qhi = P.r2lim * (1.0 + 1e-9);            // candidates only: the reference's own test decides below
     if (z == 0.0 || !(qhi >= z2)) return;
     // the main kernel's own rule for picking the last sample, in metres^2
-    const double qlo = kg_halfway_s2((double)(snum - 2), P) / (P.cscale * P.cscale);
+    const double cs2 = P.cscale * P.cscale;
+    const double qlo = kg_halfway_s2((double)(snum - 2), P) / cs2;
     const double dhi = sqrt(qhi - z2) * (1.0 + 1e-12);
     const double dlo = qlo > z2 ? sqrt(qlo - z2) * (1.0 - 1e-12) : -1.0;
     const double x = P.dist[xi];
@@ -394,7 +423,9 @@ __global__ __launch_bounds__(256) void kirch_gen_shell_kernel(GenParams P)
         for (int j = max(j0, 0); j < min(j1, tnum); ++j) {
             const double dx = P.dist[j] - x;
             const double q = dx * dx + z2;                     // :44
-            if (!(q > qlo)) continue;                          // picks a sample below the last one
+            bool last = q > qlo;                               // picks the last sample (the main kernel's rule ...
+            if (kg_near_tie(q * cs2, qlo * cs2, P.tie2)) last = kg_ref_upper(P.dist, P.zs2, P.tt, P.vel, j, xi, ti, snum - 2);      // ... ties included)
+            if (!last) continue;
             const double rs = sqrt(q);
             // the time limit in the reference's own arithmetic (:49,:52): in the last row the pair (xi, xi) and every
             // trace at the same position sit ON the limit, and the rounding of 2 rs / vel decides them
@@ -468,6 +499,7 @@ int kirch_launch_gen(impdar_kirch_plan *p, void *d_out, int xlo, int xhi, hipStr
     P.dist = p->d_dist.as<double>();
     P.zs = p->d_zs.as<double>();
     P.zs2 = p->d_zs2.as<double>();
+    P.tt = p->d_tt.as<double>();
     P.a = p->d_ga32.as<float>();
     P.a2 = p->d_ga2_32.as<float>();
     P.jr = p->d_jr.as<int2>();
@@ -478,6 +510,7 @@ int kirch_launch_gen(impdar_kirch_plan *p, void *d_out, int xlo, int xhi, hipStr
     P.tt0 = p->tt0;
     P.dt = p->dt;
     P.hh = 0.5 + p->tt0 / p->dt;
+    P.tie2 = 2.0 * KG_TIE_EPS * ((double)snum + std::fabs(P.hh) + 1.0);
     P.vel = p->vel;
     P.nu0 = (float)(-p->tt0 / p->dt);
     P.fin = (float)(1.0 / (2.0 * M_PI * p->vel));

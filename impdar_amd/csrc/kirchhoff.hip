@@ -1959,8 +1959,10 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
     }
     // ---- picks that rounding noise decides (see kirch_tiescan_kernel): the table-driven kernels would break those
     // ties one way per offset, the reference breaks them pair by pair
-    if (p->uniform && (mode == IMPDAR_KIRCH_FAST || p->dquad || !getenv("IMPDAR_KIRCH_EXACT_IMPL") ||
-                       strcmp(getenv("IMPDAR_KIRCH_EXACT_IMPL"), "pair"))) {
+    // (kirch_gen_kernel needs no list, on a uniform profile either: it re-does every pair on a half-way point in the
+    // reference's own arithmetic by itself, kg_ref_upper; rounds 3-4 sent uniform profiles with ties to the float64 kernels)
+    if (p->uniform && !p->gen && (mode == IMPDAR_KIRCH_FAST || p->dquad || !getenv("IMPDAR_KIRCH_EXACT_IMPL") ||
+                                  strcmp(getenv("IMPDAR_KIRCH_EXACT_IMPL"), "pair"))) {
         int hg = 0;
         for (int k = 0; k < snum; ++k) hg = std::max(hg, p->h_half[k] + 1);
         hg = std::min(hg, tnum) + 1;
@@ -1993,21 +1995,6 @@ extern "C" int impdar_kirch_plan_create(impdar_ctx *ctx, int dtype, int snum, in
             hipStreamSynchronize(ctx->stream) != hipSuccess) {
             impdar_set_error("tie scan failed: %s", hipGetErrorString(hipGetLastError()));
             return fail(IMPDAR_ERR_HIP);
-        }
-        if (p->gen && count > 0) {
-            // kirch_gen_kernel on a UNIFORM profile (steep moveout: the ring kernels' windows do not fit) decides a pick
-            // that sits on a half-way point by exact arithmetic; the reference by the rounding noise of its own
-            // sqrt / divide, pair by pair (see kirch_tiescan_kernel).  A rational moveout has such entries: those
-            // profiles keep the float64 kernels, which re-do them the reference's way.
-            if (requested_mode == IMPDAR_KIRCH_FAST) {
-                impdar_set_error("the float32 Kirchhoff kernels cannot reproduce the %d picks that rounding noise "
-                                 "decides on this uniform profile (moveout %.4f samples per trace); use mode auto / exact",
-                                 count, sa);
-                return fail(IMPDAR_ERR_UNSUPPORTED);
-            }
-            p->gen = false;
-            mode = p->mode = IMPDAR_KIRCH_EXACT;
-            p->xb = 16;
         }
         const bool no_fix = getenv("IMPDAR_KIRCH_TIEFIX") && !strcmp(getenv("IMPDAR_KIRCH_TIEFIX"), "0");   // diagnostic
         if (count > 0 && count <= TIE_CAP && !no_fix) {

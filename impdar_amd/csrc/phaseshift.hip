@@ -1633,7 +1633,9 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             makers.push_back([&] { return pl.f_trace.create(rocfft_transform_type_complex_forward, dbl, true, tnum, nt, ci, ci, nt, 1, nt, 1, 1.0, st); });
         }
         if (!makers.empty()) {
+            impdar_trace("phaseshift: %zu rocFFT plans to make", makers.size());
             if ((rc = impdar_parallel_plans(ctx->device, makers))) return rc;
+            impdar_trace("phaseshift: plans ready");
             pl.b_ready = true;
             if (herm) pl.r_ready = true;
             else pl.c_ready = true;
@@ -1802,6 +1804,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     };
     if (sizeof(T) == 8 && P.sched && (rc = order_rows())) return rc;       // float64: always the vector kernels
     if ((rc = impdar_ctx_ktic(ctx))) return rc;
+    impdar_trace("phaseshift: forward transforms enqueued");
     bool mfma_done = false;
     if constexpr (sizeof(T) == 4) {
         // float32: the frequency sums on the matrix cores when the depth axis is a few long runs of constant velocity
@@ -1882,6 +1885,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     }
     IMPDAR_HIP_CHECK(hipGetLastError());
     if ((rc = impdar_ctx_toc(ctx))) return rc;
+    impdar_trace("phaseshift: all kernels enqueued");
     // host staging vectors (w, thr) must outlive the async copies
     IMPDAR_HIP_CHECK(hipStreamSynchronize(st));
     return IMPDAR_OK;
@@ -1898,11 +1902,13 @@ extern "C" int impdar_phaseshift(impdar_ctx *ctx, const void *data, int dtype, i
                      "Interpolated velocity profile is not the length of the number of samples in a trace.");
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t bytes = (size_t)snum * tnum * impdar_dtype_size(dtype);
+    impdar_trace("impdar_phaseshift: enter (%d x %d, nt %d)", snum, tnum, nt);
     impdar_ctx_pinned_prefetch(ctx, bytes);      // the download's staging buffer, pinned while the call works
     DevBuf din, dout;
     IMPDAR_HIP_CHECK(din.ensure(bytes));
     IMPDAR_HIP_CHECK(dout.ensure(bytes));
     IMPDAR_HIP_CHECK(hipMemcpyAsync(din.p, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    impdar_trace("impdar_phaseshift: upload enqueued");
     std::lock_guard<std::mutex> lk(g_ps_mu);
     ImpdarBusy busy(t_ps_busy);
     if (!g_ps_plan) g_ps_plan = new PsPlan();
@@ -1911,7 +1917,10 @@ extern "C" int impdar_phaseshift(impdar_ctx *ctx, const void *data, int dtype, i
                                  : ps_run<double>(ctx, *g_ps_plan, din.p, snum, tnum, nt, kx, ws, dt, tt_us, vconst, vmig,
                                                   vmig_len, htaper, vtaper, dout.p);
     if (rc) return rc;
-    return impdar_download(ctx, out, dout.p, bytes, ctx->stream);
+    impdar_trace("impdar_phaseshift: device work complete");
+    rc = impdar_download(ctx, out, dout.p, bytes, ctx->stream);
+    impdar_trace("impdar_phaseshift: downloaded");
+    return rc;
 }
 
 // resident form: d_data and d_out are device arrays of `dtype` (snum, tnum); runs on the context's compute stream

@@ -312,6 +312,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
                             }
                         }
                     }
+                    // R itself is re-anchored every 64 steps: R *= exp(i d) rounds once per step (1e-16), so R's phase is off by
+                    // ~tau 1e-16 after tau steps, and the state, which integrates R, by ~tau^2 / 2 of that: 4.4e-10 of the
+                    // image maximum at 8192 steps (round 5: the 8192^2 spot-wavenumber test; 2e-11 with the anchors)
+                    if ((tau & 63) == 0 && tau > 0) {                             // uniform
+#pragma unroll
+                        PSS_EACH {
+                            if (!((dead >> m) & 1u)) {
+                                T sn, cn;
+                                sincos_t<T>(wdt[m] * q[j].y2, &sn, &cn);
+                                q[j].ncr = cn;
+                                q[j].nsr = sn;
+                            }
+                        }
+                    }
 #pragma unroll
                     PSS_EACH {
                         y[m] = q[j].y2;

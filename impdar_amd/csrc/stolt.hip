@@ -22,9 +22,11 @@ static int g_fft_rc = IMPDAR_OK;
 int impdar_fft_global_setup()
 {
     std::call_once(g_fft_once, [] {
+        impdar_trace("rocfft_setup: start");
         if (rocfft_setup() != rocfft_status_success) {
             g_fft_rc = IMPDAR_ERR_FFT;
         }
+        impdar_trace("rocfft_setup: done");
     });
     if (g_fft_rc) impdar_set_error("rocfft_setup failed");
     return g_fft_rc;
@@ -227,6 +229,7 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
         IMPDAR_HIP_CHECK(pl.Y.ensure((size_t)tnum * nout * sizeof(T)));
         IMPDAR_HIP_CHECK(pl.d_kx.ensure((size_t)tnum * 8));
         IMPDAR_HIP_CHECK(pl.d_ws.ensure((size_t)m * 8));
+        impdar_trace("stolt: plans and buffers ready");
         pl.dtype = dbl ? IMPDAR_F64 : IMPDAR_F32;
         pl.snum = snum;
         pl.tnum = tnum;
@@ -260,6 +263,7 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
     dim3 bgrid((tnum + 63) / 64, (nout + 63) / 64);
     hipLaunchKernelGGL((stolt_transpose_back<T>), bgrid, dim3(256), 0, st, pl.Y.as<T>(), (T *)d_out, nout, tnum);
     IMPDAR_HIP_CHECK(hipGetLastError());
+    impdar_trace("stolt: all kernels enqueued");
     ctx->m_entry = "impdar_stolt";
     ctx->m_kernel = "stolt_stretch (+ rocFFT 2-D real transforms)";
     ctx->m_kernel_ms = -1.f;
@@ -285,6 +289,7 @@ extern "C" int impdar_stolt_dev(impdar_ctx *ctx, const void *d_data, int dtype, 
     if (rc) return rc;
     // kx/ws were staged from caller memory: complete before returning
     IMPDAR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    impdar_trace("stolt: device work complete");
     return impdar_ctx_mark_produced(ctx);
 }
 
@@ -297,12 +302,16 @@ extern "C" int impdar_stolt(impdar_ctx *ctx, const void *data, int dtype, int sn
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t esz = impdar_dtype_size(dtype);
     const size_t inb = (size_t)snum * tnum * esz, outb = (size_t)(2 * (snum / 2)) * tnum * esz;
+    impdar_trace("impdar_stolt: enter (%d x %d)", snum, tnum);
     impdar_ctx_pinned_prefetch(ctx, outb);       // the download's staging buffer, pinned while the call works
     DevBuf din, dout;
     IMPDAR_HIP_CHECK(din.ensure(inb));
     IMPDAR_HIP_CHECK(dout.ensure(outb ? outb : 8));
     IMPDAR_HIP_CHECK(hipMemcpyAsync(din.p, data, inb, hipMemcpyHostToDevice, ctx->stream));
+    impdar_trace("impdar_stolt: upload enqueued");
     int rc = impdar_stolt_dev(ctx, din.p, dtype, snum, tnum, kx, ws, vel, htaper, vtaper, dout.p);
     if (rc) return rc;
-    return impdar_download(ctx, out, dout.p, outb, ctx->stream);
+    rc = impdar_download(ctx, out, dout.p, outb, ctx->stream);
+    impdar_trace("impdar_stolt: downloaded");
+    return rc;
 }

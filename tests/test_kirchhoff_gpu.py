@@ -145,8 +145,7 @@ def test_general_geometry_kernel_random_profiles(hip, kind):
 def test_general_geometry_kernel_against_the_ring_on_a_uniform_profile(hip, monkeypatch):
     """IMPDAR_KIRCH_IMPL=gen sends a UNIFORM profile through kirch_gen_kernel (A/B against the ring kernels): same
     picks (both are held to the reference's), sums rounded differently.  A rational moveout whose ties the reference
-    decides by rounding noise is a profile the general kernel must not take by itself: steep enough for the ring
-    kernels' windows not to fit, the plan keeps the float64 kernels in auto mode and refuses 'fast'."""
+    decides by rounding noise, steep enough for the ring kernels' windows not to fit: the general kernel takes it too."""
     from impdar_amd import synth
     from impdar_amd.kirchhoff import KirchhoffPlan, migrate_resident
     from oracle import c_oracle
@@ -163,7 +162,21 @@ def test_general_geometry_kernel_against_the_ring_on_a_uniform_profile(hip, monk
     gen, _, _ = migrate_resident(ctx, x, geo['dist'], geo['travel_time'], vel, False, 'auto')
     monkeypatch.delenv('IMPDAR_KIRCH_IMPL')
     assert rel_l2(gen, want) < FAST_L2 and rel_l2(ring, want) < FAST_L2 and rel_l2(gen, ring) < 1e-5
-    # 25 samples of moveout per trace exactly: (2 a)^2 + (50 n)^2 is an odd square for whole families of (a, n)
+    # 22.5 samples of moveout per trace exactly -- too steep for the ring kernels' windows (16.5), inside the general
+    # kernel's (24.5): (45 n)^2 + (2 a)^2 is an odd square for whole families of (a, n), e.g. 22.5^2 + 506^2 = 506.5^2 --
+    # picks ON a half-way point, which the reference decides by rounding noise.  Rounds 3-4 kept such a profile on the
+    # float64 kernels; kirch_gen_kernel now re-does those pairs in the reference's own arithmetic and takes it.
+    geo = synth.geometry(700, 200, dt=2e-9, dx=4.5)
+    x = synth.noise_radargram(700, 200, seed=13).astype(np.float32)
+    for near in (False, True):
+        want = c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], 2.0e8, near)
+        for mode in ('auto', 'fast'):
+            plan = KirchhoffPlan(ctx, np.float32, 700, 200, geo['dist'], geo['travel_time'], 2.0e8, near, mode)
+            assert plan.mode == 'fast' and plan.kernel == 'kirch_gen_kernel', (plan.mode, plan.kernel)
+            plan.destroy()
+            got, _, _ = migrate_resident(ctx, x, geo['dist'], geo['travel_time'], 2.0e8, near, mode)
+            assert rel_l2(got, want) < FAST_L2 and rel_max(got, want) < FAST_MAX, (near, mode, rel_l2(got, want))
+    # steeper than that (25 samples per trace): no float32 kernel fits; auto keeps the float64 kernels, 'fast' is refused
     geo = synth.geometry(600, 200, dt=2e-9, dx=5.0)
     auto = KirchhoffPlan(ctx, np.float32, 600, 200, geo['dist'], geo['travel_time'], 2.0e8, False, 'auto')
     assert auto.mode == 'exact' and auto.kernel != 'kirch_gen_kernel', (auto.mode, auto.kernel)
@@ -202,6 +215,111 @@ def test_general_geometry_kernel_at_config3_size(hip):
     want = c_oracle.kirchhoff(x, geo['travel_time'], dist, vel, False, traces=cols)
     assert rel_l2(got, want) < FAST_L2 and rel_max(got, want) < FAST_MAX, rel_l2(got, want)
     assert min(ms) <= 64.0, ms
+
+
+def _lattice_with_gaps(rng, tnum, dx, drop):
+    """Positions of an evenly spaced survey (dx metres) with a fraction `drop` of its traces missing, in km."""
+    n_all = int(round(tnum / (1.0 - drop)))
+    keep = np.sort(rng.choice(n_all, size=tnum, replace=False))
+    return (keep - keep[0]) * dx / 1e3
+
+
+@pytest.mark.parametrize('dt,dx,vel', [(1e-8, 1.0, 1.69e8), (1e-8, 1.0, 1.68e8), (2e-9, 0.5, 2.0e8), (1e-8, 2.5, 1.68e8)])
+@pytest.mark.parametrize('nearfield', [False, True])
+def test_general_geometry_kernel_on_a_lattice_with_dropped_traces(hip, dt, dx, vel, nearfield):
+    """An evenly spaced survey with 5-20 % of its traces dropped is NOT uniform (kirch_gen_kernel takes it) but its
+    positions sit on a lattice: with a rational moveout 2 dx / (v dt) -- 200/169 (config 3), 25/21, exactly 2.5 -- whole
+    families of pairs land ON the half-way point between two samples or on max(tt), where the reference's pick
+    (mig_python.py:49, argmin |tt - 2 rs / vel|) is decided by the rounding noise of its own sqrt / divide, pair by pair.
+    kirch_gen_kernel re-does every pair within 1e-9 samples of a half-way point in the reference's literal float64
+    arithmetic (kg_ref_upper).  White noise (every flipped pick shows), whole image against the C oracle."""
+    from impdar_amd import _hip, synth
+    from impdar_amd.kirchhoff import KirchhoffPlan
+    from oracle import c_oracle
+    ctx = hip.context()
+    rng = np.random.default_rng(int(dx * 100) + int(vel / 1e6) + nearfield)
+    snum, tnum = 1024, 2000
+    for drop in (0.05, 0.2):
+        geo = synth.geometry(snum, tnum, dt=dt, dx=dx)
+        geo['dist'] = _lattice_with_gaps(rng, tnum, dx, drop)
+        x = rng.standard_normal((snum, tnum)).astype(np.float32)
+        plan = KirchhoffPlan(ctx, np.float32, snum, tnum, geo['dist'], geo['travel_time'], vel, nearfield, 'auto')
+        assert plan.kernel == 'kirch_gen_kernel', plan.kernel
+        d_in = _hip.DeviceArray.from_host(ctx, x)
+        d_out = _hip.DeviceArray(ctx, (snum, tnum), np.float32)
+        plan.prep(d_in, tnum, 0, tnum)
+        plan.migrate(d_out, 0, tnum)
+        plan.sync()
+        got = d_out.to_host()
+        plan.destroy()
+        d_in.free()
+        d_out.free()
+        want = c_oracle.kirchhoff(x, geo['travel_time'], geo['dist'], vel, nearfield)
+        assert rel_l2(got, want) < FAST_L2 and rel_max(got, want) < FAST_MAX, (drop, rel_l2(got, want), rel_max(got, want))
+
+
+def test_general_geometry_kernel_on_a_lattice_with_dropped_traces_at_config3_width(hip):
+    """... and at config-3 width and depth (10000 kept traces of an 11100-trace survey, 4096 samples, dx 1 m, dt 10 ns,
+    1.69e8 m/s): spot columns against the C oracle."""
+    from impdar_amd import _hip, synth
+    from impdar_amd.kirchhoff import KirchhoffPlan
+    from oracle import c_oracle
+    ctx = hip.context()
+    snum, tnum, vel = 4096, 10000, 1.69e8
+    rng = np.random.default_rng(31)
+    geo = synth.geometry(snum, tnum)
+    dist = _lattice_with_gaps(rng, tnum, 1.0, 0.1)
+    x = synth.noise_radargram(snum, tnum, seed=6).astype(np.float32)
+    plan = KirchhoffPlan(ctx, np.float32, snum, tnum, dist, geo['travel_time'], vel, False, 'auto')
+    assert plan.kernel == 'kirch_gen_kernel'
+    d_in = _hip.DeviceArray.from_host(ctx, x)
+    d_out = _hip.DeviceArray(ctx, (snum, tnum), np.float32)
+    plan.prep(d_in, tnum, 0, tnum)
+    plan.migrate(d_out, 0, tnum)
+    plan.sync()
+    cols = np.array([0, 3, 2500, 5000, 5001, 8191, 9998, 9999])
+    got = d_out.to_host()[:, cols]
+    plan.destroy()
+    d_in.free()
+    d_out.free()
+    want = c_oracle.kirchhoff(x, geo['travel_time'], dist, vel, False, traces=cols)
+    assert rel_l2(got, want) < FAST_L2 and rel_max(got, want) < FAST_MAX, rel_l2(got, want)
+
+
+def test_general_geometry_kernel_at_config4_width(hip):
+    """40000 jittered traces x 4096 samples (BASELINE config 4's width on one GPU, the K3 recipe +-0.3 dx): spot columns
+    of kirch_gen_kernel against the C oracle, and one 8-way rank block of output traces equal to the same columns of the
+    whole launch."""
+    from impdar_amd import _hip, synth
+    from impdar_amd.kirchhoff import KirchhoffPlan
+    from oracle import c_oracle
+    ctx = hip.context()
+    snum, tnum, vel = 4096, 40000, 1.69e8
+    geo = synth.geometry(snum, tnum)
+    dist = (np.arange(tnum) + np.random.default_rng(4).uniform(-0.3, 0.3, tnum)) / 1e3
+    x = synth.noise_radargram(snum, tnum, seed=8).astype(np.float32)
+    plan = KirchhoffPlan(ctx, np.float32, snum, tnum, dist, geo['travel_time'], vel, False, 'auto')
+    assert plan.kernel == 'kirch_gen_kernel'
+    d_in = _hip.DeviceArray.from_host(ctx, x)
+    d_out = _hip.DeviceArray(ctx, (snum, tnum), np.float32)
+    plan.prep(d_in, tnum, 0, tnum)
+    plan.migrate(d_out, 0, tnum)
+    plan.sync()
+    cols = np.array([0, 1, 4999, 20000, 20001, 33333, 39998, 39999])
+    full = d_out.to_host()
+    got = full[:, cols]
+    d_out.free()
+    lo, hi = 15000, 20000
+    d_blk = _hip.DeviceArray(ctx, (snum, hi - lo), np.float32)
+    plan.migrate(d_blk, lo, hi)
+    plan.sync()
+    blk = d_blk.to_host()
+    d_blk.free()
+    plan.destroy()
+    d_in.free()
+    assert np.array_equal(blk, full[:, lo:hi])
+    want = c_oracle.kirchhoff(x, geo['travel_time'], dist, vel, False, traces=cols)
+    assert rel_l2(got, want) < FAST_L2 and rel_max(got, want) < FAST_MAX, rel_l2(got, want)
 
 
 def _hook(hip, data, tt_sec, dist_m, vel, tmax=None, zs=None, zs2=None, nearfield=0, fill=0.0):

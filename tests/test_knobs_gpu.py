@@ -48,6 +48,30 @@ def test_metrics_line_of_the_four_migration_entry_points(hip, monkeypatch, capfd
     assert '"impdar_metrics"' not in capfd.readouterr().err
 
 
+def test_trace_lines_of_a_first_call(hip, monkeypatch, capfd):
+    """IMPDAR_TRACE=1: the library prints its milestones with the time since its first trace point -- plan creation
+    per rocFFT plan, uploads, the kernels enqueued, the download: the breakdown behind profiles/r05_first_call.txt."""
+    import re
+    from impdar_amd import synth
+    snum, tnum = 212, 76                       # a size no other test uses: the plans are new
+    geo = synth.geometry(snum, tnum)
+    x = synth.noise_radargram(snum, tnum, seed=4).astype(np.float32)
+    monkeypatch.setenv('IMPDAR_TRACE', '1')
+    capfd.readouterr()
+    _dat(x, geo).migrate('stolt', vel=1.69e8)
+    _dat(x, geo).migrate('phsh', vel=1.69e8)
+    err = capfd.readouterr().err
+    lines = re.findall(r'^\[impdar \+ *([0-9.]+) ms\] (.*)$', err, flags=re.M)
+    text = [t for _, t in lines]
+    assert any(t.startswith('rocfft_plan_create 2-D') and t.endswith('done') for t in text), err
+    assert any(t.startswith('stolt: all kernels enqueued') for t in text) and any('phaseshift: plans ready' in t for t in text), err
+    stamps = [float(ms) for ms, _ in lines]
+    assert stamps and stamps[-1] >= stamps[0]
+    monkeypatch.delenv('IMPDAR_TRACE')
+    _dat(x, geo).migrate('stolt', vel=1.69e8)
+    assert '[impdar +' not in capfd.readouterr().err
+
+
 def test_phase_shift_strided_transform_plans(hip, monkeypatch):
     """IMPDAR_PS_FFT=strided: the transforms over the traces / wavenumbers as rocFFT's strided plans on the arrays as
     they lie (rounds 1-3a) instead of transpose + contiguous plan: same image to the transforms' rounding."""

@@ -1,9 +1,10 @@
 """Parity of the HIP phase-shift (Gazdag) path and the taper-only T-K stub
 with the reference's golden vectors and the CPU oracle.
 
-Stated tolerances: float64 data  max|diff| <= 1e-9 * max|ref|  (the reference's
+Stated tolerances: float64 data  max|diff| <= 1e-10 * max|ref|  (the reference's
                    multiplicative recurrence and this kernel's differ by
-                   rounding only)
+                   rounding only; observed <= 5.2e-12 over 1300 randomized cases,
+                   profiles/r04_fuzz.txt; 1e-9 until round 4)
                    float32 data  relative L2 <= 2e-4."""
 import os
 
@@ -14,7 +15,7 @@ from conftest import ROOT, golden, golden_names, make_dat, rel_l2, rel_max
 
 pytestmark = pytest.mark.gpu
 
-F64_TOL = 1e-9
+F64_TOL = 1e-10
 F32_L2 = 2e-4
 
 
@@ -153,6 +154,88 @@ def test_config5_size_spot_wavenumbers_and_linearity(hip, kind):
     err = np.linalg.norm(got - want) / np.linalg.norm(want)
     print('config 5 (%s) spot-wavenumber relative L2 error %.3g' % (kind, err))
     assert err < F32_L2, err
+
+
+_SPOT_KS = np.array([0, 1, 37, 200, 1000, 4000, 4095, 4096])
+_spot_cache = {}
+
+
+def _spot_oracle(n, geo, x64, vmig):
+    """phaseShift (mig_python.py:438-487) on the (k, -k) column pairs of _SPOT_KS of the 2-D spectrum of the tapered
+    float64 radargram -> what fft_x of the migrated image must hold in those columns,
+    fft_x(Re ifft_k TK)[k] = (TK[k] + conj(TK[-k])) / 2  (wavenumbers are independent in phaseShift)."""
+    from oracle import mig_oracle
+    ks = _SPOT_KS
+    tap = mig_oracle._apply_taper(x64, 100, 1000, inplace_form=True)
+    cols = np.concatenate([ks, (n - ks) % n])
+    FKc = np.fft.fft(np.fft.fft(tap, axis=1)[:, cols], n=n, axis=0)
+    del tap
+    kx = mig_oracle._kx(n, geo['trace_int'], geo['dist'])[cols]
+    ws = 2. * np.pi * np.fft.fftfreq(n, d=geo['dt'])
+    TK = mig_oracle.phase_shift_tk(FKc, vmig, kx, ws, geo['dt'], geo['travel_time'], n, len(cols))     # ~30 s
+    return 0.5 * (TK[:, :len(ks)] + np.conj(TK[:, len(ks):]))
+
+
+def _config5_profile(name, n, geo):
+    from oracle import mig_oracle
+    u = np.linspace(0., 1., n)
+    if name == 'gradient':
+        return np.ascontiguousarray(1.69e8 + 0.5e8 * u)
+    if name == 'wavy':
+        return np.ascontiguousarray(1.8e8 + 0.15e8 * np.sin(7. * u) + 0.1e8 * u)
+    assert name == 'layers41'
+    Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+    tab = np.stack([np.linspace(1.69e8, 2.2e8, 41), np.linspace(0., 2.0 * Rp, 41)], axis=1)
+    return np.ascontiguousarray(mig_oracle.get_velocity_profile(geo['travel_time'], tab))
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('profile', ['gradient', 'wavy', 'layers41'])
+def test_config5_size_spot_wavenumbers_per_step_profiles_and_many_layers(hip, profile, dtype):
+    """The kernels of round 4 at the size they are quoted at (8192 x 8192): ps_smooth32_kernel / ps_smooth_kernel carry
+    sqrt(coss) and the rotation by Newton / series updates between float64 anchors and expand about one velocity per 32
+    steps -- a scheme whose error could grow with the number of steps -- and a 41-row table (40 layers of ~200 steps)
+    is what the many-run paths get.  Spot wavenumbers (zero, low, two that hold a frequency on the evanescent boundary of
+    1.69e8 m/s, high, the Nyquist row) against the oracle's literal per-step loop (mig_python.py:438-487)."""
+    import ctypes as C
+    import json
+    from impdar_amd import _hip, synth
+    from oracle import mig_oracle
+    lib, ctx = _hip.load(), _hip.context()
+    n = 8192
+    geo = synth.geometry(n, n)
+    vm = _config5_profile(profile, n, geo)
+    x = np.random.default_rng(2).standard_normal((n, n)).astype(np.float32)
+    if profile not in _spot_cache:
+        _spot_cache.clear()                      # (one 8192 x 8 complex array at a time is plenty)
+        _spot_cache[profile] = _spot_oracle(n, geo, x.astype(np.float64), vm)
+    want = _spot_cache[profile]
+    data = x.astype(dtype)
+    del x
+    kx = mig_oracle._kx(n, geo['trace_int'], geo['dist'])
+    ws = 2. * np.pi * np.fft.fftfreq(n, d=geo['dt'])
+    out = np.empty((n, n), dtype=dtype)
+    tt = np.ascontiguousarray(geo['travel_time'], dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    _hip.check(lib.impdar_phaseshift(ctx, data.ctypes.data_as(C.c_void_p), _hip.dtype_code(dtype), n, n, n,
+                                     kx.ctypes.data_as(dp), ws.ctypes.data_as(dp), C.c_double(geo['dt']),
+                                     tt.ctypes.data_as(dp), C.c_double(0.0), vm.ctypes.data_as(dp), n, C.c_double(100.),
+                                     C.c_double(1000.), out.ctypes.data_as(C.c_void_p)), 'impdar_phaseshift')
+    buf = C.create_string_buffer(1024)
+    _hip.check(lib.impdar_ctx_last_metrics(ctx, buf, len(buf)), 'metrics')
+    kernel = json.loads(buf.value.decode())['kernel']
+    if profile != 'layers41':
+        assert kernel == ('ps_smooth32_kernel' if dtype == np.float32 else 'ps_smooth_kernel'), kernel
+    del data
+    assert np.isfinite(out).all()
+    got = np.fft.fft(out.astype(np.float64), axis=1)[:, _SPOT_KS]
+    err_l2 = np.linalg.norm(got - want) / np.linalg.norm(want)
+    err_max = np.max(np.abs(got - want)) / np.max(np.abs(want))
+    print('8192^2 %s %s (%s): spot-wavenumber rel L2 %.3g, rel max %.3g' % (profile, np.dtype(dtype).name, kernel, err_l2, err_max))
+    if dtype == np.float32:
+        assert err_l2 < F32_L2, err_l2
+    else:
+        assert err_max < F64_TOL, err_max
 
 
 @pytest.mark.parametrize('snum,tnum', [(300, 64), (257, 65), (1100, 24), (40, 7)])

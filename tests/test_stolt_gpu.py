@@ -1,7 +1,8 @@
 """Parity of the HIP Stolt f-k path (rocFFT + taper/stretch kernels) with the
 reference's golden vectors and the CPU oracle.
 
-Stated tolerances: float64 data  max|diff| <= 1e-10 * max|ref|
+Stated tolerances: float64 data  max|diff| <= 1e-12 * max|ref|  (observed <= 2.4e-15 over the randomized sweeps,
+                   profiles/r04_fuzz.txt; 1e-10 until round 4)
                    float32 data  relative L2 <= 1e-4 (the reference's own
                    float32-vs-float64 difference is ~1e-7)."""
 import numpy as np
@@ -11,7 +12,7 @@ from conftest import golden, golden_names, make_dat, rel_l2, rel_max
 
 pytestmark = pytest.mark.gpu
 
-F64_TOL = 1e-10
+F64_TOL = 1e-12
 F32_L2 = 1e-4
 
 

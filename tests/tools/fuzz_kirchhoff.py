@@ -40,6 +40,13 @@ def main():
         kind = str(rng.choice(['f32', 'f32', 'f64', 'i16']))
         geo = synth.geometry(snum, tnum, dt=dt, dx=dx, t0_us=t0)
         irregular = tnum > 2 and rng.integers(0, 5) == 0
+        lattice = (not irregular) and tnum > 8 and rng.integers(0, 4) == 0
+        if lattice:        # an evenly spaced survey with dropped traces: positions on the lattice, gaps of 1-3 cells; round
+            # numbers make whole families of picks land ON a half-way point, which the reference decides by rounding noise
+            keep = np.sort(rng.choice(int(tnum * 1.25) + 2, size=tnum, replace=False))
+            geo['dist'] = (keep - keep[0]) * dx / 1e3
+            if rng.integers(0, 3) == 0:
+                geo['dist'] = geo['dist'] + float(rng.choice([2.0, 50.0, 1234.5]))      # ... starting far along the line
         if irregular:      # uneven trace spacing (and, half of the time, an uneven time axis): the per-pair kernels
             geo['dist'] = np.cumsum(np.concatenate([[0.], rng.uniform(0.3, 1.7, tnum - 1) * dx])) / 1e3
             if rng.integers(0, 2) and snum > 2:
@@ -65,7 +72,7 @@ def main():
         bad += 0 if ok else 1
         worst[key] = max(worst[key], err)
         print('%3d %s snum %4d tnum %3d dt %.3g dx %.3g vel %.4g t0 %.3g near %d %s err %.3g %s'
-              % (case, kind, snum, tnum, dt, dx, vel, t0, near, 'irregular' if irregular else 'uniform', err,
+              % (case, kind, snum, tnum, dt, dx, vel, t0, near, 'irregular' if irregular else ('lattice' if lattice else 'uniform'), err,
                  'ok' if ok else 'MISS'), flush=True)
     print('cases %d, misses %d, worst float32 rel-L2 %.3g (bar 1e-4), worst float64/int16 rel-max %.3g (bar 1e-12), %.0f s'
           % (ncases, bad, worst['f32'], worst['f64'], time.time() - t_start))

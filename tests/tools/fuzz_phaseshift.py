@@ -85,7 +85,7 @@ def main():
             tol = 2e-4
         else:
             err = np.max(np.abs(d.data - want)) / max(np.max(np.abs(want)), 1e-300)
-            tol = 1e-9
+            tol = 1e-10
         ok = np.isfinite(d.data).all() and err < tol
         bad += 0 if ok else 1
         worst[dtype] = max(worst[dtype], err)
@@ -93,7 +93,7 @@ def main():
               % (case, 'f32' if dtype == np.float32 else 'f64', snum, tnum, dt, dx,
                  'const %.3g' % vel if np.isscalar(vel) else '%s%d layers from %.3g' % ('per-step ' if kind == 4 else '', len(vel), vel[0, 0]),
                  '', err, 'ok' if ok else 'MISS'), flush=True)
-    print('cases %d, misses %d, worst float32 rel-L2 %.3g (bar 2e-4), worst float64 rel-max %.3g (bar 1e-9), %.0f s'
+    print('cases %d, misses %d, worst float32 rel-L2 %.3g (bar 2e-4), worst float64 rel-max %.3g (bar 1e-10), %.0f s'
           % (ncases, bad, worst[np.float32], worst[np.float64], time.time() - t_start))
     return 1 if bad else 0
 

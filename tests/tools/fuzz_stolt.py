@@ -50,12 +50,12 @@ def main():
             ok, key = bool(np.isfinite(got).all() and err < 1e-4), 'f32'
         else:
             err = np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1e-300) if got.size else 0.0
-            ok, key = bool(np.isfinite(got).all() and err < 1e-10), 'f64'
+            ok, key = bool(np.isfinite(got).all() and err < 1e-12), 'f64'
         bad += 0 if ok else 1
         worst[key] = max(worst[key], err if np.isfinite(err) else 1e300)
         print('%3d %s snum %4d tnum %3d dt %.3g dx %.3g vel %.4g tapers %d %d err %.3g %s'
               % (case, kind, snum, tnum, dt, dx, vel, ht, vt, err, 'ok' if ok else 'MISS'), flush=True)
-    print('cases %d, misses %d, worst float32 rel-L2 %.3g (bar 1e-4), worst float64/int16 rel-max %.3g (bar 1e-10), %.0f s'
+    print('cases %d, misses %d, worst float32 rel-L2 %.3g (bar 1e-4), worst float64/int16 rel-max %.3g (bar 1e-12), %.0f s'
           % (ncases, bad, worst['f32'], worst['f64'], time.time() - t_start))
     return 1 if bad else 0
 
