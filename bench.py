@@ -495,17 +495,30 @@ def first_call_child(kind):
 
 
 def first_call_records():
-    """Run the three first-call children (must happen before this process touches the GPU)."""
+    """Run the first-call children (must happen before this process touches the GPU).  Per path two fresh processes:
+    `cold` -- HOME, XDG_CACHE_HOME and rocFFT's user kernel database (ROCFFT_RTC_CACHE_PATH) in an empty temporary
+    directory: what the first call on a machine that has never run the size costs; `warm_cache` -- once more against the
+    database the first child left: what every later `impproc migrate` process pays (the library points rocFFT at a
+    persistent user database by itself when the user has set none).  The record of a path is its cold child's, with the
+    warm-cache child's beside it."""
     import subprocess
+    import tempfile
     out = {}
     for kind in ('kirch', 'stolt', 'phsh'):
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--first-call', kind], capture_output=True,
-                               text=True, timeout=240)
-            line = [l for l in r.stdout.splitlines() if l.startswith('{"kind"')]
-            out[kind] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]}
-        except Exception as exc:
-            out[kind] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        with tempfile.TemporaryDirectory() as tmp:
+            env = dict(os.environ, HOME=tmp, XDG_CACHE_HOME=os.path.join(tmp, 'xdg'),
+                       ROCFFT_RTC_CACHE_PATH=os.path.join(tmp, 'rocfft_kernel_cache.db'))
+            recs = []
+            for tag in ('cold', 'warm_cache'):
+                try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), '--first-call', kind], capture_output=True,
+                                       text=True, timeout=240, env=env)
+                    line = [l for l in r.stdout.splitlines() if l.startswith('{"kind"')]
+                    recs.append(json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]})
+                except Exception as exc:
+                    recs.append({"error": "%s: %s" % (type(exc).__name__, exc)})
+            out[kind] = dict(recs[0], kernel_cache="cold (empty HOME / ROCFFT_RTC_CACHE_PATH)",
+                             warm_cache={k: v for k, v in recs[1].items() if k != 'kind'})
     return out
 
 

@@ -579,6 +579,10 @@ extern "C" int impdar_dev_upload(impdar_ctx *ctx, void *dst_dev, const void *src
 {
     IMPDAR_ARG_CHECK(ctx && dst_dev && src_host, "null context/pointer");
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
+    // an image that goes up usually comes down again, through the context's pinned staging buffer: have it pinned by a
+    // thread of its own while the upload and the migration run (44 ms for the 256 MB of an 8192^2 float32 image when the
+    // download has to do it itself: profiles/r05_first_call.txt)
+    impdar_ctx_pinned_prefetch(ctx, bytes);
     // straight from pageable memory: the runtime's own staging pipeline reaches 17 GB/s here; copying into the
     // context's pinned buffer on host threads first was slower (9.8 -> 17 ms for 164 MB)
     IMPDAR_HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));

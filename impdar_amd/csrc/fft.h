@@ -17,6 +17,9 @@
     } while (0)
 
 int impdar_fft_global_setup();   // rocfft_setup once per process
+// rocFFT 1.0.36 creates plans safely only one at a time (see impdar_parallel_plans): every rocfft_plan_create of the
+// library runs under this process-wide lock
+std::mutex &impdar_fft_plan_mutex();
 
 struct FftPlan {
     rocfft_plan plan = nullptr;
@@ -44,6 +47,7 @@ struct FftPlan {
         rocfft_status s = rocfft_plan_description_set_data_layout(desc, in_t, out_t, nullptr, nullptr, 1, &in_stride,
                                                                   in_dist, 1, &out_stride, out_dist);
         if (s == rocfft_status_success && scale != 1.0) s = rocfft_plan_description_set_scale_factor(desc, scale);
+        std::lock_guard<std::mutex> plan_lock(impdar_fft_plan_mutex());
         impdar_trace("rocfft_plan_create 1-D type %d length %zu batch %zu strides %zu/%zu: start", (int)type, length, batch, in_stride, out_stride);
         if (s == rocfft_status_success)
             s = rocfft_plan_create(&plan, inplace ? rocfft_placement_inplace : rocfft_placement_notinplace, type,
@@ -84,6 +88,7 @@ struct FftPlan {
                                                                   out_dist ? out_dist : out_row * len1);
         if (s == rocfft_status_success && scale != 1.0) s = rocfft_plan_description_set_scale_factor(desc, scale);
         size_t lengths[2] = {len0, len1};
+        std::lock_guard<std::mutex> plan_lock(impdar_fft_plan_mutex());
         impdar_trace("rocfft_plan_create 2-D type %d %zu x %zu: start", (int)type, len0, len1);
         if (s == rocfft_status_success)
             s = rocfft_plan_create(&plan, inplace ? rocfft_placement_inplace : rocfft_placement_notinplace, type,
@@ -113,44 +118,18 @@ struct FftPlan {
     }
 };
 
-// Several rocFFT plans created at the same time, each by a thread of its own (the first by the caller): the plans of a
-// new size are compiled at run time -- 0.2-0.6 s each on a machine that has not seen the size -- and a first Stolt or
-// phase-shift call needs two or three.  Returns the first failure (its message becomes this thread's last error).
+// The rocFFT plans a call still lacks, created ONE AFTER THE OTHER (each under the process-wide lock of FftPlan::create).  Rounds 3-4 created them
+// side by side on threads (a plan of a new size costs 0.25-2 s on a machine whose kernel cache is cold): with rocFFT
+// 1.0.36 that is not safe -- three plans of length 8192 created concurrently made the first kernels after them die with a
+// GPU memory access fault in 3 of 13 fresh processes, never in 16 with the plans in turn (profiles/r05_first_call.txt).
+// Returns the first failure.
 static int impdar_parallel_plans(int device, std::vector<std::function<int()>> makers)
 {
-    std::vector<int> rcs(makers.size(), 0);
-    std::vector<std::string> msgs(makers.size());
-    std::vector<std::thread> pool;
-    {
-        const char *te = getenv("IMPDAR_TRACE");           // IMPDAR_TRACE=2: the trace, and the plans one after the other (diagnosis)
-        if (te && atoi(te) >= 2) {
-            for (auto &m : makers) {
-                const int rc = m();
-                if (rc) return rc;
-            }
-            return IMPDAR_OK;
-        }
+    (void)device;           // (the lock is taken per plan: FftPlan::create)
+    for (auto &m : makers) {
+        const int rc = m();
+        if (rc) return rc;
     }
-    for (size_t i = 1; i < makers.size(); ++i)
-        pool.emplace_back([&, i] {
-            if (hipSetDevice(device) != hipSuccess) {
-                rcs[i] = IMPDAR_ERR_HIP;
-                msgs[i] = "hipSetDevice failed in a plan thread";
-                return;
-            }
-            rcs[i] = makers[i]();
-            if (rcs[i]) msgs[i] = impdar_last_error();
-        });
-    if (!makers.empty()) {
-        rcs[0] = makers[0]();
-        if (rcs[0]) msgs[0] = impdar_last_error();
-    }
-    for (auto &t : pool) t.join();
-    for (size_t i = 0; i < makers.size(); ++i)
-        if (rcs[i]) {
-            impdar_set_error("%s", msgs[i].c_str());
-            return rcs[i];
-        }
     return IMPDAR_OK;
 }
 

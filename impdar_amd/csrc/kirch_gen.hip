@@ -482,8 +482,10 @@ int kirch_launch_gen(impdar_kirch_plan *p, void *d_out, int xlo, int xhi, hipStr
             }
         }
         IMPDAR_HIP_CHECK(p->d_jr.ensure(p->h_jr.size() * sizeof(int2)));
-        // (h_jr lives in the plan: the copy may still be in flight when this returns)
-        IMPDAR_HIP_CHECK(hipMemcpyAsync(p->d_jr.p, p->h_jr.data(), p->h_jr.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+        // a blocking copy (tens of KB, only when the block of output traces changes): the next call with another block
+        // re-fills h_jr, which an asynchronous copy from that pageable vector might still be reading
+        IMPDAR_HIP_CHECK(hipStreamSynchronize(st));
+        IMPDAR_HIP_CHECK(hipMemcpy(p->d_jr.p, p->h_jr.data(), p->h_jr.size() * sizeof(int2), hipMemcpyHostToDevice));
         p->jr_key[0] = xlo;
         p->jr_key[1] = xhi;
     }

@@ -3065,9 +3065,6 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
     impdar_kirch_plan *p = c.plan;
     const size_t esz = impdar_dtype_size(dtype);
     const size_t bytes = (size_t)snum * tnum * esz;
-    // the download's staging ring, pinned by a thread of its own while this call uploads and sums (started behind the
-    // plan: beside it the two contend for the runtime -- plan 18 -> 40 ms)
-    impdar_ctx_pinned_prefetch(ctx, std::min(bytes, IMPDAR_STAGE_RING_BYTES));
     auto done = [&](int code) {
         if (code != IMPDAR_OK) {
             // the uploads of the pipelined form read the caller's array asynchronously: nothing may still be in flight
@@ -3097,6 +3094,11 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
     const int kern = impdar_kirch_plan_kernel(p);
     const bool split = !(se && atoi(se) == 0) && tnum >= 4096 && bytes >= ((size_t)64 << 20) &&
                        (kern == IMPDAR_KERNEL_QUAD || kern == IMPDAR_KERNEL_DQUAD);
+    // the download's staging buffer, pinned by a thread of its own while this call uploads and sums (started behind the
+    // plan: beside it the two contend for the runtime -- plan 18 -> 40 ms): the 64 MB ring of the pipelined blocks, or
+    // the whole image where the download is one piece (round 4 asked for the ring there too, and the download then freed
+    // it and pinned the image synchronously: both pins and a free on the first call)
+    impdar_ctx_pinned_prefetch(ctx, split ? std::min(bytes, IMPDAR_STAGE_RING_BYTES) : bytes);
     int nlaunch = 1;
     if (split) {
         const int halo = p->ntab + 16;                 // aperture half width (+ the kernels' staging look-ahead)
@@ -3179,8 +3181,15 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
     ctx->m_kernel_ms = kms;
     ctx->timed = false;
     const auto t2 = now();
-    snprintf(ctx->m_extra, sizeof ctx->m_extra, "\"plan\": \"%s\", \"launches\": %d, \"plan_ms\": %.3f, \"call_ms\": %.3f",
-             hit ? "cached" : "new", nlaunch, ms(t0, t0b), ms(t0, t2));
+    // xnoise: the position noise of the profile against its fitted grid, in trace spacings (impdar_kirch_plan_xnoise); the
+    // float64 ring / tabulated kernels weight a pair by its trace OFFSET, so their stated bar against the reference is
+    // max(1e-12, 0.1 xnoise) of the image maximum -- parity_bar says which one this call ran under (the per-pair kernel,
+    // IMPDAR_KIRCH_EXACT_IMPL=pair, holds 1e-12 on any profile)
+    const bool offset_weighted = kern == IMPDAR_KERNEL_DQUAD || kern == IMPDAR_KERNEL_EXACT_TAB;
+    snprintf(ctx->m_extra, sizeof ctx->m_extra,
+             "\"plan\": \"%s\", \"launches\": %d, \"plan_ms\": %.3f, \"call_ms\": %.3f, \"xnoise\": %.3g, \"parity_bar\": %.3g",
+             hit ? "cached" : "new", nlaunch, ms(t0, t0b), ms(t0, t2), p->xnoise,
+             dtype == IMPDAR_F32 && p->mode == IMPDAR_KIRCH_FAST ? 1e-4 : (offset_weighted ? std::max(1e-12, 0.1 * p->xnoise) : 1e-12));
     rc = done(IMPDAR_OK);
     return rc;
 }

@@ -292,6 +292,8 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
 #pragma unroll
             for (int rb = 0; rb < PM_NRB; ++rb)
                 if (brun[rb] >= 0 && __builtin_amdgcn_ballot_w64(any_f && phis[rb] == phis[rb]) != 0) rb_in |= 1u << rb;
+            static_assert(PM_NQ == 1, "the skip below is uniform over the WORKGROUP only while every wave walks the same chunks: "
+                                      "with more frequency parts decide it through LDS / __syncthreads_or");
             if (rb_in == 0) continue;
         }
         // ---- phase 1, fused: the state tile of this wave's own block as TWO recurrences (rows 0..15 and 16..31 of the tile,

@@ -15,6 +15,9 @@
 // the contiguous axis and the trace transform is a strided batched C2C.
 #include "fft.h"
 #include <mutex>
+#include <string>
+#include <sys/stat.h>
+#include <unistd.h>
 
 static std::once_flag g_fft_once;
 static int g_fft_rc = IMPDAR_OK;
@@ -22,6 +25,27 @@ static int g_fft_rc = IMPDAR_OK;
 int impdar_fft_global_setup()
 {
     std::call_once(g_fft_once, [] {
+        // rocFFT keeps the kernels of the plans it has built in a small user database; without one every new process
+        // fetches them again from the 1.8 GB system database (0.25 s per plan with that file in the page cache, up to
+        // 1.7 s from a cold disk: profiles/r05_first_call.txt) instead of 25 ms.  Where the user has not chosen a place
+        // (ROCFFT_RTC_CACHE_PATH) and rocFFT's own default is not writable ($HOME on a batch node), give it one.
+        if (!getenv("ROCFFT_RTC_CACHE_PATH")) {
+            std::string dir;
+            const char *xdg = getenv("XDG_CACHE_HOME"), *home = getenv("HOME");
+            auto usable = [](const std::string &d) {
+                if (d.empty()) return false;
+                (void)mkdir(d.c_str(), 0700);
+                return access(d.c_str(), W_OK | X_OK) == 0;
+            };
+            if (xdg && *xdg && usable(xdg)) dir = std::string(xdg) + "/impdar_amd";
+            else if (home && *home && usable(std::string(home) + "/.cache")) dir = std::string(home) + "/.cache/impdar_amd";
+            else dir = "/tmp/impdar_amd-" + std::to_string((long)getuid());
+            if (usable(dir)) {
+                const std::string path = dir + "/rocfft_kernel_cache.db";
+                (void)setenv("ROCFFT_RTC_CACHE_PATH", path.c_str(), 0);
+                impdar_trace("rocFFT user kernel cache: %s", path.c_str());
+            }
+        }
         impdar_trace("rocfft_setup: start");
         if (rocfft_setup() != rocfft_status_success) {
             g_fft_rc = IMPDAR_ERR_FFT;
@@ -30,6 +54,12 @@ int impdar_fft_global_setup()
     });
     if (g_fft_rc) impdar_set_error("rocfft_setup failed");
     return g_fft_rc;
+}
+
+std::mutex &impdar_fft_plan_mutex()
+{
+    static std::mutex mu;
+    return mu;
 }
 
 template <typename T> struct Cx { T x, y; };
