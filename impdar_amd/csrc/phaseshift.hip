@@ -1314,6 +1314,10 @@ struct PsPlan {
     const impdar_ctx *slab_owner = nullptr;
     DevBuf d_sendbuf, d_slab;            // ... packed blocks of the all-to-all; the transposed slab
     DevBuf d_blocks, d_edge, d_runtab;   // matrix-core path: row-block table; boundary-frequency counts + lists; per-run phases
+    DevBuf d_pr_runs, d_pr_stages, d_rw; // many-runs matrix-core path (ps_runs.h): runs, stages, 1 / w
+    // a (kx, runs) geometry whose boundary-frequency lists overflowed in a matrix-core path: not tried again
+    std::vector<double> ovf_kx;
+    std::vector<PsMfmaRun> ovf_runs;
     DevBuf X, TK, d_kx, d_w, d_vz, d_thr, d_sched, d_rowmap, d_eps, d_sm, d_part;
     std::vector<double> h_sm_step, h_sm_tile;
     bool b_ready = false;
@@ -1405,17 +1409,162 @@ static int ps_dispatch(const PsParams &P, hipStream_t st)
     return IMPDAR_OK;
 }
 
+#include "ps_runs.h"        // many runs of constant velocity: float32 MFMA, phases generated in the kernel
+
+// did a matrix-core path find more boundary frequencies than it lists on this (kx, runs) geometry before?  (ADVICE r4:
+// such inputs paid set-up + sums + a blocking read-back on EVERY call, discarded, before the vector kernels ran)
+static bool ps_known_overflow(const PsPlan &pl, const double *kx, int tnum, const std::vector<PsMfmaRun> &runs)
+{
+    if (pl.ovf_kx.size() != (size_t)tnum || pl.ovf_runs.size() != runs.size() || runs.empty()) return false;
+    if (memcmp(pl.ovf_kx.data(), kx, (size_t)tnum * 8) != 0) return false;
+    for (size_t i = 0; i < runs.size(); ++i)
+        if (runs[i].v != pl.ovf_runs[i].v || runs[i].start != pl.ovf_runs[i].start || runs[i].len != pl.ovf_runs[i].len) return false;
+    return true;
+}
+static void ps_note_overflow(PsPlan &pl, const double *kx, int tnum, const std::vector<PsMfmaRun> &runs)
+{
+    pl.ovf_kx.assign(kx, kx + tnum);
+    pl.ovf_runs = runs;
+}
+
+// ---- many-runs matrix-core path (ps_runs.h): stages, launch.  Same contract as ps_mfma_run.
+static int ps_runs_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &runs, const double *kx_host, const double *w_host,
+                       const double *thr, hipStream_t st, bool *done)
+{
+    *done = false;
+    const int snum = P.snum, tnum = P.tnum;
+    if (P.nf % 32 != 0 || P.nf < 256 || snum < 64 || runs.empty()) return IMPDAR_OK;
+    for (int i = 0; i < snum; ++i)
+        if (!(thr[i] < 1e-10)) return IMPDAR_OK;           // the evanescence test must be the sign of coss off the boundary band
+    if (ps_known_overflow(pl, kx_host, tnum, runs)) return IMPDAR_OK;
+    // runs -> pieces: long (<= 512 steps, tiles of 8) and single steps
+    std::vector<PrRun> pr;
+    int nshort_total = 0, nblk_total = 0;
+    for (const PsMfmaRun &r : runs) {
+        if (r.len <= PR_SHORT_LEN) {
+            pr.push_back(PrRun{r.v, r.start, r.len, 1, 0});
+            nshort_total += r.len;
+            continue;
+        }
+        const int npiece = (r.len + PR_LONG_MAX - 1) / PR_LONG_MAX;
+        for (int i = 0, at = 0; i < npiece; ++i) {
+            // pieces of (nearly) equal length, whole tiles except the last
+            int len = ((r.len - at) / (npiece - i) + PR_TT - 1) / PR_TT * PR_TT;
+            len = std::min(len, r.len - at);
+            pr.push_back(PrRun{r.v, r.start + at, len, 0, 0});
+            nblk_total += ((len + PR_TT - 1) / PR_TT + PR_ROWS - 1) / PR_ROWS;
+            at += len;
+        }
+    }
+    // a record that is mostly single steps (a velocity that changes at nearly every step) is ps_smooth's
+    if (nshort_total > snum / 4 || nblk_total == 0) return IMPDAR_OK;
+    std::vector<PrStage> stages;
+    {
+        PrStage cur;
+        auto open = [&](int run0) {
+            cur = PrStage{};
+            cur.run0 = run0;
+            for (int i = 0; i < PR_LONGS; ++i) cur.long_run[i] = -1;
+        };
+        auto close = [&]() {
+            if (cur.nruns == 0) return;
+            // the single steps go to the wave with the fewest blocks
+            int best = 0;
+            for (int i = 1; i < PR_LONGS; ++i)
+                if (cur.long_nblk[i] < cur.long_nblk[best]) best = i;
+            cur.short_wave = best;
+            stages.push_back(cur);
+        };
+        open(0);
+        int nlong = 0;
+        for (int i = 0; i < (int)pr.size(); ++i) {
+            const bool is_long = pr[i].kind == 0;
+            // (single steps lead the long run that follows them: the set-up chains their states into its anchor -- a stage
+            // that has its four long runs is closed before the next group)
+            const bool fits = cur.nruns < PR_STAGE_RUNS && (is_long ? nlong < PR_LONGS : (nlong < PR_LONGS && cur.nshort + pr[i].len <= PR_SROWS));
+            if (!fits) {
+                close();
+                open(i);
+                nlong = 0;
+            }
+            if (is_long) {
+                pr[i].slot = nlong;
+                cur.long_run[nlong] = i;
+                cur.long_nblk[nlong] = ((pr[i].len + PR_TT - 1) / PR_TT + PR_ROWS - 1) / PR_ROWS;
+                ++nlong;
+            } else {
+                pr[i].slot = cur.nshort;
+                for (int s_ = 0; s_ < pr[i].len; ++s_) cur.short_tau[cur.nshort++] = pr[i].start + s_;
+            }
+            ++cur.nruns;
+        }
+        close();
+    }
+    const int nparts = (P.nf + PR_PART - 1) / PR_PART;
+    const size_t part_bytes = nparts > 1 ? (size_t)nparts * P.nk * snum * sizeof(Cp<float>) : 0;
+    std::vector<double> rw((size_t)P.nf);
+    for (int i = 0; i < P.nf; ++i) rw[i] = 1.0 / w_host[i];
+    if (pl.d_pr_runs.ensure(pr.size() * sizeof(PrRun)) != hipSuccess || pl.d_pr_stages.ensure(stages.size() * sizeof(PrStage)) != hipSuccess ||
+        pl.d_rw.ensure(rw.size() * 8) != hipSuccess || pl.d_edge.ensure((size_t)tnum * (1 + PM_EMAX) * sizeof(int)) != hipSuccess ||
+        (part_bytes && pl.d_part.ensure(part_bytes) != hipSuccess)) {
+        (void)hipGetLastError();
+        return IMPDAR_OK;                      // no room: the other paths take the call
+    }
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_pr_runs.p, pr.data(), pr.size() * sizeof(PrRun), hipMemcpyHostToDevice, st));
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_pr_stages.p, stages.data(), stages.size() * sizeof(PrStage), hipMemcpyHostToDevice, st));
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_rw.p, rw.data(), rw.size() * 8, hipMemcpyHostToDevice, st));
+    PrParams Q;
+    Q.P = P;
+    Q.runs = pl.d_pr_runs.as<PrRun>();
+    Q.stages = pl.d_pr_stages.as<PrStage>();
+    Q.rw = pl.d_rw.as<double>();
+    Q.nstages = (int)stages.size();
+    Q.nruns = (int)pr.size();
+    Q.nparts = nparts;
+    Q.part = pl.d_part.p;
+    Q.edge_cnt = pl.d_edge.as<int>();
+    Q.edge_list = Q.edge_cnt + tnum;
+    IMPDAR_HIP_CHECK(hipMemsetAsync(Q.edge_cnt, 0, (size_t)tnum * sizeof(int), st));
+    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PR_LDS_BYTES));
+    hipLaunchKernelGGL(ps_runs_kernel, dim3((unsigned)P.nk * nparts), dim3(256), PR_LDS_BYTES, st, Q);
+    if (nparts > 1) {
+        const size_t n = (size_t)P.nk * snum;
+        hipLaunchKernelGGL((ps_smooth_sum_kernel<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<const Cp<float> *>(pl.d_part.p), reinterpret_cast<Cp<float> *>(P.TK), nparts, n, snum);
+    }
+    {
+        PsMfmaParams E;                        // (ps_edge_kernel reads P and the lists only)
+        E.P = P;
+        E.nruns = 0;
+        E.edge_cnt = Q.edge_cnt;
+        E.edge_list = Q.edge_list;
+        hipLaunchKernelGGL(ps_edge_kernel, dim3(P.nk), dim3(256), 0, st, E);
+    }
+    IMPDAR_HIP_CHECK(hipGetLastError());
+    IMPDAR_HIP_CHECK(hipStreamSynchronize(st));            // (the host tables must outlive their copies)
+    std::vector<int> cnt((size_t)P.nk);
+    IMPDAR_HIP_CHECK(hipMemcpy(cnt.data(), Q.edge_cnt + P.k0, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+    int worst = 0;
+    for (int c : cnt) worst = std::max(worst, c);
+    // every part of a wavenumber counts its own boundary frequencies into the same list: the first PM_EMAX are walked
+    if (worst > PM_EMAX) {
+        ps_note_overflow(pl, kx_host, tnum, runs);
+        return IMPDAR_OK;                      // contributions missing from TK: discarded, another path produces the result
+    }
+    *done = true;
+    return IMPDAR_OK;
+}
+
 // ---- matrix-core path (ps_mfma.h): eligibility, row-block table, launch ---------------------------------------
 // runs: (velocity, first step, length) of every constant-velocity run (one run for a constant velocity).  Returns
 // IMPDAR_OK with *done = true when the frequency sums were produced here; *done = false: not eligible, the vector
 // kernels take the call.
-static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &runs, bool vz, const double *thr, hipStream_t st,
-                       bool *done)
+static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &runs, bool vz, const double *kx_host, const double *thr,
+                       hipStream_t st, bool *done)
 {
     *done = false;
-    const char *me = getenv("IMPDAR_PS_MFMA");             // 0: vector kernels only (A/B runs, tests)
-    if (me && atoi(me) == 0) return IMPDAR_OK;
     const int snum = P.snum, tnum = P.tnum;
+    if (vz && ps_known_overflow(pl, kx_host, tnum, runs)) return IMPDAR_OK;
     if (P.nf % (PM_CH * PM_NQ) != 0 || P.nf < 256 || P.nf > 4096 + 2048 || snum < 256 || runs.empty() || (int)runs.size() > PM_MAX_RUNS) return IMPDAR_OK;
     if (vz)
         for (int i = 0; i < snum; ++i)
@@ -1503,6 +1652,7 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
         int worst = 0;
         for (int c : cnt) worst = std::max(worst, c);
         const bool force_overflow = getenv("IMPDAR_PS_TEST_EDGE_OVERFLOW") != nullptr;      // test hook (read per call)
+        if (worst > PM_EMAX) ps_note_overflow(pl, kx_host, tnum, runs);    // (remembered: not tried again on this geometry)
         if (worst > PM_EMAX || force_overflow) return IMPDAR_OK;           // *done stays false
     }
     *done = true;
@@ -1533,6 +1683,9 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             pl.d_blocks.release();
             pl.d_edge.release();
             pl.d_runtab.release();
+            pl.d_pr_runs.release();
+            pl.d_pr_stages.release();
+            pl.d_rw.release();
             pl.d_sendbuf.release();
             pl.d_slab.release();
             pl.X.release(); pl.TK.release(); pl.d_kx.release(); pl.d_w.release(); pl.d_vz.release(); pl.d_thr.release(); pl.d_sm.release(); pl.d_part.release();
@@ -1806,6 +1959,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     if ((rc = impdar_ctx_ktic(ctx))) return rc;
     impdar_trace("phaseshift: forward transforms enqueued");
     bool mfma_done = false;
+    const char *mfma_kernel_name = "";
     if constexpr (sizeof(T) == 4) {
         // float32: the frequency sums on the matrix cores when the depth axis is a few long runs of constant velocity
         std::vector<PsMfmaRun> mruns;
@@ -1815,12 +1969,34 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
                 ok = std::isfinite(vmig[i]) && vmig[i] != 0.0;
                 if (sched[i]) mruns.push_back(PsMfmaRun{vmig[i], i, 0});
                 if (!mruns.empty()) mruns.back().len += 1;
-                ok = ok && (int)mruns.size() <= PM_MAX_RUNS;
             }
         } else {
             mruns.push_back(PsMfmaRun{vconst, 0, snum});
         }
-        if (ok && (rc = ps_mfma_run(pl, P, mruns, vlen != 0, thr.data(), st, &mfma_done))) return rc;
+        // IMPDAR_PS_MFMA: 0 the vector kernels only; 2 / 3 only ps_mfma_kernel / only ps_runs_kernel of the two matrix-core
+        // paths (A/B runs, tests).  By themselves: up to 16 thick layers -> ps_mfma_kernel (64-step tiles, float16 hi / lo);
+        // more long runs -> ps_runs_kernel (8-step tiles, float32, phases generated in the kernel); whichever declines
+        // (ps_mfma_kernel: rows mostly padding on short records) hands over to the other, then to the vector kernels.
+        const char *me = getenv("IMPDAR_PS_MFMA");
+        const int pref = me ? atoi(me) : 1;
+        int nlong = 0;
+        for (const PsMfmaRun &r : mruns) nlong += r.len > PM_SHORT;
+        const bool force_overflow = getenv("IMPDAR_PS_TEST_EDGE_OVERFLOW") != nullptr;
+        // (8192^2, equal layers, profiles/r05_ps_runs.txt: ps_mfma_kernel 9.1 / 12.5 / 15.9 / 19.4 / 26.7 ms at 4 / 5 / 9 / 13 / 21
+        // table rows -- about 7.5 + 0.96 ms per long run; ps_runs_kernel 19-23 ms up to 13 rows, 25.6 at 21, 29 at 41, 39 at 81)
+        const bool runs_first = vlen != 0 && nlong > 16;
+        for (int turn = 0; turn < 2 && ok && !mfma_done && pref != 0; ++turn) {
+            const bool use_runs = (turn == 0) == runs_first;
+            if (use_runs) {
+                if (pref == 2 || !vlen || force_overflow) continue;
+                if ((rc = ps_runs_run(pl, P, mruns, kx, w.data(), thr.data(), st, &mfma_done))) return rc;
+                if (mfma_done) mfma_kernel_name = "ps_runs_kernel";
+            } else {
+                if (pref == 3) continue;
+                if ((rc = ps_mfma_run(pl, P, mruns, vlen != 0, kx, thr.data(), st, &mfma_done))) return rc;
+                if (mfma_done) mfma_kernel_name = "ps_mfma_kernel";
+            }
+        }
     }
     if (sizeof(T) == 4 && !mfma_done && P.sched && (rc = order_rows())) return rc;
     bool smooth_done = false;
@@ -1856,7 +2032,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     }
     if (!mfma_done && !smooth_done && (rc = ps_dispatch<T>(P, st))) return rc;
     ctx->m_entry = tk_out ? "impdar_phaseshift_tk_dev" : "impdar_phaseshift";
-    ctx->m_kernel = mfma_done ? "ps_mfma_kernel" : t_ps_kernel;
+    ctx->m_kernel = mfma_done ? mfma_kernel_name : t_ps_kernel;
     ctx->m_kernel_ms = -1.f;                 // (bracketed by ktic / ktoc)
     snprintf(ctx->m_extra, sizeof ctx->m_extra, "\"hermitian_walk\": %s, \"frequencies\": %d", herm ? "true" : "false", nf);
     if (herm)

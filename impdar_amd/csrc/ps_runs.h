@@ -1,0 +1,441 @@
+// Phase-shift frequency sum for MANY runs of constant velocity (float32 data; included by phaseshift.hip).
+//
+// Reference: mig_python.py:438-487 with the vmig that getVelocityProfile (:582-604) makes of an N-row (v, z) table: N - 1
+// layers of constant velocity, each boundary smeared over three or four single steps by 2 * gradient(z(t)).  ps_mfma.h
+// cuts a run into 64-step tiles and row blocks of 2048 steps -- right for 2-4 thick layers, mostly padding for layers of
+// 100-400 steps: tables of more than 16 runs fell back to the vector kernels (41 / 81 rows at 8192^2: 46.6 / 62.0 ms
+// against 9.4 for four rows).  This kernel is built for the short layers:
+//
+//   * tiles of 8 steps, blocks of 16 tiles: inside a run  step = 8 a + b,
+//         TK[start + 8 a + b] = sum_w [F_w e^{i Phi_w} e^{i 8 a phi_w}] [e^{i (b + 1) phi_w}] = sum_w S_w(a) B_w(b),
+//     one v_mfma_f32_16x16x4_f32 accumulator = 16 tiles x (8 steps x (re, im)) = 128 steps per block.  float32 operands:
+//     no hi / lo split, no scaling, products exact to float32 -- the matrix pipe runs at the float32 VECTOR rate here
+//     (64 flop / clk / SIMD, 1/16 of the float16 rate ps_mfma.h uses), and that is the point: a state row costs 4 vector
+//     instructions instead of 10, so the vector work (states, step factors, the per-run set-up) fits UNDER the matrix
+//     pipe's time instead of on top of it;
+//   * phases generated in the kernel: a thread owns ONE frequency at a time and walks the stage's runs in order with
+//     the phase in a float64 register -- coss, the square root (reciprocal-root seed + two Newton steps), the phase at the
+//     run's start, and for the run three sincos: the anchor state F e^{i Phi}, the tile rotation e^{i 8 phi}, the step
+//     rotation e^{i phi}.  No table in HBM (ps_mfma.h: 16 bytes per wavenumber, frequency and run), no limit on runs;
+//   * single steps between the layers are ROWS of their own: the state at that step against a unit matrix, up to 12 of
+//     them in one more accumulator per stage -- the sum over the frequencies still runs on the matrix pipe.
+//
+// Work split.  A workgroup = (wavenumber, PART of the spectrum: 1024 frequency slots, 4 per thread); its sums over the
+// part go to a partial image [part][k][tau], added in order by ps_smooth_sum_kernel (deterministic; one part: straight to
+// TK).  The depth axis is cut into STAGES of up to four long runs (<= 512 steps each: longer runs are cut) and twelve
+// single steps; per stage and super-chunk of 256 frequencies: (1) every thread sets up its frequency for the stage's
+// runs -> LDS; (2) wave p multiplies ITS long run: per chunk of 32 frequencies it generates the state tile (two lanes
+// per frequency, rows by S *= e^{i 16 phi}) and the step-factor tile into its own LDS tiles and issues 16 MFMAs per
+// block; the wave with the least work also takes the stage's single steps.  Accumulators: 4 blocks + 1 per wave.
+// Frequencies on the evanescent boundary of some run take no part and are listed for ps_edge_kernel, as in ps_mfma.h;
+// a frequency that has turned evanescent is out for good (NaN phase), chunks of 32 dead frequencies are skipped.
+#pragma once
+
+typedef float pr_float4 __attribute__((ext_vector_type(4)));
+
+constexpr int PR_TT = 8;            // depth steps per tile
+constexpr int PR_ROWS = 16;         // tiles per block
+constexpr int PR_NM = 4;            // frequencies per thread (super-chunks of 256 slots per part)
+constexpr int PR_PART = PR_NM * 256;
+constexpr int PR_LONGS = 4;         // long runs per stage = waves
+constexpr int PR_NBLK = 4;          // blocks per long run: up to 512 steps
+constexpr int PR_LONG_MAX = PR_NBLK * PR_ROWS * PR_TT;
+constexpr int PR_SHORT_LEN = 2;     // runs of up to this many steps: every step a row of its own
+constexpr int PR_SROWS = 12;        // single-step rows per stage
+constexpr int PR_STAGE_RUNS = 16;   // runs per stage
+constexpr size_t PR_LDS_FLOATS = 3 * 2 * PR_LONGS * 8 * 32 + 8 * PR_SROWS * 64 + PR_LONGS * PR_ROWS * 64 + PR_LONGS * 16 * 8 * 4 + 16 + PR_STAGE_RUNS * 6;
+constexpr size_t PR_LDS_BYTES = PR_LDS_FLOATS * 4;
+
+struct PrRun {
+    double v;               // velocity
+    int start, len;         // first depth step, steps
+    int kind;               // 0: long (tiles of 8 steps), 1: single steps
+    int slot;               // long: the wave that multiplies it; short: its first row among the stage's single-step rows
+};
+static_assert(sizeof(PrRun) == 24, "the kernel copies a stage's runs to LDS as 6 words each");
+struct PrStage {
+    int run0, nruns;        // the stage's runs, in depth order
+    int nshort, short_wave; // single-step rows and the wave that multiplies them
+    int long_run[PR_LONGS]; // run of wave p (-1: none)
+    int long_nblk[PR_LONGS];
+    int short_tau[PR_SROWS];
+};
+struct PrParams {
+    PsParams P;
+    const PrRun *runs;
+    const PrStage *stages;
+    const double *rw;       // [nf] 1 / w
+    int nstages, nruns, nparts;
+    void *part;             // [nparts][nk][snum] complex float32 partial images (nparts > 1)
+    int *edge_cnt, *edge_list;
+};
+
+// sqrt(x), x in [1e-8, 1]: v_rsq_f64 as the seed and ONE Newton step that carries h ~ 1 / (2 y) (relative error of the
+// seed squared: < 1e-15).  pm_sqrt01 goes through float32 (two conversions and v_rsq_f32: three quarter-rate
+// instructions) and takes two steps; in this kernel's set-up, where every instruction of a float64 chain waits for the one
+// before, that was a third of a run's time.
+__device__ __forceinline__ double pr_sqrt01(double x)
+{
+    const double r = __builtin_amdgcn_rsq(x);
+    const double y = x * r, h = 0.5 * r;
+    return fma(fma(-y, y, x), h, y);
+}
+
+// pm_sincos with the quadrant found by adding and subtracting 1.5 * 2^52 (the integer is then the sum's low word: no
+// v_rndne_f64, no v_cvt_i32_f64 -- quarter-rate instructions both); |x| < 1e9
+__device__ __forceinline__ void pr_sincos(double x, float *s, float *c)
+{
+    const double t = x * 0.6366197723675814;              // 2 / pi
+    const double tm = t + 6755399441055744.0;
+    const int q = __double2loint(tm);
+    const double n = tm - 6755399441055744.0;
+    const float r = (float)((t - n) * 1.5707963267948966);
+    const float z = r * r;
+    const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+    const float cp = fmaf(z * z, fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f),
+                          fmaf(-0.5f, z, 1.0f));
+    const bool odd = q & 1;
+    const float sv = odd ? cp : sp, cv = odd ? sp : cp;
+    *s = (q & 2) ? -sv : sv;
+    *c = ((q + 1) & 2) ? -cv : cv;
+}
+
+__device__ __forceinline__ float2 pr_cmul(float2 a, float2 b)
+{
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+
+__global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
+{
+    extern __shared__ __attribute__((aligned(16))) float pr_lds[];
+    const PsParams &P = Q.P;
+    const int tid = threadIdx.x, lane = tid & 63, p = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // block -> (wavenumber, part): the blocks of ONE part are consecutive -- blocks are dealt round robin to the 8 XCDs, and
+    // with the parts of a wavenumber side by side (part = block % 4) every XCD saw one part only: the low parts are mostly
+    // evanescent and leave early, so four XCDs did most of the work (first form: 1.4 waves per SIMD on average, 43 ms).
+    // The high, long-lived parts first.
+    const int part = Q.nparts - 1 - (int)blockIdx.x / P.nk, kb = (int)blockIdx.x % P.nk, k = P.k0 + kb;
+    // LDS: per long run (wave) and chunk the anchor state / tile rotation / step rotation of every frequency; the
+    // single-step state tiles of the 8 chunks; a state tile and a step-factor tile per wave; the chunks' alive flags
+    float2 *TS = reinterpret_cast<float2 *>(pr_lds);
+    float2 *TA = TS + PR_LONGS * 8 * 32, *TB = TA + PR_LONGS * 8 * 32;
+    float *SH = pr_lds + 3 * 2 * PR_LONGS * 8 * 32;
+    float *AT = SH + 8 * PR_SROWS * 64 + (size_t)p * PR_ROWS * 64;
+    float *BT = SH + 8 * PR_SROWS * 64 + PR_LONGS * PR_ROWS * 64 + (size_t)p * 16 * 8 * 4;
+    int *alive = reinterpret_cast<int *>(SH + 8 * PR_SROWS * 64 + PR_LONGS * PR_ROWS * 64 + PR_LONGS * 16 * 8 * 4);
+    // the stage's runs, copied here once per stage (read from global memory inside the set-up walk every iteration waited a
+    // scalar-load round trip: 16 runs x ~250 cycles per walk)
+    PrRun *sruns = reinterpret_cast<PrRun *>(alive + 16);
+
+    const Cp<float> *Frow = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.fstride;
+    const double kxk = P.kx[k];
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+
+    // ---- this thread's frequencies: slot part * 1024 + 256 m + tid.  The arrays are ROTATED after every super-chunk, so
+    // the code below only ever indexes element 0 (a run-time index into registers would be a scratch array)
+    double phi[PR_NM], rw[PR_NM], wdt[PR_NM], incq[PR_NM];     // incq / rbq: phase per step and step rotation of the last long run
+    float2 F[PR_NM], rbq[PR_NM];
+    bool edge[PR_NM], inpart[PR_NM];
+#pragma unroll
+    for (int m = 0; m < PR_NM; ++m) {
+        const int slot = part * PR_PART + 256 * m + tid;
+        const bool in = slot < P.nf;
+        const Cp<float> f = in ? ps_load_slot<float>(Frow, P, slot) : Cp<float>{0.f, 0.f};
+        F[m] = make_float2(f.x, f.y);
+        rw[m] = in ? Q.rw[slot] : 1.0;
+        wdt[m] = in ? P.w[slot] * P.dt : 0.0;
+        edge[m] = false;
+        inpart[m] = in;
+        incq[m] = 0.0;
+        rbq[m] = make_float2(1.f, 0.f);
+    }
+    // boundary frequencies (|coss| < 1e-8 at ANY run's velocity: kept or dropped by the reference at every step's own
+    // velocity, :456-485) take no part here: listed for ps_edge_kernel (as ps_setup_kernel does).  Runs in the outer loop:
+    // one scalar load per distinct velocity for the thread's four frequencies.
+    {
+        double vprev = 0.0;
+        for (int r = 0; r < Q.nruns; ++r) {
+            const double v = Q.runs[r].v;
+            if (v == vprev) continue;                                         // uniform (pieces of one run, equal layers)
+            vprev = v;
+#pragma unroll
+            for (int m = 0; m < PR_NM; ++m) edge[m] = edge[m] || fabs(pm_coss(v, kxk, rw[m])) < 1e-8;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < PR_NM; ++m) {
+        if (edge[m] && inpart[m]) {
+            const int at = atomicAdd(Q.edge_cnt + k, 1);
+            if (at < PM_EMAX) Q.edge_list[(size_t)k * PM_EMAX + at] = part * PR_PART + 256 * m + tid;
+        }
+        phi[m] = (edge[m] || !inpart[m]) ? nan : 0.0;                         // NaN phase = out of every run from here on
+    }
+    {
+        // a part all of whose frequencies are evanescent at the FIRST run's velocity already (the low band) adds nothing
+        bool any = false;
+#pragma unroll
+        for (int m = 0; m < PR_NM; ++m) any = any || (phi[m] == phi[m] && pm_coss(Q.runs[0].v, kxk, rw[m]) > 0.0);
+        if (!__syncthreads_or(any)) {
+            Cp<float> *out = reinterpret_cast<Cp<float> *>(Q.nparts > 1 ? Q.part : P.TK) + ((size_t)(Q.nparts > 1 ? part : 0) * P.nk + kb) * P.snum;
+            for (int t = tid; t < P.snum; t += 256) out[t] = Cp<float>{0.f, 0.f};
+            return;
+        }
+    }
+    Cp<float> *out = reinterpret_cast<Cp<float> *>(Q.nparts > 1 ? Q.part : P.TK) + ((size_t)(Q.nparts > 1 ? part : 0) * P.nk + kb) * P.snum;
+    const float scale = Q.nparts > 1 ? 1.0f : 1.0f / (float)P.snum;         // (:492; with parts ps_smooth_sum_kernel divides)
+
+    const int cc = tid >> 5, f = tid & 31;           // set-up roles: chunk of the super-chunk, frequency of the chunk
+    const int gf = lane & 31, hh = lane >> 5;        // generation roles: frequency, which of its two lanes
+    const int orow = lane & 15, kk = lane >> 4;      // MFMA operand roles: row (A) / column (B), K slot
+    const int ob = orow >> 1, onc = orow & 1;        // ... the column's step and component
+
+    for (int j = 0; j < Q.nstages; ++j) {
+        const PrStage *st = Q.stages + j;
+        const int run0 = st->run0, nruns = st->nruns, nshort = st->nshort;
+        const int my_run = st->long_run[p], my_nblk = st->long_nblk[p];
+        if (tid < nruns * 6) reinterpret_cast<unsigned *>(sruns)[tid] = reinterpret_cast<const unsigned *>(Q.runs + run0)[tid];
+        __syncthreads();
+        pr_float4 acc[PR_NBLK][2], accs;
+#pragma unroll
+        for (int b = 0; b < PR_NBLK; ++b) acc[b][0] = acc[b][1] = pr_float4{0.f, 0.f, 0.f, 0.f};
+        accs = pr_float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int m = 0; m < PR_NM; ++m) {
+            // ---- (1) set-up: this thread's frequency through the stage's runs.  A long run costs the square root and two or
+            // three sincos (anchor state, tile rotation, step rotation).  The single steps between two layers are CHAINED: the
+            // first of a group is anchored with a sincos of the float64 phase, every step then turns the state by
+            // e^{i phi*} = (step rotation of the last long run) e^{i (phi* - phi_run)} -- the difference is small (the
+            // velocity moves by a per cent from layer to layer), its sine and cosine come from their series -- and the state
+            // after the group's last step IS the anchor of the next long run (three rotations in float32; the next group
+            // starts from the float64 phase again).  First form: a sincos per single step -- the set-up was 63 % of the
+            // kernel's vector instructions at 41 rows.
+            {
+                double ph = phi[0], incp = incq[0];
+                float2 rBp = rbq[0];
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(ph == ph);
+                if (f == 0) alive[cc] = ((hh ? (bal >> 32) : bal) & 0xffffffffull) != 0ull;
+                float2 chain = make_float2(0.f, 0.f);
+                bool chain_valid = false;                                       // uniform
+                // (a wave all of whose 64 frequencies are out skips the walk: their chunks are skipped below too)
+#ifdef PR_ABL_NOSETUP
+                for (int rl = 0; rl < (bal != 0ull && j == 0 && m == 0 ? nruns : 0); ++rl) {       // timing only: one walk
+#else
+                for (int rl = 0; rl < (bal != 0ull ? nruns : 0); ++rl) {       // uniform
+#endif
+                    const PrRun *R = sruns + rl;
+                    const double v = R->v;
+                    const int len = R->len, kind = R->kind, slot = R->slot;
+                    const double cs = pm_coss(v, kxk, rw[0]);                  // :456
+                    double inc = 0.0;
+                    if (cs <= 0.0) ph = nan;                                   // :484-485, for good
+                    else inc = wdt[0] * pr_sqrt01(cs);                         // :458-460 (off the boundary band: cs >= 1e-8)
+                    const bool in = ph == ph;
+                    if (kind == 0) {                                           // uniform
+                        float2 S = chain;
+                        if (!chain_valid) {                                     // uniform
+                            float s, c;
+                            pr_sincos(in ? ph : 0.0, &s, &c);
+                            S = make_float2(fmaf(F[0].x, c, -(F[0].y * s)), fmaf(F[0].x, s, F[0].y * c));
+                        }
+                        if (!in) S = make_float2(0.f, 0.f);
+                        float as, ac, bs, bc;
+                        pr_sincos(8.0 * inc, &as, &ac);
+                        pr_sincos(inc, &bs, &bc);
+                        const int idx = (slot * 8 + cc) * 32 + f;
+                        TS[idx] = S;
+                        TA[idx] = make_float2(ac, as);
+                        TB[idx] = make_float2(bc, bs);
+                        incp = inc;
+                        rBp = make_float2(bc, bs);
+                        chain_valid = false;
+                        ph += (double)len * inc;                               // NaN stays NaN
+                    } else {
+                        for (int s_ = 0; s_ < len; ++s_) {                     // uniform, len <= PR_SHORT_LEN
+                            if (!chain_valid) {                                 // uniform: the first single step of a group
+                                float s, c;
+                                pr_sincos(in ? ph : 0.0, &s, &c);
+                                chain = make_float2(fmaf(F[0].x, c, -(F[0].y * s)), fmaf(F[0].x, s, F[0].y * c));
+                                chain_valid = true;
+                            }
+                            const float dl = (float)(inc - incp);
+                            const bool exact = in && !(incp != 0.0 && fabsf(dl) <= 0.25f);
+                            const float h = dl * dl;
+                            const float dc = fmaf(h, fmaf(h, fmaf(h, -1.0f / 720.0f, 1.0f / 24.0f), -0.5f), 1.0f);
+                            const float ds = dl * fmaf(h, fmaf(h, 1.0f / 120.0f, -1.0f / 6.0f), 1.0f);
+                            float2 rot = pr_cmul(rBp, make_float2(dc, ds));
+                            if (__builtin_amdgcn_ballot_w64(exact) != 0ull) {   // no long run before it, or a large step in phi
+                                float s, c;
+                                pr_sincos(inc, &s, &c);
+                                if (exact) rot = make_float2(c, s);
+                            }
+                            chain = in ? pr_cmul(chain, rot) : make_float2(0.f, 0.f);      // :464
+                            const int row = slot + s_;
+                            *reinterpret_cast<float2 *>(SH + (cc * PR_SROWS + row) * 64 + 4 * ((f >> 1) ^ (row & 15)) + 2 * (f & 1)) = chain;
+                            ph += inc;
+                        }
+                    }
+                }
+                phi[0] = pm_wrap(ph);                                           // NaN stays NaN
+                incq[0] = incp;
+                rbq[0] = rBp;
+            }
+            __syncthreads();
+            // ---- (2) the products, chunk by chunk.  (A v_mfma_f32_16x16x4_f32 keeps the SIMD's vector unit for its 32 cycles:
+            // SQ_VALU_MFMA_COEXEC_CYCLES = 0, and a timing-only build without the MFMAs is faster by exactly their pipe time.
+            // Forming the next block's rows between the MFMAs, and a form that writes / reads the next block's operands before
+            // this block's MFMAs are issued, both measured slower than this plain sequence: profiles/r05_ps_runs.txt.)
+#ifdef PR_ABL_NOITEMS
+            if (my_run >= 0 && j == 0 && m == 0) {                              // timing only
+#else
+            if (my_run >= 0) {                                                  // uniform over the wave
+#endif
+#pragma unroll 1
+                for (int c2 = 0; c2 < 8; ++c2) {
+                    if (!alive[c2]) continue;                                   // uniform over the workgroup
+                    const int idx = (p * 8 + c2) * 32 + gf;
+                    const float2 S = TS[idx], rA = TA[idx], rB = TB[idx];
+                    const float2 rA2 = pr_cmul(rA, rA), rB2 = pr_cmul(rB, rB);
+                    float2 cur = hh ? pr_cmul(S, rA) : S;                      // this lane's rows: hh, hh + 2, ...
+                    float2 cb = hh ? rB2 : rB;                                 // ... and steps b = hh, hh + 2, ...: e^{i (b + 1) phi}
+                    float bt[16];
+#pragma unroll
+                    for (int blk = 0; blk < PR_NBLK; ++blk) {
+                        if (blk >= my_nblk) break;                              // uniform
+                        __builtin_amdgcn_wave_barrier();
+#ifndef PR_ABL_NOGEN
+#pragma unroll
+                        for (int jr = 0; jr < PR_ROWS / 2; ++jr) {
+                            const int row = 2 * jr + hh;
+                            *reinterpret_cast<float2 *>(AT + row * 64 + 4 * ((gf >> 1) ^ row) + 2 * (gf & 1)) = cur;
+                            cur = pr_cmul(cur, rA2);
+                        }
+                        if (blk == 0) {
+#pragma unroll
+                            for (int jb = 0; jb < PR_TT / 2; ++jb) {
+                                const int b = 2 * jb + hh;
+                                *reinterpret_cast<float2 *>(BT + ((gf >> 1) * 8 + (b ^ ((gf >> 1) & 7))) * 4 + 2 * (gf & 1)) = cb;
+                                cb = pr_cmul(cb, rB2);
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+#endif
+                        pr_float4 a4[4];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int jp = 4 * g + kk;                          // frequency pair of this lane's K slot
+#ifdef PR_ABL_NOGEN
+                            a4[g] = pr_float4{cur.x, cur.y, cb.x, cb.y};         // timing only: no LDS round trip
+#else
+                            a4[g] = *reinterpret_cast<const pr_float4 *>(AT + orow * 64 + 4 * (jp ^ orow));
+#endif
+                        }
+                        if (blk == 0) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int jp = 4 * g + kk;
+                                // (c0, s0, c1, s1) of the pair at step ob; against (S_re, S_im) the column (b, re) holds (c, -s),
+                                // the column (b, im) holds (s, c)
+#ifdef PR_ABL_NOGEN
+                                const pr_float4 b4 = pr_float4{rB.x, rB.y, rB2.x, rB2.y};
+#else
+                                const pr_float4 b4 = *reinterpret_cast<const pr_float4 *>(BT + (jp * 8 + (ob ^ (jp & 7))) * 4);
+#endif
+                                bt[4 * g + 0] = onc ? b4.y : b4.x;
+                                bt[4 * g + 1] = onc ? b4.x : -b4.y;
+                                bt[4 * g + 2] = onc ? b4.w : b4.z;
+                                bt[4 * g + 3] = onc ? b4.z : -b4.w;
+                            }
+                        }
+                        // two accumulators per block in turn: a v_mfma_f32_16x16x4_f32 that waits for its predecessor's sum
+                        // waits 40 cycles, the pipe takes one every 32
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+#ifdef PR_ABL_NOMFMA
+                            acc[blk][0][g] += a4[g].x * bt[4 * g + 0] + a4[g].y * bt[4 * g + 1];      // timing only: the operands stay live
+                            acc[blk][1][g] += a4[g].z * bt[4 * g + 2] + a4[g].w * bt[4 * g + 3];
+#else
+                            acc[blk][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].x, bt[4 * g + 0], acc[blk][0], 0, 0, 0);
+                            acc[blk][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].y, bt[4 * g + 1], acc[blk][1], 0, 0, 0);
+                            acc[blk][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].z, bt[4 * g + 2], acc[blk][0], 0, 0, 0);
+                            acc[blk][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].w, bt[4 * g + 3], acc[blk][1], 0, 0, 0);
+#endif
+                        }
+                    }
+                }
+            }
+            // the stage's single steps: a quarter of the frequencies of every chunk per wave (their sums are added at the
+            // end of the stage)
+            if (nshort > 0) {
+                const float e0 = orow == 0 ? 1.f : 0.f, e1 = orow == 1 ? 1.f : 0.f;       // column 0 = sum of re, column 1 = sum of im
+#pragma unroll 1
+                for (int c2 = 0; c2 < 8; ++c2) {
+                    if (!alive[c2]) continue;                                   // uniform over the workgroup
+                    const float *St = SH + c2 * PR_SROWS * 64;
+                    const int jp = 4 * p + kk;                                  // frequency pairs 4 p .. 4 p + 3: this wave's share
+                    const pr_float4 a4 = *reinterpret_cast<const pr_float4 *>(St + orow * 64 + 4 * (jp ^ orow));
+                    accs = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, e0, accs, 0, 0, 0);
+                    accs = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, e1, accs, 0, 0, 0);
+                    accs = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, e0, accs, 0, 0, 0);
+                    accs = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, e1, accs, 0, 0, 0);
+                }
+            }
+            __syncthreads();                    // the stage's tables are re-written by the next super-chunk
+            // rotate this thread's frequencies: the next super-chunk's comes to the front
+            {
+                const double p0 = phi[0], r0 = rw[0], w0 = wdt[0], i0 = incq[0];
+                const float2 f0 = F[0], b0 = rbq[0];
+#pragma unroll
+                for (int i = 0; i + 1 < PR_NM; ++i) {
+                    phi[i] = phi[i + 1];
+                    rw[i] = rw[i + 1];
+                    wdt[i] = wdt[i + 1];
+                    incq[i] = incq[i + 1];
+                    F[i] = F[i + 1];
+                    rbq[i] = rbq[i + 1];
+                }
+                phi[PR_NM - 1] = p0;
+                rw[PR_NM - 1] = r0;
+                wdt[PR_NM - 1] = w0;
+                incq[PR_NM - 1] = i0;
+                F[PR_NM - 1] = f0;
+                rbq[PR_NM - 1] = b0;
+            }
+        }
+        // ---- the stage's sums over this part's frequencies.  Accumulator register e of lane l: row 4 (l >> 4) + e, column l & 15
+        if (my_run >= 0) {
+            const PrRun *R = Q.runs + my_run;
+            const int start = R->start, len = R->len;
+#pragma unroll
+            for (int blk = 0; blk < PR_NBLK; ++blk) {
+                if (blk >= my_nblk) break;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int rel = PR_TT * (PR_ROWS * blk + 4 * kk + e) + ob;
+                    if (rel < len) reinterpret_cast<float *>(out + start + rel)[onc] = (acc[blk][0][e] + acc[blk][1][e]) * scale;
+                }
+            }
+        }
+        if (nshort > 0) {
+            // the four waves' shares of the single-step sums, added in a fixed order through LDS (the waves' state tiles are
+            // free: every wave is past its last block)
+            float *red = SH + 8 * PR_SROWS * 64;                               // = the first wave's state tile: 4 x 64 x 4 floats
+            __syncthreads();
+            *reinterpret_cast<pr_float4 *>(red + (p * 64 + lane) * 4) = accs;
+            __syncthreads();
+            if (p == 0 && orow < 2) {
+                pr_float4 t = *reinterpret_cast<const pr_float4 *>(red + lane * 4);
+#pragma unroll
+                for (int q = 1; q < PR_LONGS; ++q) {
+                    const pr_float4 u = *reinterpret_cast<const pr_float4 *>(red + (q * 64 + lane) * 4);
+                    t = t + u;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = 4 * kk + e;
+                    if (row < nshort) reinterpret_cast<float *>(out + st->short_tau[row])[orow] = t[e] * scale;
+                }
+            }
+            __syncthreads();                    // (the tile is written again by the next stage's first block)
+        }
+    }
+}

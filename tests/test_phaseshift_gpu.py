@@ -226,6 +226,8 @@ def test_config5_size_spot_wavenumbers_per_step_profiles_and_many_layers(hip, pr
     kernel = json.loads(buf.value.decode())['kernel']
     if profile != 'layers41':
         assert kernel == ('ps_smooth32_kernel' if dtype == np.float32 else 'ps_smooth_kernel'), kernel
+    elif dtype == np.float32:
+        assert kernel == 'ps_runs_kernel', kernel
     del data
     assert np.isfinite(out).all()
     got = np.fft.fft(out.astype(np.float64), axis=1)[:, _SPOT_KS]
@@ -311,9 +313,76 @@ def test_matrix_core_path_against_the_vector_kernels_and_the_oracle(hip, monkeyp
     assert rel_l2(outs['1', '1'], want) < max(5.0 * rel_l2(outs['0', '1'], want), 2e-6)
 
 
+@pytest.mark.parametrize('snum,tnum', [(520, 33), (700, 24), (1100, 40), (2100, 16), (4200, 6)])
+@pytest.mark.parametrize('kind', ['layers13', 'layers40', 'uneven', 'boundary', 'slowing', 'thick'])
+def test_many_runs_matrix_core_path_against_the_vector_kernels_and_the_oracle(hip, monkeypatch, snum, tnum, kind):
+    """float32 data with MANY layers of constant velocity (what getVelocityProfile, mig_python.py:582-604, makes of a table
+    of N rows: N - 1 layers, every boundary smeared over single steps): ps_runs_kernel -- 8-step tiles against float32
+    matrix-core products, phases generated in the kernel, single steps as rows of their own, partial images per 1024
+    frequencies (4200 samples: 4 parts).  Held to the oracle at the float32 bar; against the vector kernels
+    (IMPDAR_PS_MFMA=0); with the reference's walk over all frequencies; the metrics line names the kernel.  Tables: equal
+    layers, layers of very different thickness (long runs are cut into pieces of <= 512 steps), a first layer at 1.68e8
+    m/s that puts frequencies exactly on the evanescent boundary, a velocity that FALLS with depth (frequencies once
+    evanescent stay out: :484-485), two thick layers (IMPDAR_PS_MFMA=3 asks for this kernel where ps_mfma_kernel would
+    take the call)."""
+    import ctypes as C
+    import json
+    from impdar_amd import _hip, synth
+    from impdar_amd.lib.RadarData import RadarData
+    from impdar_amd.lib import migrationlib
+    from oracle import mig_oracle
+    geo = synth.geometry(snum, tnum)
+    data = (synth.noise_radargram(snum, tnum, seed=snum + 1) + 0.5).astype(np.float32)
+    Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+    lin = lambda n, v0, v1: np.stack([np.linspace(v0, v1, n), np.linspace(0., 1.3 * Rp, n)], axis=1)
+    vel = {'layers13': lin(13, 1.69e8, 2.1e8), 'layers40': lin(40, 1.68e8, 1.9e8),
+           'uneven': np.array([[1.6e8, 0.], [1.6e8, 0.02 * Rp], [1.66e8, 0.05 * Rp], [1.75e8, 0.61 * Rp], [1.78e8, 0.63 * Rp],
+                               [1.82e8, 0.83 * Rp], [1.86e8, 0.9 * Rp], [1.9e8, 1.3 * Rp]]),
+           'boundary': np.concatenate([[[1.68e8, 0.]], lin(9, 1.68e8, 1.95e8) + [[0., 0.3 * Rp]] * 9])[:, :],
+           'slowing': lin(11, 2.1e8, 1.7e8),
+           'thick': np.array([[1.69e8, 0.], [1.69e8, 0.5 * Rp], [1.9e8, 1.3 * Rp]])}[kind]
+    want = mig_oracle.phase_shift(data.astype(np.float64), geo['dt'], geo['trace_int'], geo['travel_time'],
+                                  geo['dist'], vel, 20, 30)
+    outs, kernels = {}, {}
+    for mfma, herm in (('3', '1'), ('0', '1'), ('3', '0')):
+        monkeypatch.setenv('IMPDAR_PS_MFMA', mfma)
+        monkeypatch.setenv('IMPDAR_PS_HERMITIAN', herm)
+        d = RadarData(None)
+        d.data, d.snum, d.tnum = data.copy(), snum, tnum
+        d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
+        migrationlib.migrationPhaseShift(d, vel=vel, htaper=20, vtaper=30)
+        outs[mfma, herm] = d.data
+        buf = C.create_string_buffer(1024)
+        _hip.check(_hip.load().impdar_ctx_last_metrics(_hip.context(), buf, len(buf)), 'metrics')
+        kernels[mfma, herm] = json.loads(buf.value.decode())['kernel']
+        assert rel_l2(d.data, want) < F32_L2, (mfma, herm, kernels[mfma, herm], rel_l2(d.data, want))
+    print('%s %dx%d: rel L2 vs oracle: %s %.2e, %s %.2e, full walk %.2e'
+          % (kind, snum, tnum, kernels['3', '1'], rel_l2(outs['3', '1'], want), kernels['0', '1'], rel_l2(outs['0', '1'], want),
+             rel_l2(outs['3', '0'], want)))
+    assert kernels['3', '1'] == 'ps_runs_kernel' and kernels['3', '0'] == 'ps_runs_kernel' and kernels['0', '1'] != 'ps_runs_kernel', kernels
+    assert rel_l2(outs['3', '1'], outs['0', '1']) < F32_L2
+    # the matrix-core result must not be worse than a few times the vector kernels' own float32 error
+    assert rel_l2(outs['3', '1'], want) < max(5.0 * rel_l2(outs['0', '1'], want), 3e-6)
+    # by itself the library picks one of the two matrix-core kernels (this one for more than 16 long runs)
+    monkeypatch.delenv('IMPDAR_PS_MFMA')
+    monkeypatch.delenv('IMPDAR_PS_HERMITIAN')
+    d = RadarData(None)
+    d.data, d.snum, d.tnum = data.copy(), snum, tnum
+    d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
+    migrationlib.migrationPhaseShift(d, vel=vel, htaper=20, vtaper=30)
+    buf = C.create_string_buffer(1024)
+    _hip.check(_hip.load().impdar_ctx_last_metrics(_hip.context(), buf, len(buf)), 'metrics')
+    chosen = json.loads(buf.value.decode())['kernel']
+    # (up to 16 long runs: ps_mfma_kernel where its 2048-step row blocks are not mostly padding, i.e. on long records)
+    assert chosen in ('ps_runs_kernel', 'ps_mfma_kernel'), (kind, chosen)
+    assert chosen == 'ps_runs_kernel' or kind not in ('layers40',), (kind, chosen)
+    if chosen == 'ps_runs_kernel':
+        assert np.array_equal(d.data, outs['3', '1'])
+
+
 def test_matrix_core_path_leaves_many_short_runs_to_the_vector_kernels(hip, monkeypatch):
-    """A table of 40 thin layers (rows of 32 tiles would be mostly padding) and a spectrum too short for the
-    32-frequency chunks keep the vector kernels; the answer is the same either way."""
+    """A table of 40 thin layers (ps_mfma_kernel's rows of 32 tiles would be mostly padding: ps_runs_kernel takes it since
+    round 5, the vector kernels with IMPDAR_PS_MFMA=0); the answer is the same either way."""
     from impdar_amd import synth
     from impdar_amd.lib.RadarData import RadarData
     from impdar_amd.lib import migrationlib
