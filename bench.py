@@ -203,9 +203,97 @@ def pmc_child_path(path, calls):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# parity of the 8192 x 8192 phase-shift sub-records: the oracle on a few wavenumbers, in CPU-only child processes that run
+# beside the GPU legs (wavenumbers are independent in phaseShift, mig_python.py:438-487: tests/test_phaseshift_gpu.py)
+# ---------------------------------------------------------------------------------------------------------
+SPOT_KS = (0, 37, 200, 4096)          # zero, low, one that holds a frequency ON the evanescent boundary of 1.69e8 m/s, Nyquist
+SPOT_KINDS = ('vz4', 'const', 'layers41', 'gradient', 'gradient_f64')
+
+
+def gazdag_velocity(kind, geo, n):
+    """What the sub-record `kind` migrates with: a scalar, a (v, z) table or a per-step profile of length n."""
+    Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+    if kind == 'vz4':
+        return np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rp], [1.8e8, 0.5 * Rp], [1.9e8, 1.2 * Rp]])
+    if kind == 'const':
+        return 1.69e8
+    if kind == 'layers41':
+        return np.stack([np.linspace(1.69e8, 2.2e8, 41), np.linspace(0., 2.0 * Rp, 41)], axis=1)
+    assert kind.startswith('gradient')
+    return np.ascontiguousarray(1.69e8 + 0.5e8 * np.linspace(0., 1., n))      # changes at every step: no runs of constant velocity
+
+
+def config5_radargram():
+    """The 8192 x 8192 float32 white-noise radargram of path_records (second draw of its generator)."""
+    rng = np.random.default_rng(0)
+    rng.standard_normal((4096, 4096))
+    return rng.standard_normal((8192, 8192)).astype(np.float32)
+
+
+def spot_dft(n):
+    ks = np.array(SPOT_KS)
+    cols = np.concatenate([ks, (n - ks) % n])
+    return ks, cols, np.exp(-2j * np.pi * np.outer(np.arange(n), cols) / n)
+
+
+def spot_oracle_child(kind, out_path):
+    """`bench.py --spot-oracle KIND OUT`: CPU only.  fft_x(Re ifft_k TK)[k] = (TK[k] + conj(TK[-k])) / 2 on SPOT_KS."""
+    from impdar_amd import synth
+    from oracle import mig_oracle
+    n = 8192
+    geo = synth.geometry(n, n)
+    x = config5_radargram()
+    f64 = kind.endswith('_f64')
+    tap = mig_oracle._apply_taper(x.astype(np.float64) if f64 else x, 100, 1000, inplace_form=True)
+    tap = np.asarray(tap, dtype=np.float64 if f64 else np.float32).astype(np.float64)
+    ks, cols, E = spot_dft(n)
+    FKc = np.fft.fft(tap @ E.real + 1j * (tap @ E.imag), n=n, axis=0)       # (nt, len(cols)): the 2-D spectrum's columns
+    kx = mig_oracle._kx(n, geo['trace_int'], geo['dist'])[cols]
+    ws = 2. * np.pi * np.fft.fftfreq(n, d=geo['dt'])
+    vel = gazdag_velocity(kind, geo, n)
+    vmig = vel if np.ndim(vel) == 0 else (vel if np.ndim(vel) == 1 else mig_oracle.get_velocity_profile(geo['travel_time'], vel))
+    TK = mig_oracle.phase_shift_tk(FKc, vmig, kx, ws, geo['dt'], geo['travel_time'], n, len(cols))
+    np.save(out_path, 0.5 * (TK[:, :len(ks)] + np.conj(TK[:, len(ks):])))
+
+
+def start_spot_oracles():
+    """One child per kind (about 15 s of one core each); returns {kind: (Popen, path)}."""
+    tmp = tempfile.mkdtemp(prefix='impdar_spot_', dir='/tmp')
+    procs = {}
+    for kind in SPOT_KINDS:
+        out = os.path.join(tmp, kind + '.npy')
+        procs[kind] = (subprocess.Popen([sys.executable, os.path.abspath(__file__), '--spot-oracle', kind, out],
+                                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                        env=dict(os.environ, OMP_NUM_THREADS='8', OPENBLAS_NUM_THREADS='8')), out)
+    return procs
+
+
+def spot_parity(img, spot, kind, bar):
+    """rel-L2 of the image's spot wavenumbers against the child's oracle columns (None when the child failed)."""
+    if not spot or kind not in spot:
+        return {"error": "no oracle child"}
+    proc, path = spot[kind]
+    try:
+        proc.wait(timeout=120)
+        want = np.load(path)
+    except Exception as exc:
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
+    n = img.shape[1]
+    ks, cols, E = spot_dft(n)
+    a = np.asarray(img, dtype=np.float64)
+    got = a @ E.real[:, :len(ks)] + 1j * (a @ E.imag[:, :len(ks)])
+    err = float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-300))
+    rec = {"parity_rel_l2": err, "parity_wavenumbers": list(SPOT_KS), "parity_bar": bar,
+           "parity_vs": "oracle/mig_oracle.py phase_shift_tk on the (k, -k) columns of the 2-D spectrum, CPU child process"}
+    if not err <= bar:
+        rec["error"] = "spot wavenumbers differ from the oracle"
+    return rec
+
+
+# ---------------------------------------------------------------------------------------------------------
 # secondary paths, driver-timed: BASELINE configs 2 (Stolt) and 5 (Gazdag v(z)), config 3 in float64
 # ---------------------------------------------------------------------------------------------------------
-def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None):
+def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None, spot=None):
     import contextlib
     import io
     import ctypes as C
@@ -238,8 +326,12 @@ def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None):
                 _hip.check(lib.impdar_ctx_last_kernel_ms(ctx, C.byref(v)), 'impdar_ctx_last_kernel_ms')
                 kms.append(v.value)
             if i == reps:
+                buf = C.create_string_buffer(1024)
+                _hip.check(lib.impdar_ctx_last_metrics(ctx, buf, len(buf)), 'metrics')
+                device_ms.metrics = json.loads(buf.value.decode())
                 d.from_device()
                 fin = bool(np.isfinite(d.data).all())
+                device_ms.image = d.data
             else:
                 d._dev.free()
                 d._dev = None
@@ -313,14 +405,19 @@ def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None):
     #                                                      for their mirror images too, + the Nyquist row (Hermitian walk)
     flop = steps * 8                                     # 8 flop per complex multiply-accumulate
     tf = flop / (kms * 1e-3) / 1e12
+    # MFMA instructions the kernel issued, counted by the kernel itself (rounds and row blocks it skips -- all-evanescent
+    # chunks -- are not in it): x 32768 flop per v_mfma_f32_32x32x16_f16
+    mm = getattr(device_ms, 'metrics', {})
+    mfma_flop = float(mm.get('mfma_instructions', 0)) * float(mm.get('flop_per_mfma', 0)) or None
+    par5 = spot_parity(device_ms.image, spot, 'vz4', 2e-4)
     rec = {"workload": "phase-shift (Gazdag) migration, 1-D v(z) table, 8192x8192 float32 (BASELINE config 5), "
                        "resident in HBM",
            "device_ms": ms, "kernel_ms": kms, "call_ms": wall * 1e3, "traces_per_s": n / (ms * 1e-3), "output_finite": fin,
            "rotate_accumulate_steps": steps_ref, "steps_executed": steps,
            "roofline": {"bound": "mfma", "achieved": tf, "peak": FP16_MFMA_PEAK_TF, "unit": "TFLOP/s",
                         "frac": tf / FP16_MFMA_PEAK_TF, "algorithmic_flop": flop,
-                        "mfma_flop_executed": 3.0 * flop,
-                        "frac_executed": 3.0 * tf / FP16_MFMA_PEAK_TF,
+                        "mfma_flop_executed": mfma_flop,
+                        "frac_executed": (mfma_flop / (kms * 1e-3) / 1e12 / FP16_MFMA_PEAK_TF) if mfma_flop else None,
                         "x_fp32_vector_peak": tf / FP32_VECTOR_PEAK_TF,
                         "frac_device_ms": flop / (ms * 1e-3) / 1e12 / FP16_MFMA_PEAK_TF,
                         "x_fp32_vector_peak_device_ms": flop / (ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TF,
@@ -331,7 +428,10 @@ def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None):
                                 "units; device_ms also holds the real-to-complex and trace transforms, the inverse "
                                 "transform and the transposes; kernel_ms includes ps_setup_kernel and the host-side "
                                 "synchronisation inside the matrix-core path; frac_device_ms / x_fp32_vector_peak_device_ms "
-                                "are the same flop over device_ms (the basis rounds 1-2 reported)"}}
+                                "are the same flop over device_ms (the basis rounds 1-2 reported); mfma_flop_executed = the "
+                                "kernel's own count of issued MFMAs x 32768"}}
+    rec.update(par5)
+    rec["kernel"] = mm.get('kernel')
     e2e = host_call_ms(lambda d: d.migrate('phsh', vel=tab, htaper=100, vtaper=1000), lambda: dat_of(x, geo), reps=2)
     rec["end_to_end"] = {"wall_ms": e2e, "value": n / (e2e * 1e-3), "unit": "traces/s",
                          "note": "RadarData.migrate('phsh', vel=table) on a host float32 array: getVelocityProfile + H2D + "
@@ -366,6 +466,63 @@ def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None):
                      "note": "8 flop per needed complex rotate-accumulate (half walk) over kernel_ms against the float64 "
                              "vector peak; 42 % of the (kx, w) plane is evanescent and skipped pair-wise (DESIGN 11.7)"}}
     del x64
+    # ---- the other velocity structures at config-5 size (figures the builder alone had measured)
+    def ps_dev(data, vel, reps=2):
+        """impdar_phaseshift_dev on a resident radargram with a scalar / per-step velocity: (device ms, kernel ms, image, metrics)."""
+        from oracle import mig_oracle as mo
+        kx = mo._kx(n, geo['trace_int'], geo['dist'])
+        ws = 2. * np.pi * np.fft.fftfreq(n, d=geo['dt'])
+        tt = np.ascontiguousarray(geo['travel_time'], dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        vm = None if np.ndim(vel) == 0 else np.ascontiguousarray(vel, dtype=np.float64)
+        d_in = _hip.DeviceArray.from_host(ctx, data)
+        d_out = _hip.DeviceArray(ctx, d_in.shape, d_in.dtype)
+        ms_, kms_ = [], []
+        for _ in range(reps + 1):
+            _hip.check(lib.impdar_phaseshift_dev(ctx, d_in.ptr, _hip.dtype_code(data.dtype), n, n, n, kx.ctypes.data_as(dp),
+                                                 ws.ctypes.data_as(dp), C.c_double(geo['dt']), tt.ctypes.data_as(dp),
+                                                 C.c_double(float(vel) if vm is None else 0.0),
+                                                 vm.ctypes.data_as(dp) if vm is not None else None, 0 if vm is None else n,
+                                                 C.c_double(100.), C.c_double(1000.), d_out.ptr), 'impdar_phaseshift_dev')
+            v = C.c_float()
+            _hip.check(lib.impdar_ctx_last_ms(ctx, C.byref(v)), 'impdar_ctx_last_ms')
+            ms_.append(v.value)
+            _hip.check(lib.impdar_ctx_last_kernel_ms(ctx, C.byref(v)), 'impdar_ctx_last_kernel_ms')
+            kms_.append(v.value)
+        buf = C.create_string_buffer(1024)
+        _hip.check(lib.impdar_ctx_last_metrics(ctx, buf, len(buf)), 'metrics')
+        img = d_out.to_host()
+        d_in.free()
+        d_out.free()
+        return float(np.median(ms_[1:])), float(np.median(kms_[1:])), img, json.loads(buf.value.decode())
+
+    def gazdag_extra(name, kind, data, bound, peak, bar, what):
+        from oracle import mig_oracle as mo
+        vel = gazdag_velocity(kind, geo, n)
+        if np.ndim(vel) == 2:
+            vel = mo.get_velocity_profile(geo['travel_time'], vel)           # what getVelocityProfile hands to phaseShift (:278)
+        ms_, kms_, img, met = ps_dev(data, vel)
+        tf_ = flop / (kms_ * 1e-3) / 1e12
+        r = {"workload": "phase-shift migration, %s, 8192x8192 %s, resident in HBM" % (what, data.dtype.name),
+             "kernel": met.get('kernel'), "device_ms": ms_, "kernel_ms": kms_, "traces_per_s": n / (ms_ * 1e-3),
+             "output_finite": bool(np.isfinite(img).all()), "steps_executed": steps,
+             "roofline": {"bound": bound, "achieved": tf_, "peak": peak, "unit": "TFLOP/s", "frac": tf_ / peak, "algorithmic_flop": flop,
+                          "note": "8 flop per needed complex rotate-accumulate (half walk, evanescent pairs included) over kernel_ms"}}
+        if met.get('mfma_instructions'):
+            ex = float(met['mfma_instructions']) * float(met['flop_per_mfma'])
+            r["roofline"]["mfma_flop_executed"] = ex
+            r["roofline"]["frac_executed"] = ex / (kms_ * 1e-3) / 1e12 / peak
+        r.update(spot_parity(img, spot, kind, bar))
+        out[name] = r
+
+    gazdag_extra("gazdag_const_config5", 'const', x, "mfma", FP16_MFMA_PEAK_TF, 2e-4, "constant velocity 1.69e8 m/s (mig_python.py:396-420)")
+    gazdag_extra("gazdag_layers41_config5", 'layers41', x, "mfma_f32", FP32_VECTOR_PEAK_TF, 2e-4,
+                 "41-row (v, z) table: 40 layers of ~200 steps, every boundary smeared over single steps "
+                 "(ps_runs_kernel: float32 MFMA at the vector rate, 157.3 TFLOP/s)")
+    gazdag_extra("gazdag_smooth_config5", 'gradient', x, "fp32 vector", FP32_VECTOR_PEAK_TF, 2e-4,
+                 "velocity changing at EVERY step (linear gradient 1.69e8 -> 2.19e8 m/s) through the C entry point")
+    gazdag_extra("gazdag_smooth_f64_config5", 'gradient_f64', x.astype(np.float64), "fp64 vector", FP64_VECTOR_PEAK_TF, 1e-10,
+                 "velocity changing at EVERY step (linear gradient), float64 data")
     del x
 
     # ---- config 3 in the reference's own arithmetic: float64 data, kirch_dquad_kernel (mig_python.py:53,118 sum in float64)
@@ -543,10 +700,14 @@ def main():
     ap.add_argument('--no-e2e', action='store_true', help='skip the PCIe-inclusive one-shot figure')
     ap.add_argument('--cpu-budget', type=float, default=15.0)
     ap.add_argument('--first-call', default=None, choices=['kirch', 'stolt', 'phsh'], help=argparse.SUPPRESS)
+    ap.add_argument('--spot-oracle', nargs=2, default=None, metavar=('KIND', 'OUT'), help=argparse.SUPPRESS)
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--pmc-child-path', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--data-child', default='zeros', choices=['zeros', 'synthetic'], help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.spot_oracle:
+        spot_oracle_child(*args.spot_oracle)
+        return
     if args.pmc_child_path:
         pmc_child_path(args.pmc_child_path, args.steps)
         return
@@ -579,6 +740,10 @@ def main():
         t0 = time.time()
         first_calls = first_call_records()
         log('[bench] first-call children took %.1f s' % (time.time() - t0))
+    # the CPU oracle of the 8192^2 phase-shift sub-records' spot wavenumbers: child processes beside everything below
+    spot = None
+    if rank == 0 and world == 1 and not args.no_paths and not args.no_cpu and not args.pmc_child:
+        spot = start_spot_oracles()
 
     from impdar_amd import _hip, parallel, synth
     np_dtype = np.float32 if args.dtype == 'f32' else np.float64
@@ -836,7 +1001,7 @@ def main():
         if not args.no_paths:
             t0 = time.time()
             try:
-                res["paths"] = path_records(args.no_cpu, args.no_pmc, full_data, geo)
+                res["paths"] = path_records(args.no_cpu, args.no_pmc, full_data, geo, spot)
             except Exception as exc:                      # a sub-record must not take the headline down
                 res["paths"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             log('[bench] config-2 / config-5 sub-records took %.1f s' % (time.time() - t0))

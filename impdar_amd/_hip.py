@@ -67,6 +67,7 @@ SIGNATURES = {
     'impdar_kirch_count_pairs': (C.c_longlong, [_p, _i, _i]),
     'impdar_stolt': (_i, [_p, _p, _i, _i, _i, _dp, _dp, _d, _d, _d, _p]),
     'impdar_stolt_dev': (_i, [_p, _p, _i, _i, _i, _dp, _dp, _d, _d, _d, _p]),
+    'impdar_fft_rows_dev': (_i, [_p, _i, _i, _i, _i, _p, _p, _d]),
     'impdar_phaseshift': (_i, [_p, _p, _i, _i, _i, _i, _dp, _dp, _d, _dp, _d, _dp, _i, _d, _d, _p]),
     'impdar_phaseshift_dev': (_i, [_p, _p, _i, _i, _i, _i, _dp, _dp, _d, _dp, _d, _dp, _i, _d, _d, _p]),
     'impdar_phaseshift_tk_dev': (_i, [_p, _p, _i, _i, _i, _i, _dp, _dp, _d, _dp, _d, _dp, _i, _d, _d, _i, _i, _p]),

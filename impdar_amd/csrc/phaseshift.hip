@@ -19,6 +19,8 @@
 // followed by one LDS pass across the waves, so each workgroup emits 128-byte
 // contiguous runs of TK_T[k][tau].
 #include "fft.h"
+#include "own_fft.h"
+#include <atomic>
 #include <algorithm>
 #include <mutex>
 #include <type_traits>
@@ -1299,6 +1301,16 @@ __global__ __launch_bounds__(256) void ps_dc_kernel(const Cp<T> *__restrict__ F,
 #include "ps_mfma.h"
 
 struct PsPlan {
+    // the rocFFT plans of the Hermitian rows form being made by a thread of their own while the first call runs on the
+    // library's own transforms (own_fft.h): 0 none, 1 running, 2 made, 3 failed
+    std::thread bg;
+    std::atomic<int> bg_state{0};
+    OwnTwiddles tw_time, tw_trace;
+    void bg_join()
+    {
+        if (bg.joinable()) bg.join();
+    }
+    ~PsPlan() { bg_join(); }
     int dtype = -1, snum = 0, tnum = 0, nt = 0;
     const impdar_ctx *owner = nullptr;   // plans and buffers live on this context's device and stream
     FftPlan f_time, f_trace, b_trace;
@@ -1315,6 +1327,8 @@ struct PsPlan {
     DevBuf d_sendbuf, d_slab;            // ... packed blocks of the all-to-all; the transposed slab
     DevBuf d_blocks, d_edge, d_runtab;   // matrix-core path: row-block table; boundary-frequency counts + lists; per-run phases
     DevBuf d_pr_runs, d_pr_stages, d_rw; // many-runs matrix-core path (ps_runs.h): runs, stages, 1 / w
+    DevBuf d_mcount;                     // matrix-core paths: MFMA instructions the kernel issued (one 64-bit counter)
+    double mfma_instructions = -1.0;     // ... of the last call (-1: not a matrix-core call)
     // a (kx, runs) geometry whose boundary-frequency lists overflowed in a matrix-core path: not tried again
     std::vector<double> ovf_kx;
     std::vector<PsMfmaRun> ovf_runs;
@@ -1506,7 +1520,7 @@ static int ps_runs_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
     for (int i = 0; i < P.nf; ++i) rw[i] = 1.0 / w_host[i];
     if (pl.d_pr_runs.ensure(pr.size() * sizeof(PrRun)) != hipSuccess || pl.d_pr_stages.ensure(stages.size() * sizeof(PrStage)) != hipSuccess ||
         pl.d_rw.ensure(rw.size() * 8) != hipSuccess || pl.d_edge.ensure((size_t)tnum * (1 + PM_EMAX) * sizeof(int)) != hipSuccess ||
-        (part_bytes && pl.d_part.ensure(part_bytes) != hipSuccess)) {
+        (part_bytes && pl.d_part.ensure(part_bytes) != hipSuccess) || pl.d_mcount.ensure(8) != hipSuccess) {
         (void)hipGetLastError();
         return IMPDAR_OK;                      // no room: the other paths take the call
     }
@@ -1524,7 +1538,9 @@ static int ps_runs_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
     Q.part = pl.d_part.p;
     Q.edge_cnt = pl.d_edge.as<int>();
     Q.edge_list = Q.edge_cnt + tnum;
+    Q.mfma_count = pl.d_mcount.as<unsigned long long>();
     IMPDAR_HIP_CHECK(hipMemsetAsync(Q.edge_cnt, 0, (size_t)tnum * sizeof(int), st));
+    IMPDAR_HIP_CHECK(hipMemsetAsync(Q.mfma_count, 0, 8, st));
     IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PR_LDS_BYTES));
     hipLaunchKernelGGL(ps_runs_kernel, dim3((unsigned)P.nk * nparts), dim3(256), PR_LDS_BYTES, st, Q);
     if (nparts > 1) {
@@ -1534,6 +1550,7 @@ static int ps_runs_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
     }
     {
         PsMfmaParams E;                        // (ps_edge_kernel reads P and the lists only)
+        E.mfma_count = nullptr;
         E.P = P;
         E.nruns = 0;
         E.edge_cnt = Q.edge_cnt;
@@ -1550,6 +1567,11 @@ static int ps_runs_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
     if (worst > PM_EMAX) {
         ps_note_overflow(pl, kx_host, tnum, runs);
         return IMPDAR_OK;                      // contributions missing from TK: discarded, another path produces the result
+    }
+    {
+        unsigned long long n = 0;
+        IMPDAR_HIP_CHECK(hipMemcpy(&n, Q.mfma_count, 8, hipMemcpyDeviceToHost));
+        pl.mfma_instructions = (double)n;
     }
     *done = true;
     return IMPDAR_OK;
@@ -1617,7 +1639,8 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
             return IMPDAR_OK;                  // would take more than half of what is free: leave it to the vector kernels
         }
         if (pl.d_blocks.ensure(table.size() * sizeof(int2)) != hipSuccess ||
-            pl.d_edge.ensure((size_t)tnum * (1 + PM_EMAX) * sizeof(int)) != hipSuccess || pl.d_runtab.ensure(rt_bytes) != hipSuccess) {
+            pl.d_edge.ensure((size_t)tnum * (1 + PM_EMAX) * sizeof(int)) != hipSuccess || pl.d_runtab.ensure(rt_bytes) != hipSuccess ||
+            pl.d_mcount.ensure(8) != hipSuccess) {
             (void)hipGetLastError();
             return IMPDAR_OK;
         }
@@ -1627,6 +1650,8 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
     Q.edge_cnt = pl.d_edge.as<int>();
     Q.edge_list = Q.edge_cnt + tnum;
     if (vz) IMPDAR_HIP_CHECK(hipMemsetAsync(Q.edge_cnt, 0, (size_t)tnum * sizeof(int), st));
+    Q.mfma_count = pl.d_mcount.as<unsigned long long>();
+    IMPDAR_HIP_CHECK(hipMemsetAsync(Q.mfma_count, 0, 8, st));
     Q.vz = vz ? 1 : 0;
     Q.runtab = pl.d_runtab.as<double2>();
     {
@@ -1655,6 +1680,11 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
         if (worst > PM_EMAX) ps_note_overflow(pl, kx_host, tnum, runs);    // (remembered: not tried again on this geometry)
         if (worst > PM_EMAX || force_overflow) return IMPDAR_OK;           // *done stays false
     }
+    {
+        unsigned long long n = 0;
+        IMPDAR_HIP_CHECK(hipMemcpy(&n, Q.mfma_count, 8, hipMemcpyDeviceToHost));
+        pl.mfma_instructions = (double)n;
+    }
     *done = true;
     return IMPDAR_OK;
 }
@@ -1671,10 +1701,13 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     const bool dbl = sizeof(T) == 8;
     // IMPDAR_PS_FFT=strided: the transforms over the traces / wavenumbers as rocFFT's strided plans on the arrays as
     // they lie (rounds 1-3a); default: transpose, contiguous plan, transpose (see ps_transpose_c)
-    const char *fe = getenv("IMPDAR_PS_FFT");
+    const char *fe = getenv("IMPDAR_PS_FFT");            // strided | own (own_fft.h on every call, no rocFFT plans: tests, A/B)
     const bool rows_form = !(fe && strcmp(fe, "strided") == 0);
+    const bool own_forced = fe && strcmp(fe, "own") == 0;
     if (pl.owner != ctx || pl.dtype != (dbl ? IMPDAR_F64 : IMPDAR_F32) || pl.snum != snum || pl.tnum != tnum || pl.nt != nt ||
         pl.rows_form != rows_form) {
+        pl.bg_join();                        // (a thread still making the old size's plans)
+        pl.bg_state = 0;
         pl.dtype = -1;
         pl.rm_state = -1;
         pl.r_ready = pl.c_ready = false;
@@ -1684,6 +1717,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             pl.d_edge.release();
             pl.d_runtab.release();
             pl.d_pr_runs.release();
+            pl.d_mcount.release();
             pl.d_pr_stages.release();
             pl.d_rw.release();
             pl.d_sendbuf.release();
@@ -1755,7 +1789,45 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         const size_t rows = tk_out ? scratch_rows : std::max<size_t>((size_t)snum, scratch_rows);
         if (rows) IMPDAR_HIP_CHECK(pl.TK.ensure((size_t)tnum * rows * 2 * sizeof(T)));
     }
-    {
+    // A FIRST call on power-of-two sizes runs its transforms on the library's own row kernels while a thread makes the
+    // rocFFT plans (0.25-3 s: their kernels are compiled at run time); later calls use the plans.
+    bool use_own = false;
+    if (herm && pl.rows_form && own_fft_len_ok(nt / 2) && own_fft_len_ok(tnum)) {
+        if (pl.bg_state == 2 || pl.bg_state == 3) {
+            const bool made = pl.bg_state == 2;
+            pl.bg_join();
+            pl.bg_state = 0;
+            if (made) pl.b_ready = pl.r_ready = true;
+            else impdar_trace("phaseshift: the background plans failed (%s): made in the foreground", impdar_last_error());
+        }
+        IMPDAR_HIP_CHECK(pl.Xr.ensure((size_t)tnum * nt * sizeof(T)));
+        if (own_forced) {
+            use_own = true;
+        } else if (!(pl.b_ready && pl.r_ready)) {
+            use_own = true;
+            if (pl.bg_state == 0) {
+                pl.bg_state = 1;
+                const int device = ctx->device;
+                PsPlan *plp = &pl;
+                impdar_trace("phaseshift: first call on the library's own transforms; 3 rocFFT plans on a thread");
+                pl.bg = std::thread([plp, device, tnum, snum, nt, fstride, st] {
+                    const rocfft_array_type ci = rocfft_array_type_complex_interleaved;
+                    int rc = hipSetDevice(device) == hipSuccess ? IMPDAR_OK : IMPDAR_ERR_HIP;
+                    if (!rc) rc = plp->b_trace.create(rocfft_transform_type_complex_inverse, dbl, true, tnum, snum, ci, ci, 1, tnum, 1, tnum, 1.0 / tnum, st);
+                    if (!rc) rc = plp->r_time.create(rocfft_transform_type_real_forward, dbl, false, nt, tnum, rocfft_array_type_real,
+                                                     rocfft_array_type_hermitian_interleaved, 1, nt, 1, fstride, 1.0, st);
+                    if (!rc) rc = plp->r_trace.create(rocfft_transform_type_complex_forward, dbl, true, tnum, fstride, ci, ci, 1, tnum, 1, tnum, 1.0, st);
+                    plp->bg_state = rc ? 3 : 2;
+                });
+            }
+        }
+        if (use_own) {
+            int rc;
+            if ((rc = pl.tw_time.ensure<T>(nt, st)) || (rc = pl.tw_trace.ensure<T>(tnum, st))) return rc;
+        }
+    }
+    if (!use_own) {
+        if (pl.bg_state == 1) pl.bg_join();      // (cannot happen for one size; a thread must not make plans beside the ones below)
         int rc;
         const rocfft_array_type ci = rocfft_array_type_complex_interleaved;
         // the plans this call still lacks, created side by side (run-time compilation: impdar_parallel_plans)
@@ -1813,12 +1885,20 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         // real-to-complex along time: only rows 0 .. nt/2 of the spectrum exist, and only they are walked
         hipLaunchKernelGGL((ps_taper_pad_transpose_real<T>), tgrid, dim3(256), 0, st, (const T *)d_data, pl.Xr.as<T>(), snum,
                            tnum, nt, htaper, vtaper);
-        if ((rc = pl.r_time.exec(pl.Xr.p, pl.X.p))) return rc;
+        if (use_own) {
+            if ((rc = own_fft_launch<T>(OWN_R2C, nt, (size_t)tnum, pl.Xr.p, pl.X.p, (size_t)nt, (size_t)fstride, 1.0, pl.tw_time, st))) return rc;
+        } else if ((rc = pl.r_time.exec(pl.Xr.p, pl.X.p))) {
+            return rc;
+        }
         if (pl.rows_form) {
             // over the traces on contiguous rows: X [x][fstride] -> [fstride][x] (pl.TK is free until the frequency sums
             // write it, and large enough: snum > nt / 2), transform, and back -> X [k][fstride]
             ps_launch_transpose<T>(pl.X.p, pl.TK.p, tnum, fstride, st);
-            if ((rc = pl.r_trace.exec(pl.TK.p, nullptr))) return rc;
+            if (use_own) {
+                if ((rc = own_fft_launch<T>(OWN_C2C_FWD, tnum, (size_t)fstride, pl.TK.p, pl.TK.p, (size_t)tnum, (size_t)tnum, 1.0, pl.tw_trace, st))) return rc;
+            } else if ((rc = pl.r_trace.exec(pl.TK.p, nullptr))) {
+                return rc;
+            }
             ps_launch_transpose<T>(pl.TK.p, pl.X.p, fstride, tnum, st);
             IMPDAR_HIP_CHECK(hipGetLastError());
         } else if ((rc = pl.r_trace.exec(pl.X.p, nullptr))) {
@@ -1960,6 +2040,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     impdar_trace("phaseshift: forward transforms enqueued");
     bool mfma_done = false;
     const char *mfma_kernel_name = "";
+    pl.mfma_instructions = -1.0;
     if constexpr (sizeof(T) == 4) {
         // float32: the frequency sums on the matrix cores when the depth axis is a few long runs of constant velocity
         std::vector<PsMfmaRun> mruns;
@@ -2034,7 +2115,14 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     ctx->m_entry = tk_out ? "impdar_phaseshift_tk_dev" : "impdar_phaseshift";
     ctx->m_kernel = mfma_done ? mfma_kernel_name : t_ps_kernel;
     ctx->m_kernel_ms = -1.f;                 // (bracketed by ktic / ktoc)
-    snprintf(ctx->m_extra, sizeof ctx->m_extra, "\"hermitian_walk\": %s, \"frequencies\": %d", herm ? "true" : "false", nf);
+    if (mfma_done)      // (MFMA instructions the kernel issued, counted by the kernel: rounds and blocks it skips are not in it)
+        snprintf(ctx->m_extra, sizeof ctx->m_extra,
+                 "\"hermitian_walk\": %s, \"frequencies\": %d, \"transforms\": \"%s\", \"mfma_instructions\": %.0f, \"flop_per_mfma\": %d",
+                 herm ? "true" : "false", nf, use_own ? "own" : "rocfft", pl.mfma_instructions,
+                 strcmp(mfma_kernel_name, "ps_runs_kernel") == 0 ? 2048 : 32768);
+    else
+        snprintf(ctx->m_extra, sizeof ctx->m_extra, "\"hermitian_walk\": %s, \"frequencies\": %d, \"transforms\": \"%s\"",
+                 herm ? "true" : "false", nf, use_own ? "own" : "rocfft");
     if (herm)
         for (int kz : k_zero)
             if (kz >= k0 && kz < k0 + nk)
@@ -2051,7 +2139,11 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         // inverse over k on contiguous rows: TK [k][tau] -> [tau][k] (pl.X: the spectrum is not needed any more, and
         // nt >= snum), transform, real part (:282) -- already (snum, tnum)
         ps_launch_transpose<T>(pl.TK.p, pl.X.p, tnum, snum, st);
-        if ((rc = pl.b_trace.exec(pl.X.p, nullptr))) return rc;
+        if (use_own) {
+            if ((rc = own_fft_launch<T>(OWN_C2C_INV, tnum, (size_t)snum, pl.X.p, pl.X.p, (size_t)tnum, (size_t)tnum, 1.0 / tnum, pl.tw_trace, st))) return rc;
+        } else if ((rc = pl.b_trace.exec(pl.X.p, nullptr))) {
+            return rc;
+        }
         const size_t n = (size_t)snum * tnum;
         hipLaunchKernelGGL((ps_real_part<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pl.X.as<Cp<T>>(), (T *)d_out, n);
     } else {

@@ -91,6 +91,7 @@ struct PsMfmaParams {
     int nlong;
     int long_of[PM_MAX_RUNS];   // run -> index among the long runs (-1: short)
     int vz;
+    unsigned long long *mfma_count;     // MFMA instructions issued, summed over the launch (bench.py: mfma_flop_executed)
 };
 
 // coss = 1 - (0.5 v kx / w)^2 (mig_python.py:456) with the division by w as a multiplication by rw = 1/w: one
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
         }
     };
 
+    unsigned nmfma = 0;                     // (uniform) MFMA instructions this wave has issued
     const int nchunk = P.nf / PM_CH;        // a multiple of PM_NQ (host): every wave makes the same number of rounds
     // long-run index of every row block (ps_setup_kernel's table)
     int blong[PM_NRB];
@@ -408,6 +410,7 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
                 }
             }
             const unsigned *Ahi = Aq + (size_t)rb * 2 * PM_TILE, *Alo = Ahi + PM_TILE;
+            nmfma += 3 * (PM_CH / 8);
             uint4 ra_hi = *reinterpret_cast<const uint4 *>(Ahi + rd0), ra_lo = *reinterpret_cast<const uint4 *>(Alo + rd0);
 #pragma unroll
             for (int s = 0; s < PM_CH / 8; ++s) {
@@ -426,6 +429,7 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
         pm_lds_barrier();           // ... and read by everybody before the next round overwrites them
     }
 
+    if (lane == 0 && Q.mfma_count) atomicAdd(Q.mfma_count, (unsigned long long)nmfma);
     // ---- every wave owns its sums outright (all frequencies of its 16 steps): TK /= snum (:492) and store.
     // accumulator register i of lane l: row (i & 3) + 8 (i >> 2) + 4 (l >> 5), column l & 31 = 16 (im ? 1 : 0) + b
     const float scale = 1.0f / (sigma * 256.0f * (float)P.snum);

@@ -68,6 +68,7 @@ struct PrParams {
     int nstages, nruns, nparts;
     void *part;             // [nparts][nk][snum] complex float32 partial images (nparts > 1)
     int *edge_cnt, *edge_list;
+    unsigned long long *mfma_count;     // MFMA instructions issued, summed over the launch (bench.py: mfma_flop_executed)
 };
 
 // sqrt(x), x in [1e-8, 1]: v_rsq_f64 as the seed and ONE Newton step that carries h ~ 1 / (2 y) (relative error of the
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
     const int orow = lane & 15, kk = lane >> 4;      // MFMA operand roles: row (A) / column (B), K slot
     const int ob = orow >> 1, onc = orow & 1;        // ... the column's step and component
 
+    unsigned nmfma = 0;                              // (uniform) MFMA instructions this wave has issued
     for (int j = 0; j < Q.nstages; ++j) {
         const PrStage *st = Q.stages + j;
         const int run0 = st->run0, nruns = st->nruns, nshort = st->nshort;
@@ -292,6 +294,7 @@ __global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
 #pragma unroll 1
                 for (int c2 = 0; c2 < 8; ++c2) {
                     if (!alive[c2]) continue;                                   // uniform over the workgroup
+                    nmfma += 16 * my_nblk;
                     const int idx = (p * 8 + c2) * 32 + gf;
                     const float2 S = TS[idx], rA = TA[idx], rB = TB[idx];
                     const float2 rA2 = pr_cmul(rA, rA), rB2 = pr_cmul(rB, rB);
@@ -370,6 +373,7 @@ __global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
 #pragma unroll 1
                 for (int c2 = 0; c2 < 8; ++c2) {
                     if (!alive[c2]) continue;                                   // uniform over the workgroup
+                    nmfma += 4;
                     const float *St = SH + c2 * PR_SROWS * 64;
                     const int jp = 4 * p + kk;                                  // frequency pairs 4 p .. 4 p + 3: this wave's share
                     const pr_float4 a4 = *reinterpret_cast<const pr_float4 *>(St + orow * 64 + 4 * (jp ^ orow));
@@ -438,4 +442,5 @@ __global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
             __syncthreads();                    // (the tile is written again by the next stage's first block)
         }
     }
+    if (lane == 0 && Q.mfma_count) atomicAdd(Q.mfma_count, (unsigned long long)nmfma);
 }

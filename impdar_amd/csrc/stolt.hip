@@ -14,6 +14,8 @@
 // m = snum/2+1, so the real transforms and the omega-interpolation run along
 // the contiguous axis and the trace transform is a strided batched C2C.
 #include "fft.h"
+#include "own_fft.h"
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <sys/stat.h>
@@ -60,6 +62,29 @@ std::mutex &impdar_fft_plan_mutex()
 {
     static std::mutex mu;
     return mu;
+}
+
+extern "C" int impdar_fft_rows_dev(impdar_ctx *ctx, int mode, int dtype, int n, int batch, const void *d_in, void *d_out, double scale)
+{
+    IMPDAR_ARG_CHECK(ctx && d_in && d_out, "null argument");
+    IMPDAR_ARG_CHECK(mode >= 0 && mode <= 3 && (dtype == IMPDAR_F32 || dtype == IMPDAR_F64) && batch >= 1, "bad mode / dtype / batch");
+    const int M = mode >= 2 ? n / 2 : n;
+    IMPDAR_ARG_CHECK(n >= 2 && (n & (n - 1)) == 0 && own_fft_len_ok(M), "length %d is not a power of two in range", n);
+    IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
+    OwnTwiddles tw;
+    int rc;
+    const size_t cin = mode == OWN_R2C ? (size_t)n : (mode == OWN_C2R ? (size_t)M + 1 : (size_t)n);
+    const size_t cout = mode == OWN_R2C ? (size_t)M + 1 : (size_t)n;
+    if (dtype == IMPDAR_F32) {
+        if ((rc = tw.ensure<float>(n, ctx->stream))) return rc;
+        rc = own_fft_launch<float>(mode, n, (size_t)batch, d_in, d_out, cin, cout, scale, tw, ctx->stream);
+    } else {
+        if ((rc = tw.ensure<double>(n, ctx->stream))) return rc;
+        rc = own_fft_launch<double>(mode, n, (size_t)batch, d_in, d_out, cin, cout, scale, tw, ctx->stream);
+    }
+    if (rc) return rc;
+    IMPDAR_HIP_CHECK(hipStreamSynchronize(ctx->stream));         // (the table is this call's)
+    return impdar_ctx_mark_produced(ctx);
 }
 
 template <typename T> struct Cx { T x, y; };
@@ -168,6 +193,17 @@ __global__ void stolt_fix_hermitian(Cx<T> *K, int m, int tnum)
 }
 
 struct StoltPlan {
+    // the two rocFFT plans being made by a thread of their own while the first call runs on the library's own row
+    // transforms (own_fft.h): 0 none, 1 running, 2 made, 3 failed
+    std::thread bg;
+    std::atomic<int> bg_state{0};
+    bool plans_ready = false;
+    OwnTwiddles tw_time, tw_trace;
+    void bg_join()
+    {
+        if (bg.joinable()) bg.join();
+    }
+    ~StoltPlan() { bg_join(); }
     int dtype = -1, snum = 0, tnum = 0;
     const impdar_ctx *owner = nullptr;   // plans and buffers live on this context's device and stream
     FftPlan r2c, c2c_f, c2c_b, c2r;     // separate passes (IMPDAR_STOLT_FFT=1d)
@@ -208,12 +244,18 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
     const int m = snum / 2 + 1, nz = snum / 2, nout = 2 * (snum / 2);
     hipStream_t st = ctx->stream;
     const bool dbl = sizeof(T) == 8;
-    bool want2d = true;
+    bool want2d = true, own_forced = false;
     {
-        const char *e = getenv("IMPDAR_STOLT_FFT");          // tuning knob: "1d" = four 1-D passes
+        const char *e = getenv("IMPDAR_STOLT_FFT");          // tuning knob: "1d" = four 1-D passes; "own" = own_fft.h on every call
         want2d = !(e && !strcmp(e, "1d"));
+        own_forced = e && !strcmp(e, "own");
     }
+    // power-of-two sizes: a FIRST call runs on the library's own row transforms while a thread makes the rocFFT plans
+    const bool own_ok = want2d && snum % 2 == 0 && own_fft_len_ok(snum / 2) && own_fft_len_ok(tnum);
     if (pl.owner != ctx || pl.dtype != (dbl ? IMPDAR_F64 : IMPDAR_F32) || pl.snum != snum || pl.tnum != tnum || pl.use2d != want2d) {
+        pl.bg_join();                        // (a thread still making the old size's plans)
+        pl.bg_state = 0;
+        pl.plans_ready = false;
         pl.dtype = -1;
         if (pl.owner != ctx) {               // another device / stream: drop everything bound to the old one
             pl.X.release(); pl.F.release(); pl.K.release(); pl.Y.release(); pl.d_kx.release(); pl.d_ws.release();
@@ -224,7 +266,7 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
         // rfft2(axes=(1,0)) (:159) = real transform over time (contiguous here), complex over the traces (rows);
         // irfft2 (:202) = complex inverse over the traces, then C2R over time.  rocFFT's 2-D real plans do
         // exactly these two passes each, with its own blocked column kernels instead of a strided batch.
-        if (pl.use2d) {
+        if (pl.use2d && !own_ok) {
             // (asking rocFFT for the spectrum frequency-major -- its layout before the plan's last transpose -- removes two
             // transposes but makes it pick slower kernels: 0.76 ms against 0.37 ms at 4096 x 4096 float32, round 2)
             if ((rc = impdar_parallel_plans(ctx->device, {
@@ -234,6 +276,7 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
                                                     rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, m, nout,
                                                     1.0 / ((double)nout * tnum), st); }})))
                 return rc;
+            pl.plans_ready = true;
         }
         if (!pl.use2d) {
             // (round 3 built these four beside the 2-D pair on every new size: four run-time compilations nobody ran)
@@ -264,6 +307,49 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
         pl.snum = snum;
         pl.tnum = tnum;
     }
+    bool use_own = false;
+    if (own_ok) {
+        if (pl.bg_state == 2 || pl.bg_state == 3) {
+            const bool made = pl.bg_state == 2;
+            pl.bg_join();
+            pl.bg_state = 0;
+            if (made) {
+                pl.plans_ready = true;
+            } else {                             // made in the foreground, loudly
+                int rc;
+                if ((rc = pl.fwd2d.create2d(rocfft_transform_type_real_forward, dbl, false, snum, tnum, rocfft_array_type_real,
+                                            rocfft_array_type_hermitian_interleaved, snum, m, 1.0, st)) ||
+                    (rc = pl.inv2d.create2d(rocfft_transform_type_real_inverse, dbl, false, nout, tnum, rocfft_array_type_hermitian_interleaved,
+                                            rocfft_array_type_real, m, nout, 1.0 / ((double)nout * tnum), st)))
+                    return rc;
+                pl.plans_ready = true;
+            }
+        }
+        if (own_forced) {
+            use_own = true;
+        } else if (!pl.plans_ready) {
+            use_own = true;
+            if (pl.bg_state == 0) {
+                pl.bg_state = 1;
+                const int device = ctx->device;
+                StoltPlan *plp = &pl;
+                impdar_trace("stolt: first call on the library's own transforms; 2 rocFFT plans on a thread");
+                pl.bg = std::thread([plp, device, snum, tnum, m, nout, st] {
+                    int rc = hipSetDevice(device) == hipSuccess ? IMPDAR_OK : IMPDAR_ERR_HIP;
+                    if (!rc) rc = plp->fwd2d.create2d(rocfft_transform_type_real_forward, dbl, false, snum, tnum, rocfft_array_type_real,
+                                                      rocfft_array_type_hermitian_interleaved, snum, m, 1.0, st);
+                    if (!rc) rc = plp->inv2d.create2d(rocfft_transform_type_real_inverse, dbl, false, nout, tnum,
+                                                      rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, m, nout,
+                                                      1.0 / ((double)nout * tnum), st);
+                    plp->bg_state = rc ? 3 : 2;
+                });
+            }
+        }
+        if (use_own) {
+            int rc;
+            if ((rc = pl.tw_time.ensure<T>(snum, st)) || (rc = pl.tw_trace.ensure<T>(tnum, st))) return rc;
+        }
+    }
     IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_kx.p, kx, (size_t)tnum * 8, hipMemcpyHostToDevice, st));
     IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_ws.p, ws, (size_t)m * 8, hipMemcpyHostToDevice, st));
     {
@@ -275,7 +361,14 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
     hipLaunchKernelGGL((stolt_taper_transpose<T>), tgrid, dim3(256), 0, st, (const T *)d_data, pl.X.as<T>(), snum, tnum,
                        htaper, vtaper, do_taper);
     int rc;
-    if (pl.use2d) {
+    if (use_own) {
+        // the four 1-D passes of the "1d" form on the library's own row kernels: real-to-complex over time (rows of X), over
+        // the traces on contiguous rows of the transposed spectrum (K is free until the stretch writes it)
+        if ((rc = own_fft_launch<T>(OWN_R2C, snum, (size_t)tnum, pl.X.p, pl.F.p, (size_t)snum, (size_t)m, 1.0, pl.tw_time, st))) return rc;
+        own_launch_transpose<T>(pl.F.p, pl.K.p, tnum, m, st);
+        if ((rc = own_fft_launch<T>(OWN_C2C_FWD, tnum, (size_t)m, pl.K.p, pl.K.p, (size_t)tnum, (size_t)tnum, 1.0, pl.tw_trace, st))) return rc;
+        own_launch_transpose<T>(pl.K.p, pl.F.p, m, tnum, st);
+    } else if (pl.use2d) {
         if ((rc = pl.fwd2d.exec(pl.X.p, pl.F.p))) return rc;
     } else {
         if ((rc = pl.r2c.exec(pl.X.p, pl.F.p))) return rc;
@@ -283,7 +376,13 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
     }
     hipLaunchKernelGGL((stolt_stretch<T>), dim3((m + 255) / 256, tnum), dim3(256), 0, st, pl.F.as<Cx<T>>(),
                        pl.K.as<Cx<T>>(), pl.d_kx.as<double>(), pl.d_ws.as<double>(), m, nz, tnum, vel);
-    if (pl.use2d) {
+    if (use_own) {
+        own_launch_transpose<T>(pl.K.p, pl.F.p, tnum, m, st);
+        if ((rc = own_fft_launch<T>(OWN_C2C_INV, tnum, (size_t)m, pl.F.p, pl.F.p, (size_t)tnum, (size_t)tnum, 1.0 / tnum, pl.tw_trace, st))) return rc;
+        own_launch_transpose<T>(pl.F.p, pl.K.p, m, tnum, st);
+        hipLaunchKernelGGL((stolt_fix_hermitian<T>), dim3((tnum + 255) / 256), dim3(256), 0, st, pl.K.as<Cx<T>>(), m, tnum);
+        if ((rc = own_fft_launch<T>(OWN_C2R, nout, (size_t)tnum, pl.K.p, pl.Y.p, (size_t)m, (size_t)nout, 1.0 / nout, pl.tw_time, st))) return rc;
+    } else if (pl.use2d) {
         if ((rc = pl.inv2d.exec(pl.K.p, pl.Y.p))) return rc;
     } else {
         if ((rc = pl.c2c_b.exec(pl.K.p, nullptr))) return rc;
@@ -295,7 +394,7 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
     IMPDAR_HIP_CHECK(hipGetLastError());
     impdar_trace("stolt: all kernels enqueued");
     ctx->m_entry = "impdar_stolt";
-    ctx->m_kernel = "stolt_stretch (+ rocFFT 2-D real transforms)";
+    ctx->m_kernel = use_own ? "stolt_stretch (+ the library's own row transforms)" : "stolt_stretch (+ rocFFT 2-D real transforms)";
     ctx->m_kernel_ms = -1.f;
     ctx->ktimed = false;
     ctx->m_extra[0] = 0;

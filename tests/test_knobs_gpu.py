@@ -165,3 +165,81 @@ def test_slot_reserve_and_rank_emulation(hip, monkeypatch):
         monkeypatch.delenv('IMPDAR_COMM_EMULATE', raising=False)
         monkeypatch.delenv('IMPDAR_KIRCH_RESERVE', raising=False)
         lib.impdar_ctx_destroy(ctx)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('snum,tnum', [(256, 128), (1024, 512), (2048, 64)])
+def test_own_row_transforms_carry_stolt_and_phase_shift(hip, monkeypatch, snum, tnum, dtype):
+    """IMPDAR_STOLT_FFT=own / IMPDAR_PS_FFT=own: every call (not only the first of a size) runs its transforms on the
+    library's own power-of-two row kernels (csrc/own_fft.h) -- what a first call does by itself while a thread makes the
+    rocFFT plans.  Against the oracle at the stated bars, and against the rocFFT form of the same call."""
+    import ctypes as C
+    from impdar_amd import _hip, synth
+    from oracle import mig_oracle
+    geo = synth.geometry(snum, tnum)
+    x = (synth.noise_radargram(snum, tnum, seed=snum + tnum) + 0.25).astype(dtype)
+    Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+    tab = np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rp], [1.8e8, 0.5 * Rp], [1.9e8, 1.2 * Rp]])
+    want_s = mig_oracle.stolt(x.astype(np.float64), geo['dt'], geo['trace_int'], geo['dist'], 1.68e8, 10, 12)
+    want_p = mig_oracle.phase_shift(x.astype(np.float64), geo['dt'], geo['trace_int'], geo['travel_time'], geo['dist'], tab, 10, 12)
+    outs = {}
+    for own in (True, False):
+        for k in ('IMPDAR_STOLT_FFT', 'IMPDAR_PS_FFT'):
+            monkeypatch.delenv(k, raising=False)
+        if own:
+            monkeypatch.setenv('IMPDAR_STOLT_FFT', 'own')
+            monkeypatch.setenv('IMPDAR_PS_FFT', 'own')
+        else:
+            monkeypatch.setenv('IMPDAR_STOLT_FFT', '1d')     # (the synchronous rocFFT plans)
+            monkeypatch.setenv('IMPDAR_PS_FFT', 'strided')
+        d = _dat(x, geo)
+        d.migrate('stolt', vel=1.68e8, htaper=10, vtaper=12)
+        buf = C.create_string_buffer(1024)
+        _hip.check(hip.load().impdar_ctx_last_metrics(hip.context(), buf, len(buf)), 'metrics')
+        assert ('own row transforms' in json.loads(buf.value.decode())['kernel']) == own
+        outs['stolt', own] = d.data
+        d = _dat(x, geo)
+        d.migrate('phsh', vel=tab, htaper=10, vtaper=12)
+        _hip.check(hip.load().impdar_ctx_last_metrics(hip.context(), buf, len(buf)), 'metrics')
+        assert (json.loads(buf.value.decode())['transforms'] == 'own') == own
+        outs['phsh', own] = d.data
+    for own in (True, False):
+        if dtype == np.float32:
+            assert rel_l2(outs['stolt', own], want_s) < 1e-4 and rel_l2(outs['phsh', own], want_p) < 2e-4
+        else:
+            assert np.max(np.abs(outs['stolt', own] - want_s)) < 1e-12 * np.max(np.abs(want_s))
+            assert np.max(np.abs(outs['phsh', own] - want_p)) < 1e-10 * np.max(np.abs(want_p))
+    assert rel_l2(outs['stolt', True], outs['stolt', False]) < (2e-6 if dtype == np.float32 else 1e-13)
+    assert rel_l2(outs['phsh', True], outs['phsh', False]) < (5e-6 if dtype == np.float32 else 1e-12)
+
+
+def test_first_call_runs_on_the_own_transforms_and_later_calls_on_rocfft(hip, monkeypatch):
+    """A size the process has not seen: the first call uses the library's own transforms and starts a thread that makes
+    the rocFFT plans; once they exist the calls use them.  Same image either way (to the transforms' rounding)."""
+    import ctypes as C
+    import time
+    from impdar_amd import _hip, synth
+    for k in ('IMPDAR_STOLT_FFT', 'IMPDAR_PS_FFT'):
+        monkeypatch.delenv(k, raising=False)
+    snum, tnum = 512, 1024                      # (no other test uses this size)
+    geo = synth.geometry(snum, tnum)
+    x = synth.noise_radargram(snum, tnum, seed=77).astype(np.float32)
+    buf = C.create_string_buffer(1024)
+
+    def call(mtype):
+        d = _dat(x, geo)
+        d.migrate(mtype, vel=1.69e8, htaper=10, vtaper=12)
+        _hip.check(hip.load().impdar_ctx_last_metrics(hip.context(), buf, len(buf)), 'metrics')
+        m = json.loads(buf.value.decode())
+        return d.data, ('own' if ('own row transforms' in m['kernel'] or m.get('transforms') == 'own') else 'rocfft')
+
+    for mtype in ('stolt', 'phsh'):
+        first, how = call(mtype)
+        assert how == 'own', (mtype, how)
+        for _ in range(100):                    # the plans take 0.1-3 s
+            later, how = call(mtype)
+            if how == 'rocfft':
+                break
+            time.sleep(0.1)
+        assert how == 'rocfft', mtype
+        assert rel_l2(later, first) < 5e-6, (mtype, rel_l2(later, first))
