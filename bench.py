@@ -978,6 +978,18 @@ def main():
                                          "upload); wall_ms_fresh_array: median of 3 calls on arrays uploaded for the first time; "
                                          "first_call_ms: the first call of a fresh process after its context exists "
                                          "(first_call has the three paths, with import and context creation beside them)"}
+            # what the link alone allows: the (snum, tnum) float32 image up and down at the measured
+            # 56.5 GB/s of this host's PCIe (profiles/r03_h2d_probe.txt: pageable 164 MB in 2.90 ms up, 2.93 ms down) around
+            # the resident step.  sequential = up + step + down; pipelined = the first launch's share of the input (45 %:
+            # its output block + the aperture), the step, the last output block (30 %) down.  The float64 widening on the
+            # host (the reference returns float64) rides on the download threads.
+            link_gbs = 56.5
+            up_ms = snum * tnum * 4 / link_gbs / 1e6
+            res["end_to_end"]["floor"] = {"link_GBps": link_gbs, "h2d_ms": up_ms, "d2h_ms": up_ms, "step_ms": res["ms_per_step"],
+                                          "sequential_ms": 2 * up_ms + res["ms_per_step"],
+                                          "pipelined_ms": 0.45 * up_ms + res["ms_per_step"] + 0.30 * up_ms,
+                                          "wall_over_pipelined": e2e * 1e3 / (0.75 * up_ms + res["ms_per_step"]),
+                                          "source": "profiles/r03_h2d_probe.txt"}
             if first_calls:
                 res["end_to_end"]["first_call_ms"] = first_calls.get('kirch', {}).get('first_call_ms')
                 res["end_to_end"]["first_call"] = first_calls

@@ -299,9 +299,9 @@ __global__ __launch_bounds__(256, 4) void kirch_gen_kernel(GenParams P)
                         const float mlo = fminf(fmaxf(kf + (df > 0.f ? kmin_f : kmin_f - 1.0f), 0.f), smax2_f);
                         const double ds = xj_s - *(lds_dp)(uintptr_t)(XT_OFF + 8u * (unsigned)i);
                         const double qs = ds * ds + a2s;                              // mig_python.py:44 in samples^2
-                        const double h2 = kg_halfway_s2((double)mlo, P);
-                        bool up = qs > h2;                                            // :49
-                        if (__builtin_expect(kg_near_tie(qs, h2, P.tie2), 0))         // ... a tie: the reference's own rounding decides
+                        const double dq = qs - kg_halfway_s2((double)mlo, P);
+                        bool up = dq > 0.0;                                           // :49
+                        if (__builtin_expect(fabs(dq) <= P.tie2, 0))                  // ... a tie: the reference's own rounding decides
                             up = kg_ref_upper(P.dist, P.zs2, P.tt, P.vel, min(jb + blk * S + jj, tnum - 1), min(x0 + i, tnum - 1), ti, (int)mlo);
                         const float pick = mlo + (up ? 1.0f : 0.0f);
                         addr = base_k + 4u * (unsigned)pick;

@@ -36,6 +36,31 @@
 #define PSS_NARROW 0.01     // bands up to this take the short way through the exact branch
 #define PSS_TT 16           // steps per tile
 
+
+// sin / cos of a float64 angle in [-pi/2, 3 pi / 2] (the per-step phase w dt sqrt(coss) lies in [0, pi]): quadrant by
+// Cody-Waite with pi/2 in two pieces, the kernels of fdlibm's __kernel_sin / __kernel_cos on [-pi/4, pi/4] (< 1 ulp).
+// The library's sincos carries a large-argument path (a table in scratch memory): in ps_smooth_kernel's anchors that cost
+// the 8-frequencies-per-lane kernel 372 bytes of scratch per lane and made it 60 % slower.
+__device__ __forceinline__ void pss_sincos_small(double x, double *s, double *c)
+{
+    const double n = rint(x * 0.63661977236758134308);
+    double r = fma(-n, 1.57079632673412561417e+00, x);
+    r = fma(-n, 6.07710050650619224932e-11, r);
+    r = fma(-n, 2.02226624879595063154e-21, r);
+    const double z = r * r;
+    const double sp = fma(z * r, fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                                        2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                                           8.33333333332248946124e-03), -1.66666666666666324348e-01), r);
+    const double cp = fma(z * z, fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                                         -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                                            -1.38888888888741095749e-03), 4.16666666666666019037e-02), fma(-0.5, z, 1.0));
+    const int q = (int)n;
+    const bool odd = q & 1;
+    const double sv = odd ? cp : sp, cv = odd ? sp : cp;
+    *s = (q & 2) ? -sv : sv;
+    *c = ((q + 1) & 2) ? -cv : cv;
+}
+
 // what a wave of either kernel starts with
 struct PssWave {
     int k, chunk, lane;
@@ -312,20 +337,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
                             }
                         }
                     }
-                    // R itself is re-anchored every 64 steps: R *= exp(i d) rounds once per step (1e-16), so R's phase is off by
-                    // ~tau 1e-16 after tau steps, and the state, which integrates R, by ~tau^2 / 2 of that: 4.4e-10 of the
-                    // image maximum at 8192 steps (round 5: the 8192^2 spot-wavenumber test; 2e-11 with the anchors)
-                    if ((tau & 63) == 0 && tau > 0) {                             // uniform
-#pragma unroll
-                        PSS_EACH {
-                            if (!((dead >> m) & 1u)) {
-                                T sn, cn;
-                                sincos_t<T>(wdt[m] * q[j].y2, &sn, &cn);
-                                q[j].ncr = cn;
-                                q[j].nsr = sn;
-                            }
-                        }
-                    }
 #pragma unroll
                     PSS_EACH {
                         y[m] = q[j].y2;
@@ -357,6 +368,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
             acc[2 * t + 1] = pv.y;
         }
         pss_write_tile<T>(acc, lane, out, tau0, P.snum, final_scale);
+        // R itself is re-anchored every 64 steps: R *= exp(i d) rounds once per step (1e-16), so R's phase is off by
+        // ~tau 1e-16 after tau steps, and the state, which integrates R, by ~tau^2 / 2 of that: 4.4e-10 of the image
+        // maximum at 8192 steps (round 5: the 8192^2 spot-wavenumber test; 4e-12 with the anchors).  Here, between two
+        // tiles, not inside the step loop: there the extra live values pushed the 8-frequencies-per-lane kernel further
+        // into scratch (220 -> 377 ms at 8192^2).
+        if ((tile & 3) == 3) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                if (!((dead >> m) & 1u)) {
+                    double sn, cn;
+                    pss_sincos_small(wdt[m] * y[m], &sn, &cn);
+                    rc[m] = cn;
+                    rs[m] = sn;
+                }
+            }
+        }
     }
 }
 

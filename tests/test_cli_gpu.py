@@ -13,6 +13,14 @@ from conftest import rel_max
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _one_transform_implementation(monkeypatch):
+    """The first Stolt / phase-shift call of a power-of-two size runs on the library's own row transforms and later calls on
+    rocFFT's plans (csrc/own_fft.h): the bit-for-bit host / resident comparisons of this module pin one implementation."""
+    monkeypatch.setenv('IMPDAR_PS_FFT', 'own')
+    monkeypatch.setenv('IMPDAR_STOLT_FFT', 'own')
+
+
 @pytest.mark.parametrize('mtype', ['kirch', 'stolt', 'phsh', 'tk'])
 def test_impproc_migrate_on_mat_file(hip, tmp_path, mtype):
     from impdar_amd import synth

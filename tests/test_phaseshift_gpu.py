@@ -376,8 +376,8 @@ def test_many_runs_matrix_core_path_against_the_vector_kernels_and_the_oracle(hi
     # (up to 16 long runs: ps_mfma_kernel where its 2048-step row blocks are not mostly padding, i.e. on long records)
     assert chosen in ('ps_runs_kernel', 'ps_mfma_kernel'), (kind, chosen)
     assert chosen == 'ps_runs_kernel' or kind not in ('layers40',), (kind, chosen)
-    if chosen == 'ps_runs_kernel':
-        assert np.array_equal(d.data, outs['3', '1'])
+    if chosen == 'ps_runs_kernel':      # (the same sums; the transforms around them may be the library's own or rocFFT's by now)
+        assert rel_l2(d.data, outs['3', '1']) < 5e-6
 
 
 def test_matrix_core_path_leaves_many_short_runs_to_the_vector_kernels(hip, monkeypatch):
@@ -424,6 +424,7 @@ def test_matrix_core_path_hands_over_when_a_wavenumber_has_more_boundary_frequen
     want = mig_oracle.phase_shift(data.astype(np.float64), geo['dt'], geo['trace_int'], geo['travel_time'],
                                   geo['dist'], vel, 20, 30)
     outs, kernels = {}, {}
+    monkeypatch.setenv('IMPDAR_PS_FFT', 'own')       # (one transform implementation for the bit-for-bit comparison below)
     for name, env in (('mfma', {}), ('overflow', {'IMPDAR_PS_TEST_EDGE_OVERFLOW': '1'}), ('vector', {'IMPDAR_PS_MFMA': '0'})):
         for k in ('IMPDAR_PS_TEST_EDGE_OVERFLOW', 'IMPDAR_PS_MFMA'):
             monkeypatch.delenv(k, raising=False)

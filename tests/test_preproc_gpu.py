@@ -12,6 +12,14 @@ from conftest import golden, golden_names
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _one_transform_implementation(monkeypatch):
+    """The first Stolt / phase-shift call of a power-of-two size runs on the library's own row transforms and later calls on
+    rocFFT's plans (csrc/own_fft.h): the bit-for-bit host / resident comparisons of this module pin one implementation."""
+    monkeypatch.setenv('IMPDAR_PS_FFT', 'own')
+    monkeypatch.setenv('IMPDAR_STOLT_FFT', 'own')
+
 TOL = 1e-12
 
 
