@@ -464,7 +464,7 @@ def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None, spot=None):
         "roofline": {"bound": "fp64 vector", "achieved": tf64, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
                      "frac": tf64 / FP64_VECTOR_PEAK_TF, "algorithmic_flop": flop,
                      "note": "8 flop per needed complex rotate-accumulate (half walk) over kernel_ms against the float64 "
-                             "vector peak; 42 % of the (kx, w) plane is evanescent and skipped pair-wise (DESIGN 11.7)"}}
+                             "vector peak; 42 % of the (kx, w) plane is evanescent and skipped pair-wise (docs/DESIGN_rounds1-4.md 11.7)"}}
     del x64
     # ---- the other velocity structures at config-5 size (figures the builder alone had measured)
     def ps_dev(data, vel, reps=2):

@@ -368,12 +368,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
             acc[2 * t + 1] = pv.y;
         }
         pss_write_tile<T>(acc, lane, out, tau0, P.snum, final_scale);
-        // R itself is re-anchored every 64 steps: R *= exp(i d) rounds once per step (1e-16), so R's phase is off by
+        // R itself is re-anchored every 128 steps: R *= exp(i d) rounds once per step (1e-16), so R's phase is off by
         // ~tau 1e-16 after tau steps, and the state, which integrates R, by ~tau^2 / 2 of that: 4.4e-10 of the image
         // maximum at 8192 steps (round 5: the 8192^2 spot-wavenumber test; 4e-12 with the anchors).  Here, between two
         // tiles, not inside the step loop: there the extra live values pushed the 8-frequencies-per-lane kernel further
         // into scratch (220 -> 377 ms at 8192^2).
-        if ((tile & 3) == 3) {
+        if ((tile & 7) == 7) {
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 if (!((dead >> m) & 1u)) {
