@@ -516,9 +516,8 @@ def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None, spot=None):
         out[name] = r
 
     gazdag_extra("gazdag_const_config5", 'const', x, "mfma", FP16_MFMA_PEAK_TF, 2e-4, "constant velocity 1.69e8 m/s (mig_python.py:396-420)")
-    gazdag_extra("gazdag_layers41_config5", 'layers41', x, "mfma_f32", FP32_VECTOR_PEAK_TF, 2e-4,
-                 "41-row (v, z) table: 40 layers of ~200 steps, every boundary smeared over single steps "
-                 "(ps_runs_kernel: float32 MFMA at the vector rate, 157.3 TFLOP/s)")
+    gazdag_extra("gazdag_layers41_config5", 'layers41', x, "mfma", FP16_MFMA_PEAK_TF, 2e-4,
+                 "41-row (v, z) table: 21 layers of ~420 steps, every boundary smeared over single steps (ps_runs_kernel)")
     gazdag_extra("gazdag_smooth_config5", 'gradient', x, "fp32 vector", FP32_VECTOR_PEAK_TF, 2e-4,
                  "velocity changing at EVERY step (linear gradient 1.69e8 -> 2.19e8 m/s) through the C entry point")
     gazdag_extra("gazdag_smooth_f64_config5", 'gradient_f64', x.astype(np.float64), "fp64 vector", FP64_VECTOR_PEAK_TF, 1e-10,

@@ -4,9 +4,9 @@
 // lengths up to 1024): a first Stolt call at 4096 x 4096 or phase-shift call at 8192 x 8192 spends 0.25-0.5 s per plan in
 // the run-time compiler on a machine that has run before, 2-3 s on a fresh one (profiles/r05_first_call.txt; `impproc
 // migrate` is one process per call, so the first call IS the call).  These kernels are part of the library's own code
-// object -- nothing to compile, nothing to look up.  stolt.hip / phaseshift.hip run a first call through them when the
-// sizes are powers of two while a thread creates the rocFFT plans in the background; calls after that use rocFFT (its
-// 2-D plans fuse passes these row transforms do not).
+// object -- nothing to compile, nothing to look up.  stolt.hip / phaseshift.hip run the first call of a power-of-two size
+// through them; the second call of the size makes the rocFFT plans (its 2-D plans fuse passes these row transforms do
+// not) and every later call uses them.
 //
 // Reference semantics (numpy.fft, mig_python.py:159,202,270,282): unnormalised forward transforms with e^{-2 pi i k n / N},
 // inverse with e^{+...} and no 1/N (the caller passes the scale, as with the rocFFT plans).

@@ -20,7 +20,6 @@
 // contiguous runs of TK_T[k][tau].
 #include "fft.h"
 #include "own_fft.h"
-#include <atomic>
 #include <algorithm>
 #include <mutex>
 #include <type_traits>
@@ -1301,16 +1300,8 @@ __global__ __launch_bounds__(256) void ps_dc_kernel(const Cp<T> *__restrict__ F,
 #include "ps_mfma.h"
 
 struct PsPlan {
-    // the rocFFT plans of the Hermitian rows form being made by a thread of their own while the first call runs on the
-    // library's own transforms (own_fft.h): 0 none, 1 running, 2 made, 3 failed
-    std::thread bg;
-    std::atomic<int> bg_state{0};
-    OwnTwiddles tw_time, tw_trace;
-    void bg_join()
-    {
-        if (bg.joinable()) bg.join();
-    }
-    ~PsPlan() { bg_join(); }
+    OwnTwiddles tw_time, tw_trace;       // the library's own row transforms (own_fft.h): what the first call of a size runs on
+    int own_calls = 0;                   // ... calls of this size that did
     int dtype = -1, snum = 0, tnum = 0, nt = 0;
     const impdar_ctx *owner = nullptr;   // plans and buffers live on this context's device and stream
     FftPlan f_time, f_trace, b_trace;
@@ -1706,8 +1697,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     const bool own_forced = fe && strcmp(fe, "own") == 0;
     if (pl.owner != ctx || pl.dtype != (dbl ? IMPDAR_F64 : IMPDAR_F32) || pl.snum != snum || pl.tnum != tnum || pl.nt != nt ||
         pl.rows_form != rows_form) {
-        pl.bg_join();                        // (a thread still making the old size's plans)
-        pl.bg_state = 0;
+        pl.own_calls = 0;
         pl.dtype = -1;
         pl.rm_state = -1;
         pl.r_ready = pl.c_ready = false;
@@ -1789,45 +1779,23 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         const size_t rows = tk_out ? scratch_rows : std::max<size_t>((size_t)snum, scratch_rows);
         if (rows) IMPDAR_HIP_CHECK(pl.TK.ensure((size_t)tnum * rows * 2 * sizeof(T)));
     }
-    // A FIRST call on power-of-two sizes runs its transforms on the library's own row kernels while a thread makes the
-    // rocFFT plans (0.25-3 s: their kernels are compiled at run time); later calls use the plans.
+    // The FIRST call of a power-of-two size runs its transforms on the library's own row kernels (own_fft.h: nothing to
+    // compile); the rocFFT plans -- 0.25-3 s: their kernels are compiled at run time -- are made by the SECOND call of the
+    // size, if there is one (`impproc migrate` is one call per process).  (A first form made them on a thread during
+    // the first call: a process that exits while rocFFT is still compiling on another thread crashes in its teardown --
+    // rc -11 / -6 in 2 of 2 such exits, profiles/r05_first_call.txt.)
     bool use_own = false;
     if (herm && pl.rows_form && own_fft_len_ok(nt / 2) && own_fft_len_ok(tnum)) {
-        if (pl.bg_state == 2 || pl.bg_state == 3) {
-            const bool made = pl.bg_state == 2;
-            pl.bg_join();
-            pl.bg_state = 0;
-            if (made) pl.b_ready = pl.r_ready = true;
-            else impdar_trace("phaseshift: the background plans failed (%s): made in the foreground", impdar_last_error());
-        }
         IMPDAR_HIP_CHECK(pl.Xr.ensure((size_t)tnum * nt * sizeof(T)));
-        if (own_forced) {
+        if (own_forced || (!(pl.b_ready && pl.r_ready) && pl.own_calls == 0)) {
             use_own = true;
-        } else if (!(pl.b_ready && pl.r_ready)) {
-            use_own = true;
-            if (pl.bg_state == 0) {
-                pl.bg_state = 1;
-                const int device = ctx->device;
-                PsPlan *plp = &pl;
-                impdar_trace("phaseshift: first call on the library's own transforms; 3 rocFFT plans on a thread");
-                pl.bg = std::thread([plp, device, tnum, snum, nt, fstride, st] {
-                    const rocfft_array_type ci = rocfft_array_type_complex_interleaved;
-                    int rc = hipSetDevice(device) == hipSuccess ? IMPDAR_OK : IMPDAR_ERR_HIP;
-                    if (!rc) rc = plp->b_trace.create(rocfft_transform_type_complex_inverse, dbl, true, tnum, snum, ci, ci, 1, tnum, 1, tnum, 1.0 / tnum, st);
-                    if (!rc) rc = plp->r_time.create(rocfft_transform_type_real_forward, dbl, false, nt, tnum, rocfft_array_type_real,
-                                                     rocfft_array_type_hermitian_interleaved, 1, nt, 1, fstride, 1.0, st);
-                    if (!rc) rc = plp->r_trace.create(rocfft_transform_type_complex_forward, dbl, true, tnum, fstride, ci, ci, 1, tnum, 1, tnum, 1.0, st);
-                    plp->bg_state = rc ? 3 : 2;
-                });
-            }
-        }
-        if (use_own) {
+            pl.own_calls += own_forced ? 0 : 1;
+            impdar_trace("phaseshift: transforms on the library's own row kernels");
             int rc;
             if ((rc = pl.tw_time.ensure<T>(nt, st)) || (rc = pl.tw_trace.ensure<T>(tnum, st))) return rc;
         }
     }
     if (!use_own) {
-        if (pl.bg_state == 1) pl.bg_join();      // (cannot happen for one size; a thread must not make plans beside the ones below)
         int rc;
         const rocfft_array_type ci = rocfft_array_type_complex_interleaved;
         // the plans this call still lacks, created side by side (run-time compilation: impdar_parallel_plans)
@@ -2119,7 +2087,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         snprintf(ctx->m_extra, sizeof ctx->m_extra,
                  "\"hermitian_walk\": %s, \"frequencies\": %d, \"transforms\": \"%s\", \"mfma_instructions\": %.0f, \"flop_per_mfma\": %d",
                  herm ? "true" : "false", nf, use_own ? "own" : "rocfft", pl.mfma_instructions,
-                 strcmp(mfma_kernel_name, "ps_runs_kernel") == 0 ? 2048 : 32768);
+                 strcmp(mfma_kernel_name, "ps_runs_kernel") == 0 ? 16384 : 32768);
     else
         snprintf(ctx->m_extra, sizeof ctx->m_extra, "\"hermitian_walk\": %s, \"frequencies\": %d, \"transforms\": \"%s\"",
                  herm ? "true" : "false", nf, use_own ? "own" : "rocfft");

@@ -8,11 +8,12 @@
 //
 //   * tiles of 8 steps, blocks of 16 tiles: inside a run  step = 8 a + b,
 //         TK[start + 8 a + b] = sum_w [F_w e^{i Phi_w} e^{i 8 a phi_w}] [e^{i (b + 1) phi_w}] = sum_w S_w(a) B_w(b),
-//     one v_mfma_f32_16x16x4_f32 accumulator = 16 tiles x (8 steps x (re, im)) = 128 steps per block.  float32 operands:
-//     no hi / lo split, no scaling, products exact to float32 -- the matrix pipe runs at the float32 VECTOR rate here
-//     (64 flop / clk / SIMD, 1/16 of the float16 rate ps_mfma.h uses), and that is the point: a state row costs 4 vector
-//     instructions instead of 10, so the vector work (states, step factors, the per-run set-up) fits UNDER the matrix
-//     pipe's time instead of on top of it;
+//     one 16 x 16 accumulator = 16 tiles x (8 steps x (re, im)) = 128 steps per block, v_mfma_f32_16x16x32_f16 with the
+//     float16 hi / lo operands of ps_mfma.h (x = hi + lo, three products hi.hi + hi.lo + lo.hi, the spectrum scaled by a
+//     power of two into [2^11, 2^12), the step factors by 2^8).  The first form of this kernel used float32 operands
+//     (v_mfma_f32_16x16x4_f32: no split, 4 vector instructions per state row instead of 8) -- but a float32 MFMA runs at
+//     the VECTOR rate and keeps the SIMD's vector unit for its 32 cycles (SQ_VALU_MFMA_COEXEC_CYCLES = 0): its 10.9 ms of
+//     pipe time at 41 rows came on top of the vector work instead of under it (profiles/r05_ps_runs.txt);
 //   * phases generated in the kernel: a thread owns ONE frequency at a time and walks the stage's runs in order with
 //     the phase in a float64 register -- coss, the square root (reciprocal-root seed + two Newton steps), the phase at the
 //     run's start, and for the run three sincos: the anchor state F e^{i Phi}, the tile rotation e^{i 8 phi}, the step
@@ -43,7 +44,9 @@ constexpr int PR_LONG_MAX = PR_NBLK * PR_ROWS * PR_TT;
 constexpr int PR_SHORT_LEN = 2;     // runs of up to this many steps: every step a row of its own
 constexpr int PR_SROWS = 12;        // single-step rows per stage
 constexpr int PR_STAGE_RUNS = 16;   // runs per stage
-constexpr size_t PR_LDS_FLOATS = 3 * 2 * PR_LONGS * 8 * 32 + 8 * PR_SROWS * 64 + PR_LONGS * PR_ROWS * 64 + PR_LONGS * 16 * 8 * 4 + 16 + PR_STAGE_RUNS * 6;
+constexpr int PR_LD = 36;            // dwords per tile row: 32 frequencies (one float16 pair each) + 4: the 16 rows a ds_read_b128 serves start on different banks
+constexpr int PR_TILE = PR_ROWS * PR_LD;    // dwords per tile (hi or lo halves)
+constexpr size_t PR_LDS_FLOATS = 3 * 2 * PR_LONGS * 8 * 32 + 2 * 8 * PR_SROWS * PR_LD + PR_LONGS * 2 * PR_TILE + 16 + PR_STAGE_RUNS * 6;
 constexpr size_t PR_LDS_BYTES = PR_LDS_FLOATS * 4;
 
 struct PrRun {
@@ -116,14 +119,16 @@ __global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
     // evanescent and leave early, so four XCDs did most of the work (first form: 1.4 waves per SIMD on average, 43 ms).
     // The high, long-lived parts first.
     const int part = Q.nparts - 1 - (int)blockIdx.x / P.nk, kb = (int)blockIdx.x % P.nk, k = P.k0 + kb;
-    // LDS: per long run (wave) and chunk the anchor state / tile rotation / step rotation of every frequency; the
-    // single-step state tiles of the 8 chunks; a state tile and a step-factor tile per wave; the chunks' alive flags
+    // LDS: per long run (wave) and chunk the anchor state / tile rotation / step rotation of every frequency (float32); the
+    // single-step state tiles of the 8 chunks; one operand tile per wave; the chunks' alive flags; the stage's runs
     float2 *TS = reinterpret_cast<float2 *>(pr_lds);
     float2 *TA = TS + PR_LONGS * 8 * 32, *TB = TA + PR_LONGS * 8 * 32;
-    float *SH = pr_lds + 3 * 2 * PR_LONGS * 8 * 32;
-    float *AT = SH + 8 * PR_SROWS * 64 + (size_t)p * PR_ROWS * 64;
-    float *BT = SH + 8 * PR_SROWS * 64 + PR_LONGS * PR_ROWS * 64 + (size_t)p * 16 * 8 * 4;
-    int *alive = reinterpret_cast<int *>(SH + 8 * PR_SROWS * 64 + PR_LONGS * PR_ROWS * 64 + PR_LONGS * 16 * 8 * 4);
+    // single-step state tiles of the 8 chunks, hi halves then lo halves: [chunk][row][PR_LD] dwords (one float16 pair each)
+    unsigned *SHh = reinterpret_cast<unsigned *>(pr_lds) + 3 * 2 * PR_LONGS * 8 * 32, *SHl = SHh + 8 * PR_SROWS * PR_LD;
+    // this wave's tile (hi, lo): the step factors of a chunk first -- [column][PR_LD] -- then, once those are in registers,
+    // the state rows of its blocks -- [tile][PR_LD]
+    unsigned *Wh = SHl + 8 * PR_SROWS * PR_LD + (size_t)p * 2 * PR_TILE, *Wl = Wh + PR_TILE;
+    int *alive = reinterpret_cast<int *>(SHl + 8 * PR_SROWS * PR_LD + PR_LONGS * 2 * PR_TILE);
     // the stage's runs, copied here once per stage (read from global memory inside the set-up walk every iteration waited a
     // scalar-load round trip: 16 runs x ~250 cycles per walk)
     PrRun *sruns = reinterpret_cast<PrRun *>(alive + 16);
@@ -137,18 +142,36 @@ __global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
     double phi[PR_NM], rw[PR_NM], wdt[PR_NM], incq[PR_NM];     // incq / rbq: phase per step and step rotation of the last long run
     float2 F[PR_NM], rbq[PR_NM];
     bool edge[PR_NM], inpart[PR_NM];
+    float fmx = 0.f;
 #pragma unroll
     for (int m = 0; m < PR_NM; ++m) {
         const int slot = part * PR_PART + 256 * m + tid;
         const bool in = slot < P.nf;
         const Cp<float> f = in ? ps_load_slot<float>(Frow, P, slot) : Cp<float>{0.f, 0.f};
         F[m] = make_float2(f.x, f.y);
+        fmx = fmaxf(fmx, fmaxf(fabsf(f.x), fabsf(f.y)));
         rw[m] = in ? Q.rw[slot] : 1.0;
         wdt[m] = in ? P.w[slot] * P.dt : 0.0;
         edge[m] = false;
         inpart[m] = in;
         incq[m] = 0.0;
         rbq[m] = make_float2(1.f, 0.f);
+    }
+    // scale of the part's spectrum: the largest component into [2^11, 2^12) (float16 operands; exact, divided out at the end)
+    float sigma;
+    {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) fmx = fmaxf(fmx, __shfl_xor(fmx, o, 64));
+        float *mx = reinterpret_cast<float *>(alive);
+        if (lane == 0) mx[p] = fmx;
+        __syncthreads();
+        fmx = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+        __syncthreads();
+        int e = 0;
+        (void)frexpf(fmx, &e);
+        sigma = (fmx > 0.f && fmx < 3.0e38f) ? ldexpf(1.0f, 12 - e) : 1.0f;
+#pragma unroll
+        for (int m = 0; m < PR_NM; ++m) F[m] = make_float2(F[m].x * sigma, F[m].y * sigma);
     }
     // boundary frequencies (|coss| < 1e-8 at ANY run's velocity: kept or dropped by the reference at every step's own
     // velocity, :456-485) take no part here: listed for ps_edge_kernel (as ps_setup_kernel does).  Runs in the outer loop:
@@ -183,7 +206,8 @@ __global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
         }
     }
     Cp<float> *out = reinterpret_cast<Cp<float> *>(Q.nparts > 1 ? Q.part : P.TK) + ((size_t)(Q.nparts > 1 ? part : 0) * P.nk + kb) * P.snum;
-    const float scale = Q.nparts > 1 ? 1.0f : 1.0f / (float)P.snum;         // (:492; with parts ps_smooth_sum_kernel divides)
+    // (:492; with parts ps_smooth_sum_kernel divides by snum); the operands' scales divided out
+    const float scale = (Q.nparts > 1 ? 1.0f : 1.0f / (float)P.snum) / (sigma * 256.0f);
 
     const int cc = tid >> 5, f = tid & 31;           // set-up roles: chunk of the super-chunk, frequency of the chunk
     const int gf = lane & 31, hh = lane >> 5;        // generation roles: frequency, which of its two lanes
@@ -272,7 +296,9 @@ __global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
                             }
                             chain = in ? pr_cmul(chain, rot) : make_float2(0.f, 0.f);      // :464
                             const int row = slot + s_;
-                            *reinterpret_cast<float2 *>(SH + (cc * PR_SROWS + row) * 64 + 4 * ((f >> 1) ^ (row & 15)) + 2 * (f & 1)) = chain;
+                            float rr, ri;
+                            SHh[(cc * PR_SROWS + row) * PR_LD + f] = pm_split(chain.x, chain.y, &rr, &ri);
+                            SHl[(cc * PR_SROWS + row) * PR_LD + f] = pm_pack(rr, ri);
                             ph += inc;
                         }
                     }
@@ -282,10 +308,8 @@ __global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
                 rbq[0] = rBp;
             }
             __syncthreads();
-            // ---- (2) the products, chunk by chunk.  (A v_mfma_f32_16x16x4_f32 keeps the SIMD's vector unit for its 32 cycles:
-            // SQ_VALU_MFMA_COEXEC_CYCLES = 0, and a timing-only build without the MFMAs is faster by exactly their pipe time.
-            // Forming the next block's rows between the MFMAs, and a form that writes / reads the next block's operands before
-            // this block's MFMAs are issued, both measured slower than this plain sequence: profiles/r05_ps_runs.txt.)
+            // ---- (2) the products, chunk by chunk: per chunk the step factors go through the wave's tile into registers, then
+            // block after block the state rows (8 per lane: rotate, split into float16 hi / lo) and 6 MFMAs
 #ifdef PR_ABL_NOITEMS
             if (my_run >= 0 && j == 0 && m == 0) {                              // timing only
 #else
@@ -294,74 +318,55 @@ __global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
 #pragma unroll 1
                 for (int c2 = 0; c2 < 8; ++c2) {
                     if (!alive[c2]) continue;                                   // uniform over the workgroup
-                    nmfma += 16 * my_nblk;
+                    nmfma += 6 * my_nblk;
                     const int idx = (p * 8 + c2) * 32 + gf;
                     const float2 S = TS[idx], rA = TA[idx], rB = TB[idx];
                     const float2 rA2 = pr_cmul(rA, rA), rB2 = pr_cmul(rB, rB);
                     float2 cur = hh ? pr_cmul(S, rA) : S;                      // this lane's rows: hh, hh + 2, ...
-                    float2 cb = hh ? rB2 : rB;                                 // ... and steps b = hh, hh + 2, ...: e^{i (b + 1) phi}
-                    float bt[16];
+                    // ... and steps b = hh, hh + 2, ...: 2^8 e^{i (b + 1) phi}.  Against (S_re, S_im) the column (b, re) holds
+                    // (c, -s), the column (b, im) holds (s, c): both written, so that a lane reads its column's form
+                    float2 cb = hh ? rB2 : rB;
+                    cb = make_float2(cb.x * 256.f, cb.y * 256.f);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int jb = 0; jb < PR_TT / 2; ++jb) {
+                        const int b = 2 * jb + hh;
+                        float rc, rs;
+                        const unsigned h0 = pm_split(cb.x, cb.y, &rc, &rs), l0 = pm_pack(rc, rs);
+                        Wh[(2 * b) * PR_LD + gf] = pm_conj(h0);
+                        Wh[(2 * b + 1) * PR_LD + gf] = pm_swap(h0);
+                        Wl[(2 * b) * PR_LD + gf] = pm_conj(l0);
+                        Wl[(2 * b + 1) * PR_LD + gf] = pm_swap(l0);
+                        cb = pr_cmul(cb, rB2);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    uint4 bh[2], bl[2];                                          // K-steps of 16 frequencies: this lane's 4 of each
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        bh[ks] = *reinterpret_cast<const uint4 *>(Wh + orow * PR_LD + 16 * ks + 4 * kk);
+                        bl[ks] = *reinterpret_cast<const uint4 *>(Wl + orow * PR_LD + 16 * ks + 4 * kk);
+                    }
 #pragma unroll
                     for (int blk = 0; blk < PR_NBLK; ++blk) {
                         if (blk >= my_nblk) break;                              // uniform
-                        __builtin_amdgcn_wave_barrier();
-#ifndef PR_ABL_NOGEN
+                        __builtin_amdgcn_wave_barrier();                        // (the tile's last readers are done: in-order LDS)
 #pragma unroll
                         for (int jr = 0; jr < PR_ROWS / 2; ++jr) {
                             const int row = 2 * jr + hh;
-                            *reinterpret_cast<float2 *>(AT + row * 64 + 4 * ((gf >> 1) ^ row) + 2 * (gf & 1)) = cur;
+                            float rr, ri;
+                            Wh[row * PR_LD + gf] = pm_split(cur.x, cur.y, &rr, &ri);
+                            Wl[row * PR_LD + gf] = pm_pack(rr, ri);
                             cur = pr_cmul(cur, rA2);
                         }
-                        if (blk == 0) {
-#pragma unroll
-                            for (int jb = 0; jb < PR_TT / 2; ++jb) {
-                                const int b = 2 * jb + hh;
-                                *reinterpret_cast<float2 *>(BT + ((gf >> 1) * 8 + (b ^ ((gf >> 1) & 7))) * 4 + 2 * (gf & 1)) = cb;
-                                cb = pr_cmul(cb, rB2);
-                            }
-                        }
                         __builtin_amdgcn_wave_barrier();
-#endif
-                        pr_float4 a4[4];
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int jp = 4 * g + kk;                          // frequency pair of this lane's K slot
-#ifdef PR_ABL_NOGEN
-                            a4[g] = pr_float4{cur.x, cur.y, cb.x, cb.y};         // timing only: no LDS round trip
-#else
-                            a4[g] = *reinterpret_cast<const pr_float4 *>(AT + orow * 64 + 4 * (jp ^ orow));
-#endif
-                        }
-                        if (blk == 0) {
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                const int jp = 4 * g + kk;
-                                // (c0, s0, c1, s1) of the pair at step ob; against (S_re, S_im) the column (b, re) holds (c, -s),
-                                // the column (b, im) holds (s, c)
-#ifdef PR_ABL_NOGEN
-                                const pr_float4 b4 = pr_float4{rB.x, rB.y, rB2.x, rB2.y};
-#else
-                                const pr_float4 b4 = *reinterpret_cast<const pr_float4 *>(BT + (jp * 8 + (ob ^ (jp & 7))) * 4);
-#endif
-                                bt[4 * g + 0] = onc ? b4.y : b4.x;
-                                bt[4 * g + 1] = onc ? b4.x : -b4.y;
-                                bt[4 * g + 2] = onc ? b4.w : b4.z;
-                                bt[4 * g + 3] = onc ? b4.z : -b4.w;
-                            }
-                        }
-                        // two accumulators per block in turn: a v_mfma_f32_16x16x4_f32 that waits for its predecessor's sum
-                        // waits 40 cycles, the pipe takes one every 32
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-#ifdef PR_ABL_NOMFMA
-                            acc[blk][0][g] += a4[g].x * bt[4 * g + 0] + a4[g].y * bt[4 * g + 1];      // timing only: the operands stay live
-                            acc[blk][1][g] += a4[g].z * bt[4 * g + 2] + a4[g].w * bt[4 * g + 3];
-#else
-                            acc[blk][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].x, bt[4 * g + 0], acc[blk][0], 0, 0, 0);
-                            acc[blk][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].y, bt[4 * g + 1], acc[blk][1], 0, 0, 0);
-                            acc[blk][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].z, bt[4 * g + 2], acc[blk][0], 0, 0, 0);
-                            acc[blk][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g].w, bt[4 * g + 3], acc[blk][1], 0, 0, 0);
-#endif
+                        for (int ks = 0; ks < 2; ++ks) {
+                            const pm_half8 a_hi = __builtin_bit_cast(pm_half8, *reinterpret_cast<const uint4 *>(Wh + orow * PR_LD + 16 * ks + 4 * kk));
+                            const pm_half8 a_lo = __builtin_bit_cast(pm_half8, *reinterpret_cast<const uint4 *>(Wl + orow * PR_LD + 16 * ks + 4 * kk));
+                            const pm_half8 b_hi = __builtin_bit_cast(pm_half8, bh[ks]), b_lo = __builtin_bit_cast(pm_half8, bl[ks]);
+                            acc[blk][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi, acc[blk][0], 0, 0, 0);
+                            acc[blk][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo, acc[blk][1], 0, 0, 0);
+                            acc[blk][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi, acc[blk][0], 0, 0, 0);
                         }
                     }
                 }
@@ -369,18 +374,20 @@ __global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
             // the stage's single steps: a quarter of the frequencies of every chunk per wave (their sums are added at the
             // end of the stage)
             if (nshort > 0) {
-                const float e0 = orow == 0 ? 1.f : 0.f, e1 = orow == 1 ? 1.f : 0.f;       // column 0 = sum of re, column 1 = sum of im
+                // column 0 = 2^8 x the sum of the real parts, column 1 = of the imaginary parts: against (S_re, S_im) the unit
+                // columns (2^8, 0) and (0, 2^8), exact in float16 (no lo half: two products)
+                const unsigned u = orow == 0 ? 0x00005C00u : (orow == 1 ? 0x5C000000u : 0u);     // float16 256 = 0x5C00
+                const pm_half8 bu = __builtin_bit_cast(pm_half8, make_uint4(u, u, u, u));
 #pragma unroll 1
                 for (int c2 = 0; c2 < 8; ++c2) {
                     if (!alive[c2]) continue;                                   // uniform over the workgroup
-                    nmfma += 4;
-                    const float *St = SH + c2 * PR_SROWS * 64;
-                    const int jp = 4 * p + kk;                                  // frequency pairs 4 p .. 4 p + 3: this wave's share
-                    const pr_float4 a4 = *reinterpret_cast<const pr_float4 *>(St + orow * 64 + 4 * (jp ^ orow));
-                    accs = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, e0, accs, 0, 0, 0);
-                    accs = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, e1, accs, 0, 0, 0);
-                    accs = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, e0, accs, 0, 0, 0);
-                    accs = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, e1, accs, 0, 0, 0);
+                    nmfma += 2;
+                    // frequencies 8 p .. 8 p + 7 of the chunk: this wave's share (a K-step holds 16: the other 8 slots are zero)
+                    const int fo = (c2 * PR_SROWS + orow) * PR_LD + 8 * p + 4 * (kk & 1);
+                    uint4 ah = *reinterpret_cast<const uint4 *>(SHh + fo), al = *reinterpret_cast<const uint4 *>(SHl + fo);
+                    if (kk >= 2) ah = al = make_uint4(0u, 0u, 0u, 0u);
+                    accs = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pm_half8, ah), bu, accs, 0, 0, 0);
+                    accs = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pm_half8, al), bu, accs, 0, 0, 0);
                 }
             }
             __syncthreads();                    // the stage's tables are re-written by the next super-chunk
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
         if (nshort > 0) {
             // the four waves' shares of the single-step sums, added in a fixed order through LDS (the waves' state tiles are
             // free: every wave is past its last block)
-            float *red = SH + 8 * PR_SROWS * 64;                               // = the first wave's state tile: 4 x 64 x 4 floats
+            float *red = reinterpret_cast<float *>(SHl + 8 * PR_SROWS * PR_LD);     // = the first wave's tile: 4 x 64 x 4 floats
             __syncthreads();
             *reinterpret_cast<pr_float4 *>(red + (p * 64 + lane) * 4) = accs;
             __syncthreads();

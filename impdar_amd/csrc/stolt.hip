@@ -15,7 +15,6 @@
 // the contiguous axis and the trace transform is a strided batched C2C.
 #include "fft.h"
 #include "own_fft.h"
-#include <atomic>
 #include <mutex>
 #include <string>
 #include <sys/stat.h>
@@ -193,17 +192,11 @@ __global__ void stolt_fix_hermitian(Cx<T> *K, int m, int tnum)
 }
 
 struct StoltPlan {
-    // the two rocFFT plans being made by a thread of their own while the first call runs on the library's own row
-    // transforms (own_fft.h): 0 none, 1 running, 2 made, 3 failed
-    std::thread bg;
-    std::atomic<int> bg_state{0};
+    // the first call of a power-of-two size runs on the library's own row transforms (own_fft.h); the two rocFFT plans are
+    // made by the second call of the size (see phaseshift.hip: why not on a thread)
     bool plans_ready = false;
+    int own_calls = 0;
     OwnTwiddles tw_time, tw_trace;
-    void bg_join()
-    {
-        if (bg.joinable()) bg.join();
-    }
-    ~StoltPlan() { bg_join(); }
     int dtype = -1, snum = 0, tnum = 0;
     const impdar_ctx *owner = nullptr;   // plans and buffers live on this context's device and stream
     FftPlan r2c, c2c_f, c2c_b, c2r;     // separate passes (IMPDAR_STOLT_FFT=1d)
@@ -253,8 +246,7 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
     // power-of-two sizes: a FIRST call runs on the library's own row transforms while a thread makes the rocFFT plans
     const bool own_ok = want2d && snum % 2 == 0 && own_fft_len_ok(snum / 2) && own_fft_len_ok(tnum);
     if (pl.owner != ctx || pl.dtype != (dbl ? IMPDAR_F64 : IMPDAR_F32) || pl.snum != snum || pl.tnum != tnum || pl.use2d != want2d) {
-        pl.bg_join();                        // (a thread still making the old size's plans)
-        pl.bg_state = 0;
+        pl.own_calls = 0;
         pl.plans_ready = false;
         pl.dtype = -1;
         if (pl.owner != ctx) {               // another device / stream: drop everything bound to the old one
@@ -309,45 +301,20 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
     }
     bool use_own = false;
     if (own_ok) {
-        if (pl.bg_state == 2 || pl.bg_state == 3) {
-            const bool made = pl.bg_state == 2;
-            pl.bg_join();
-            pl.bg_state = 0;
-            if (made) {
-                pl.plans_ready = true;
-            } else {                             // made in the foreground, loudly
-                int rc;
-                if ((rc = pl.fwd2d.create2d(rocfft_transform_type_real_forward, dbl, false, snum, tnum, rocfft_array_type_real,
-                                            rocfft_array_type_hermitian_interleaved, snum, m, 1.0, st)) ||
-                    (rc = pl.inv2d.create2d(rocfft_transform_type_real_inverse, dbl, false, nout, tnum, rocfft_array_type_hermitian_interleaved,
-                                            rocfft_array_type_real, m, nout, 1.0 / ((double)nout * tnum), st)))
-                    return rc;
-                pl.plans_ready = true;
-            }
-        }
-        if (own_forced) {
+        if (own_forced || (!pl.plans_ready && pl.own_calls == 0)) {
             use_own = true;
-        } else if (!pl.plans_ready) {
-            use_own = true;
-            if (pl.bg_state == 0) {
-                pl.bg_state = 1;
-                const int device = ctx->device;
-                StoltPlan *plp = &pl;
-                impdar_trace("stolt: first call on the library's own transforms; 2 rocFFT plans on a thread");
-                pl.bg = std::thread([plp, device, snum, tnum, m, nout, st] {
-                    int rc = hipSetDevice(device) == hipSuccess ? IMPDAR_OK : IMPDAR_ERR_HIP;
-                    if (!rc) rc = plp->fwd2d.create2d(rocfft_transform_type_real_forward, dbl, false, snum, tnum, rocfft_array_type_real,
-                                                      rocfft_array_type_hermitian_interleaved, snum, m, 1.0, st);
-                    if (!rc) rc = plp->inv2d.create2d(rocfft_transform_type_real_inverse, dbl, false, nout, tnum,
-                                                      rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, m, nout,
-                                                      1.0 / ((double)nout * tnum), st);
-                    plp->bg_state = rc ? 3 : 2;
-                });
-            }
-        }
-        if (use_own) {
+            pl.own_calls += own_forced ? 0 : 1;
+            impdar_trace("stolt: transforms on the library's own row kernels");
             int rc;
             if ((rc = pl.tw_time.ensure<T>(snum, st)) || (rc = pl.tw_trace.ensure<T>(tnum, st))) return rc;
+        } else if (!pl.plans_ready) {
+            int rc;
+            if ((rc = pl.fwd2d.create2d(rocfft_transform_type_real_forward, dbl, false, snum, tnum, rocfft_array_type_real,
+                                        rocfft_array_type_hermitian_interleaved, snum, m, 1.0, st)) ||
+                (rc = pl.inv2d.create2d(rocfft_transform_type_real_inverse, dbl, false, nout, tnum, rocfft_array_type_hermitian_interleaved,
+                                        rocfft_array_type_real, m, nout, 1.0 / ((double)nout * tnum), st)))
+                return rc;
+            pl.plans_ready = true;
         }
     }
     IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_kx.p, kx, (size_t)tnum * 8, hipMemcpyHostToDevice, st));

@@ -185,8 +185,9 @@ int impdar_stolt_dev(impdar_ctx *ctx, const void *d_data, int dtype, int snum, i
                      double vtaper, void *d_out);
 
 /* ---- the library's own batched power-of-two row transforms (csrc/own_fft.h) ----
- * What a FIRST Stolt / phase-shift call of a process runs on while rocFFT's plans are still being made (rocFFT compiles
- * the kernels of lengths above 1024 at run time: 0.25-3 s per plan, profiles/r05_first_call.txt).  numpy.fft conventions
+ * What the FIRST Stolt / phase-shift call of a power-of-two size runs its transforms on (rocFFT compiles the kernels of
+ * lengths above 1024 at run time: 0.25-3 s per plan, profiles/r05_first_call.txt; the second call of a size makes the
+ * rocFFT plans).  numpy.fft conventions
  * (mig_python.py:159, 202, 270, 282), unnormalised, times `scale`.
  * mode 0: complex forward, 1: complex inverse -- d_in / d_out [batch][n] complex (d_out may be d_in);
  * mode 2: real forward -- d_in [batch][n] real, d_out [batch][n/2 + 1] complex;
