@@ -2009,6 +2009,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     bool mfma_done = false;
     const char *mfma_kernel_name = "";
     pl.mfma_instructions = -1.0;
+    int long_runs = 0;                       // runs of constant velocity longer than a smeared layer boundary (metrics)
     if constexpr (sizeof(T) == 4) {
         // float32: the frequency sums on the matrix cores when the depth axis is a few long runs of constant velocity
         std::vector<PsMfmaRun> mruns;
@@ -2023,17 +2024,19 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             mruns.push_back(PsMfmaRun{vconst, 0, snum});
         }
         // IMPDAR_PS_MFMA: 0 the vector kernels only; 2 / 3 only ps_mfma_kernel / only ps_runs_kernel of the two matrix-core
-        // paths (A/B runs, tests).  By themselves: up to 16 thick layers -> ps_mfma_kernel (64-step tiles, float16 hi / lo);
-        // more long runs -> ps_runs_kernel (8-step tiles, float32, phases generated in the kernel); whichever declines
+        // paths (A/B runs, tests).  By themselves: up to 10 thick layers -> ps_mfma_kernel (64-step tiles, phases from a table);
+        // more long runs -> ps_runs_kernel (8-step tiles, phases generated in the kernel); whichever declines
         // (ps_mfma_kernel: rows mostly padding on short records) hands over to the other, then to the vector kernels.
         const char *me = getenv("IMPDAR_PS_MFMA");
         const int pref = me ? atoi(me) : 1;
         int nlong = 0;
         for (const PsMfmaRun &r : mruns) nlong += r.len > PM_SHORT;
+        long_runs = nlong;
         const bool force_overflow = getenv("IMPDAR_PS_TEST_EDGE_OVERFLOW") != nullptr;
-        // (8192^2, equal layers, profiles/r05_ps_runs.txt: ps_mfma_kernel 9.1 / 12.5 / 15.9 / 19.4 / 26.7 ms at 4 / 5 / 9 / 13 / 21
-        // table rows -- about 7.5 + 0.96 ms per long run; ps_runs_kernel 19-23 ms up to 13 rows, 25.6 at 21, 29 at 41, 39 at 81)
-        const bool runs_first = vlen != 0 && nlong > 16;
+        // (8192^2, equal layers, profiles/r05_ps_runs.txt: ps_mfma_kernel 9.1 / 12.6 / 15.9 / 19.7 / 24.2 / 26.8 ms at 4 / 5 / 9 / 13 /
+        // 17 / 21 table rows -- about 7.5 + 0.96 ms per long run; ps_runs_kernel 16.5 / 17.6 / 18.6 / 17.9 / 20.0 at 5 / 9 / 13 / 17 /
+        // 21 rows, 23 at 41, 33 at 81: they cross at 10-11 long runs)
+        const bool runs_first = vlen != 0 && nlong > 6;
         for (int turn = 0; turn < 2 && ok && !mfma_done && pref != 0; ++turn) {
             const bool use_runs = (turn == 0) == runs_first;
             if (use_runs) {
@@ -2085,8 +2088,8 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     ctx->m_kernel_ms = -1.f;                 // (bracketed by ktic / ktoc)
     if (mfma_done)      // (MFMA instructions the kernel issued, counted by the kernel: rounds and blocks it skips are not in it)
         snprintf(ctx->m_extra, sizeof ctx->m_extra,
-                 "\"hermitian_walk\": %s, \"frequencies\": %d, \"transforms\": \"%s\", \"mfma_instructions\": %.0f, \"flop_per_mfma\": %d",
-                 herm ? "true" : "false", nf, use_own ? "own" : "rocfft", pl.mfma_instructions,
+                 "\"hermitian_walk\": %s, \"frequencies\": %d, \"transforms\": \"%s\", \"long_runs\": %d, \"mfma_instructions\": %.0f, \"flop_per_mfma\": %d",
+                 herm ? "true" : "false", nf, use_own ? "own" : "rocfft", long_runs, pl.mfma_instructions,
                  strcmp(mfma_kernel_name, "ps_runs_kernel") == 0 ? 16384 : 32768);
     else
         snprintf(ctx->m_extra, sizeof ctx->m_extra, "\"hermitian_walk\": %s, \"frequencies\": %d, \"transforms\": \"%s\"",

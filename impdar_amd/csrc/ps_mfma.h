@@ -176,7 +176,10 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
     const PsParams &P = Q.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = wave & (PM_NQ - 1), part = wave / PM_NQ;
-    const int g = (int)blockIdx.x % Q.ngroups, kb = (int)blockIdx.x / Q.ngroups, k = P.k0 + kb;
+    // wavenumbers from both ends of the axis in turn: small |kx| -- few evanescent frequencies, the long workgroups -- first
+    // (natural order: 0 .. tnum/2 ascending |kx|, then descending: the launch ended on its longest workgroups)
+    const int g = (int)blockIdx.x % Q.ngroups, bq = (int)blockIdx.x / Q.ngroups;
+    const int kb = (bq & 1) ? P.nk - 1 - (bq >> 1) : (bq >> 1), k = P.k0 + kb;
     const int om = lane % PM_CH, hh = lane / PM_CH;      // frequency of the chunk; which of its PM_NSUB generating lanes
     const Cp<float> *Frow = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.fstride;
     float *TKrow = reinterpret_cast<float *>(reinterpret_cast<Cp<float> *>(P.TK) + (size_t)kb * P.snum);

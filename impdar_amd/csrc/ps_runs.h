@@ -44,7 +44,9 @@ constexpr int PR_LONG_MAX = PR_NBLK * PR_ROWS * PR_TT;
 constexpr int PR_SHORT_LEN = 2;     // runs of up to this many steps: every step a row of its own
 constexpr int PR_SROWS = 12;        // single-step rows per stage
 constexpr int PR_STAGE_RUNS = 16;   // runs per stage
-constexpr int PR_LD = 36;            // dwords per tile row: 32 frequencies (one float16 pair each) + 4: the 16 rows a ds_read_b128 serves start on different banks
+constexpr int PR_LD = 32;            // dwords per tile row: 32 frequencies, one float16 pair each; the eight 16-byte slots of row r sit at slot ^ (r & 7):
+                                     // both the generating ds_write_b32 and the operands' ds_read_b128 touch every bank once (a padded row of 36
+                                     // dwords: SQ_LDS_BANK_CONFLICT 23 % of the LDS cycles, profiles/r05_ps_runs.txt)
 constexpr int PR_TILE = PR_ROWS * PR_LD;    // dwords per tile (hi or lo halves)
 constexpr size_t PR_LDS_FLOATS = 3 * 2 * PR_LONGS * 8 * 32 + 2 * 8 * PR_SROWS * PR_LD + PR_LONGS * 2 * PR_TILE + 16 + PR_STAGE_RUNS * 6;
 constexpr size_t PR_LDS_BYTES = PR_LDS_FLOATS * 4;
@@ -104,6 +106,10 @@ __device__ __forceinline__ void pr_sincos(double x, float *s, float *c)
     *c = ((q + 1) & 2) ? -cv : cv;
 }
 
+// dword of frequency f (0..31) in row r of a tile; first dword of the 16-byte slot of frequencies 4 q .. 4 q + 3
+__device__ __forceinline__ int pr_at(int r, int f) { return r * PR_LD + ((((f >> 2) ^ r) & 7) << 2) + (f & 3); }
+__device__ __forceinline__ int pr_slot(int r, int q) { return r * PR_LD + (((q ^ r) & 7) << 2); }
+
 __device__ __forceinline__ float2 pr_cmul(float2 a, float2 b)
 {
     return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
@@ -118,7 +124,9 @@ __global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
     // with the parts of a wavenumber side by side (part = block % 4) every XCD saw one part only: the low parts are mostly
     // evanescent and leave early, so four XCDs did most of the work (first form: 1.4 waves per SIMD on average, 43 ms).
     // The high, long-lived parts first.
-    const int part = Q.nparts - 1 - (int)blockIdx.x / P.nk, kb = (int)blockIdx.x % P.nk, k = P.k0 + kb;
+    // ... and inside a part the wavenumbers from both ends of the axis in turn (small |kx|: the long workgroups first).
+    const int part = Q.nparts - 1 - (int)blockIdx.x / P.nk, bq = (int)blockIdx.x % P.nk;
+    const int kb = (bq & 1) ? P.nk - 1 - (bq >> 1) : (bq >> 1), k = P.k0 + kb;
     // LDS: per long run (wave) and chunk the anchor state / tile rotation / step rotation of every frequency (float32); the
     // single-step state tiles of the 8 chunks; one operand tile per wave; the chunks' alive flags; the stage's runs
     float2 *TS = reinterpret_cast<float2 *>(pr_lds);
@@ -297,8 +305,8 @@ __global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
                             chain = in ? pr_cmul(chain, rot) : make_float2(0.f, 0.f);      // :464
                             const int row = slot + s_;
                             float rr, ri;
-                            SHh[(cc * PR_SROWS + row) * PR_LD + f] = pm_split(chain.x, chain.y, &rr, &ri);
-                            SHl[(cc * PR_SROWS + row) * PR_LD + f] = pm_pack(rr, ri);
+                            SHh[cc * PR_SROWS * PR_LD + pr_at(row, f)] = pm_split(chain.x, chain.y, &rr, &ri);
+                            SHl[cc * PR_SROWS * PR_LD + pr_at(row, f)] = pm_pack(rr, ri);
                             ph += inc;
                         }
                     }
@@ -333,18 +341,18 @@ __global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
                         const int b = 2 * jb + hh;
                         float rc, rs;
                         const unsigned h0 = pm_split(cb.x, cb.y, &rc, &rs), l0 = pm_pack(rc, rs);
-                        Wh[(2 * b) * PR_LD + gf] = pm_conj(h0);
-                        Wh[(2 * b + 1) * PR_LD + gf] = pm_swap(h0);
-                        Wl[(2 * b) * PR_LD + gf] = pm_conj(l0);
-                        Wl[(2 * b + 1) * PR_LD + gf] = pm_swap(l0);
+                        Wh[pr_at(2 * b, gf)] = pm_conj(h0);
+                        Wh[pr_at(2 * b + 1, gf)] = pm_swap(h0);
+                        Wl[pr_at(2 * b, gf)] = pm_conj(l0);
+                        Wl[pr_at(2 * b + 1, gf)] = pm_swap(l0);
                         cb = pr_cmul(cb, rB2);
                     }
                     __builtin_amdgcn_wave_barrier();
                     uint4 bh[2], bl[2];                                          // K-steps of 16 frequencies: this lane's 4 of each
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        bh[ks] = *reinterpret_cast<const uint4 *>(Wh + orow * PR_LD + 16 * ks + 4 * kk);
-                        bl[ks] = *reinterpret_cast<const uint4 *>(Wl + orow * PR_LD + 16 * ks + 4 * kk);
+                        bh[ks] = *reinterpret_cast<const uint4 *>(Wh + pr_slot(orow, 4 * ks + kk));
+                        bl[ks] = *reinterpret_cast<const uint4 *>(Wl + pr_slot(orow, 4 * ks + kk));
                     }
 #pragma unroll
                     for (int blk = 0; blk < PR_NBLK; ++blk) {
@@ -352,17 +360,19 @@ __global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
                         __builtin_amdgcn_wave_barrier();                        // (the tile's last readers are done: in-order LDS)
 #pragma unroll
                         for (int jr = 0; jr < PR_ROWS / 2; ++jr) {
+                            // (leaving out the rows past a run's last tile -- uniform breaks in the unrolled loop -- was slower:
+                            // 45 spilled SGPRs, 183 VGPRs, 23.0 -> 24.0 ms at 41 rows)
                             const int row = 2 * jr + hh;
                             float rr, ri;
-                            Wh[row * PR_LD + gf] = pm_split(cur.x, cur.y, &rr, &ri);
-                            Wl[row * PR_LD + gf] = pm_pack(rr, ri);
+                            Wh[pr_at(row, gf)] = pm_split(cur.x, cur.y, &rr, &ri);
+                            Wl[pr_at(row, gf)] = pm_pack(rr, ri);
                             cur = pr_cmul(cur, rA2);
                         }
                         __builtin_amdgcn_wave_barrier();
 #pragma unroll
                         for (int ks = 0; ks < 2; ++ks) {
-                            const pm_half8 a_hi = __builtin_bit_cast(pm_half8, *reinterpret_cast<const uint4 *>(Wh + orow * PR_LD + 16 * ks + 4 * kk));
-                            const pm_half8 a_lo = __builtin_bit_cast(pm_half8, *reinterpret_cast<const uint4 *>(Wl + orow * PR_LD + 16 * ks + 4 * kk));
+                            const pm_half8 a_hi = __builtin_bit_cast(pm_half8, *reinterpret_cast<const uint4 *>(Wh + pr_slot(orow, 4 * ks + kk)));
+                            const pm_half8 a_lo = __builtin_bit_cast(pm_half8, *reinterpret_cast<const uint4 *>(Wl + pr_slot(orow, 4 * ks + kk)));
                             const pm_half8 b_hi = __builtin_bit_cast(pm_half8, bh[ks]), b_lo = __builtin_bit_cast(pm_half8, bl[ks]);
                             acc[blk][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi, acc[blk][0], 0, 0, 0);
                             acc[blk][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo, acc[blk][1], 0, 0, 0);
@@ -383,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
                     if (!alive[c2]) continue;                                   // uniform over the workgroup
                     nmfma += 2;
                     // frequencies 8 p .. 8 p + 7 of the chunk: this wave's share (a K-step holds 16: the other 8 slots are zero)
-                    const int fo = (c2 * PR_SROWS + orow) * PR_LD + 8 * p + 4 * (kk & 1);
+                    const int fo = c2 * PR_SROWS * PR_LD + pr_slot(orow, 2 * p + (kk & 1));
                     uint4 ah = *reinterpret_cast<const uint4 *>(SHh + fo), al = *reinterpret_cast<const uint4 *>(SHl + fo);
                     if (kk >= 2) ah = al = make_uint4(0u, 0u, 0u, 0u);
                     accs = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pm_half8, ah), bu, accs, 0, 0, 0);

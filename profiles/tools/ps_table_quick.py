@@ -25,6 +25,6 @@ for nr in rows:
             d.migrate('phsh', vel=tab, htaper=100, vtaper=1000)
         v = C.c_float(); _hip.check(lib.impdar_ctx_last_ms(ctx, C.byref(v))); ms.append(round(v.value, 2))
         _hip.check(lib.impdar_ctx_last_kernel_ms(ctx, C.byref(v))); kms.append(round(v.value, 2))
-        buf = C.create_string_buffer(1024); _hip.check(lib.impdar_ctx_last_metrics(ctx, buf, len(buf))); kern = json.loads(buf.value.decode())['kernel']
+        buf = C.create_string_buffer(1024); _hip.check(lib.impdar_ctx_last_metrics(ctx, buf, len(buf))); mt = json.loads(buf.value.decode()); kern = mt['kernel']; nl = mt.get('long_runs')
         d._dev.free(); d._dev = None
-    print(json.dumps({'n': n, 'table rows': nr, 'kernel': kern, 'device_ms': ms, 'kernel_ms': kms}), flush=True)
+    print(json.dumps({'n': n, 'table rows': nr, 'long_runs': nl, 'kernel': kern, 'device_ms': ms, 'kernel_ms': kms}), flush=True)
