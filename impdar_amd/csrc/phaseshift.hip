@@ -1414,6 +1414,7 @@ static int ps_dispatch(const PsParams &P, hipStream_t st)
     return IMPDAR_OK;
 }
 
+#include "ps_pair.h"
 #include "ps_runs.h"        // many runs of constant velocity: float32 MFMA, phases generated in the kernel
 
 // did a matrix-core path find more boundary frequencies than it lists on this (kx, runs) geometry before?  (ADVICE r4:
@@ -1532,8 +1533,17 @@ static int ps_runs_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
     Q.mfma_count = pl.d_mcount.as<unsigned long long>();
     IMPDAR_HIP_CHECK(hipMemsetAsync(Q.edge_cnt, 0, (size_t)tnum * sizeof(int), st));
     IMPDAR_HIP_CHECK(hipMemsetAsync(Q.mfma_count, 0, 8, st));
-    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PR_LDS_BYTES));
-    hipLaunchKernelGGL(ps_runs_kernel, dim3((unsigned)P.nk * nparts), dim3(256), PR_LDS_BYTES, st, Q);
+    // the whole wavenumber axis with kx[tnum - k] = -kx[k]: rows k and tnum - k in one workgroup (ps_runs.h); a slab of a
+    // kx-sharded run has no mirror rows
+    bool pairs = P.k0 == 0 && P.nk == tnum && tnum >= 2;
+    for (int k = 1; 2 * k < tnum && pairs; ++k) pairs = kx_host[k] == -kx_host[tnum - k];      // (the Nyquist row of an even axis is its own partner)
+    if (pairs) {
+        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_runs_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pr_lds_bytes(2)));
+        hipLaunchKernelGGL(ps_runs_kernel<2>, dim3((unsigned)(tnum / 2 + 1) * nparts), dim3(256), pr_lds_bytes(2), st, Q);
+    } else {
+        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_runs_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pr_lds_bytes(1)));
+        hipLaunchKernelGGL(ps_runs_kernel<1>, dim3((unsigned)P.nk * nparts), dim3(256), pr_lds_bytes(1), st, Q);
+    }
     if (nparts > 1) {
         const size_t n = (size_t)P.nk * snum;
         hipLaunchKernelGGL((ps_smooth_sum_kernel<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
@@ -1573,9 +1583,10 @@ static int ps_runs_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
 // IMPDAR_OK with *done = true when the frequency sums were produced here; *done = false: not eligible, the vector
 // kernels take the call.
 static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &runs, bool vz, const double *kx_host, const double *thr,
-                       hipStream_t st, bool *done)
+                       hipStream_t st, bool *done, bool allow_pairs, const char **kernel_name)
 {
     *done = false;
+    *kernel_name = "ps_mfma_kernel";
     const int snum = P.snum, tnum = P.tnum;
     if (vz && ps_known_overflow(pl, kx_host, tnum, runs)) return IMPDAR_OK;
     if (P.nf % (PM_CH * PM_NQ) != 0 || P.nf < 256 || P.nf > 4096 + 2048 || snum < 256 || runs.empty() || (int)runs.size() > PM_MAX_RUNS) return IMPDAR_OK;
@@ -1652,8 +1663,18 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
         else if (P.nf <= 4096) hipLaunchKernelGGL(ps_setup_kernel<8>, dim3(P.nk), dim3(512), lds, st, Q);
         else hipLaunchKernelGGL(ps_setup_kernel<12>, dim3(P.nk), dim3(512), lds, st, Q);
     }
-    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PM_LDS_BYTES));
-    hipLaunchKernelGGL(ps_mfma_kernel, dim3((unsigned)P.nk * Q.ngroups), dim3(PM_WAVES * 64), PM_LDS_BYTES, st, Q);
+    // the whole wavenumber axis with kx[tnum - k] = -kx[k]: rows k and tnum - k turn by the same angles -- ps_pair_kernel makes
+    // the state tiles once for both (ps_pair.h); a slab of a kx-sharded run keeps ps_mfma_kernel
+    bool pairs = allow_pairs && P.k0 == 0 && P.nk == tnum && tnum >= 2;
+    for (int k = 1; 2 * k < tnum && pairs; ++k) pairs = kx_host[k] == -kx_host[tnum - k];      // (the Nyquist row of an even axis is its own partner)
+    if (pairs) {
+        *kernel_name = "ps_pair_kernel";
+        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_LDS_BYTES));
+        hipLaunchKernelGGL(ps_pair_kernel, dim3((unsigned)(tnum / 2 + 1) * Q.ngroups), dim3(PP_WAVES * 64), PP_LDS_BYTES, st, Q);
+    } else {
+        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PM_LDS_BYTES));
+        hipLaunchKernelGGL(ps_mfma_kernel, dim3((unsigned)P.nk * Q.ngroups), dim3(PM_WAVES * 64), PM_LDS_BYTES, st, Q);
+    }
     if (vz) hipLaunchKernelGGL(ps_edge_kernel, dim3(P.nk), dim3(256), 0, st, Q);
     IMPDAR_HIP_CHECK(hipGetLastError());
     // the host table must outlive its async copy
@@ -2023,8 +2044,9 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         } else {
             mruns.push_back(PsMfmaRun{vconst, 0, snum});
         }
-        // IMPDAR_PS_MFMA: 0 the vector kernels only; 2 / 3 only ps_mfma_kernel / only ps_runs_kernel of the two matrix-core
-        // paths (A/B runs, tests).  By themselves: up to 10 thick layers -> ps_mfma_kernel (64-step tiles, phases from a table);
+        // IMPDAR_PS_MFMA: 0 the vector kernels only; 2 / 3 only ps_mfma_kernel / only ps_runs_kernel of the matrix-core
+        // paths; 5 as 2 with ps_pair_kernel (two wavenumbers per workgroup: an experiment that did not pay, ps_pair.h) where
+        // it applies (A/B runs, tests).  By themselves: up to 3 thick layers -> ps_mfma_kernel (64-step tiles, phases from a table);
         // more long runs -> ps_runs_kernel (8-step tiles, phases generated in the kernel); whichever declines
         // (ps_mfma_kernel: rows mostly padding on short records) hands over to the other, then to the vector kernels.
         const char *me = getenv("IMPDAR_PS_MFMA");
@@ -2033,20 +2055,21 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         for (const PsMfmaRun &r : mruns) nlong += r.len > PM_SHORT;
         long_runs = nlong;
         const bool force_overflow = getenv("IMPDAR_PS_TEST_EDGE_OVERFLOW") != nullptr;
-        // (8192^2, equal layers, profiles/r05_ps_runs.txt: ps_mfma_kernel 9.1 / 12.6 / 15.9 / 19.7 / 24.2 / 26.8 ms at 4 / 5 / 9 / 13 /
-        // 17 / 21 table rows -- about 7.5 + 0.96 ms per long run; ps_runs_kernel 16.5 / 17.6 / 18.6 / 17.9 / 20.0 at 5 / 9 / 13 / 17 /
-        // 21 rows, 23 at 41, 33 at 81: they cross at 10-11 long runs)
-        const bool runs_first = vlen != 0 && nlong > 6;
+        // (8192^2 device ms, equal layers, profiles/r05_ps_runs.txt: ps_mfma_kernel 12.9 / 15.7 / 16.0 / 19.7 / 26.8 at 3 / 4 / 5 / 7 /
+        // 11 long runs -- and 10.8 on the config-5 table; ps_runs_kernel, two wavenumbers per workgroup, 11.8 / 11.9 / 12.4 /
+        // 12.8 / 13.8 at 3 / 4 / 5 / 7 / 11 long runs, 15.3 at 21, 21.3 at 42, 12.0 on the config-5 table)
+        const bool runs_first = vlen != 0 && nlong > 3;
         for (int turn = 0; turn < 2 && ok && !mfma_done && pref != 0; ++turn) {
             const bool use_runs = (turn == 0) == runs_first;
             if (use_runs) {
-                if (pref == 2 || !vlen || force_overflow) continue;
+                if (pref == 2 || pref == 5 || !vlen || force_overflow) continue;
                 if ((rc = ps_runs_run(pl, P, mruns, kx, w.data(), thr.data(), st, &mfma_done))) return rc;
                 if (mfma_done) mfma_kernel_name = "ps_runs_kernel";
             } else {
                 if (pref == 3) continue;
-                if ((rc = ps_mfma_run(pl, P, mruns, vlen != 0, kx, thr.data(), st, &mfma_done))) return rc;
-                if (mfma_done) mfma_kernel_name = "ps_mfma_kernel";
+                const char *name = "";
+                if ((rc = ps_mfma_run(pl, P, mruns, vlen != 0, kx, thr.data(), st, &mfma_done, pref == 5, &name))) return rc;
+                if (mfma_done) mfma_kernel_name = name;
             }
         }
     }

@@ -18,7 +18,7 @@ tab = np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rp], [1.8e8, 0.5 * Rp], [1.9e8, 1.2
 out = {}
 flat = np.array([[1.69e8, 0.], [1.69e8, 10. * Rp]])      # one constant-velocity run through the v(z) kernel
 for name, vel in (('const', 1.69e8), ('vz', tab), ('vz_flat', flat)):
-    ms = []
+    ms, kms = [], []
     for i in range(reps + 1):
         d = RadarData(None)
         d.data, (d.snum, d.tnum) = x, x.shape
@@ -29,7 +29,10 @@ for name, vel in (('const', 1.69e8), ('vz', tab), ('vz_flat', flat)):
         v = C.c_float()
         _hip.check(lib.impdar_ctx_last_ms(ctx, C.byref(v)), 'impdar_ctx_last_ms')
         ms.append(v.value)
+        _hip.check(lib.impdar_ctx_last_kernel_ms(ctx, C.byref(v)), 'impdar_ctx_last_kernel_ms')
+        kms.append(v.value)
+        buf = C.create_string_buffer(1024); _hip.check(lib.impdar_ctx_last_metrics(ctx, buf, len(buf))); kern = json.loads(buf.value.decode())['kernel']
         d._dev.free()
         d._dev = None
-    out[name] = {'device_ms': float(np.median(ms[1:])), 'all': [round(m, 2) for m in ms]}
+    out[name] = {'kernel': kern, 'device_ms': round(float(np.median(ms[1:])), 2), 'kernel_ms': round(float(np.median(kms[1:])), 2), 'all': [round(m, 2) for m in ms]}
 print(json.dumps(out))

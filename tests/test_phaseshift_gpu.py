@@ -296,8 +296,13 @@ def test_matrix_core_path_against_the_vector_kernels_and_the_oracle(hip, monkeyp
            'boundary': np.array([[1.68e8, 0.], [1.68e8, 0.45 * Rp], [1.8e8, 0.7 * Rp], [1.9e8, 1.2 * Rp]])}[kind]
     want = mig_oracle.phase_shift(data.astype(np.float64), geo['dt'], geo['trace_int'], geo['travel_time'],
                                   geo['dist'], vel, 20, 30)
-    outs = {}
-    for mfma, herm in (('1', '1'), ('0', '1'), ('1', '0')):
+    import ctypes as C
+    import json
+    from impdar_amd import _hip
+    outs, kernels = {}, {}
+    # '5': ps_pair_kernel (the wavenumbers kx and -kx in one workgroup, state tiles made once for both -- an odd and two even
+    # trace counts: k = 0 and the Nyquist row are their own partners; not the default: it is no faster); '2': ps_mfma_kernel
+    for mfma, herm in (('5', '1'), ('2', '1'), ('0', '1'), ('5', '0'), ('2', '0')):
         monkeypatch.setenv('IMPDAR_PS_MFMA', mfma)
         monkeypatch.setenv('IMPDAR_PS_HERMITIAN', herm)
         d = RadarData(None)
@@ -306,11 +311,21 @@ def test_matrix_core_path_against_the_vector_kernels_and_the_oracle(hip, monkeyp
         migrationlib.migrationPhaseShift(d, vel=vel, htaper=20, vtaper=30)
         outs[mfma, herm] = d.data
         assert rel_l2(d.data, want) < F32_L2, (mfma, herm, rel_l2(d.data, want))
-    print('%s %dx%d: rel L2 vs oracle: matrix cores %.2e, vector kernels %.2e, matrix cores on the full walk %.2e'
-          % (kind, snum, tnum, rel_l2(outs['1', '1'], want), rel_l2(outs['0', '1'], want), rel_l2(outs['1', '0'], want)))
-    assert rel_l2(outs['1', '1'], outs['0', '1']) < F32_L2
-    # the matrix-core result must not be worse than a few times the vector kernels' own float32 error
-    assert rel_l2(outs['1', '1'], want) < max(5.0 * rel_l2(outs['0', '1'], want), 2e-6)
+        buf = C.create_string_buffer(1024)
+        _hip.check(_hip.load().impdar_ctx_last_metrics(_hip.context(), buf, len(buf)), 'metrics')
+        kernels[mfma, herm] = json.loads(buf.value.decode())['kernel']
+    print('%s %dx%d: rel L2 vs oracle: pairs %.2e, one wavenumber per workgroup %.2e, vector kernels %.2e, on the full walk %.2e / %.2e'
+          % (kind, snum, tnum, rel_l2(outs['5', '1'], want), rel_l2(outs['2', '1'], want), rel_l2(outs['0', '1'], want),
+             rel_l2(outs['5', '0'], want), rel_l2(outs['2', '0'], want)))
+    for herm in ('1', '0'):      # (short records with layers: rows mostly padding, both decline)
+        assert (kernels['5', herm], kernels['2', herm]) in (('ps_pair_kernel', 'ps_mfma_kernel'), (kernels['0', '1'], kernels['0', '1'])), kernels
+    if kind == 'const':
+        assert kernels['5', '1'] == 'ps_pair_kernel', kernels
+    assert 'mfma' not in kernels['0', '1'] and 'pair' not in kernels['0', '1'], kernels
+    for m in ('5', '2'):
+        assert rel_l2(outs[m, '1'], outs['0', '1']) < F32_L2
+        # the matrix-core result must not be worse than a few times the vector kernels' own float32 error
+        assert rel_l2(outs[m, '1'], want) < max(5.0 * rel_l2(outs['0', '1'], want), 2e-6), (m, rel_l2(outs[m, '1'], want))
 
 
 @pytest.mark.parametrize('snum,tnum', [(520, 33), (700, 24), (1100, 40), (2100, 16), (4200, 6)])
@@ -374,7 +389,7 @@ def test_many_runs_matrix_core_path_against_the_vector_kernels_and_the_oracle(hi
     _hip.check(_hip.load().impdar_ctx_last_metrics(_hip.context(), buf, len(buf)), 'metrics')
     chosen = json.loads(buf.value.decode())['kernel']
     # (up to 16 long runs: ps_mfma_kernel where its 2048-step row blocks are not mostly padding, i.e. on long records)
-    assert chosen in ('ps_runs_kernel', 'ps_mfma_kernel'), (kind, chosen)
+    assert chosen in ('ps_runs_kernel', 'ps_mfma_kernel', 'ps_pair_kernel'), (kind, chosen)
     assert chosen == 'ps_runs_kernel' or kind not in ('layers40',), (kind, chosen)
     if chosen == 'ps_runs_kernel':      # (the same sums; the transforms around them may be the library's own or rocFFT's by now)
         assert rel_l2(d.data, outs['3', '1']) < 5e-6
