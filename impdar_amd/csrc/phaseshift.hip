@@ -190,6 +190,7 @@ struct PsParams {
     const double *sm_step, *sm_tile;   // float32, ps_smooth32_kernel: the tables of ps_smooth_tables
     void *sm_part;          // ps_smooth kernels: [sm_nchunks][nk][snum] complex partial images (more than one chunk)
     int sm_nchunks;
+    int sm_m;               // ... and the frequencies per lane of a wave (chunks of 64 sm_m)
     const double *eps;      // float64 v(z), ps_vz64_kernel: [ceil(snum/16)] sum over the tile's steps of v / v_run - 1
     int snum, tnum, nt, vz_mode;
     // Frequency slots a workgroup walks.  Full walk: nf = nt, slot i = row i of F.  Hermitian walk (herm = 1, real
@@ -1923,6 +1924,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     P.sm_step = P.sm_tile = nullptr;
     P.sm_part = nullptr;
     P.sm_nchunks = 1;
+    P.sm_m = 8;
     std::vector<int> sched, rowmap;
     std::vector<double> epsum;
     if (vlen) {
@@ -2080,7 +2082,11 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         bool ok = true;
         for (int i = 0; i < snum && ok; ++i) ok = std::isfinite(vmig[i]) && vmig[i] != 0.0 && thr[i] < 1e-10;
         if (ok) {
-            P.sm_nchunks = ps_smooth_chunks(nf);
+            // float32, the whole wavenumber axis with kx[tnum - k] = -kx[k]: rows k and tnum - k in one wave (ps_smooth.h)
+            bool sm_pairs = P.k0 == 0 && nk == tnum && tnum >= 2;
+            for (int k = 1; 2 * k < tnum && sm_pairs; ++k) sm_pairs = kx[k] == -kx[tnum - k];
+            P.sm_m = ps_smooth_m(dbl, sm_pairs);
+            P.sm_nchunks = ps_smooth_chunks(nf, P.sm_m);
             const size_t part_bytes = P.sm_nchunks > 1 ? (size_t)P.sm_nchunks * nk * snum * sizeof(Cp<T>) : 0;
             std::vector<double> &sm_step = pl.h_sm_step, &sm_tile = pl.h_sm_tile;     // (alive until the next call: async copies)
             if (sizeof(T) == 4) ps_smooth_tables(vmig, thr.data(), snum, sm_step, sm_tile);
@@ -2095,7 +2101,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
                     P.sm_tile = pl.d_sm.as<double>() + sm_step.size();
                 }
                 P.sm_part = pl.d_part.p;
-                ps_smooth_launch<T>(P, st);
+                ps_smooth_launch<T>(P, st, sm_pairs);
                 IMPDAR_HIP_CHECK(hipGetLastError());
                 t_ps_kernel = sizeof(T) == 4 ? "ps_smooth32_kernel" : "ps_smooth_kernel";
                 smooth_done = true;

@@ -94,7 +94,9 @@ template <typename T> __device__ __forceinline__ void pss_write_tile(T (&acc)[2 
     }
 }
 
-template <int M>
+// NMEM = 2: the wave takes the wavenumbers kx and -kx (rows k and tnum - k) together: y, g, the band and the rotation R depend
+// on kx^2 only -- 26 of the ~32 instructions per (step, frequency) -- the state's rotation and the sums are per wavenumber.
+template <int M, int NMEM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps_smooth_kernel(PsParams P)
 {
     using T = double;
@@ -103,28 +105,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
     // other waits ~16 cycles for each), ONE branch per group for the band, and a group whose frequencies have turned
     // evanescent in all 64 lanes is skipped
     constexpr int G = M < 2 ? M : 2;
-    __shared__ Cp<T> part[TT][64];                        // per-step partial sums of a lane's frequencies
+    __shared__ Cp<T> part[NMEM][TT][64];                  // per-step partial sums of a lane's frequencies
     __shared__ double4 stepc[2][TT];                      // the steps' {c = v^2, band, threshold, v}
-    const int k = P.k0 + blockIdx.x, chunk = gridDim.y - 1 - blockIdx.y;     // (the high, busy chunks first)
+    const int chunk = gridDim.y - 1 - blockIdx.y;         // (the high, busy chunks first)
     const int lane = threadIdx.x;
-    const Cp<T> *F = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k * P.fstride;
-    Cp<T> *out = reinterpret_cast<Cp<T> *>(P.sm_nchunks > 1 ? P.sm_part : P.TK) +
-                 ((size_t)(P.sm_nchunks > 1 ? chunk : 0) * P.nk + (k - P.k0)) * P.snum;
+    int km[NMEM];                                         // rows of the wavenumber axis
+    km[0] = P.k0 + blockIdx.x;
+    if (NMEM == 2) km[NMEM - 1] = (P.tnum - (int)blockIdx.x) % P.tnum;
+    const bool has_b = NMEM == 2 && km[NMEM - 1] != km[0];    // (k = 0 and the Nyquist row are their own partners)
+    const int k = km[0];
+    const Cp<T> *F[NMEM];
+    Cp<T> *out[NMEM];
+#pragma unroll
+    for (int mm = 0; mm < NMEM; ++mm) {
+        F[mm] = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)km[mm] * P.fstride;
+        out[mm] = reinterpret_cast<Cp<T> *>(P.sm_nchunks > 1 ? P.sm_part : P.TK) +
+                  ((size_t)(P.sm_nchunks > 1 ? chunk : 0) * P.nk + (km[mm] - P.k0)) * P.snum;
+    }
     const bool final_scale = P.sm_nchunks == 1;
     const double kxk = P.kx[k];
 
     // per owned frequency: x = (kx / 2w)^2, w dt, y = sqrt(coss) and g ~ 1 / (2 y) of the last step
     double x[M], wdt[M], y[M], g[M];
-    T sr_[M], si_[M], rc[M], rs[M];                       // state FK and rotation R = exp(i phi)
+    T sr_[NMEM][M], si_[NMEM][M], rc[M], rs[M];           // states FK and rotation R = exp(i phi)
     unsigned dead = 0;                                    // bit m: frequency m of this lane has turned evanescent
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const int slot = (chunk * M + m) * 64 + lane;
-        Cp<T> f;
-        f.x = f.y = 0;
+        Cp<T> f[NMEM];
+#pragma unroll
+        for (int mm = 0; mm < NMEM; ++mm) f[mm].x = f[mm].y = 0;
         double w = 1.0;
         if (slot < P.nf) {
-            f = ps_load_slot<T>(F, P, slot);
+            f[0] = ps_load_slot<T>(F[0], P, slot);
+            if (NMEM == 2 && has_b) f[NMEM - 1] = ps_load_slot<T>(F[NMEM - 1], P, slot);
             w = P.w[slot];
         } else {
             dead |= 1u << m;
@@ -134,8 +148,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
         wdt[m] = w * P.dt;
         y[m] = 1.0;
         g[m] = 0.5;
-        sr_[m] = f.x;
-        si_[m] = f.y;
+#pragma unroll
+        for (int mm = 0; mm < NMEM; ++mm) {
+            sr_[mm][m] = f[mm].x;
+            si_[mm][m] = f[mm].y;
+        }
         rc[m] = 1;
         rs[m] = 0;
     }
@@ -172,13 +189,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
         if (all_out) {                                    // uniform: zeros from here to the end of the record
             Cp<T> z;
             z.x = z.y = 0;
-            for (int tau = tau0 + lane; tau < P.snum; tau += 64) out[tau] = z;
+#pragma unroll
+            for (int mm = 0; mm < NMEM; ++mm)
+                if (mm == 0 || has_b)
+                    for (int tau = tau0 + lane; tau < P.snum; tau += 64) out[mm][tau] = z;
             return;
         }
 #pragma unroll 1
         for (int t = 0; t < TT; ++t) {
             const int tau = tau0 + t;
-            T psr = 0, psi = 0;
+            T psr[NMEM], psi[NMEM];
+#pragma unroll
+            for (int mm = 0; mm < NMEM; ++mm) psr[mm] = psi[mm] = 0;
             if (tau < P.snum) {                                   // uniform
                 const double4 sc = stepc[tile & 1][t];
                 const double c = sc.x, csb = sc.y;
@@ -285,8 +307,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
                                     // good -- a velocity that falls again must not revive the carried values of such a
                                     // lane, which are parked where they stay finite)
                                     dead |= 1u << m;
-                                    sr_[m] = 0;
-                                    si_[m] = 0;
+#pragma unroll
+                                    for (int mm = 0; mm < NMEM; ++mm) sr_[mm][m] = si_[mm][m] = 0;
                                     x[m] = 0.0;
                                     q[j].y2 = 1.0;
                                     q[j].gn = 0.5;
@@ -343,31 +365,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
                         g[m] = q[j].gn;
                         rc[m] = q[j].ncr;
                         rs[m] = q[j].nsr;
-                        const T nr = fma(sr_[m], q[j].ncr, -(si_[m] * q[j].nsr));     // FK *= exp(i phi), :464
-                        const T ni = fma(sr_[m], q[j].nsr, si_[m] * q[j].ncr);
-                        sr_[m] = nr;
-                        si_[m] = ni;
-                        psr += nr;                                                  // :487
-                        psi += ni;
+#pragma unroll
+                        for (int mm = 0; mm < NMEM; ++mm) {
+                            const T nr = fma(sr_[mm][m], q[j].ncr, -(si_[mm][m] * q[j].nsr));     // FK *= exp(i phi), :464
+                            const T ni = fma(sr_[mm][m], q[j].nsr, si_[mm][m] * q[j].ncr);
+                            sr_[mm][m] = nr;
+                            si_[mm][m] = ni;
+                            psr[mm] += nr;                                          // :487
+                            psi[mm] += ni;
+                        }
                     }
-                    asm volatile("" : "+v"(psr), "+v"(psi));
+#pragma unroll
+                    for (int mm = 0; mm < NMEM; ++mm) asm volatile("" : "+v"(psr[mm]), "+v"(psi[mm]));
                 }
 #undef PSS_PIN
 #undef PSS_EACH
             }
-            Cp<T> pv;
-            pv.x = psr;
-            pv.y = psi;
-            part[t][lane] = pv;                           // (each lane reads back only what it wrote)
-        }
-        T acc[2 * TT];
 #pragma unroll
-        for (int t = 0; t < TT; ++t) {
-            const Cp<T> pv = part[t][lane];
-            acc[2 * t] = pv.x;
-            acc[2 * t + 1] = pv.y;
+            for (int mm = 0; mm < NMEM; ++mm) {
+                Cp<T> pv;
+                pv.x = psr[mm];
+                pv.y = psi[mm];
+                part[mm][t][lane] = pv;                   // (each lane reads back only what it wrote)
+            }
         }
-        pss_write_tile<T>(acc, lane, out, tau0, P.snum, final_scale);
+#pragma unroll
+        for (int mm = 0; mm < NMEM; ++mm) {
+            if (mm == 1 && !has_b) break;                 // uniform
+            T acc[2 * TT];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const Cp<T> pv = part[mm][t][lane];
+                acc[2 * t] = pv.x;
+                acc[2 * t + 1] = pv.y;
+            }
+            pss_write_tile<T>(acc, lane, out[mm], tau0, P.snum, final_scale);
+        }
         // R itself is re-anchored every 128 steps: R *= exp(i d) rounds once per step (1e-16), so R's phase is off by
         // ~tau 1e-16 after tau steps, and the state, which integrates R, by ~tau^2 / 2 of that: 4.4e-10 of the image
         // maximum at 8192 steps (round 5: the 8192^2 spot-wavenumber test; 4e-12 with the anchors).  Here, between two
@@ -477,36 +510,51 @@ __device__ __forceinline__ void pss_scalar_load_4f64(const double *p, double *a,
     *d = w;
 }
 
-template <int M>
+// NMEM = 2: the wave takes the wavenumbers kx and -kx (rows k and tnum - k) together -- coss, the expansion, the band and every
+// step's rotation depend on kx^2 only (:456-460): 13 of the 19 instructions per (step, frequency) are shared, the state's
+// rotation and the sums (6) are per wavenumber.  blockIdx.x = the pair.
+template <int M, int NMEM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps_smooth32_kernel(PsParams P)
 {
     using T = float;
     constexpr int TT = PSS_TT;
     constexpr int ANCHOR_TILES = 4;
     constexpr int G = M < 2 ? M : 2;
-    __shared__ Cp<T> f0_lds[M][64];                       // original spectrum (the anchors rotate it)
-    __shared__ Cp<T> part[TT][64];                        // per-step partial sums of a lane's frequencies
+    __shared__ Cp<T> f0_lds[NMEM][M][64];                 // original spectra (the anchors rotate them)
+    __shared__ Cp<T> part[NMEM][TT][64];                  // per-step partial sums of a lane's frequencies
     __shared__ double4 stepc[2][TT];                      // the steps' {c, thr, v, delta}
-    const int k = P.k0 + blockIdx.x, chunk = gridDim.y - 1 - blockIdx.y;     // (the high, busy chunks first)
+    const int chunk = gridDim.y - 1 - blockIdx.y;         // (the high, busy chunks first)
     const int lane = threadIdx.x;
-    const Cp<T> *F = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k * P.fstride;
-    Cp<T> *out = reinterpret_cast<Cp<T> *>(P.sm_nchunks > 1 ? P.sm_part : P.TK) +
-                 ((size_t)(P.sm_nchunks > 1 ? chunk : 0) * P.nk + (k - P.k0)) * P.snum;
+    int km[NMEM];                                         // rows of the wavenumber axis
+    km[0] = P.k0 + blockIdx.x;
+    if (NMEM == 2) km[NMEM - 1] = (P.tnum - (int)blockIdx.x) % P.tnum;
+    const bool has_b = NMEM == 2 && km[NMEM - 1] != km[0];    // (k = 0 and the Nyquist row are their own partners)
+    const int k = km[0];
+    const Cp<T> *F[NMEM];
+    Cp<T> *out[NMEM];
+#pragma unroll
+    for (int mm = 0; mm < NMEM; ++mm) {
+        F[mm] = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)km[mm] * P.fstride;
+        out[mm] = reinterpret_cast<Cp<T> *>(P.sm_nchunks > 1 ? P.sm_part : P.TK) +
+                  ((size_t)(P.sm_nchunks > 1 ? chunk : 0) * P.nk + (km[mm] - P.k0)) * P.snum;
+    }
     const bool final_scale = P.sm_nchunks == 1;
     const double kxk = P.kx[k];
     const double4 *gstep = reinterpret_cast<const double4 *>(P.sm_step);
 
     double x[M], wdt[M], Phi[M], Kp[M];                   // (kx / 2w)^2, w dt, phase at the END of the tile, w dt y_a
-    T sr_[M], si_[M], ca[M], sa[M], xi[M], Kf[M];         // state FK, R_a = exp(i w dt y_a), x / coss_a, w dt y_a
+    T sr_[NMEM][M], si_[NMEM][M], ca[M], sa[M], xi[M], Kf[M];     // states FK, R_a = exp(i w dt y_a), x / coss_a, w dt y_a
     unsigned dead = 0;                                    // bit m: frequency m of this lane has turned evanescent
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const int slot = (chunk * M + m) * 64 + lane;
-        Cp<T> f;
-        f.x = f.y = 0;
+        Cp<T> f[NMEM];
+#pragma unroll
+        for (int mm = 0; mm < NMEM; ++mm) f[mm].x = f[mm].y = 0;
         double w = 1.0;
         if (slot < P.nf) {
-            f = ps_load_slot<T>(F, P, slot);
+            f[0] = ps_load_slot<T>(F[0], P, slot);
+            if (NMEM == 2 && has_b) f[NMEM - 1] = ps_load_slot<T>(F[NMEM - 1], P, slot);
             w = P.w[slot];
         } else {
             dead |= 1u << m;
@@ -516,9 +564,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
         wdt[m] = w * P.dt;
         Phi[m] = 0.0;
         Kp[m] = 0.0;
-        f0_lds[m][lane] = f;
-        sr_[m] = f.x;
-        si_[m] = f.y;
+#pragma unroll
+        for (int mm = 0; mm < NMEM; ++mm) {
+            f0_lds[mm][m][lane] = f[mm];
+            sr_[mm][m] = f[mm].x;
+            si_[mm][m] = f[mm].y;
+        }
         ca[m] = 1;
         sa[m] = 0;
         xi[m] = 0;
@@ -545,10 +596,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
                 Phi[m] = ph;
                 T sn, cs;
                 sincos_t<T>((T)ph, &sn, &cs);
-                const Cp<T> f0 = f0_lds[m][lane];
-                sr_[m] = fma(f0.x, cs, -(f0.y * sn));
-                si_[m] = fma(f0.x, sn, f0.y * cs);
-                asm volatile("" : "+v"(sr_[m]), "+v"(si_[m]));
+#pragma unroll
+                for (int mm = 0; mm < NMEM; ++mm) {
+                    const Cp<T> f0 = f0_lds[mm][m][lane];
+                    sr_[mm][m] = fma(f0.x, cs, -(f0.y * sn));
+                    si_[mm][m] = fma(f0.x, sn, f0.y * cs);
+                    asm volatile("" : "+v"(sr_[mm][m]), "+v"(si_[mm][m]));
+                }
             }
         }
         // groups all of whose frequencies, in all 64 lanes, are out
@@ -631,13 +685,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
         if (all_out) {                                    // uniform: zeros from here to the end of the record
             Cp<T> z;
             z.x = z.y = 0;
-            for (int tau = tau0 + lane; tau < P.snum; tau += 64) out[tau] = z;
+#pragma unroll
+            for (int mm = 0; mm < NMEM; ++mm)
+                if (mm == 0 || has_b)
+                    for (int tau = tau0 + lane; tau < P.snum; tau += 64) out[mm][tau] = z;
             return;
         }
 #pragma unroll 1
         for (int t = 0; t < TT; ++t) {
             const int tau = tau0 + t;
-            T psr = 0, psi = 0;
+            T psr[NMEM], psi[NMEM];
+#pragma unroll
+            for (int mm = 0; mm < NMEM; ++mm) psr[mm] = psi[mm] = 0;
             if (tau < P.snum) {                                   // uniform
                 const double4 sc = stepc[tile & 1][t];
                 const T dl = (T)sc.w;
@@ -711,11 +770,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
                                 if (cr <= thr || ((dead >> m) & 1u)) {
                                     // evanescent: zero from here on (:484-485 zero the spectrum itself: once out, out for good)
                                     dead |= 1u << m;
-                                    sr_[m] = 0;
-                                    si_[m] = 0;
                                     Cp<T> z;
                                     z.x = z.y = 0;
-                                    f0_lds[m][lane] = z;
+#pragma unroll
+                                    for (int mm = 0; mm < NMEM; ++mm) {
+                                        sr_[mm][m] = 0;
+                                        si_[mm][m] = 0;
+                                        f0_lds[mm][m][lane] = z;
+                                    }
                                     x[m] = 0.0;
                                     q[j].ncr = 1;
                                     q[j].nsr = 0;
@@ -741,51 +803,75 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
                     }
 #pragma unroll
                     PSS_EACH {
-                        const T nr = fma(sr_[m], q[j].ncr, -(si_[m] * q[j].nsr));     // FK *= exp(i phi), :464
-                        const T ni = fma(sr_[m], q[j].nsr, si_[m] * q[j].ncr);
-                        sr_[m] = nr;
-                        si_[m] = ni;
-                        psr += nr;                                                  // :487
-                        psi += ni;
+#pragma unroll
+                        for (int mm = 0; mm < NMEM; ++mm) {
+                            const T nr = fma(sr_[mm][m], q[j].ncr, -(si_[mm][m] * q[j].nsr));     // FK *= exp(i phi), :464
+                            const T ni = fma(sr_[mm][m], q[j].nsr, si_[mm][m] * q[j].ncr);
+                            sr_[mm][m] = nr;
+                            si_[mm][m] = ni;
+                            psr[mm] += nr;                                          // :487
+                            psi[mm] += ni;
+                        }
                     }
-                    asm volatile("" : "+v"(psr), "+v"(psi));
+#pragma unroll
+                    for (int mm = 0; mm < NMEM; ++mm) asm volatile("" : "+v"(psr[mm]), "+v"(psi[mm]));
                 }
 #undef PSS_PIN
 #undef PSS_EACH
             }
-            Cp<T> pv;
-            pv.x = psr;
-            pv.y = psi;
-            part[t][lane] = pv;                           // (each lane reads back only what it wrote)
-        }
-        T acc[2 * TT];
 #pragma unroll
-        for (int t = 0; t < TT; ++t) {
-            const Cp<T> pv = part[t][lane];
-            acc[2 * t] = pv.x;
-            acc[2 * t + 1] = pv.y;
+            for (int mm = 0; mm < NMEM; ++mm) {
+                Cp<T> pv;
+                pv.x = psr[mm];
+                pv.y = psi[mm];
+                part[mm][t][lane] = pv;                   // (each lane reads back only what it wrote)
+            }
         }
-        pss_write_tile<T>(acc, lane, out, tau0, P.snum, final_scale);
+#pragma unroll
+        for (int mm = 0; mm < NMEM; ++mm) {
+            if (mm == 1 && !has_b) break;                 // uniform
+            T acc[2 * TT];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const Cp<T> pv = part[mm][t][lane];
+                acc[2 * t] = pv.x;
+                acc[2 * t + 1] = pv.y;
+            }
+            pss_write_tile<T>(acc, lane, out[mm], tau0, P.snum, final_scale);
+        }
     }
 }
 
-// frequencies per wave: 64 M.  One chunk while the frequencies fit a wave (M up to 8), chunks of 512 beyond.
-template <typename T, int M> static void ps_smooth_launch_one(const PsParams &P, int nchunks, hipStream_t st)
+// Frequencies per wave: 64 M, M <= P.sm_m (the host's choice for records of many frequencies: what fits the registers --
+// float32 8, with two wavenumbers per wave 4; float64 4 (8 spilled 200 registers), pairs 4); chunks of 64 sm_m beyond.
+#ifndef PSS_M64_PAIRS
+#define PSS_M64_PAIRS 4     // (8192^2, pairs: 2 -> 218 ms, 4 -> 179 ms; one wavenumber per wave, 8 with 200 spilled registers: 264 ms)
+#endif
+static int ps_smooth_m(bool dbl, bool pairs) { return dbl ? (pairs ? PSS_M64_PAIRS : 4) : (pairs ? 4 : 8); }
+static int ps_smooth_chunks(int nf, int m) { return nf <= 64 * m ? 1 : (nf + 64 * m - 1) / (64 * m); }
+
+template <typename T, int M, int NMEM> static void ps_smooth_launch_one(const PsParams &P, int nchunks, hipStream_t st)
 {
-    if constexpr (sizeof(T) == 4) hipLaunchKernelGGL(ps_smooth32_kernel<M>, dim3(P.nk, nchunks), dim3(64), 0, st, P);
-    else hipLaunchKernelGGL(ps_smooth_kernel<M>, dim3(P.nk, nchunks), dim3(64), 0, st, P);
+    const dim3 grid(NMEM == 2 ? P.tnum / 2 + 1 : P.nk, nchunks);
+    if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((ps_smooth32_kernel<M, NMEM>), grid, dim3(64), 0, st, P);
+    else hipLaunchKernelGGL((ps_smooth_kernel<M, NMEM>), grid, dim3(64), 0, st, P);
 }
 
-static int ps_smooth_chunks(int nf) { return nf <= 512 ? 1 : (nf + 511) / 512; }
-
-// P.sm_nchunks (and, beyond one chunk, P.sm_part: [chunks][nk][snum] complex) set by the caller
-template <typename T> static void ps_smooth_launch(const PsParams &P, hipStream_t st)
+// P.sm_nchunks, P.sm_m (and, beyond one chunk, P.sm_part: [chunks][nk][snum] complex) set by the caller; pairs: the whole
+// wavenumber axis with kx[tnum - k] = -kx[k]
+template <typename T, int NMEM> static void ps_smooth_launch_n(const PsParams &P, hipStream_t st)
 {
-    const int nf = P.nf, nchunks = P.sm_nchunks;
-    if (nf <= 64) ps_smooth_launch_one<T, 1>(P, 1, st);
-    else if (nf <= 128) ps_smooth_launch_one<T, 2>(P, 1, st);
-    else if (nf <= 256) ps_smooth_launch_one<T, 4>(P, 1, st);
-    else ps_smooth_launch_one<T, 8>(P, nchunks, st);
+    const int nf = P.nf, nchunks = P.sm_nchunks, mmax = P.sm_m;
+    if (nf <= 64 || mmax == 1) ps_smooth_launch_one<T, 1, NMEM>(P, nchunks, st);
+    else if (nf <= 128 || mmax == 2) ps_smooth_launch_one<T, 2, NMEM>(P, nchunks, st);
+    else if (nf <= 256 || mmax == 4) ps_smooth_launch_one<T, 4, NMEM>(P, nchunks, st);
+    else if constexpr (sizeof(T) == 4 && NMEM == 1) ps_smooth_launch_one<T, 8, NMEM>(P, nchunks, st);
+}
+template <typename T> static void ps_smooth_launch(const PsParams &P, hipStream_t st, bool pairs)
+{
+    if (pairs) ps_smooth_launch_n<T, 2>(P, st);
+    else ps_smooth_launch_n<T, 1>(P, st);
+    const int nchunks = P.sm_nchunks;
     if (nchunks > 1) {
         const size_t n = (size_t)P.nk * P.snum;
         hipLaunchKernelGGL((ps_smooth_sum_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
