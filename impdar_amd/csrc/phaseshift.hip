@@ -1555,6 +1555,7 @@ static int ps_runs_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
         E.mfma_count = nullptr;
         E.P = P;
         E.nruns = 0;
+        E.pairs = 0;
         E.edge_cnt = Q.edge_cnt;
         E.edge_list = Q.edge_list;
         hipLaunchKernelGGL(ps_edge_kernel, dim3(P.nk), dim3(256), 0, st, E);
@@ -1657,18 +1658,20 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
     IMPDAR_HIP_CHECK(hipMemsetAsync(Q.mfma_count, 0, 8, st));
     Q.vz = vz ? 1 : 0;
     Q.runtab = pl.d_runtab.as<double2>();
+    // the whole wavenumber axis with kx[tnum - k] = -kx[k]: rows k and tnum - k turn by the same angles -- one set-up walk and
+    // one table row for both (and, on request, ps_pair_kernel: ps_pair.h); a slab of a kx-sharded run has no mirror rows
+    bool sym = P.k0 == 0 && P.nk == tnum && tnum >= 2;
+    for (int k = 1; 2 * k < tnum && sym; ++k) sym = kx_host[k] == -kx_host[tnum - k];      // (the Nyquist row of an even axis is its own partner)
+    Q.pairs = sym ? 1 : 0;
     {
         // set-up pass: per-run phases of every (wavenumber, frequency), boundary frequencies, the steps of the short runs
-        const size_t lds = 8 * 2 * PM_SHORT * sizeof(float);
-        if (P.nf <= 2048) hipLaunchKernelGGL(ps_setup_kernel<4>, dim3(P.nk), dim3(512), lds, st, Q);
-        else if (P.nf <= 4096) hipLaunchKernelGGL(ps_setup_kernel<8>, dim3(P.nk), dim3(512), lds, st, Q);
-        else hipLaunchKernelGGL(ps_setup_kernel<12>, dim3(P.nk), dim3(512), lds, st, Q);
+        const size_t lds = 2 * 8 * 2 * PM_SHORT * sizeof(float);
+        const dim3 grid(sym ? tnum / 2 + 1 : P.nk);
+        if (P.nf <= 2048) hipLaunchKernelGGL(ps_setup_kernel<4>, grid, dim3(512), lds, st, Q);
+        else if (P.nf <= 4096) hipLaunchKernelGGL(ps_setup_kernel<8>, grid, dim3(512), lds, st, Q);
+        else hipLaunchKernelGGL(ps_setup_kernel<12>, grid, dim3(512), lds, st, Q);
     }
-    // the whole wavenumber axis with kx[tnum - k] = -kx[k]: rows k and tnum - k turn by the same angles -- ps_pair_kernel makes
-    // the state tiles once for both (ps_pair.h); a slab of a kx-sharded run keeps ps_mfma_kernel
-    bool pairs = allow_pairs && P.k0 == 0 && P.nk == tnum && tnum >= 2;
-    for (int k = 1; 2 * k < tnum && pairs; ++k) pairs = kx_host[k] == -kx_host[tnum - k];      // (the Nyquist row of an even axis is its own partner)
-    if (pairs) {
+    if (allow_pairs && sym) {
         *kernel_name = "ps_pair_kernel";
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_LDS_BYTES));
         hipLaunchKernelGGL(ps_pair_kernel, dim3((unsigned)(tnum / 2 + 1) * Q.ngroups), dim3(PP_WAVES * 64), PP_LDS_BYTES, st, Q);

@@ -91,6 +91,7 @@ struct PsMfmaParams {
     int nlong;
     int long_of[PM_MAX_RUNS];   // run -> index among the long runs (-1: short)
     int vz;
+    int pairs;              // the whole wavenumber axis with kx[tnum - k] = -kx[k]: runtab row min(k, tnum - k) serves both (ps_setup_kernel makes it once)
     unsigned long long *mfma_count;     // MFMA instructions issued, summed over the launch (bench.py: mfma_flop_executed)
 };
 
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
     int blong[PM_NRB];
 #pragma unroll
     for (int rb = 0; rb < PM_NRB; ++rb) blong[rb] = brun[rb] >= 0 ? Q.long_of[brun[rb]] : 0;
-    const double2 *tab = Q.runtab + (size_t)kb * P.nf * Q.nlong;
+    const double2 *tab = Q.runtab + (size_t)(Q.pairs ? min(kb, P.tnum - kb) : kb) * P.nf * Q.nlong;       // (phases depend on kx^2 only)
     // the next round's spectrum and run entries are requested a round ahead
     Cp<float> f_next = ps_load_slot<float>(Frow, P, q * PM_CH + om);
     double2 t_next[PM_NRB];
@@ -467,14 +468,20 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
 //     runs do not cover them).
 // ---------------------------------------------------------------------------
 template <int PM_SM>      // frequencies per thread: nf <= 512 PM_SM
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(PM_SM <= 8 ? 4 : 2))) void ps_setup_kernel(PsMfmaParams Q)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(PM_SM <= 4 ? 4 : (PM_SM <= 8 ? 3 : 2)))) void ps_setup_kernel(PsMfmaParams Q)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned pm_lds[];
     const PsParams &P = Q.P;
-    const int k = P.k0 + (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float *red = reinterpret_cast<float *>(pm_lds);                         // [8][2 * PM_SHORT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Q.pairs: one workgroup per PAIR of wavenumbers (rows k and tnum - k: the same kx^2, the same phases) -- one walk over
+    // the runs, one table row, the single steps summed for both spectra
+    const int k = P.k0 + (int)blockIdx.x, k2 = Q.pairs ? (P.tnum - (int)blockIdx.x) % P.tnum : k;
+    const bool has2 = k2 != k;
+    float *red = reinterpret_cast<float *>(pm_lds);                         // [2][8][2 * PM_SHORT]
     const Cp<float> *Frow = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.fstride;
+    const Cp<float> *Frow2 = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k2 * P.fstride;
     float *TKrow = reinterpret_cast<float *>(reinterpret_cast<Cp<float> *>(P.TK) + (size_t)(k - P.k0) * P.snum);
+    float *TKrow2 = reinterpret_cast<float *>(reinterpret_cast<Cp<float> *>(P.TK) + (size_t)(k2 - P.k0) * P.snum);
     double2 *tab = Q.runtab + (size_t)(k - P.k0) * P.nf * Q.nlong;
     const double kxk = P.kx[k];
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
@@ -494,12 +501,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(PM_SM <= 8 
     // 1.83; a branch-free body -- selects instead of the two ifs -- measured no better: the pass is bound by its ~450
     // instructions per (wavenumber, frequency) of the nine runs of that table, six of them one-step runs with a sincos each).
     double ph[PM_SM], rw[PM_SM], wv[PM_SM];
-    float2 fv[PM_SM];
+    float2 fv[PM_SM], fw[PM_SM];
 #pragma unroll
     for (int m = 0; m < PM_SM; ++m) {
         const int slot = tid + 512 * m;
         const bool in = slot < P.nf;
         const Cp<float> f = in ? ps_load_slot<float>(Frow, P, slot) : Cp<float>{0.f, 0.f};
+        const Cp<float> f2 = (in && has2) ? ps_load_slot<float>(Frow2, P, slot) : Cp<float>{0.f, 0.f};
         wv[m] = in ? P.w[slot] : 1.0;
         rw[m] = 1.0 / wv[m];
         bool edge = false;
@@ -507,9 +515,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(PM_SM <= 8 
         if (edge && in) {
             const int at = atomicAdd(Q.edge_cnt + k, 1);
             if (at < PM_EMAX) Q.edge_list[(size_t)k * PM_EMAX + at] = slot;
+            if (has2) {
+                const int at2 = atomicAdd(Q.edge_cnt + k2, 1);
+                if (at2 < PM_EMAX) Q.edge_list[(size_t)k2 * PM_EMAX + at2] = slot;
+            }
         }
         // (a frequency whose spectrum value IS zero stays in: only the NaN phase says "out")
         fv[m] = make_float2(f.x, f.y);
+        fw[m] = make_float2(f2.x, f2.y);
         ph[m] = (edge || !in) ? nan : 0.0;                                    // NaN phase = out of every run from here on
     }
     for (int r = 0; r < Q.nruns; ++r) {
@@ -517,9 +530,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(PM_SM <= 8 
         const int len = Q.runs[r].len, start = Q.runs[r].start;
         const bool is_short = len <= PM_SHORT;                                // uniform
         const int L = Q.long_of[r];
-        float acc[2 * PM_SHORT];
+        float acc[2 * PM_SHORT], acc2[2 * PM_SHORT];
 #pragma unroll
-        for (int j = 0; j < 2 * PM_SHORT; ++j) acc[j] = 0.f;
+        for (int j = 0; j < 2 * PM_SHORT; ++j) acc[j] = acc2[j] = 0.f;
 #pragma unroll
         for (int m = 0; m < PM_SM; ++m) {
             const int slot = tid + 512 * m;
@@ -536,6 +549,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(PM_SM <= 8 
                         pm_sincos(ph[m] + (double)(j + 1) * inc, &sn, &c2);
                         acc[2 * j] += fmaf(fv[m].x, c2, -(fv[m].y * sn));    // :464, :487
                         acc[2 * j + 1] += fmaf(fv[m].x, sn, fv[m].y * c2);
+                        acc2[2 * j] += fmaf(fw[m].x, c2, -(fw[m].y * sn));
+                        acc2[2 * j + 1] += fmaf(fw[m].x, sn, fw[m].y * c2);
                     }
             }
             ph[m] = pm_wrap(ph[m] + (double)len * inc);                       // NaN stays NaN
@@ -543,17 +558,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(PM_SM <= 8 
         if (is_short) {
 #pragma unroll
             for (int j = 0; j < 2 * PM_SHORT; ++j) {
-                float x = acc[j];
+                float x = acc[j], y = acc2[j];
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-                if (lane == 0) red[wave * 2 * PM_SHORT + j] = x;
+                for (int o = 32; o > 0; o >>= 1) {
+                    x += __shfl_xor(x, o, 64);
+                    y += __shfl_xor(y, o, 64);
+                }
+                if (lane == 0) {
+                    red[wave * 2 * PM_SHORT + j] = x;
+                    red[(8 + wave) * 2 * PM_SHORT + j] = y;
+                }
             }
             __syncthreads();
             if (tid < 2 * len) {
-                float sum = 0.f;
+                float sum = 0.f, sum2 = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) sum += red[i * 2 * PM_SHORT + tid];
+                for (int i = 0; i < 8; ++i) {
+                    sum += red[i * 2 * PM_SHORT + tid];
+                    sum2 += red[(8 + i) * 2 * PM_SHORT + tid];
+                }
                 TKrow[2 * (size_t)(start + (tid >> 1)) + (tid & 1)] = sum / (float)P.snum;      // :492
+                if (has2) TKrow2[2 * (size_t)(start + (tid >> 1)) + (tid & 1)] = sum2 / (float)P.snum;
             }
             __syncthreads();
         }

@@ -842,12 +842,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
     }
 }
 
-// Frequencies per wave: 64 M, M <= P.sm_m (the host's choice for records of many frequencies: what fits the registers --
-// float32 8, with two wavenumbers per wave 4; float64 4 (8 spilled 200 registers), pairs 4); chunks of 64 sm_m beyond.
-#ifndef PSS_M64_PAIRS
-#define PSS_M64_PAIRS 4     // (8192^2, pairs: 2 -> 218 ms, 4 -> 179 ms; one wavenumber per wave, 8 with 200 spilled registers: 264 ms)
-#endif
-static int ps_smooth_m(bool dbl, bool pairs) { return dbl ? (pairs ? PSS_M64_PAIRS : 4) : (pairs ? 4 : 8); }
+// Frequencies per wave: 64 M, M <= P.sm_m = 4: what fits the registers with two wavenumbers per wave (float64, 8192^2, pairs:
+// 2 -> 218 ms, 4 -> 179 ms; one wavenumber per wave with 8 spilled 200 registers: 264 ms).  A slab of a kx-sharded run (one
+// wavenumber per wave) uses the SAME chunks: its rows are then bit-identical to the unsharded image's
+// (tests/tools/fuzz_ps_sharded.py); chunks of 256 frequencies beyond.
+static int ps_smooth_m(bool, bool) { return 4; }
 static int ps_smooth_chunks(int nf, int m) { return nf <= 64 * m ? 1 : (nf + 64 * m - 1) / (64 * m); }
 
 template <typename T, int M, int NMEM> static void ps_smooth_launch_one(const PsParams &P, int nchunks, hipStream_t st)
@@ -864,8 +863,7 @@ template <typename T, int NMEM> static void ps_smooth_launch_n(const PsParams &P
     const int nf = P.nf, nchunks = P.sm_nchunks, mmax = P.sm_m;
     if (nf <= 64 || mmax == 1) ps_smooth_launch_one<T, 1, NMEM>(P, nchunks, st);
     else if (nf <= 128 || mmax == 2) ps_smooth_launch_one<T, 2, NMEM>(P, nchunks, st);
-    else if (nf <= 256 || mmax == 4) ps_smooth_launch_one<T, 4, NMEM>(P, nchunks, st);
-    else if constexpr (sizeof(T) == 4 && NMEM == 1) ps_smooth_launch_one<T, 8, NMEM>(P, nchunks, st);
+    else ps_smooth_launch_one<T, 4, NMEM>(P, nchunks, st);
 }
 template <typename T> static void ps_smooth_launch(const PsParams &P, hipStream_t st, bool pairs)
 {
