@@ -1507,6 +1507,7 @@ static int ps_runs_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
         }
         close();
     }
+    impdar_trace("ps_runs: %zu pieces in %zu stages", pr.size(), stages.size());
     const int nparts = (P.nf + PR_PART - 1) / PR_PART;
     const size_t part_bytes = nparts > 1 ? (size_t)nparts * P.nk * snum * sizeof(Cp<float>) : 0;
     std::vector<double> rw((size_t)P.nf);
@@ -1538,6 +1539,11 @@ static int ps_runs_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
     // kx-sharded run has no mirror rows
     bool pairs = P.k0 == 0 && P.nk == tnum && tnum >= 2;
     for (int k = 1; 2 * k < tnum && pairs; ++k) pairs = kx_host[k] == -kx_host[tnum - k];      // (the Nyquist row of an even axis is its own partner)
+    const bool tr = impdar_trace_on();           // tracing: drain the stream between the launches, a line each
+    if (tr) {
+        (void)hipStreamSynchronize(st);
+        impdar_trace("ps_runs: stream idle before the frequency sums");
+    }
     if (pairs) {
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_runs_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pr_lds_bytes(2)));
         hipLaunchKernelGGL(ps_runs_kernel<2>, dim3((unsigned)(tnum / 2 + 1) * nparts), dim3(256), pr_lds_bytes(2), st, Q);
@@ -1545,10 +1551,18 @@ static int ps_runs_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_runs_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pr_lds_bytes(1)));
         hipLaunchKernelGGL(ps_runs_kernel<1>, dim3((unsigned)P.nk * nparts), dim3(256), pr_lds_bytes(1), st, Q);
     }
+    if (tr) {
+        (void)hipStreamSynchronize(st);
+        impdar_trace("ps_runs: ps_runs_kernel done");
+    }
     if (nparts > 1) {
         const size_t n = (size_t)P.nk * snum;
         hipLaunchKernelGGL((ps_smooth_sum_kernel<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                            reinterpret_cast<const Cp<float> *>(pl.d_part.p), reinterpret_cast<Cp<float> *>(P.TK), nparts, n, snum);
+    }
+    if (tr) {
+        (void)hipStreamSynchronize(st);
+        impdar_trace("ps_runs: partial images summed");
     }
     {
         PsMfmaParams E;                        // (ps_edge_kernel reads P and the lists only)
@@ -1561,7 +1575,9 @@ static int ps_runs_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
         hipLaunchKernelGGL(ps_edge_kernel, dim3(P.nk), dim3(256), 0, st, E);
     }
     IMPDAR_HIP_CHECK(hipGetLastError());
+    impdar_trace("ps_runs: buffers ready, tables copied, kernels enqueued");
     IMPDAR_HIP_CHECK(hipStreamSynchronize(st));            // (the host tables must outlive their copies)
+    impdar_trace("ps_runs: stream drained");
     std::vector<int> cnt((size_t)P.nk);
     IMPDAR_HIP_CHECK(hipMemcpy(cnt.data(), Q.edge_cnt + P.k0, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
     int worst = 0;
@@ -1576,6 +1592,7 @@ static int ps_runs_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
         IMPDAR_HIP_CHECK(hipMemcpy(&n, Q.mfma_count, 8, hipMemcpyDeviceToHost));
         pl.mfma_instructions = (double)n;
     }
+    impdar_trace("ps_runs: counters read back: %.0f MFMA instructions, worst edge count %d, %d parts, pairs %d", pl.mfma_instructions, worst, nparts, (int)pairs);
     *done = true;
     return IMPDAR_OK;
 }
