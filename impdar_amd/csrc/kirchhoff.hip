@@ -3113,7 +3113,10 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
         auto r8 = [](long long x) { return (int)(x / 8 * 8); };
         std::vector<int> cut;
         const bool two = se && atoi(se) == 2;          // the round-3 first form, kept for A/B
-        const std::vector<int> pct = {10, 40, 70};         // interior cuts in percent of tnum (sweep: profiles/r03_oneshot_pipeline.txt)
+#ifndef KOS_PCT
+#define KOS_PCT {10, 40, 70}
+#endif
+        const std::vector<int> pct = KOS_PCT;              // interior cuts in percent of tnum (sweeps: profiles/r03_oneshot_pipeline.txt, r05_oneshot_cuts.txt)
         if (!two && (long long)tnum * pct[pct.size() > 1 ? 1 : 0] / 100 + halo < (long long)tnum * 9 / 10) {
             cut = {0};
             for (int q : pct) cut.push_back(r8((long long)tnum * q / 100));
