@@ -454,7 +454,8 @@ __global__ __launch_bounds__(PM_WAVES * 64, PM_CH == 16 ? 3 : 2) void ps_mfma_ke
 
 
 // ---------------------------------------------------------------------------
-// Set-up pass, one workgroup per wavenumber, one thread per frequency at a time: everything that is float64 and per
+// Set-up pass, one workgroup per wavenumber -- per PAIR of wavenumbers (k, tnum - k: the same kx^2, the same phases, one
+// table row) when the call has the whole symmetric axis --, one thread per frequency at a time: everything that is float64 and per
 // (wavenumber, frequency, run) is done HERE, once, at full lane efficiency, instead of by the 8 lanes per frequency
 // of ps_mfma_kernel in every round (two float64 divisions, a square root and the catch-up over the runs per
 // frequency were the larger part of that kernel's vector work, profiles/r03_ps_mfma_*.txt):
