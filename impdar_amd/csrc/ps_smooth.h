@@ -846,7 +846,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
 // 2 -> 218 ms, 4 -> 179 ms; one wavenumber per wave with 8 spilled 200 registers: 264 ms).  A slab of a kx-sharded run (one
 // wavenumber per wave) uses the SAME chunks: its rows are then bit-identical to the unsharded image's
 // (tests/tools/fuzz_ps_sharded.py); chunks of 256 frequencies beyond.
-static int ps_smooth_m(bool, bool) { return 4; }
+static int ps_smooth_m(bool, bool) { return 4; }       // (float32 pairs with 2 per lane -- four waves per SIMD instead of two: 89.7 -> 98.6 ms)
 static int ps_smooth_chunks(int nf, int m) { return nf <= 64 * m ? 1 : (nf + 64 * m - 1) / (64 * m); }
 
 template <typename T, int M, int NMEM> static void ps_smooth_launch_one(const PsParams &P, int nchunks, hipStream_t st)
