@@ -519,7 +519,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
     using T = float;
     constexpr int TT = PSS_TT;
     constexpr int ANCHOR_TILES = 4;
-    constexpr int G = M < 2 ? M : 2;
+#ifndef PSS32_G
+#define PSS32_G 4      // (2: 89.7 ms, 4: 87.4 ms at 8192^2 with two wavenumbers per wave)
+#endif
+    constexpr int G = M < PSS32_G ? M : PSS32_G;          // frequencies whose chains are interleaved, stage by stage
     __shared__ Cp<T> f0_lds[NMEM][M][64];                 // original spectra (the anchors rotate them)
     __shared__ Cp<T> part[NMEM][TT][64];                  // per-step partial sums of a lane's frequencies
     __shared__ double4 stepc[2][TT];                      // the steps' {c, thr, v, delta}
@@ -703,7 +706,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ps
 #define PSS_EACH for (int j = 0, m = m0; j < G; ++j, ++m)
 #define PSS_PIN(f)                                                                   \
     do {                                                                             \
-        if constexpr (G == 2) asm volatile("" : "+v"(q[0].f), "+v"(q[G > 1 ? 1 : 0].f)); \
+        if constexpr (G == 4) asm volatile("" : "+v"(q[0].f), "+v"(q[G > 1 ? 1 : 0].f), "+v"(q[G > 2 ? 2 : 0].f), "+v"(q[G > 3 ? 3 : 0].f)); \
+        else if constexpr (G == 2) asm volatile("" : "+v"(q[0].f), "+v"(q[G > 1 ? 1 : 0].f)); \
         else asm volatile("" : "+v"(q[0].f));                                        \
     } while (0)
 #pragma unroll
