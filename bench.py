@@ -399,7 +399,7 @@ def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None, spot=None):
     Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
     tab = np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rp], [1.8e8, 0.5 * Rp], [1.9e8, 1.2 * Rp]])
     ms, wall, fin, kms = device_ms(lambda d: d.migrate('phsh', vel=tab, htaper=100, vtaper=1000), lambda: dat_of(x, geo),
-                                   reps=2, kernel=True)
+                                   reps=3, kernel=True)
     steps_ref = float(n) ** 3                            # nt * snum * tnum rotate-accumulates: what the reference executes
     steps = float(n // 2) * n * n                        # ... and what a real radargram needs: frequencies 1..nt/2-1 stand
     #                                                      for their mirror images too, + the Nyquist row (Hermitian walk)
@@ -454,7 +454,7 @@ def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None, spot=None):
     # ... and on float64 data (what a float64 .mat file gets: the vector runs kernel ps_vz64_kernel, no matrix cores)
     x64 = x.astype(np.float64)
     ms64, wall64, fin64, kms64 = device_ms(lambda d: d.migrate('phsh', vel=tab, htaper=100, vtaper=1000), lambda: dat_of(x64, geo),
-                                           reps=2, kernel=True)
+                                           reps=3, kernel=True)
     tf64 = flop / (kms64 * 1e-3) / 1e12
     out["gazdag_f64_config5"] = {
         "workload": "phase-shift (Gazdag) migration, 1-D v(z) table, 8192x8192 float64 data (BASELINE config 5 in the "
