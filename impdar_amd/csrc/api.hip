@@ -32,8 +32,9 @@ void impdar_trace(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
+    const double unix_s = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
     std::lock_guard<std::mutex> lk(mu);
-    fprintf(stderr, "[impdar +%9.2f ms] %s\n", ms, buf);
+    fprintf(stderr, "[impdar +%9.2f ms, unix %.3f] %s\n", ms, unix_s, buf);
 }
 
 extern "C" int impdar_device_count(void)
