@@ -179,6 +179,46 @@ __global__ __launch_bounds__(256) void stolt_stretch(const Cx<T> *__restrict__ F
     K[(size_t)xi * m + zj] = o;
 }
 
+// The same on the spectrum as the own transforms leave it after the pass over the traces: frequency-major, F[w][kx].  One
+// thread per (zj, xi) with xi the fast index: the two rows a wavenumber interpolates between move slowly with xi (kk grows
+// with |kx|), so neighbouring lanes read neighbouring words of the same or the next row -- no transposes around the stretch.
+template <typename T>
+__global__ __launch_bounds__(256) void stolt_stretch_t(const Cx<T> *__restrict__ F, Cx<T> *__restrict__ K,
+                                                       const double *__restrict__ kx, const double *__restrict__ ws,
+                                                       int m, int nz, int tnum, double vel)
+{
+    const int xi = blockIdx.x * 256 + threadIdx.x;
+    const int zj = blockIdx.y;
+    if (xi >= tnum) return;
+    Cx<T> o;
+    o.x = 0;
+    o.y = 0;
+    if (zj < nz) {
+        const double kxi = kx[xi];
+        const double kz = ws[zj] * 2.0 / vel;                       // :180
+        const double kk = sqrt(kz * kz + kxi * kxi);                // :188 and :196
+        double wq = vel / 2.0 * kk;
+        const double wlast = ws[m - 1];
+        if (wq > wlast) wq = wlast;                                 // FITPACK clamps to the last knot
+        const double dw = ws[1] - ws[0];
+        int i0 = (int)floor(wq / dw);
+        i0 = min(max(i0, 0), m - 2);
+        while (i0 > 0 && ws[i0] > wq) --i0;
+        while (i0 < m - 2 && ws[i0 + 1] <= wq) ++i0;
+        const double w = (wq - ws[i0]) / (ws[i0 + 1] - ws[i0]);
+        const Cx<T> a = F[(size_t)i0 * tnum + xi], b = F[(size_t)(i0 + 1) * tnum + xi];
+        const T re = (T)((1.0 - w) * (double)a.x + w * (double)b.x);    // (:190, :198: stored, then scaled in double and rounded again)
+        const T im = (T)((1.0 - w) * (double)a.y + w * (double)b.y);
+        const double sc = kz / kk;                                  // :196
+        o.x = (T)((double)re * sc);
+        o.y = (T)((double)im * sc);
+        if (zj == 0 && xi == 0) {                                   // :200
+            o.x = 0;
+            o.y = 0;
+        }
+    }
+    K[(size_t)zj * tnum + xi] = o;
+}
 
 // C2R ignores the imaginary part of the DC and Nyquist bins (numpy irfft):
 // clear them so any Hermitian-assuming backend agrees.
@@ -192,8 +232,7 @@ __global__ void stolt_fix_hermitian(Cx<T> *K, int m, int tnum)
 }
 
 struct StoltPlan {
-    // the first call of a power-of-two size runs on the library's own row transforms (own_fft.h); the two rocFFT plans are
-    // made by the second call of the size (see phaseshift.hip: why not on a thread)
+    // power-of-two sizes run on the library's own row transforms (own_fft.h) and need no rocFFT plan
     bool plans_ready = false;
     int own_calls = 0;
     OwnTwiddles tw_time, tw_trace;
@@ -201,7 +240,7 @@ struct StoltPlan {
     const impdar_ctx *owner = nullptr;   // plans and buffers live on this context's device and stream
     FftPlan r2c, c2c_f, c2c_b, c2r;     // separate passes (IMPDAR_STOLT_FFT=1d)
     FftPlan fwd2d, inv2d;               // the same two pairs as 2-D real transforms (default)
-    bool use2d = true;
+    bool use2d = true, no_own = false;
     DevBuf X, F, K, Y, d_kx, d_ws;
 };
 
@@ -237,15 +276,19 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
     const int m = snum / 2 + 1, nz = snum / 2, nout = 2 * (snum / 2);
     hipStream_t st = ctx->stream;
     const bool dbl = sizeof(T) == 8;
-    bool want2d = true, own_forced = false;
+    bool want2d = true, no_own = false;
     {
-        const char *e = getenv("IMPDAR_STOLT_FFT");          // tuning knob: "1d" = four 1-D passes; "own" = own_fft.h on every call
+        // tuning knob: "1d" = four 1-D rocFFT passes; "rocfft" = rocFFT's 2-D real plans also where the own transforms apply;
+        // "own" = the default, spelled out (tests that pin one implementation)
+        const char *e = getenv("IMPDAR_STOLT_FFT");
         want2d = !(e && !strcmp(e, "1d"));
-        own_forced = e && !strcmp(e, "own");
+        no_own = e && !strcmp(e, "rocfft");
     }
-    // power-of-two sizes: a FIRST call runs on the library's own row transforms while a thread makes the rocFFT plans
-    const bool own_ok = want2d && snum % 2 == 0 && own_fft_len_ok(snum / 2) && own_fft_len_ok(tnum);
-    if (pl.owner != ctx || pl.dtype != (dbl ? IMPDAR_F64 : IMPDAR_F32) || pl.snum != snum || pl.tnum != tnum || pl.use2d != want2d) {
+    // power-of-two sizes run on the library's own row transforms (own_fft.h), every call: 0.35 ms at 4096^2 against 0.37 on
+    // rocFFT's 2-D plans (round 5: the stretch on the frequency-major spectrum, two transposes fewer), nothing compiled at
+    // run time, no plan to make (rocFFT: 0.3-3 s per process for lengths above 1024)
+    const bool own_ok = want2d && !no_own && snum % 2 == 0 && own_fft_len_ok(snum / 2) && own_fft_len_ok(tnum);
+    if (pl.owner != ctx || pl.dtype != (dbl ? IMPDAR_F64 : IMPDAR_F32) || pl.snum != snum || pl.tnum != tnum || pl.use2d != want2d || pl.no_own != no_own) {
         pl.own_calls = 0;
         pl.plans_ready = false;
         pl.dtype = -1;
@@ -255,6 +298,7 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
         }
         int rc;
         pl.use2d = want2d;
+        pl.no_own = no_own;
         // rfft2(axes=(1,0)) (:159) = real transform over time (contiguous here), complex over the traces (rows);
         // irfft2 (:202) = complex inverse over the traces, then C2R over time.  rocFFT's 2-D real plans do
         // exactly these two passes each, with its own blocked column kernels instead of a strided batch.
@@ -299,23 +343,11 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
         pl.snum = snum;
         pl.tnum = tnum;
     }
-    bool use_own = false;
-    if (own_ok) {
-        if (own_forced || (!pl.plans_ready && pl.own_calls == 0)) {
-            use_own = true;
-            pl.own_calls += own_forced ? 0 : 1;
-            impdar_trace("stolt: transforms on the library's own row kernels");
-            int rc;
-            if ((rc = pl.tw_time.ensure<T>(snum, st)) || (rc = pl.tw_trace.ensure<T>(tnum, st))) return rc;
-        } else if (!pl.plans_ready) {
-            int rc;
-            if ((rc = pl.fwd2d.create2d(rocfft_transform_type_real_forward, dbl, false, snum, tnum, rocfft_array_type_real,
-                                        rocfft_array_type_hermitian_interleaved, snum, m, 1.0, st)) ||
-                (rc = pl.inv2d.create2d(rocfft_transform_type_real_inverse, dbl, false, nout, tnum, rocfft_array_type_hermitian_interleaved,
-                                        rocfft_array_type_real, m, nout, 1.0 / ((double)nout * tnum), st)))
-                return rc;
-            pl.plans_ready = true;
-        }
+    const bool use_own = own_ok;
+    if (use_own) {
+        impdar_trace("stolt: transforms on the library's own row kernels");
+        int rc;
+        if ((rc = pl.tw_time.ensure<T>(snum, st)) || (rc = pl.tw_trace.ensure<T>(tnum, st))) return rc;
     }
     IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_kx.p, kx, (size_t)tnum * 8, hipMemcpyHostToDevice, st));
     IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_ws.p, ws, (size_t)m * 8, hipMemcpyHostToDevice, st));
@@ -334,17 +366,19 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
         if ((rc = own_fft_launch<T>(OWN_R2C, snum, (size_t)tnum, pl.X.p, pl.F.p, (size_t)snum, (size_t)m, 1.0, pl.tw_time, st))) return rc;
         own_launch_transpose<T>(pl.F.p, pl.K.p, tnum, m, st);
         if ((rc = own_fft_launch<T>(OWN_C2C_FWD, tnum, (size_t)m, pl.K.p, pl.K.p, (size_t)tnum, (size_t)tnum, 1.0, pl.tw_trace, st))) return rc;
-        own_launch_transpose<T>(pl.K.p, pl.F.p, m, tnum, st);
     } else if (pl.use2d) {
         if ((rc = pl.fwd2d.exec(pl.X.p, pl.F.p))) return rc;
     } else {
         if ((rc = pl.r2c.exec(pl.X.p, pl.F.p))) return rc;
         if ((rc = pl.c2c_f.exec(pl.F.p, nullptr))) return rc;
     }
-    hipLaunchKernelGGL((stolt_stretch<T>), dim3((m + 255) / 256, tnum), dim3(256), 0, st, pl.F.as<Cx<T>>(),
-                       pl.K.as<Cx<T>>(), pl.d_kx.as<double>(), pl.d_ws.as<double>(), m, nz, tnum, vel);
+    if (use_own)      // K [w][kx] -> F [w][kx]
+        hipLaunchKernelGGL((stolt_stretch_t<T>), dim3((tnum + 255) / 256, m), dim3(256), 0, st, pl.K.as<Cx<T>>(),
+                           pl.F.as<Cx<T>>(), pl.d_kx.as<double>(), pl.d_ws.as<double>(), m, nz, tnum, vel);
+    else
+        hipLaunchKernelGGL((stolt_stretch<T>), dim3((m + 255) / 256, tnum), dim3(256), 0, st, pl.F.as<Cx<T>>(),
+                           pl.K.as<Cx<T>>(), pl.d_kx.as<double>(), pl.d_ws.as<double>(), m, nz, tnum, vel);
     if (use_own) {
-        own_launch_transpose<T>(pl.K.p, pl.F.p, tnum, m, st);
         if ((rc = own_fft_launch<T>(OWN_C2C_INV, tnum, (size_t)m, pl.F.p, pl.F.p, (size_t)tnum, (size_t)tnum, 1.0 / tnum, pl.tw_trace, st))) return rc;
         own_launch_transpose<T>(pl.F.p, pl.K.p, m, tnum, st);
         hipLaunchKernelGGL((stolt_fix_hermitian<T>), dim3((tnum + 255) / 256), dim3(256), 0, st, pl.K.as<Cx<T>>(), m, tnum);
