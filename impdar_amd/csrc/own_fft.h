@@ -23,7 +23,7 @@
 
 template <typename T> struct OCp { T x, y; };
 
-enum { OWN_C2C_FWD = 0, OWN_C2C_INV = 1, OWN_R2C = 2, OWN_C2R = 3 };
+enum { OWN_C2C_FWD = 0, OWN_C2C_INV = 1, OWN_R2C = 2, OWN_C2R = 3, OWN_C2C_INV_RE = 4 };     // 4: the inverse's REAL parts only
 
 __host__ __device__ inline int own_pad(int i) { return i + (i >> 5); }
 // complex length M the kernel supports: a power of two, 16 ... 8192 (float64 rows of 8192 take 132 KB of LDS)
@@ -52,19 +52,21 @@ __device__ __forceinline__ int own_rev(int k, int M, int logm)
 }
 
 // in:  MODE 0/1: [batch][M] complex, rows in_dist COMPLEX elements apart;  MODE 2: [batch][2 M] real, rows in_dist REAL elements
-//      apart;  MODE 3: [batch][M + 1] complex, rows in_dist complex elements apart
-// out: MODE 0/1: [batch][M] complex;  MODE 2: [batch][M + 1] complex;  MODE 3: [batch][2 M] real (out_dist in real elements)
+//      apart;  MODE 3: [batch][M + 1] complex, rows in_dist complex elements apart;  MODE 4: as MODE 1
+// out: MODE 0/1: [batch][M] complex;  MODE 2: [batch][M + 1] complex;  MODE 3: [batch][2 M] real (out_dist in real elements);
+//      MODE 4: [batch][M] real -- Re of the inverse transform (out_dist in real elements): what the phase shift keeps of its
+//      inverse over the wavenumbers (mig_python.py:282) without a pass of its own
 // tw:  e^{-2 pi i k / NT}, k < NT, NT = M (MODE 0/1) or 2 M (MODE 2/3)
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void own_fft_rows(const void *__restrict__ in_, void *__restrict__ out_, int M, int logm, size_t in_dist,
+__global__ __launch_bounds__(1024) void own_fft_rows(const void *__restrict__ in_, void *__restrict__ out_, int M, int logm, size_t in_dist,
                                                     size_t out_dist, T scale, const OCp<T> *__restrict__ tw)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char own_lds[];
     OCp<T> *s = reinterpret_cast<OCp<T> *>(own_lds);
     const int tid = threadIdx.x, nth = blockDim.x;
     const size_t row = blockIdx.x;
-    constexpr bool INV = MODE == OWN_C2C_INV || MODE == OWN_C2R;
-    constexpr int TWS = MODE >= 2 ? 2 : 1;           // stride of the length-M twiddles in the table
+    constexpr bool INV = MODE == OWN_C2C_INV || MODE == OWN_C2R || MODE == OWN_C2C_INV_RE;
+    constexpr int TWS = (MODE == OWN_R2C || MODE == OWN_C2R) ? 2 : 1;           // stride of the length-M twiddles in the table
     // ---- load
     if (MODE == OWN_C2R) {
         const OCp<T> *X = reinterpret_cast<const OCp<T> *>(in_) + row * in_dist;
@@ -131,6 +133,9 @@ __global__ __launch_bounds__(256) void own_fft_rows(const void *__restrict__ in_
             const OCp<T> z = s[own_pad(own_rev(n, M, logm))];
             Y[n] = OCp<T>{z.x * scale, z.y * scale};
         }
+    } else if (MODE == OWN_C2C_INV_RE) {
+        T *Y = reinterpret_cast<T *>(out_) + row * out_dist;
+        for (int k = tid; k < M; k += nth) Y[k] = s[own_pad(own_rev(k, M, logm))].x * scale;
     } else {
         OCp<T> *Y = reinterpret_cast<OCp<T> *>(out_) + row * out_dist;
         for (int k = tid; k < M; k += nth) {
@@ -189,7 +194,7 @@ template <typename T>
 static int own_fft_launch(int mode, int n, size_t batch, const void *in, void *out, size_t in_dist, size_t out_dist, double scale,
                           const OwnTwiddles &tw, hipStream_t st)
 {
-    const int M = mode >= 2 ? n / 2 : n;
+    const int M = (mode == OWN_R2C || mode == OWN_C2R) ? n / 2 : n;
     int logm = 0;
     while ((1 << logm) < M) ++logm;
     if (!own_fft_len_ok(M) || (1 << logm) != M || tw.nt != n || tw.dbl != (sizeof(T) == 8)) {
@@ -197,7 +202,13 @@ static int own_fft_launch(int mode, int n, size_t batch, const void *in, void *o
         return IMPDAR_ERR_UNSUPPORTED;
     }
     const size_t lds = (size_t)(own_pad(M) + 1) * sizeof(OCp<T>);
-    const int threads = M >= 1024 ? 256 : (M >= 256 ? 64 : 64);
+#ifndef OWN_T_BIG
+#define OWN_T_BIG 1024
+#endif
+    // (a butterfly waits for its twiddle from the table in global memory: rows of 4096+ points with 256 threads ran 8 dependent
+    // butterflies per thread and pass, 3x rocFFT's time at 8192 points -- C2C over 8192 x 8192: 656 us, 1024 threads: 376 us,
+    // rocFFT 234 us; the twiddles from two small LDS tables instead (one more rounding) changed nothing more: 355 us)
+    const int threads = M >= 4096 ? OWN_T_BIG : (M >= 2048 ? (OWN_T_BIG > 512 ? 512 : OWN_T_BIG) : (M >= 1024 ? 256 : 64));
     const OCp<T> *t = tw.buf.as<OCp<T>>();
 #define OWN_LAUNCH(MODE)                                                                                                          \
     do {                                                                                                                          \
@@ -209,6 +220,7 @@ static int own_fft_launch(int mode, int n, size_t batch, const void *in, void *o
     case OWN_C2C_FWD: OWN_LAUNCH(OWN_C2C_FWD); break;
     case OWN_C2C_INV: OWN_LAUNCH(OWN_C2C_INV); break;
     case OWN_R2C: OWN_LAUNCH(OWN_R2C); break;
+    case OWN_C2C_INV_RE: OWN_LAUNCH(OWN_C2C_INV_RE); break;
     default: OWN_LAUNCH(OWN_C2R); break;
     }
 #undef OWN_LAUNCH

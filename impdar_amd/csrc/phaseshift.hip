@@ -1734,9 +1734,10 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     const bool dbl = sizeof(T) == 8;
     // IMPDAR_PS_FFT=strided: the transforms over the traces / wavenumbers as rocFFT's strided plans on the arrays as
     // they lie (rounds 1-3a); default: transpose, contiguous plan, transpose (see ps_transpose_c)
-    const char *fe = getenv("IMPDAR_PS_FFT");            // strided | own (own_fft.h on every call, no rocFFT plans: tests, A/B)
+    // rocfft: rocFFT's plans also where the library's own row transforms apply; own: that default spelled out (tests that pin one)
+    const char *fe = getenv("IMPDAR_PS_FFT");
     const bool rows_form = !(fe && strcmp(fe, "strided") == 0);
-    const bool own_forced = fe && strcmp(fe, "own") == 0;
+    const bool no_own = fe && strcmp(fe, "rocfft") == 0;
     if (pl.owner != ctx || pl.dtype != (dbl ? IMPDAR_F64 : IMPDAR_F32) || pl.snum != snum || pl.tnum != tnum || pl.nt != nt ||
         pl.rows_form != rows_form) {
         pl.own_calls = 0;
@@ -1821,21 +1822,19 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         const size_t rows = tk_out ? scratch_rows : std::max<size_t>((size_t)snum, scratch_rows);
         if (rows) IMPDAR_HIP_CHECK(pl.TK.ensure((size_t)tnum * rows * 2 * sizeof(T)));
     }
-    // The FIRST call of a power-of-two size runs its transforms on the library's own row kernels (own_fft.h: nothing to
-    // compile); the rocFFT plans -- 0.25-3 s: their kernels are compiled at run time -- are made by the SECOND call of the
-    // size, if there is one (`impproc migrate` is one call per process).  (A first form made them on a thread during
-    // the first call: a process that exits while rocFFT is still compiling on another thread crashes in its teardown --
-    // rc -11 / -6 in 2 of 2 such exits, profiles/r05_first_call.txt.)
+    // Power-of-two sizes run their transforms on the library's own row kernels (own_fft.h), every call: nothing to compile,
+    // no plan to make (rocFFT: 0.25-3 s per process, its kernels for lengths above 1024 are compiled at run time), and within
+    // 0.1 ms of rocFFT's plans at 8192^2 since the long rows run 1024 threads (round 5; until then the first call of a size
+    // only).  (Plans made on a thread during a first call: a process that exits while rocFFT is still compiling on
+    // another thread crashes in its teardown -- rc -11 / -6 in 2 of 2 such exits, profiles/r05_first_call.txt.)
     bool use_own = false;
-    if (herm && pl.rows_form && own_fft_len_ok(nt / 2) && own_fft_len_ok(tnum)) {
+    if (herm && pl.rows_form && !no_own && own_fft_len_ok(nt / 2) && own_fft_len_ok(tnum)) {
         IMPDAR_HIP_CHECK(pl.Xr.ensure((size_t)tnum * nt * sizeof(T)));
-        if (own_forced || (!(pl.b_ready && pl.r_ready) && pl.own_calls == 0)) {
-            use_own = true;
-            pl.own_calls += own_forced ? 0 : 1;
-            impdar_trace("phaseshift: transforms on the library's own row kernels");
-            int rc;
-            if ((rc = pl.tw_time.ensure<T>(nt, st)) || (rc = pl.tw_trace.ensure<T>(tnum, st))) return rc;
-        }
+        use_own = true;
+        pl.own_calls += 1;
+        impdar_trace("phaseshift: transforms on the library's own row kernels");
+        int rc;
+        if ((rc = pl.tw_time.ensure<T>(nt, st)) || (rc = pl.tw_trace.ensure<T>(tnum, st))) return rc;
     }
     if (!use_own) {
         int rc;
@@ -2160,12 +2159,13 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         // nt >= snum), transform, real part (:282) -- already (snum, tnum)
         ps_launch_transpose<T>(pl.TK.p, pl.X.p, tnum, snum, st);
         if (use_own) {
-            if ((rc = own_fft_launch<T>(OWN_C2C_INV, tnum, (size_t)snum, pl.X.p, pl.X.p, (size_t)tnum, (size_t)tnum, 1.0 / tnum, pl.tw_trace, st))) return rc;
-        } else if ((rc = pl.b_trace.exec(pl.X.p, nullptr))) {
-            return rc;
+            // (the real part is all that is kept: stored by the transform itself, no pass of its own -- 0.16 ms at 8192^2)
+            if ((rc = own_fft_launch<T>(OWN_C2C_INV_RE, tnum, (size_t)snum, pl.X.p, d_out, (size_t)tnum, (size_t)tnum, 1.0 / tnum, pl.tw_trace, st))) return rc;
+        } else {
+            if ((rc = pl.b_trace.exec(pl.X.p, nullptr))) return rc;
+            const size_t n = (size_t)snum * tnum;
+            hipLaunchKernelGGL((ps_real_part<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pl.X.as<Cp<T>>(), (T *)d_out, n);
         }
-        const size_t n = (size_t)snum * tnum;
-        hipLaunchKernelGGL((ps_real_part<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pl.X.as<Cp<T>>(), (T *)d_out, n);
     } else {
         if ((rc = pl.b_trace.exec(pl.TK.p, nullptr))) return rc;
         dim3 bgrid((tnum + 63) / 64, (snum + 63) / 64);

@@ -66,8 +66,8 @@ std::mutex &impdar_fft_plan_mutex()
 extern "C" int impdar_fft_rows_dev(impdar_ctx *ctx, int mode, int dtype, int n, int batch, const void *d_in, void *d_out, double scale)
 {
     IMPDAR_ARG_CHECK(ctx && d_in && d_out, "null argument");
-    IMPDAR_ARG_CHECK(mode >= 0 && mode <= 3 && (dtype == IMPDAR_F32 || dtype == IMPDAR_F64) && batch >= 1, "bad mode / dtype / batch");
-    const int M = mode >= 2 ? n / 2 : n;
+    IMPDAR_ARG_CHECK(mode >= 0 && mode <= 4 && (dtype == IMPDAR_F32 || dtype == IMPDAR_F64) && batch >= 1, "bad mode / dtype / batch");
+    const int M = (mode == OWN_R2C || mode == OWN_C2R) ? n / 2 : n;
     IMPDAR_ARG_CHECK(n >= 2 && (n & (n - 1)) == 0 && own_fft_len_ok(M), "length %d is not a power of two in range", n);
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
     OwnTwiddles tw;

@@ -185,14 +185,14 @@ int impdar_stolt_dev(impdar_ctx *ctx, const void *d_data, int dtype, int snum, i
                      double vtaper, void *d_out);
 
 /* ---- the library's own batched power-of-two row transforms (csrc/own_fft.h) ----
- * What the FIRST Stolt / phase-shift call of a power-of-two size runs its transforms on (rocFFT compiles the kernels of
- * lengths above 1024 at run time: 0.25-3 s per plan, profiles/r05_first_call.txt; the second call of a size makes the
- * rocFFT plans).  numpy.fft conventions
+ * What the Stolt / phase-shift calls of power-of-two sizes run their transforms on (rocFFT compiles the kernels of
+ * lengths above 1024 at run time: 0.25-3 s per plan, profiles/r05_first_call.txt).  numpy.fft conventions
  * (mig_python.py:159, 202, 270, 282), unnormalised, times `scale`.
  * mode 0: complex forward, 1: complex inverse -- d_in / d_out [batch][n] complex (d_out may be d_in);
  * mode 2: real forward -- d_in [batch][n] real, d_out [batch][n/2 + 1] complex;
  * mode 3: real inverse -- d_in [batch][n/2 + 1] complex, d_out [batch][n] real (imaginary parts of the first and last
- * entry are the caller's business: numpy.fft.irfft ignores them).
+ * entry are the caller's business: numpy.fft.irfft ignores them);
+ * mode 4: complex inverse, real parts only -- d_in [batch][n] complex, d_out [batch][n] real (mig_python.py:282).
  * n a power of two; complex length (n, or n/2 for the real modes) 16 .. 8192.  dtype IMPDAR_F32 / IMPDAR_F64. */
 int impdar_fft_rows_dev(impdar_ctx *ctx, int mode, int dtype, int n, int batch, const void *d_in, void *d_out, double scale);
 

@@ -214,8 +214,8 @@ def test_own_row_transforms_carry_stolt_and_phase_shift(hip, monkeypatch, snum, 
 
 
 def test_first_call_runs_on_the_own_transforms_and_later_calls_on_rocfft(hip, monkeypatch):
-    """A size the process has not seen: the first call uses the library's own transforms (nothing to compile); for the phase
-    shift the second call of the size makes the rocFFT plans and uses them.  Same image either way (to the transforms' rounding)."""
+    """A power-of-two size: every call runs on the library's own transforms (nothing to compile, no plan); rocFFT's plans on
+    request.  Same image either way (to the transforms' rounding)."""
     import ctypes as C
     from impdar_amd import _hip, synth
     for k in ('IMPDAR_STOLT_FFT', 'IMPDAR_PS_FFT'):
@@ -236,12 +236,11 @@ def test_first_call_runs_on_the_own_transforms_and_later_calls_on_rocfft(hip, mo
         first, how1 = call(mtype)
         second, how2 = call(mtype)
         third, how3 = call(mtype)
-        # (Stolt: the own transforms are also the faster ones at power-of-two sizes -- every call; IMPDAR_STOLT_FFT=rocfft asks for the plans)
-        assert (how1, how2, how3) == (('own', 'own', 'own') if mtype == 'stolt' else ('own', 'rocfft', 'rocfft')), (mtype, how1, how2, how3)
-        assert rel_l2(second, first) < 5e-6, (mtype, rel_l2(second, first))
-        assert np.array_equal(second, third)
-        if mtype == 'stolt':
-            monkeypatch.setenv('IMPDAR_STOLT_FFT', 'rocfft')
-            lib_form, how = call('stolt')
-            monkeypatch.delenv('IMPDAR_STOLT_FFT')
-            assert how == 'rocfft' and rel_l2(lib_form, third) < 5e-6, (how, rel_l2(lib_form, third))
+        # (power-of-two sizes: the own transforms on every call since round 5; IMPDAR_STOLT_FFT / IMPDAR_PS_FFT = rocfft ask for the plans)
+        assert (how1, how2, how3) == ('own', 'own', 'own'), (mtype, how1, how2, how3)
+        assert np.array_equal(second, first) and np.array_equal(second, third)
+        knob = 'IMPDAR_STOLT_FFT' if mtype == 'stolt' else 'IMPDAR_PS_FFT'
+        monkeypatch.setenv(knob, 'rocfft')
+        lib_form, how = call(mtype)
+        monkeypatch.delenv(knob)
+        assert how == 'rocfft' and rel_l2(lib_form, third) < 5e-6, (how, rel_l2(lib_form, third))

@@ -40,6 +40,7 @@ def test_row_transforms_against_numpy(hip, n, dtype):
         z = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(cdt)
         close(run(0, z, (batch, n), cdt), np.fft.fft(z.astype(np.complex128), axis=1))
         close(run(1, z, (batch, n), cdt, scale=1.0 / n, inplace=True), np.fft.ifft(z.astype(np.complex128), axis=1))
+        close(run(4, z, (batch, n), dtype, scale=1.0 / n), np.fft.ifft(z.astype(np.complex128), axis=1).real)      # Re only
     x = rng.standard_normal((batch, n)).astype(dtype)
     X = np.fft.rfft(x.astype(np.float64), axis=1)
     close(run(2, x, (batch, n // 2 + 1), cdt), X)
