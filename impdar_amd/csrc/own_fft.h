@@ -25,7 +25,7 @@ template <typename T> struct OCp { T x, y; };
 
 enum { OWN_C2C_FWD = 0, OWN_C2C_INV = 1, OWN_R2C = 2, OWN_C2R = 3, OWN_C2C_INV_RE = 4 };     // 4: the inverse's REAL parts only
 
-__host__ __device__ inline int own_pad(int i) { return i + (i >> 5); }
+__host__ __device__ constexpr int own_pad(int i) { return i + (i >> 5); }
 // complex length M the kernel supports: a power of two, 16 ... 8192 (float64 rows of 8192 take 132 KB of LDS)
 static inline bool own_fft_len_ok(long long m) { return m >= 16 && m <= 8192 && (m & (m - 1)) == 0; }
 
@@ -49,6 +49,43 @@ __device__ __forceinline__ int own_rev(int k, int M, int logm)
     }
     if (logm & 1) p += (k & 1);         // span is 2 here: the last digit has weight 1
     return p;
+}
+
+// The passes of a length-M transform on a row that sits in LDS at s[own_pad(i)] (decimation in frequency, in place, radix 4
+// and a last radix 2 when log2 M is odd): the result of index k is left at position own_rev(k).  Every thread of the
+// workgroup calls it (barriers inside).  tw: e^{-2 pi i k / (M tws)}.
+template <typename T, bool INV>
+__device__ __forceinline__ void own_fft_passes(OCp<T> *s, int M, int logm, int tid, int nth, const OCp<T> *__restrict__ tw, int TWS)
+{
+    int ll = logm;                      // log2 of the span of the pass
+    while (ll >= 2) {
+        const int lq = ll - 2, q = 1 << lq, L = 1 << ll, tstep = (M >> ll) * TWS;
+        for (int b = tid; b < (M >> 2); b += nth) {
+            const int g = b >> lq, j = b & (q - 1), base = g * L + j;
+            const OCp<T> a0 = s[own_pad(base)], a1 = s[own_pad(base + q)], a2 = s[own_pad(base + 2 * q)], a3 = s[own_pad(base + 3 * q)];
+            const OCp<T> t0 = own_add(a0, a2), t1 = own_sub(a0, a2), t2 = own_add(a1, a3), d = own_sub(a1, a3);
+            // forward: -i d = (d.y, -d.x); inverse: +i d = (-d.y, d.x)
+            const OCp<T> t3 = INV ? OCp<T>{-d.y, d.x} : OCp<T>{d.y, -d.x};
+            OCp<T> w1 = tw[j * tstep];
+            if (INV) w1.y = -w1.y;
+            const OCp<T> w2 = own_mul(w1, w1), w3 = own_mul(w2, w1);
+            s[own_pad(base)] = own_add(t0, t2);
+            s[own_pad(base + q)] = own_mul(own_add(t1, t3), w1);
+            s[own_pad(base + 2 * q)] = own_mul(own_sub(t0, t2), w2);
+            s[own_pad(base + 3 * q)] = own_mul(own_sub(t1, t3), w3);
+        }
+        __syncthreads();
+        ll -= 2;
+    }
+    const int L = 1 << ll;
+    if (L == 2) {
+        for (int b = tid; b < (M >> 1); b += nth) {
+            const OCp<T> a0 = s[own_pad(2 * b)], a1 = s[own_pad(2 * b + 1)];
+            s[own_pad(2 * b)] = own_add(a0, a1);
+            s[own_pad(2 * b + 1)] = own_sub(a0, a1);
+        }
+        __syncthreads();
+    }
 }
 
 // in:  MODE 0/1: [batch][M] complex, rows in_dist COMPLEX elements apart;  MODE 2: [batch][2 M] real, rows in_dist REAL elements
@@ -85,36 +122,7 @@ __global__ __launch_bounds__(1024) void own_fft_rows(const void *__restrict__ in
         for (int i = tid; i < M; i += nth) s[own_pad(i)] = X[i];
     }
     __syncthreads();
-    // ---- decimation in frequency, in place
-    int ll = logm;                      // log2 of the span of the pass
-    while (ll >= 2) {
-        const int lq = ll - 2, q = 1 << lq, L = 1 << ll, tstep = (M >> ll) * TWS;
-        for (int b = tid; b < (M >> 2); b += nth) {
-            const int g = b >> lq, j = b & (q - 1), base = g * L + j;
-            const OCp<T> a0 = s[own_pad(base)], a1 = s[own_pad(base + q)], a2 = s[own_pad(base + 2 * q)], a3 = s[own_pad(base + 3 * q)];
-            const OCp<T> t0 = own_add(a0, a2), t1 = own_sub(a0, a2), t2 = own_add(a1, a3), d = own_sub(a1, a3);
-            // forward: -i d = (d.y, -d.x); inverse: +i d = (-d.y, d.x)
-            const OCp<T> t3 = INV ? OCp<T>{-d.y, d.x} : OCp<T>{d.y, -d.x};
-            OCp<T> w1 = tw[j * tstep];
-            if (INV) w1.y = -w1.y;
-            const OCp<T> w2 = own_mul(w1, w1), w3 = own_mul(w2, w1);
-            s[own_pad(base)] = own_add(t0, t2);
-            s[own_pad(base + q)] = own_mul(own_add(t1, t3), w1);
-            s[own_pad(base + 2 * q)] = own_mul(own_sub(t0, t2), w2);
-            s[own_pad(base + 3 * q)] = own_mul(own_sub(t1, t3), w3);
-        }
-        __syncthreads();
-        ll -= 2;
-    }
-    const int L = 1 << ll;
-    if (L == 2) {
-        for (int b = tid; b < (M >> 1); b += nth) {
-            const OCp<T> a0 = s[own_pad(2 * b)], a1 = s[own_pad(2 * b + 1)];
-            s[own_pad(2 * b)] = own_add(a0, a1);
-            s[own_pad(2 * b + 1)] = own_sub(a0, a1);
-        }
-        __syncthreads();
-    }
+    own_fft_passes<T, INV>(s, M, logm, tid, nth, tw, TWS);
     // ---- store (the digit reversal is undone here)
     if (MODE == OWN_R2C) {
         OCp<T> *Y = reinterpret_cast<OCp<T> *>(out_) + row * out_dist;

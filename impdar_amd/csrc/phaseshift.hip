@@ -1320,6 +1320,10 @@ struct PsPlan {
     DevBuf d_blocks, d_edge, d_runtab;   // matrix-core path: row-block table; boundary-frequency counts + lists; per-run phases
     DevBuf d_pr_runs, d_pr_stages, d_rw; // many-runs matrix-core path (ps_runs.h): runs, stages, 1 / w
     DevBuf d_mcount;                     // matrix-core paths: MFMA instructions the kernel issued (one 64-bit counter)
+    DevBuf d_pn_pieces, d_pn_corr;       // transform path (ps_nufft.h): pieces, the window's correction tables
+    OwnTwiddles pn_tw[13];               // ... twiddles of the grid lengths 2^l
+    std::vector<float> h_pn_corr;        // ... the tables on the host (made once per padded length)
+    int pn_corr_off[12] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
     double mfma_instructions = -1.0;     // ... of the last call (-1: not a matrix-core call)
     // a (kx, runs) geometry whose boundary-frequency lists overflowed in a matrix-core path: not tried again
     std::vector<double> ovf_kx;
@@ -1416,6 +1420,7 @@ static int ps_dispatch(const PsParams &P, hipStream_t st)
 }
 
 #include "ps_pair.h"
+#include "ps_nufft.h"
 #include "ps_runs.h"        // many runs of constant velocity: float32 MFMA, phases generated in the kernel
 
 // did a matrix-core path find more boundary frequencies than it lists on this (kx, runs) geometry before?  (ADVICE r4:
@@ -1593,6 +1598,121 @@ static int ps_runs_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
         pl.mfma_instructions = (double)n;
     }
     impdar_trace("ps_runs: counters read back: %.0f MFMA instructions, worst edge count %d, %d parts, pairs %d", pl.mfma_instructions, worst, nparts, (int)pairs);
+    *done = true;
+    return IMPDAR_OK;
+}
+
+// ---- transform path (ps_nufft.h): pieces, correction tables, launch.  Same contract as ps_mfma_run.
+static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &runs, bool vz, const double *kx_host, const double *w_host,
+                        const double *thr, hipStream_t st, bool *done)
+{
+    *done = false;
+    const int snum = P.snum, tnum = P.tnum, nf = P.nf;
+    if (!P.herm || nf < 64 || nf > PN_NFMAX || snum < 64 || runs.empty()) return IMPDAR_OK;
+    if (vz && ps_known_overflow(pl, kx_host, tnum, runs)) return IMPDAR_OK;
+    if (vz)
+        for (int i = 0; i < snum; ++i)
+            if (!(thr[i] < 1e-10)) return IMPDAR_OK;       // the evanescence test must be the sign of coss off the boundary band
+    // the gather inverts the dispersion relation on a uniform frequency axis: slot i + 1 at (i + 1) dw, the Nyquist row (slot 0) at nf dw
+    const double dw = w_host[1];
+    if (!(dw > 0.0)) return IMPDAR_OK;
+    for (int i = 1; i < nf; ++i)
+        if (std::fabs(w_host[i] - (double)i * dw) > 1e-9 * (double)i * dw) return IMPDAR_OK;
+    if (std::fabs(std::fabs(w_host[0]) - (double)nf * dw) > 1e-9 * (double)nf * dw) return IMPDAR_OK;
+    std::vector<PnPiece> pc;
+    int nshort_steps = 0;
+    bool need[12] = {};
+    for (const PsMfmaRun &r : runs) {
+        if (vz && r.len <= PN_SHORT) {
+            pc.push_back(PnPiece{r.v, r.start, r.len, 1, 0});
+            nshort_steps += r.len;
+            continue;
+        }
+        const int npiece = (r.len + PN_LMAX - 1) / PN_LMAX;
+        for (int i = 0, at = 0; i < npiece; ++i) {
+            const int len = (r.len - at) / (npiece - i);
+            int l = 4;
+            while ((1 << l) < len) ++l;
+            pc.push_back(PnPiece{r.v, r.start + at, len, 0, l});
+            need[l] = true;
+            at += len;
+        }
+    }
+    // a direct step costs as much as a tenth of a piece: tables of many layers stay with ps_runs_kernel
+    if (nshort_steps > 64 || pc.size() > 256) return IMPDAR_OK;
+    // 1 / psihat(n), n = 0 .. Lp/2, of every padded length in use: psihat(n) = int psi(x) cos(2 pi n x / G) dx over |x| < W/2
+    // (Simpson, float64; the integrand ends at e^{-beta} = 1e-8 of its maximum).  Made once per length and plan.
+    PnParams Q;
+    std::vector<float> &corr = pl.h_pn_corr;
+    bool grew = false;
+    for (int l = 0; l < 12; ++l) {
+        if (!need[l] || pl.pn_corr_off[l] >= 0) continue;
+        pl.pn_corr_off[l] = (int)corr.size();
+        grew = true;
+        const int Lp = 1 << l, G = 2 * Lp, NS = 512;
+        const double beta = 2.30 * PN_W, h = (double)PN_W / NS;
+        std::vector<double> psi((size_t)NS + 1);
+        for (int q = 0; q <= NS; ++q) {
+            const double x = -0.5 * PN_W + q * h, z = 1.0 - (2.0 * x / PN_W) * (2.0 * x / PN_W);
+            psi[q] = std::exp(beta * (std::sqrt(z > 0.0 ? z : 0.0) - 1.0)) * ((q == 0 || q == NS) ? 1.0 : ((q & 1) ? 4.0 : 2.0));
+        }
+        for (int n = 0; n <= Lp / 2; ++n) {
+            double sum = 0.0;
+            const double f = 6.283185307179586 * n / G;
+            for (int q = 0; q <= NS; ++q) sum += psi[q] * std::cos(f * (-0.5 * PN_W + q * h));
+            corr.push_back((float)(1.0 / (sum * h / 3.0)));
+        }
+    }
+    for (int l = 0; l < 12; ++l) Q.corr_off[l] = pl.pn_corr_off[l] < 0 ? 0 : pl.pn_corr_off[l];
+    std::vector<double> rw((size_t)nf);
+    for (int i = 0; i < nf; ++i) rw[i] = 1.0 / w_host[i];
+    if (pl.d_pn_pieces.ensure(pc.size() * sizeof(PnPiece)) != hipSuccess || pl.d_pn_corr.ensure(corr.size() * 4 + 16) != hipSuccess ||
+        pl.d_rw.ensure(rw.size() * 8) != hipSuccess || pl.d_edge.ensure((size_t)tnum * (1 + PM_EMAX) * sizeof(int)) != hipSuccess) {
+        (void)hipGetLastError();
+        return IMPDAR_OK;
+    }
+    for (int l = 5; l <= 12; ++l)
+        if (need[l - 1]) {
+            int rc = pl.pn_tw[l].ensure<float>(1 << l, st);
+            if (rc) return rc;
+        }
+    for (int l = 0; l < 13; ++l) Q.tw[l] = pl.pn_tw[l].buf.as<OCp<float>>();
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_pn_pieces.p, pc.data(), pc.size() * sizeof(PnPiece), hipMemcpyHostToDevice, st));
+    if (grew || !pl.d_pn_corr.p) IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_pn_corr.p, corr.data(), corr.size() * 4, hipMemcpyHostToDevice, st));
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_rw.p, rw.data(), rw.size() * 8, hipMemcpyHostToDevice, st));
+    Q.P = P;
+    Q.pieces = pl.d_pn_pieces.as<PnPiece>();
+    Q.npieces = (int)pc.size();
+    Q.rw = pl.d_rw.as<double>();
+    Q.corr = pl.d_pn_corr.as<float>();
+    Q.edge_cnt = pl.d_edge.as<int>();
+    Q.edge_list = Q.edge_cnt + tnum;
+    Q.vz = vz ? 1 : 0;
+    if (vz) IMPDAR_HIP_CHECK(hipMemsetAsync(Q.edge_cnt, 0, (size_t)tnum * sizeof(int), st));
+    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_nufft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pn_lds_bytes()));
+    hipLaunchKernelGGL(ps_nufft_kernel, dim3((unsigned)P.nk), dim3(PN_NTH), pn_lds_bytes(), st, Q);
+    if (vz) {
+        PsMfmaParams E;                        // (ps_edge_kernel reads P and the lists only)
+        E.mfma_count = nullptr;
+        E.P = P;
+        E.nruns = 0;
+        E.pairs = 0;
+        E.edge_cnt = Q.edge_cnt;
+        E.edge_list = Q.edge_list;
+        hipLaunchKernelGGL(ps_edge_kernel, dim3(P.nk), dim3(256), 0, st, E);
+    }
+    IMPDAR_HIP_CHECK(hipGetLastError());
+    IMPDAR_HIP_CHECK(hipStreamSynchronize(st));            // (the host tables must outlive their copies)
+    if (vz) {
+        std::vector<int> cnt((size_t)P.nk);
+        IMPDAR_HIP_CHECK(hipMemcpy(cnt.data(), Q.edge_cnt + P.k0, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+        int worst = 0;
+        for (int c : cnt) worst = std::max(worst, c);
+        if (worst > PM_EMAX) {
+            ps_note_overflow(pl, kx_host, tnum, runs);
+            return IMPDAR_OK;                  // contributions missing from TK: discarded, another path produces the result
+        }
+    }
     *done = true;
     return IMPDAR_OK;
 }
@@ -2080,6 +2200,14 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         // 11 long runs -- and 10.8 on the config-5 table; ps_runs_kernel, two wavenumbers per workgroup, 11.8 / 11.9 / 12.4 /
         // 12.8 / 13.8 at 3 / 4 / 5 / 7 / 11 long runs, 15.3 at 21, 21.3 at 42, 12.0 on the config-5 table)
         const bool runs_first = vlen != 0 && nlong > 3;
+        // ... 6: only the transform path (ps_nufft.h) ahead of them.  By itself: the transform path for a constant velocity and
+        // tables of up to 12 thick layers (8192^2 device ms at 3 / 5 / 7 / 11 / 21 long runs: 6.9 / 8.7 / 10.4 / 12.3 / 21.7 against
+        // ps_runs_kernel's 11.8 / 12.4 / 12.8 / 13.8 / 15.3; config 5: 6.7 against ps_mfma_kernel's 10.6, constant velocity 4.9
+        // against 6.8 -- profiles/r05_ps_nufft.txt), then the matrix-core paths as before
+        if (ok && (pref == 6 || (pref == 1 && nlong <= 12)) && !force_overflow) {
+            if ((rc = ps_nufft_run(pl, P, mruns, vlen != 0, kx, w.data(), thr.data(), st, &mfma_done))) return rc;
+            if (mfma_done) mfma_kernel_name = "ps_nufft_kernel";
+        }
         for (int turn = 0; turn < 2 && ok && !mfma_done && pref != 0; ++turn) {
             const bool use_runs = (turn == 0) == runs_first;
             if (use_runs) {
@@ -2134,14 +2262,14 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     ctx->m_entry = tk_out ? "impdar_phaseshift_tk_dev" : "impdar_phaseshift";
     ctx->m_kernel = mfma_done ? mfma_kernel_name : t_ps_kernel;
     ctx->m_kernel_ms = -1.f;                 // (bracketed by ktic / ktoc)
-    if (mfma_done)      // (MFMA instructions the kernel issued, counted by the kernel: rounds and blocks it skips are not in it)
+    if (mfma_done && pl.mfma_instructions >= 0.0)      // (MFMA instructions the kernel issued, counted by the kernel: rounds and blocks it skips are not in it)
         snprintf(ctx->m_extra, sizeof ctx->m_extra,
                  "\"hermitian_walk\": %s, \"frequencies\": %d, \"transforms\": \"%s\", \"long_runs\": %d, \"mfma_instructions\": %.0f, \"flop_per_mfma\": %d",
                  herm ? "true" : "false", nf, use_own ? "own" : "rocfft", long_runs, pl.mfma_instructions,
                  strcmp(mfma_kernel_name, "ps_runs_kernel") == 0 ? 16384 : 32768);
     else
-        snprintf(ctx->m_extra, sizeof ctx->m_extra, "\"hermitian_walk\": %s, \"frequencies\": %d, \"transforms\": \"%s\"",
-                 herm ? "true" : "false", nf, use_own ? "own" : "rocfft");
+        snprintf(ctx->m_extra, sizeof ctx->m_extra, "\"hermitian_walk\": %s, \"frequencies\": %d, \"transforms\": \"%s\", \"long_runs\": %d",
+                 herm ? "true" : "false", nf, use_own ? "own" : "rocfft", long_runs);
     if (herm)
         for (int kz : k_zero)
             if (kz >= k0 && kz < k0 + nk)

@@ -1,0 +1,271 @@
+// Phase-shift frequency sum as a NON-UNIFORM FAST FOURIER TRANSFORM (float32 data, a few long runs of constant velocity;
+// included by phaseshift.hip after own_fft.h and ps_mfma.h).
+//
+// Inside a run of constant velocity every frequency turns by a fixed angle phi_w per depth step, so what the reference
+// accumulates step by step (mig_python.py:418-420, :464, :487) is a sum of exponentials sampled on the integers,
+//     TK[tau0 + n] = sum_w  C_w e^{i phi_w (n + 1)},     C_w = FK_w e^{i Phi_w(tau0)},   n = 0 .. L - 1,
+// a type-1 non-uniform discrete Fourier transform ("non-uniform frequencies phi_w in (0, 2 pi) -> uniform samples n").  The
+// kernels of ps.hip / ps_mfma.h / ps_runs.h evaluate it directly, O(frequencies x steps) rotations per wavenumber -- on the
+// vector units, or as a matrix product on the matrix cores.  Here it costs O(frequencies x W + G log G):
+//   1. the coefficient of every frequency, turned to the middle of the piece (the transform's band is centred),
+//      D_w = C_w e^{i phi_w (1 + Lp/2)}, and its place on a fine grid of G = 2 Lp points, u_w = phi_w G / 2 pi;
+//   2. SPREADING: g[m] = sum_w D_w psi(u_w - m) with a window psi of W = 8 grid points ("exponential of semicircle",
+//      psi(x) = exp(beta (sqrt(1 - (2x/W)^2) - 1)), beta = 2.30 W: Barnett, Magland, af Klinteberg 2019).  As a GATHER: a
+//      thread owns grid points and walks the frequencies that reach them -- u_w grows with the slot index, and the range
+//      comes from the dispersion relation itself, w(u) = sqrt((2 pi u / G dt)^2 + (v kx / 2)^2) -- so every sum has a fixed
+//      order (no atomics: results are reproducible bit for bit);
+//   3. one inverse FFT of length G in LDS (own_fft.h's passes);
+//   4. TK[tau0 + n] = ghat[n - Lp/2] / psihat(n - Lp/2): the window's transform divided out (a table per Lp, host, float64
+//      Gauss-Legendre quadrature).
+// Error of the scheme with W = 8, twofold oversampling, float32 arithmetic: 3.5e-7 of the result (rel-L2; measured against a
+// float64 direct sum on config-5 geometries before any of this was written) -- the matrix-core paths, with their float16
+// hi/lo operands, are at 1.1e-6.
+//
+// Work split: one workgroup per wavenumber; every thread owns nf / 256 frequencies with their phase in a float64 register
+// and walks the pieces (runs cut to <= 1024 steps) in depth order; the few single steps a layer boundary is smeared over
+// are summed directly (a sincos per frequency and step, block reduction in a fixed order).  Frequencies on the
+// evanescent boundary of some run take no part and are listed for ps_edge_kernel, as in ps_mfma.h / ps_runs.h.
+#pragma once
+
+constexpr int PN_W = 8;                     // grid points a frequency is spread over
+constexpr float PN_BETA = 2.30f * PN_W;
+constexpr int PN_LMAX = 1024;               // steps per piece at most (G = 2048 grid points)
+constexpr int PN_GMAX = 2 * PN_LMAX;
+constexpr int PN_NFMAX = 4096;              // frequencies per wavenumber this kernel takes (one workgroup holds them all)
+constexpr int PN_NTH = 256;
+constexpr int PN_PER = PN_NFMAX / PN_NTH;   // frequencies per thread
+constexpr int PN_SHORT = 8;                 // runs of up to this many steps are summed directly
+
+struct PnPiece {
+    double v;               // velocity
+    int start, len;         // first depth step, steps
+    int kind;               // 0: transform, 1: direct sums (len <= PN_SHORT)
+    int loglp;              // kind 0: log2 of the padded length Lp >= len (G = 2 Lp)
+};
+struct PnParams {
+    PsParams P;
+    const PnPiece *pieces;
+    int npieces;
+    const double *rw;               // [nf] 1 / w, by slot
+    const float *corr;              // the tables 1 / psihat, concatenated
+    int corr_off[12];               // ... of Lp = 2^l at corr + corr_off[l], Lp/2 + 1 entries (|n - Lp/2| = 0 .. Lp/2)
+    const OCp<float> *tw[13];       // e^{-2 pi i k / G}, G = 2^l
+    int *edge_cnt, *edge_list;      // v(z): boundary frequencies for ps_edge_kernel (null: constant velocity, none)
+    int vz;
+};
+
+__host__ __device__ constexpr size_t pn_lds_bytes()
+{
+    return (size_t)(own_pad(PN_GMAX) + 1) * 8 + (size_t)PN_NFMAX * (8 + 4 + 2) + 64 * 8;
+}
+
+__device__ __forceinline__ float pn_window(float x)      // psi(x), |x| < W/2 (0 outside)
+{
+    const float z = fmaf(-x * x, 4.0f / (PN_W * PN_W), 1.0f);
+    return z > 0.f ? __expf(PN_BETA * (__builtin_amdgcn_sqrtf(z) - 1.0f)) : 0.f;
+}
+
+__global__ __launch_bounds__(PN_NTH, 2) void ps_nufft_kernel(PnParams Q)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char pn_lds[];
+    const PsParams &P = Q.P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nf = P.nf;
+    // small |kx| (few evanescent frequencies: the long workgroups) first
+    const int bq = (int)blockIdx.x, kb = (bq & 1) ? P.nk - 1 - (bq >> 1) : (bq >> 1), k = P.k0 + kb;
+    OCp<float> *grid = reinterpret_cast<OCp<float> *>(pn_lds);                          // [own_pad(G)]
+    OCp<float> *D = grid + own_pad(PN_GMAX) + 1;                                        // [nf] coefficients, by index
+    float *fr = reinterpret_cast<float *>(D + PN_NFMAX);                                // [nf] u - floor(u)
+    unsigned short *m0 = reinterpret_cast<unsigned short *>(fr + PN_NFMAX);             // [nf] floor(u)
+    float *red = reinterpret_cast<float *>(m0 + PN_NFMAX);                              // [4][2 PN_SHORT] block reduction
+    const Cp<float> *Frow = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.fstride;
+    float *TKrow = reinterpret_cast<float *>(reinterpret_cast<Cp<float> *>(P.TK) + (size_t)kb * P.snum);
+    const double kxk = P.kx[k];
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    const float inv_snum = 1.0f / (float)P.snum;
+
+    // ---- this thread's frequencies: index i = tid + 256 j in ascending |w| (Hermitian walk: slot i + 1, the Nyquist row --
+    // slot 0 -- last: P.w is by slot).  phase NaN = out of every run from here on (evanescent, boundary band, past nf)
+    double ph[PN_PER];
+    bool edge[PN_PER];
+#pragma unroll
+    for (int j = 0; j < PN_PER; ++j) {
+        const int i = tid + PN_NTH * j;
+        ph[j] = i < nf ? 0.0 : nan;
+        edge[j] = false;
+    }
+    auto slot_of = [&](int i) { return i == nf - 1 ? 0 : i + 1; };
+    // phase per depth step of frequency `slot` at velocity v; 0 and *alive = false where it is evanescent.  Constant velocity:
+    // the reference's own test and expression (:411-415), as ps_setup_kernel; v(z): :456-460 off the boundary band
+    auto step_phase = [&](int slot, double v, bool *alive) -> double {
+        const double w = P.w[slot];
+        if (!Q.vz) {
+            const double vk = v * kxk / 2.0, vkx2 = vk * vk;
+            *alive = vkx2 < w * w;
+            return *alive ? w * P.dt * sqrt(1.0 - vkx2 / (w * w)) : 0.0;
+        }
+        const double cs = pm_coss(v, kxk, Q.rw[slot]);
+        *alive = cs > 0.0;
+        return *alive ? w * P.dt * pm_sqrt01(cs) : 0.0;
+    };
+    if (Q.vz) {
+        double vprev = 0.0;
+        for (int r = 0; r < Q.npieces; ++r) {
+            const double v = Q.pieces[r].v;
+            if (v == vprev) continue;                                         // uniform
+            vprev = v;
+#pragma unroll
+            for (int j = 0; j < PN_PER; ++j) {
+                const int i = tid + PN_NTH * j;
+                if (i < nf) edge[j] = edge[j] || fabs(pm_coss(v, kxk, Q.rw[slot_of(i)])) < 1e-8;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PN_PER; ++j) {
+            const int i = tid + PN_NTH * j;
+            if (edge[j] && i < nf) {
+                const int at = atomicAdd(Q.edge_cnt + k, 1);
+                if (at < PM_EMAX) Q.edge_list[(size_t)k * PM_EMAX + at] = slot_of(i);
+                ph[j] = nan;
+            }
+        }
+    }
+    // the frequency axis is uniform: w_i = (i + 1) dw (the Nyquist row, last, too) -- what the gather inverts
+    const double dw_d = fabs(P.w[1]);
+    const float inv_dw = (float)(1.0 / dw_d);
+
+    for (int r = 0; r < Q.npieces; ++r) {
+        const PnPiece pc = Q.pieces[r];
+        const double v = pc.v;
+        const int L = pc.len;
+        if (pc.kind == 1) {
+            // ---- single steps, summed directly: FK e^{i (Phi + (s + 1) phi)} per frequency and step (:464, :487)
+            float acc[2 * PN_SHORT];
+#pragma unroll
+            for (int s_ = 0; s_ < 2 * PN_SHORT; ++s_) acc[s_] = 0.f;
+#pragma unroll
+            for (int j = 0; j < PN_PER; ++j) {
+                const int i = tid + PN_NTH * j;
+                if (i >= nf) continue;
+                const int slot = slot_of(i);
+                bool alive;
+                const double inc = step_phase(slot, v, &alive);
+                if (!alive) ph[j] = nan;                                      // :484-485, for good
+                if (ph[j] == ph[j]) {
+                    const Cp<float> f = ps_load_slot<float>(Frow, P, slot);
+#pragma unroll
+                    for (int s_ = 0; s_ < PN_SHORT; ++s_)
+                        if (s_ < L) {                                         // uniform
+                            float sn, c;
+                            pm_sincos(ph[j] + (double)(s_ + 1) * inc, &sn, &c);
+                            acc[2 * s_] += fmaf(f.x, c, -(f.y * sn));
+                            acc[2 * s_ + 1] += fmaf(f.x, sn, f.y * c);
+                        }
+                    ph[j] = pm_wrap(ph[j] + (double)L * inc);
+                }
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < 2 * PN_SHORT; ++s_) {
+                float x = acc[s_];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+                if (lane == 0) red[wave * 2 * PN_SHORT + s_] = x;
+            }
+            __syncthreads();
+            if (tid < 2 * L) {
+                float sum = 0.f;
+#pragma unroll
+                for (int q = 0; q < PN_NTH / 64; ++q) sum += red[q * 2 * PN_SHORT + tid];
+                TKrow[2 * (size_t)(pc.start + (tid >> 1)) + (tid & 1)] = sum * inv_snum;      // :492
+            }
+            __syncthreads();
+            continue;
+        }
+        // ---- a piece of a long run: coefficients and grid places, spreading, inverse FFT, window divided out
+        const int Lp = 1 << pc.loglp, G = 2 * Lp, logg = pc.loglp + 1;
+        const double ug = (double)G * 0.15915494309189535;                    // G / 2 pi
+        for (int m = tid; m < own_pad(G) + 1; m += PN_NTH) grid[m] = OCp<float>{0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < PN_PER; ++j) {
+            const int i = tid + PN_NTH * j;
+            if (i >= nf) continue;
+            const int slot = slot_of(i);
+#ifdef PN_ABL_NOSETUP
+            if (r > 0) continue;                                              // timing only
+#endif
+            bool alive;
+            const double inc = step_phase(slot, v, &alive);                   // (negative for the Nyquist row: w = -pi / dt)
+            if (!alive) ph[j] = nan;
+            OCp<float> d{0.f, 0.f};
+            if (ph[j] == ph[j]) {
+                const Cp<float> f = ps_load_slot<float>(Frow, P, slot);
+                float sn, c;
+                pm_sincos(ph[j] + (double)(1 + Lp / 2) * inc, &sn, &c);
+                d = OCp<float>{fmaf(f.x, c, -(f.y * sn)), fmaf(f.x, sn, f.y * c)};
+                ph[j] = pm_wrap(ph[j] + (double)L * inc);
+            }
+            // place on the grid: phi mod 2 pi in units of the grid spacing (dead frequencies: 0 -- they carry D = 0)
+            double u = inc * ug;
+            u -= (double)G * floor(u / (double)G);
+            const double fl = floor(u);
+            D[i] = d;
+            m0[i] = (unsigned short)min((int)fl, G - 1);
+            fr[i] = (float)(u - fl);
+        }
+        __syncthreads();
+        {
+            // gather: grid point m takes the frequencies with |u_w - m| < W/2.  Their indices from the dispersion relation:
+            // u = (G dt / 2 pi) sqrt(w^2 - c^2), c = v kx / 2, w = (i + 1) dw  ->  i(u) = sqrt((2 pi u / G dt)^2 + c^2) / dw - 1
+            const float cq = (float)(0.5 * v * kxk), c2 = cq * cq;
+            const float a = (float)(6.283185307179586 / ((double)G * P.dt)), a2 = a * a;
+            const int ilast = nf - 2;                                         // regular frequencies: indices 0 .. nf - 2
+            // the Nyquist row (index nf - 1): anywhere on the grid, looked at by every grid point
+            const float uN = (float)m0[nf - 1] + fr[nf - 1];
+            const OCp<float> dN = D[nf - 1];
+#ifdef PN_ABL_NOGATHER
+            for (int m = tid; m < 0; m += PN_NTH) {      // timing only
+#else
+            for (int m = tid; m < G; m += PN_NTH) {
+#endif
+                const float mm = (float)(m > G / 2 + PN_W ? m - G : m);      // centred: the regular frequencies sit in [0, G/2]
+                float gx = 0.f, gy = 0.f;
+                const float uhi = mm + 0.5f * PN_W, ulo = fmaxf(mm - 0.5f * PN_W, 0.f);
+                if (uhi > 0.f) {
+                    int ilo = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * ulo, ulo, c2)) * inv_dw) - 3;
+                    int ihi = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * uhi, uhi, c2)) * inv_dw) + 2;
+                    ilo = max(ilo, 0);
+                    ihi = min(ihi, ilast);
+                    for (int i = ilo; i <= ihi; ++i) {
+                        const float x = ((float)m0[i] - mm) + fr[i];
+                        const float wgt = pn_window(x);
+                        const OCp<float> d = D[i];
+                        gx = fmaf(d.x, wgt, gx);
+                        gy = fmaf(d.y, wgt, gy);
+                    }
+                }
+                {
+                    float x = uN - (float)m;
+                    x -= (float)G * rintf(x / (float)G);
+                    const float wgt = pn_window(x);
+                    gx = fmaf(dN.x, wgt, gx);
+                    gy = fmaf(dN.y, wgt, gy);
+                }
+                grid[own_pad(m)] = OCp<float>{gx, gy};
+            }
+        }
+        __syncthreads();
+#ifndef PN_ABL_NOFFT
+        own_fft_passes<float, true>(grid, G, logg, tid, PN_NTH, Q.tw[logg], 1);
+#endif
+        {
+            const float *corr = Q.corr + Q.corr_off[pc.loglp];
+            for (int n = tid; n < L; n += PN_NTH) {
+                const int np = n - Lp / 2;                                    // the band is centred: n' in [-Lp/2, Lp/2)
+                const OCp<float> z = grid[own_pad(own_rev(np & (G - 1), G, logg))];
+                const float cf = corr[np < 0 ? -np : np] * inv_snum;
+                reinterpret_cast<float2 *>(TKrow)[pc.start + n] = make_float2(z.x * cf, z.y * cf);
+            }
+        }
+        __syncthreads();
+    }
+}

@@ -302,7 +302,8 @@ def test_matrix_core_path_against_the_vector_kernels_and_the_oracle(hip, monkeyp
     outs, kernels = {}, {}
     # '5': ps_pair_kernel (the wavenumbers kx and -kx in one workgroup, state tiles made once for both -- an odd and two even
     # trace counts: k = 0 and the Nyquist row are their own partners; not the default: it is no faster); '2': ps_mfma_kernel
-    for mfma, herm in (('5', '1'), ('2', '1'), ('0', '1'), ('5', '0'), ('2', '0')):
+    # '6': ps_nufft_kernel -- the frequency sum of a run as a non-uniform FFT (what a call runs by itself on such tables)
+    for mfma, herm in (('5', '1'), ('2', '1'), ('0', '1'), ('5', '0'), ('2', '0'), ('6', '1'), ('1', '1')):
         monkeypatch.setenv('IMPDAR_PS_MFMA', mfma)
         monkeypatch.setenv('IMPDAR_PS_HERMITIAN', herm)
         d = RadarData(None)
@@ -322,7 +323,9 @@ def test_matrix_core_path_against_the_vector_kernels_and_the_oracle(hip, monkeyp
     if kind == 'const':
         assert kernels['5', '1'] == 'ps_pair_kernel', kernels
     assert 'mfma' not in kernels['0', '1'] and 'pair' not in kernels['0', '1'], kernels
-    for m in ('5', '2'):
+    assert kernels['6', '1'] == kernels['1', '1'] == 'ps_nufft_kernel', kernels
+    assert np.array_equal(outs['6', '1'], outs['1', '1'])
+    for m in ('5', '2', '6'):
         assert rel_l2(outs[m, '1'], outs['0', '1']) < F32_L2
         # the matrix-core result must not be worse than a few times the vector kernels' own float32 error
         assert rel_l2(outs[m, '1'], want) < max(5.0 * rel_l2(outs['0', '1'], want), 2e-6), (m, rel_l2(outs[m, '1'], want))
@@ -389,7 +392,7 @@ def test_many_runs_matrix_core_path_against_the_vector_kernels_and_the_oracle(hi
     _hip.check(_hip.load().impdar_ctx_last_metrics(_hip.context(), buf, len(buf)), 'metrics')
     chosen = json.loads(buf.value.decode())['kernel']
     # (up to 16 long runs: ps_mfma_kernel where its 2048-step row blocks are not mostly padding, i.e. on long records)
-    assert chosen in ('ps_runs_kernel', 'ps_mfma_kernel', 'ps_pair_kernel'), (kind, chosen)
+    assert chosen in ('ps_runs_kernel', 'ps_mfma_kernel', 'ps_pair_kernel', 'ps_nufft_kernel'), (kind, chosen)
     assert chosen == 'ps_runs_kernel' or kind not in ('layers40',), (kind, chosen)
     if chosen == 'ps_runs_kernel':      # (the same sums; the transforms around them may be the library's own or rocFFT's by now)
         assert rel_l2(d.data, outs['3', '1']) < 5e-6
@@ -454,7 +457,7 @@ def test_matrix_core_path_hands_over_when_a_wavenumber_has_more_boundary_frequen
         buf = C.create_string_buffer(1024)
         _hip.check(_hip.load().impdar_ctx_last_metrics(_hip.context(), buf, len(buf)), 'metrics')
         kernels[name] = json.loads(buf.value.decode())['kernel']
-    assert kernels['mfma'] == 'ps_mfma_kernel' and kernels['overflow'] == kernels['vector'] != 'ps_mfma_kernel', kernels
+    assert kernels['mfma'] == 'ps_nufft_kernel' and kernels['overflow'] == kernels['vector'] and 'nufft' not in kernels['vector'] and 'mfma' not in kernels['vector'], kernels
     assert np.array_equal(outs['overflow'], outs['vector'])
 
 
