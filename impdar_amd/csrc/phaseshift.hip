@@ -1321,9 +1321,10 @@ struct PsPlan {
     DevBuf d_pr_runs, d_pr_stages, d_rw; // many-runs matrix-core path (ps_runs.h): runs, stages, 1 / w
     DevBuf d_mcount;                     // matrix-core paths: MFMA instructions the kernel issued (one 64-bit counter)
     DevBuf d_pn_pieces, d_pn_corr;       // transform path (ps_nufft.h): pieces, the window's correction tables
-    OwnTwiddles pn_tw[13];               // ... twiddles of the grid lengths 2^l
+    OwnTwiddles pn_tw[14];               // ... twiddles of the grid lengths 2^l
     std::vector<float> h_pn_corr;        // ... the tables on the host (made once per padded length)
-    int pn_corr_off[12] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+    std::vector<double> h_pn_corr64;
+    int pn_corr_off[13] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
     double mfma_instructions = -1.0;     // ... of the last call (-1: not a matrix-core call)
     // a (kx, runs) geometry whose boundary-frequency lists overflowed in a matrix-core path: not tried again
     std::vector<double> ovf_kx;
@@ -1577,7 +1578,7 @@ static int ps_runs_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
         E.pairs = 0;
         E.edge_cnt = Q.edge_cnt;
         E.edge_list = Q.edge_list;
-        hipLaunchKernelGGL(ps_edge_kernel, dim3(P.nk), dim3(256), 0, st, E);
+        hipLaunchKernelGGL(ps_edge_kernel_t<float>, dim3(P.nk), dim3(256), 0, st, E);
     }
     IMPDAR_HIP_CHECK(hipGetLastError());
     impdar_trace("ps_runs: buffers ready, tables copied, kernels enqueued");
@@ -1603,9 +1604,11 @@ static int ps_runs_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
 }
 
 // ---- transform path (ps_nufft.h): pieces, correction tables, launch.  Same contract as ps_mfma_run.
+template <typename T>
 static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &runs, bool vz, const double *kx_host, const double *w_host,
                         const double *thr, hipStream_t st, bool *done)
 {
+    constexpr int PN_W = PnCfg<T>::W;
     *done = false;
     const int snum = P.snum, tnum = P.tnum, nf = P.nf;
     if (!P.herm || nf < 64 || nf > PN_NFMAX || snum < 64 || runs.empty()) return IMPDAR_OK;
@@ -1621,7 +1624,7 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
     if (std::fabs(std::fabs(w_host[0]) - (double)nf * dw) > 1e-9 * (double)nf * dw) return IMPDAR_OK;
     std::vector<PnPiece> pc;
     int nshort_steps = 0;
-    bool need[12] = {};
+    bool need[13] = {};
     for (const PsMfmaRun &r : runs) {
         if (vz && r.len <= PN_SHORT) {
             pc.push_back(PnPiece{r.v, r.start, r.len, 1, 0});
@@ -1643,9 +1646,9 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
     // 1 / psihat(n), n = 0 .. Lp/2, of every padded length in use: psihat(n) = int psi(x) cos(2 pi n x / G) dx over |x| < W/2
     // (Simpson, float64; the integrand ends at e^{-beta} = 1e-8 of its maximum).  Made once per length and plan.
     PnParams Q;
-    std::vector<float> &corr = pl.h_pn_corr;
+    std::vector<T> &corr = sizeof(T) == 4 ? reinterpret_cast<std::vector<T> &>(pl.h_pn_corr) : reinterpret_cast<std::vector<T> &>(pl.h_pn_corr64);
     bool grew = false;
-    for (int l = 0; l < 12; ++l) {
+    for (int l = 0; l < 13; ++l) {
         if (!need[l] || pl.pn_corr_off[l] >= 0) continue;
         pl.pn_corr_off[l] = (int)corr.size();
         grew = true;
@@ -1660,37 +1663,43 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
             double sum = 0.0;
             const double f = 6.283185307179586 * n / G;
             for (int q = 0; q <= NS; ++q) sum += psi[q] * std::cos(f * (-0.5 * PN_W + q * h));
-            corr.push_back((float)(1.0 / (sum * h / 3.0)));
+            corr.push_back((T)(1.0 / (sum * h / 3.0)));
         }
     }
-    for (int l = 0; l < 12; ++l) Q.corr_off[l] = pl.pn_corr_off[l] < 0 ? 0 : pl.pn_corr_off[l];
+    for (int l = 0; l < 13; ++l) Q.corr_off[l] = pl.pn_corr_off[l] < 0 ? 0 : pl.pn_corr_off[l];
     std::vector<double> rw((size_t)nf);
     for (int i = 0; i < nf; ++i) rw[i] = 1.0 / w_host[i];
-    if (pl.d_pn_pieces.ensure(pc.size() * sizeof(PnPiece)) != hipSuccess || pl.d_pn_corr.ensure(corr.size() * 4 + 16) != hipSuccess ||
+    if (pl.d_pn_pieces.ensure(pc.size() * sizeof(PnPiece)) != hipSuccess || pl.d_pn_corr.ensure(corr.size() * sizeof(T) + 16) != hipSuccess ||
         pl.d_rw.ensure(rw.size() * 8) != hipSuccess || pl.d_edge.ensure((size_t)tnum * (1 + PM_EMAX) * sizeof(int)) != hipSuccess) {
         (void)hipGetLastError();
         return IMPDAR_OK;
     }
-    for (int l = 5; l <= 12; ++l)
+    for (int l = 5; l <= 13; ++l)
         if (need[l - 1]) {
-            int rc = pl.pn_tw[l].ensure<float>(1 << l, st);
+            int rc = pl.pn_tw[l].ensure<T>(1 << l, st);
             if (rc) return rc;
         }
-    for (int l = 0; l < 13; ++l) Q.tw[l] = pl.pn_tw[l].buf.as<OCp<float>>();
+    for (int l = 0; l < 14; ++l) Q.tw[l] = pl.pn_tw[l].buf.p;
     IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_pn_pieces.p, pc.data(), pc.size() * sizeof(PnPiece), hipMemcpyHostToDevice, st));
-    if (grew || !pl.d_pn_corr.p) IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_pn_corr.p, corr.data(), corr.size() * 4, hipMemcpyHostToDevice, st));
+    if (grew || !pl.d_pn_corr.p) IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_pn_corr.p, corr.data(), corr.size() * sizeof(T), hipMemcpyHostToDevice, st));
     IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_rw.p, rw.data(), rw.size() * 8, hipMemcpyHostToDevice, st));
     Q.P = P;
     Q.pieces = pl.d_pn_pieces.as<PnPiece>();
     Q.npieces = (int)pc.size();
     Q.rw = pl.d_rw.as<double>();
-    Q.corr = pl.d_pn_corr.as<float>();
+    Q.corr = pl.d_pn_corr.p;
     Q.edge_cnt = pl.d_edge.as<int>();
     Q.edge_list = Q.edge_cnt + tnum;
     Q.vz = vz ? 1 : 0;
     if (vz) IMPDAR_HIP_CHECK(hipMemsetAsync(Q.edge_cnt, 0, (size_t)tnum * sizeof(int), st));
-    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_nufft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pn_lds_bytes()));
-    hipLaunchKernelGGL(ps_nufft_kernel, dim3((unsigned)P.nk), dim3(PN_NTH), pn_lds_bytes(), st, Q);
+    {
+        int lmax = 4;
+        for (int l = 0; l < 13; ++l)
+            if (need[l]) lmax = l;
+        Q.gmax = 2 << lmax;
+    }
+    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_nufft_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pn_lds_bytes<T>(PN_GMAX)));
+    hipLaunchKernelGGL(ps_nufft_kernel<T>, dim3((unsigned)P.nk), dim3(PnCfg<T>::NTH), pn_lds_bytes<T>(Q.gmax), st, Q);
     if (vz) {
         PsMfmaParams E;                        // (ps_edge_kernel reads P and the lists only)
         E.mfma_count = nullptr;
@@ -1699,7 +1708,7 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
         E.pairs = 0;
         E.edge_cnt = Q.edge_cnt;
         E.edge_list = Q.edge_list;
-        hipLaunchKernelGGL(ps_edge_kernel, dim3(P.nk), dim3(256), 0, st, E);
+        hipLaunchKernelGGL(ps_edge_kernel_t<T>, dim3(P.nk), dim3(256), 0, st, E);
     }
     IMPDAR_HIP_CHECK(hipGetLastError());
     IMPDAR_HIP_CHECK(hipStreamSynchronize(st));            // (the host tables must outlive their copies)
@@ -1816,7 +1825,7 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PM_LDS_BYTES));
         hipLaunchKernelGGL(ps_mfma_kernel, dim3((unsigned)P.nk * Q.ngroups), dim3(PM_WAVES * 64), PM_LDS_BYTES, st, Q);
     }
-    if (vz) hipLaunchKernelGGL(ps_edge_kernel, dim3(P.nk), dim3(256), 0, st, Q);
+    if (vz) hipLaunchKernelGGL(ps_edge_kernel_t<float>, dim3(P.nk), dim3(256), 0, st, Q);
     IMPDAR_HIP_CHECK(hipGetLastError());
     // the host table must outlive its async copy
     IMPDAR_HIP_CHECK(hipStreamSynchronize(st));
@@ -2201,11 +2210,11 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         // 12.8 / 13.8 at 3 / 4 / 5 / 7 / 11 long runs, 15.3 at 21, 21.3 at 42, 12.0 on the config-5 table)
         const bool runs_first = vlen != 0 && nlong > 3;
         // ... 6: only the transform path (ps_nufft.h) ahead of them.  By itself: the transform path for a constant velocity and
-        // tables of up to 12 thick layers (8192^2 device ms at 3 / 5 / 7 / 11 / 21 long runs: 6.9 / 8.7 / 10.4 / 12.3 / 21.7 against
-        // ps_runs_kernel's 11.8 / 12.4 / 12.8 / 13.8 / 15.3; config 5: 6.7 against ps_mfma_kernel's 10.6, constant velocity 4.9
+        // tables of up to 10 thick layers (8192^2 device ms at 3 / 5 / 7 / 11 long runs: 5.8 / 7.7 / 9.4 / 13.4 against
+        // ps_runs_kernel's 11.8 / 12.4 / 12.8 / 13.8; config 5: 5.2 against ps_mfma_kernel's 10.6, constant velocity 3.0
         // against 6.8 -- profiles/r05_ps_nufft.txt), then the matrix-core paths as before
-        if (ok && (pref == 6 || (pref == 1 && nlong <= 12)) && !force_overflow) {
-            if ((rc = ps_nufft_run(pl, P, mruns, vlen != 0, kx, w.data(), thr.data(), st, &mfma_done))) return rc;
+        if (ok && (pref == 6 || (pref == 1 && nlong <= 10)) && !force_overflow) {
+            if ((rc = ps_nufft_run<float>(pl, P, mruns, vlen != 0, kx, w.data(), thr.data(), st, &mfma_done))) return rc;
             if (mfma_done) mfma_kernel_name = "ps_nufft_kernel";
         }
         for (int turn = 0; turn < 2 && ok && !mfma_done && pref != 0; ++turn) {

@@ -593,7 +593,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(PM_SM <= 4 
 // sum over the steps (each thread owns a contiguous stretch of steps), and added to TK.  Slots in ascending order:
 // the result does not depend on the order the frequency kernel found them in.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ps_edge_kernel(PsMfmaParams Q)
+template <typename T>
+__global__ __launch_bounds__(256) void ps_edge_kernel_t(PsMfmaParams Q)
 {
     const PsParams &P = Q.P;
     const int k = P.k0 + (int)blockIdx.x, tid = threadIdx.x;
@@ -613,14 +614,14 @@ __global__ __launch_bounds__(256) void ps_edge_kernel(PsMfmaParams Q)
             }
     }
     __syncthreads();
-    const Cp<float> *Frow = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.fstride;
-    Cp<float> *TKrow = reinterpret_cast<Cp<float> *>(P.TK) + (size_t)(k - P.k0) * P.snum;
+    const Cp<T> *Frow = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k * P.fstride;
+    Cp<T> *TKrow = reinterpret_cast<Cp<T> *>(P.TK) + (size_t)(k - P.k0) * P.snum;
     const double kxk = P.kx[k];
     const int seg = (P.snum + 255) / 256;
     const int lo = min(tid * seg, P.snum), hi = min(lo + seg, P.snum);
     for (int e = 0; e < n; ++e) {
         const int slot = slots[e];
-        const Cp<float> f = ps_load_slot<float>(Frow, P, slot);
+        const Cp<T> f = ps_load_slot<T>(Frow, P, slot);
         const double w = P.w[slot];
         // pass 1: this stretch's phase and its first dead step
         double sum = 0.0;
@@ -650,8 +651,8 @@ __global__ __launch_bounds__(256) void ps_edge_kernel(PsMfmaParams Q)
                 double sn, c2;
                 sincos(pm_wrap(ph), &sn, &c2);
                 const double re = (double)f.x * c2 - (double)f.y * sn, im = (double)f.x * sn + (double)f.y * c2;   // :464
-                TKrow[t].x += (float)(re / (double)P.snum);                     // :487, :492
-                TKrow[t].y += (float)(im / (double)P.snum);
+                TKrow[t].x += (T)(re / (double)P.snum);                     // :487, :492
+                TKrow[t].y += (T)(im / (double)P.snum);
             }
         }
         __syncthreads();

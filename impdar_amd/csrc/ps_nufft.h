@@ -1,4 +1,4 @@
-// Phase-shift frequency sum as a NON-UNIFORM FAST FOURIER TRANSFORM (float32 data, a few long runs of constant velocity;
+// Phase-shift frequency sum as a NON-UNIFORM FAST FOURIER TRANSFORM (float32 and float64 data, a few long runs of constant velocity;
 // included by phaseshift.hip after own_fft.h and ps_mfma.h).
 //
 // Inside a run of constant velocity every frequency turns by a fixed angle phi_w per depth step, so what the reference
@@ -21,20 +21,24 @@
 // float64 direct sum on config-5 geometries before any of this was written) -- the matrix-core paths, with their float16
 // hi/lo operands, are at 1.1e-6.
 //
-// Work split: one workgroup per wavenumber; every thread owns nf / 256 frequencies with their phase in a float64 register
+// Work split: one workgroup per wavenumber; every thread owns nf / 256 (512) frequencies with their phase in a float64 register
 // and walks the pieces (runs cut to <= 1024 steps) in depth order; the few single steps a layer boundary is smeared over
 // are summed directly (a sincos per frequency and step, block reduction in a fixed order).  Frequencies on the
 // evanescent boundary of some run take no part and are listed for ps_edge_kernel, as in ps_mfma.h / ps_runs.h.
 #pragma once
 
-constexpr int PN_W = 8;                     // grid points a frequency is spread over
-constexpr float PN_BETA = 2.30f * PN_W;
-constexpr int PN_LMAX = 1024;               // steps per piece at most (G = 2048 grid points)
+constexpr int PN_LMAX = 4096;               // steps per piece at most (G = 8192 grid points): spreading and coefficients cost per PIECE
 constexpr int PN_GMAX = 2 * PN_LMAX;
 constexpr int PN_NFMAX = 4096;              // frequencies per wavenumber this kernel takes (one workgroup holds them all)
-constexpr int PN_NTH = 256;
-constexpr int PN_PER = PN_NFMAX / PN_NTH;   // frequencies per thread
 constexpr int PN_SHORT = 8;                 // runs of up to this many steps are summed directly
+// float32 data: a window of 8 grid points (3.5e-7 of the result in float32 arithmetic), 256 threads, two workgroups per CU;
+// float64 data: 14 points (5e-13 in float64 arithmetic; the stated bar against the reference is 1e-10), 512 threads, one per CU
+// -- written, NOT enabled: inside a "run" the interpolated velocity carries ~4e-13 of rounding noise (2 * gradient(z(t))), which over
+// 8192 steps moves a phase by 1e-8 rad; the float64 vector kernels carry that deviation along (P.eps), a transform needs it as a
+// first-order term (a second transform with coefficients kappa_w C_w per piece) before it can hold 1e-10.  float32 data only.
+template <typename T> struct PnCfg;
+template <> struct PnCfg<float> { static constexpr int W = 8, NTH = 1024, OCC = 1; };
+template <> struct PnCfg<double> { static constexpr int W = 14, NTH = 1024, OCC = 1; };
 
 struct PnPiece {
     double v;               // velocity
@@ -47,42 +51,55 @@ struct PnParams {
     const PnPiece *pieces;
     int npieces;
     const double *rw;               // [nf] 1 / w, by slot
-    const float *corr;              // the tables 1 / psihat, concatenated
-    int corr_off[12];               // ... of Lp = 2^l at corr + corr_off[l], Lp/2 + 1 entries (|n - Lp/2| = 0 .. Lp/2)
-    const OCp<float> *tw[13];       // e^{-2 pi i k / G}, G = 2^l
+    const void *corr;               // the tables 1 / psihat (T), concatenated
+    int corr_off[13];               // ... of Lp = 2^l at corr + corr_off[l], Lp/2 + 1 entries (|n - Lp/2| = 0 .. Lp/2)
+    const void *tw[14];             // e^{-2 pi i k / G} (complex T), G = 2^l
     int *edge_cnt, *edge_list;      // v(z): boundary frequencies for ps_edge_kernel (null: constant velocity, none)
     int vz;
+    int gmax;                       // grid points of the longest piece (the LDS layout)
 };
 
-__host__ __device__ constexpr size_t pn_lds_bytes()
+// LDS: the grid of the call's longest piece (gmax points), then coefficients / grid places of all frequencies, the block reduction
+template <typename T> __host__ __device__ constexpr size_t pn_lds_bytes(int gmax)
 {
-    return (size_t)(own_pad(PN_GMAX) + 1) * 8 + (size_t)PN_NFMAX * (8 + 4 + 2) + 64 * 8;
+    return (size_t)(own_pad(gmax) + 1) * 2 * sizeof(T) + (size_t)PN_NFMAX * (2 * sizeof(T) + sizeof(T) + 2) + 16 * 2 * PN_SHORT * sizeof(T);
 }
 
 __device__ __forceinline__ float pn_window(float x)      // psi(x), |x| < W/2 (0 outside)
 {
-    const float z = fmaf(-x * x, 4.0f / (PN_W * PN_W), 1.0f);
-    return z > 0.f ? __expf(PN_BETA * (__builtin_amdgcn_sqrtf(z) - 1.0f)) : 0.f;
+    constexpr int W = PnCfg<float>::W;
+    const float z = fmaf(-x * x, 4.0f / (W * W), 1.0f);
+    return z > 0.f ? __expf(2.30f * W * (__builtin_amdgcn_sqrtf(z) - 1.0f)) : 0.f;
 }
-
-__global__ __launch_bounds__(PN_NTH, 2) void ps_nufft_kernel(PnParams Q)
+__device__ __forceinline__ double pn_window(double x)
 {
+    constexpr int W = PnCfg<double>::W;
+    const double z = fma(-x * x, 4.0 / (W * W), 1.0);
+    return z > 0.0 ? exp(2.30 * W * (sqrt(z) - 1.0)) : 0.0;
+}
+__device__ __forceinline__ void pn_sincos(double x, float *s, float *c) { pm_sincos(x, s, c); }
+__device__ __forceinline__ void pn_sincos(double x, double *s, double *c) { pss_sincos_small(pm_wrap(x), s, c); }
+
+template <typename T>
+__global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(PnParams Q)
+{
+    constexpr int PN_W = PnCfg<T>::W, PN_NTH = PnCfg<T>::NTH, PN_PER = PN_NFMAX / PN_NTH;
     extern __shared__ __attribute__((aligned(16))) unsigned char pn_lds[];
     const PsParams &P = Q.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nf = P.nf;
     // small |kx| (few evanescent frequencies: the long workgroups) first
     const int bq = (int)blockIdx.x, kb = (bq & 1) ? P.nk - 1 - (bq >> 1) : (bq >> 1), k = P.k0 + kb;
-    OCp<float> *grid = reinterpret_cast<OCp<float> *>(pn_lds);                          // [own_pad(G)]
-    OCp<float> *D = grid + own_pad(PN_GMAX) + 1;                                        // [nf] coefficients, by index
-    float *fr = reinterpret_cast<float *>(D + PN_NFMAX);                                // [nf] u - floor(u)
+    OCp<T> *grid = reinterpret_cast<OCp<T> *>(pn_lds);                          // [own_pad(G)]
+    OCp<T> *D = grid + own_pad(Q.gmax) + 1;                                         // [nf] coefficients, by index
+    T *fr = reinterpret_cast<T *>(D + PN_NFMAX);                                        // [nf] u - floor(u)
     unsigned short *m0 = reinterpret_cast<unsigned short *>(fr + PN_NFMAX);             // [nf] floor(u)
-    float *red = reinterpret_cast<float *>(m0 + PN_NFMAX);                              // [4][2 PN_SHORT] block reduction
-    const Cp<float> *Frow = reinterpret_cast<const Cp<float> *>(P.F) + (size_t)k * P.fstride;
-    float *TKrow = reinterpret_cast<float *>(reinterpret_cast<Cp<float> *>(P.TK) + (size_t)kb * P.snum);
+    T *red = reinterpret_cast<T *>(m0 + PN_NFMAX);                                      // [waves][2 PN_SHORT] block reduction
+    const Cp<T> *Frow = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k * P.fstride;
+    T *TKrow = reinterpret_cast<T *>(reinterpret_cast<Cp<T> *>(P.TK) + (size_t)kb * P.snum);
     const double kxk = P.kx[k];
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
-    const float inv_snum = 1.0f / (float)P.snum;
+    const T inv_snum = (T)1 / (T)P.snum;
 
     // ---- this thread's frequencies: index i = tid + 256 j in ascending |w| (Hermitian walk: slot i + 1, the Nyquist row --
     // slot 0 -- last: P.w is by slot).  phase NaN = out of every run from here on (evanescent, boundary band, past nf)
@@ -99,13 +116,14 @@ __global__ __launch_bounds__(PN_NTH, 2) void ps_nufft_kernel(PnParams Q)
     // the reference's own test and expression (:411-415), as ps_setup_kernel; v(z): :456-460 off the boundary band
     auto step_phase = [&](int slot, double v, bool *alive) -> double {
         const double w = P.w[slot];
-        if (!Q.vz) {
-            const double vk = v * kxk / 2.0, vkx2 = vk * vk;
-            *alive = vkx2 < w * w;
-            return *alive ? w * P.dt * sqrt(1.0 - vkx2 / (w * w)) : 0.0;
-        }
         const double cs = pm_coss(v, kxk, Q.rw[slot]);
-        *alive = cs > 0.0;
+        if (!Q.vz) {
+            // (:412 decides in its own arithmetic; the phase itself from the fast root: 1e-16 of :415's)
+            const double vk = v * kxk / 2.0;
+            *alive = vk * vk < w * w && cs > 0.0;
+        } else {
+            *alive = cs > 0.0;
+        }
         return *alive ? w * P.dt * pm_sqrt01(cs) : 0.0;
     };
     if (Q.vz) {
@@ -140,9 +158,9 @@ __global__ __launch_bounds__(PN_NTH, 2) void ps_nufft_kernel(PnParams Q)
         const int L = pc.len;
         if (pc.kind == 1) {
             // ---- single steps, summed directly: FK e^{i (Phi + (s + 1) phi)} per frequency and step (:464, :487)
-            float acc[2 * PN_SHORT];
+            T acc[2 * PN_SHORT];
 #pragma unroll
-            for (int s_ = 0; s_ < 2 * PN_SHORT; ++s_) acc[s_] = 0.f;
+            for (int s_ = 0; s_ < 2 * PN_SHORT; ++s_) acc[s_] = 0;
 #pragma unroll
             for (int j = 0; j < PN_PER; ++j) {
                 const int i = tid + PN_NTH * j;
@@ -152,28 +170,28 @@ __global__ __launch_bounds__(PN_NTH, 2) void ps_nufft_kernel(PnParams Q)
                 const double inc = step_phase(slot, v, &alive);
                 if (!alive) ph[j] = nan;                                      // :484-485, for good
                 if (ph[j] == ph[j]) {
-                    const Cp<float> f = ps_load_slot<float>(Frow, P, slot);
+                    const Cp<T> f = ps_load_slot<T>(Frow, P, slot);
 #pragma unroll
                     for (int s_ = 0; s_ < PN_SHORT; ++s_)
                         if (s_ < L) {                                         // uniform
-                            float sn, c;
-                            pm_sincos(ph[j] + (double)(s_ + 1) * inc, &sn, &c);
-                            acc[2 * s_] += fmaf(f.x, c, -(f.y * sn));
-                            acc[2 * s_ + 1] += fmaf(f.x, sn, f.y * c);
+                            T sn, c;
+                            pn_sincos(ph[j] + (double)(s_ + 1) * inc, &sn, &c);
+                            acc[2 * s_] += fma(f.x, c, -(f.y * sn));
+                            acc[2 * s_ + 1] += fma(f.x, sn, f.y * c);
                         }
                     ph[j] = pm_wrap(ph[j] + (double)L * inc);
                 }
             }
 #pragma unroll
             for (int s_ = 0; s_ < 2 * PN_SHORT; ++s_) {
-                float x = acc[s_];
+                T x = acc[s_];
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
                 if (lane == 0) red[wave * 2 * PN_SHORT + s_] = x;
             }
             __syncthreads();
             if (tid < 2 * L) {
-                float sum = 0.f;
+                T sum = 0;
 #pragma unroll
                 for (int q = 0; q < PN_NTH / 64; ++q) sum += red[q * 2 * PN_SHORT + tid];
                 TKrow[2 * (size_t)(pc.start + (tid >> 1)) + (tid & 1)] = sum * inv_snum;      // :492
@@ -184,7 +202,7 @@ __global__ __launch_bounds__(PN_NTH, 2) void ps_nufft_kernel(PnParams Q)
         // ---- a piece of a long run: coefficients and grid places, spreading, inverse FFT, window divided out
         const int Lp = 1 << pc.loglp, G = 2 * Lp, logg = pc.loglp + 1;
         const double ug = (double)G * 0.15915494309189535;                    // G / 2 pi
-        for (int m = tid; m < own_pad(G) + 1; m += PN_NTH) grid[m] = OCp<float>{0.f, 0.f};
+        for (int m = tid; m < own_pad(G) + 1; m += PN_NTH) grid[m] = OCp<T>{(T)0, (T)0};
 #pragma unroll
         for (int j = 0; j < PN_PER; ++j) {
             const int i = tid + PN_NTH * j;
@@ -196,12 +214,12 @@ __global__ __launch_bounds__(PN_NTH, 2) void ps_nufft_kernel(PnParams Q)
             bool alive;
             const double inc = step_phase(slot, v, &alive);                   // (negative for the Nyquist row: w = -pi / dt)
             if (!alive) ph[j] = nan;
-            OCp<float> d{0.f, 0.f};
+            OCp<T> d{(T)0, (T)0};
             if (ph[j] == ph[j]) {
-                const Cp<float> f = ps_load_slot<float>(Frow, P, slot);
-                float sn, c;
-                pm_sincos(ph[j] + (double)(1 + Lp / 2) * inc, &sn, &c);
-                d = OCp<float>{fmaf(f.x, c, -(f.y * sn)), fmaf(f.x, sn, f.y * c)};
+                const Cp<T> f = ps_load_slot<T>(Frow, P, slot);
+                T sn, c;
+                pn_sincos(ph[j] + (double)(1 + Lp / 2) * inc, &sn, &c);
+                d = OCp<T>{fma(f.x, c, -(f.y * sn)), fma(f.x, sn, f.y * c)};
                 ph[j] = pm_wrap(ph[j] + (double)L * inc);
             }
             // place on the grid: phi mod 2 pi in units of the grid spacing (dead frequencies: 0 -- they carry D = 0)
@@ -210,7 +228,7 @@ __global__ __launch_bounds__(PN_NTH, 2) void ps_nufft_kernel(PnParams Q)
             const double fl = floor(u);
             D[i] = d;
             m0[i] = (unsigned short)min((int)fl, G - 1);
-            fr[i] = (float)(u - fl);
+            fr[i] = (T)(u - fl);
         }
         __syncthreads();
         {
@@ -220,15 +238,15 @@ __global__ __launch_bounds__(PN_NTH, 2) void ps_nufft_kernel(PnParams Q)
             const float a = (float)(6.283185307179586 / ((double)G * P.dt)), a2 = a * a;
             const int ilast = nf - 2;                                         // regular frequencies: indices 0 .. nf - 2
             // the Nyquist row (index nf - 1): anywhere on the grid, looked at by every grid point
-            const float uN = (float)m0[nf - 1] + fr[nf - 1];
-            const OCp<float> dN = D[nf - 1];
+            const T uN = (T)m0[nf - 1] + fr[nf - 1];
+            const OCp<T> dN = D[nf - 1];
 #ifdef PN_ABL_NOGATHER
             for (int m = tid; m < 0; m += PN_NTH) {      // timing only
 #else
             for (int m = tid; m < G; m += PN_NTH) {
 #endif
                 const float mm = (float)(m > G / 2 + PN_W ? m - G : m);      // centred: the regular frequencies sit in [0, G/2]
-                float gx = 0.f, gy = 0.f;
+                T gx = 0, gy = 0;
                 const float uhi = mm + 0.5f * PN_W, ulo = fmaxf(mm - 0.5f * PN_W, 0.f);
                 if (uhi > 0.f) {
                     int ilo = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * ulo, ulo, c2)) * inv_dw) - 3;
@@ -236,34 +254,34 @@ __global__ __launch_bounds__(PN_NTH, 2) void ps_nufft_kernel(PnParams Q)
                     ilo = max(ilo, 0);
                     ihi = min(ihi, ilast);
                     for (int i = ilo; i <= ihi; ++i) {
-                        const float x = ((float)m0[i] - mm) + fr[i];
-                        const float wgt = pn_window(x);
-                        const OCp<float> d = D[i];
-                        gx = fmaf(d.x, wgt, gx);
-                        gy = fmaf(d.y, wgt, gy);
+                        const T x = (T)((int)m0[i] - (int)mm) + fr[i];
+                        const T wgt = pn_window(x);
+                        const OCp<T> d = D[i];
+                        gx = fma(d.x, wgt, gx);
+                        gy = fma(d.y, wgt, gy);
                     }
                 }
                 {
-                    float x = uN - (float)m;
-                    x -= (float)G * rintf(x / (float)G);
-                    const float wgt = pn_window(x);
-                    gx = fmaf(dN.x, wgt, gx);
-                    gy = fmaf(dN.y, wgt, gy);
+                    T x = uN - (T)m;
+                    x -= (T)G * rint(x / (T)G);
+                    const T wgt = pn_window(x);
+                    gx = fma(dN.x, wgt, gx);
+                    gy = fma(dN.y, wgt, gy);
                 }
-                grid[own_pad(m)] = OCp<float>{gx, gy};
+                grid[own_pad(m)] = OCp<T>{gx, gy};
             }
         }
         __syncthreads();
 #ifndef PN_ABL_NOFFT
-        own_fft_passes<float, true>(grid, G, logg, tid, PN_NTH, Q.tw[logg], 1);
+        own_fft_passes<T, true>(grid, G, logg, tid, PN_NTH, reinterpret_cast<const OCp<T> *>(Q.tw[logg]), 1);
 #endif
         {
-            const float *corr = Q.corr + Q.corr_off[pc.loglp];
+            const T *corr = reinterpret_cast<const T *>(Q.corr) + Q.corr_off[pc.loglp];
             for (int n = tid; n < L; n += PN_NTH) {
                 const int np = n - Lp / 2;                                    // the band is centred: n' in [-Lp/2, Lp/2)
-                const OCp<float> z = grid[own_pad(own_rev(np & (G - 1), G, logg))];
-                const float cf = corr[np < 0 ? -np : np] * inv_snum;
-                reinterpret_cast<float2 *>(TKrow)[pc.start + n] = make_float2(z.x * cf, z.y * cf);
+                const OCp<T> z = grid[own_pad(own_rev(np & (G - 1), G, logg))];
+                const T cf = corr[np < 0 ? -np : np] * inv_snum;
+                reinterpret_cast<Cp<T> *>(TKrow)[pc.start + n] = Cp<T>{z.x * cf, z.y * cf};
             }
         }
         __syncthreads();
