@@ -421,6 +421,28 @@ def test_matrix_core_path_leaves_many_short_runs_to_the_vector_kernels(hip, monk
         assert rel_l2(d.data, want) < F32_L2
 
 
+@pytest.mark.parametrize('snum,tnum,dx', [(200, 512, 1.0), (700, 256, 0.5)])
+def test_transform_path_keeps_the_boundary_frequencies_of_a_constant_velocity(hip, monkeypatch, snum, tnum, dx):
+    """Round numbers (2e8 m/s, 5 ns, 0.5 / 1 m) put frequencies exactly ON the evanescent boundary v kx / 2 = w.  The
+    reference keeps a frequency when vkx2 < w^2 in ITS arithmetic (mig_python.py:411-412) -- with a phase of ~1e-8 w dt, i.e. as a
+    constant term of every depth step.  ps_nufft_kernel first decided it from 1 - (v kx / 2w)^2 with 1/w rounded separately and
+    dropped such frequencies: 1.3e-2 / 6.6e-3 of the image on exactly these two geometries (fuzz, profiles/r05_fuzz.txt)."""
+    from impdar_amd import synth
+    from impdar_amd.lib.RadarData import RadarData
+    from impdar_amd.lib import migrationlib
+    from oracle import mig_oracle
+    geo = synth.geometry(snum, tnum, dt=5e-9, dx=dx)
+    data = synth.noise_radargram(snum, tnum, seed=snum + tnum).astype(np.float32)
+    want = mig_oracle.phase_shift(data.astype(np.float64), geo['dt'], geo['trace_int'], geo['travel_time'], geo['dist'], 2.0e8, 7, 9)
+    for mode in ('6', '2', '0'):
+        monkeypatch.setenv('IMPDAR_PS_MFMA', mode)
+        d = RadarData(None)
+        d.data, d.snum, d.tnum = data.copy(), snum, tnum
+        d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
+        migrationlib.migrationPhaseShift(d, vel=2.0e8, htaper=7, vtaper=9)
+        assert rel_l2(d.data, want) < 1e-5, (mode, rel_l2(d.data, want))
+
+
 def test_matrix_core_path_hands_over_when_a_wavenumber_has_more_boundary_frequencies_than_it_lists(hip, monkeypatch):
     """ps_setup_kernel takes every boundary frequency out of the matrix-core sums and lists the first 16 per wavenumber
     for ps_edge_kernel; beyond that contributions would be missing from TK.  The host reads the counters back after the
