@@ -16,15 +16,19 @@
 //      order (no atomics: results are reproducible bit for bit);
 //   3. one inverse FFT of length G in LDS (own_fft.h's passes);
 //   4. TK[tau0 + n] = ghat[n - Lp/2] / psihat(n - Lp/2): the window's transform divided out (a table per Lp, host, float64
-//      Gauss-Legendre quadrature).
+//      Simpson quadrature, once per plan).
 // Error of the scheme with W = 8, twofold oversampling, float32 arithmetic: 3.5e-7 of the result (rel-L2; measured against a
 // float64 direct sum on config-5 geometries before any of this was written) -- the matrix-core paths, with their float16
 // hi/lo operands, are at 1.1e-6.
 //
-// Work split: one workgroup per wavenumber; every thread owns nf / 256 (512) frequencies with their phase in a float64 register
-// and walks the pieces (runs cut to <= 1024 steps) in depth order; the few single steps a layer boundary is smeared over
-// are summed directly (a sincos per frequency and step, block reduction in a fixed order).  Frequencies on the
-// evanescent boundary of some run take no part and are listed for ps_edge_kernel, as in ps_mfma.h / ps_runs.h.
+// Work split: one workgroup of 1024 threads per wavenumber; a thread owns 4 frequencies with their phase in a float64
+// register and walks the pieces in depth order -- runs cut to <= 4096 steps (G <= 8192 grid points: the coefficients and the
+// spreading cost per PIECE, frequencies x 8 window values, the FFT per grid point: long pieces are the cheap ones; LDS by the
+// call's longest piece, <= 126 KB).  The few single steps a layer boundary is smeared over are summed directly (a sincos per
+// frequency and step, block reduction in a fixed order): a tenth of a piece each, which is what hands tables of more than
+// ~10 layers to ps_runs_kernel.  Frequencies on the evanescent boundary of some run take no part and are listed for
+// ps_edge_kernel, as in ps_mfma.h / ps_runs.h; for a constant velocity the reference's own test decides them (:411-412).
+// Measured (profiles/r05_ps_nufft.txt): config 5 at 8192^2 3.7 ms (ps_mfma_kernel 9.1), constant velocity 1.6 ms (5.3).
 #pragma once
 
 constexpr int PN_LMAX = 4096;               // steps per piece at most (G = 8192 grid points): spreading and coefficients cost per PIECE
