@@ -1627,8 +1627,16 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
     bool need[13] = {};
     for (const PsMfmaRun &r : runs) {
         if (vz && r.len <= PN_SHORT) {
-            pc.push_back(PnPiece{r.v, r.start, r.len, 1, 0});
+            // consecutive short runs (the single steps of one smeared boundary) share a piece: one pass over the frequencies
             nshort_steps += r.len;
+            if (!pc.empty() && pc.back().kind == 1 && pc.back().start + pc.back().len == r.start && pc.back().len + r.len <= PN_SHORT) {
+                for (int q = 0; q < r.len; ++q) pc.back().vs[pc.back().len + q] = r.v;
+                pc.back().len += r.len;
+            } else {
+                PnPiece p1{r.v, r.start, r.len, 1, 0, {}};
+                for (int q = 0; q < PN_SHORT; ++q) p1.vs[q] = r.v;
+                pc.push_back(p1);
+            }
             continue;
         }
         const int npiece = (r.len + PN_LMAX - 1) / PN_LMAX;
@@ -1636,7 +1644,8 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
             const int len = (r.len - at) / (npiece - i);
             int l = 4;
             while ((1 << l) < len) ++l;
-            pc.push_back(PnPiece{r.v, r.start + at, len, 0, l});
+            PnPiece p0{r.v, r.start + at, len, 0, l, {}};
+            pc.push_back(p0);
             need[l] = true;
             at += len;
         }
@@ -2210,10 +2219,10 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         // 12.8 / 13.8 at 3 / 4 / 5 / 7 / 11 long runs, 15.3 at 21, 21.3 at 42, 12.0 on the config-5 table)
         const bool runs_first = vlen != 0 && nlong > 3;
         // ... 6: only the transform path (ps_nufft.h) ahead of them.  By itself: the transform path for a constant velocity and
-        // tables of up to 10 thick layers (8192^2 device ms at 3 / 5 / 7 / 11 long runs: 5.8 / 7.7 / 9.4 / 13.4 against
-        // ps_runs_kernel's 11.8 / 12.4 / 12.8 / 13.8; config 5: 5.2 against ps_mfma_kernel's 10.6, constant velocity 3.0
-        // against 6.8 -- profiles/r05_ps_nufft.txt), then the matrix-core paths as before
-        if (ok && (pref == 6 || (pref == 1 && nlong <= 10)) && !force_overflow) {
+        // tables of up to 16 thick layers (8192^2 device ms at 3 / 5 / 7 / 11 / 16 / 21 long runs: 5.1 / 6.1 / 7.2 / 9.5 / 13.0 /
+        // 16.8 against ps_runs_kernel's 11.8 / 12.4 / 12.8 / 13.7 / 14.4 / 15.3; config 5: 4.5 against ps_mfma_kernel's 10.6,
+        // constant velocity 3.0 against 6.8 -- profiles/r05_ps_nufft.txt), then the matrix-core paths as before
+        if (ok && (pref == 6 || (pref == 1 && nlong <= 16)) && !force_overflow) {
             if ((rc = ps_nufft_run<float>(pl, P, mruns, vlen != 0, kx, w.data(), thr.data(), st, &mfma_done))) return rc;
             if (mfma_done) mfma_kernel_name = "ps_nufft_kernel";
         }

@@ -45,10 +45,12 @@ template <> struct PnCfg<float> { static constexpr int W = 8, NTH = 1024, OCC = 
 template <> struct PnCfg<double> { static constexpr int W = 14, NTH = 1024, OCC = 1; };
 
 struct PnPiece {
-    double v;               // velocity
+    double v;               // velocity (kind 0)
     int start, len;         // first depth step, steps
-    int kind;               // 0: transform, 1: direct sums (len <= PN_SHORT)
+    int kind;               // 0: transform, 1: direct sums (len <= PN_SHORT steps, each at its own velocity: the single steps of a
+                            // smeared layer boundary, and short runs, taken in ONE pass over the frequencies)
     int loglp;              // kind 0: log2 of the padded length Lp >= len (G = 2 Lp)
+    double vs[PN_SHORT];    // kind 1: the steps' velocities
 };
 struct PnParams {
     PsParams P;
@@ -135,13 +137,16 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
     if (Q.vz) {
         double vprev = 0.0;
         for (int r = 0; r < Q.npieces; ++r) {
-            const double v = Q.pieces[r].v;
-            if (v == vprev) continue;                                         // uniform
-            vprev = v;
+            const int nv = Q.pieces[r].kind == 1 ? Q.pieces[r].len : 1;
+            for (int q = 0; q < nv; ++q) {
+                const double v = Q.pieces[r].kind == 1 ? Q.pieces[r].vs[q] : Q.pieces[r].v;
+                if (v == vprev) continue;                                     // uniform
+                vprev = v;
 #pragma unroll
-            for (int j = 0; j < PN_PER; ++j) {
-                const int i = tid + PN_NTH * j;
-                if (i < nf) edge[j] = edge[j] || fabs(pm_coss(v, kxk, Q.rw[slot_of(i)])) < 1e-8;
+                for (int j = 0; j < PN_PER; ++j) {
+                    const int i = tid + PN_NTH * j;
+                    if (i < nf) edge[j] = edge[j] || fabs(pm_coss(v, kxk, Q.rw[slot_of(i)])) < 1e-8;
+                }
             }
         }
 #pragma unroll
@@ -163,30 +168,33 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
         const double v = pc.v;
         const int L = pc.len;
         if (pc.kind == 1) {
-            // ---- single steps, summed directly: FK e^{i (Phi + (s + 1) phi)} per frequency and step (:464, :487)
+            // ---- single steps, summed directly: FK e^{i Phi} with Phi advanced by every step's own phase (:464, :487); a
+            // frequency that turns evanescent at one of them is out from there on (:484-485)
             T acc[2 * PN_SHORT];
 #pragma unroll
             for (int s_ = 0; s_ < 2 * PN_SHORT; ++s_) acc[s_] = 0;
 #pragma unroll
             for (int j = 0; j < PN_PER; ++j) {
                 const int i = tid + PN_NTH * j;
-                if (i >= nf) continue;
+                if (i >= nf || !(ph[j] == ph[j])) continue;
                 const int slot = slot_of(i);
-                bool alive;
-                const double inc = step_phase(slot, v, &alive);
-                if (!alive) ph[j] = nan;                                      // :484-485, for good
-                if (ph[j] == ph[j]) {
-                    const Cp<T> f = ps_load_slot<T>(Frow, P, slot);
+                const Cp<T> f = ps_load_slot<T>(Frow, P, slot);
+                double p = ph[j];
 #pragma unroll
-                    for (int s_ = 0; s_ < PN_SHORT; ++s_)
-                        if (s_ < L) {                                         // uniform
+                for (int s_ = 0; s_ < PN_SHORT; ++s_)
+                    if (s_ < L) {                                             // uniform
+                        bool alive;
+                        const double inc = step_phase(slot, pc.vs[s_], &alive);
+                        if (!alive) p = nan;
+                        p += inc;
+                        if (p == p) {
                             T sn, c;
-                            pn_sincos(ph[j] + (double)(s_ + 1) * inc, &sn, &c);
+                            pn_sincos(p, &sn, &c);
                             acc[2 * s_] += fma(f.x, c, -(f.y * sn));
                             acc[2 * s_ + 1] += fma(f.x, sn, f.y * c);
                         }
-                    ph[j] = pm_wrap(ph[j] + (double)L * inc);
-                }
+                    }
+                ph[j] = pm_wrap(p);                                           // NaN stays NaN
             }
 #pragma unroll
             for (int s_ = 0; s_ < 2 * PN_SHORT; ++s_) {
