@@ -1324,7 +1324,8 @@ struct PsPlan {
     OwnTwiddles pn_tw[14];               // ... twiddles of the grid lengths 2^l
     std::vector<float> h_pn_corr;        // ... the tables on the host (made once per padded length)
     std::vector<double> h_pn_corr64;
-    int pn_corr_off[13] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+    int pn_corr_off[2][13] = {{-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}};     // [float32, float64]
+    int pn_corr_dev = -1;                // which of the two tables the device buffer holds
     double mfma_instructions = -1.0;     // ... of the last call (-1: not a matrix-core call)
     // a (kx, runs) geometry whose boundary-frequency lists overflowed in a matrix-core path: not tried again
     std::vector<double> ovf_kx;
@@ -1639,7 +1640,7 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
             }
             continue;
         }
-        const int npiece = (r.len + PN_LMAX - 1) / PN_LMAX;
+        const int npiece = (r.len + PnCfg<T>::LMAX - 1) / PnCfg<T>::LMAX;
         for (int i = 0, at = 0; i < npiece; ++i) {
             const int len = (r.len - at) / (npiece - i);
             int l = 4;
@@ -1657,9 +1658,10 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
     PnParams Q;
     std::vector<T> &corr = sizeof(T) == 4 ? reinterpret_cast<std::vector<T> &>(pl.h_pn_corr) : reinterpret_cast<std::vector<T> &>(pl.h_pn_corr64);
     bool grew = false;
+    int *corr_off = pl.pn_corr_off[sizeof(T) == 8 ? 1 : 0];
     for (int l = 0; l < 13; ++l) {
-        if (!need[l] || pl.pn_corr_off[l] >= 0) continue;
-        pl.pn_corr_off[l] = (int)corr.size();
+        if (!need[l] || corr_off[l] >= 0) continue;
+        corr_off[l] = (int)corr.size();
         grew = true;
         const int Lp = 1 << l, G = 2 * Lp, NS = 512;
         const double beta = 2.30 * PN_W, h = (double)PN_W / NS;
@@ -1675,7 +1677,7 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
             corr.push_back((T)(1.0 / (sum * h / 3.0)));
         }
     }
-    for (int l = 0; l < 13; ++l) Q.corr_off[l] = pl.pn_corr_off[l] < 0 ? 0 : pl.pn_corr_off[l];
+    for (int l = 0; l < 13; ++l) Q.corr_off[l] = corr_off[l] < 0 ? 0 : corr_off[l];
     std::vector<double> rw((size_t)nf);
     for (int i = 0; i < nf; ++i) rw[i] = 1.0 / w_host[i];
     if (pl.d_pn_pieces.ensure(pc.size() * sizeof(PnPiece)) != hipSuccess || pl.d_pn_corr.ensure(corr.size() * sizeof(T) + 16) != hipSuccess ||
@@ -1690,7 +1692,10 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
         }
     for (int l = 0; l < 14; ++l) Q.tw[l] = pl.pn_tw[l].buf.p;
     IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_pn_pieces.p, pc.data(), pc.size() * sizeof(PnPiece), hipMemcpyHostToDevice, st));
-    if (grew || !pl.d_pn_corr.p) IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_pn_corr.p, corr.data(), corr.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    if (grew || pl.pn_corr_dev != (int)sizeof(T)) {
+        IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_pn_corr.p, corr.data(), corr.size() * sizeof(T), hipMemcpyHostToDevice, st));
+        pl.pn_corr_dev = (int)sizeof(T);
+    }
     IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_rw.p, rw.data(), rw.size() * 8, hipMemcpyHostToDevice, st));
     Q.P = P;
     Q.pieces = pl.d_pn_pieces.as<PnPiece>();
@@ -1707,7 +1712,7 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
             if (need[l]) lmax = l;
         Q.gmax = 2 << lmax;
     }
-    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_nufft_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pn_lds_bytes<T>(PN_GMAX)));
+    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_nufft_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pn_lds_bytes<T>(2 * PnCfg<T>::LMAX)));
     hipLaunchKernelGGL(ps_nufft_kernel<T>, dim3((unsigned)P.nk), dim3(PnCfg<T>::NTH), pn_lds_bytes<T>(Q.gmax), st, Q);
     if (vz) {
         PsMfmaParams E;                        // (ps_edge_kernel reads P and the lists only)
@@ -1888,6 +1893,13 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             pl.d_edge.release();
             pl.d_runtab.release();
             pl.d_pr_runs.release();
+            pl.d_pn_pieces.release();
+            pl.d_pn_corr.release();
+            pl.pn_corr_dev = -1;
+            for (OwnTwiddles &t : pl.pn_tw) {
+                t.buf.release();
+                t.nt = 0;
+            }
             pl.d_mcount.release();
             pl.d_pr_stages.release();
             pl.d_rw.release();
@@ -2190,6 +2202,17 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     const char *mfma_kernel_name = "";
     pl.mfma_instructions = -1.0;
     int long_runs = 0;                       // runs of constant velocity longer than a smeared layer boundary (metrics)
+    if constexpr (sizeof(T) == 8) {
+        // float64 data at a constant velocity: the transform path (ps_nufft.h: a 14-point window in float64 arithmetic); a v(z)
+        // table keeps the vector kernels (the velocity noise inside its runs: ps_nufft.h)
+        const char *me = getenv("IMPDAR_PS_MFMA");
+        const int pref = me ? atoi(me) : 1;
+        if (!vlen && pref != 0 && std::isfinite(vconst) && vconst != 0.0) {
+            std::vector<PsMfmaRun> one{PsMfmaRun{vconst, 0, snum}};
+            if ((rc = ps_nufft_run<double>(pl, P, one, false, kx, w.data(), thr.data(), st, &mfma_done))) return rc;
+            if (mfma_done) mfma_kernel_name = "ps_nufft_kernel";
+        }
+    }
     if constexpr (sizeof(T) == 4) {
         // float32: the frequency sums on the matrix cores when the depth axis is a few long runs of constant velocity
         std::vector<PsMfmaRun> mruns;

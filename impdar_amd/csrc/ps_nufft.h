@@ -31,18 +31,18 @@
 // Measured (profiles/r05_ps_nufft.txt): config 5 at 8192^2 3.7 ms (ps_mfma_kernel 9.1), constant velocity 1.6 ms (5.3).
 #pragma once
 
-constexpr int PN_LMAX = 4096;               // steps per piece at most (G = 8192 grid points): spreading and coefficients cost per PIECE
-constexpr int PN_GMAX = 2 * PN_LMAX;
 constexpr int PN_NFMAX = 4096;              // frequencies per wavenumber this kernel takes (one workgroup holds them all)
 constexpr int PN_SHORT = 8;                 // runs of up to this many steps are summed directly
 // float32 data: a window of 8 grid points (3.5e-7 of the result in float32 arithmetic), 256 threads, two workgroups per CU;
 // float64 data: 14 points (5e-13 in float64 arithmetic; the stated bar against the reference is 1e-10), 512 threads, one per CU
-// -- written, NOT enabled: inside a "run" the interpolated velocity carries ~4e-13 of rounding noise (2 * gradient(z(t))), which over
-// 8192 steps moves a phase by 1e-8 rad; the float64 vector kernels carry that deviation along (P.eps), a transform needs it as a
-// first-order term (a second transform with coefficients kappa_w C_w per piece) before it can hold 1e-10.  float32 data only.
+// -- for a CONSTANT velocity only: inside a "run" of a v(z) table the interpolated velocity carries ~4e-13 of rounding noise
+// (2 * gradient(z(t))), which over 8192 steps moves a phase by 1e-8 rad; the float64 vector kernels carry that deviation along
+// (P.eps), a transform needs it as a first-order term (a second transform with coefficients kappa_w C_w per piece) before it
+// can hold the 1e-10 bar on a table.
 template <typename T> struct PnCfg;
-template <> struct PnCfg<float> { static constexpr int W = 8, NTH = 1024, OCC = 1; };
-template <> struct PnCfg<double> { static constexpr int W = 14, NTH = 1024, OCC = 1; };
+// LMAX: steps per piece at most (G = 2 LMAX grid points): spreading and coefficients cost per PIECE -- as long as LDS allows
+template <> struct PnCfg<float> { static constexpr int W = 8, NTH = 1024, OCC = 1, LMAX = 4096; };
+template <> struct PnCfg<double> { static constexpr int W = 14, NTH = 512, OCC = 1, LMAX = 1024; };
 
 struct PnPiece {
     double v;               // velocity (kind 0)
