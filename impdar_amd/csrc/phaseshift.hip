@@ -20,6 +20,7 @@
 // contiguous runs of TK_T[k][tau].
 #include "fft.h"
 #include "own_fft.h"
+#include "ps_series_plan.h"
 #include <algorithm>
 #include <mutex>
 #include <type_traits>
@@ -1321,6 +1322,9 @@ struct PsPlan {
     DevBuf d_pr_runs, d_pr_stages, d_rw; // many-runs matrix-core path (ps_runs.h): runs, stages, 1 / w
     DevBuf d_mcount;                     // matrix-core paths: MFMA instructions the kernel issued (one 64-bit counter)
     DevBuf d_pn_pieces, d_pn_corr;       // transform path (ps_nufft.h): pieces, the window's correction tables
+    SrHostPlan sr_plan;                  // series path (ps_series.h): the pieces of the last velocity profile, and on the device
+    DevBuf d_sr_pieces, d_sr_ev;
+    bool sr_dev = false;                 // ... the device copies are those of sr_plan
     OwnTwiddles pn_tw[14];               // ... twiddles of the grid lengths 2^l
     std::vector<float> h_pn_corr;        // ... the tables on the host (made once per padded length)
     std::vector<double> h_pn_corr64;
@@ -1423,6 +1427,7 @@ static int ps_dispatch(const PsParams &P, hipStream_t st)
 
 #include "ps_pair.h"
 #include "ps_nufft.h"
+#include "ps_series.h"      // a velocity that changes inside a piece: a few transforms with shared nodes + direct sums at the boundary
 #include "ps_runs.h"        // many runs of constant velocity: float32 MFMA, phases generated in the kernel
 
 // did a matrix-core path find more boundary frequencies than it lists on this (kx, runs) geometry before?  (ADVICE r4:
@@ -1604,12 +1609,42 @@ static int ps_runs_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
     return IMPDAR_OK;
 }
 
+// 1 / psihat(n), n = 0 .. Lp/2, of every padded length in `need`: psihat(n) = int psi(x) cos(2 pi n x / G) dx over |x| < W/2
+// (Simpson, float64; the integrand ends at e^{-beta} = 1e-8 of its maximum).  Made once per length and plan; *grew: the device
+// copy is stale.  (Shared by the transform paths ps_nufft.h and ps_series.h: same window, same tables.)
+template <typename T>
+static std::vector<T> &pn_corr_tables(PsPlan &pl, const bool (&need)[13], int (&off_out)[13], bool *grew)
+{
+    constexpr int PN_W = PnCfg<T>::W;
+    std::vector<T> &corr = sizeof(T) == 4 ? reinterpret_cast<std::vector<T> &>(pl.h_pn_corr) : reinterpret_cast<std::vector<T> &>(pl.h_pn_corr64);
+    int *corr_off = pl.pn_corr_off[sizeof(T) == 8 ? 1 : 0];
+    for (int l = 0; l < 13; ++l) {
+        if (!need[l] || corr_off[l] >= 0) continue;
+        corr_off[l] = (int)corr.size();
+        *grew = true;
+        const int Lp = 1 << l, G = 2 * Lp, NS = 512;
+        const double beta = 2.30 * PN_W, h = (double)PN_W / NS;
+        std::vector<double> psi((size_t)NS + 1);
+        for (int q = 0; q <= NS; ++q) {
+            const double x = -0.5 * PN_W + q * h, z = 1.0 - (2.0 * x / PN_W) * (2.0 * x / PN_W);
+            psi[q] = std::exp(beta * (std::sqrt(z > 0.0 ? z : 0.0) - 1.0)) * ((q == 0 || q == NS) ? 1.0 : ((q & 1) ? 4.0 : 2.0));
+        }
+        for (int n = 0; n <= Lp / 2; ++n) {
+            double sum = 0.0;
+            const double f = 6.283185307179586 * n / G;
+            for (int q = 0; q <= NS; ++q) sum += psi[q] * std::cos(f * (-0.5 * PN_W + q * h));
+            corr.push_back((T)(1.0 / (sum * h / 3.0)));
+        }
+    }
+    for (int l = 0; l < 13; ++l) off_out[l] = corr_off[l] < 0 ? 0 : corr_off[l];
+    return corr;
+}
+
 // ---- transform path (ps_nufft.h): pieces, correction tables, launch.  Same contract as ps_mfma_run.
 template <typename T>
 static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &runs, bool vz, const double *kx_host, const double *w_host,
                         const double *thr, hipStream_t st, bool *done)
 {
-    constexpr int PN_W = PnCfg<T>::W;
     *done = false;
     const int snum = P.snum, tnum = P.tnum, nf = P.nf;
     if (!P.herm || nf < 64 || nf > PN_NFMAX || snum < 64 || runs.empty()) return IMPDAR_OK;
@@ -1653,31 +1688,9 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
     }
     // a direct step costs as much as a tenth of a piece: tables of many layers stay with ps_runs_kernel
     if (nshort_steps > 64 || pc.size() > 256) return IMPDAR_OK;
-    // 1 / psihat(n), n = 0 .. Lp/2, of every padded length in use: psihat(n) = int psi(x) cos(2 pi n x / G) dx over |x| < W/2
-    // (Simpson, float64; the integrand ends at e^{-beta} = 1e-8 of its maximum).  Made once per length and plan.
     PnParams Q;
-    std::vector<T> &corr = sizeof(T) == 4 ? reinterpret_cast<std::vector<T> &>(pl.h_pn_corr) : reinterpret_cast<std::vector<T> &>(pl.h_pn_corr64);
     bool grew = false;
-    int *corr_off = pl.pn_corr_off[sizeof(T) == 8 ? 1 : 0];
-    for (int l = 0; l < 13; ++l) {
-        if (!need[l] || corr_off[l] >= 0) continue;
-        corr_off[l] = (int)corr.size();
-        grew = true;
-        const int Lp = 1 << l, G = 2 * Lp, NS = 512;
-        const double beta = 2.30 * PN_W, h = (double)PN_W / NS;
-        std::vector<double> psi((size_t)NS + 1);
-        for (int q = 0; q <= NS; ++q) {
-            const double x = -0.5 * PN_W + q * h, z = 1.0 - (2.0 * x / PN_W) * (2.0 * x / PN_W);
-            psi[q] = std::exp(beta * (std::sqrt(z > 0.0 ? z : 0.0) - 1.0)) * ((q == 0 || q == NS) ? 1.0 : ((q & 1) ? 4.0 : 2.0));
-        }
-        for (int n = 0; n <= Lp / 2; ++n) {
-            double sum = 0.0;
-            const double f = 6.283185307179586 * n / G;
-            for (int q = 0; q <= NS; ++q) sum += psi[q] * std::cos(f * (-0.5 * PN_W + q * h));
-            corr.push_back((T)(1.0 / (sum * h / 3.0)));
-        }
-    }
-    for (int l = 0; l < 13; ++l) Q.corr_off[l] = corr_off[l] < 0 ? 0 : corr_off[l];
+    std::vector<T> &corr = pn_corr_tables<T>(pl, need, Q.corr_off, &grew);
     std::vector<double> rw((size_t)nf);
     for (int i = 0; i < nf; ++i) rw[i] = 1.0 / w_host[i];
     if (pl.d_pn_pieces.ensure(pc.size() * sizeof(PnPiece)) != hipSuccess || pl.d_pn_corr.ensure(corr.size() * sizeof(T) + 16) != hipSuccess ||
@@ -1736,6 +1749,100 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
             return IMPDAR_OK;                  // contributions missing from TK: discarded, another path produces the result
         }
     }
+    *done = true;
+    return IMPDAR_OK;
+}
+
+// ---- series path (ps_series.h): any v(z) profile -- pieces from the planner (ps_series_plan.h, cached per profile), tables, launch.
+// Same contract as ps_mfma_run: *done = false and IMPDAR_OK when the call is not for this path.
+template <typename T>
+static int ps_series_run(PsPlan &pl, PsParams P, const double *vmig, const double *kx_host, const double *w_host, const double *thr,
+                         hipStream_t st, bool *done)
+{
+    *done = false;
+    const int snum = P.snum, tnum = P.tnum, nf = P.nf;
+    constexpr bool dbl = sizeof(T) == 8;
+    if (!P.herm || nf < 64 || nf > SR_NFMAX || snum < 32) return IMPDAR_OK;
+    for (int i = 0; i < snum; ++i)
+        if (!(thr[i] < 1e-10) || !std::isfinite(vmig[i]) || vmig[i] == 0.0) return IMPDAR_OK;   // the evanescence test must be the sign of coss off the boundary band
+    // the gather inverts the dispersion relation on a uniform frequency axis: slot i + 1 at (i + 1) dw, the Nyquist row (slot 0) at nf dw
+    // (the kernel's coefficients take w = (i + 1) dw: the axis must be that to rounding -- 2 pi fftfreq is)
+    const double dw = w_host[1];
+    if (!(dw > 0.0)) return IMPDAR_OK;
+    for (int i = 1; i < nf; ++i)
+        if (std::fabs(w_host[i] - (double)i * dw) > 2e-15 * (double)i * dw) return IMPDAR_OK;
+    if (std::fabs(std::fabs(w_host[0]) - (double)nf * dw) > 2e-15 * (double)nf * dw) return IMPDAR_OK;
+    double kxh_max = 0.0;
+    for (int k = 0; k < tnum; ++k) kxh_max = std::max(kxh_max, 0.5 * std::fabs(kx_host[k]));
+    if (!(kxh_max > 0.0) || !std::isfinite(kxh_max)) return IMPDAR_OK;
+    SrHostPlan &hp = pl.sr_plan;
+    const bool same = hp.v.size() == (size_t)snum && memcmp(hp.v.data(), vmig, (size_t)snum * 8) == 0 && hp.dt == P.dt && hp.dw == dw &&
+                      hp.nf == nf && hp.kxh_max == kxh_max && hp.dbl == dbl && !hp.pieces.empty();
+    if (!same) {
+        pl.sr_dev = false;
+        impdar_trace("ps_series: planning the pieces of a %d-step profile", snum);
+        if (!sr_make_plan(hp, vmig, snum, P.dt, dw, nf, kxh_max, dbl)) {
+            hp.pieces.clear();
+            return IMPDAR_OK;
+        }
+        impdar_trace("ps_series: %zu pieces", hp.pieces.size());
+    }
+    if (hp.pieces.empty() || hp.pieces.size() > 4096) return IMPDAR_OK;
+    bool need[13] = {};
+    for (const SrPiece &pc : hp.pieces) need[pc.loglp] = true;
+    SrParams Q;
+    bool grew = false;
+    std::vector<T> &corr = pn_corr_tables<T>(pl, need, Q.corr_off, &grew);
+    std::vector<double> rw((size_t)nf);
+    for (int i = 0; i < nf; ++i) rw[i] = 1.0 / w_host[i];
+    std::vector<T> ev(hp.ev.begin(), hp.ev.end());
+    if (pl.d_sr_pieces.ensure(hp.pieces.size() * sizeof(SrPiece)) != hipSuccess || pl.d_sr_ev.ensure(ev.size() * sizeof(T) + 16) != hipSuccess ||
+        pl.d_pn_corr.ensure(corr.size() * sizeof(T) + 16) != hipSuccess || pl.d_rw.ensure(rw.size() * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        return IMPDAR_OK;
+    }
+    for (int l = 5; l <= 13; ++l)
+        if (need[l - 1]) {
+            int rc = pl.pn_tw[l].ensure<T>(1 << l, st);
+            if (rc) return rc;
+        }
+    {
+        int rc = pl.pn_tw[9].ensure<T>(SR_TWLDS, st);       // (the kernel keeps this one in LDS)
+        if (rc) return rc;
+    }
+    for (int l = 0; l < 14; ++l) Q.tw[l] = pl.pn_tw[l].buf.p;
+    if (!pl.sr_dev) {
+        IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_sr_pieces.p, hp.pieces.data(), hp.pieces.size() * sizeof(SrPiece), hipMemcpyHostToDevice, st));
+        if (!ev.empty()) IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_sr_ev.p, ev.data(), ev.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    }
+    if (grew || pl.pn_corr_dev != (int)sizeof(T)) {
+        IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_pn_corr.p, corr.data(), corr.size() * sizeof(T), hipMemcpyHostToDevice, st));
+        pl.pn_corr_dev = (int)sizeof(T);
+    }
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_rw.p, rw.data(), rw.size() * 8, hipMemcpyHostToDevice, st));
+    Q.P = P;
+    Q.pieces = pl.d_sr_pieces.as<SrPiece>();
+    Q.npieces = (int)hp.pieces.size();
+    Q.ev = pl.d_sr_ev.p;
+    Q.rw = pl.d_rw.as<double>();
+    Q.corr = pl.d_pn_corr.p;
+    Q.kxh_max = kxh_max;
+    Q.grid_bytes = (hp.grid_bytes + 15) & ~15;
+    const size_t lds = sr_lds_bytes<T>(Q.grid_bytes);
+    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_series_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sr_lds_bytes<T>(SR_GRID_BYTES + 16)));
+    hipLaunchKernelGGL(ps_series_kernel<T>, dim3((unsigned)P.nk), dim3(SrCfg<T>::NTH), lds, st, Q);
+    IMPDAR_HIP_CHECK(hipGetLastError());
+    IMPDAR_HIP_CHECK(hipStreamSynchronize(st));            // (the host tables must outlive their copies)
+#ifdef SR_STAMPS
+    {
+        unsigned long long h[16];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(sr_stamps), sizeof h);
+        fprintf(stderr, "[sr_stamps] classify %llu list %llu direct %llu setup %llu gather %llu fft %llu output %llu (cycles of thread 0, summed over workgroups)\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
+        memset(h, 0, sizeof h);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(sr_stamps), h, sizeof h);
+    }
+#endif
+    pl.sr_dev = true;
     *done = true;
     return IMPDAR_OK;
 }
@@ -1896,6 +2003,9 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             pl.d_pn_pieces.release();
             pl.d_pn_corr.release();
             pl.pn_corr_dev = -1;
+            pl.d_sr_pieces.release();
+            pl.d_sr_ev.release();
+            pl.sr_dev = false;
             for (OwnTwiddles &t : pl.pn_tw) {
                 t.buf.release();
                 t.nt = 0;
@@ -2212,6 +2322,12 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             if ((rc = ps_nufft_run<double>(pl, P, one, false, kx, w.data(), thr.data(), st, &mfma_done))) return rc;
             if (mfma_done) mfma_kernel_name = "ps_nufft_kernel";
         }
+        // a v(z) profile of any kind -- a table's "runs" with their 4e-13 of velocity noise, a velocity that changes at every step:
+        // the series path (ps_series.h)
+        if (vlen && (pref == 1 || pref == 7)) {
+            if ((rc = ps_series_run<double>(pl, P, vmig, kx, w.data(), thr.data(), st, &mfma_done))) return rc;
+            if (mfma_done) mfma_kernel_name = "ps_series_kernel";
+        }
     }
     if constexpr (sizeof(T) == 4) {
         // float32: the frequency sums on the matrix cores when the depth axis is a few long runs of constant velocity
@@ -2245,11 +2361,16 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         // tables of up to 16 thick layers (8192^2 device ms at 3 / 5 / 7 / 11 / 16 / 21 long runs: 5.1 / 6.1 / 7.2 / 9.5 / 13.0 /
         // 16.8 against ps_runs_kernel's 11.8 / 12.4 / 12.8 / 13.7 / 14.4 / 15.3; config 5: 4.5 against ps_mfma_kernel's 10.6,
         // constant velocity 3.0 against 6.8 -- profiles/r05_ps_nufft.txt), then the matrix-core paths as before
-        if (ok && (pref == 6 || (pref == 1 && nlong <= 16)) && !force_overflow) {
+        // ... 7: only the series path (ps_series.h).  By itself: profiles without runs of constant velocity to live on
+        if (ok && vlen && (pref == 7 || (pref == 1 && !P.sched)) && !force_overflow) {
+            if ((rc = ps_series_run<float>(pl, P, vmig, kx, w.data(), thr.data(), st, &mfma_done))) return rc;
+            if (mfma_done) mfma_kernel_name = "ps_series_kernel";
+        }
+        if (ok && !mfma_done && (pref == 6 || (pref == 1 && nlong <= 16)) && !force_overflow) {
             if ((rc = ps_nufft_run<float>(pl, P, mruns, vlen != 0, kx, w.data(), thr.data(), st, &mfma_done))) return rc;
             if (mfma_done) mfma_kernel_name = "ps_nufft_kernel";
         }
-        for (int turn = 0; turn < 2 && ok && !mfma_done && pref != 0; ++turn) {
+        for (int turn = 0; turn < 2 && ok && !mfma_done && pref != 0 && pref != 7; ++turn) {
             const bool use_runs = (turn == 0) == runs_first;
             if (use_runs) {
                 if (pref == 2 || pref == 5 || !vlen || force_overflow) continue;

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
 #else
             for (int m = tid; m < G; m += PN_NTH) {
 #endif
-                const float mm = (float)(m > G / 2 + PN_W ? m - G : m);      // centred: the regular frequencies sit in [0, G/2]
+                const float mm = (float)(m > G / 2 + PN_W / 2 ? m - G : m);  // centred: the regular frequencies sit in [0, G/2], reach W/2 to either side (G >= 32 > 2 W)
                 T gx = 0, gy = 0;
                 const float uhi = mm + 0.5f * PN_W, ulo = fmaxf(mm - 0.5f * PN_W, 0.f);
                 if (uhi > 0.f) {

@@ -6,7 +6,7 @@
 R=$(cd "$(dirname "$0")/../.." && pwd)
 SRC=${SRC:-kirchhoff}
 OBJS=""
-for o in api comm kirchhoff stolt phaseshift preproc; do [ $o != $SRC ] && OBJS="$OBJS $R/impdar_amd/csrc/$o.o"; done
+for o in api comm kirchhoff kirch_gen stolt phaseshift preproc; do [ $o != $SRC ] && OBJS="$OBJS $R/impdar_amd/csrc/$o.o"; done
 mkdir -p $R/build/diag
 while [ $# -ge 2 ]; do
   n=$1; f=$2; shift 2
