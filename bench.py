@@ -202,24 +202,92 @@ def pmc_child_path(path, calls):
         d._dev = None
 
 
+def pmc_valu_busy(kind, kernel_substr, timeout_s=150.0):
+    """Share of the vector-issue slots the phase shift's frequency-sum kernel keeps busy at 8192 x 8192: one rocprofv3 --pmc
+    child pass of this file (--pmc-child-ps KIND), SQ_ACTIVE_INST_VALU (quad-cycles, summed over the chip) x 4 over
+    1024 SIMDs x the kernel's cycles (GRBM_GUI_ACTIVE / 8 XCDs).  Returns a dict or {"error": ...}."""
+    prof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(prof):
+        return {"error": "rocprofv3 not found"}
+    if under_profiler():
+        return {"error": "bench.py itself runs under a profiler"}
+    d = tempfile.mkdtemp(prefix='impdar_pmc_', dir='/tmp')
+    cmd = [prof, '--pmc', 'SQ_ACTIVE_INST_VALU', 'GRBM_GUI_ACTIVE', 'SQ_INSTS_VALU', '--kernel-trace', '-d', d, '-o', 'x', '--output-format', 'csv',
+           '--', sys.executable, os.path.abspath(__file__), '--pmc-child-ps', kind]
+    try:
+        p = subprocess.Popen(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        try:
+            rc = p.wait(timeout_s)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+            return {"error": "counter pass timed out"}
+        if rc:
+            return {"error": "counter pass exited with %d" % rc}
+        acc = {}
+        for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if kernel_substr in r.get('Kernel_Name', ''):
+                    acc.setdefault(r.get('Counter_Name'), []).append(float(r['Counter_Value']))
+        if not acc.get('SQ_ACTIVE_INST_VALU') or not acc.get('GRBM_GUI_ACTIVE'):
+            return {"error": "no counter rows for %s" % kernel_substr}
+        valu = float(np.mean(acc['SQ_ACTIVE_INST_VALU'])) * 4.0
+        cyc = float(np.mean(acc['GRBM_GUI_ACTIVE'])) / 8.0
+        return {"valu_busy": valu / (1024.0 * cyc), "kernel_cycles": cyc, "valu_instructions": float(np.mean(acc.get('SQ_INSTS_VALU', [0.])))}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def pmc_child_ps(kind):
+    """Child of pmc_valu_busy: two resident phase-shift calls of `kind` at 8192 x 8192, nothing else on the GPU."""
+    import ctypes as C
+    from impdar_amd import _hip, synth
+    from oracle import mig_oracle as mo
+    lib, ctx = _hip.load(), _hip.context()
+    n = 8192
+    geo = synth.geometry(n, n)
+    dt = np.float64 if kind.endswith('_f64') else np.float32
+    x = np.random.default_rng(0).standard_normal((n, n)).astype(dt)
+    vel = gazdag_velocity(kind, geo, n)
+    if np.ndim(vel) == 2:
+        vel = mo.get_velocity_profile(geo['travel_time'], vel)
+    kx = mo._kx(n, geo['trace_int'], geo['dist'])
+    ws = 2. * np.pi * np.fft.fftfreq(n, d=geo['dt'])
+    tt = np.ascontiguousarray(geo['travel_time'], dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    vm = None if np.ndim(vel) == 0 else np.ascontiguousarray(vel, dtype=np.float64)
+    d_in = _hip.DeviceArray.from_host(ctx, x)
+    d_out = _hip.DeviceArray(ctx, d_in.shape, d_in.dtype)
+    for _ in range(2):
+        _hip.check(lib.impdar_phaseshift_dev(ctx, d_in.ptr, _hip.dtype_code(dt), n, n, n, kx.ctypes.data_as(dp), ws.ctypes.data_as(dp),
+                                             C.c_double(geo['dt']), tt.ctypes.data_as(dp), C.c_double(float(vel) if vm is None else 0.0),
+                                             vm.ctypes.data_as(dp) if vm is not None else None, 0 if vm is None else n,
+                                             C.c_double(100.), C.c_double(1000.), d_out.ptr), 'impdar_phaseshift_dev')
+    d_in.free()
+    d_out.free()
+
+
 # ---------------------------------------------------------------------------------------------------------
 # parity of the 8192 x 8192 phase-shift sub-records: the oracle on a few wavenumbers, in CPU-only child processes that run
 # beside the GPU legs (wavenumbers are independent in phaseShift, mig_python.py:438-487: tests/test_phaseshift_gpu.py)
 # ---------------------------------------------------------------------------------------------------------
 SPOT_KS = (0, 37, 200, 4096)          # zero, low, one that holds a frequency ON the evanescent boundary of 1.69e8 m/s, Nyquist
-SPOT_KINDS = ('vz4', 'const', 'layers41', 'gradient', 'gradient_f64')
+SPOT_KINDS = ('vz4', 'vz4_f64', 'const', 'const_f64', 'layers41', 'gradient', 'gradient_f64', 'firn', 'firn_f64')
 
 
 def gazdag_velocity(kind, geo, n):
     """What the sub-record `kind` migrates with: a scalar, a (v, z) table or a per-step profile of length n."""
     Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+    kind = kind[:-4] if kind.endswith('_f64') else kind
     if kind == 'vz4':
         return np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rp], [1.8e8, 0.5 * Rp], [1.9e8, 1.2 * Rp]])
     if kind == 'const':
         return 1.69e8
     if kind == 'layers41':
         return np.stack([np.linspace(1.69e8, 2.2e8, 41), np.linspace(0., 2.0 * Rp, 41)], axis=1)
-    assert kind.startswith('gradient')
+    if kind == 'firn':                # fast near the surface, flat below: what a firn column looks like (changes at every step)
+        return np.ascontiguousarray(1.69e8 + 0.6e8 * np.exp(-np.arange(n) * geo['dt'] / 0.8e-6))
+    assert kind == 'gradient'
     return np.ascontiguousarray(1.69e8 + 0.5e8 * np.linspace(0., 1., n))      # changes at every step: no runs of constant velocity
 
 
@@ -290,9 +358,34 @@ def spot_parity(img, spot, kind, bar):
     return rec
 
 
+
+def valu_roofline(kind, kernel, kms, n, flop, no_pmc):
+    """The roofline object of a phase-shift record whose frequency sums ran on a transform path (ps_nufft_kernel /
+    ps_series_kernel): what binds those kernels is vector ISSUE, measured by a counter pass; the direct sum's equivalent rate
+    stays as a labelled extra."""
+    nf, nk = n // 2, n
+    esz = 16 if kind.endswith('_f64') else 8
+    floor_ms = (esz * nf * nk + esz * n * nk) / (HBM_PEAK_GBS * 1e9) * 1e3       # spectrum read once + TK written once
+    r = {"bound": "valu issue", "unit": "share of vector issue slots busy", "peak": 1.0, "achieved": None, "frac": None,
+         "hbm_floor_ms": floor_ms, "kernel_ms_over_hbm_floor": kms / floor_ms,
+         "x_direct_sum": {"TFLOPs_equivalent": flop / (kms * 1e-3) / 1e12, "x_fp32_vector_peak": flop / (kms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TF}}
+    if not no_pmc:
+        c = pmc_valu_busy(kind, kernel)
+        if "error" in c:
+            r["counter_error"] = c["error"]
+        else:
+            r["achieved"] = r["frac"] = c["valu_busy"]
+            r["kernel_cycles"] = c["kernel_cycles"]
+            r["valu_instructions"] = c["valu_instructions"]
+    return r
+
+
 # ---------------------------------------------------------------------------------------------------------
 # secondary paths, driver-timed: BASELINE configs 2 (Stolt) and 5 (Gazdag v(z)), config 3 in float64
 # ---------------------------------------------------------------------------------------------------------
+TRANSFORM_KERNELS = ('ps_nufft_kernel', 'ps_series_kernel')
+
+
 def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None, spot=None):
     import contextlib
     import io
@@ -436,8 +529,8 @@ def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None, spot=None):
                                 "synchronisation inside the matrix-core path; frac_device_ms / x_fp32_vector_peak_device_ms "
                                 "are the same flop over device_ms (the basis rounds 1-2 reported); mfma_flop_executed = the "
                                 "kernel's own count of issued MFMAs x 32768"}}
-    if mm.get('kernel') == 'ps_nufft_kernel':
-        rec["roofline"]["note"] = nufft_note
+    if mm.get('kernel') in TRANSFORM_KERNELS:
+        rec["roofline"] = valu_roofline('vz4', mm.get('kernel'), kms, n, flop, no_pmc)
     rec.update(par5)
     rec["kernel"] = mm.get('kernel')
     e2e = host_call_ms(lambda d: d.migrate('phsh', vel=tab, htaper=100, vtaper=1000), lambda: dat_of(x, geo), reps=2)
@@ -464,6 +557,8 @@ def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None, spot=None):
     ms64, wall64, fin64, kms64 = device_ms(lambda d: d.migrate('phsh', vel=tab, htaper=100, vtaper=1000), lambda: dat_of(x64, geo),
                                            reps=3, kernel=True)
     tf64 = flop / (kms64 * 1e-3) / 1e12
+    mm64 = getattr(device_ms, 'metrics', {})
+    img64 = device_ms.image
     out["gazdag_f64_config5"] = {
         "workload": "phase-shift (Gazdag) migration, 1-D v(z) table, 8192x8192 float64 data (BASELINE config 5 in the "
                     "reference's own arithmetic), resident in HBM",
@@ -473,7 +568,11 @@ def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None, spot=None):
                      "frac": tf64 / FP64_VECTOR_PEAK_TF, "algorithmic_flop": flop,
                      "note": "8 flop per needed complex rotate-accumulate (half walk) over kernel_ms against the float64 "
                              "vector peak; 42 % of the (kx, w) plane is evanescent and skipped pair-wise (docs/DESIGN_rounds1-4.md 11.7)"}}
-    del x64
+    out["gazdag_f64_config5"]["kernel"] = mm64.get('kernel')
+    if mm64.get('kernel') in TRANSFORM_KERNELS:
+        out["gazdag_f64_config5"]["roofline"] = valu_roofline('vz4_f64', mm64.get('kernel'), kms64, n, flop, no_pmc)
+    out["gazdag_f64_config5"].update(spot_parity(img64, spot, 'vz4_f64', 1e-10))
+    del x64, img64
     # ---- the other velocity structures at config-5 size (figures the builder alone had measured)
     def ps_dev(data, vel, reps=4):       # (the median of four timed calls: one disturbed call -- seen once per run on a shared pod -- does not move it)
         """impdar_phaseshift_dev on a resident radargram with a scalar / per-step velocity: (device ms, kernel ms, image, metrics)."""
@@ -519,9 +618,8 @@ def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None, spot=None):
              "output_finite": bool(np.isfinite(img).all()), "steps_executed": steps,
              "roofline": {"bound": bound, "achieved": tf_, "peak": peak, "unit": "TFLOP/s", "frac": tf_ / peak, "algorithmic_flop": flop,
                           "note": "8 flop per needed complex rotate-accumulate (half walk, evanescent pairs included) over kernel_ms"}}
-        if met.get('kernel') == 'ps_nufft_kernel':
-            r["roofline"]["method"] = "non-uniform FFT"
-            r["roofline"]["note"] = nufft_note
+        if met.get('kernel') in TRANSFORM_KERNELS:
+            r["roofline"] = valu_roofline(kind, met.get('kernel'), kms_, n, flop, no_pmc)
         if met.get('mfma_instructions') and float(met['mfma_instructions']) > 0:
             ex = float(met['mfma_instructions']) * float(met['flop_per_mfma'])
             r["roofline"]["mfma_flop_executed"] = ex
@@ -536,6 +634,12 @@ def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None, spot=None):
                  "velocity changing at EVERY step (linear gradient 1.69e8 -> 2.19e8 m/s) through the C entry point")
     gazdag_extra("gazdag_smooth_f64_config5", 'gradient_f64', x.astype(np.float64), "fp64 vector", FP64_VECTOR_PEAK_TF, 1e-10,
                  "velocity changing at EVERY step (linear gradient), float64 data")
+    gazdag_extra("gazdag_const_f64_config5", 'const_f64', x.astype(np.float64), "fp64 vector", FP64_VECTOR_PEAK_TF, 1e-10,
+                 "constant velocity 1.69e8 m/s, float64 data")
+    gazdag_extra("gazdag_firn_config5", 'firn', x, "fp32 vector", FP32_VECTOR_PEAK_TF, 2e-4,
+                 "a firn column (velocity changing at every step, fast near the surface, flat below)")
+    gazdag_extra("gazdag_firn_f64_config5", 'firn_f64', x.astype(np.float64), "fp64 vector", FP64_VECTOR_PEAK_TF, 1e-10,
+                 "a firn column, float64 data")
     del x
 
     # ---- config 3 in the reference's own arithmetic: float64 data, kirch_dquad_kernel (mig_python.py:53,118 sum in float64)
@@ -693,6 +797,38 @@ def first_call_records():
 
 
 # ---------------------------------------------------------------------------------------------------------
+
+# keys whose values are prose: explained once in profiles/bench_record_keys.md, not printed with every run (the driver keeps the
+# last 8 KB of stdout: round 5's 14.7 KB line lost config 2, the one-shot calls and the first calls)
+PROSE_KEYS = ('note', 'traffic_source', 'parity_vs', 'source', 'what', 'method')
+SUBRECORD_DROPS = ('workload', 'parity_wavenumbers', 'steps_executed', 'rotate_accumulate_steps', 'algorithmic_flop', 'kernel_cache', 'import_ms',
+                   'kind', 'finite', 'fused_floor_bytes', 'algorithmic_bytes', 'fetch_bytes_if_all_16B_per_lane', 'fetch_raw_over_write',
+                   'valu_instructions', 'kernel_cycles', 'parity_cols')
+
+
+SUBRECORD_DROPS_EXTRA = []
+
+
+def compact_record(o, depth=0):
+    """The record without its prose, floats to 5 significant digits; the keys stay."""
+    if isinstance(o, dict):
+        out = {}
+        for k, v in o.items():
+            if k in PROSE_KEYS:
+                continue
+            if (depth > 1 and k in SUBRECORD_DROPS) or (depth > 0 and k in SUBRECORD_DROPS_EXTRA):     # sub-records: constants of the workload (profiles/bench_record_keys.md)
+                continue
+            if k == 'sample' and isinstance(v, str) and len(v) > (90 if depth < 2 else 44):
+                v = v[:(87 if depth < 2 else 41)] + '...'
+            out[k] = compact_record(v, depth + 1)
+        return out
+    if isinstance(o, (list, tuple)):
+        return [compact_record(v, depth + 1) for v in o]
+    if isinstance(o, float):
+        return float('%.5g' % o) if np.isfinite(o) else None
+    return o
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -716,6 +852,8 @@ def main():
     ap.add_argument('--spot-oracle', nargs=2, default=None, metavar=('KIND', 'OUT'), help=argparse.SUPPRESS)
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--pmc-child-path', default=None, help=argparse.SUPPRESS)
+    ap.add_argument('--pmc-child-ps', default=None, help=argparse.SUPPRESS)
+    ap.add_argument('--full-line', action='store_true', help='print the record with its prose notes (default: numbers only, so that the line fits the driver\'s 8 KB tail; the keys are explained in profiles/bench_record_keys.md)')
     ap.add_argument('--data-child', default='zeros', choices=['zeros', 'synthetic'], help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.spot_oracle:
@@ -723,6 +861,9 @@ def main():
         return
     if args.pmc_child_path:
         pmc_child_path(args.pmc_child_path, args.steps)
+        return
+    if args.pmc_child_ps:
+        pmc_child_ps(args.pmc_child_ps)
         return
     if args.first_call:
         first_call_child(args.first_call)
@@ -1032,7 +1173,16 @@ def main():
             log('[bench] config-2 / config-5 sub-records took %.1f s' % (time.time() - t0))
 
     if rank == 0:
-        os.write(result_fd, (json.dumps(res) + '\n').encode())
+        line = json.dumps(res if args.full_line else compact_record(res), separators=(',', ':'))
+        if not args.full_line:
+            # (the driver keeps 8192 bytes: what goes first if the line still does not fit)
+            for drop in ('device_ms_calls', 'warm_cache', 'floor', 'ranks', 'cpu_numpy_1core'):
+                if len(line) <= 7800:
+                    break
+                SUBRECORD_DROPS_EXTRA.append(drop)
+                line = json.dumps(compact_record(res), separators=(',', ':'))
+        log('[bench] result line: %d bytes' % len(line))
+        os.write(result_fd, (line + '\n').encode())
     rdv.barrier()
     rdv.close()
     if rank == 0 and res.get("error"):

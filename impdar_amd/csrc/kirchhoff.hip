@@ -1484,9 +1484,6 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_dquad_kernel(FastP
     // cos(theta) = rsqrt(1 + c1 n^2) in float64: float32 seed + one third-order correction (see the header)
     auto cosine = [&](double n2) {
         const double x = fma(c1, n2, 1.0);
-#ifdef KD_ABL_NOWEIGHT
-        return c1;                                    // timing only (profiles/r05_dquad_ablation.txt)
-#endif
         const double y0 = (double)__builtin_amdgcn_rsqf((float)x);
         const double h = x * y0;
         const double rr = fma(-h, y0, 1.0);
@@ -1569,11 +1566,7 @@ __global__ __launch_bounds__(KF_THREADS * NH, OCC) void kirch_dquad_kernel(FastP
             if (i0 < XB || i1 < XB) {
                 const kd_d2 dv = __builtin_bit_cast(kd_d2, v[qd]);
                 const kd_d2 du = __builtin_bit_cast(kd_d2, u[NEAR ? qd : 0]);
-#ifdef KD_ABL_NOFMA
-#define KD_FMA(a, b, c_) ({ asm volatile("" ::"v"(b)); (c_); })      /* timing only: the operand is still read */
-#else
 #define KD_FMA(a, b, c_) fma(a, b, c_)
-#endif
 #define KD_COMP(ix, c)                                                              \
     if (ix < XB) {                                                                  \
         KD_ACC(ix < XB ? ix : 0) = KD_FMA(w, dv[c], KD_ACC(ix < XB ? ix : 0));         \

@@ -1321,7 +1321,7 @@ struct PsPlan {
     DevBuf d_blocks, d_edge, d_runtab;   // matrix-core path: row-block table; boundary-frequency counts + lists; per-run phases
     DevBuf d_pr_runs, d_pr_stages, d_rw; // many-runs matrix-core path (ps_runs.h): runs, stages, 1 / w
     DevBuf d_mcount;                     // matrix-core paths: MFMA instructions the kernel issued (one 64-bit counter)
-    DevBuf d_pn_pieces, d_pn_corr;       // transform path (ps_nufft.h): pieces, the window's correction tables
+    DevBuf d_pn_pieces, d_pn_corr, d_pn_e1;    // transform path (ps_nufft.h): pieces, the window's correction tables, the first-order sums
     SrHostPlan sr_plan;                  // series path (ps_series.h): the pieces of the last velocity profile, and on the device
     DevBuf d_sr_pieces, d_sr_ev;
     bool sr_dev = false;                 // ... the device copies are those of sr_plan
@@ -1425,7 +1425,6 @@ static int ps_dispatch(const PsParams &P, hipStream_t st)
     return IMPDAR_OK;
 }
 
-#include "ps_pair.h"
 #include "ps_nufft.h"
 #include "ps_series.h"      // a velocity that changes inside a piece: a few transforms with shared nodes + direct sums at the boundary
 #include "ps_runs.h"        // many runs of constant velocity: float32 MFMA, phases generated in the kernel
@@ -1643,8 +1642,10 @@ static std::vector<T> &pn_corr_tables(PsPlan &pl, const bool (&need)[13], int (&
 // ---- transform path (ps_nufft.h): pieces, correction tables, launch.  Same contract as ps_mfma_run.
 template <typename T>
 static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &runs, bool vz, const double *kx_host, const double *w_host,
-                        const double *thr, hipStream_t st, bool *done)
+                        const double *thr, hipStream_t st, bool *done, const double *vmig = nullptr)
 {
+    // vmig (float64 data, v(z)): the per-step velocities -- the runs' rounding noise enters as a first-order term (ps_nufft.h)
+    const bool first_order = sizeof(T) == 8 && vz && vmig != nullptr;
     *done = false;
     const int snum = P.snum, tnum = P.tnum, nf = P.nf;
     if (!P.herm || nf < 64 || nf > PN_NFMAX || snum < 64 || runs.empty()) return IMPDAR_OK;
@@ -1688,6 +1689,27 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
     }
     // a direct step costs as much as a tenth of a piece: tables of many layers stay with ps_runs_kernel
     if (nshort_steps > 64 || pc.size() > 256) return IMPDAR_OK;
+    std::vector<double> e1;
+    if (first_order) {
+        // per piece: the reference velocity sqrt(mean v^2) and E(n) / cbar^2 = sum_{t <= n} (v_t^2 / mean - 1)
+        e1.assign((size_t)snum, 0.0);
+        for (PnPiece &p0 : pc) {
+            if (p0.kind != 0) continue;
+            long double acc = 0.0L;
+            for (int t = 0; t < p0.len; ++t) acc += (long double)vmig[p0.start + t] * vmig[p0.start + t];
+            const double vb2 = (double)(acc / p0.len);
+            p0.v = std::sqrt(vb2);
+            long double run = 0.0L;
+            for (int t = 0; t < p0.len; ++t) {
+                run += ((long double)vmig[p0.start + t] * vmig[p0.start + t] - (long double)vb2) / (long double)vb2;
+                e1[(size_t)p0.start + t] = (double)run;
+            }
+        }
+        if (pl.d_pn_e1.ensure(e1.size() * 8) != hipSuccess) {
+            (void)hipGetLastError();
+            return IMPDAR_OK;
+        }
+    }
     PnParams Q;
     bool grew = false;
     std::vector<T> &corr = pn_corr_tables<T>(pl, need, Q.corr_off, &grew);
@@ -1710,6 +1732,11 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
         pl.pn_corr_dev = (int)sizeof(T);
     }
     IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_rw.p, rw.data(), rw.size() * 8, hipMemcpyHostToDevice, st));
+    Q.e1 = nullptr;
+    if (first_order) {
+        IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_pn_e1.p, e1.data(), e1.size() * 8, hipMemcpyHostToDevice, st));
+        Q.e1 = pl.d_pn_e1.as<double>();
+    }
     Q.P = P;
     Q.pieces = pl.d_pn_pieces.as<PnPiece>();
     Q.npieces = (int)pc.size();
@@ -1725,8 +1752,8 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
             if (need[l]) lmax = l;
         Q.gmax = 2 << lmax;
     }
-    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_nufft_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pn_lds_bytes<T>(2 * PnCfg<T>::LMAX)));
-    hipLaunchKernelGGL(ps_nufft_kernel<T>, dim3((unsigned)P.nk), dim3(PnCfg<T>::NTH), pn_lds_bytes<T>(Q.gmax), st, Q);
+    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_nufft_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pn_lds_bytes<T>(2 * PnCfg<T>::LMAX, sizeof(T) == 8)));
+    hipLaunchKernelGGL(ps_nufft_kernel<T>, dim3((unsigned)P.nk), dim3(PnCfg<T>::NTH), pn_lds_bytes<T>(Q.gmax, first_order), st, Q);
     if (vz) {
         PsMfmaParams E;                        // (ps_edge_kernel reads P and the lists only)
         E.mfma_count = nullptr;
@@ -1757,8 +1784,10 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
 // Same contract as ps_mfma_run: *done = false and IMPDAR_OK when the call is not for this path.
 template <typename T>
 static int ps_series_run(PsPlan &pl, PsParams P, const double *vmig, const double *kx_host, const double *w_host, const double *thr,
-                         hipStream_t st, bool *done)
+                         hipStream_t st, bool *done, double alt_ms_8192 = 0.0)
 {
+    // alt_ms_8192 > 0: what the kernel that would take the call otherwise is expected to need (per 8192 wavenumbers); the call is
+    // taken only where the planner's estimate is 0.85 of that or less.  0: taken regardless (IMPDAR_PS_MFMA=7)
     *done = false;
     const int snum = P.snum, tnum = P.tnum, nf = P.nf;
     constexpr bool dbl = sizeof(T) == 8;
@@ -1788,6 +1817,13 @@ static int ps_series_run(PsPlan &pl, PsParams P, const double *vmig, const doubl
         impdar_trace("ps_series: %zu pieces", hp.pieces.size());
     }
     if (hp.pieces.empty() || hp.pieces.size() > 4096) return IMPDAR_OK;
+    if (alt_ms_8192 != 0.0) {
+        // (alt < 0: per alive pair -- the per-step kernels)
+        const double alt = alt_ms_8192 > 0.0 ? alt_ms_8192 : -alt_ms_8192 * hp.alive_pairs;
+        const double est = (dbl ? SR_MS_PER_MODEL_F64 : SR_MS_PER_MODEL_F32) * hp.model_cost;
+        impdar_trace("ps_series: estimate %.1f ms per 8192 wavenumbers against %.1f", est, alt);
+        if (est > 0.85 * alt) return IMPDAR_OK;
+    }
     bool need[13] = {};
     for (const SrPiece &pc : hp.pieces) need[pc.loglp] = true;
     SrParams Q;
@@ -1833,15 +1869,6 @@ static int ps_series_run(PsPlan &pl, PsParams P, const double *vmig, const doubl
     hipLaunchKernelGGL(ps_series_kernel<T>, dim3((unsigned)P.nk), dim3(SrCfg<T>::NTH), lds, st, Q);
     IMPDAR_HIP_CHECK(hipGetLastError());
     IMPDAR_HIP_CHECK(hipStreamSynchronize(st));            // (the host tables must outlive their copies)
-#ifdef SR_STAMPS
-    {
-        unsigned long long h[16];
-        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(sr_stamps), sizeof h);
-        fprintf(stderr, "[sr_stamps] classify %llu list %llu direct %llu setup %llu gather %llu fft %llu output %llu (cycles of thread 0, summed over workgroups)\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
-        memset(h, 0, sizeof h);
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(sr_stamps), h, sizeof h);
-    }
-#endif
     pl.sr_dev = true;
     *done = true;
     return IMPDAR_OK;
@@ -1852,7 +1879,7 @@ static int ps_series_run(PsPlan &pl, PsParams P, const double *vmig, const doubl
 // IMPDAR_OK with *done = true when the frequency sums were produced here; *done = false: not eligible, the vector
 // kernels take the call.
 static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &runs, bool vz, const double *kx_host, const double *thr,
-                       hipStream_t st, bool *done, bool allow_pairs, const char **kernel_name)
+                       hipStream_t st, bool *done, const char **kernel_name)
 {
     *done = false;
     *kernel_name = "ps_mfma_kernel";
@@ -1926,7 +1953,7 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
     Q.vz = vz ? 1 : 0;
     Q.runtab = pl.d_runtab.as<double2>();
     // the whole wavenumber axis with kx[tnum - k] = -kx[k]: rows k and tnum - k turn by the same angles -- one set-up walk and
-    // one table row for both (and, on request, ps_pair_kernel: ps_pair.h); a slab of a kx-sharded run has no mirror rows
+    // one table row for both; a slab of a kx-sharded run has no mirror rows
     bool sym = P.k0 == 0 && P.nk == tnum && tnum >= 2;
     for (int k = 1; 2 * k < tnum && sym; ++k) sym = kx_host[k] == -kx_host[tnum - k];      // (the Nyquist row of an even axis is its own partner)
     Q.pairs = sym ? 1 : 0;
@@ -1938,14 +1965,8 @@ static int ps_mfma_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &run
         else if (P.nf <= 4096) hipLaunchKernelGGL(ps_setup_kernel<8>, grid, dim3(512), lds, st, Q);
         else hipLaunchKernelGGL(ps_setup_kernel<12>, grid, dim3(512), lds, st, Q);
     }
-    if (allow_pairs && sym) {
-        *kernel_name = "ps_pair_kernel";
-        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_LDS_BYTES));
-        hipLaunchKernelGGL(ps_pair_kernel, dim3((unsigned)(tnum / 2 + 1) * Q.ngroups), dim3(PP_WAVES * 64), PP_LDS_BYTES, st, Q);
-    } else {
-        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PM_LDS_BYTES));
-        hipLaunchKernelGGL(ps_mfma_kernel, dim3((unsigned)P.nk * Q.ngroups), dim3(PM_WAVES * 64), PM_LDS_BYTES, st, Q);
-    }
+    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PM_LDS_BYTES));
+    hipLaunchKernelGGL(ps_mfma_kernel, dim3((unsigned)P.nk * Q.ngroups), dim3(PM_WAVES * 64), PM_LDS_BYTES, st, Q);
     if (vz) hipLaunchKernelGGL(ps_edge_kernel_t<float>, dim3(P.nk), dim3(256), 0, st, Q);
     IMPDAR_HIP_CHECK(hipGetLastError());
     // the host table must outlive its async copy
@@ -2002,6 +2023,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             pl.d_pr_runs.release();
             pl.d_pn_pieces.release();
             pl.d_pn_corr.release();
+            pl.d_pn_e1.release();
             pl.pn_corr_dev = -1;
             pl.d_sr_pieces.release();
             pl.d_sr_ev.release();
@@ -2206,6 +2228,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     P.sm_m = 8;
     std::vector<int> sched, rowmap;
     std::vector<double> epsum;
+    int ndirty_tiles = 0;                    // 16-step tiles that hold a change of velocity
     if (vlen) {
         // runs of constant velocity (ps_vz32_kernel): a step starts a new run when its velocity differs from the
         // run's first by more than vtol (relative) -- 2*gradient(z(t)) of a layered table is constant inside a
@@ -2229,6 +2252,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             }
             epsum[i / 16] += vmig[i] / vrun - 1.0;      // float64 kernel: the run's velocity noise, tile by tile
         }
+        ndirty_tiles = ndirty;
         // the per-step tiles of the runs kernels cost several quiet tiles each: beyond a share of such tiles the
         // per-step kernel is faster for float32 (2048^2, 40 / 80 / 160 layers: 4.6 / 7.5 / 12.2 ms against
         // 5.5 / 6.8 / 9.5 ms); the float64 runs kernel stays ahead until every tile holds a change (10.1 / 16.6 /
@@ -2322,10 +2346,30 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             if ((rc = ps_nufft_run<double>(pl, P, one, false, kx, w.data(), thr.data(), st, &mfma_done))) return rc;
             if (mfma_done) mfma_kernel_name = "ps_nufft_kernel";
         }
-        // a v(z) profile of any kind -- a table's "runs" with their 4e-13 of velocity noise, a velocity that changes at every step:
-        // the series path (ps_series.h)
-        if (vlen && (pref == 1 || pref == 7)) {
-            if ((rc = ps_series_run<double>(pl, P, vmig, kx, w.data(), thr.data(), st, &mfma_done))) return rc;
+        // a v(z) table of up to 16 thick layers: the transform path with the runs' velocity noise (~4e-13, cut at 1e-11) as its
+        // first-order term (ps_nufft.h); 6 asks for it at any number of layers
+        if (vlen && P.sched && (pref == 1 || pref == 6)) {
+            std::vector<PsMfmaRun> mruns;
+            bool ok = true;
+            for (int i = 0; i < snum && ok; ++i) {
+                ok = std::isfinite(vmig[i]) && vmig[i] != 0.0;
+                if (sched[i]) mruns.push_back(PsMfmaRun{vmig[i], i, 0});
+                if (!mruns.empty()) mruns.back().len += 1;
+            }
+            int nlong = 0;
+            for (const PsMfmaRun &r : mruns) nlong += r.len > PM_SHORT;
+            long_runs = nlong;
+            if (ok && (pref == 6 || nlong <= 16)) {
+                if ((rc = ps_nufft_run<double>(pl, P, mruns, true, kx, w.data(), thr.data(), st, &mfma_done, vmig))) return rc;
+                if (mfma_done) mfma_kernel_name = "ps_nufft_kernel";
+            }
+        }
+        // any other v(z) profile -- a velocity that changes at every step, many layers: the series path (ps_series.h)
+        if (vlen && !mfma_done && (pref == 1 || pref == 7)) {
+            // (what would run otherwise: ps_smooth_kernel, 10.8e-6 ms per alive pair; the runs kernel ps_vz64_kernel
+            // -- 43 ms + 0.35 per 16-step tile that holds a change of velocity, at 8192^2: profiles/r06_series.txt)
+            const double alt = pref == 7 ? 0.0 : (P.sched ? (43.0 + 0.35 * (double)ndirty_tiles) * ((double)nf / 4096.0) * ((double)snum / 8192.0) : -SR_MS_PER_PAIR_F64);
+            if ((rc = ps_series_run<double>(pl, P, vmig, kx, w.data(), thr.data(), st, &mfma_done, alt))) return rc;
             if (mfma_done) mfma_kernel_name = "ps_series_kernel";
         }
     }
@@ -2343,8 +2387,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             mruns.push_back(PsMfmaRun{vconst, 0, snum});
         }
         // IMPDAR_PS_MFMA: 0 the vector kernels only; 2 / 3 only ps_mfma_kernel / only ps_runs_kernel of the matrix-core
-        // paths; 5 as 2 with ps_pair_kernel (two wavenumbers per workgroup: an experiment that did not pay, ps_pair.h) where
-        // it applies (A/B runs, tests).  By themselves: up to 3 thick layers -> ps_mfma_kernel (64-step tiles, phases from a table);
+        // paths (A/B runs, tests).  By themselves: up to 3 thick layers -> ps_mfma_kernel (64-step tiles, phases from a table);
         // more long runs -> ps_runs_kernel (8-step tiles, phases generated in the kernel); whichever declines
         // (ps_mfma_kernel: rows mostly padding on short records) hands over to the other, then to the vector kernels.
         const char *me = getenv("IMPDAR_PS_MFMA");
@@ -2362,8 +2405,11 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         // 16.8 against ps_runs_kernel's 11.8 / 12.4 / 12.8 / 13.7 / 14.4 / 15.3; config 5: 4.5 against ps_mfma_kernel's 10.6,
         // constant velocity 3.0 against 6.8 -- profiles/r05_ps_nufft.txt), then the matrix-core paths as before
         // ... 7: only the series path (ps_series.h).  By itself: profiles without runs of constant velocity to live on
-        if (ok && vlen && (pref == 7 || (pref == 1 && !P.sched)) && !force_overflow) {
-            if ((rc = ps_series_run<float>(pl, P, vmig, kx, w.data(), thr.data(), st, &mfma_done))) return rc;
+        if (ok && vlen && (pref == 7 || (pref == 1 && (!P.sched || mruns.size() > 64))) && !force_overflow) {
+            // (what would run otherwise, at 8192^2: ps_smooth32_kernel 5.3e-6 ms per alive pair; ps_runs_kernel 8 ms + 0.14 per run)
+            const double alt = pref == 7 ? 0.0 : (!P.sched ? -SR_MS_PER_PAIR_F32
+                                                           : (8.0 + 0.14 * (double)mruns.size()) * ((double)nf / 4096.0) * ((double)snum / 8192.0));
+            if ((rc = ps_series_run<float>(pl, P, vmig, kx, w.data(), thr.data(), st, &mfma_done, alt))) return rc;
             if (mfma_done) mfma_kernel_name = "ps_series_kernel";
         }
         if (ok && !mfma_done && (pref == 6 || (pref == 1 && nlong <= 16)) && !force_overflow) {
@@ -2373,13 +2419,13 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         for (int turn = 0; turn < 2 && ok && !mfma_done && pref != 0 && pref != 7; ++turn) {
             const bool use_runs = (turn == 0) == runs_first;
             if (use_runs) {
-                if (pref == 2 || pref == 5 || !vlen || force_overflow) continue;
+                if (pref == 2 || !vlen || force_overflow) continue;
                 if ((rc = ps_runs_run(pl, P, mruns, kx, w.data(), thr.data(), st, &mfma_done))) return rc;
                 if (mfma_done) mfma_kernel_name = "ps_runs_kernel";
             } else {
                 if (pref == 3) continue;
                 const char *name = "";
-                if ((rc = ps_mfma_run(pl, P, mruns, vlen != 0, kx, thr.data(), st, &mfma_done, pref == 5, &name))) return rc;
+                if ((rc = ps_mfma_run(pl, P, mruns, vlen != 0, kx, thr.data(), st, &mfma_done, &name))) return rc;
                 if (mfma_done) mfma_kernel_name = name;
             }
         }

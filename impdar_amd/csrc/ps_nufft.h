@@ -33,12 +33,15 @@
 
 constexpr int PN_NFMAX = 4096;              // frequencies per wavenumber this kernel takes (one workgroup holds them all)
 constexpr int PN_SHORT = 8;                 // runs of up to this many steps are summed directly
-// float32 data: a window of 8 grid points (3.5e-7 of the result in float32 arithmetic), 256 threads, two workgroups per CU;
-// float64 data: 14 points (5e-13 in float64 arithmetic; the stated bar against the reference is 1e-10), 512 threads, one per CU
-// -- for a CONSTANT velocity only: inside a "run" of a v(z) table the interpolated velocity carries ~4e-13 of rounding noise
-// (2 * gradient(z(t))), which over 8192 steps moves a phase by 1e-8 rad; the float64 vector kernels carry that deviation along
-// (P.eps), a transform needs it as a first-order term (a second transform with coefficients kappa_w C_w per piece) before it
-// can hold the 1e-10 bar on a table.
+// float32 data: a window of 8 grid points (3.5e-7 of the result in float32 arithmetic), 1024 threads;
+// float64 data: 14 points (5e-13 in float64 arithmetic; the stated bar against the reference is 1e-10), 512 threads.
+// A v(z) TABLE on float64 data: inside a "run" the interpolated velocity carries ~4e-13 of rounding noise (2 * gradient(z(t));
+// the host cuts runs at 1e-11), which over 8192 steps moves a phase by 1e-8 rad -- the 1e-10 bar resolves that.  It enters as the
+// first-order term of ps_series.h's series: with c^2 = cbar^2 + eps_t inside the piece (cbar^2 the piece's mean),
+//     Phi(n) = (n + 1) phi_w - (dt / 2 psi_w) E(n),  E(n) = sum_{t <= n} eps_t,   e^{i Phi} = e^{i (n + 1) phi} (1 + i kappa_w E(n)),
+// kappa_w = -dt / 2 psi_w (second order: 1e-15): a SECOND transform with the coefficients kappa_w D_w on the same nodes, scaled
+// by i E(n) at the output.  The correction is 1e-8 of the sum, so its grid, its FFT and its products are FLOAT32 (1e-7 of 1e-8):
+// one more accumulation per window value and 17 KB of LDS instead of a second float64 grid.
 template <typename T> struct PnCfg;
 // LMAX: steps per piece at most (G = 2 LMAX grid points): spreading and coefficients cost per PIECE -- as long as LDS allows
 template <> struct PnCfg<float> { static constexpr int W = 8, NTH = 1024, OCC = 1, LMAX = 4096; };
@@ -63,12 +66,46 @@ struct PnParams {
     int *edge_cnt, *edge_list;      // v(z): boundary frequencies for ps_edge_kernel (null: constant velocity, none)
     int vz;
     int gmax;                       // grid points of the longest piece (the LDS layout)
+    const double *e1;               // float64 v(z) tables: [snum] sum over the piece's steps up to this one of v_t^2 / vb2 - 1 (null: none)
 };
 
 // LDS: the grid of the call's longest piece (gmax points), then coefficients / grid places of all frequencies, the block reduction
-template <typename T> __host__ __device__ constexpr size_t pn_lds_bytes(int gmax)
+template <typename T> __host__ __device__ constexpr size_t pn_lds_bytes(int gmax, bool first_order = false)
 {
-    return (size_t)(own_pad(gmax) + 1) * 2 * sizeof(T) + (size_t)PN_NFMAX * (2 * sizeof(T) + sizeof(T) + 2) + 16 * 2 * PN_SHORT * sizeof(T);
+    return (size_t)(own_pad(gmax) + 1) * 2 * sizeof(T) + (size_t)PN_NFMAX * (2 * sizeof(T) + sizeof(T) + 2) + 16 * 2 * PN_SHORT * sizeof(T) +
+           (first_order ? (size_t)(own_pad(gmax) + 1) * 2 * sizeof(float) : 0);
+}
+
+// the float32 grid of the first-order term: own_fft_passes<float, true> with the twiddles of the float64 table
+__device__ __forceinline__ void pn_fft_f32(OCp<float> *s, int M, int logm, int tid, int nth, const OCp<double> *__restrict__ tw)
+{
+    int ll = logm;
+    while (ll >= 2) {
+        const int lq = ll - 2, q = 1 << lq, L = 1 << ll, tstep = M >> ll;
+        for (int b = tid; b < (M >> 2); b += nth) {
+            const int g = b >> lq, j = b & (q - 1), base = g * L + j;
+            const OCp<float> a0 = s[own_pad(base)], a1 = s[own_pad(base + q)], a2 = s[own_pad(base + 2 * q)], a3 = s[own_pad(base + 3 * q)];
+            const OCp<float> t0 = own_add(a0, a2), t1 = own_sub(a0, a2), t2 = own_add(a1, a3), d = own_sub(a1, a3);
+            const OCp<float> t3 = OCp<float>{-d.y, d.x};
+            const OCp<double> wd = tw[j * tstep];
+            const OCp<float> w1{(float)wd.x, -(float)wd.y};
+            const OCp<float> w2 = own_mul(w1, w1), w3 = own_mul(w2, w1);
+            s[own_pad(base)] = own_add(t0, t2);
+            s[own_pad(base + q)] = own_mul(own_add(t1, t3), w1);
+            s[own_pad(base + 2 * q)] = own_mul(own_sub(t0, t2), w2);
+            s[own_pad(base + 3 * q)] = own_mul(own_sub(t1, t3), w3);
+        }
+        __syncthreads();
+        ll -= 2;
+    }
+    if (ll == 1) {
+        for (int b = tid; b < (M >> 1); b += nth) {
+            const OCp<float> a0 = s[own_pad(2 * b)], a1 = s[own_pad(2 * b + 1)];
+            s[own_pad(2 * b)] = own_add(a0, a1);
+            s[own_pad(2 * b + 1)] = own_sub(a0, a1);
+        }
+        __syncthreads();
+    }
 }
 
 __device__ __forceinline__ float pn_window(float x)      // psi(x), |x| < W/2 (0 outside)
@@ -101,6 +138,8 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
     T *fr = reinterpret_cast<T *>(D + PN_NFMAX);                                        // [nf] u - floor(u)
     unsigned short *m0 = reinterpret_cast<unsigned short *>(fr + PN_NFMAX);             // [nf] floor(u)
     T *red = reinterpret_cast<T *>(m0 + PN_NFMAX);                                      // [waves][2 PN_SHORT] block reduction
+    OCp<float> *grid2 = reinterpret_cast<OCp<float> *>(red + 16 * 2 * PN_SHORT);        // [own_pad(G) + 1] the first-order term's grid (Q.e1)
+    const bool fo = sizeof(T) == 8 && Q.e1 != nullptr;
     const Cp<T> *Frow = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k * P.fstride;
     T *TKrow = reinterpret_cast<T *>(reinterpret_cast<Cp<T> *>(P.TK) + (size_t)kb * P.snum);
     const double kxk = P.kx[k];
@@ -217,14 +256,14 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
         const int Lp = 1 << pc.loglp, G = 2 * Lp, logg = pc.loglp + 1;
         const double ug = (double)G * 0.15915494309189535;                    // G / 2 pi
         for (int m = tid; m < own_pad(G) + 1; m += PN_NTH) grid[m] = OCp<T>{(T)0, (T)0};
+        // first-order term: kappa_w = -dt / 2 psi_w = kc / u_w (u = psi dt G / 2 pi: kc = -dt^2 G (v kx / 2)^2 ... / 4 pi), per unit of E / cbar^2
+        const double c2d = 0.25 * v * v * kxk * kxk;
+        const float kc = (float)(-P.dt * P.dt * (double)G * c2d / 12.566370614359172);
 #pragma unroll
         for (int j = 0; j < PN_PER; ++j) {
             const int i = tid + PN_NTH * j;
             if (i >= nf) continue;
             const int slot = slot_of(i);
-#ifdef PN_ABL_NOSETUP
-            if (r > 0) continue;                                              // timing only
-#endif
             bool alive;
             const double inc = step_phase(slot, v, &alive);                   // (negative for the Nyquist row: w = -pi / dt)
             if (!alive) ph[j] = nan;
@@ -234,7 +273,21 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
                 T sn, c;
                 pn_sincos(ph[j] + (double)(1 + Lp / 2) * inc, &sn, &c);
                 d = OCp<T>{fma(f.x, c, -(f.y * sn)), fma(f.x, sn, f.y * c)};
-                ph[j] = pm_wrap(ph[j] + (double)L * inc);
+                double adv = (double)L * inc;
+                if (fo) {
+                    // kappa_w (signed with the frequency: inc = +- dt psi) times E at the piece's last step
+                    const double kap = -P.dt * P.dt * c2d / (2.0 * inc);
+                    adv += kap * Q.e1[pc.start + L - 1];
+                    if (i == nf - 1) {                                        // the Nyquist row's second coefficient (its u is wrapped)
+                        float *dn2 = reinterpret_cast<float *>(red);
+                        dn2[0] = (float)((double)d.x * kap);
+                        dn2[1] = (float)((double)d.y * kap);
+                    }
+                }
+                ph[j] = pm_wrap(ph[j] + adv);
+            } else if (fo && i == nf - 1) {
+                float *dn2 = reinterpret_cast<float *>(red);
+                dn2[0] = dn2[1] = 0.f;
             }
             // place on the grid: phi mod 2 pi in units of the grid spacing (dead frequencies: 0 -- they carry D = 0)
             double u = inc * ug;
@@ -254,13 +307,10 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
             // the Nyquist row (index nf - 1): anywhere on the grid, looked at by every grid point
             const T uN = (T)m0[nf - 1] + fr[nf - 1];
             const OCp<T> dN = D[nf - 1];
-#ifdef PN_ABL_NOGATHER
-            for (int m = tid; m < 0; m += PN_NTH) {      // timing only
-#else
             for (int m = tid; m < G; m += PN_NTH) {
-#endif
                 const float mm = (float)(m > G / 2 + PN_W / 2 ? m - G : m);  // centred: the regular frequencies sit in [0, G/2], reach W/2 to either side (G >= 32 > 2 W)
                 T gx = 0, gy = 0;
+                float hx = 0.f, hy = 0.f;                                    // the first-order term's grid point (float32)
                 const float uhi = mm + 0.5f * PN_W, ulo = fmaxf(mm - 0.5f * PN_W, 0.f);
                 if (uhi > 0.f) {
                     int ilo = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * ulo, ulo, c2)) * inv_dw) - 3;
@@ -273,6 +323,11 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
                         const OCp<T> d = D[i];
                         gx = fma(d.x, wgt, gx);
                         gy = fma(d.y, wgt, gy);
+                        if (fo) {
+                            const float wk = (float)wgt * kc * __builtin_amdgcn_rcpf(fmaxf((float)m0[i] + (float)fr[i], 1e-3f));
+                            hx = fmaf((float)d.x, wk, hx);
+                            hy = fmaf((float)d.y, wk, hy);
+                        }
                     }
                 }
                 {
@@ -281,21 +336,36 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
                     const T wgt = pn_window(x);
                     gx = fma(dN.x, wgt, gx);
                     gy = fma(dN.y, wgt, gy);
+                    if (fo) {
+                        const float *dn2 = reinterpret_cast<const float *>(red);
+                        hx = fmaf(dn2[0], (float)wgt, hx);
+                        hy = fmaf(dn2[1], (float)wgt, hy);
+                    }
                 }
                 grid[own_pad(m)] = OCp<T>{gx, gy};
+                if (fo) grid2[own_pad(m)] = OCp<float>{hx, hy};
             }
         }
         __syncthreads();
-#ifndef PN_ABL_NOFFT
         own_fft_passes<T, true>(grid, G, logg, tid, PN_NTH, reinterpret_cast<const OCp<T> *>(Q.tw[logg]), 1);
-#endif
+        if constexpr (sizeof(T) == 8) {
+            if (fo) pn_fft_f32(grid2, G, logg, tid, PN_NTH, reinterpret_cast<const OCp<double> *>(Q.tw[logg]));
+        }
         {
             const T *corr = reinterpret_cast<const T *>(Q.corr) + Q.corr_off[pc.loglp];
             for (int n = tid; n < L; n += PN_NTH) {
                 const int np = n - Lp / 2;                                    // the band is centred: n' in [-Lp/2, Lp/2)
                 const OCp<T> z = grid[own_pad(own_rev(np & (G - 1), G, logg))];
                 const T cf = corr[np < 0 ? -np : np] * inv_snum;
-                reinterpret_cast<Cp<T> *>(TKrow)[pc.start + n] = Cp<T>{z.x * cf, z.y * cf};
+                T ox = z.x * cf, oy = z.y * cf;
+                if (fo) {
+                    // + i E(n) * (second transform): (x + i y) i e = (-y e, x e)
+                    const OCp<float> z2 = grid2[own_pad(own_rev(np & (G - 1), G, logg))];
+                    const T e = (T)Q.e1[pc.start + n] * cf;
+                    ox -= (T)z2.y * e;
+                    oy += (T)z2.x * e;
+                }
+                reinterpret_cast<Cp<T> *>(TKrow)[pc.start + n] = Cp<T>{ox, oy};
             }
         }
         __syncthreads();

@@ -318,11 +318,7 @@ __global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
                 float2 chain = make_float2(0.f, 0.f);                           // 2^8 e^{i phase}
                 bool chain_valid = false;                                       // uniform
                 // (a wave all of whose 64 frequencies are out skips the walk: their chunks are skipped below too)
-#ifdef PR_ABL_NOSETUP
-                for (int rl = 0; rl < (bal != 0ull && j == 0 && m == 0 ? nruns : 0); ++rl) {       // timing only: one walk
-#else
                 for (int rl = 0; rl < (bal != 0ull ? nruns : 0); ++rl) {       // uniform
-#endif
                     const PrRun *R = sruns + rl;
                     const double v = R->v;
                     const int len = R->len, kind = R->kind, slot = R->slot;
@@ -386,11 +382,7 @@ __global__ __launch_bounds__(256, 2) void ps_runs_kernel(PrParams Q)
             // ---- (2) the products, chunk by chunk: per chunk the step factors of every wavenumber go through the wave's tile
             // into registers, then block after block the state rows (8 per lane: rotate, split into float16 hi / lo) and
             // 6 MFMAs per wavenumber
-#ifdef PR_ABL_NOITEMS
-            if (my_run >= 0 && j == 0 && m == 0) {                              // timing only
-#else
             if (my_run >= 0) {                                                  // uniform over the wave
-#endif
 #pragma unroll 1
                 for (int c2 = 0; c2 < 8; ++c2) {
                     if (!alive[c2]) continue;                                   // uniform over the workgroup

@@ -239,19 +239,9 @@ __device__ __forceinline__ void sr_gather(const SrFq<T> *__restrict__ fq, const 
     }
 }
 
-#ifdef SR_STAMPS
-__device__ unsigned long long sr_stamps[16];
-#define SR_STAMP(i) do { if (tid == 0) { const unsigned long long now_ = clock64(); atomicAdd(&sr_stamps[i], now_ - t_last); t_last = now_; } } while (0)
-#else
-#define SR_STAMP(i)
-#endif
-
 template <typename T>
 __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
 {
-#ifdef SR_STAMPS
-    unsigned long long t_last = clock64();
-#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char sr_lds[];
     const PsParams &P = Q.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -327,7 +317,6 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
             }
             regm |= reg ? 1u << j : 0u;
         }
-        SR_STAMP(0);
         // ---- direct list: ranks in index order (j major, thread minor)
         int rank[PER];
 #pragma unroll
@@ -352,7 +341,6 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
 #pragma unroll
             for (int j = 0; j < PER; ++j) rank[j] += before[j];
         }
-        SR_STAMP(1);
         // ---- direct sums.  Passes of up to SR_DMAX listed frequencies in groups of 64: a wave takes (group, chunk of SR_DCH steps)
         // -- lanes = frequencies, the steps of a round shared out over the waves.  Pass 1: the chunk's phase increments (kept in
         // registers), their sum and the first dead step; pass 2, after the chunks' sums are exchanged through LDS: the phases, a
@@ -488,7 +476,6 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
                 __syncthreads();
             }
         }
-        SR_STAMP(2);
         // ---- regular frequencies: coefficient at the middle of the piece, grid place, z = psi_min / psi; the phase at the end
         const double ug = (double)G * 0.15915494309189535;                    // G / 2 pi
         for (int m = tid; m < J * gstride; m += NTH) grids[m] = OCp<T>{(T)0, (T)0};
@@ -564,7 +551,6 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
                 zz[own_pad(il)] = z;
             }
             __syncthreads();
-            SR_STAMP(3);
             {
                 // gather: indices from the dispersion relation, u = (G dt / 2 pi) sqrt(w^2 - cbar^2), w = (i + 1) dw
                 const float c2 = (float)cb2;
@@ -583,10 +569,8 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
             }
         }
         __syncthreads();
-        SR_STAMP(4);
         if (G <= SR_TWLDS) sr_fft_passes<T>(grids, J, gstride, G, logg, tid, twl, SR_TWLDS / G);
         else sr_fft_passes<T>(grids, J, gstride, G, logg, tid, reinterpret_cast<const OCp<T> *>(Q.tw[logg]), 1);
-        SR_STAMP(5);
         {
             const T *corr = reinterpret_cast<const T *>(Q.corr) + Q.corr_off[loglp];
 #pragma unroll 1
@@ -647,7 +631,6 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
             }
         }
         __syncthreads();
-        SR_STAMP(6);
     }
 }
 

@@ -44,11 +44,17 @@ constexpr int SR_MMAJ = 12;          // sums E_m the majorant looks at
 struct SrModel {                     // lane-ns
     double fix, cls, set, win, perj, dir, out, fft, tol;
     int W;
+    double dir_measured;             // a direct pair as measured (the walk is steered by `dir`: pieces chosen with the measured figure ran slower)
 };
 static inline SrModel sr_model(bool dbl)
 {
-    return dbl ? SrModel{3.0e6, 30., 220., 80., 7.5, 300., 120., 6., 1e-11, 14} : SrModel{3.0e6, 20., 110., 20., 4., 150., 60., 3., 1e-5, 8};
+    return dbl ? SrModel{3.0e6, 30., 220., 80., 7.5, 300., 120., 6., 1e-11, 14, 300.} : SrModel{3.0e6, 20., 110., 20., 4., 150., 60., 3., 1e-5, 8, 400.};
 }
+
+// Measured at 8192 x 8192 on one MI355X (profiles/r06_series.txt): the kernel takes ~2.0e-7 (float32) / ~3.5e-7 (float64) ms per unit
+// of the model and 8192 wavenumbers; the per-step kernels 5.3e-6 (float32) / 10.8e-6 (float64) ms per alive pair.  The library takes this path
+// where the estimate says it wins by a margin (phaseshift.hip).
+constexpr double SR_MS_PER_MODEL_F32 = 2.2e-7, SR_MS_PER_MODEL_F64 = 3.5e-7, SR_MS_PER_PAIR_F32 = 5.3e-6, SR_MS_PER_PAIR_F64 = 10.8e-6;
 
 static inline double sr_b(int m)     // sqrt(1 - x) = 1 - sum_m b_m x^m
 {
@@ -168,6 +174,8 @@ struct SrHostPlan {
     std::vector<double> ev;          // per-step tables (float64; converted for float32 data at upload)
     double kxh_max = 0;
     int grid_bytes = 0;
+    double model_cost = 0;           // the walk's modelled cost of the whole profile (lane-ns per wavenumber, mean of the two judged)
+    double alive_pairs = 0;          // (frequency, step) pairs that are alive, mean of the same two wavenumbers: what a per-step kernel walks
     // what it was made from
     std::vector<double> v;
     double dt = 0, dw = 0;
@@ -188,6 +196,8 @@ static bool sr_make_plan(SrHostPlan &hp, const double *v, int snum, double dt, d
     hp.ev.clear();
     hp.kxh_max = kxh_max;
     hp.grid_bytes = 0;
+    hp.model_cost = 0;
+    hp.alive_pairs = 0;
     hp.v.assign(v, v + snum);
     hp.dt = dt;
     hp.dw = dw;
@@ -201,7 +211,7 @@ static bool sr_make_plan(SrHostPlan &hp, const double *v, int snum, double dt, d
     int a = 0;
     while (a < snum) {
         int bestL = 0, bestJ = 0;
-        double best = 1e300;
+        double best = 1e300, best_est = 0.0;
         // candidate lengths: powers of two, the rest of the record, and the end of the run of constant velocity we stand in
         int cand[16], nc = 0;
         for (int L = 32; L <= 2048 && nc < 12; L *= 2) cand[nc++] = std::min(L, snum - a);
@@ -224,25 +234,30 @@ static bool sr_make_plan(SrHostPlan &hp, const double *v, int snum, double dt, d
                 const int J = ji < 0 ? 1 : JS[ji];
                 if ((J == 1) != (st.s == 0.0)) continue;
                 if (!sr_fits(1 << l, J, csize, grid_budget)) continue;
-                double cost = 0.0;
+                double cost = 0.0, cost_est = 0.0;
                 for (double kxh : kreps) {
                     const double lam = sr_cut(st, dt, kxh, J, M.tol, ji < 0 ? 1.0 : xj[ji], 0, SR_RHO);
                     const double cb2 = kxh * kxh * st.vb2, pm2 = kxh * kxh * lam * lam;
-                    const double w_alive = kxh * vmax_prev, w_cut = std::sqrt(cb2 + pm2);
+                    // (alive: above every velocity so far AND the piece's first -- what fails there is dead on arrival, at no cost)
+                    const double w_alive = kxh * std::max(vmax_prev, std::fabs(v[a])), w_cut = std::sqrt(cb2 + pm2);
                     const double i_alive = std::min(std::max(w_alive / dw, 0.0), (double)nf), i_cut = std::min(std::max(w_cut / dw, i_alive), (double)nf);
                     const double n_dir = i_cut - i_alive + 1.0, n_reg = (double)nf - i_cut;
-                    cost += M.fix + nf * M.cls + n_reg * (M.set + M.W * (M.win + M.perj * J)) + n_dir * L * M.dir + L * (M.out + 0.5 * J * J) +
-                            (double)J * G * (l + 1) * M.fft;
+                    const double rest = M.fix + nf * M.cls + n_reg * (M.set + M.W * (M.win + M.perj * J)) + L * (M.out + 0.5 * J * J) +
+                                        (double)J * G * (l + 1) * M.fft;
+                    cost += rest + n_dir * L * M.dir;
+                    cost_est += rest + n_dir * L * M.dir_measured;
                 }
                 const double per_step = cost / L;
                 if (per_step < best) {
                     best = per_step;
+                    best_est = cost_est;
                     bestL = L;
                     bestJ = J;
                 }
             }
         }
         if (!bestL) return false;                      // (nothing fits: not ours)
+        hp.model_cost += 0.5 * best_est;
         SrPiece pc{};
         pc.start = a;
         pc.len = bestL;
@@ -276,7 +291,10 @@ static bool sr_make_plan(SrHostPlan &hp, const double *v, int snum, double dt, d
         }
         hp.grid_bytes = std::max(hp.grid_bytes, (int)((size_t)bestJ * (sr_pad(2 << l) + 1) * csize));
         hp.pieces.push_back(pc);
-        for (int t = a; t < a + bestL; ++t) vmax_prev = std::max(vmax_prev, std::fabs(v[t]));
+        for (int t = a; t < a + bestL; ++t) {
+            vmax_prev = std::max(vmax_prev, std::fabs(v[t]));
+            for (double kxh : kreps) hp.alive_pairs += 0.5 * std::max((double)nf - kxh * vmax_prev / dw, 0.0);
+        }
         a += bestL;
     }
     return true;
@@ -303,6 +321,8 @@ extern "C" int impdar_sr_plan_probe(const double *v, int snum, double dt, double
         ev_offs[i] = p.ev_off;
     }
     for (size_t i = 0; i < hp.ev.size(); ++i) ev[i] = hp.ev[i];
+    dbls[1] = dbls[1];
+    if (max_pieces > 0 && ev_cap > 0) ev[hp.ev.size() < (size_t)ev_cap ? hp.ev.size() : (size_t)ev_cap - 1] = hp.model_cost;   // (one past the tables)
     return (int)hp.pieces.size();
 }
 #endif

@@ -55,7 +55,7 @@ def check():
             want = oracle_ps(data.astype(np.float64), geo, vm)
             row = {}
             for dt in (np.float32, np.float64):
-                for mode in ('7', '0'):
+                for mode in ('7', '1', '0'):
                     os.environ['IMPDAR_PS_MFMA'] = mode
                     x = np.ascontiguousarray(data.astype(dt))
                     out = np.empty((snum, tnum), dtype=dt)
@@ -88,7 +88,7 @@ def timeit(n, names=None, dts=None):
             d_in = _hip.DeviceArray.from_host(ctx, x)
             d_out = _hip.DeviceArray(ctx, (n, n), dt)
             res = {}
-            for mode in ('7', '1'):
+            for mode in ('7', '1', '0'):
                 os.environ['IMPDAR_PS_MFMA'] = mode
                 ms, kms = [], []
                 for i in range(3):
@@ -99,7 +99,7 @@ def timeit(n, names=None, dts=None):
                 res[mode] = dict(kernel=metrics().get('kernel'), device_ms=ms, kernel_ms=kms)
                 if mode == '7':
                     o7 = d_out.to_host().astype(np.float64)
-                else:
+                elif mode == '1':
                     o1 = d_out.to_host().astype(np.float64)
             res['7 vs 1 rel L2'] = '%.2e' % rel(o7, o1)[0]
             print(n, name, np.dtype(dt).name, json.dumps(res), flush=True)

@@ -33,6 +33,7 @@ def plan(lib, v, dt, dw, nf, kxh_max, dbl):
     n = lib.impdar_sr_plan_probe(v.ctypes.data_as(dp), len(v), C.c_double(dt), C.c_double(dw), nf, C.c_double(kxh_max), int(dbl), cap,
                                  ints.ctypes.data_as(ip), dbls.ctypes.data_as(dp), ev.ctypes.data_as(dp), evcap, offs.ctypes.data_as(ip))
     assert n > 0, n
+    plan.model_cost = float(ev[int(offs[n - 1]) + int(ints[n - 1, 1]) * int(ints[n - 1, 5])])
     out = []
     for i in range(n):
         start, ln, loglp, J, mser, mj = (int(x) for x in ints[i])

@@ -6,29 +6,30 @@ the kernel itself is held to the oracle by the GPU tests."""
 import numpy as np
 import pytest
 
-W, SIGMA = 8, 2
-BETA = 2.30 * W
+SIGMA = 2
 
 
-def window(x, dtype):
+def window(x, dtype, W=8):
     z = (1 - (2 * x / W) ** 2).astype(dtype)
-    return np.where(z > 0, np.exp((BETA * (np.sqrt(np.maximum(z, 0)) - 1)).astype(dtype)), 0).astype(dtype)
+    return np.where(z > 0, np.exp((2.30 * W * (np.sqrt(np.maximum(z, 0)) - 1)).astype(dtype)), 0).astype(dtype)
 
 
-def correction(lp):
+def correction(lp, W=8):
     """1 / psihat(n), n = -Lp/2 .. Lp/2 - 1: Simpson in float64, as the library's host side"""
     g, ns = SIGMA * lp, 512
     x = np.linspace(-W / 2, W / 2, ns + 1)
     wq = np.ones(ns + 1)
     wq[1:-1:2], wq[2:-1:2] = 4, 2
-    psi = np.exp(BETA * (np.sqrt(np.maximum(1 - (2 * x / W) ** 2, 0)) - 1)) * wq
+    psi = np.exp(2.30 * W * (np.sqrt(np.maximum(1 - (2 * x / W) ** 2, 0)) - 1)) * wq
     n = np.arange(-lp // 2, lp // 2)
     return 1.0 / ((psi[None, :] * np.cos(2 * np.pi * np.outer(n, x) / g)).sum(1) * (W / ns) / 3)
 
 
+@pytest.mark.parametrize('W,dtype,cdtype,bar', [(8, np.float32, np.complex64, 1.5e-6), (14, np.float64, np.complex128, 5e-12)])
 @pytest.mark.parametrize('k', [0, 37, 700])
 @pytest.mark.parametrize('lp', [64, 512])
-def test_frequency_sum_of_a_run_as_a_nonuniform_fft(k, lp):
+def test_frequency_sum_of_a_run_as_a_nonuniform_fft(k, lp, W, dtype, cdtype, bar):
+    """W = 8 in float32 arithmetic (float32 data) and W = 14 in float64 (float64 data: ps_nufft_kernel<double>, PnCfg<double>)"""
     rng = np.random.default_rng(k + lp)
     nt, dt, v, tnum, piece = 2048, 1e-8, 1.69e8, 2048, 3
     ws = 2 * np.pi * np.fft.fftfreq(nt, d=dt)
@@ -41,15 +42,15 @@ def test_frequency_sum_of_a_run_as_a_nonuniform_fft(k, lp):
     n = np.arange(lp)
     want = (coef[None, :] * np.exp(1j * np.outer(piece * lp + n + 1, phi))).sum(1)      # the direct sum, float64
     g = SIGMA * lp
-    d = (coef * np.exp(1j * phi * (piece * lp + 1 + lp / 2))).astype(np.complex64)      # coefficients at the middle of the piece
+    d = (coef * np.exp(1j * phi * (piece * lp + 1 + lp / 2))).astype(cdtype)            # coefficients at the middle of the piece
     u = phi * g / (2 * np.pi)
     m0 = np.floor(u).astype(int)
-    fr = (u - m0).astype(np.float32)
-    grid = np.zeros(g, dtype=np.complex64)
+    fr = (u - m0).astype(dtype)
+    grid = np.zeros(g, dtype=cdtype)
     for dm in range(-W // 2 + 1, W // 2 + 1):                          # spreading (the kernel gathers; the sums are the same)
-        np.add.at(grid, (m0 + dm) % g, (d * window(fr - np.float32(dm), np.float32)).astype(np.complex64))
-    ghat = (np.fft.ifft(grid) * g).astype(np.complex64)
+        np.add.at(grid, (m0 + dm) % g, (d * window(fr - dtype(dm), dtype, W)).astype(cdtype))
+    ghat = (np.fft.ifft(grid) * g).astype(cdtype)
     npr = np.arange(-lp // 2, lp // 2)
-    got = ghat[npr % g] * correction(lp)
+    got = ghat[npr % g] * correction(lp, W)
     err = np.linalg.norm(got - want) / np.linalg.norm(want)
-    assert err < 1.5e-6, err
+    assert err < bar, err

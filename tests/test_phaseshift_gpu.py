@@ -183,16 +183,35 @@ def _config5_profile(name, n, geo):
         return np.ascontiguousarray(1.69e8 + 0.5e8 * u)
     if name == 'wavy':
         return np.ascontiguousarray(1.8e8 + 0.15e8 * np.sin(7. * u) + 0.1e8 * u)
-    assert name == 'layers41'
+    if name == 'falling':
+        return np.ascontiguousarray(2.2e8 - 0.5e8 * u)
+    if name == 'firn':                           # fast near the surface, flat below: what a firn column looks like
+        return np.ascontiguousarray(1.69e8 + 0.6e8 * np.exp(-np.arange(n) * geo['dt'] / 0.8e-6))
     Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
-    tab = np.stack([np.linspace(1.69e8, 2.2e8, 41), np.linspace(0., 2.0 * Rp, 41)], axis=1)
+    if name == 'vz4':                            # BASELINE config 5's table
+        tab = np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rp], [1.8e8, 0.5 * Rp], [1.9e8, 1.2 * Rp]])
+    else:
+        assert name == 'layers41'
+        tab = np.stack([np.linspace(1.69e8, 2.2e8, 41), np.linspace(0., 2.0 * Rp, 41)], axis=1)
     return np.ascontiguousarray(mig_oracle.get_velocity_profile(geo['travel_time'], tab))
 
 
+# what runs by itself at 8192 x 8192 (the library's estimate decides between the series path and the per-step / runs kernels:
+# phaseshift.hip, ps_series_plan.h)
+_CONFIG5_KERNEL = {('gradient', 'float32'): 'ps_smooth32_kernel', ('gradient', 'float64'): 'ps_smooth_kernel',
+                   ('wavy', 'float32'): 'ps_smooth32_kernel', ('wavy', 'float64'): 'ps_smooth_kernel',
+                   ('falling', 'float32'): 'ps_series_kernel', ('falling', 'float64'): 'ps_smooth_kernel',
+                   ('firn', 'float32'): 'ps_series_kernel', ('firn', 'float64'): 'ps_series_kernel',
+                   ('vz4', 'float64'): 'ps_nufft_kernel', ('const', 'float64'): 'ps_nufft_kernel',
+                   ('layers41', 'float32'): 'ps_runs_kernel'}
+
+
 @pytest.mark.parametrize('dtype', [np.float32, np.float64])
-@pytest.mark.parametrize('profile', ['gradient', 'wavy', 'layers41'])
+@pytest.mark.parametrize('profile', ['gradient', 'wavy', 'layers41', 'falling', 'firn', 'vz4', 'const'])
 def test_config5_size_spot_wavenumbers_per_step_profiles_and_many_layers(hip, profile, dtype):
-    """The kernels of round 4 at the size they are quoted at (8192 x 8192): ps_smooth32_kernel / ps_smooth_kernel carry
+    """Round 6: the series path (ps_series_kernel: a falling gradient, a firn column) and the float64 transform path with its
+    first-order term (config 5's table; a constant velocity) at the size they are quoted at, asserting WHICH kernel ran.
+    The kernels of round 4 at the size they are quoted at (8192 x 8192): ps_smooth32_kernel / ps_smooth_kernel carry
     sqrt(coss) and the rotation by Newton / series updates between float64 anchors and expand about one velocity per 32
     steps -- a scheme whose error could grow with the number of steps -- and a 41-row table (40 layers of ~200 steps)
     is what the many-run paths get.  Spot wavenumbers (zero, low, two that hold a frequency on the evanescent boundary of
@@ -204,11 +223,13 @@ def test_config5_size_spot_wavenumbers_per_step_profiles_and_many_layers(hip, pr
     lib, ctx = _hip.load(), _hip.context()
     n = 8192
     geo = synth.geometry(n, n)
-    vm = _config5_profile(profile, n, geo)
+    if profile in ('vz4', 'const') and dtype == np.float32:
+        pytest.skip('test_config5_size_spot_wavenumbers_and_linearity holds the float32 table and constant velocity')
+    vm = _config5_profile(profile, n, geo) if profile != 'const' else None
     x = np.random.default_rng(2).standard_normal((n, n)).astype(np.float32)
     if profile not in _spot_cache:
         _spot_cache.clear()                      # (one 8192 x 8 complex array at a time is plenty)
-        _spot_cache[profile] = _spot_oracle(n, geo, x.astype(np.float64), vm)
+        _spot_cache[profile] = _spot_oracle(n, geo, x.astype(np.float64), vm if vm is not None else 1.69e8)
     want = _spot_cache[profile]
     data = x.astype(dtype)
     del x
@@ -219,15 +240,15 @@ def test_config5_size_spot_wavenumbers_per_step_profiles_and_many_layers(hip, pr
     dp = C.POINTER(C.c_double)
     _hip.check(lib.impdar_phaseshift(ctx, data.ctypes.data_as(C.c_void_p), _hip.dtype_code(dtype), n, n, n,
                                      kx.ctypes.data_as(dp), ws.ctypes.data_as(dp), C.c_double(geo['dt']),
-                                     tt.ctypes.data_as(dp), C.c_double(0.0), vm.ctypes.data_as(dp), n, C.c_double(100.),
+                                     tt.ctypes.data_as(dp), C.c_double(1.69e8 if vm is None else 0.0),
+                                     vm.ctypes.data_as(dp) if vm is not None else None, n if vm is not None else 0, C.c_double(100.),
                                      C.c_double(1000.), out.ctypes.data_as(C.c_void_p)), 'impdar_phaseshift')
     buf = C.create_string_buffer(1024)
     _hip.check(lib.impdar_ctx_last_metrics(ctx, buf, len(buf)), 'metrics')
     kernel = json.loads(buf.value.decode())['kernel']
-    if profile != 'layers41':
-        assert kernel == ('ps_smooth32_kernel' if dtype == np.float32 else 'ps_smooth_kernel'), kernel
-    elif dtype == np.float32:
-        assert kernel == 'ps_runs_kernel', kernel
+    want_kernel = _CONFIG5_KERNEL.get((profile, np.dtype(dtype).name))
+    if want_kernel:
+        assert kernel == want_kernel, kernel
     del data
     assert np.isfinite(out).all()
     got = np.fft.fft(out.astype(np.float64), axis=1)[:, _SPOT_KS]
@@ -300,10 +321,9 @@ def test_matrix_core_path_against_the_vector_kernels_and_the_oracle(hip, monkeyp
     import json
     from impdar_amd import _hip
     outs, kernels = {}, {}
-    # '5': ps_pair_kernel (the wavenumbers kx and -kx in one workgroup, state tiles made once for both -- an odd and two even
-    # trace counts: k = 0 and the Nyquist row are their own partners; not the default: it is no faster); '2': ps_mfma_kernel
-    # '6': ps_nufft_kernel -- the frequency sum of a run as a non-uniform FFT (what a call runs by itself on such tables)
-    for mfma, herm in (('5', '1'), ('2', '1'), ('0', '1'), ('5', '0'), ('2', '0'), ('6', '1'), ('1', '1')):
+    # '2': ps_mfma_kernel; '6': ps_nufft_kernel -- the frequency sum of a run as a non-uniform FFT (what a call runs by itself on
+    # such tables); '7': ps_series_kernel (round 6; constant velocity: not its call)
+    for mfma, herm in (('2', '1'), ('0', '1'), ('2', '0'), ('6', '1'), ('1', '1'), ('7', '1')):
         monkeypatch.setenv('IMPDAR_PS_MFMA', mfma)
         monkeypatch.setenv('IMPDAR_PS_HERMITIAN', herm)
         d = RadarData(None)
@@ -315,17 +335,16 @@ def test_matrix_core_path_against_the_vector_kernels_and_the_oracle(hip, monkeyp
         buf = C.create_string_buffer(1024)
         _hip.check(_hip.load().impdar_ctx_last_metrics(_hip.context(), buf, len(buf)), 'metrics')
         kernels[mfma, herm] = json.loads(buf.value.decode())['kernel']
-    print('%s %dx%d: rel L2 vs oracle: pairs %.2e, one wavenumber per workgroup %.2e, vector kernels %.2e, on the full walk %.2e / %.2e'
-          % (kind, snum, tnum, rel_l2(outs['5', '1'], want), rel_l2(outs['2', '1'], want), rel_l2(outs['0', '1'], want),
-             rel_l2(outs['5', '0'], want), rel_l2(outs['2', '0'], want)))
-    for herm in ('1', '0'):      # (short records with layers: rows mostly padding, both decline)
-        assert (kernels['5', herm], kernels['2', herm]) in (('ps_pair_kernel', 'ps_mfma_kernel'), (kernels['0', '1'], kernels['0', '1'])), kernels
-    if kind == 'const':
-        assert kernels['5', '1'] == 'ps_pair_kernel', kernels
-    assert 'mfma' not in kernels['0', '1'] and 'pair' not in kernels['0', '1'], kernels
+    print('%s %dx%d: rel L2 vs oracle: ps_mfma_kernel %.2e, vector kernels %.2e, on the full walk %.2e, ps_nufft_kernel %.2e, mode 7 (%s) %.2e'
+          % (kind, snum, tnum, rel_l2(outs['2', '1'], want), rel_l2(outs['0', '1'], want), rel_l2(outs['2', '0'], want),
+             rel_l2(outs['6', '1'], want), kernels['7', '1'], rel_l2(outs['7', '1'], want)))
+    for herm in ('1', '0'):      # (short records with layers: rows mostly padding, it declines)
+        assert kernels['2', herm] in ('ps_mfma_kernel', kernels['0', '1']), kernels
+    assert 'mfma' not in kernels['0', '1'], kernels
     assert kernels['6', '1'] == kernels['1', '1'] == 'ps_nufft_kernel', kernels
+    assert kernels['7', '1'] == ('ps_series_kernel' if kind != 'const' else kernels['0', '1']), kernels
     assert np.array_equal(outs['6', '1'], outs['1', '1'])
-    for m in ('5', '2', '6'):
+    for m in ('2', '6', '7'):
         assert rel_l2(outs[m, '1'], outs['0', '1']) < F32_L2
         # the matrix-core result must not be worse than a few times the vector kernels' own float32 error
         assert rel_l2(outs[m, '1'], want) < max(5.0 * rel_l2(outs['0', '1'], want), 2e-6), (m, rel_l2(outs[m, '1'], want))
@@ -392,7 +411,7 @@ def test_many_runs_matrix_core_path_against_the_vector_kernels_and_the_oracle(hi
     _hip.check(_hip.load().impdar_ctx_last_metrics(_hip.context(), buf, len(buf)), 'metrics')
     chosen = json.loads(buf.value.decode())['kernel']
     # (up to 16 long runs: ps_mfma_kernel where its 2048-step row blocks are not mostly padding, i.e. on long records)
-    assert chosen in ('ps_runs_kernel', 'ps_mfma_kernel', 'ps_pair_kernel', 'ps_nufft_kernel'), (kind, chosen)
+    assert chosen in ('ps_runs_kernel', 'ps_mfma_kernel', 'ps_nufft_kernel', 'ps_series_kernel'), (kind, chosen)
     assert chosen == 'ps_runs_kernel' or kind not in ('layers40',), (kind, chosen)
     if chosen == 'ps_runs_kernel':      # (the same sums; the transforms around them may be the library's own or rocFFT's by now)
         assert rel_l2(d.data, outs['3', '1']) < 5e-6
@@ -776,3 +795,88 @@ def test_tk_is_taper_only(hip):
     data = NoInitRadarData(big=True)
     data = migrationlib.migrationTimeWavenumber(data)
     assert not data.data.any()
+
+
+def _per_step_oracle(data64, geo, vm, htaper=20, vtaper=30):
+    """migrationPhaseShift's steps (mig_python.py:253-282) with the per-step velocities given (what getVelocityProfile returns)"""
+    from oracle import mig_oracle
+    snum, tnum = data64.shape
+    tap = mig_oracle._apply_taper(data64, htaper, vtaper, inplace_form=True)
+    nt = 2 ** int(np.ceil(np.log2(snum)))
+    kx = mig_oracle._kx(tnum, geo['trace_int'], geo['dist'])
+    ws = 2. * np.pi * np.fft.fftfreq(nt, d=geo['dt'])
+    FK = np.fft.fft2(tap, s=(nt, tnum))
+    TK = mig_oracle.phase_shift_tk(FK, vm, kx, ws, geo['dt'], geo['travel_time'], snum, tnum)
+    return np.fft.ifft(TK).real, nt, kx, ws
+
+
+def _run_per_step(hip, data, geo, vm, nt, kx, ws, htaper=20., vtaper=30.):
+    import ctypes as C
+    import json
+    from impdar_amd import _hip
+    lib, ctx = _hip.load(), _hip.context()
+    snum, tnum = data.shape
+    out = np.empty((snum, tnum), dtype=data.dtype)
+    tt = np.ascontiguousarray(geo['travel_time'], dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    _hip.check(lib.impdar_phaseshift(ctx, data.ctypes.data_as(C.c_void_p), _hip.dtype_code(data.dtype), snum, tnum, nt,
+                                     kx.ctypes.data_as(dp), ws.ctypes.data_as(dp), C.c_double(geo['dt']), tt.ctypes.data_as(dp),
+                                     C.c_double(0.0), vm.ctypes.data_as(dp), snum, C.c_double(htaper), C.c_double(vtaper),
+                                     out.ctypes.data_as(C.c_void_p)), 'impdar_phaseshift')
+    buf = C.create_string_buffer(1024)
+    _hip.check(lib.impdar_ctx_last_metrics(ctx, buf, len(buf)), 'metrics')
+    return out, json.loads(buf.value.decode())['kernel']
+
+
+def _small_profiles(snum, geo):
+    from oracle import mig_oracle
+    u = np.linspace(0., 1., snum)
+    Rp = 1.9e8 * geo['travel_time'][-1] * 1e-6 / 2.
+    tab4 = np.array([[1.69e8, 0.], [1.69e8, 0.2 * Rp], [1.8e8, 0.5 * Rp], [1.9e8, 1.2 * Rp]])
+    tab41 = np.stack([np.linspace(1.69e8, 2.2e8, 41), np.linspace(0., 2.0 * Rp, 41)], axis=1)
+    return {'gradient': np.ascontiguousarray(1.69e8 + 0.5e8 * u), 'falling': np.ascontiguousarray(2.2e8 - 0.5e8 * u),
+            'wavy': np.ascontiguousarray(1.8e8 + 0.15e8 * np.sin(7. * u) + 0.1e8 * u),
+            'firn': np.ascontiguousarray(1.69e8 + 0.6e8 * np.exp(-np.arange(snum) * geo['dt'] / 0.8e-6)),
+            'jumps': np.ascontiguousarray(1.69e8 + 0.3e8 * u + 0.05e8 * (u > 0.3) + 0.08e8 * (u > 0.7)),
+            'vz4': np.ascontiguousarray(mig_oracle.get_velocity_profile(geo['travel_time'], tab4)),
+            'layers41': np.ascontiguousarray(mig_oracle.get_velocity_profile(geo['travel_time'], tab41))}
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('snum,tnum', [(300, 64), (520, 40), (1100, 24), (2100, 16), (4200, 8)])
+def test_series_path_against_the_oracle(hip, snum, tnum, dtype, monkeypatch):
+    """ps_series_kernel (round 6: a velocity that changes inside a piece -- J non-uniform FFTs with shared nodes, direct sums in
+    the band above the evanescent boundary) forced onto seven kinds of profile, against the oracle's literal per-step loop
+    (mig_python.py:438-487): rising / falling gradients (frequencies dying step by step / none), a wavy profile (both), a firn
+    column, jumps inside pieces, smeared layer boundaries of thin and thick layers; record lengths that leave remainders of 8
+    and 12 steps (grids of 32 points: the window reaches around them)."""
+    from impdar_amd import synth
+    monkeypatch.setenv('IMPDAR_PS_MFMA', '7')
+    geo = synth.geometry(snum, tnum)
+    data64 = synth.noise_radargram(snum, tnum, seed=snum) + 0.5
+    for name, vm in _small_profiles(snum, geo).items():
+        want, nt, kx, ws = _per_step_oracle(data64, geo, vm)
+        got, kernel = _run_per_step(hip, np.ascontiguousarray(data64.astype(dtype)), geo, vm, nt, kx, ws)
+        assert kernel == 'ps_series_kernel', (name, kernel)
+        if dtype == np.float32:
+            assert rel_l2(got, want) < F32_L2, (name, rel_l2(got, want))
+            assert rel_l2(got, want) < 2e-6, (name, rel_l2(got, want))       # (observed 2e-7 ... 5e-7)
+        else:
+            assert rel_max(got, want) < F64_TOL, (name, rel_max(got, want))
+            assert rel_max(got, want) < 5e-12, (name, rel_max(got, want))    # (observed 6e-14 ... 3e-12)
+
+
+@pytest.mark.parametrize('snum,tnum', [(300, 64), (520, 40), (1100, 24), (2100, 16), (4200, 8)])
+def test_float64_table_on_the_transform_path_with_its_first_order_term(hip, snum, tnum):
+    """A v(z) table on float64 data: ps_nufft_kernel<double> with the runs' velocity noise (2 * gradient(z(t)): ~4e-13, cut at
+    1e-11) as the first-order term of the series, in a float32 grid of its own (ps_nufft.h) -- by itself for up to 16 thick
+    layers.  Against the oracle at the float64 bar, and against the vector kernels that carried such tables until round 5."""
+    from impdar_amd import synth
+    geo = synth.geometry(snum, tnum)
+    data = synth.noise_radargram(snum, tnum, seed=snum + 1) + 0.5
+    vm = _small_profiles(snum, geo)['vz4']
+    want, nt, kx, ws = _per_step_oracle(data, geo, vm)
+    got, kernel = _run_per_step(hip, np.ascontiguousarray(data), geo, vm, nt, kx, ws)
+    assert kernel == 'ps_nufft_kernel', kernel
+    assert rel_max(got, want) < F64_TOL, rel_max(got, want)
+    assert rel_max(got, want) < 5e-12, rel_max(got, want)
