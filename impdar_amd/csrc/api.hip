@@ -2,6 +2,9 @@
 #include "common.h"
 #include <algorithm>
 #include <thread>
+#include <unistd.h>
+#include <condition_variable>
+#include <functional>
 
 static thread_local char g_err[1024] = "";
 
@@ -240,33 +243,89 @@ void *impdar_ctx_pinned(impdar_ctx *ctx, size_t bytes)
     return p;
 }
 
-void impdar_host_copy_f64(double *dst, const void *src, size_t n, bool src_is_f32)
+// Host worker threads that live as long as the process (round 6): a parallel copy used to start and join 16 threads of its own
+// -- 0.3-0.5 ms each time, which is why download pieces below 48 MB did not pay.  The pool is created on first use and never
+// destroyed (its threads sleep on a condition variable; a static destructor that joined them would run at exit, in the order
+// the runtime tears its own threads down).  One job at a time: callers hold ctx->pinned_mu or are the only caller.
+struct ImpdarPool {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::function<void(unsigned)> job;
+    unsigned nthr = 0, generation = 0, pending = 0;
+    std::mutex user_mu;                                     // one parallel_for at a time
+    explicit ImpdarPool(unsigned n) : nthr(n)
+    {
+        for (unsigned t = 0; t < n; ++t)
+            std::thread([this, t] {
+                unsigned seen = 0;
+                for (;;) {
+                    std::function<void(unsigned)> f;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv_work.wait(lk, [&] { return generation != seen; });
+                        seen = generation;
+                        f = job;
+                    }
+                    f(t);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (--pending == 0) cv_done.notify_all();
+                    }
+                }
+            }).detach();
+    }
+    void run(const std::function<void(unsigned)> &f)
+    {
+        std::lock_guard<std::mutex> user(user_mu);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = f;
+            pending = nthr;
+            ++generation;
+        }
+        cv_work.notify_all();
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+};
+static ImpdarPool *impdar_pool()
 {
-    const unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < nthr; ++t)
-        pool.emplace_back([=] {
-            const size_t a = n * t / nthr, b = n * (t + 1) / nthr;
-            if (src_is_f32) {
-                const float *f = reinterpret_cast<const float *>(src);
-                for (size_t i = a; i < b; ++i) dst[i] = (double)f[i];
-            } else {
-                memcpy(dst + a, reinterpret_cast<const double *>(src) + a, (b - a) * sizeof(double));
-            }
-        });
-    for (auto &th : pool) th.join();
+    // (leaked on purpose; a forked child has the pointer but none of the threads: it makes its own)
+    static std::mutex mu;
+    static ImpdarPool *pool = nullptr;
+    static pid_t owner = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!pool || owner != getpid()) {
+        pool = new ImpdarPool(std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
+        owner = getpid();
+    }
+    return pool;
 }
 
-// `n` items on several host threads: fn(begin, end)
+// `n` items on the host worker threads: fn(begin, end)
 template <typename F> static void impdar_parallel_for(size_t n, size_t align, F fn)
 {
-    const unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < nthr; ++t) {
-        const size_t a = (n * t / nthr) / align * align, b = t + 1 == nthr ? n : (n * (t + 1) / nthr) / align * align;
-        if (b > a) pool.emplace_back([=] { fn(a, b); });
+    ImpdarPool *pool = impdar_pool();
+    const unsigned nthr = pool->nthr;
+    if (n * 1 <= (size_t)nthr * align) {                   // (nothing to share out)
+        fn(0, n);
+        return;
     }
-    for (auto &th : pool) th.join();
+    pool->run([&](unsigned t) {
+        const size_t a = (n * t / nthr) / align * align, b = t + 1 == nthr ? n : (n * (t + 1) / nthr) / align * align;
+        if (b > a) fn(a, b);
+    });
+}
+
+void impdar_host_copy_f64(double *dst, const void *src, size_t n, bool src_is_f32)
+{
+    if (src_is_f32) {
+        const float *f = reinterpret_cast<const float *>(src);
+        impdar_parallel_for(n, 16, [=](size_t a, size_t b) { for (size_t i = a; i < b; ++i) dst[i] = (double)f[i]; });
+    } else {
+        const double *d = reinterpret_cast<const double *>(src);
+        impdar_parallel_for(n, 16, [=](size_t a, size_t b) { memcpy(dst + a, d + a, (b - a) * sizeof(double)); });
+    }
 }
 
 // Device -> pageable host memory in pieces: every piece is DMA-ed into the pinned staging buffer and copied out
@@ -294,8 +353,8 @@ static int impdar_download_piped(impdar_ctx *ctx, void *host_dst, const void *de
         fallback.resize(bytes);
         stage = fallback.data();
     }
-    // pieces of >= 48 MB: below that the host-thread start-up of every piece costs more than the overlap gains
-    const int npiece = (int)std::min<size_t>(8, std::max<size_t>(1, bytes / (48u << 20)));
+    // pieces of >= 16 MB (48 MB until round 6, when every piece started its own host threads)
+    const int npiece = (int)std::min<size_t>(8, std::max<size_t>(1, bytes / (16u << 20)));
     hipEvent_t ev[8] = {};
     size_t lo[9];
     const size_t gran = block ? width : 16;                  // block pieces are whole rows

@@ -2329,7 +2329,6 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         }
         return IMPDAR_OK;
     };
-    if (sizeof(T) == 8 && P.sched && (rc = order_rows())) return rc;       // float64: always the vector kernels
     if ((rc = impdar_ctx_ktic(ctx))) return rc;
     impdar_trace("phaseshift: forward transforms enqueued");
     bool mfma_done = false;
@@ -2430,7 +2429,8 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             }
         }
     }
-    if (sizeof(T) == 4 && !mfma_done && P.sched && (rc = order_rows())) return rc;
+    // (made only when the runs kernels of the vector path are about to be launched: ~2 ms of host time with the GPU idle)
+    if (!mfma_done && P.sched && (rc = order_rows())) return rc;
     bool smooth_done = false;
     if (!mfma_done && vlen && !P.sched) {
         // no runs of constant velocity to live on (the velocity changes in most 16-step tiles): ps_smooth_kernel

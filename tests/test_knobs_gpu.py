@@ -213,7 +213,7 @@ def test_own_row_transforms_carry_stolt_and_phase_shift(hip, monkeypatch, snum, 
     assert rel_l2(outs['phsh', True], outs['phsh', False]) < (5e-6 if dtype == np.float32 else 1e-12)
 
 
-def test_first_call_runs_on_the_own_transforms_and_later_calls_on_rocfft(hip, monkeypatch):
+def test_every_call_runs_on_the_own_transforms_and_rocfft_on_request(hip, monkeypatch):
     """A power-of-two size: every call runs on the library's own transforms (nothing to compile, no plan); rocFFT's plans on
     request.  Same image either way (to the transforms' rounding)."""
     import ctypes as C

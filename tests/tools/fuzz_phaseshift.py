@@ -4,9 +4,14 @@ pytest suites: the oracle needs seconds per case).  Random sizes, sample / trace
 thick layers, first layers at round velocities so that boundary frequencies occur), float32 and float64 data.
 
     python tests/tools/fuzz_phaseshift.py [ncases] [seed]  ->  one line per case, summary at the end, exit code 1 on a miss
+
+IMPDAR_PS_MFMA=7 in the environment sends every v(z) case to ps_series_kernel, =6 every table to ps_nufft_kernel (round 6); the
+kernel that ran is printed with each case.
 """
 import contextlib
+import ctypes
 import io
+import json
 import os
 import sys
 import time
@@ -14,7 +19,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from impdar_amd import synth                                    # noqa: E402
+from impdar_amd import synth, _hip                              # noqa: E402
 from impdar_amd.lib.RadarData import RadarData                  # noqa: E402
 from impdar_amd.lib import migrationlib                         # noqa: E402
 from oracle import mig_oracle                                   # noqa: E402
@@ -25,6 +30,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     worst = {np.float32: 0.0, np.float64: 0.0}
     bad = 0
+    kernels = {}
     t_start = time.time()
     for case in range(ncases):
         snum = int(rng.choice([40, 97, 128, 200, 333, 512, 700, 1000, 1300, 2100]))
@@ -80,6 +86,10 @@ def main():
         d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
         with contextlib.redirect_stdout(io.StringIO()):
             migrationlib.migrationPhaseShift(d, vel=vel, htaper=ht, vtaper=vt)
+        buf = ctypes.create_string_buffer(1024)
+        _hip.load().impdar_ctx_last_metrics(_hip.context(), buf, len(buf))
+        kernel = json.loads(buf.value.decode()).get('kernel', '?')
+        kernels[kernel] = kernels.get(kernel, 0) + 1
         if dtype == np.float32:
             err = np.linalg.norm(d.data - want) / max(np.linalg.norm(want), 1e-300)
             tol = 2e-4
@@ -92,9 +102,10 @@ def main():
         print('%3d %s snum %4d tnum %3d dt %.3g dx %.3g vel %s %s err %.3g %s'
               % (case, 'f32' if dtype == np.float32 else 'f64', snum, tnum, dt, dx,
                  'const %.3g' % vel if np.isscalar(vel) else '%s%d layers from %.3g' % ('per-step ' if kind == 4 else '', len(vel), vel[0, 0]),
-                 '', err, 'ok' if ok else 'MISS'), flush=True)
+                 kernel, err, 'ok' if ok else 'MISS'), flush=True)
     print('cases %d, misses %d, worst float32 rel-L2 %.3g (bar 2e-4), worst float64 rel-max %.3g (bar 1e-10), %.0f s'
           % (ncases, bad, worst[np.float32], worst[np.float64], time.time() - t_start))
+    print('kernels: ' + ', '.join('%s %d' % kv for kv in sorted(kernels.items())))
     return 1 if bad else 0
 
 
