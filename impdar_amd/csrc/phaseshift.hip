@@ -1863,7 +1863,13 @@ static int ps_series_run(PsPlan &pl, PsParams P, const double *vmig, const doubl
     Q.rw = pl.d_rw.as<double>();
     Q.corr = pl.d_pn_corr.p;
     Q.kxh_max = kxh_max;
-    Q.grid_bytes = (hp.grid_bytes + 15) & ~15;
+    {
+        // the grids' LDS doubles as the scratch of the direct sums: the chunk sums of every wave and lane + one group's [L] partial sums
+        int lmax = 0;
+        for (const SrPiece &pc : hp.pieces) lmax = std::max(lmax, pc.len);
+        const int direct_scratch = (SrCfg<T>::NTH / 64) * 64 * 12 + lmax * (int)sizeof(OCp<T>);
+        Q.grid_bytes = (std::max(hp.grid_bytes, direct_scratch) + 15) & ~15;
+    }
     const size_t lds = sr_lds_bytes<T>(Q.grid_bytes);
     IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_series_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sr_lds_bytes<T>(SR_GRID_BYTES + 16)));
     hipLaunchKernelGGL(ps_series_kernel<T>, dim3((unsigned)P.nk), dim3(SrCfg<T>::NTH), lds, st, Q);

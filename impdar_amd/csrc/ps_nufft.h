@@ -72,6 +72,8 @@ struct PnParams {
 // LDS: the grid of the call's longest piece (gmax points), then coefficients / grid places of all frequencies, the block reduction
 template <typename T> __host__ __device__ constexpr size_t pn_lds_bytes(int gmax, bool first_order = false)
 {
+    // (coefficient, fraction and floor of the grid place: three arrays -- one 16-byte record per frequency and a ds_read_b128 per
+    // window value measured 36 % SLOWER at config 5: 2.23 against 1.64 ms at a constant velocity, same box)
     return (size_t)(own_pad(gmax) + 1) * 2 * sizeof(T) + (size_t)PN_NFMAX * (2 * sizeof(T) + sizeof(T) + 2) + 16 * 2 * PN_SHORT * sizeof(T) +
            (first_order ? (size_t)(own_pad(gmax) + 1) * 2 * sizeof(float) : 0);
 }
@@ -108,17 +110,33 @@ __device__ __forceinline__ void pn_fft_f32(OCp<float> *s, int M, int logm, int t
     }
 }
 
-__device__ __forceinline__ float pn_window(float x)      // psi(x), |x| < W/2 (0 outside)
+// psi(x) = exp(beta (sqrt(1 - (2x/W)^2) - 1)) for |x| <= W/2 and e^{-beta} (1e-8 / 1e-14 of its maximum) beyond: no select -- on
+// the select and its compare cost the gather 5 % (1.72 -> 1.64 ms at config 5's size, constant velocity); the gather's index
+// range keeps what lies beyond the support to two or three frequencies
+struct PnWinF {                                                        // the window's two constants, in vector registers
+    float c4, bl;                                                      // (a scalar-register or literal operand halves a v_fma_f32's rate)
+    __device__ __forceinline__ PnWinF()
+    {
+        constexpr int W = PnCfg<float>::W;
+        c4 = 4.0f / (W * W);
+        bl = 2.30f * W * 1.4426950408889634f;                           // beta log2(e)
+        asm volatile("" : "+v"(c4), "+v"(bl));
+    }
+};
+__device__ __forceinline__ float pn_window(float x, const PnWinF &k)
 {
-    constexpr int W = PnCfg<float>::W;
-    const float z = fmaf(-x * x, 4.0f / (W * W), 1.0f);
-    return z > 0.f ? __expf(2.30f * W * (__builtin_amdgcn_sqrtf(z) - 1.0f)) : 0.f;
+    const float z = fmaxf(fmaf(-x * x, k.c4, 1.0f), 0.f);
+    return __builtin_amdgcn_exp2f(fmaf(__builtin_amdgcn_sqrtf(z), k.bl, -k.bl));
 }
+__device__ __forceinline__ float pn_window(float x) { return pn_window(x, PnWinF()); }
+__device__ __forceinline__ float pn_winT(float x, const PnWinF &k) { return pn_window(x, k); }
+__device__ __forceinline__ double pn_window(double x);
+__device__ __forceinline__ double pn_winT(double x, const PnWinF &) { return pn_window(x); }
 __device__ __forceinline__ double pn_window(double x)
 {
     constexpr int W = PnCfg<double>::W;
-    const double z = fma(-x * x, 4.0 / (W * W), 1.0);
-    return z > 0.0 ? exp(2.30 * W * (sqrt(z) - 1.0)) : 0.0;
+    const double z = fmax(fma(-x * x, 4.0 / (W * W), 1.0), 0.0);
+    return exp(2.30 * W * (sqrt(z) - 1.0));
 }
 __device__ __forceinline__ void pn_sincos(double x, float *s, float *c) { pm_sincos(x, s, c); }
 __device__ __forceinline__ void pn_sincos(double x, double *s, double *c) { pss_sincos_small(pm_wrap(x), s, c); }
@@ -134,7 +152,7 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
     // small |kx| (few evanescent frequencies: the long workgroups) first
     const int bq = (int)blockIdx.x, kb = (bq & 1) ? P.nk - 1 - (bq >> 1) : (bq >> 1), k = P.k0 + kb;
     OCp<T> *grid = reinterpret_cast<OCp<T> *>(pn_lds);                          // [own_pad(G)]
-    OCp<T> *D = grid + own_pad(Q.gmax) + 1;                                         // [nf] coefficients, by index
+    OCp<T> *D = grid + own_pad(Q.gmax) + 1;                                         // [nf] coefficients, by index (float64)
     T *fr = reinterpret_cast<T *>(D + PN_NFMAX);                                        // [nf] u - floor(u)
     unsigned short *m0 = reinterpret_cast<unsigned short *>(fr + PN_NFMAX);             // [nf] floor(u)
     T *red = reinterpret_cast<T *>(m0 + PN_NFMAX);                                      // [waves][2 PN_SHORT] block reduction
@@ -307,6 +325,7 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
             // the Nyquist row (index nf - 1): anywhere on the grid, looked at by every grid point
             const T uN = (T)m0[nf - 1] + fr[nf - 1];
             const OCp<T> dN = D[nf - 1];
+            const PnWinF wk_;
             for (int m = tid; m < G; m += PN_NTH) {
                 const float mm = (float)(m > G / 2 + PN_W / 2 ? m - G : m);  // centred: the regular frequencies sit in [0, G/2], reach W/2 to either side (G >= 32 > 2 W)
                 T gx = 0, gy = 0;
@@ -319,7 +338,7 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
                     ihi = min(ihi, ilast);
                     for (int i = ilo; i <= ihi; ++i) {
                         const T x = (T)((int)m0[i] - (int)mm) + fr[i];
-                        const T wgt = pn_window(x);
+                        const T wgt = pn_winT(x, wk_);
                         const OCp<T> d = D[i];
                         gx = fma(d.x, wgt, gx);
                         gy = fma(d.y, wgt, gy);

@@ -74,13 +74,10 @@ template <typename T> __host__ __device__ constexpr size_t sr_lds_bytes(int grid
            (size_t)SR_DMAX * sizeof(SrDirect) + 512 + SR_MSER * sizeof(double) + (size_t)SR_TWLDS * sizeof(OCp<T>);
 }
 
-__device__ __forceinline__ float sr_window(float x)       // psi(x) for |x| <= W/2; e^{-beta} = 1e-8 beyond (no select: v_cndmask is 5x a multiply)
-{
-    constexpr int W = SrCfg<float>::W;
-    const float z = fmaxf(fmaf(-x * x, 4.0f / (W * W), 1.0f), 0.f);
-    return __expf(2.30f * W * (__builtin_amdgcn_sqrtf(z) - 1.0f));
-}
-__device__ __forceinline__ double sr_window(double x)
+__device__ __forceinline__ float sr_window(float x, const PnWinF &k) { return pn_window(x, k); }     // (ps_nufft.h: no select, e^{-beta} = 1e-8 beyond the support)
+struct SrWinD {};
+__device__ __forceinline__ double sr_window(double x, const SrWinD &);
+__device__ __forceinline__ double sr_window(double x, const SrWinD &)
 {
     constexpr int W = SrCfg<double>::W;
     const double z = fmax(fma(-x * x, 4.0 / (W * W), 1.0), 0.0);
@@ -186,6 +183,7 @@ __device__ __forceinline__ void sr_gather(const SrFq<T> *__restrict__ fq, const 
     constexpr int W = SrCfg<T>::W;
     // S threads per grid point (G < 1024), q fastest: the partial sums of a grid point sit in neighbouring lanes
     constexpr int NTH = SrCfg<T>::NTH;
+    const std::conditional_t<sizeof(T) == 4, PnWinF, SrWinD> wk_;
     const int logs = G >= NTH ? 0 : __builtin_ctz(NTH / G), S = 1 << logs;
     for (int mb = 0; mb < G; mb += (NTH >> logs)) {
         const int m = mb + (tid >> logs), q = tid & (S - 1);
@@ -205,7 +203,7 @@ __device__ __forceinline__ void sr_gather(const SrFq<T> *__restrict__ fq, const 
             for (int i = i0; i < i1; ++i) {
                 const SrFq<T> f = fq[own_pad(i - ifirst)];
                 const T x = (T)(f.uh - mm) + f.fr;
-                const T wgt = sr_window(x);
+                const T wgt = sr_window(x, wk_);
                 T tx = f.dx * wgt, ty = f.dy * wgt;
                 ax[0] += tx;
                 ay[0] += ty;
@@ -353,7 +351,7 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
             double *csum = reinterpret_cast<double *>(grids);
             int *cdead = reinterpret_cast<int *>(csum + NWV * 64);
             OCp<T> *part = reinterpret_cast<OCp<T> *>(reinterpret_cast<unsigned char *>(grids) + CSB);     // [group][L]
-            const int gfit = max(1, (int)(((size_t)Q.grid_bytes - CSB) / ((size_t)L * sizeof(OCp<T>))));
+            const int gfit = max(1, (Q.grid_bytes - CSB) / (L * (int)sizeof(OCp<T>)));      // (>= 1 by the host's sizing of grid_bytes)
             const int wv_u = __builtin_amdgcn_readfirstlane(wave);
             for (int base = 0; base < ndir; base += 64 * min(min(gfit, SR_DMAX / 64), NWV)) {
                 const int gp = min(min(min(gfit, SR_DMAX / 64), NWV), (ndir - base + 63) >> 6), nd = min(ndir - base, 64 * gp);

@@ -880,3 +880,30 @@ def test_float64_table_on_the_transform_path_with_its_first_order_term(hip, snum
     assert kernel == 'ps_nufft_kernel', kernel
     assert rel_max(got, want) < F64_TOL, rel_max(got, want)
     assert rel_max(got, want) < 5e-12, rel_max(got, want)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('snum,tnum,dt,dx,nl', [(128, 16, 1e-8, 1.0, 7), (200, 64, 5e-9, 2.0, 40), (97, 256, 1.25e-8, 0.5, 70)])
+def test_series_path_on_short_records_with_wild_tables(hip, snum, tnum, dt, dx, nl, dtype, monkeypatch):
+    """Found by the round-6 fuzz (13 misses of 230 with IMPDAR_PS_MFMA=7): a short record under a table of many layers is ONE piece
+    with J = 2, its two grids (8 KB) smaller than the scratch the direct sums keep in the same LDS (12 KB of chunk sums + the
+    partial sums) -- which every frequency needs here, the velocity doubling inside the piece.  The host sizes the region for
+    both now."""
+    from impdar_amd import synth
+    from oracle import mig_oracle
+    monkeypatch.setenv('IMPDAR_PS_MFMA', '7')
+    geo = synth.geometry(snum, tnum, dt=dt, dx=dx)
+    rng = np.random.default_rng(nl)
+    vs = np.concatenate([[1.68e8], 1.68e8 + np.cumsum(rng.uniform(0.0, 0.06e8, nl - 1))])
+    Rv = vs.max() * geo['travel_time'][-1] * 1e-6 / 2.
+    zs = np.sort(np.concatenate([[0.], rng.uniform(0.05, 1.2, nl - 1)])) * Rv
+    zs[-1] = 1.3 * Rv
+    vm = np.ascontiguousarray(mig_oracle.get_velocity_profile(geo['travel_time'], np.stack([vs, zs], axis=1)))
+    data64 = synth.noise_radargram(snum, tnum, seed=nl) + 0.5
+    want, nt, kx, ws = _per_step_oracle(data64, geo, vm, 7, 9)
+    got, kernel = _run_per_step(hip, np.ascontiguousarray(data64.astype(dtype)), geo, vm, nt, kx, ws, 7., 9.)
+    assert kernel == 'ps_series_kernel', kernel
+    if dtype == np.float32:
+        assert rel_l2(got, want) < 5e-6, rel_l2(got, want)
+    else:
+        assert rel_max(got, want) < F64_TOL, rel_max(got, want)
