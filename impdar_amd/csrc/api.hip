@@ -176,11 +176,14 @@ void impdar_kirch_trim();    // kirchhoff.hip
 void impdar_stolt_trim();    // stolt.hip
 void impdar_ps_trim();       // phaseshift.hip
 
+void impdar_devcache_trim(int device);
+
 void impdar_release_caches()
 {
     impdar_kirch_trim();
     impdar_stolt_trim();
     impdar_ps_trim();
+    impdar_devcache_trim(-1);
 }
 
 static void pinned_adopt(impdar_ctx *ctx)
@@ -595,6 +598,7 @@ extern "C" void impdar_ctx_destroy(impdar_ctx *ctx)
     impdar_ps_forget(ctx);
     impdar_kirch_forget(ctx);
     impdar_preproc_forget(ctx);
+    impdar_devcache_trim(ctx->device);
     pinned_adopt(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->ev_produced) (void)hipEventDestroy(ctx->ev_produced);
@@ -617,12 +621,106 @@ extern "C" int impdar_ctx_sync(impdar_ctx *ctx)
     return IMPDAR_OK;
 }
 
+// Device arrays of the one-shot calls -- the radargram a call uploads, the image it downloads -- come from a small cache
+// (round 6): hipMalloc + hipFree of a 64 ... 268 MB array were ~1.5 ms of every call through host arrays (a third of a Stolt
+// call at 4096^2).  A freed array is kept (at most four, 2 GiB in total, per process) and handed to the next request of
+// [its size / 1.25, its size]; impdar_release_caches and impdar_ctx_destroy empty it.  Everything a cached array was used
+// for has been waited for before it went back (impdar_devcache_free synchronises the context's streams first).
+struct DevCacheEntry {
+    void *p;
+    size_t bytes;
+    int device;
+    bool free_;
+};
+static std::mutex g_devcache_mu;
+static std::vector<DevCacheEntry> g_devcache;                  // arrays handed out (free_ = false) and kept (free_ = true)
+constexpr size_t DEVCACHE_MAX_BYTES = (size_t)2 << 30;
+constexpr int DEVCACHE_MAX_KEPT = 4;
+
+int impdar_devcache_alloc(int device, size_t bytes, void **dptr)
+{
+    if (bytes == 0) bytes = 8;
+    {
+        std::lock_guard<std::mutex> lk(g_devcache_mu);
+        DevCacheEntry *best = nullptr;
+        for (DevCacheEntry &e : g_devcache)
+            if (e.free_ && e.device == device && e.bytes >= bytes && e.bytes <= bytes + bytes / 4 + ((size_t)1 << 20) && (!best || e.bytes < best->bytes)) best = &e;
+        if (best) {
+            best->free_ = false;
+            *dptr = best->p;
+            return IMPDAR_OK;
+        }
+    }
+    DevBuf b;                                                   // (its ensure() retries after impdar_release_caches when memory is short)
+    IMPDAR_HIP_CHECK(b.ensure(bytes));
+    *dptr = b.p;
+    b.p = nullptr;
+    b.bytes = 0;
+    std::lock_guard<std::mutex> lk(g_devcache_mu);
+    g_devcache.push_back(DevCacheEntry{*dptr, bytes, device, false});
+    return IMPDAR_OK;
+}
+
+// the caller has synchronised whatever used the array
+void impdar_devcache_free(void *p)
+{
+    if (!p) return;
+    void *drop[DEVCACHE_MAX_KEPT + 2] = {};
+    int ndrop = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_devcache_mu);
+        size_t kept_bytes = 0;
+        int kept = 0;
+        bool found = false;
+        for (DevCacheEntry &e : g_devcache) {
+            if (e.p == p) {
+                e.free_ = true;
+                found = true;
+            }
+            if (e.free_) {
+                kept_bytes += e.bytes;
+                ++kept;
+            }
+        }
+        if (!found) drop[ndrop++] = p;                           // (not one of ours: plain hipFree)
+        // over the limits: the oldest kept arrays go
+        for (size_t i = 0; i < g_devcache.size() && (kept > DEVCACHE_MAX_KEPT || kept_bytes > DEVCACHE_MAX_BYTES) && ndrop < DEVCACHE_MAX_KEPT + 2;) {
+            if (g_devcache[i].free_) {
+                drop[ndrop++] = g_devcache[i].p;
+                kept_bytes -= g_devcache[i].bytes;
+                --kept;
+                g_devcache.erase(g_devcache.begin() + (long)i);
+            } else {
+                ++i;
+            }
+        }
+    }
+    for (int i = 0; i < ndrop; ++i) (void)hipFree(drop[i]);
+}
+
+// device < 0: every device
+void impdar_devcache_trim(int device)
+{
+    std::vector<void *> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_devcache_mu);
+        for (size_t i = 0; i < g_devcache.size();) {
+            if (g_devcache[i].free_ && (device < 0 || g_devcache[i].device == device)) {
+                drop.push_back(g_devcache[i].p);
+                g_devcache.erase(g_devcache.begin() + (long)i);
+            } else {
+                ++i;
+            }
+        }
+    }
+    for (void *p : drop) (void)hipFree(p);
+}
+
 extern "C" int impdar_dev_alloc(impdar_ctx *ctx, size_t bytes, void **dptr)
 {
     IMPDAR_ARG_CHECK(ctx && dptr, "null context/pointer");
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
-    IMPDAR_HIP_CHECK(hipMalloc(dptr, bytes ? bytes : 8));
-    return IMPDAR_OK;
+    return impdar_devcache_alloc(ctx->device, bytes, dptr);
 }
 
 extern "C" int impdar_dev_free(impdar_ctx *ctx, void *dptr)
@@ -631,7 +729,7 @@ extern "C" int impdar_dev_free(impdar_ctx *ctx, void *dptr)
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
     IMPDAR_HIP_CHECK(hipStreamSynchronize(ctx->aux));
     IMPDAR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    IMPDAR_HIP_CHECK(hipFree(dptr));
+    impdar_devcache_free(dptr);
     return IMPDAR_OK;
 }
 

@@ -80,6 +80,10 @@ int impdar_download_blocks_f64(impdar_ctx *ctx, double *dst_host, size_t ld, siz
                                const size_t *col0, const size_t *width, const void *const *src, const hipEvent_t *after,
                                hipStream_t st);
 
+// device arrays of the one-shot calls, from a small cache of freed ones (api.hip); the caller of _free has synchronised their users
+int impdar_devcache_alloc(int device, size_t bytes, void **dptr);
+void impdar_devcache_free(void *p);
+
 void impdar_set_error(const char *fmt, ...);
 // IMPDAR_TRACE=1: one line on stderr per milestone of a call ("[impdar +12.3 ms] stolt: plans ready"), the time since the
 // library's first trace point -- where a first call's time goes (profiles/r05_first_call.txt).  A no-op otherwise.

@@ -2534,21 +2534,32 @@ extern "C" int impdar_phaseshift(impdar_ctx *ctx, const void *data, int dtype, i
     const size_t bytes = (size_t)snum * tnum * impdar_dtype_size(dtype);
     impdar_trace("impdar_phaseshift: enter (%d x %d, nt %d)", snum, tnum, nt);
     impdar_ctx_pinned_prefetch(ctx, bytes);      // the download's staging buffer, pinned while the call works
-    DevBuf din, dout;
-    IMPDAR_HIP_CHECK(din.ensure(bytes));
-    IMPDAR_HIP_CHECK(dout.ensure(bytes));
-    IMPDAR_HIP_CHECK(hipMemcpyAsync(din.p, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    // (the two device arrays of the call come from the cache of freed ones, api.hip: no hipMalloc / hipFree per call)
+    struct Arrays {
+        impdar_ctx *ctx;
+        void *din = nullptr, *dout = nullptr;
+        ~Arrays()
+        {
+            (void)hipStreamSynchronize(ctx->stream);          // (nothing in flight may still touch them)
+            impdar_devcache_free(din);
+            impdar_devcache_free(dout);
+        }
+    } a{ctx};
+    int rc = impdar_devcache_alloc(ctx->device, bytes, &a.din);
+    if (rc) return rc;
+    if ((rc = impdar_devcache_alloc(ctx->device, bytes, &a.dout))) return rc;
+    IMPDAR_HIP_CHECK(hipMemcpyAsync(a.din, data, bytes, hipMemcpyHostToDevice, ctx->stream));
     impdar_trace("impdar_phaseshift: upload enqueued");
     std::lock_guard<std::mutex> lk(g_ps_mu);
     ImpdarBusy busy(t_ps_busy);
     if (!g_ps_plan) g_ps_plan = new PsPlan();
-    int rc = dtype == IMPDAR_F32 ? ps_run<float>(ctx, *g_ps_plan, din.p, snum, tnum, nt, kx, ws, dt, tt_us, vconst, vmig,
-                                                 vmig_len, htaper, vtaper, dout.p)
-                                 : ps_run<double>(ctx, *g_ps_plan, din.p, snum, tnum, nt, kx, ws, dt, tt_us, vconst, vmig,
-                                                  vmig_len, htaper, vtaper, dout.p);
+    rc = dtype == IMPDAR_F32 ? ps_run<float>(ctx, *g_ps_plan, a.din, snum, tnum, nt, kx, ws, dt, tt_us, vconst, vmig,
+                                             vmig_len, htaper, vtaper, a.dout)
+                             : ps_run<double>(ctx, *g_ps_plan, a.din, snum, tnum, nt, kx, ws, dt, tt_us, vconst, vmig,
+                                              vmig_len, htaper, vtaper, a.dout);
     if (rc) return rc;
     impdar_trace("impdar_phaseshift: device work complete");
-    rc = impdar_download(ctx, out, dout.p, bytes, ctx->stream);
+    rc = impdar_download(ctx, out, a.dout, bytes, ctx->stream);
     impdar_trace("impdar_phaseshift: downloaded");
     return rc;
 }

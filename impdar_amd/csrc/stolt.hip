@@ -434,14 +434,20 @@ extern "C" int impdar_stolt(impdar_ctx *ctx, const void *data, int dtype, int sn
     const size_t inb = (size_t)snum * tnum * esz, outb = (size_t)(2 * (snum / 2)) * tnum * esz;
     impdar_trace("impdar_stolt: enter (%d x %d)", snum, tnum);
     impdar_ctx_pinned_prefetch(ctx, outb);       // the download's staging buffer, pinned while the call works
-    DevBuf din, dout;
-    IMPDAR_HIP_CHECK(din.ensure(inb));
-    IMPDAR_HIP_CHECK(dout.ensure(outb ? outb : 8));
-    IMPDAR_HIP_CHECK(hipMemcpyAsync(din.p, data, inb, hipMemcpyHostToDevice, ctx->stream));
+    // (the two device arrays of the call come from the cache of freed ones: no hipMalloc / hipFree per call)
+    void *din = nullptr, *dout = nullptr;
+    int rc = impdar_devcache_alloc(ctx->device, inb, &din);
+    if (rc == IMPDAR_OK) rc = impdar_devcache_alloc(ctx->device, outb ? outb : 8, &dout);
+    if (rc == IMPDAR_OK && hipMemcpyAsync(din, data, inb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        impdar_set_error("impdar_stolt: upload failed: %s", hipGetErrorString(hipGetLastError()));
+        rc = IMPDAR_ERR_HIP;
+    }
     impdar_trace("impdar_stolt: upload enqueued");
-    int rc = impdar_stolt_dev(ctx, din.p, dtype, snum, tnum, kx, ws, vel, htaper, vtaper, dout.p);
-    if (rc) return rc;
-    rc = impdar_download(ctx, out, dout.p, outb, ctx->stream);
+    if (rc == IMPDAR_OK) rc = impdar_stolt_dev(ctx, din, dtype, snum, tnum, kx, ws, vel, htaper, vtaper, dout);
+    if (rc == IMPDAR_OK) rc = impdar_download(ctx, out, dout, outb, ctx->stream);
     impdar_trace("impdar_stolt: downloaded");
+    (void)hipStreamSynchronize(ctx->stream);                  // (nothing in flight may still touch the arrays)
+    impdar_devcache_free(din);
+    impdar_devcache_free(dout);
     return rc;
 }
