@@ -17,18 +17,21 @@
 // evanescent boundary (psi -> 0): frequencies with psi < psi_min -- a narrow band above the boundary, chosen per (piece, kx) so
 // that a majorant of the series' tail at z = 1 stays below a tolerance (1e-5 float32 data / 1e-11 float64: the relative error of
 // the WORST frequency; the sums come out at 1e-7 ... 1e-6 / 1e-13) -- are summed DIRECTLY, step by step in float64 phases, with
-// the reference's own expression for coss where it decides life and death (|coss| < 1e-12).  So are the Nyquist row (its phase
-// runs backwards: it would need conj y_p) and everything else that is alive and not regular.  A frequency dies for good when
-// coss <= thr at some step (:484-485); regular frequencies cannot (eps <= 0.1 psi^2 on them).
+// the reference's own expression for coss where it decides life and death (|coss| < 1e-12), and so is everything else that is
+// alive and not regular (what fails the reference's test at a piece's first step is dead on arrival).  The Nyquist row of the
+// Hermitian walk (w < 0: its phase runs backwards) is added per output step through the same series with conjugate coefficients.
+// A frequency dies for good when coss <= thr at some step (:484-485); regular frequencies cannot (eps <= 0.1 psi^2 on them).
 //
-// Prototype and error table: profiles/tools/r06_series_proto.py, profiles/r06_series_proto.txt.  The same machinery with J = 2
-// carries the 4e-13 velocity noise inside the "runs" of a float64 v(z) table (ps_nufft.h declines those), and with pieces that
-// span layer boundaries the tables of many layers.
+// Prototype and error table: profiles/tools/r06_series_proto.py, profiles/r06_series_proto.txt; measurements, stage by stage:
+// profiles/r06_series.txt.  The library takes this path where the planner's estimate beats the per-step kernels (phaseshift.hip):
+// profiles whose velocity settles -- a firn column -- or falls; on a rising gradient every piece has a band of frequencies about
+// to turn evanescent, and the direct sums there cost more than the transforms save.
 //
-// Work split: one workgroup of 1024 threads per wavenumber; a thread owns 4 frequencies (float64 phase in registers, NaN = dead)
-// and walks the pieces in depth order.  Per piece: classification -> direct list -> direct sums (a wave per listed frequency,
-// lanes = steps, float64 prefix sums of the phase) -> coefficients / grid places of the regular frequencies -> gather -> J FFTs ->
-// output.  Every sum has a fixed order: results are reproducible bit for bit.
+// Work split: one workgroup of 1024 threads (float64: 512) per wavenumber; a thread owns 4 (8) frequencies (float64 phase in
+// registers, NaN = dead) and walks the pieces in depth order.  Per piece: classification -> direct list (ranks by ballot, fixed
+// order) -> direct sums (a wave per (group of 64 listed frequencies, chunk of 16 steps): lanes = frequencies, two passes -- the
+// chunk's phase sum, then the phases, a sincos per (frequency, step) and a wave sum per step) -> coefficients / grid places of
+// the regular frequencies -> gather -> J FFTs -> output.  Every sum has a fixed order: results are reproducible bit for bit.
 #pragma once
 
 #include "ps_series_plan.h"
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
                         return cs > 0.0 ? w * P.dt * sqrt(cs) : 0.0;
                     };
                     if (g < gp) {
-#pragma unroll 1
+#pragma unroll 2
                         for (int q = 0; q < SR_DCH; ++q) {
                             const int n = ns + q;
                             if (n < L) {                                  // (uniform)
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
                         }
                         const T fx = mine ? (T)dl[e].fx : (T)0, fy = mine ? (T)dl[e].fy : (T)0;
                         T keepx = 0, keepy = 0;                            // lane q keeps step q's sum
-#pragma unroll 1
+#pragma unroll 2
                         for (int q = 0; q < SR_DCH; ++q) {
                             const int n = ns + q;
                             if (n >= L) break;                            // (uniform)
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
         else sr_fft_passes<T>(grids, J, gstride, G, logg, tid, reinterpret_cast<const OCp<T> *>(Q.tw[logg]), 1);
         {
             const T *corr = reinterpret_cast<const T *>(Q.corr) + Q.corr_off[loglp];
-#pragma unroll 1
+#pragma unroll 2
             for (int jj = 0; jj < NOUT; ++jj) {                                  // (not unrolled: 40 registers of series coefficients per step)
                 const int n = tid + NTH * jj;
                 if (n >= L) break;
