@@ -2411,9 +2411,10 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         // constant velocity 3.0 against 6.8 -- profiles/r05_ps_nufft.txt), then the matrix-core paths as before
         // ... 7: only the series path (ps_series.h).  By itself: profiles without runs of constant velocity to live on
         if (ok && vlen && (pref == 7 || (pref == 1 && (!P.sched || mruns.size() > 64))) && !force_overflow) {
-            // (what would run otherwise, at 8192^2: ps_smooth32_kernel 5.3e-6 ms per alive pair; ps_runs_kernel 8 ms + 0.14 per run)
+            // (what would run otherwise, at 8192^2: ps_smooth32_kernel 5.3e-6 ms per alive pair; ps_runs_kernel 8 ms + 0.036 per run,
+            // long or single step -- 41 / 81 / 161 table rows = 160 / 320 / 640 runs: 13.8 / 19.8 / 30.5 ms; a firn column's 1470: 70)
             const double alt = pref == 7 ? 0.0 : (!P.sched ? -SR_MS_PER_PAIR_F32
-                                                           : (8.0 + 0.14 * (double)mruns.size()) * ((double)nf / 4096.0) * ((double)snum / 8192.0));
+                                                           : (8.0 + 0.036 * (double)mruns.size()) * ((double)nf / 4096.0) * ((double)snum / 8192.0));
             if ((rc = ps_series_run<float>(pl, P, vmig, kx, w.data(), thr.data(), st, &mfma_done, alt))) return rc;
             if (mfma_done) mfma_kernel_name = "ps_series_kernel";
         }
