@@ -45,7 +45,7 @@ constexpr int PN_SHORT = 8;                 // runs of up to this many steps are
 template <typename T> struct PnCfg;
 // LMAX: steps per piece at most (G = 2 LMAX grid points): spreading and coefficients cost per PIECE -- as long as LDS allows
 template <> struct PnCfg<float> { static constexpr int W = 8, NTH = 1024, OCC = 1, LMAX = 4096; };
-template <> struct PnCfg<double> { static constexpr int W = 14, NTH = 512, OCC = 1, LMAX = 1024; };
+template <> struct PnCfg<double> { static constexpr int W = 14, NTH = 512, OCC = 1, LMAX = 1024; };       // (1024 threads at 128 registers: 54 spilled, 9.34 -> 9.82 ms at 8192^2)
 
 struct PnPiece {
     double v;               // velocity (kind 0)
@@ -132,11 +132,32 @@ __device__ __forceinline__ float pn_window(float x) { return pn_window(x, PnWinF
 __device__ __forceinline__ float pn_winT(float x, const PnWinF &k) { return pn_window(x, k); }
 __device__ __forceinline__ double pn_window(double x);
 __device__ __forceinline__ double pn_winT(double x, const PnWinF &) { return pn_window(x); }
+// float64: the library's sqrt and exp (all ranges, ~65 float64 instructions together) replaced by what this argument range needs
+// -- sqrt on (0, 1] from the float32 reciprocal root + two Newton steps (pm_sqrt01), exp on [-beta, 0] by y = k ln 2 + r,
+// |r| <= 0.35, the series of e^r to r^12 (1.7e-16) and one ldexp: ~38 instructions; the window is what a float64 gather spends
+// its time on (config 5 on float64 data 14.0 -> 13.6 ms in the frequency-sum kernels, a firn column 66 -> 63.4)
 __device__ __forceinline__ double pn_window(double x)
 {
     constexpr int W = PnCfg<double>::W;
-    const double z = fmax(fma(-x * x, 4.0 / (W * W), 1.0), 0.0);
-    return exp(2.30 * W * (sqrt(z) - 1.0));
+    const double z = fmax(fma(-x * x, 4.0 / (W * W), 1.0), 1e-8);       // (below 1e-8: e^{-beta} (1 + 3e-3), 1e-14 of the maximum either way)
+    const double y = (2.30 * W) * (pm_sqrt01(z) - 1.0);                  // in [-beta, 0]
+    const double k = rint(y * 1.4426950408889634);
+    double r = fma(-k, 6.93147180369123816490e-01, y);                  // ln 2 in two pieces (Cody-Waite)
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 479001600.0;
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
 }
 __device__ __forceinline__ void pn_sincos(double x, float *s, float *c) { pm_sincos(x, s, c); }
 __device__ __forceinline__ void pn_sincos(double x, double *s, double *c) { pss_sincos_small(pm_wrap(x), s, c); }

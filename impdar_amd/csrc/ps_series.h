@@ -79,13 +79,7 @@ template <typename T> __host__ __device__ constexpr size_t sr_lds_bytes(int grid
 
 __device__ __forceinline__ float sr_window(float x, const PnWinF &k) { return pn_window(x, k); }     // (ps_nufft.h: no select, e^{-beta} = 1e-8 beyond the support)
 struct SrWinD {};
-__device__ __forceinline__ double sr_window(double x, const SrWinD &);
-__device__ __forceinline__ double sr_window(double x, const SrWinD &)
-{
-    constexpr int W = SrCfg<double>::W;
-    const double z = fmax(fma(-x * x, 4.0 / (W * W), 1.0), 0.0);
-    return exp(2.30 * W * (sqrt(z) - 1.0));
-}
+__device__ __forceinline__ double sr_window(double x, const SrWinD &) { return pn_window(x); }     // (ps_nufft.h)
 
 // sqrt(x) and 1 / sqrt(x), x > 0 of any size: the hardware's float64 reciprocal root as the seed, two Newton steps (~1e-16 relative)
 __device__ __forceinline__ double sr_sqrt(double x, double *rinv)
