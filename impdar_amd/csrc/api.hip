@@ -345,8 +345,13 @@ static int impdar_download_piped(impdar_ctx *ctx, void *host_dst, const void *de
     // one staged download per context at a time: the staging buffer is shared (and may be re-allocated) and
     // ctypes callers run without the GIL
     std::lock_guard<std::mutex> lock(ctx->pinned_mu);
-    void *stage = bytes >= (1u << 20) ? impdar_ctx_pinned(ctx, bytes) : nullptr;
+    // The staging buffer is a RING of at most 64 MB (round 6; the whole image before -- 268 MB at 8192^2 float32, 59 ms of
+    // hipHostMalloc in a process's first phase-shift call): pieces of <= 16 MB go round it, up to four DMAs in flight, the
+    // copy of piece c + 4 enqueued once the host threads have copied (or widened) piece c out of its slot.
+    const size_t cap = std::min(bytes, IMPDAR_STAGE_RING_BYTES);
+    char *stage = bytes >= (1u << 20) ? reinterpret_cast<char *>(impdar_ctx_pinned(ctx, cap)) : nullptr;
     std::vector<char> fallback;
+    size_t ring = cap;
     if (!stage) {
         if (!widen && !block) {
             IMPDAR_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, st));
@@ -355,48 +360,55 @@ static int impdar_download_piped(impdar_ctx *ctx, void *host_dst, const void *de
         }
         fallback.resize(bytes);
         stage = fallback.data();
+        ring = bytes;
     }
-    // pieces of >= 16 MB (48 MB until round 6, when every piece started its own host threads)
-    const int npiece = (int)std::min<size_t>(8, std::max<size_t>(1, bytes / (16u << 20)));
-    hipEvent_t ev[8] = {};
-    size_t lo[9];
     const size_t gran = block ? width : 16;                  // block pieces are whole rows
-    for (int c = 0; c <= npiece; ++c) lo[c] = (n * c / npiece) / gran * gran;
-    lo[npiece] = n;
-    int rc = IMPDAR_OK, issued = 0;
-    for (int c = 0; c < npiece && rc == IMPDAR_OK; ++c) {
-        if (hipEventCreateWithFlags(&ev[c], hipEventDisableTiming) != hipSuccess) {
-            ev[c] = nullptr;
+    constexpr int NSLOT = 4;
+    const size_t slot_bytes = ring / NSLOT >= ((size_t)1 << 20) ? ring / NSLOT / 256 * 256 : ring;
+    const int nslot = slot_bytes == ring ? 1 : NSLOT;
+    size_t per = std::max<size_t>(slot_bytes / elem_in / gran * gran, gran);     // elements per piece
+    if (per * elem_in > slot_bytes) {                        // (a row wider than a slot: one slot, the whole ring)
+        if (gran * elem_in > ring) {
+            impdar_set_error("device -> host copy: a row of %zu bytes does not fit the staging ring", gran * elem_in);
+            return IMPDAR_ERR_ARG;
+        }
+        per = std::max<size_t>(ring / elem_in / gran * gran, gran);
+    }
+    const int slots = per * elem_in > slot_bytes ? 1 : nslot;
+    const size_t slot_stride = slots == 1 ? 0 : slot_bytes;
+    const size_t npiece = (n + per - 1) / per;
+    hipEvent_t ev[NSLOT] = {};
+    int rc = IMPDAR_OK;
+    for (int q = 0; q < slots && rc == IMPDAR_OK; ++q)
+        if (hipEventCreateWithFlags(&ev[q], hipEventDisableTiming) != hipSuccess) {
+            ev[q] = nullptr;
+            rc = IMPDAR_ERR_HIP;
+        }
+    auto issue = [&](size_t c) {
+        const size_t a = c * per, cnt = std::min(per, n - a);
+        const int q = (int)(c % (size_t)slots);
+        if (hipMemcpyAsync(stage + q * slot_stride, (const char *)dev_src + a * elem_in, cnt * elem_in, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipEventRecord(ev[q], st) != hipSuccess)
+            rc = IMPDAR_ERR_HIP;
+    };
+    size_t issued = 0;
+    for (; issued < npiece && issued < (size_t)slots && rc == IMPDAR_OK; ++issued) issue(issued);
+    for (size_t c = 0; c < npiece && rc == IMPDAR_OK; ++c) {
+        const int q = (int)(c % (size_t)slots);
+        if (hipEventSynchronize(ev[q]) != hipSuccess) {
             rc = IMPDAR_ERR_HIP;
             break;
         }
-        ++issued;
-        if (hipMemcpyAsync((char *)stage + lo[c] * elem_in, (const char *)dev_src + lo[c] * elem_in,
-                           (lo[c + 1] - lo[c]) * elem_in, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipEventRecord(ev[c], st) != hipSuccess)
-            rc = IMPDAR_ERR_HIP;
-    }
-    if (rc) {
-        // no DMA into the staging buffer may still be in flight when it is handed to the next caller
-        (void)hipStreamSynchronize(st);
-        for (int c = 0; c < issued; ++c) (void)hipEventDestroy(ev[c]);
-        impdar_set_error("device -> host copy failed: %s", hipGetErrorString(hipGetLastError()));
-        return rc;
-    }
-    for (int c = 0; c < npiece; ++c) {
-        if (hipEventSynchronize(ev[c]) != hipSuccess) rc = IMPDAR_ERR_HIP;
-        (void)hipEventDestroy(ev[c]);
-        if (rc) continue;
-        const size_t base = lo[c], cnt = lo[c + 1] - lo[c];
+        const size_t base = c * per, cnt = std::min(per, n - base);
+        const char *sp = stage + q * slot_stride;
         if (block) {
             // rows base / width .. of the block -> host rows of `ld` elements, columns col0 ..
             const size_t r0 = base / width, nr = cnt / width;
-            const char *sp = reinterpret_cast<const char *>(stage);
             char *dp = reinterpret_cast<char *>(host_dst);
             impdar_parallel_for(nr, 1, [=](size_t a, size_t b) {
-                for (size_t r = r0 + a; r < r0 + b; ++r) {
+                for (size_t r = a; r < b; ++r) {
                     const char *src = sp + r * width * elem_in;
-                    char *dst = dp + (r * ld + col0) * elem_out;
+                    char *dst = dp + ((r0 + r) * ld + col0) * elem_out;
                     if (widen) {
                         const float *f = reinterpret_cast<const float *>(src);
                         double *d = reinterpret_cast<double *>(dst);
@@ -407,26 +419,22 @@ static int impdar_download_piped(impdar_ctx *ctx, void *host_dst, const void *de
                 }
             });
         } else if (widen) {
-            const float *f = reinterpret_cast<const float *>(stage) + base;
+            const float *f = reinterpret_cast<const float *>(sp);
             double *d = reinterpret_cast<double *>(host_dst) + base;
             impdar_parallel_for(cnt, 16, [=](size_t a, size_t b) { for (size_t i = a; i < b; ++i) d[i] = (double)f[i]; });
         } else {
-            const char *sp = reinterpret_cast<const char *>(stage) + base * elem_in;
             char *dp = reinterpret_cast<char *>(host_dst) + base * elem_in;
             impdar_parallel_for(cnt * elem_in, 64, [=](size_t a, size_t b) { memcpy(dp + a, sp + a, b - a); });
         }
+        if (issued < npiece) issue(issued++);                // (the slot just emptied takes the next piece)
     }
     if (rc) {
+        // no DMA into the staging buffer may still be in flight when it is handed to the next caller
         (void)hipStreamSynchronize(st);
-        impdar_set_error("device -> host copy failed");
+        impdar_set_error("device -> host copy failed: %s", hipGetErrorString(hipGetLastError()));
     }
-    // a staging buffer above 1 GiB is not kept pinned for the life of the process (re-pinning costs ~0.2 ms per MB,
-    // so the common radargram sizes keep theirs)
-    if (ctx->pinned_bytes > ((size_t)1 << 30)) {
-        (void)hipHostFree(ctx->pinned);
-        ctx->pinned = nullptr;
-        ctx->pinned_bytes = 0;
-    }
+    for (int q = 0; q < slots; ++q)
+        if (ev[q]) (void)hipEventDestroy(ev[q]);
     return rc;
 }
 
@@ -740,7 +748,7 @@ extern "C" int impdar_dev_upload(impdar_ctx *ctx, void *dst_dev, const void *src
     // an image that goes up usually comes down again, through the context's pinned staging buffer: have it pinned by a
     // thread of its own while the upload and the migration run (44 ms for the 256 MB of an 8192^2 float32 image when the
     // download has to do it itself: profiles/r05_first_call.txt)
-    impdar_ctx_pinned_prefetch(ctx, bytes);
+    impdar_ctx_pinned_prefetch(ctx, std::min(bytes, IMPDAR_STAGE_RING_BYTES));
     // straight from pageable memory: the runtime's own staging pipeline reaches 17 GB/s here; copying into the
     // context's pinned buffer on host threads first was slower (9.8 -> 17 ms for 164 MB)
     IMPDAR_HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));

@@ -3096,10 +3096,9 @@ extern "C" int impdar_kirchhoff(impdar_ctx *ctx, const void *data, int dtype, in
     const bool split = !(se && atoi(se) == 0) && tnum >= 4096 && bytes >= ((size_t)64 << 20) &&
                        (kern == IMPDAR_KERNEL_QUAD || kern == IMPDAR_KERNEL_DQUAD);
     // the download's staging buffer, pinned by a thread of its own while this call uploads and sums (started behind the
-    // plan: beside it the two contend for the runtime -- plan 18 -> 40 ms): the 64 MB ring of the pipelined blocks, or
-    // the whole image where the download is one piece (round 4 asked for the ring there too, and the download then freed
-    // it and pinned the image synchronously: both pins and a free on the first call)
-    impdar_ctx_pinned_prefetch(ctx, split ? std::min(bytes, IMPDAR_STAGE_RING_BYTES) : bytes);
+    // plan: beside it the two contend for the runtime -- plan 18 -> 40 ms): the 64 MB ring -- of the pipelined blocks, and
+    // since round 6 of the one-piece download too (api.hip)
+    impdar_ctx_pinned_prefetch(ctx, std::min(bytes, IMPDAR_STAGE_RING_BYTES));
     int nlaunch = 1;
     if (split) {
         const int halo = p->ntab + 16;                 // aperture half width (+ the kernels' staging look-ahead)

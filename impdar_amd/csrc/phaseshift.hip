@@ -2534,7 +2534,7 @@ extern "C" int impdar_phaseshift(impdar_ctx *ctx, const void *data, int dtype, i
     IMPDAR_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t bytes = (size_t)snum * tnum * impdar_dtype_size(dtype);
     impdar_trace("impdar_phaseshift: enter (%d x %d, nt %d)", snum, tnum, nt);
-    impdar_ctx_pinned_prefetch(ctx, bytes);      // the download's staging buffer, pinned while the call works
+    impdar_ctx_pinned_prefetch(ctx, std::min(bytes, IMPDAR_STAGE_RING_BYTES));      // the download's staging ring, pinned while the call works
     // (the two device arrays of the call come from the cache of freed ones, api.hip: no hipMalloc / hipFree per call)
     struct Arrays {
         impdar_ctx *ctx;

@@ -433,7 +433,7 @@ extern "C" int impdar_stolt(impdar_ctx *ctx, const void *data, int dtype, int sn
     const size_t esz = impdar_dtype_size(dtype);
     const size_t inb = (size_t)snum * tnum * esz, outb = (size_t)(2 * (snum / 2)) * tnum * esz;
     impdar_trace("impdar_stolt: enter (%d x %d)", snum, tnum);
-    impdar_ctx_pinned_prefetch(ctx, outb);       // the download's staging buffer, pinned while the call works
+    impdar_ctx_pinned_prefetch(ctx, std::min(outb, IMPDAR_STAGE_RING_BYTES));       // the download's staging ring, pinned while the call works
     // (the two device arrays of the call come from the cache of freed ones: no hipMalloc / hipFree per call)
     void *din = nullptr, *dout = nullptr;
     int rc = impdar_devcache_alloc(ctx->device, inb, &din);
