@@ -721,6 +721,11 @@ def path_records(no_cpu, no_pmc=False, full_data=None, geo3=None, spot=None):
     d_in.free()
     d_out.free()
     out["kirchhoff_jittered_config3"] = rec
+    # how often a timed call of these records ran well over its median (the intermittent device stall of profiles/r05_slow_call.txt:
+    # the medians above do not show it, a one-shot user call would meet it)
+    calls = [(k, v["device_ms_calls"]) for k, v in out.items() if isinstance(v, dict) and v.get("device_ms_calls")]
+    slow = [(k, round(max(c), 2)) for k, c in calls if max(c) > 1.5 * float(np.median(c))]
+    out["slow_calls"] = {"timed_calls": int(sum(len(c) for _, c in calls)), "over_1p5x_median": len(slow), "which": dict(slow)}
     return out
 
 
