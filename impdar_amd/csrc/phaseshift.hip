@@ -2246,7 +2246,6 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     P.sm_m = 8;
     std::vector<int> sched, rowmap;
     std::vector<double> epsum;
-    int ndirty_tiles = 0;                    // 16-step tiles that hold a change of velocity
     if (vlen) {
         // runs of constant velocity (ps_vz32_kernel): a step starts a new run when its velocity differs from the
         // run's first by more than vtol (relative) -- 2*gradient(z(t)) of a layered table is constant inside a
@@ -2270,7 +2269,6 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             }
             epsum[i / 16] += vmig[i] / vrun - 1.0;      // float64 kernel: the run's velocity noise, tile by tile
         }
-        ndirty_tiles = ndirty;
         // the per-step tiles of the runs kernels cost several quiet tiles each: beyond a share of such tiles the
         // per-step kernel is faster for float32 (2048^2, 40 / 80 / 160 layers: 4.6 / 7.5 / 12.2 ms against
         // 5.5 / 6.8 / 9.5 ms); the float64 runs kernel stays ahead until every tile holds a change (10.1 / 16.6 /
@@ -2384,8 +2382,13 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         // any other v(z) profile -- a velocity that changes at every step, many layers: the series path (ps_series.h)
         if (vlen && !mfma_done && (pref == 1 || pref == 7)) {
             // (what would run otherwise: ps_smooth_kernel, 10.8e-6 ms per alive pair; the runs kernel ps_vz64_kernel
-            // -- 43 ms + 0.35 per 16-step tile that holds a change of velocity, at 8192^2: profiles/r06_series.txt)
-            const double alt = pref == 7 ? 0.0 : (P.sched ? (43.0 + 0.35 * (double)ndirty_tiles) * ((double)nf / 4096.0) * ((double)snum / 8192.0) : -SR_MS_PER_PAIR_F64);
+            // -- 43 ms for the record + 0.09 per step that starts a run, at 8192^2 (4-row table 43, 41 rows 56, a firn column's
+            // 1960 changing steps 226; 4096^2: 14 / 121 per 8192 wavenumbers): profiles/r06_series.txt)
+            int nstarts = 0;
+            if (P.sched)
+                for (int i = 0; i < snum; ++i) nstarts += sched[i] != 0;
+            const double alt = pref == 7 ? 0.0 : (P.sched ? 43.0 * ((double)nf / 4096.0) * ((double)snum / 8192.0) + 0.09 * (double)nstarts * ((double)nf / 4096.0)
+                                                          : -SR_MS_PER_PAIR_F64);
             if ((rc = ps_series_run<double>(pl, P, vmig, kx, w.data(), thr.data(), st, &mfma_done, alt))) return rc;
             if (mfma_done) mfma_kernel_name = "ps_series_kernel";
         }
@@ -2426,7 +2429,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             // (what would run otherwise, at 8192^2: ps_smooth32_kernel 5.3e-6 ms per alive pair; ps_runs_kernel 8 ms + 0.036 per run,
             // long or single step -- 41 / 81 / 161 table rows = 160 / 320 / 640 runs: 13.8 / 19.8 / 30.5 ms; a firn column's 1470: 70)
             const double alt = pref == 7 ? 0.0 : (!P.sched ? -SR_MS_PER_PAIR_F32
-                                                           : (8.0 + 0.036 * (double)mruns.size()) * ((double)nf / 4096.0) * ((double)snum / 8192.0));
+                                                           : 8.0 * ((double)nf / 4096.0) * ((double)snum / 8192.0) + 0.036 * (double)mruns.size() * ((double)nf / 4096.0));
             if ((rc = ps_series_run<float>(pl, P, vmig, kx, w.data(), thr.data(), st, &mfma_done, alt))) return rc;
             if (mfma_done) mfma_kernel_name = "ps_series_kernel";
         }
