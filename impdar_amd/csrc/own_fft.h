@@ -55,25 +55,69 @@ __device__ __forceinline__ int own_rev(int k, int M, int logm)
 // The passes of a length-M transform on a row that sits in LDS at s[own_pad(i)] (decimation in frequency, in place, radix 4
 // and a last radix 2 when log2 M is odd): the result of index k is left at position own_rev(k).  Every thread of the
 // workgroup calls it (barriers inside).  tw: e^{-2 pi i k / (M tws)}.
+// one radix-4 decimation-in-frequency butterfly with its twiddles: outputs in the order the passes store them (quarter 0 .. 3)
 template <typename T, bool INV>
+__device__ __forceinline__ void own_bfly4(OCp<T> &a0, OCp<T> &a1, OCp<T> &a2, OCp<T> &a3, OCp<T> w1)
+{
+    const OCp<T> t0 = own_add(a0, a2), t1 = own_sub(a0, a2), t2 = own_add(a1, a3), d = own_sub(a1, a3);
+    // forward: -i d = (d.y, -d.x); inverse: +i d = (-d.y, d.x)
+    const OCp<T> t3 = INV ? OCp<T>{-d.y, d.x} : OCp<T>{d.y, -d.x};
+    if (INV) w1.y = -w1.y;
+    const OCp<T> w2 = own_mul(w1, w1), w3 = own_mul(w2, w1);
+    a0 = own_add(t0, t2);
+    a1 = own_mul(own_add(t1, t3), w1);
+    a2 = own_mul(own_sub(t0, t2), w2);
+    a3 = own_mul(own_sub(t1, t3), w3);
+}
+
+template <typename T, bool INV, bool FUSE = false>
 __device__ __forceinline__ void own_fft_passes(OCp<T> *s, int M, int logm, int tid, int nth, const OCp<T> *__restrict__ tw, int TWS)
 {
     int ll = logm;                      // log2 of the span of the pass
+    if constexpr (FUSE && sizeof(T) == 4) {
+        // float32 rows of own_fft_rows: TWO radix-4 passes in one trip through LDS while the span allows (round 6) -- a thread
+        // takes the 16 points (4 a + b) q + j of a span of 16 q, does the four butterflies of the outer pass (over a, twiddles of
+        // the span) and the four of the inner one (over b, twiddles of a quarter span) in registers and stores where two separate
+        // passes would have: 8192 points in 4 trips and barriers instead of 7.  Only while every other thread has such a
+        // 16-point job: C2C over 8192 x 8192 365 -> 314 us (forward over 4097 rows 190 -> 168), but rows of 4096 points on 1024
+        // threads -- a quarter of the threads busy -- ran 3 % SLOWER (Stolt 0.360 -> 0.373 ms), and inside ps_nufft_kernel the 32
+        // registers of the points spilled 18 (kernel +1.5 %): those keep radix 4, as does float64 (16 points = 64 registers
+        // of a 128 budget).  profiles/r06_transforms.txt
+        while (ll >= 4 && (M >> 4) * 2 >= nth) {
+            const int lq = ll - 4, q = 1 << lq, L = 1 << ll, tstep = (M >> ll) * TWS;
+            for (int b = tid; b < (M >> 4); b += nth) {
+                const int g = b >> lq, j = b & (q - 1), base = g * L + j;
+                OCp<T> r[4][4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) r[a][c] = s[own_pad(base + (4 * a + c) * q)];
+                // outer pass: span L, quarter 4 q; butterfly c works on position x = c q + j of the first quarter
+#pragma unroll
+                for (int c = 0; c < 4; ++c) own_bfly4<T, INV>(r[0][c], r[1][c], r[2][c], r[3][c], tw[(c * q + j) * tstep]);
+                // inner pass: span 4 q, quarter q, inside every quarter a of the outer span
+                const OCp<T> wi = tw[j * 4 * tstep];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) own_bfly4<T, INV>(r[a][0], r[a][1], r[a][2], r[a][3], wi);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) s[own_pad(base + (4 * a + c) * q)] = r[a][c];
+            }
+            __syncthreads();
+            ll -= 4;
+        }
+    }
     while (ll >= 2) {
         const int lq = ll - 2, q = 1 << lq, L = 1 << ll, tstep = (M >> ll) * TWS;
         for (int b = tid; b < (M >> 2); b += nth) {
             const int g = b >> lq, j = b & (q - 1), base = g * L + j;
-            const OCp<T> a0 = s[own_pad(base)], a1 = s[own_pad(base + q)], a2 = s[own_pad(base + 2 * q)], a3 = s[own_pad(base + 3 * q)];
-            const OCp<T> t0 = own_add(a0, a2), t1 = own_sub(a0, a2), t2 = own_add(a1, a3), d = own_sub(a1, a3);
-            // forward: -i d = (d.y, -d.x); inverse: +i d = (-d.y, d.x)
-            const OCp<T> t3 = INV ? OCp<T>{-d.y, d.x} : OCp<T>{d.y, -d.x};
-            OCp<T> w1 = tw[j * tstep];
-            if (INV) w1.y = -w1.y;
-            const OCp<T> w2 = own_mul(w1, w1), w3 = own_mul(w2, w1);
-            s[own_pad(base)] = own_add(t0, t2);
-            s[own_pad(base + q)] = own_mul(own_add(t1, t3), w1);
-            s[own_pad(base + 2 * q)] = own_mul(own_sub(t0, t2), w2);
-            s[own_pad(base + 3 * q)] = own_mul(own_sub(t1, t3), w3);
+            OCp<T> a0 = s[own_pad(base)], a1 = s[own_pad(base + q)], a2 = s[own_pad(base + 2 * q)], a3 = s[own_pad(base + 3 * q)];
+            own_bfly4<T, INV>(a0, a1, a2, a3, tw[j * tstep]);
+            s[own_pad(base)] = a0;
+            s[own_pad(base + q)] = a1;
+            s[own_pad(base + 2 * q)] = a2;
+            s[own_pad(base + 3 * q)] = a3;
         }
         __syncthreads();
         ll -= 2;
@@ -123,7 +167,7 @@ __global__ __launch_bounds__(1024) void own_fft_rows(const void *__restrict__ in
         for (int i = tid; i < M; i += nth) s[own_pad(i)] = X[i];
     }
     __syncthreads();
-    own_fft_passes<T, INV>(s, M, logm, tid, nth, tw, TWS);
+    own_fft_passes<T, INV, true>(s, M, logm, tid, nth, tw, TWS);
     // ---- store (the digit reversal is undone here)
     if (MODE == OWN_R2C) {
         OCp<T> *Y = reinterpret_cast<OCp<T> *>(out_) + row * out_dist;

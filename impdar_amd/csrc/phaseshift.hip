@@ -63,13 +63,19 @@ __global__ __launch_bounds__(256) void ps_taper_pad_transpose_real(const T *__re
                                                                    int nt, double htaper, double vtaper)
 {
     __shared__ T tile[64][65];
+    __shared__ double vw[64];
     const int k0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    // (the weights are float64 divisions: the column's once per thread, the tile's 64 rows' once per tile -- two per element
+    // until round 6, 141 us at 8192^2 for a pass that moves 0.54 GB)
+    const double hw = j0 + tx < tnum ? impdar_taper_w(j0 + tx, tnum, htaper) : 0.0;
+    if (threadIdx.x < 64) vw[threadIdx.x] = k0 + (int)threadIdx.x < snum ? impdar_taper_w(k0 + (int)threadIdx.x, snum, vtaper) : 0.0;
+    __syncthreads();
     for (int r = ty; r < 64; r += 4) {
         const int k = k0 + r, j = j0 + tx;
         T v = 0;
         if (k < snum && j < tnum) {
-            const double hv = impdar_taper_w(j, tnum, htaper) * impdar_taper_w(k, snum, vtaper);
+            const double hv = hw * vw[r];
             v = (T)((double)in[(size_t)k * tnum + j] * hv);        // data *= H*V, :258
         }
         tile[r][tx] = v;
@@ -115,6 +121,35 @@ template <typename T> static void ps_launch_transpose(const void *in, void *out,
     constexpr int TS = sizeof(T) == 4 ? 64 : 32;
     hipLaunchKernelGGL((ps_transpose_c<T, TS>), dim3((cols + TS - 1) / TS, (rows + TS - 1) / TS), dim3(256), 0, st,
                        reinterpret_cast<const Cp<T> *>(in), reinterpret_cast<Cp<T> *>(out), rows, cols);
+}
+
+// Only the REAL part of the inverse transform over the wavenumbers is kept (mig_python.py:282), and Re sum_k TK[k] e^{+i k x} =
+// sum_k G[k] e^{+i k x} with G[k] = (TK[k] + conj TK[-k]) / 2 Hermitian: the transpose forms G for k = 0 .. tnum / 2 on its way
+// ([k][tau] -> [tau][k], rows hs apart), and a real inverse transform of HALF the complex length does the rest (round 6: the
+// transposed array written is half as large, the transform's row in LDS too).
+template <typename T, int TS>
+__global__ __launch_bounds__(256) void ps_transpose_herm(const Cp<T> *__restrict__ in, Cp<T> *__restrict__ out, int tnum, int snum, int hs)
+{
+    __shared__ Cp<T> tile[TS][TS + 1];
+    const int c0 = blockIdx.x * TS, r0 = blockIdx.y * TS;          // c: tau, r: k
+    const int tx = threadIdx.x % TS, ty = threadIdx.x / TS, nh = tnum / 2;
+    for (int r = ty; r < TS; r += 256 / TS) {
+        const int k = r0 + r;
+        if (k <= nh && c0 + tx < snum) {
+            const Cp<T> a = in[(size_t)k * snum + c0 + tx], b = in[(size_t)(k ? tnum - k : 0) * snum + c0 + tx];
+            tile[r][tx] = Cp<T>{(T)0.5 * (a.x + b.x), (T)0.5 * (a.y - b.y)};
+        }
+    }
+    __syncthreads();
+    for (int c = ty; c < TS; c += 256 / TS)
+        if (c0 + c < snum && r0 + tx <= nh) out[(size_t)(c0 + c) * hs + r0 + tx] = tile[tx][c];
+}
+
+template <typename T> static void ps_launch_transpose_herm(const void *in, void *out, int tnum, int snum, int hs, hipStream_t st)
+{
+    constexpr int TS = sizeof(T) == 4 ? 64 : 32;
+    hipLaunchKernelGGL((ps_transpose_herm<T, TS>), dim3((snum + TS - 1) / TS, (tnum / 2 + TS) / TS), dim3(256), 0, st,
+                       reinterpret_cast<const Cp<T> *>(in), reinterpret_cast<Cp<T> *>(out), tnum, snum, hs);
 }
 
 // out[i] = Re Z[i] (mig_python.py:282 keeps the real part of the inverse transform)
@@ -2515,11 +2550,18 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     if (pl.rows_form) {
         // inverse over k on contiguous rows: TK [k][tau] -> [tau][k] (pl.X: the spectrum is not needed any more, and
         // nt >= snum), transform, real part (:282) -- already (snum, tnum)
-        ps_launch_transpose<T>(pl.TK.p, pl.X.p, tnum, snum, st);
-        if (use_own) {
-            // (the real part is all that is kept: stored by the transform itself, no pass of its own -- 0.16 ms at 8192^2)
+        if (use_own && tnum >= 32) {
+            // (the real part is all that is kept: the Hermitian half of the sums goes through a real inverse transform of half
+            // the length -- ps_transpose_herm; until round 6 a full transpose and a complex transform that stored real parts:
+            // 175 + 314 us at 8192^2 float32)
+            const int hs = tnum / 2 + 1;
+            ps_launch_transpose_herm<T>(pl.TK.p, pl.X.p, tnum, snum, hs, st);
+            if ((rc = own_fft_launch<T>(OWN_C2R, tnum, (size_t)snum, pl.X.p, d_out, (size_t)hs, (size_t)tnum, 1.0 / tnum, pl.tw_trace, st))) return rc;
+        } else if (use_own) {
+            ps_launch_transpose<T>(pl.TK.p, pl.X.p, tnum, snum, st);
             if ((rc = own_fft_launch<T>(OWN_C2C_INV_RE, tnum, (size_t)snum, pl.X.p, d_out, (size_t)tnum, (size_t)tnum, 1.0 / tnum, pl.tw_trace, st))) return rc;
         } else {
+            ps_launch_transpose<T>(pl.TK.p, pl.X.p, tnum, snum, st);
             if ((rc = pl.b_trace.exec(pl.X.p, nullptr))) return rc;
             const size_t n = (size_t)snum * tnum;
             hipLaunchKernelGGL((ps_real_part<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pl.X.as<Cp<T>>(), (T *)d_out, n);
