@@ -1689,9 +1689,11 @@ static std::vector<T> &pn_corr_tables(PsPlan &pl, const bool (&need)[13], int (&
 // ---- transform path (ps_nufft.h): pieces, correction tables, launch.  Same contract as ps_mfma_run.
 template <typename T>
 static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &runs, bool vz, const double *kx_host, const double *w_host,
-                        const double *thr, hipStream_t st, bool *done, const double *vmig = nullptr)
+                        const double *thr, hipStream_t st, bool *done, const double *vmig = nullptr, bool allow_pairs = false)
 {
     // vmig (float64 data, v(z)): the per-step velocities -- the runs' rounding noise enters as a first-order term (ps_nufft.h)
+    // allow_pairs: the sums go on into the inverse transform (not to a caller who asked for the rows TK themselves): rows k and
+    // tnum - k may be written as their Hermitian combination and its conjugate (ps_nufft_kernel<float, true>)
     const bool first_order = sizeof(T) == 8 && vz && vmig != nullptr;
     *done = false;
     const int snum = P.snum, tnum = P.tnum, nf = P.nf;
@@ -1799,8 +1801,21 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
             if (need[l]) lmax = l;
         Q.gmax = 2 << lmax;
     }
-    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_nufft_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pn_lds_bytes<T>(2 * PnCfg<T>::LMAX, sizeof(T) == 8)));
-    hipLaunchKernelGGL(ps_nufft_kernel<T>, dim3((unsigned)P.nk), dim3(PnCfg<T>::NTH), pn_lds_bytes<T>(Q.gmax, first_order), st, Q);
+    // the whole wavenumber axis with kx[tnum - k] = -kx[k] (float32): a pair of rows per workgroup, as ps_runs_kernel's
+    bool pairs = sizeof(T) == 4 && allow_pairs && P.k0 == 0 && P.nk == tnum && tnum >= 2 && tnum % 2 == 0;
+    for (int k = 1; 2 * k < tnum && pairs; ++k) pairs = kx_host[k] == -kx_host[tnum - k];
+    if constexpr (sizeof(T) == 4) {
+        if (pairs) {
+            IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_nufft_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)pn_lds_bytes<float>(2 * PnCfg<float>::LMAX, false, true)));
+            hipLaunchKernelGGL((ps_nufft_kernel<float, true>), dim3((unsigned)(tnum / 2 + 1)), dim3(PnCfg<float>::NTH),
+                               pn_lds_bytes<float>(Q.gmax, false, true), st, Q);
+        }
+    }
+    if (!pairs) {
+        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_nufft_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pn_lds_bytes<T>(2 * PnCfg<T>::LMAX, sizeof(T) == 8)));
+        hipLaunchKernelGGL(ps_nufft_kernel<T>, dim3((unsigned)P.nk), dim3(PnCfg<T>::NTH), pn_lds_bytes<T>(Q.gmax, first_order), st, Q);
+    }
     if (vz) {
         PsMfmaParams E;                        // (ps_edge_kernel reads P and the lists only)
         E.mfma_count = nullptr;
@@ -2469,7 +2484,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             if (mfma_done) mfma_kernel_name = "ps_series_kernel";
         }
         if (ok && !mfma_done && (pref == 6 || (pref == 1 && nlong <= 16)) && !force_overflow) {
-            if ((rc = ps_nufft_run<float>(pl, P, mruns, vlen != 0, kx, w.data(), thr.data(), st, &mfma_done))) return rc;
+            if ((rc = ps_nufft_run<float>(pl, P, mruns, vlen != 0, kx, w.data(), thr.data(), st, &mfma_done, nullptr, tk_out == nullptr))) return rc;
             if (mfma_done) mfma_kernel_name = "ps_nufft_kernel";
         }
         for (int turn = 0; turn < 2 && ok && !mfma_done && pref != 0 && pref != 7; ++turn) {

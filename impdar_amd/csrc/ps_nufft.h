@@ -70,12 +70,12 @@ struct PnParams {
 };
 
 // LDS: the grid of the call's longest piece (gmax points), then coefficients / grid places of all frequencies, the block reduction
-template <typename T> __host__ __device__ constexpr size_t pn_lds_bytes(int gmax, bool first_order = false)
+template <typename T> __host__ __device__ constexpr size_t pn_lds_bytes(int gmax, bool first_order = false, bool pair = false)
 {
     // (coefficient, fraction and floor of the grid place: three arrays -- one 16-byte record per frequency and a ds_read_b128 per
     // window value measured 36 % SLOWER at config 5: 2.23 against 1.64 ms at a constant velocity, same box)
     return (size_t)(own_pad(gmax) + 1) * 2 * sizeof(T) + (size_t)PN_NFMAX * (2 * sizeof(T) + sizeof(T) + 2) + 16 * 2 * PN_SHORT * sizeof(T) +
-           (first_order ? (size_t)(own_pad(gmax) + 1) * 2 * sizeof(float) : 0);
+           (first_order ? (size_t)(own_pad(gmax) + 1) * 2 * sizeof(float) : 0) + (pair ? (size_t)PN_NFMAX * 2 * sizeof(T) : 0);
 }
 
 // the float32 grid of the first-order term: own_fft_passes<float, true> with the twiddles of the float64 table
@@ -162,25 +162,40 @@ __device__ __forceinline__ double pn_window(double x)
 __device__ __forceinline__ void pn_sincos(double x, float *s, float *c) { pm_sincos(x, s, c); }
 __device__ __forceinline__ void pn_sincos(double x, double *s, double *c) { pss_sincos_small(pm_wrap(x), s, c); }
 
-template <typename T>
+// PAIR (round 6): the wavenumbers k and tnum - k in ONE transform.  Only the real part of the inverse transform over the wavenumbers
+// is kept (mig_python.py:282), so all that is needed of the rows TK[k], TK[tnum - k] is the Hermitian combination
+//     G[k] = (TK[k] + conj TK[tnum - k]) / 2 = 1/2 sum_w [ F_w(k) e^{+i Phi_w} + conj F_w(tnum - k) e^{-i Phi_w} ]
+// -- the phases depend on kx^2 only -- which is ONE non-uniform transform with the nodes +-phi_w: the regular frequencies' nodes
+// fill the grid's half [0, G/2] and left the other half empty; the mirrored ones fill it.  A thread owns the grid points m and -m:
+// the window value psi(u_w - m) serves a_w -> g[m] and b_w -> g[-m] (psi is even), the coefficients' sincos both rows', one FFT,
+// one output pass -- G to row k, conj G to row tnum - k, so that everything downstream sees a Hermitian TK and reads the same
+// image out of it.  The Nyquist row (w < 0: its node on the negative half) is, mirrored, the node that continues the positive
+// frequencies' sorted order: index nf - 1 with the two coefficients' roles swapped, and no special case is left in the gather.
+template <typename T, bool PAIR = false>
 __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(PnParams Q)
 {
+    static_assert(!PAIR || sizeof(T) == 4, "pairs: float32 (two float64 coefficient arrays do not fit beside the grid)");
     constexpr int PN_W = PnCfg<T>::W, PN_NTH = PnCfg<T>::NTH, PN_PER = PN_NFMAX / PN_NTH;
     extern __shared__ __attribute__((aligned(16))) unsigned char pn_lds[];
     const PsParams &P = Q.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nf = P.nf;
     // small |kx| (few evanescent frequencies: the long workgroups) first
-    const int bq = (int)blockIdx.x, kb = (bq & 1) ? P.nk - 1 - (bq >> 1) : (bq >> 1), k = P.k0 + kb;
+    // (PAIR: the whole axis, k = 0 .. tnum / 2 with its partner tnum - k; rows 0 and tnum / 2 are their own)
+    const int bq = (int)blockIdx.x, kb = PAIR ? bq : ((bq & 1) ? P.nk - 1 - (bq >> 1) : (bq >> 1)), k = P.k0 + kb;
+    const int k2 = PAIR ? (k == 0 ? 0 : P.nk - k) : k;
     OCp<T> *grid = reinterpret_cast<OCp<T> *>(pn_lds);                          // [own_pad(G)]
     OCp<T> *D = grid + own_pad(Q.gmax) + 1;                                         // [nf] coefficients, by index (float64)
     T *fr = reinterpret_cast<T *>(D + PN_NFMAX);                                        // [nf] u - floor(u)
     unsigned short *m0 = reinterpret_cast<unsigned short *>(fr + PN_NFMAX);             // [nf] floor(u)
     T *red = reinterpret_cast<T *>(m0 + PN_NFMAX);                                      // [waves][2 PN_SHORT] block reduction
     OCp<float> *grid2 = reinterpret_cast<OCp<float> *>(red + 16 * 2 * PN_SHORT);        // [own_pad(G) + 1] the first-order term's grid (Q.e1)
-    const bool fo = sizeof(T) == 8 && Q.e1 != nullptr;
+    OCp<T> *D2 = reinterpret_cast<OCp<T> *>(red + 16 * 2 * PN_SHORT);                   // PAIR (no first-order grid): [nf] the partner row's coefficients
+    const bool fo = !PAIR && sizeof(T) == 8 && Q.e1 != nullptr;
     const Cp<T> *Frow = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k * P.fstride;
+    const Cp<T> *Frow2 = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k2 * P.fstride;
     T *TKrow = reinterpret_cast<T *>(reinterpret_cast<Cp<T> *>(P.TK) + (size_t)kb * P.snum);
+    T *TKrow2 = reinterpret_cast<T *>(reinterpret_cast<Cp<T> *>(P.TK) + (size_t)k2 * P.snum);      // (PAIR: k0 = 0)
     const double kxk = P.kx[k];
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     const T inv_snum = (T)1 / (T)P.snum;
@@ -233,6 +248,10 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
             if (edge[j] && i < nf) {
                 const int at = atomicAdd(Q.edge_cnt + k, 1);
                 if (at < PM_EMAX) Q.edge_list[(size_t)k * PM_EMAX + at] = slot_of(i);
+                if (PAIR && k2 != k) {                                        // the partner's list: the same frequencies
+                    const int at2 = atomicAdd(Q.edge_cnt + k2, 1);
+                    if (at2 < PM_EMAX) Q.edge_list[(size_t)k2 * PM_EMAX + at2] = slot_of(i);
+                }
                 ph[j] = nan;
             }
         }
@@ -256,7 +275,13 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
                 const int i = tid + PN_NTH * j;
                 if (i >= nf || !(ph[j] == ph[j])) continue;
                 const int slot = slot_of(i);
-                const Cp<T> f = ps_load_slot<T>(Frow, P, slot);
+                Cp<T> f = ps_load_slot<T>(Frow, P, slot), fq = f;
+                if (PAIR) {
+                    // f1 e^{ip} + conj(f2) e^{-ip} = [(f1 + f2).x c - (f1 + f2).y s] + i [(f1 - f2).x s + (f1 - f2).y c]: the one sum's cost
+                    const Cp<T> f2 = ps_load_slot<T>(Frow2, P, slot);
+                    fq = Cp<T>{f.x - f2.x, f.y - f2.y};
+                    f = Cp<T>{f.x + f2.x, f.y + f2.y};
+                }
                 double p = ph[j];
 #pragma unroll
                 for (int s_ = 0; s_ < PN_SHORT; ++s_)
@@ -269,7 +294,7 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
                             T sn, c;
                             pn_sincos(p, &sn, &c);
                             acc[2 * s_] += fma(f.x, c, -(f.y * sn));
-                            acc[2 * s_ + 1] += fma(f.x, sn, f.y * c);
+                            acc[2 * s_ + 1] += fma(fq.x, sn, fq.y * c);
                         }
                     }
                 ph[j] = pm_wrap(p);                                           // NaN stays NaN
@@ -286,6 +311,10 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
                 T sum = 0;
 #pragma unroll
                 for (int q = 0; q < PN_NTH / 64; ++q) sum += red[q * 2 * PN_SHORT + tid];
+                if (PAIR) {
+                    sum *= (T)0.5;
+                    if (k2 != k) TKrow2[2 * (size_t)(pc.start + (tid >> 1)) + (tid & 1)] = (tid & 1) ? -(sum * inv_snum) : sum * inv_snum;
+                }
                 TKrow[2 * (size_t)(pc.start + (tid >> 1)) + (tid & 1)] = sum * inv_snum;      // :492
             }
             __syncthreads();
@@ -306,12 +335,16 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
             bool alive;
             const double inc = step_phase(slot, v, &alive);                   // (negative for the Nyquist row: w = -pi / dt)
             if (!alive) ph[j] = nan;
-            OCp<T> d{(T)0, (T)0};
+            OCp<T> d{(T)0, (T)0}, d2{(T)0, (T)0};
             if (ph[j] == ph[j]) {
                 const Cp<T> f = ps_load_slot<T>(Frow, P, slot);
                 T sn, c;
                 pn_sincos(ph[j] + (double)(1 + Lp / 2) * inc, &sn, &c);
                 d = OCp<T>{fma(f.x, c, -(f.y * sn)), fma(f.x, sn, f.y * c)};
+                if (PAIR) {
+                    const Cp<T> f2 = ps_load_slot<T>(Frow2, P, slot);       // the partner's, mirrored: conj(f2 e^{i theta})
+                    d2 = OCp<T>{fma(f2.x, c, -(f2.y * sn)), -fma(f2.x, sn, f2.y * c)};
+                }
                 double adv = (double)L * inc;
                 if (fo) {
                     // kappa_w (signed with the frequency: inc = +- dt psi) times E at the piece's last step
@@ -330,14 +363,67 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
             }
             // place on the grid: phi mod 2 pi in units of the grid spacing (dead frequencies: 0 -- they carry D = 0)
             double u = inc * ug;
-            u -= (double)G * floor(u / (double)G);
+            if (PAIR) {
+                // every node by its |phi|: the Nyquist row (inc < 0) trades places with its mirror image
+                const bool neg = u < 0.0;
+                u = fabs(u);
+                D[i] = neg ? d2 : d;
+                D2[i] = neg ? d : d2;
+            } else {
+                u -= (double)G * floor(u / (double)G);
+                D[i] = d;
+            }
             const double fl = floor(u);
-            D[i] = d;
             m0[i] = (unsigned short)min((int)fl, G - 1);
             fr[i] = (T)(u - fl);
         }
         __syncthreads();
-        {
+        if constexpr (PAIR) {
+            // gather over the points mm = -W/2 .. G/2 + W/2 that the nodes in [0, G/2] reach: A = sum D psi(u - mm) is g[mm],
+            // B = sum D2 psi(u - mm) is g[-mm].  The two index sets overlap at the ends (|mm| <= W/2, and around G/2): A is stored,
+            // B added after a barrier -- every sum in a fixed order, as before
+            const float cq = (float)(0.5 * v * kxk), c2 = cq * cq;
+            const float a = (float)(6.283185307179586 / ((double)G * P.dt)), a2 = a * a;
+            const int ilast = nf - 1, NE = G / 2 + PN_W + 1;
+            constexpr int NQ = (PnCfg<T>::LMAX + PN_W + 1 + PN_NTH - 1) / PN_NTH;
+            const PnWinF wk_;
+            T bx[NQ], by[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                bx[q] = by[q] = 0;
+                const int idx = tid + PN_NTH * q;
+                if (idx >= NE) continue;
+                const int mi = idx - PN_W / 2;
+                const float mm = (float)mi;
+                T gx = 0, gy = 0;
+                const float uhi = mm + 0.5f * PN_W, ulo = fmaxf(mm - 0.5f * PN_W, 0.f);
+                if (uhi > 0.f) {
+                    int ilo = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * ulo, ulo, c2)) * inv_dw) - 3;
+                    int ihi = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * uhi, uhi, c2)) * inv_dw) + 2;
+                    ilo = max(ilo, 0);
+                    ihi = min(ihi, ilast);
+                    for (int i = ilo; i <= ihi; ++i) {
+                        const T x = (T)((int)m0[i] - mi) + fr[i];
+                        const T wgt = pn_winT(x, wk_);
+                        const OCp<T> d = D[i], e = D2[i];
+                        gx = fma(d.x, wgt, gx);
+                        gy = fma(d.y, wgt, gy);
+                        bx[q] = fma(e.x, wgt, bx[q]);
+                        by[q] = fma(e.y, wgt, by[q]);
+                    }
+                }
+                grid[own_pad(mi & (G - 1))] = OCp<T>{gx, gy};
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int idx = tid + PN_NTH * q;
+                if (idx >= NE) continue;
+                const int at = own_pad((PN_W / 2 - idx) & (G - 1));
+                const OCp<T> g = grid[at];
+                grid[at] = OCp<T>{g.x + bx[q], g.y + by[q]};
+            }
+        } else {
             // gather: grid point m takes the frequencies with |u_w - m| < W/2.  Their indices from the dispersion relation:
             // u = (G dt / 2 pi) sqrt(w^2 - c^2), c = v kx / 2, w = (i + 1) dw  ->  i(u) = sqrt((2 pi u / G dt)^2 + c^2) / dw - 1
             const float cq = (float)(0.5 * v * kxk), c2 = cq * cq;
@@ -404,6 +490,11 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
                     const T e = (T)Q.e1[pc.start + n] * cf;
                     ox -= (T)z2.y * e;
                     oy += (T)z2.x * e;
+                }
+                if (PAIR) {
+                    ox *= (T)0.5;
+                    oy *= (T)0.5;
+                    if (k2 != k) reinterpret_cast<Cp<T> *>(TKrow2)[pc.start + n] = Cp<T>{ox, -oy};
                 }
                 reinterpret_cast<Cp<T> *>(TKrow)[pc.start + n] = Cp<T>{ox, oy};
             }
