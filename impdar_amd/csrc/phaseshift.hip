@@ -1801,18 +1801,14 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
             if (need[l]) lmax = l;
         Q.gmax = 2 << lmax;
     }
-    // the whole wavenumber axis with kx[tnum - k] = -kx[k] (float32): a pair of rows per workgroup, as ps_runs_kernel's
-    bool pairs = sizeof(T) == 4 && allow_pairs && P.k0 == 0 && P.nk == tnum && tnum >= 2 && tnum % 2 == 0;
+    // the whole wavenumber axis with kx[tnum - k] = -kx[k]: a pair of rows per workgroup, as ps_runs_kernel's
+    bool pairs = allow_pairs && P.k0 == 0 && P.nk == tnum && tnum >= 2 && tnum % 2 == 0;
     for (int k = 1; 2 * k < tnum && pairs; ++k) pairs = kx_host[k] == -kx_host[tnum - k];
-    if constexpr (sizeof(T) == 4) {
-        if (pairs) {
-            IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_nufft_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)pn_lds_bytes<float>(2 * PnCfg<float>::LMAX, false, true)));
-            hipLaunchKernelGGL((ps_nufft_kernel<float, true>), dim3((unsigned)(tnum / 2 + 1)), dim3(PnCfg<float>::NTH),
-                               pn_lds_bytes<float>(Q.gmax, false, true), st, Q);
-        }
-    }
-    if (!pairs) {
+    if (pairs) {
+        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_nufft_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)pn_lds_bytes<T>(2 * PnCfg<T>::LMAX, sizeof(T) == 8, true)));
+        hipLaunchKernelGGL((ps_nufft_kernel<T, true>), dim3((unsigned)(tnum / 2 + 1)), dim3(PnCfg<T>::NTH), pn_lds_bytes<T>(Q.gmax, first_order, true), st, Q);
+    } else {
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_nufft_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pn_lds_bytes<T>(2 * PnCfg<T>::LMAX, sizeof(T) == 8)));
         hipLaunchKernelGGL(ps_nufft_kernel<T>, dim3((unsigned)P.nk), dim3(PnCfg<T>::NTH), pn_lds_bytes<T>(Q.gmax, first_order), st, Q);
     }
@@ -2408,7 +2404,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         const int pref = me ? atoi(me) : 1;
         if (!vlen && pref != 0 && std::isfinite(vconst) && vconst != 0.0) {
             std::vector<PsMfmaRun> one{PsMfmaRun{vconst, 0, snum}};
-            if ((rc = ps_nufft_run<double>(pl, P, one, false, kx, w.data(), thr.data(), st, &mfma_done))) return rc;
+            if ((rc = ps_nufft_run<double>(pl, P, one, false, kx, w.data(), thr.data(), st, &mfma_done, nullptr, tk_out == nullptr))) return rc;
             if (mfma_done) mfma_kernel_name = "ps_nufft_kernel";
         }
         // a v(z) table of up to 16 thick layers: the transform path with the runs' velocity noise (~4e-13, cut at 1e-11) as its
@@ -2425,7 +2421,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             for (const PsMfmaRun &r : mruns) nlong += r.len > PM_SHORT;
             long_runs = nlong;
             if (ok && (pref == 6 || nlong <= 16)) {
-                if ((rc = ps_nufft_run<double>(pl, P, mruns, true, kx, w.data(), thr.data(), st, &mfma_done, vmig))) return rc;
+                if ((rc = ps_nufft_run<double>(pl, P, mruns, true, kx, w.data(), thr.data(), st, &mfma_done, vmig, tk_out == nullptr))) return rc;
                 if (mfma_done) mfma_kernel_name = "ps_nufft_kernel";
             }
         }

@@ -70,12 +70,14 @@ struct PnParams {
 };
 
 // LDS: the grid of the call's longest piece (gmax points), then coefficients / grid places of all frequencies, the block reduction
+// float64 pairs take the frequencies in two halves (two float64 coefficient arrays of 4096 do not fit beside the grids)
+template <typename T> __host__ __device__ constexpr int pn_halves(bool pair) { return pair && sizeof(T) == 8 ? 2 : 1; }
 template <typename T> __host__ __device__ constexpr size_t pn_lds_bytes(int gmax, bool first_order = false, bool pair = false)
 {
     // (coefficient, fraction and floor of the grid place: three arrays -- one 16-byte record per frequency and a ds_read_b128 per
     // window value measured 36 % SLOWER at config 5: 2.23 against 1.64 ms at a constant velocity, same box)
-    return (size_t)(own_pad(gmax) + 1) * 2 * sizeof(T) + (size_t)PN_NFMAX * (2 * sizeof(T) + sizeof(T) + 2) + 16 * 2 * PN_SHORT * sizeof(T) +
-           (first_order ? (size_t)(own_pad(gmax) + 1) * 2 * sizeof(float) : 0) + (pair ? (size_t)PN_NFMAX * 2 * sizeof(T) : 0);
+    return (size_t)(own_pad(gmax) + 1) * 2 * sizeof(T) + (size_t)(PN_NFMAX / pn_halves<T>(pair)) * ((pair ? 4 : 2) * sizeof(T) + sizeof(T) + 2) +
+           16 * 2 * PN_SHORT * sizeof(T) + (first_order ? (size_t)(own_pad(gmax) + 1) * 2 * sizeof(float) : 0);
 }
 
 // the float32 grid of the first-order term: own_fft_passes<float, true> with the twiddles of the float64 table
@@ -174,8 +176,8 @@ __device__ __forceinline__ void pn_sincos(double x, double *s, double *c) { pss_
 template <typename T, bool PAIR = false>
 __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(PnParams Q)
 {
-    static_assert(!PAIR || sizeof(T) == 4, "pairs: float32 (two float64 coefficient arrays do not fit beside the grid)");
     constexpr int PN_W = PnCfg<T>::W, PN_NTH = PnCfg<T>::NTH, PN_PER = PN_NFMAX / PN_NTH;
+    constexpr int PN_NH = pn_halves<T>(PAIR), PN_NFH = PN_NFMAX / PN_NH;     // the frequencies whose coefficients LDS holds at a time
     extern __shared__ __attribute__((aligned(16))) unsigned char pn_lds[];
     const PsParams &P = Q.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -185,13 +187,13 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
     const int bq = (int)blockIdx.x, kb = PAIR ? bq : ((bq & 1) ? P.nk - 1 - (bq >> 1) : (bq >> 1)), k = P.k0 + kb;
     const int k2 = PAIR ? (k == 0 ? 0 : P.nk - k) : k;
     OCp<T> *grid = reinterpret_cast<OCp<T> *>(pn_lds);                          // [own_pad(G)]
-    OCp<T> *D = grid + own_pad(Q.gmax) + 1;                                         // [nf] coefficients, by index (float64)
-    T *fr = reinterpret_cast<T *>(D + PN_NFMAX);                                        // [nf] u - floor(u)
-    unsigned short *m0 = reinterpret_cast<unsigned short *>(fr + PN_NFMAX);             // [nf] floor(u)
-    T *red = reinterpret_cast<T *>(m0 + PN_NFMAX);                                      // [waves][2 PN_SHORT] block reduction
+    OCp<T> *D = grid + own_pad(Q.gmax) + 1;                                         // [PN_NFH] coefficients, by index
+    OCp<T> *D2 = D + (PAIR ? PN_NFH : 0);                                               // PAIR: [PN_NFH] the partner row's, mirrored
+    T *fr = reinterpret_cast<T *>(D + (PAIR ? 2 : 1) * PN_NFH);                         // [PN_NFH] u - floor(u)
+    unsigned short *m0 = reinterpret_cast<unsigned short *>(fr + PN_NFH);               // [PN_NFH] floor(u)
+    T *red = reinterpret_cast<T *>(m0 + PN_NFH);                                        // [waves][2 PN_SHORT] block reduction
     OCp<float> *grid2 = reinterpret_cast<OCp<float> *>(red + 16 * 2 * PN_SHORT);        // [own_pad(G) + 1] the first-order term's grid (Q.e1)
-    OCp<T> *D2 = reinterpret_cast<OCp<T> *>(red + 16 * 2 * PN_SHORT);                   // PAIR (no first-order grid): [nf] the partner row's coefficients
-    const bool fo = !PAIR && sizeof(T) == 8 && Q.e1 != nullptr;
+    const bool fo = sizeof(T) == 8 && Q.e1 != nullptr;
     const Cp<T> *Frow = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k * P.fstride;
     const Cp<T> *Frow2 = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k2 * P.fstride;
     T *TKrow = reinterpret_cast<T *>(reinterpret_cast<Cp<T> *>(P.TK) + (size_t)kb * P.snum);
@@ -324,152 +326,184 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
         const int Lp = 1 << pc.loglp, G = 2 * Lp, logg = pc.loglp + 1;
         const double ug = (double)G * 0.15915494309189535;                    // G / 2 pi
         for (int m = tid; m < own_pad(G) + 1; m += PN_NTH) grid[m] = OCp<T>{(T)0, (T)0};
+        if (PAIR && fo)
+            for (int m = tid; m < own_pad(G) + 1; m += PN_NTH) grid2[m] = OCp<float>{0.f, 0.f};
         // first-order term: kappa_w = -dt / 2 psi_w = kc / u_w (u = psi dt G / 2 pi: kc = -dt^2 G (v kx / 2)^2 ... / 4 pi), per unit of E / cbar^2
         const double c2d = 0.25 * v * v * kxk * kxk;
         const float kc = (float)(-P.dt * P.dt * (double)G * c2d / 12.566370614359172);
+        // gather: grid point m takes the frequencies with |u_w - m| < W/2.  Their indices from the dispersion relation:
+        // u = (G dt / 2 pi) sqrt(w^2 - c^2), c = v kx / 2, w = (i + 1) dw  ->  i(u) = sqrt((2 pi u / G dt)^2 + c^2) / dw - 1
+        const float cq = (float)(0.5 * v * kxk), c2 = cq * cq;
+        const float a = (float)(6.283185307179586 / ((double)G * P.dt)), a2 = a * a;
+        const PnWinF wk_;
+        // PAIR: what a thread keeps of its points between the two phases of a half (NE = G/2 + W + 1 points, below)
+        constexpr int NQ = PAIR ? (PnCfg<T>::LMAX + PN_W + 1 + PN_NTH - 1) / PN_NTH : 1;
+        T bx[NQ], by[NQ];
+        float b2x[NQ], b2y[NQ];
 #pragma unroll
-        for (int j = 0; j < PN_PER; ++j) {
-            const int i = tid + PN_NTH * j;
-            if (i >= nf) continue;
-            const int slot = slot_of(i);
-            bool alive;
-            const double inc = step_phase(slot, v, &alive);                   // (negative for the Nyquist row: w = -pi / dt)
-            if (!alive) ph[j] = nan;
-            OCp<T> d{(T)0, (T)0}, d2{(T)0, (T)0};
-            if (ph[j] == ph[j]) {
-                const Cp<T> f = ps_load_slot<T>(Frow, P, slot);
-                T sn, c;
-                pn_sincos(ph[j] + (double)(1 + Lp / 2) * inc, &sn, &c);
-                d = OCp<T>{fma(f.x, c, -(f.y * sn)), fma(f.x, sn, f.y * c)};
+        for (int h = 0; h < PN_NH; ++h) {
+            // (PN_NH = 2, float64 pairs: the frequencies in two halves -- LDS holds the coefficients of 2048 pairs beside the grids)
+            if (h) __syncthreads();
+#pragma unroll
+            for (int jj = 0; jj < PN_PER / PN_NH; ++jj) {
+                const int j = h * (PN_PER / PN_NH) + jj;
+                const int i = tid + PN_NTH * j, il = i - h * PN_NFH;
+                if (i >= nf) continue;
+                const int slot = slot_of(i);
+                bool alive;
+                const double inc = step_phase(slot, v, &alive);                   // (negative for the Nyquist row: w = -pi / dt)
+                if (!alive) ph[j] = nan;
+                OCp<T> d{(T)0, (T)0}, d2{(T)0, (T)0};
+                if (ph[j] == ph[j]) {
+                    const Cp<T> f = ps_load_slot<T>(Frow, P, slot);
+                    T sn, c;
+                    pn_sincos(ph[j] + (double)(1 + Lp / 2) * inc, &sn, &c);
+                    d = OCp<T>{fma(f.x, c, -(f.y * sn)), fma(f.x, sn, f.y * c)};
+                    if (PAIR) {
+                        const Cp<T> f2 = ps_load_slot<T>(Frow2, P, slot);       // the partner's, mirrored: conj(f2 e^{i theta})
+                        d2 = OCp<T>{fma(f2.x, c, -(f2.y * sn)), -fma(f2.x, sn, f2.y * c)};
+                    }
+                    double adv = (double)L * inc;
+                    if (fo) {
+                        // kappa_w (signed with the frequency: inc = +- dt psi) times E at the piece's last step
+                        const double kap = -P.dt * P.dt * c2d / (2.0 * inc);
+                        adv += kap * Q.e1[pc.start + L - 1];
+                        if (!PAIR && i == nf - 1) {                               // the Nyquist row's second coefficient (its u is wrapped)
+                            float *dn2 = reinterpret_cast<float *>(red);
+                            dn2[0] = (float)((double)d.x * kap);
+                            dn2[1] = (float)((double)d.y * kap);
+                        }
+                    }
+                    ph[j] = pm_wrap(ph[j] + adv);
+                } else if (!PAIR && fo && i == nf - 1) {
+                    float *dn2 = reinterpret_cast<float *>(red);
+                    dn2[0] = dn2[1] = 0.f;
+                }
+                // place on the grid: phi mod 2 pi in units of the grid spacing (dead frequencies: 0 -- they carry D = 0)
+                double u = inc * ug;
                 if (PAIR) {
-                    const Cp<T> f2 = ps_load_slot<T>(Frow2, P, slot);       // the partner's, mirrored: conj(f2 e^{i theta})
-                    d2 = OCp<T>{fma(f2.x, c, -(f2.y * sn)), -fma(f2.x, sn, f2.y * c)};
+                    // every node by its |phi|: the Nyquist row (inc < 0) trades places with its mirror image
+                    const bool neg = u < 0.0;
+                    u = fabs(u);
+                    D[il] = neg ? d2 : d;
+                    D2[il] = neg ? d : d2;
+                } else {
+                    u -= (double)G * floor(u / (double)G);
+                    D[il] = d;
                 }
-                double adv = (double)L * inc;
-                if (fo) {
-                    // kappa_w (signed with the frequency: inc = +- dt psi) times E at the piece's last step
-                    const double kap = -P.dt * P.dt * c2d / (2.0 * inc);
-                    adv += kap * Q.e1[pc.start + L - 1];
-                    if (i == nf - 1) {                                        // the Nyquist row's second coefficient (its u is wrapped)
-                        float *dn2 = reinterpret_cast<float *>(red);
-                        dn2[0] = (float)((double)d.x * kap);
-                        dn2[1] = (float)((double)d.y * kap);
-                    }
-                }
-                ph[j] = pm_wrap(ph[j] + adv);
-            } else if (fo && i == nf - 1) {
-                float *dn2 = reinterpret_cast<float *>(red);
-                dn2[0] = dn2[1] = 0.f;
-            }
-            // place on the grid: phi mod 2 pi in units of the grid spacing (dead frequencies: 0 -- they carry D = 0)
-            double u = inc * ug;
-            if (PAIR) {
-                // every node by its |phi|: the Nyquist row (inc < 0) trades places with its mirror image
-                const bool neg = u < 0.0;
-                u = fabs(u);
-                D[i] = neg ? d2 : d;
-                D2[i] = neg ? d : d2;
-            } else {
-                u -= (double)G * floor(u / (double)G);
-                D[i] = d;
-            }
-            const double fl = floor(u);
-            m0[i] = (unsigned short)min((int)fl, G - 1);
-            fr[i] = (T)(u - fl);
-        }
-        __syncthreads();
-        if constexpr (PAIR) {
-            // gather over the points mm = -W/2 .. G/2 + W/2 that the nodes in [0, G/2] reach: A = sum D psi(u - mm) is g[mm],
-            // B = sum D2 psi(u - mm) is g[-mm].  The two index sets overlap at the ends (|mm| <= W/2, and around G/2): A is stored,
-            // B added after a barrier -- every sum in a fixed order, as before
-            const float cq = (float)(0.5 * v * kxk), c2 = cq * cq;
-            const float a = (float)(6.283185307179586 / ((double)G * P.dt)), a2 = a * a;
-            const int ilast = nf - 1, NE = G / 2 + PN_W + 1;
-            constexpr int NQ = (PnCfg<T>::LMAX + PN_W + 1 + PN_NTH - 1) / PN_NTH;
-            const PnWinF wk_;
-            T bx[NQ], by[NQ];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                bx[q] = by[q] = 0;
-                const int idx = tid + PN_NTH * q;
-                if (idx >= NE) continue;
-                const int mi = idx - PN_W / 2;
-                const float mm = (float)mi;
-                T gx = 0, gy = 0;
-                const float uhi = mm + 0.5f * PN_W, ulo = fmaxf(mm - 0.5f * PN_W, 0.f);
-                if (uhi > 0.f) {
-                    int ilo = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * ulo, ulo, c2)) * inv_dw) - 3;
-                    int ihi = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * uhi, uhi, c2)) * inv_dw) + 2;
-                    ilo = max(ilo, 0);
-                    ihi = min(ihi, ilast);
-                    for (int i = ilo; i <= ihi; ++i) {
-                        const T x = (T)((int)m0[i] - mi) + fr[i];
-                        const T wgt = pn_winT(x, wk_);
-                        const OCp<T> d = D[i], e = D2[i];
-                        gx = fma(d.x, wgt, gx);
-                        gy = fma(d.y, wgt, gy);
-                        bx[q] = fma(e.x, wgt, bx[q]);
-                        by[q] = fma(e.y, wgt, by[q]);
-                    }
-                }
-                grid[own_pad(mi & (G - 1))] = OCp<T>{gx, gy};
+                const double fl = floor(u);
+                m0[il] = (unsigned short)min((int)fl, G - 1);
+                fr[il] = (T)(u - fl);
             }
             __syncthreads();
+            if constexpr (PAIR) {
+                // gather over the points mm = -W/2 .. G/2 + W/2 that the nodes in [0, G/2] reach: A = sum D psi(u - mm) is g[mm],
+                // B = sum D2 psi(u - mm) is g[-mm].  The two index sets overlap at the ends (|mm| <= W/2, and around G/2): A is
+                // stored (added by a second half), B added after a barrier -- every sum in a fixed order, as before.  First-order
+                // term: kappa = kc / u at the node +u, -kc / u at its mirror image
+                const int i0 = h * PN_NFH, i1 = min(nf, i0 + PN_NFH) - 1, NE = G / 2 + PN_W + 1;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int idx = tid + PN_NTH * q;
-                if (idx >= NE) continue;
-                const int at = own_pad((PN_W / 2 - idx) & (G - 1));
-                const OCp<T> g = grid[at];
-                grid[at] = OCp<T>{g.x + bx[q], g.y + by[q]};
-            }
-        } else {
-            // gather: grid point m takes the frequencies with |u_w - m| < W/2.  Their indices from the dispersion relation:
-            // u = (G dt / 2 pi) sqrt(w^2 - c^2), c = v kx / 2, w = (i + 1) dw  ->  i(u) = sqrt((2 pi u / G dt)^2 + c^2) / dw - 1
-            const float cq = (float)(0.5 * v * kxk), c2 = cq * cq;
-            const float a = (float)(6.283185307179586 / ((double)G * P.dt)), a2 = a * a;
-            const int ilast = nf - 2;                                         // regular frequencies: indices 0 .. nf - 2
-            // the Nyquist row (index nf - 1): anywhere on the grid, looked at by every grid point
-            const T uN = (T)m0[nf - 1] + fr[nf - 1];
-            const OCp<T> dN = D[nf - 1];
-            const PnWinF wk_;
-            for (int m = tid; m < G; m += PN_NTH) {
-                const float mm = (float)(m > G / 2 + PN_W / 2 ? m - G : m);  // centred: the regular frequencies sit in [0, G/2], reach W/2 to either side (G >= 32 > 2 W)
-                T gx = 0, gy = 0;
-                float hx = 0.f, hy = 0.f;                                    // the first-order term's grid point (float32)
-                const float uhi = mm + 0.5f * PN_W, ulo = fmaxf(mm - 0.5f * PN_W, 0.f);
-                if (uhi > 0.f) {
-                    int ilo = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * ulo, ulo, c2)) * inv_dw) - 3;
-                    int ihi = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * uhi, uhi, c2)) * inv_dw) + 2;
-                    ilo = max(ilo, 0);
-                    ihi = min(ihi, ilast);
-                    for (int i = ilo; i <= ihi; ++i) {
-                        const T x = (T)((int)m0[i] - (int)mm) + fr[i];
-                        const T wgt = pn_winT(x, wk_);
-                        const OCp<T> d = D[i];
-                        gx = fma(d.x, wgt, gx);
-                        gy = fma(d.y, wgt, gy);
+                for (int q = 0; q < NQ; ++q) {
+                    bx[q] = by[q] = 0;
+                    b2x[q] = b2y[q] = 0.f;
+                    const int idx = tid + PN_NTH * q;
+                    if (idx >= NE) continue;
+                    const int mi = idx - PN_W / 2;
+                    const float mm = (float)mi;
+                    T gx = 0, gy = 0;
+                    float hx = 0.f, hy = 0.f;
+                    const float uhi = mm + 0.5f * PN_W, ulo = fmaxf(mm - 0.5f * PN_W, 0.f);
+                    if (uhi > 0.f) {
+                        int ilo = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * ulo, ulo, c2)) * inv_dw) - 3;
+                        int ihi = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * uhi, uhi, c2)) * inv_dw) + 2;
+                        ilo = max(ilo, i0);
+                        ihi = min(ihi, i1);
+                        for (int i = ilo - i0; i <= ihi - i0; ++i) {
+                            const T x = (T)((int)m0[i] - mi) + fr[i];
+                            const T wgt = pn_winT(x, wk_);
+                            const OCp<T> d = D[i], e = D2[i];
+                            gx = fma(d.x, wgt, gx);
+                            gy = fma(d.y, wgt, gy);
+                            bx[q] = fma(e.x, wgt, bx[q]);
+                            by[q] = fma(e.y, wgt, by[q]);
+                            if (fo) {
+                                const float wk = (float)wgt * kc * __builtin_amdgcn_rcpf(fmaxf((float)m0[i] + (float)fr[i], 1e-3f));
+                                hx = fmaf((float)d.x, wk, hx);
+                                hy = fmaf((float)d.y, wk, hy);
+                                b2x[q] = fmaf(-(float)e.x, wk, b2x[q]);
+                                b2y[q] = fmaf(-(float)e.y, wk, b2y[q]);
+                            }
+                        }
+                    }
+                    const int at = own_pad(mi & (G - 1));
+                    if (h == 0) {
+                        grid[at] = OCp<T>{gx, gy};
+                        if (fo) grid2[at] = OCp<float>{hx, hy};
+                    } else {
+                        const OCp<T> g = grid[at];
+                        grid[at] = OCp<T>{g.x + gx, g.y + gy};
                         if (fo) {
-                            const float wk = (float)wgt * kc * __builtin_amdgcn_rcpf(fmaxf((float)m0[i] + (float)fr[i], 1e-3f));
-                            hx = fmaf((float)d.x, wk, hx);
-                            hy = fmaf((float)d.y, wk, hy);
+                            const OCp<float> g2 = grid2[at];
+                            grid2[at] = OCp<float>{g2.x + hx, g2.y + hy};
                         }
                     }
                 }
-                {
-                    T x = uN - (T)m;
-                    x -= (T)G * rint(x / (T)G);
-                    const T wgt = pn_window(x);
-                    gx = fma(dN.x, wgt, gx);
-                    gy = fma(dN.y, wgt, gy);
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int idx = tid + PN_NTH * q;
+                    if (idx >= NE) continue;
+                    const int at = own_pad((PN_W / 2 - idx) & (G - 1));
+                    const OCp<T> g = grid[at];
+                    grid[at] = OCp<T>{g.x + bx[q], g.y + by[q]};
                     if (fo) {
-                        const float *dn2 = reinterpret_cast<const float *>(red);
-                        hx = fmaf(dn2[0], (float)wgt, hx);
-                        hy = fmaf(dn2[1], (float)wgt, hy);
+                        const OCp<float> g2 = grid2[at];
+                        grid2[at] = OCp<float>{g2.x + b2x[q], g2.y + b2y[q]};
                     }
                 }
-                grid[own_pad(m)] = OCp<T>{gx, gy};
-                if (fo) grid2[own_pad(m)] = OCp<float>{hx, hy};
+            } else {
+                const int ilast = nf - 2;                                         // regular frequencies: indices 0 .. nf - 2
+                // the Nyquist row (index nf - 1): anywhere on the grid, looked at by every grid point
+                const T uN = (T)m0[nf - 1] + fr[nf - 1];
+                const OCp<T> dN = D[nf - 1];
+                for (int m = tid; m < G; m += PN_NTH) {
+                    const float mm = (float)(m > G / 2 + PN_W / 2 ? m - G : m);  // centred: the regular frequencies sit in [0, G/2], reach W/2 to either side (G >= 32 > 2 W)
+                    T gx = 0, gy = 0;
+                    float hx = 0.f, hy = 0.f;                                    // the first-order term's grid point (float32)
+                    const float uhi = mm + 0.5f * PN_W, ulo = fmaxf(mm - 0.5f * PN_W, 0.f);
+                    if (uhi > 0.f) {
+                        int ilo = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * ulo, ulo, c2)) * inv_dw) - 3;
+                        int ihi = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * uhi, uhi, c2)) * inv_dw) + 2;
+                        ilo = max(ilo, 0);
+                        ihi = min(ihi, ilast);
+                        for (int i = ilo; i <= ihi; ++i) {
+                            const T x = (T)((int)m0[i] - (int)mm) + fr[i];
+                            const T wgt = pn_winT(x, wk_);
+                            const OCp<T> d = D[i];
+                            gx = fma(d.x, wgt, gx);
+                            gy = fma(d.y, wgt, gy);
+                            if (fo) {
+                                const float wk = (float)wgt * kc * __builtin_amdgcn_rcpf(fmaxf((float)m0[i] + (float)fr[i], 1e-3f));
+                                hx = fmaf((float)d.x, wk, hx);
+                                hy = fmaf((float)d.y, wk, hy);
+                            }
+                        }
+                    }
+                    {
+                        T x = uN - (T)m;
+                        x -= (T)G * rint(x / (T)G);
+                        const T wgt = pn_window(x);
+                        gx = fma(dN.x, wgt, gx);
+                        gy = fma(dN.y, wgt, gy);
+                        if (fo) {
+                            const float *dn2 = reinterpret_cast<const float *>(red);
+                            hx = fmaf(dn2[0], (float)wgt, hx);
+                            hy = fmaf(dn2[1], (float)wgt, hy);
+                        }
+                    }
+                    grid[own_pad(m)] = OCp<T>{gx, gy};
+                    if (fo) grid2[own_pad(m)] = OCp<float>{hx, hy};
+                }
             }
         }
         __syncthreads();
