@@ -325,9 +325,8 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
         // ---- a piece of a long run: coefficients and grid places, spreading, inverse FFT, window divided out
         const int Lp = 1 << pc.loglp, G = 2 * Lp, logg = pc.loglp + 1;
         const double ug = (double)G * 0.15915494309189535;                    // G / 2 pi
-        for (int m = tid; m < own_pad(G) + 1; m += PN_NTH) grid[m] = OCp<T>{(T)0, (T)0};
-        if (PAIR && fo)
-            for (int m = tid; m < own_pad(G) + 1; m += PN_NTH) grid2[m] = OCp<float>{0.f, 0.f};
+        if (!PAIR)                                                            // (PAIR: the two gathers store every grid point)
+            for (int m = tid; m < own_pad(G) + 1; m += PN_NTH) grid[m] = OCp<T>{(T)0, (T)0};
         // first-order term: kappa_w = -dt / 2 psi_w = kc / u_w (u = psi dt G / 2 pi: kc = -dt^2 G (v kx / 2)^2 ... / 4 pi), per unit of E / cbar^2
         const double c2d = 0.25 * v * v * kxk * kxk;
         const float kc = (float)(-P.dt * P.dt * (double)G * c2d / 12.566370614359172);
@@ -336,10 +335,6 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
         const float cq = (float)(0.5 * v * kxk), c2 = cq * cq;
         const float a = (float)(6.283185307179586 / ((double)G * P.dt)), a2 = a * a;
         const PnWinF wk_;
-        // PAIR: what a thread keeps of its points between the two phases of a half (NE = G/2 + W + 1 points, below)
-        constexpr int NQ = PAIR ? (PnCfg<T>::LMAX + PN_W + 1 + PN_NTH - 1) / PN_NTH : 1;
-        T bx[NQ], by[NQ];
-        float b2x[NQ], b2y[NQ];
 #pragma unroll
         for (int h = 0; h < PN_NH; ++h) {
             // (PN_NH = 2, float64 pairs: the frequencies in two halves -- LDS holds the coefficients of 2048 pairs beside the grids)
@@ -398,20 +393,19 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
             __syncthreads();
             if constexpr (PAIR) {
                 // gather over the points mm = -W/2 .. G/2 + W/2 that the nodes in [0, G/2] reach: A = sum D psi(u - mm) is g[mm],
-                // B = sum D2 psi(u - mm) is g[-mm].  The two index sets overlap at the ends (|mm| <= W/2, and around G/2): A is
-                // stored (added by a second half), B added after a barrier -- every sum in a fixed order, as before.  First-order
-                // term: kappa = kc / u at the node +u, -kc / u at its mirror image
+                // B = sum D2 psi(u - mm) is g[-mm].  The two index sets cover the grid and overlap in two strips (|mm| <= W/2 and
+                // |mm - G/2| <= W/2): there B waits in registers for a barrier and is added; elsewhere it is stored at once (a second
+                // half of the frequencies adds) -- every sum in a fixed order, as before.  First-order term: kappa = kc / u at the
+                // node +u, -kc / u at its mirror image
                 const int i0 = h * PN_NFH, i1 = min(nf, i0 + PN_NFH) - 1, NE = G / 2 + PN_W + 1;
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    bx[q] = by[q] = 0;
-                    b2x[q] = b2y[q] = 0.f;
-                    const int idx = tid + PN_NTH * q;
-                    if (idx >= NE) continue;
+                T s0x = 0, s0y = 0, s1x = 0, s1y = 0;
+                float t0x = 0.f, t0y = 0.f, t1x = 0.f, t1y = 0.f;
+                int at0 = -1, at1 = -1;
+                for (int idx = tid; idx < NE; idx += PN_NTH) {
                     const int mi = idx - PN_W / 2;
                     const float mm = (float)mi;
-                    T gx = 0, gy = 0;
-                    float hx = 0.f, hy = 0.f;
+                    T gx = 0, gy = 0, bx = 0, by = 0;
+                    float hx = 0.f, hy = 0.f, b2x = 0.f, b2y = 0.f;
                     const float uhi = mm + 0.5f * PN_W, ulo = fmaxf(mm - 0.5f * PN_W, 0.f);
                     if (uhi > 0.f) {
                         int ilo = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * ulo, ulo, c2)) * inv_dw) - 3;
@@ -424,21 +418,26 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
                             const OCp<T> d = D[i], e = D2[i];
                             gx = fma(d.x, wgt, gx);
                             gy = fma(d.y, wgt, gy);
-                            bx[q] = fma(e.x, wgt, bx[q]);
-                            by[q] = fma(e.y, wgt, by[q]);
+                            bx = fma(e.x, wgt, bx);
+                            by = fma(e.y, wgt, by);
                             if (fo) {
                                 const float wk = (float)wgt * kc * __builtin_amdgcn_rcpf(fmaxf((float)m0[i] + (float)fr[i], 1e-3f));
                                 hx = fmaf((float)d.x, wk, hx);
                                 hy = fmaf((float)d.y, wk, hy);
-                                b2x[q] = fmaf(-(float)e.x, wk, b2x[q]);
-                                b2y[q] = fmaf(-(float)e.y, wk, b2y[q]);
+                                b2x = fmaf(-(float)e.x, wk, b2x);
+                                b2y = fmaf(-(float)e.y, wk, b2y);
                             }
                         }
                     }
-                    const int at = own_pad(mi & (G - 1));
+                    const int at = own_pad(mi & (G - 1)), atb = own_pad((-mi) & (G - 1));
+                    const bool low = mi <= PN_W / 2, high = mi >= G / 2 - PN_W / 2;
                     if (h == 0) {
                         grid[at] = OCp<T>{gx, gy};
                         if (fo) grid2[at] = OCp<float>{hx, hy};
+                        if (!low && !high) {
+                            grid[atb] = OCp<T>{bx, by};
+                            if (fo) grid2[atb] = OCp<float>{b2x, b2y};
+                        }
                     } else {
                         const OCp<T> g = grid[at];
                         grid[at] = OCp<T>{g.x + gx, g.y + gy};
@@ -446,19 +445,36 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
                             const OCp<float> g2 = grid2[at];
                             grid2[at] = OCp<float>{g2.x + hx, g2.y + hy};
                         }
+                        if (!low && !high) {
+                            const OCp<T> gb = grid[atb];
+                            grid[atb] = OCp<T>{gb.x + bx, gb.y + by};
+                            if (fo) {
+                                const OCp<float> g2 = grid2[atb];
+                                grid2[atb] = OCp<float>{g2.x + b2x, g2.y + b2y};
+                            }
+                        }
+                    }
+                    if (low) {
+                        s0x = bx, s0y = by, t0x = b2x, t0y = b2y, at0 = atb;
+                    } else if (high) {
+                        s1x = bx, s1y = by, t1x = b2x, t1y = b2y, at1 = atb;
                     }
                 }
                 __syncthreads();
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const int idx = tid + PN_NTH * q;
-                    if (idx >= NE) continue;
-                    const int at = own_pad((PN_W / 2 - idx) & (G - 1));
-                    const OCp<T> g = grid[at];
-                    grid[at] = OCp<T>{g.x + bx[q], g.y + by[q]};
+                if (at0 >= 0) {
+                    const OCp<T> g = grid[at0];
+                    grid[at0] = OCp<T>{g.x + s0x, g.y + s0y};
                     if (fo) {
-                        const OCp<float> g2 = grid2[at];
-                        grid2[at] = OCp<float>{g2.x + b2x[q], g2.y + b2y[q]};
+                        const OCp<float> g2 = grid2[at0];
+                        grid2[at0] = OCp<float>{g2.x + t0x, g2.y + t0y};
+                    }
+                }
+                if (at1 >= 0) {
+                    const OCp<T> g = grid[at1];
+                    grid[at1] = OCp<T>{g.x + s1x, g.y + s1y};
+                    if (fo) {
+                        const OCp<float> g2 = grid2[at1];
+                        grid2[at1] = OCp<float>{g2.x + t1x, g2.y + t1y};
                     }
                 }
             } else {
