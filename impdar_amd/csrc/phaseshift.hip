@@ -1708,6 +1708,10 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
     for (int i = 1; i < nf; ++i)
         if (std::fabs(w_host[i] - (double)i * dw) > 1e-9 * (double)i * dw) return IMPDAR_OK;
     if (std::fabs(std::fabs(w_host[0]) - (double)nf * dw) > 1e-9 * (double)nf * dw) return IMPDAR_OK;
+    // the whole wavenumber axis with kx[tnum - k] = -kx[k]: a pair of rows per workgroup, as ps_runs_kernel's
+    bool pairs = allow_pairs && P.k0 == 0 && P.nk == tnum && tnum >= 2 && tnum % 2 == 0;
+    for (int k = 1; 2 * k < tnum && pairs; ++k) pairs = kx_host[k] == -kx_host[tnum - k];
+    const int lmax_steps = pn_lmax<T>(pairs);
     std::vector<PnPiece> pc;
     int nshort_steps = 0;
     bool need[13] = {};
@@ -1725,7 +1729,7 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
             }
             continue;
         }
-        const int npiece = (r.len + PnCfg<T>::LMAX - 1) / PnCfg<T>::LMAX;
+        const int npiece = (r.len + lmax_steps - 1) / lmax_steps;
         for (int i = 0, at = 0; i < npiece; ++i) {
             const int len = (r.len - at) / (npiece - i);
             int l = 4;
@@ -1801,12 +1805,9 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
             if (need[l]) lmax = l;
         Q.gmax = 2 << lmax;
     }
-    // the whole wavenumber axis with kx[tnum - k] = -kx[k]: a pair of rows per workgroup, as ps_runs_kernel's
-    bool pairs = allow_pairs && P.k0 == 0 && P.nk == tnum && tnum >= 2 && tnum % 2 == 0;
-    for (int k = 1; 2 * k < tnum && pairs; ++k) pairs = kx_host[k] == -kx_host[tnum - k];
     if (pairs) {
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_nufft_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)pn_lds_bytes<T>(2 * PnCfg<T>::LMAX, sizeof(T) == 8, true)));
+                                             (int)pn_lds_bytes<T>(2 * pn_lmax<T>(true), sizeof(T) == 8, true)));
         hipLaunchKernelGGL((ps_nufft_kernel<T, true>), dim3((unsigned)(tnum / 2 + 1)), dim3(PnCfg<T>::NTH), pn_lds_bytes<T>(Q.gmax, first_order, true), st, Q);
     } else {
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_nufft_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pn_lds_bytes<T>(2 * PnCfg<T>::LMAX, sizeof(T) == 8)));

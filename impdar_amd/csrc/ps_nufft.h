@@ -70,8 +70,11 @@ struct PnParams {
 };
 
 // LDS: the grid of the call's longest piece (gmax points), then coefficients / grid places of all frequencies, the block reduction
-// float64 pairs take the frequencies in two halves (two float64 coefficient arrays of 4096 do not fit beside the grids)
-template <typename T> __host__ __device__ constexpr int pn_halves(bool pair) { return pair && sizeof(T) == 8 ? 2 : 1; }
+// float64 pairs take the frequencies a quarter at a time (two float64 coefficient arrays of 4096 do not fit beside the grids), and
+// with a quarter's arrays LDS has room for pieces of 2048 steps: half as many pieces, and a piece's cost -- coefficients, window
+// values -- does not depend on its length
+template <typename T> __host__ __device__ constexpr int pn_halves(bool pair) { return pair && sizeof(T) == 8 ? 4 : 1; }
+template <typename T> __host__ __device__ constexpr int pn_lmax(bool pair) { return pair && sizeof(T) == 8 ? 2 * PnCfg<T>::LMAX : PnCfg<T>::LMAX; }
 template <typename T> __host__ __device__ constexpr size_t pn_lds_bytes(int gmax, bool first_order = false, bool pair = false)
 {
     // (coefficient, fraction and floor of the grid place: three arrays -- one 16-byte record per frequency and a ds_read_b128 per
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
         const PnWinF wk_;
 #pragma unroll
         for (int h = 0; h < PN_NH; ++h) {
-            // (PN_NH = 2, float64 pairs: the frequencies in two halves -- LDS holds the coefficients of 2048 pairs beside the grids)
+            // (PN_NH = 4, float64 pairs: the frequencies a quarter at a time -- LDS holds the coefficients of 1024 pairs beside the grids)
             if (h) __syncthreads();
 #pragma unroll
             for (int jj = 0; jj < PN_PER / PN_NH; ++jj) {
