@@ -152,6 +152,21 @@ template <typename T> static void ps_launch_transpose_herm(const void *in, void 
                        reinterpret_cast<const Cp<T> *>(in), reinterpret_cast<Cp<T> *>(out), tnum, snum, hs);
 }
 
+// out[c][r] = in[r][c] for r < rows, 0 for rows <= r < rows_out: [snum][tnum/2 + 1] -> [tnum/2 + 1][nt], the time axis zero-padded
+// (the spectrum over the traces on its way to the transform over time, P.fhalf)
+template <typename T, int TS>
+__global__ __launch_bounds__(256) void ps_transpose_pad(const Cp<T> *__restrict__ in, Cp<T> *__restrict__ out, int rows, int cols, int rows_out)
+{
+    __shared__ Cp<T> tile[TS][TS + 1];
+    const int c0 = blockIdx.x * TS, r0 = blockIdx.y * TS;
+    const int tx = threadIdx.x % TS, ty = threadIdx.x / TS;
+    for (int r = ty; r < TS; r += 256 / TS)
+        tile[r][tx] = (r0 + r < rows && c0 + tx < cols) ? in[(size_t)(r0 + r) * cols + c0 + tx] : Cp<T>{(T)0, (T)0};
+    __syncthreads();
+    for (int c = ty; c < TS; c += 256 / TS)
+        if (c0 + c < cols && r0 + tx < rows_out) out[(size_t)(c0 + c) * rows_out + r0 + tx] = tile[tx][c];
+}
+
 // out[i] = Re Z[i] (mig_python.py:282 keeps the real part of the inverse transform)
 template <typename T>
 __global__ __launch_bounds__(256) void ps_real_part(const Cp<T> *__restrict__ Z, T *__restrict__ out, size_t n)
@@ -238,6 +253,10 @@ struct PsParams {
     int nk;                 // wavenumbers in this launch (tnum, or a rank's slab)
     int k0;                 // first wavenumber of this launch (a rank's slab of a kx-sharded run; 0 otherwise): workgroup b
                             // works on wavenumber k0 + b and writes row b of TK
+    int fhalf;              // 1: F is [tnum/2 + 1][nt] -- the wavenumbers k >= 0 with ALL frequencies (rows fstride = nt apart, the
+                            // transform over the traces taken first, on the radargram's own rows): FK[tnum - k][w] = conj FK[k][-w].
+                            // ps_nufft_kernel's pairs read both of their rows out of one; ps_edge_kernel, ps_dc_kernel know it;
+                            // no other kernel is launched on it (ps_run)
 };
 
 // Why half of the frequencies are enough for a real radargram (mig_python.py:268-270, 282, 396-420, 438-487):
@@ -253,6 +272,22 @@ template <typename T> __device__ __forceinline__ Cp<T> ps_load_slot(const Cp<T> 
 {
     if (!P.herm) return Frow[slot];
     Cp<T> f = Frow[slot == 0 ? (P.nt >> 1) : slot];
+    if (slot != 0) {
+        f.x *= (T)2;
+        f.y *= (T)2;
+    }
+    return f;
+}
+// the same for wavenumber k in either layout of F (P.fhalf: the Hermitian walk's slots of row k >= tnum/2 + 1 are the mirrored
+// frequencies of row tnum - k, conjugated)
+template <typename T> __device__ __forceinline__ Cp<T> ps_load_slot_k(const PsParams &P, int k, int slot)
+{
+    const Cp<T> *F = reinterpret_cast<const Cp<T> *>(P.F);
+    if (!P.fhalf) return ps_load_slot<T>(F + (size_t)k * P.fstride, P, slot);
+    const int idx = slot == 0 ? (P.nt >> 1) : slot;
+    const bool mirror = 2 * k > P.tnum;
+    Cp<T> f = mirror ? F[(size_t)(P.tnum - k) * P.fstride + (P.nt - idx)] : F[(size_t)k * P.fstride + idx];
+    if (mirror) f.y = -f.y;
     if (slot != 0) {
         f.x *= (T)2;
         f.y *= (T)2;
@@ -1338,6 +1373,7 @@ __global__ __launch_bounds__(256) void ps_dc_kernel(const Cp<T> *__restrict__ F,
 
 struct PsPlan {
     OwnTwiddles tw_time, tw_trace;       // the library's own row transforms (own_fft.h): what the first call of a size runs on
+    DevBuf d_taper;                      // [tnum + snum] float64 taper weights (the transform over the traces taken first: P.fhalf)
     int own_calls = 0;                   // ... calls of this size that did
     int dtype = -1, snum = 0, tnum = 0, nt = 0;
     const impdar_ctx *owner = nullptr;   // plans and buffers live on this context's device and stream
@@ -1711,6 +1747,7 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
     // the whole wavenumber axis with kx[tnum - k] = -kx[k]: a pair of rows per workgroup, as ps_runs_kernel's
     bool pairs = allow_pairs && P.k0 == 0 && P.nk == tnum && tnum >= 2 && tnum % 2 == 0;
     for (int k = 1; 2 * k < tnum && pairs; ++k) pairs = kx_host[k] == -kx_host[tnum - k];
+    if (P.fhalf && !pairs) return IMPDAR_OK;           // (the half layout is read by the pairs only; ps_run repeats the transforms)
     const int lmax_steps = pn_lmax<T>(pairs);
     std::vector<PnPiece> pc;
     int nshort_steps = 0;
@@ -2082,6 +2119,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         pl.r_ready = pl.c_ready = false;
         if (pl.owner != ctx) {               // another device / stream: drop everything bound to the old one
             pl.Xr.release();
+            pl.d_taper.release();
             pl.d_blocks.release();
             pl.d_edge.release();
             pl.d_runtab.release();
@@ -2234,38 +2272,6 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_vz.p, vmig, (size_t)snum * 8, hipMemcpyHostToDevice, st));
         IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_thr.p, thr.data(), (size_t)snum * 8, hipMemcpyHostToDevice, st));
     }
-    dim3 tgrid((tnum + 63) / 64, (nt + 63) / 64);
-    int rc;
-    if ((rc = impdar_ctx_tic(ctx))) return rc;
-    if (herm) {
-        // real-to-complex along time: only rows 0 .. nt/2 of the spectrum exist, and only they are walked
-        hipLaunchKernelGGL((ps_taper_pad_transpose_real<T>), tgrid, dim3(256), 0, st, (const T *)d_data, pl.Xr.as<T>(), snum,
-                           tnum, nt, htaper, vtaper);
-        if (use_own) {
-            if ((rc = own_fft_launch<T>(OWN_R2C, nt, (size_t)tnum, pl.Xr.p, pl.X.p, (size_t)nt, (size_t)fstride, 1.0, pl.tw_time, st))) return rc;
-        } else if ((rc = pl.r_time.exec(pl.Xr.p, pl.X.p))) {
-            return rc;
-        }
-        if (pl.rows_form) {
-            // over the traces on contiguous rows: X [x][fstride] -> [fstride][x] (pl.TK is free until the frequency sums
-            // write it, and large enough: snum > nt / 2), transform, and back -> X [k][fstride]
-            ps_launch_transpose<T>(pl.X.p, pl.TK.p, tnum, fstride, st);
-            if (use_own) {
-                if ((rc = own_fft_launch<T>(OWN_C2C_FWD, tnum, (size_t)fstride, pl.TK.p, pl.TK.p, (size_t)tnum, (size_t)tnum, 1.0, pl.tw_trace, st))) return rc;
-            } else if ((rc = pl.r_trace.exec(pl.TK.p, nullptr))) {
-                return rc;
-            }
-            ps_launch_transpose<T>(pl.TK.p, pl.X.p, fstride, tnum, st);
-            IMPDAR_HIP_CHECK(hipGetLastError());
-        } else if ((rc = pl.r_trace.exec(pl.X.p, nullptr))) {
-            return rc;
-        }
-    } else {
-        hipLaunchKernelGGL((ps_taper_pad_transpose<T>), tgrid, dim3(256), 0, st, (const T *)d_data, pl.X.as<Cp<T>>(), snum,
-                           tnum, nt, htaper, vtaper);
-        if ((rc = pl.f_time.exec(pl.X.p, nullptr))) return rc;
-        if ((rc = pl.f_trace.exec(pl.X.p, nullptr))) return rc;
-    }
     PsParams P;
     P.F = pl.X.p;
     P.fstride = fstride;
@@ -2284,6 +2290,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     P.nf = nf;
     P.herm = herm ? 1 : 0;
     P.vz_mode = vlen ? 1 : 0;
+    P.fhalf = 0;
     P.vtol = dbl ? 1e-11 : 1e-10;
     P.sched = P.tsched = P.rowmap = nullptr;
     P.eps = nullptr;
@@ -2335,6 +2342,112 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
                 P.eps = pl.d_eps.as<double>();
             }
         }
+    }
+    // ---- which layout of the spectrum (P.fhalf).  When ps_nufft_kernel will take the call with a pair of wavenumbers per workgroup
+    // (the whole axis, antisymmetric kx; a constant velocity or a table of up to 16 thick layers and 64 runs -- the conditions of the
+    // dispatch below that can be told before the transforms), the transform over the TRACES goes first, on the radargram's own rows
+    // with the taper applied on their way in, and only the wavenumbers k = 0 .. tnum/2 are kept, with all frequencies:
+    //   R2C over x [snum][tnum] -> [snum][tnum/2 + 1];  transpose (zero rows up to nt) -> [tnum/2 + 1][nt];  C2C over t in place
+    // instead of taper + transpose, R2C over t, transpose, C2C over x, transpose: two passes over the array less.  The pair (k, tnum - k)
+    // reads both of its rows out of row k (FK[tnum - k][w] = conj FK[k][-w]).  Should the kernel hand the call on after all (boundary
+    // frequencies beyond its lists), the transforms are repeated in the other layout (front_full below).
+    bool half_front = false;
+    {
+        const char *me = getenv("IMPDAR_PS_MFMA");
+        const int pref = me ? atoi(me) : 1;
+        bool sym = herm && use_own && pl.rows_form && !tk_out && k0 == 0 && nk == tnum && tnum % 2 == 0 && tnum >= 64 && own_fft_len_ok(nt) &&
+                   nf >= 64 && nf <= PN_NFMAX && snum >= 64 && (pref == 1 || pref == 6) && getenv("IMPDAR_PS_TEST_EDGE_OVERFLOW") == nullptr &&
+                   !(k_zero.size() > 1 || (k_zero.size() == 1 && k_zero[0] != 0));
+        for (int k = 1; 2 * k < tnum && sym; ++k) sym = kx[k] == -kx[tnum - k];
+        if (sym && !vlen) sym = std::isfinite(vconst) && vconst != 0.0;
+        if (sym && vlen) {
+            int nruns = 0, nlong = 0, len = 0;
+            for (int i = 0; i < snum; ++i) {
+                if (sched[i]) {
+                    nlong += len > PM_SHORT;
+                    nruns += 1;
+                    len = 0;
+                }
+                len += 1;
+            }
+            nlong += len > PM_SHORT;
+            sym = P.sched != nullptr && nruns <= 64 && (pref == 6 || nlong <= 16);
+        }
+        half_front = sym;
+    }
+    std::vector<double> tap_h, tap_v;
+    if (half_front) {
+        tap_h.resize((size_t)tnum);
+        tap_v.resize((size_t)snum);
+        for (int j = 0; j < tnum; ++j) tap_h[j] = impdar_taper_w(j, tnum, htaper);
+        for (int i = 0; i < snum; ++i) tap_v[i] = impdar_taper_w(i, snum, vtaper);
+        if (pl.d_taper.ensure(((size_t)tnum + snum) * 8) != hipSuccess) {
+            (void)hipGetLastError();
+            half_front = false;
+        } else {
+            IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_taper.p, tap_h.data(), (size_t)tnum * 8, hipMemcpyHostToDevice, st));
+            IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_taper.as<double>() + tnum, tap_v.data(), (size_t)snum * 8, hipMemcpyHostToDevice, st));
+        }
+    }
+    dim3 tgrid((tnum + 63) / 64, (nt + 63) / 64);
+    int rc;
+    // the transforms of the [k][w > 0] layout every kernel reads (Hermitian walk on the library's own or rocFFT's plans)
+    auto front_full = [&]() -> int {
+        int rc;
+        hipLaunchKernelGGL((ps_taper_pad_transpose_real<T>), tgrid, dim3(256), 0, st, (const T *)d_data, pl.Xr.as<T>(), snum,
+                           tnum, nt, htaper, vtaper);
+        if (use_own) {
+            if ((rc = own_fft_launch<T>(OWN_R2C, nt, (size_t)tnum, pl.Xr.p, pl.X.p, (size_t)nt, (size_t)fstride, 1.0, pl.tw_time, st))) return rc;
+        } else if ((rc = pl.r_time.exec(pl.Xr.p, pl.X.p))) {
+            return rc;
+        }
+        if (pl.rows_form) {
+            // over the traces on contiguous rows: X [x][fstride] -> [fstride][x] (pl.TK is free until the frequency sums
+            // write it, and large enough: snum > nt / 2), transform, and back -> X [k][fstride]
+            ps_launch_transpose<T>(pl.X.p, pl.TK.p, tnum, fstride, st);
+            if (use_own) {
+                if ((rc = own_fft_launch<T>(OWN_C2C_FWD, tnum, (size_t)fstride, pl.TK.p, pl.TK.p, (size_t)tnum, (size_t)tnum, 1.0, pl.tw_trace, st))) return rc;
+            } else if ((rc = pl.r_trace.exec(pl.TK.p, nullptr))) {
+                return rc;
+            }
+            ps_launch_transpose<T>(pl.TK.p, pl.X.p, fstride, tnum, st);
+            IMPDAR_HIP_CHECK(hipGetLastError());
+        } else if ((rc = pl.r_trace.exec(pl.X.p, nullptr))) {
+            return rc;
+        }
+        return IMPDAR_OK;
+    };
+    // the call handed on by ps_nufft_kernel after the transforms were made for its pairs: the other layout after all
+    auto leave_half_front = [&]() -> int {
+        if (!P.fhalf) return IMPDAR_OK;
+        impdar_trace("phaseshift: the transform path handed the call on: transforms repeated in the [k][w > 0] layout");
+        P.fhalf = 0;
+        P.fstride = fstride;
+        return front_full();
+    };
+    if ((rc = impdar_ctx_tic(ctx))) return rc;
+    if (herm && half_front) {
+        const int hs = tnum / 2 + 1;
+        const double *th = pl.d_taper.as<double>(), *tv = th + tnum;
+        // (pl.TK: free until the frequency sums write it, and at least tnum x snum complex)
+        if ((rc = own_fft_launch<T>(OWN_R2C, tnum, (size_t)snum, d_data, pl.TK.p, (size_t)tnum, (size_t)hs, 1.0, pl.tw_trace, st, th, tv))) return rc;
+        {
+            constexpr int TS = sizeof(T) == 4 ? 64 : 32;
+            hipLaunchKernelGGL((ps_transpose_pad<T, TS>), dim3((hs + TS - 1) / TS, (nt + TS - 1) / TS), dim3(256), 0, st, pl.TK.as<Cp<T>>(),
+                               pl.X.as<Cp<T>>(), snum, hs, nt);
+        }
+        if ((rc = own_fft_launch<T>(OWN_C2C_FWD, nt, (size_t)hs, pl.X.p, pl.X.p, (size_t)nt, (size_t)nt, 1.0, pl.tw_time, st))) return rc;
+        IMPDAR_HIP_CHECK(hipGetLastError());
+        P.fhalf = 1;
+        P.fstride = nt;
+        impdar_trace("phaseshift: the transform over the traces first: wavenumbers k >= 0 with all frequencies, for pairs in ps_nufft_kernel");
+    } else if (herm) {
+        if ((rc = front_full())) return rc;
+    } else {
+        hipLaunchKernelGGL((ps_taper_pad_transpose<T>), tgrid, dim3(256), 0, st, (const T *)d_data, pl.X.as<Cp<T>>(), snum,
+                           tnum, nt, htaper, vtaper);
+        if ((rc = pl.f_time.exec(pl.X.p, nullptr))) return rc;
+        if ((rc = pl.f_trace.exec(pl.X.p, nullptr))) return rc;
     }
     // (only the runs kernels of the vector path use it, and it costs ~2 ms of host time at config 5 with the GPU idle:
     // made when they are about to be launched, not when the matrix-core path takes the call)
@@ -2406,6 +2519,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         if (!vlen && pref != 0 && std::isfinite(vconst) && vconst != 0.0) {
             std::vector<PsMfmaRun> one{PsMfmaRun{vconst, 0, snum}};
             if ((rc = ps_nufft_run<double>(pl, P, one, false, kx, w.data(), thr.data(), st, &mfma_done, nullptr, tk_out == nullptr))) return rc;
+            if (!mfma_done && (rc = leave_half_front())) return rc;
             if (mfma_done) mfma_kernel_name = "ps_nufft_kernel";
         }
         // a v(z) table of up to 16 thick layers: the transform path with the runs' velocity noise (~4e-13, cut at 1e-11) as its
@@ -2423,6 +2537,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             long_runs = nlong;
             if (ok && (pref == 6 || nlong <= 16)) {
                 if ((rc = ps_nufft_run<double>(pl, P, mruns, true, kx, w.data(), thr.data(), st, &mfma_done, vmig, tk_out == nullptr))) return rc;
+                if (!mfma_done && (rc = leave_half_front())) return rc;
                 if (mfma_done) mfma_kernel_name = "ps_nufft_kernel";
             }
         }
@@ -2482,6 +2597,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         }
         if (ok && !mfma_done && (pref == 6 || (pref == 1 && nlong <= 16)) && !force_overflow) {
             if ((rc = ps_nufft_run<float>(pl, P, mruns, vlen != 0, kx, w.data(), thr.data(), st, &mfma_done, nullptr, tk_out == nullptr))) return rc;
+            if (!mfma_done && (rc = leave_half_front())) return rc;
             if (mfma_done) mfma_kernel_name = "ps_nufft_kernel";
         }
         for (int turn = 0; turn < 2 && ok && !mfma_done && pref != 0 && pref != 7; ++turn) {
@@ -2498,6 +2614,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             }
         }
     }
+    if (!mfma_done && (rc = leave_half_front())) return rc;         // (whatever the dispatch did: no other kernel reads P.fhalf)
     // (made only when the runs kernels of the vector path are about to be launched: ~2 ms of host time with the GPU idle)
     if (!mfma_done && P.sched && (rc = order_rows())) return rc;
     bool smooth_done = false;
@@ -2545,13 +2662,13 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
                  herm ? "true" : "false", nf, use_own ? "own" : "rocfft", long_runs, pl.mfma_instructions,
                  strcmp(mfma_kernel_name, "ps_runs_kernel") == 0 ? 16384 : 32768);
     else
-        snprintf(ctx->m_extra, sizeof ctx->m_extra, "\"hermitian_walk\": %s, \"frequencies\": %d, \"transforms\": \"%s\", \"long_runs\": %d",
-                 herm ? "true" : "false", nf, use_own ? "own" : "rocfft", long_runs);
+        snprintf(ctx->m_extra, sizeof ctx->m_extra, "\"hermitian_walk\": %s, \"frequencies\": %d, \"transforms\": \"%s\", \"long_runs\": %d, \"spectrum\": \"%s\"",
+                 herm ? "true" : "false", nf, use_own ? "own" : "rocfft", long_runs, P.fhalf ? "k >= 0, all frequencies" : "all k, frequencies walked");
     if (herm)
         for (int kz : k_zero)
             if (kz >= k0 && kz < k0 + nk)
                 hipLaunchKernelGGL((ps_dc_kernel<T>), dim3((snum + 255) / 256), dim3(256), 0, st, pl.X.as<Cp<T>>(),
-                                   reinterpret_cast<Cp<T> *>(P.TK), kz, kz - k0, fstride, snum, w0 * dt);
+                                   reinterpret_cast<Cp<T> *>(P.TK), kz, kz - k0, P.fstride, snum, w0 * dt);
     if ((rc = impdar_ctx_ktoc(ctx))) return rc;
     if (tk_out) {
         IMPDAR_HIP_CHECK(hipGetLastError());

@@ -614,14 +614,13 @@ __global__ __launch_bounds__(256) void ps_edge_kernel_t(PsMfmaParams Q)
             }
     }
     __syncthreads();
-    const Cp<T> *Frow = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k * P.fstride;
     Cp<T> *TKrow = reinterpret_cast<Cp<T> *>(P.TK) + (size_t)(k - P.k0) * P.snum;
     const double kxk = P.kx[k];
     const int seg = (P.snum + 255) / 256;
     const int lo = min(tid * seg, P.snum), hi = min(lo + seg, P.snum);
     for (int e = 0; e < n; ++e) {
         const int slot = slots[e];
-        const Cp<T> f = ps_load_slot<T>(Frow, P, slot);
+        const Cp<T> f = ps_load_slot_k<T>(P, k, slot);
         const double w = P.w[slot];
         // pass 1: this stretch's phase and its first dead step
         double sum = 0.0;

@@ -198,7 +198,6 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
     OCp<float> *grid2 = reinterpret_cast<OCp<float> *>(red + 16 * 2 * PN_SHORT);        // [own_pad(G) + 1] the first-order term's grid (Q.e1)
     const bool fo = sizeof(T) == 8 && Q.e1 != nullptr;
     const Cp<T> *Frow = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k * P.fstride;
-    const Cp<T> *Frow2 = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k2 * P.fstride;
     T *TKrow = reinterpret_cast<T *>(reinterpret_cast<Cp<T> *>(P.TK) + (size_t)kb * P.snum);
     T *TKrow2 = reinterpret_cast<T *>(reinterpret_cast<Cp<T> *>(P.TK) + (size_t)k2 * P.snum);      // (PAIR: k0 = 0)
     const double kxk = P.kx[k];
@@ -280,10 +279,10 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
                 const int i = tid + PN_NTH * j;
                 if (i >= nf || !(ph[j] == ph[j])) continue;
                 const int slot = slot_of(i);
-                Cp<T> f = ps_load_slot<T>(Frow, P, slot), fq = f;
+                Cp<T> f = PAIR ? ps_load_slot_k<T>(P, k, slot) : ps_load_slot<T>(Frow, P, slot), fq = f;
                 if (PAIR) {
                     // f1 e^{ip} + conj(f2) e^{-ip} = [(f1 + f2).x c - (f1 + f2).y s] + i [(f1 - f2).x s + (f1 - f2).y c]: the one sum's cost
-                    const Cp<T> f2 = ps_load_slot<T>(Frow2, P, slot);
+                    const Cp<T> f2 = ps_load_slot_k<T>(P, k2, slot);
                     fq = Cp<T>{f.x - f2.x, f.y - f2.y};
                     f = Cp<T>{f.x + f2.x, f.y + f2.y};
                 }
@@ -353,12 +352,12 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
                 if (!alive) ph[j] = nan;
                 OCp<T> d{(T)0, (T)0}, d2{(T)0, (T)0};
                 if (ph[j] == ph[j]) {
-                    const Cp<T> f = ps_load_slot<T>(Frow, P, slot);
+                    const Cp<T> f = PAIR ? ps_load_slot_k<T>(P, k, slot) : ps_load_slot<T>(Frow, P, slot);
                     T sn, c;
                     pn_sincos(ph[j] + (double)(1 + Lp / 2) * inc, &sn, &c);
                     d = OCp<T>{fma(f.x, c, -(f.y * sn)), fma(f.x, sn, f.y * c)};
                     if (PAIR) {
-                        const Cp<T> f2 = ps_load_slot<T>(Frow2, P, slot);       // the partner's, mirrored: conj(f2 e^{i theta})
+                        const Cp<T> f2 = ps_load_slot_k<T>(P, k2, slot);        // the partner's, mirrored: conj(f2 e^{i theta})
                         d2 = OCp<T>{fma(f2.x, c, -(f2.y * sn)), -fma(f2.x, sn, f2.y * c)};
                     }
                     double adv = (double)L * inc;

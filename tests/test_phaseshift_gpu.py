@@ -578,6 +578,55 @@ def test_velocity_that_changes_at_every_step(hip, dtype, profile, snum, tnum, ca
 
 
 @pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_transforms_are_repeated_when_the_transform_path_hands_the_call_on(hip, dtype, capfd, monkeypatch):
+    """A profile of two thick layers with 24 short runs (4 steps each) between them: few enough runs for the library to expect
+    ps_nufft_kernel and lay the spectrum out for its pairs of wavenumbers (the transform over the traces first, k >= 0 only), but 96
+    steps to sum directly, which the kernel declines -- the call goes on to another kernel, which reads the [k][w > 0] layout: the
+    transforms are made again.  And the same radargram with the thick layers alone stays on the transform path, in the half layout."""
+    import ctypes as C
+    import json
+    from impdar_amd import _hip, synth
+    from oracle import mig_oracle
+    lib, ctx = _hip.load(), _hip.context()
+    snum, tnum = 1024, 128
+    nt = 1024
+    geo = synth.geometry(snum, tnum)
+    rng = np.random.default_rng(5)
+    data = (rng.standard_normal((snum, tnum)) + 0.3).astype(dtype)
+    kx = mig_oracle._kx(tnum, geo['trace_int'], geo['dist'])
+    ws = 2. * np.pi * np.fft.fftfreq(nt, d=geo['dt'])
+    tt = np.ascontiguousarray(geo['travel_time'], dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    monkeypatch.setenv('IMPDAR_TRACE', '1')
+    for short_runs, kernels in ((24, ('ps_runs_kernel', 'ps_vz64_kernel', 'ps_vz32_kernel', 'ps_mfma_kernel')), (0, ('ps_nufft_kernel',))):
+        vm = np.full(snum, 1.69e8)
+        at = 400
+        for r in range(short_runs):
+            vm[at:at + 4] = 1.70e8 + 0.004e8 * r
+            at += 4
+        vm[at:] = 1.85e8
+        out = np.empty((snum, tnum), dtype=dtype)
+        capfd.readouterr()
+        _hip.check(lib.impdar_phaseshift(ctx, data.ctypes.data_as(C.c_void_p), _hip.dtype_code(dtype), snum, tnum, nt,
+                                         kx.ctypes.data_as(dp), ws.ctypes.data_as(dp), C.c_double(geo['dt']),
+                                         tt.ctypes.data_as(dp), C.c_double(0.0), vm.ctypes.data_as(dp), snum, C.c_double(5.),
+                                         C.c_double(7.), out.ctypes.data_as(C.c_void_p)), 'impdar_phaseshift')
+        err = capfd.readouterr().err
+        assert ('transforms repeated' in err) == (short_runs > 0), err[-2000:]
+        buf = C.create_string_buffer(1024)
+        _hip.check(lib.impdar_ctx_last_metrics(ctx, buf, len(buf)), 'metrics')
+        assert json.loads(buf.value.decode())['kernel'] in kernels, buf.value
+        tap = mig_oracle._apply_taper(data.astype(np.float64), 5, 7, inplace_form=True)
+        FK = np.fft.fft2(tap, (nt, tnum))
+        TK = mig_oracle.phase_shift_tk(FK, vm, kx, ws, geo['dt'], geo['travel_time'], snum, tnum)
+        want = np.fft.ifft(TK).real
+        if dtype == np.float32:
+            assert rel_l2(out, want) < F32_L2, (short_runs, rel_l2(out, want))
+        else:
+            assert rel_max(out, want) < F64_TOL, (short_runs, rel_max(out, want))
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
 def test_time_axis_padded_far_beyond_the_samples(hip, dtype):
     """The C entry point takes nt from the caller (any nt >= snum; the package passes the next power of two,
     mig_python.py:262): with nt = 1024 for 100 samples the half spectrum (nt / 2 + 1 rows) is larger than the image,
