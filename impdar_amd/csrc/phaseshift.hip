@@ -1778,7 +1778,7 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
         }
     }
     // a direct step costs as much as a tenth of a piece: tables of many layers stay with ps_runs_kernel
-    if (nshort_steps > 64 || pc.size() > 256) return IMPDAR_OK;
+    if (nshort_steps > 128 || pc.size() > 256) return IMPDAR_OK;
     std::vector<double> e1;
     if (first_order) {
         // per piece: the reference velocity sqrt(mean v^2) and E(n) / cbar^2 = sum_{t <= n} (v_t^2 / mean - 1)
@@ -2351,28 +2351,50 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
     // instead of taper + transpose, R2C over t, transpose, C2C over x, transpose: two passes over the array less.  The pair (k, tnum - k)
     // reads both of its rows out of row k (FK[tnum - k][w] = conj FK[k][-w]).  Should the kernel hand the call on after all (boundary
     // frequencies beyond its lists), the transforms are repeated in the other layout (front_full below).
+    // ---- will the transform path (ps_nufft_kernel) take a v(z) table?  Its cost is per PIECE (a run of constant velocity, cut at
+    // 4096 / 2048 steps) and per directly summed step of the short runs between them, and hardly depends on the record's length; the
+    // runs kernels' is per (frequency, step) plus a term per run.  Device ms per 8192 wavenumbers, pairs of wavenumbers per transform
+    // (profiles/r06_transforms.txt section 4: tables of 4 ... 41 rows at 8192^2, 4096^2, 2048^2):
+    //   float32  ps_nufft_kernel (0.135 + 0.06 nf/4096) (pieces + short steps / 3)     ps_runs_kernel 1.2 + 8.5 (nf/4096)(snum/8192) + 0.05 runs nf/4096
+    //   float64  up to 24 thick layers from 2048 frequencies on (33.6 against ps_vz64_kernel's 57.2 ms at 41 rows / 21 layers, 8192^2; level at
+    //            4096^2), 16 below
+    bool nufft_first = false;
+    int vz_runs = 0, vz_long = 0;
+    if (vlen) {
+        int len = 0, pieces = 0, nshort = 0;
+        const int lmax = dbl ? 2048 : 4096;
+        auto close_run = [&]() {
+            if (len > PN_SHORT) pieces += (len + lmax - 1) / lmax;
+            else nshort += len;
+            vz_long += len > PM_SHORT;
+        };
+        for (int i = 0; i < snum; ++i) {
+            if (sched[i]) {
+                if (vz_runs) close_run();
+                vz_runs += 1;
+                len = 0;
+            }
+            len += 1;
+        }
+        close_run();
+        const double fq = (double)nf / 4096.0;
+        if (dbl)
+            nufft_first = vz_long <= (nf >= 2048 ? 24 : 16);
+        else
+            nufft_first = nshort <= 128 && (0.135 + 0.06 * fq) * ((double)pieces + (double)nshort / 3.0) <=
+                                               1.2 + 8.5 * fq * ((double)snum / 8192.0) + 0.05 * (double)vz_runs * fq;
+    }
+    // ---- which layout of the spectrum (P.fhalf): see above
     bool half_front = false;
     {
         const char *me = getenv("IMPDAR_PS_MFMA");
         const int pref = me ? atoi(me) : 1;
         bool sym = herm && use_own && pl.rows_form && !tk_out && k0 == 0 && nk == tnum && tnum % 2 == 0 && tnum >= 64 && own_fft_len_ok(nt) &&
-                   nf >= 64 && nf <= PN_NFMAX && snum >= 64 && (pref == 1 || pref == 6) && getenv("IMPDAR_PS_TEST_EDGE_OVERFLOW") == nullptr &&
+                   nf >= 64 && nf <= PN_NFMAX && snum >= 64 && (pref == 1 || pref == 6) &&
                    !(k_zero.size() > 1 || (k_zero.size() == 1 && k_zero[0] != 0));
         for (int k = 1; 2 * k < tnum && sym; ++k) sym = kx[k] == -kx[tnum - k];
         if (sym && !vlen) sym = std::isfinite(vconst) && vconst != 0.0;
-        if (sym && vlen) {
-            int nruns = 0, nlong = 0, len = 0;
-            for (int i = 0; i < snum; ++i) {
-                if (sched[i]) {
-                    nlong += len > PM_SHORT;
-                    nruns += 1;
-                    len = 0;
-                }
-                len += 1;
-            }
-            nlong += len > PM_SHORT;
-            sym = P.sched != nullptr && nruns <= 64 && (pref == 6 || nlong <= 16);
-        }
+        if (sym && vlen) sym = P.sched != nullptr && (pref == 6 || nufft_first);
         half_front = sym;
     }
     std::vector<double> tap_h, tap_v;
@@ -2535,7 +2557,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             int nlong = 0;
             for (const PsMfmaRun &r : mruns) nlong += r.len > PM_SHORT;
             long_runs = nlong;
-            if (ok && (pref == 6 || nlong <= 16)) {
+            if (ok && (pref == 6 || nufft_first)) {
                 if ((rc = ps_nufft_run<double>(pl, P, mruns, true, kx, w.data(), thr.data(), st, &mfma_done, vmig, tk_out == nullptr))) return rc;
                 if (!mfma_done && (rc = leave_half_front())) return rc;
                 if (mfma_done) mfma_kernel_name = "ps_nufft_kernel";
@@ -2587,7 +2609,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
         // 16.8 against ps_runs_kernel's 11.8 / 12.4 / 12.8 / 13.7 / 14.4 / 15.3; config 5: 4.5 against ps_mfma_kernel's 10.6,
         // constant velocity 3.0 against 6.8 -- profiles/r05_ps_nufft.txt), then the matrix-core paths as before
         // ... 7: only the series path (ps_series.h).  By itself: profiles without runs of constant velocity to live on
-        if (ok && vlen && (pref == 7 || (pref == 1 && (!P.sched || mruns.size() > 64))) && !force_overflow) {
+        if (ok && vlen && (pref == 7 || (pref == 1 && !(P.sched && nufft_first) && (!P.sched || mruns.size() > 64))) && !force_overflow) {
             // (what would run otherwise, at 8192^2: ps_smooth32_kernel 5.3e-6 ms per alive pair; ps_runs_kernel 8 ms + 0.036 per run,
             // long or single step -- 41 / 81 / 161 table rows = 160 / 320 / 640 runs: 13.8 / 19.8 / 30.5 ms; a firn column's 1470: 70)
             const double alt = pref == 7 ? 0.0 : (!P.sched ? -SR_MS_PER_PAIR_F32
@@ -2595,7 +2617,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             if ((rc = ps_series_run<float>(pl, P, vmig, kx, w.data(), thr.data(), st, &mfma_done, alt))) return rc;
             if (mfma_done) mfma_kernel_name = "ps_series_kernel";
         }
-        if (ok && !mfma_done && (pref == 6 || (pref == 1 && nlong <= 16)) && !force_overflow) {
+        if (ok && !mfma_done && (pref == 6 || (pref == 1 && (!vlen || (P.sched && nufft_first)))) && !force_overflow) {
             if ((rc = ps_nufft_run<float>(pl, P, mruns, vlen != 0, kx, w.data(), thr.data(), st, &mfma_done, nullptr, tk_out == nullptr))) return rc;
             if (!mfma_done && (rc = leave_half_front())) return rc;
             if (mfma_done) mfma_kernel_name = "ps_nufft_kernel";
