@@ -1880,8 +1880,9 @@ static int ps_nufft_run(PsPlan &pl, PsParams P, const std::vector<PsMfmaRun> &ru
 // Same contract as ps_mfma_run: *done = false and IMPDAR_OK when the call is not for this path.
 template <typename T>
 static int ps_series_run(PsPlan &pl, PsParams P, const double *vmig, const double *kx_host, const double *w_host, const double *thr,
-                         hipStream_t st, bool *done, double alt_ms_8192 = 0.0)
+                         hipStream_t st, bool *done, double alt_ms_8192 = 0.0, bool allow_pairs = false)
 {
+    // allow_pairs: as ps_nufft_run's -- the sums go on into the inverse transform: rows k and tnum - k as their Hermitian combination
     // alt_ms_8192 > 0: what the kernel that would take the call otherwise is expected to need (per 8192 wavenumbers); the call is
     // taken only where the planner's estimate is 0.85 of that or less.  0: taken regardless (IMPDAR_PS_MFMA=7)
     *done = false;
@@ -1913,10 +1914,16 @@ static int ps_series_run(PsPlan &pl, PsParams P, const double *vmig, const doubl
         impdar_trace("ps_series: %zu pieces", hp.pieces.size());
     }
     if (hp.pieces.empty() || hp.pieces.size() > 4096) return IMPDAR_OK;
+    // the whole wavenumber axis with kx[tnum - k] = -kx[k]: a pair of rows per workgroup (ps_series_kernel<T, true>)
+    // float32 only: on float64 data the pair's records take the frequencies through LDS in four rounds of two gather passes each and the
+    // kernel spills twice as much -- 8192^2: rising gradient 368 -> 365 ms, falling 274 -> 312, firn column 66 -> 72 (float32: 110 -> 77.5,
+    // 52 -> 41, 14.7 -> 11.5; profiles/r06_series.txt section 7)
+    bool pairs = !dbl && allow_pairs && P.k0 == 0 && P.nk == tnum && tnum >= 2 && tnum % 2 == 0 && !P.fhalf;
+    for (int k = 1; 2 * k < tnum && pairs; ++k) pairs = kx_host[k] == -kx_host[tnum - k];
     if (alt_ms_8192 != 0.0) {
         // (alt < 0: per alive pair -- the per-step kernels)
         const double alt = alt_ms_8192 > 0.0 ? alt_ms_8192 : -alt_ms_8192 * hp.alive_pairs;
-        const double est = (dbl ? SR_MS_PER_MODEL_F64 : SR_MS_PER_MODEL_F32) * hp.model_cost;
+        const double est = (dbl ? SR_MS_PER_MODEL_F64 : SR_MS_PER_MODEL_F32) * hp.model_cost * (pairs ? SR_PAIR_FACTOR : 1.0);
         impdar_trace("ps_series: estimate %.1f ms per 8192 wavenumbers against %.1f", est, alt);
         if (est > 0.85 * alt) return IMPDAR_OK;
     }
@@ -1966,9 +1973,17 @@ static int ps_series_run(PsPlan &pl, PsParams P, const double *vmig, const doubl
         const int direct_scratch = (SrCfg<T>::NTH / 64) * 64 * 12 + lmax * (int)sizeof(OCp<T>);
         Q.grid_bytes = (std::max(hp.grid_bytes, direct_scratch) + 15) & ~15;
     }
-    const size_t lds = sr_lds_bytes<T>(Q.grid_bytes);
-    IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_series_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sr_lds_bytes<T>(SR_GRID_BYTES + 16)));
-    hipLaunchKernelGGL(ps_series_kernel<T>, dim3((unsigned)P.nk), dim3(SrCfg<T>::NTH), lds, st, Q);
+    if constexpr (!dbl) {
+        if (pairs) {
+            IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_series_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)sr_lds_bytes<float>(SR_GRID_BYTES + 16, true)));
+            hipLaunchKernelGGL((ps_series_kernel<float, true>), dim3((unsigned)(tnum / 2 + 1)), dim3(SrCfg<float>::NTH), sr_lds_bytes<float>(Q.grid_bytes, true), st, Q);
+        }
+    }
+    if (!pairs) {
+        IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)ps_series_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sr_lds_bytes<T>(SR_GRID_BYTES + 16)));
+        hipLaunchKernelGGL(ps_series_kernel<T>, dim3((unsigned)P.nk), dim3(SrCfg<T>::NTH), sr_lds_bytes<T>(Q.grid_bytes), st, Q);
+    }
     IMPDAR_HIP_CHECK(hipGetLastError());
     IMPDAR_HIP_CHECK(hipStreamSynchronize(st));            // (the host tables must outlive their copies)
     pl.sr_dev = true;
@@ -2573,7 +2588,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
                 for (int i = 0; i < snum; ++i) nstarts += sched[i] != 0;
             const double alt = pref == 7 ? 0.0 : (P.sched ? 43.0 * ((double)nf / 4096.0) * ((double)snum / 8192.0) + 0.09 * (double)nstarts * ((double)nf / 4096.0)
                                                           : -SR_MS_PER_PAIR_F64);
-            if ((rc = ps_series_run<double>(pl, P, vmig, kx, w.data(), thr.data(), st, &mfma_done, alt))) return rc;
+            if ((rc = ps_series_run<double>(pl, P, vmig, kx, w.data(), thr.data(), st, &mfma_done, alt, tk_out == nullptr))) return rc;
             if (mfma_done) mfma_kernel_name = "ps_series_kernel";
         }
     }
@@ -2614,7 +2629,7 @@ static int ps_run(impdar_ctx *ctx, PsPlan &pl, const void *d_data, int snum, int
             // long or single step -- 41 / 81 / 161 table rows = 160 / 320 / 640 runs: 13.8 / 19.8 / 30.5 ms; a firn column's 1470: 70)
             const double alt = pref == 7 ? 0.0 : (!P.sched ? -SR_MS_PER_PAIR_F32
                                                            : 8.0 * ((double)nf / 4096.0) * ((double)snum / 8192.0) + 0.036 * (double)mruns.size() * ((double)nf / 4096.0));
-            if ((rc = ps_series_run<float>(pl, P, vmig, kx, w.data(), thr.data(), st, &mfma_done, alt))) return rc;
+            if ((rc = ps_series_run<float>(pl, P, vmig, kx, w.data(), thr.data(), st, &mfma_done, alt, tk_out == nullptr))) return rc;
             if (mfma_done) mfma_kernel_name = "ps_series_kernel";
         }
         if (ok && !mfma_done && (pref == 6 || (pref == 1 && (!vlen || (P.sched && nufft_first)))) && !force_overflow) {

@@ -58,9 +58,14 @@ struct SrParams {
 constexpr int SR_TWLDS = 512;       // grid lengths up to this take their twiddles from LDS (a butterfly waits for nothing but LDS)
 
 template <typename T> struct SrFq { T dx, dy, fr; float uh; };    // coefficient, u - floor(u), floor(u)
+template <typename T> struct SrFq2 { T dx, dy, ex, ey, fr; float uh; };      // a pair of wavenumbers: + the partner's coefficient, mirrored (PAIR)
+template <typename T, bool PAIR> using SrFqT = std::conditional_t<PAIR, SrFq2<T>, SrFq<T>>;
+// PAIR: the regular frequencies go through LDS in twice as many rounds (a pair's record is 8 / 16 bytes longer)
+template <typename T> __host__ __device__ constexpr int sr_nhalf(bool pair) { return SrCfg<T>::NHALF * (pair ? 2 : 1); }
 struct SrDirect {
     double ph, w, rw;               // running phase (NaN once dead), frequency, 1 / w
-    double fx, fy;                  // spectrum (weighted)
+    double fx, fy;                  // spectrum (weighted); PAIR: the sum of the two rows' ...
+    double gx, gy;                  // PAIR: ... and their difference (f1 e^{ip} + conj(f2) e^{-ip} from the two, at one sum's cost)
 };
 
 // the Nyquist row of the Hermitian walk (w < 0: its phase runs backwards) while it is regular: added per output step through the
@@ -68,12 +73,13 @@ struct SrDirect {
 struct SrNyq {
     double ph0, inc;
     double fx, fy, z;
+    double f2x, f2y;                // PAIR: the partner row's
     int valid, pad_;
 };
 
-template <typename T> __host__ __device__ constexpr size_t sr_lds_bytes(int grid_bytes)
+template <typename T> __host__ __device__ constexpr size_t sr_lds_bytes(int grid_bytes, bool pair = false)
 {
-    return (size_t)(own_pad(SR_NFMAX / SrCfg<T>::NHALF) + 1) * (sizeof(SrFq<T>) + sizeof(T)) + (size_t)grid_bytes + 64 * sizeof(OCp<T>) +
+    return (size_t)(own_pad(SR_NFMAX / sr_nhalf<T>(pair)) + 1) * ((pair ? sizeof(SrFq2<T>) : sizeof(SrFq<T>)) + sizeof(T)) + (size_t)grid_bytes + 64 * sizeof(OCp<T>) +
            (size_t)SR_DMAX * sizeof(SrDirect) + 512 + SR_MSER * sizeof(double) + (size_t)SR_TWLDS * sizeof(OCp<T>);
 }
 
@@ -173,8 +179,12 @@ __device__ __forceinline__ void sr_fft_passes(OCp<T> *s, int J, int gstride, int
 
 // the gather of one piece: grid point m (S threads each, a sub-range of the frequencies in reach apiece) <- J sums over the
 // regular frequencies with |u_w - m| < W/2
-template <typename T, int J>
-__device__ __forceinline__ void sr_gather(const SrFq<T> *__restrict__ fq, const T *__restrict__ zz, OCp<T> *grids, int gstride, int G,
+// MIRROR (a pair of wavenumbers, second pass): the partner's coefficients, whose nodes are the mirror images -u_w -- the points
+// mm = -W/2 .. G/2 + W/2 that the nodes reach, summed with psi(u_w - mm) as in the first pass and ADDED to grid point -mm; grid p
+// takes (-z)^p: the series' coefficients y_p are real for even p and imaginary for odd p (the phase residual is odd in 1 / psi),
+// so conj(sum_p y_p ghat_p) of the partner's row needs its odd grids negated and nothing else
+template <typename T, int J, typename FQ, bool MIRROR = false>
+__device__ __forceinline__ void sr_gather(const FQ *__restrict__ fq, const T *__restrict__ zz, OCp<T> *grids, int gstride, int G,
                                           int tid, int ifirst, int ilast, float a2, float c2, float inv_dw, bool add)
 {
     constexpr int W = SrCfg<T>::W;
@@ -182,15 +192,16 @@ __device__ __forceinline__ void sr_gather(const SrFq<T> *__restrict__ fq, const 
     constexpr int NTH = SrCfg<T>::NTH;
     const std::conditional_t<sizeof(T) == 4, PnWinF, SrWinD> wk_;
     const int logs = G >= NTH ? 0 : __builtin_ctz(NTH / G), S = 1 << logs;
-    for (int mb = 0; mb < G; mb += (NTH >> logs)) {
+    const int npts = MIRROR ? G / 2 + W + 1 : G;
+    for (int mb = 0; mb < npts; mb += (NTH >> logs)) {
         const int m = mb + (tid >> logs), q = tid & (S - 1);
         // centred: the regular frequencies sit in [0, G/2] (the Nyquist row is direct) and reach W/2 to either side (G >= 32 > 2 W)
-        const float mm = (float)(m > G / 2 + W / 2 ? m - G : m);
+        const float mm = MIRROR ? (float)(m - W / 2) : (float)(m > G / 2 + W / 2 ? m - G : m);
         T ax[J], ay[J];
 #pragma unroll
         for (int p = 0; p < J; ++p) ax[p] = ay[p] = 0;
         const float uhi = mm + 0.5f * W, ulo = fmaxf(mm - 0.5f * W, 0.f);
-        if (uhi > 0.f) {
+        if (uhi > 0.f && m < npts) {
             int ilo = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * ulo, ulo, c2)) * inv_dw) - 3;
             int ihi = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * uhi, uhi, c2)) * inv_dw) + 2;
             ilo = max(ilo, ifirst);
@@ -198,14 +209,21 @@ __device__ __forceinline__ void sr_gather(const SrFq<T> *__restrict__ fq, const 
             const int len = max(ihi - ilo + 1, 0), per = (len + S - 1) >> logs;
             const int i0 = ilo + q * per, i1 = min(i0 + per, ihi + 1);
             for (int i = i0; i < i1; ++i) {
-                const SrFq<T> f = fq[own_pad(i - ifirst)];
+                const FQ f = fq[own_pad(i - ifirst)];
                 const T x = (T)(f.uh - mm) + f.fr;
                 const T wgt = sr_window(x, wk_);
-                T tx = f.dx * wgt, ty = f.dy * wgt;
+                T tx, ty;
+                if constexpr (MIRROR) {
+                    tx = f.ex * wgt;
+                    ty = f.ey * wgt;
+                } else {
+                    tx = f.dx * wgt;
+                    ty = f.dy * wgt;
+                }
                 ax[0] += tx;
                 ay[0] += ty;
                 if (J > 1) {
-                    const T z = zz[own_pad(i - ifirst)];
+                    const T z = MIRROR ? -zz[own_pad(i - ifirst)] : zz[own_pad(i - ifirst)];
 #pragma unroll
                     for (int p = 1; p < J; ++p) {
                         tx *= z;
@@ -224,17 +242,23 @@ __device__ __forceinline__ void sr_gather(const SrFq<T> *__restrict__ fq, const 
                 ay[p] += __shfl_xor(ay[p], o, 64);
             }
         }
-        if (q == 0) {
+        if (q == 0 && m < npts) {
+            const int at = MIRROR ? own_pad((W / 2 - m) & (G - 1)) : own_pad(m);
 #pragma unroll
             for (int p = 0; p < J; ++p) {
-                OCp<T> *g = grids + p * gstride + own_pad(m);
-                *g = add ? OCp<T>{g->x + ax[p], g->y + ay[p]} : OCp<T>{ax[p], ay[p]};       // (this thread's own grid point in every round)
+                OCp<T> *g = grids + p * gstride + at;
+                *g = (add || MIRROR) ? OCp<T>{g->x + ax[p], g->y + ay[p]} : OCp<T>{ax[p], ay[p]};       // (this thread's own grid point in every round)
             }
         }
     }
 }
 
-template <typename T>
+// PAIR (round 6, as ps_nufft_kernel<T, true>): the wavenumbers k and tnum - k in one workgroup, summed as their Hermitian combination
+// G = (TK[k] + conj TK[tnum - k]) / 2 -- all that the real part of the inverse transform over the wavenumbers keeps.  Classification,
+// direct lists, the pieces' series and coefficients' phases depend on kx^2 only and are made once; the direct band costs one sum
+// (SrDirect); the J grids take the partner's mirrored nodes in a second gather pass (sr_gather<..., MIRROR>); FFTs and the output pass
+// with its y_p recurrences once.  G goes to row k, conj G to row tnum - k.
+template <typename T, bool PAIR = false>
 __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sr_lds[];
@@ -242,10 +266,12 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nf = P.nf;
     // small |kx| (few evanescent frequencies: the long workgroups) first
-    const int bq = (int)blockIdx.x, kb = (bq & 1) ? P.nk - 1 - (bq >> 1) : (bq >> 1), k = P.k0 + kb;
-    constexpr int NTH = SrCfg<T>::NTH, NWV = NTH / 64, PER = SR_NFMAX / NTH, NHALF = SrCfg<T>::NHALF, HN = SR_NFMAX / NHALF, PERH = PER / NHALF;
+    const int bq = (int)blockIdx.x, kb = PAIR ? bq : ((bq & 1) ? P.nk - 1 - (bq >> 1) : (bq >> 1)), k = P.k0 + kb;
+    const int k2 = PAIR ? (k == 0 ? 0 : P.nk - k) : k;                                  // (PAIR: the whole axis, k0 = 0)
+    constexpr int NTH = SrCfg<T>::NTH, NWV = NTH / 64, PER = SR_NFMAX / NTH, NHALF = sr_nhalf<T>(PAIR), HN = SR_NFMAX / NHALF, PERH = PER / NHALF;
     constexpr int NOUT = 2048 / NTH;                                                    // output steps per thread: pieces of up to 2048 steps
-    SrFq<T> *fq = reinterpret_cast<SrFq<T> *>(sr_lds);                                  // [own_pad(HN) + 1]
+    using FQ = SrFqT<T, PAIR>;
+    FQ *fq = reinterpret_cast<FQ *>(sr_lds);                                            // [own_pad(HN) + 1]
     T *zz = reinterpret_cast<T *>(fq + own_pad(HN) + 1);                                // [own_pad(HN) + 1]
     OCp<T> *grids = reinterpret_cast<OCp<T> *>(zz + own_pad(HN) + 1);             // J grids; scratch of the direct sums before
     OCp<T> *gend = reinterpret_cast<OCp<T> *>(reinterpret_cast<unsigned char *>(grids) + Q.grid_bytes);
@@ -256,6 +282,7 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
     T *cmv = reinterpret_cast<T *>(gend);                                               // [SR_MJMAX] c_m of the piece (in the 64-element gap)
     const Cp<T> *Frow = reinterpret_cast<const Cp<T> *>(P.F) + (size_t)k * P.fstride;
     Cp<T> *TKrow = reinterpret_cast<Cp<T> *>(P.TK) + (size_t)kb * P.snum;
+    Cp<T> *TKrow2 = reinterpret_cast<Cp<T> *>(P.TK) + (size_t)k2 * P.snum;
     const double kxk = P.kx[k], kxh = 0.5 * fabs(kxk);
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     const T inv_snum = (T)1 / (T)P.snum;
@@ -357,13 +384,20 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
                 for (int j = 0; j < PER; ++j)
                     if (dir[j] && rank[j] >= base && rank[j] < base + nd) {
                         const int slot = slot_of(tid + NTH * j);
-                        const Cp<T> f = ps_load_slot<T>(Frow, P, slot);
+                        const Cp<T> f = PAIR ? ps_load_slot_k<T>(P, k, slot) : ps_load_slot<T>(Frow, P, slot);
                         SrDirect d;
                         d.ph = ph[j];
                         d.w = P.w[slot];
                         d.rw = Q.rw[slot];
-                        d.fx = (double)f.x;
-                        d.fy = (double)f.y;
+                        d.fx = d.gx = (double)f.x;
+                        d.fy = d.gy = (double)f.y;
+                        if (PAIR) {
+                            const Cp<T> f2 = ps_load_slot_k<T>(P, k2, slot);
+                            d.fx = (double)(f.x + f2.x);
+                            d.fy = (double)(f.y + f2.y);
+                            d.gx = (double)(f.x - f2.x);
+                            d.gy = (double)(f.y - f2.y);
+                        }
                         dl[rank[j] - base] = d;
                     }
                 for (int m = tid; m < gp * L; m += NTH) part[m] = OCp<T>{(T)0, (T)0};
@@ -428,6 +462,7 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
                             dead_at = min(dead_at, cdead[(g * nch + cc) * 64 + lane]);
                         }
                         const T fx = mine ? (T)dl[e].fx : (T)0, fy = mine ? (T)dl[e].fy : (T)0;
+                        const T hx = mine ? (T)dl[e].gx : (T)0, hy = mine ? (T)dl[e].gy : (T)0;       // (PAIR: the difference of the rows; else the same)
                         T keepx = 0, keepy = 0;                            // lane q keeps step q's sum
 #pragma unroll 2
                         for (int q = 0; q < SR_DCH; ++q) {
@@ -440,7 +475,7 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
                                 T sn, cs_;
                                 pn_sincos(start, &sn, &cs_);
                                 vx = fma(fx, cs_, -(fy * sn));               // :464, :487
-                                vy = fma(fx, sn, fy * cs_);
+                                vy = fma(hx, sn, hy * cs_);
                             }
                             vx = sr_wave_sum<T>(vx);
                             vy = sr_wave_sum<T>(vy);
@@ -493,7 +528,7 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
 #pragma unroll
             for (int jh = 0; jh < PERH; ++jh) {
                 const int j = half * PERH + jh, il = tid + NTH * jh;
-                SrFq<T> f{(T)0, (T)0, (T)0, 0.f};
+                FQ f{};
                 T z = 0;
                 const double wj = (double)(il + half * HN + 1) * dw_d, p2 = wj * wj - cb2;
                 const bool reg = (regm >> j) & 1u;
@@ -501,16 +536,21 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
                     // the Nyquist row: not on the grid (see SrNyq)
                     SrNyq q;
                     q.valid = 0;
-                    q.ph0 = q.inc = q.fx = q.fy = q.z = 0.0;
+                    q.ph0 = q.inc = q.fx = q.fy = q.z = q.f2x = q.f2y = 0.0;
                     if (reg) {
                         double rinv;
                         const double psi = sr_sqrt(p2, &rinv), inc = P.dt * psi;
-                        const Cp<T> fs = ps_load_slot<T>(Frow, P, 0);
+                        const Cp<T> fs = PAIR ? ps_load_slot_k<T>(P, k, 0) : ps_load_slot<T>(Frow, P, 0);
                         q.valid = 1;
                         q.ph0 = ph[j];
                         q.inc = inc;
                         q.fx = (double)fs.x;
                         q.fy = (double)fs.y;
+                        if (PAIR) {
+                            const Cp<T> f2 = ps_load_slot_k<T>(P, k2, 0);
+                            q.f2x = (double)f2.x;
+                            q.f2y = (double)f2.y;
+                        }
                         q.z = psi_min * rinv;
                         double ser = 0.0;
                         if (mser > 0) {
@@ -526,9 +566,14 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
                     const double psi = sr_sqrt(p2, &rinv), inc = P.dt * psi;
                     T sn, c;
                     pn_sincos(ph[j] + (double)(1 + Lp / 2) * inc, &sn, &c);
-                    const Cp<T> fs = ps_load_slot<T>(Frow, P, slot_of(il + half * HN));
+                    const Cp<T> fs = PAIR ? ps_load_slot_k<T>(P, k, slot_of(il + half * HN)) : ps_load_slot<T>(Frow, P, slot_of(il + half * HN));
                     f.dx = fma(fs.x, c, -(fs.y * sn));
                     f.dy = fma(fs.x, sn, fs.y * c);
+                    if constexpr (PAIR) {
+                        const Cp<T> f2 = ps_load_slot_k<T>(P, k2, slot_of(il + half * HN));      // the partner's, mirrored: conj(f2 e^{i theta})
+                        f.ex = fma(f2.x, c, -(f2.y * sn));
+                        f.ey = -fma(f2.x, sn, f2.y * c);
+                    }
                     // the phase at the end of the piece: L dt psi - dt psi sum_m be_m t^m, t = kxh^2 s / psi^2 <= 0.1
                     double ser = 0.0;
                     if (mser > 0) {
@@ -552,15 +597,24 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
                 const float a = (float)(6.283185307179586 / ((double)G * P.dt)), a2 = a * a;
                 const int ifirst = half * HN, ilast = min(nf - 2, ifirst + HN - 1);
                 const bool add = half > 0;
+#define SR_GATHER(JJ)                                                                                                             \
+    do {                                                                                                                          \
+        sr_gather<T, JJ, FQ>(fq, zz, grids, gstride, G, tid, ifirst, ilast, a2, c2, inv_dw, add);                                 \
+        if constexpr (PAIR) {                                                                                                     \
+            __syncthreads();               /* (the mirrored points overlap the first pass's at both ends of the half grid) */    \
+            sr_gather<T, JJ, FQ, true>(fq, zz, grids, gstride, G, tid, ifirst, ilast, a2, c2, inv_dw, true);                      \
+        }                                                                                                                         \
+    } while (0)
                 switch (J) {
-                case 1: sr_gather<T, 1>(fq, zz, grids, gstride, G, tid, ifirst, ilast, a2, c2, inv_dw, add); break;
-                case 2: sr_gather<T, 2>(fq, zz, grids, gstride, G, tid, ifirst, ilast, a2, c2, inv_dw, add); break;
-                case 4: sr_gather<T, 4>(fq, zz, grids, gstride, G, tid, ifirst, ilast, a2, c2, inv_dw, add); break;
-                case 6: sr_gather<T, 6>(fq, zz, grids, gstride, G, tid, ifirst, ilast, a2, c2, inv_dw, add); break;
-                case 8: sr_gather<T, 8>(fq, zz, grids, gstride, G, tid, ifirst, ilast, a2, c2, inv_dw, add); break;
-                case 12: sr_gather<T, 12>(fq, zz, grids, gstride, G, tid, ifirst, ilast, a2, c2, inv_dw, add); break;
-                default: sr_gather<T, 16>(fq, zz, grids, gstride, G, tid, ifirst, ilast, a2, c2, inv_dw, add); break;
+                case 1: SR_GATHER(1); break;
+                case 2: SR_GATHER(2); break;
+                case 4: SR_GATHER(4); break;
+                case 6: SR_GATHER(6); break;
+                case 8: SR_GATHER(8); break;
+                case 12: SR_GATHER(12); break;
+                default: SR_GATHER(16); break;
                 }
+#undef SR_GATHER
             }
         }
         __syncthreads();
@@ -621,8 +675,21 @@ __global__ __launch_bounds__(SrCfg<T>::NTH, 1) void ps_series_kernel(SrParams Q)
                     const T ex = fma(fx, c, -(fy * sn)), ey = fma(fx, sn, fy * c);
                     dx += fma(ex, px, ey * py);                                    // e * conj(poly)
                     dy += fma(ey, px, -(ex * py));
+                    if (PAIR) {
+                        // + conj(e2 conj(poly)) = conj(e2) poly, e2 the partner's
+                        const T f2x = (T)nyq->f2x, f2y = (T)nyq->f2y;
+                        const T e2x = fma(f2x, c, -(f2y * sn)), e2y = fma(f2x, sn, f2y * c);
+                        dx += fma(e2x, px, e2y * py);
+                        dy += fma(e2x, py, -(e2y * px));
+                    }
                 }
-                reinterpret_cast<Cp<T> *>(TKrow)[pstart + n] = Cp<T>{(sx * cf + dx) * inv_snum, (sy * cf + dy) * inv_snum};   // :492
+                T ox = (sx * cf + dx) * inv_snum, oy = (sy * cf + dy) * inv_snum;                                    // :492
+                if (PAIR) {
+                    ox *= (T)0.5;
+                    oy *= (T)0.5;
+                    if (k2 != k) TKrow2[pstart + n] = Cp<T>{ox, -oy};
+                }
+                TKrow[pstart + n] = Cp<T>{ox, oy};
             }
         }
         __syncthreads();

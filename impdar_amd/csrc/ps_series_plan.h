@@ -55,6 +55,9 @@ static inline SrModel sr_model(bool dbl)
 // of the model and 8192 wavenumbers; the per-step kernels 5.3e-6 (float32) / 10.8e-6 (float64) ms per alive pair.  The library takes this path
 // where the estimate says it wins by a margin (phaseshift.hip).
 constexpr double SR_MS_PER_MODEL_F32 = 2.2e-7, SR_MS_PER_MODEL_F64 = 3.5e-7, SR_MS_PER_PAIR_F32 = 5.3e-6, SR_MS_PER_PAIR_F64 = 10.8e-6;
+// a pair of wavenumbers per workgroup (ps_series_kernel<T, true>): everything but the gather once for two rows -- measured against the
+// one-row kernel per 8192 wavenumbers (profiles/r06_series.txt section 7)
+constexpr double SR_PAIR_FACTOR = 0.76;      // (float32, 8192^2: 110 -> 77.5, 52 -> 41.2, 87 -> 67.6, 14.7 -> 11.5 ms)
 
 static inline double sr_b(int m)     // sqrt(1 - x) = 1 - sum_m b_m x^m
 {
