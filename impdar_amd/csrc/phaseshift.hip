@@ -1884,7 +1884,7 @@ static int ps_series_run(PsPlan &pl, PsParams P, const double *vmig, const doubl
 {
     // allow_pairs: as ps_nufft_run's -- the sums go on into the inverse transform: rows k and tnum - k as their Hermitian combination
     // alt_ms_8192 > 0: what the kernel that would take the call otherwise is expected to need (per 8192 wavenumbers); the call is
-    // taken only where the planner's estimate is 0.85 of that or less.  0: taken regardless (IMPDAR_PS_MFMA=7)
+    // taken only where the estimate from the planner.s model is SR_MARGIN (0.9) of that or less.  0: taken regardless (IMPDAR_PS_MFMA=7)
     *done = false;
     const int snum = P.snum, tnum = P.tnum, nf = P.nf;
     constexpr bool dbl = sizeof(T) == 8;
@@ -1923,9 +1923,11 @@ static int ps_series_run(PsPlan &pl, PsParams P, const double *vmig, const doubl
     if (alt_ms_8192 != 0.0) {
         // (alt < 0: per alive pair -- the per-step kernels)
         const double alt = alt_ms_8192 > 0.0 ? alt_ms_8192 : -alt_ms_8192 * hp.alive_pairs;
-        const double est = (dbl ? SR_MS_PER_MODEL_F64 : SR_MS_PER_MODEL_F32) * hp.model_cost * (pairs ? SR_PAIR_FACTOR : 1.0);
+        const double rest = hp.model_cost - hp.model_gather;
+        const double est = dbl ? SR_MS_GATHER_F64 * hp.model_gather + SR_MS_REST_F64 * rest
+                               : SR_MS_GATHER_F32 * hp.model_gather + (pairs ? SR_MS_REST_PAIR_F32 : SR_MS_REST_F32) * rest;
         impdar_trace("ps_series: estimate %.1f ms per 8192 wavenumbers against %.1f", est, alt);
-        if (est > 0.85 * alt) return IMPDAR_OK;
+        if (est > SR_MARGIN * alt) return IMPDAR_OK;
     }
     bool need[13] = {};
     for (const SrPiece &pc : hp.pieces) need[pc.loglp] = true;

@@ -23,9 +23,10 @@
 // A frequency dies for good when coss <= thr at some step (:484-485); regular frequencies cannot (eps <= 0.1 psi^2 on them).
 //
 // Prototype and error table: profiles/tools/r06_series_proto.py, profiles/r06_series_proto.txt; measurements, stage by stage:
-// profiles/r06_series.txt.  The library takes this path where the planner's estimate beats the per-step kernels (phaseshift.hip):
-// profiles whose velocity settles -- a firn column -- or falls; on a rising gradient every piece has a band of frequencies about
-// to turn evanescent, and the direct sums there cost more than the transforms save.
+// profiles/r06_series.txt.  The library takes this path where the estimate from the planner's model beats the per-step kernels
+// (phaseshift.hip): profiles whose velocity settles -- a firn column -- or falls; on a rising gradient every piece has a band of
+// frequencies about to turn evanescent, and the direct sums there cost what the transforms save -- until a workgroup sums a PAIR of
+// wavenumbers (float32, below), which halves everything but the gather.
 //
 // Work split: one workgroup of 1024 threads (float64: 512) per wavenumber; a thread owns 4 (8) frequencies (float64 phase in
 // registers, NaN = dead) and walks the pieces in depth order.  Per piece: classification -> direct list (ranks by ballot, fixed

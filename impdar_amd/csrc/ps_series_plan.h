@@ -54,10 +54,16 @@ static inline SrModel sr_model(bool dbl)
 // Measured at 8192 x 8192 on one MI355X (profiles/r06_series.txt): the kernel takes ~2.0e-7 (float32) / ~3.5e-7 (float64) ms per unit
 // of the model and 8192 wavenumbers; the per-step kernels 5.3e-6 (float32) / 10.8e-6 (float64) ms per alive pair.  The library takes this path
 // where the estimate says it wins by a margin (phaseshift.hip).
-constexpr double SR_MS_PER_MODEL_F32 = 2.2e-7, SR_MS_PER_MODEL_F64 = 3.5e-7, SR_MS_PER_PAIR_F32 = 5.3e-6, SR_MS_PER_PAIR_F64 = 10.8e-6;
-// a pair of wavenumbers per workgroup (ps_series_kernel<T, true>): everything but the gather once for two rows -- measured against the
-// one-row kernel per 8192 wavenumbers (profiles/r06_series.txt section 7)
-constexpr double SR_PAIR_FACTOR = 0.76;      // (float32, 8192^2: 110 -> 77.5, 52 -> 41.2, 87 -> 67.6, 14.7 -> 11.5 ms)
+constexpr double SR_MS_PER_PAIR_F32 = 5.3e-6, SR_MS_PER_PAIR_F64 = 10.8e-6;
+// The kernel's time per 8192 wavenumbers from the model's two parts -- the gathers (window values and accumulations: per wavenumber even
+// when a workgroup sums a PAIR of them) and the rest (classification, direct band, coefficients, FFTs, output: once per workgroup) --
+// least squares over the four 8192^2 profiles of profiles/r06_series.txt section 7 (rising / falling gradient, wavy, firn column):
+//   float32, one row per workgroup   8.4e-7 gather + 1.43e-7 rest   -> 108.9 / 52.3 / 85.3 / 14.1 ms against 109 / 51 / 86 / 13.6 measured
+//   float32, a pair per workgroup    8.4e-7 gather + 0.76e-7 rest   ->  76.5 / 40.4 / 66.3 /  9.7          76.4 / 40.1 / 66.5 / 10.4
+//   float64, one row                 6.45e-7 gather + 2.24e-7 rest  -> 371 / 253 / 442 / 59                366 / 272 / 434 / 64
+// (a single factor on the whole model, the first form, was up to 17 % off)
+constexpr double SR_MS_GATHER_F32 = 8.4e-7, SR_MS_REST_F32 = 1.43e-7, SR_MS_REST_PAIR_F32 = 0.76e-7, SR_MS_GATHER_F64 = 6.45e-7, SR_MS_REST_F64 = 2.24e-7;
+constexpr double SR_MARGIN = 0.9;        // the path is taken where its estimate is this share of the other kernel's or less
 
 static inline double sr_b(int m)     // sqrt(1 - x) = 1 - sum_m b_m x^m
 {
@@ -178,6 +184,7 @@ struct SrHostPlan {
     double kxh_max = 0;
     int grid_bytes = 0;
     double model_cost = 0;           // the walk's modelled cost of the whole profile (lane-ns per wavenumber, mean of the two judged)
+    double model_gather = 0;         // ... of which the gathers' window values and accumulations: what a PAIR of wavenumbers does not share
     double alive_pairs = 0;          // (frequency, step) pairs that are alive, mean of the same two wavenumbers: what a per-step kernel walks
     // what it was made from
     std::vector<double> v;
@@ -200,6 +207,7 @@ static bool sr_make_plan(SrHostPlan &hp, const double *v, int snum, double dt, d
     hp.kxh_max = kxh_max;
     hp.grid_bytes = 0;
     hp.model_cost = 0;
+    hp.model_gather = 0;
     hp.alive_pairs = 0;
     hp.v.assign(v, v + snum);
     hp.dt = dt;
@@ -214,7 +222,7 @@ static bool sr_make_plan(SrHostPlan &hp, const double *v, int snum, double dt, d
     int a = 0;
     while (a < snum) {
         int bestL = 0, bestJ = 0;
-        double best = 1e300, best_est = 0.0;
+        double best = 1e300, best_est = 0.0, best_gather = 0.0;
         // candidate lengths: powers of two, the rest of the record, and the end of the run of constant velocity we stand in
         int cand[16], nc = 0;
         for (int L = 32; L <= 2048 && nc < 12; L *= 2) cand[nc++] = std::min(L, snum - a);
@@ -237,7 +245,7 @@ static bool sr_make_plan(SrHostPlan &hp, const double *v, int snum, double dt, d
                 const int J = ji < 0 ? 1 : JS[ji];
                 if ((J == 1) != (st.s == 0.0)) continue;
                 if (!sr_fits(1 << l, J, csize, grid_budget)) continue;
-                double cost = 0.0, cost_est = 0.0;
+                double cost = 0.0, cost_est = 0.0, cost_gather = 0.0;
                 for (double kxh : kreps) {
                     const double lam = sr_cut(st, dt, kxh, J, M.tol, ji < 0 ? 1.0 : xj[ji], 0, SR_RHO);
                     const double cb2 = kxh * kxh * st.vb2, pm2 = kxh * kxh * lam * lam;
@@ -249,11 +257,13 @@ static bool sr_make_plan(SrHostPlan &hp, const double *v, int snum, double dt, d
                                         (double)J * G * (l + 1) * M.fft;
                     cost += rest + n_dir * L * M.dir;
                     cost_est += rest + n_dir * L * M.dir_measured;
+                    cost_gather += n_reg * M.W * (M.win + M.perj * J);
                 }
                 const double per_step = cost / L;
                 if (per_step < best) {
                     best = per_step;
                     best_est = cost_est;
+                    best_gather = cost_gather;
                     bestL = L;
                     bestJ = J;
                 }
@@ -261,6 +271,7 @@ static bool sr_make_plan(SrHostPlan &hp, const double *v, int snum, double dt, d
         }
         if (!bestL) return false;                      // (nothing fits: not ours)
         hp.model_cost += 0.5 * best_est;
+        hp.model_gather += 0.5 * best_gather;
         SrPiece pc{};
         pc.start = a;
         pc.len = bestL;

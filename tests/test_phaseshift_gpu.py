@@ -198,7 +198,7 @@ def _config5_profile(name, n, geo):
 
 # what runs by itself at 8192 x 8192 (the library's estimate decides between the series path and the per-step / runs kernels:
 # phaseshift.hip, ps_series_plan.h)
-_CONFIG5_KERNEL = {('gradient', 'float32'): 'ps_smooth32_kernel', ('gradient', 'float64'): 'ps_smooth_kernel',
+_CONFIG5_KERNEL = {('gradient', 'float32'): 'ps_series_kernel', ('gradient', 'float64'): 'ps_smooth_kernel',
                    ('wavy', 'float32'): 'ps_series_kernel', ('wavy', 'float64'): 'ps_smooth_kernel',
                    ('falling', 'float32'): 'ps_series_kernel', ('falling', 'float64'): 'ps_smooth_kernel',
                    ('firn', 'float32'): 'ps_series_kernel', ('firn', 'float64'): 'ps_series_kernel',
