@@ -215,7 +215,10 @@ int impdar_phaseshift_dev(impdar_ctx *ctx, const void *d_data, int dtype, int sn
  *   impdar_phaseshift_tk_dev      -> d_tk [nk][snum] complex: TK (already / snum, :492) of wavenumbers [k0, k0 + nk)
  *   impdar_ps_alltoall_dev        -> d_t2 [tnum][tw] complex: all wavenumbers, its own depth rows (grouped RCCL
  *                                    send/recv; tau_edges / k_edges: nranks + 1 slab edges, the same on every rank)
- *   impdar_phaseshift_finish_dev  -> d_out (tw, tnum) real: ifft over k, real part (:282) */
+ *   impdar_phaseshift_finish_dev  -> d_out (tw, tnum) real: ifft over k, real part (:282)
+ * (d_tk holds the rows TK[k] themselves.  impdar_phaseshift / impdar_phaseshift_dev, which only need the real part of the inverse
+ * transform, may sum rows k and tnum - k as their Hermitian combination (TK[k] + conj TK[tnum - k]) / 2 -- one transform for two
+ * rows, csrc/ps_nufft.h, ps_series.h; the image is the same.) */
 int impdar_phaseshift_tk_dev(impdar_ctx *ctx, const void *d_data, int dtype, int snum, int tnum, int nt,
                              const double *kx, const double *ws, double dt, const double *tt_us, double vconst,
                              const double *vmig, int vmig_len, double htaper, double vtaper, int k0, int nk, void *d_tk);
