@@ -140,11 +140,12 @@ __device__ __forceinline__ void own_fft_passes(OCp<T> *s, int M, int logm, int t
 //      inverse over the wavenumbers (mig_python.py:282) without a pass of its own
 // tw:  e^{-2 pi i k / NT}, k < NT, NT = M (MODE 0/1) or 2 M (MODE 2/3)
 // wcol, wrow (MODE 2, both or neither): float64 weights -- sample j of row r enters as (T)((double) x * (wcol[j] * wrow[r])): the
-// phase shift's taper (mig_python.py:258) applied on the way into the transform over the traces
+// phase shift's taper (mig_python.py:258) applied on the way into the transform over the traces; wfirst: (T)(((double) x * wcol[j]) *
+// wrow[r]), Stolt's order (:157)
 template <typename T, int MODE>
 __global__ __launch_bounds__(1024) void own_fft_rows(const void *__restrict__ in_, void *__restrict__ out_, int M, int logm, size_t in_dist,
                                                     size_t out_dist, T scale, const OCp<T> *__restrict__ tw, const double *__restrict__ wcol,
-                                                    const double *__restrict__ wrow)
+                                                    const double *__restrict__ wrow, int wfirst)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char own_lds[];
     OCp<T> *s = reinterpret_cast<OCp<T> *>(own_lds);
@@ -171,7 +172,8 @@ __global__ __launch_bounds__(1024) void own_fft_rows(const void *__restrict__ in
             const double wr = wrow[row];
             for (int i = tid; i < M; i += nth) {
                 const OCp<T> v = X[i];
-                s[own_pad(i)] = OCp<T>{(T)((double)v.x * (wcol[2 * i] * wr)), (T)((double)v.y * (wcol[2 * i + 1] * wr))};
+                s[own_pad(i)] = wfirst ? OCp<T>{(T)(((double)v.x * wcol[2 * i]) * wr), (T)(((double)v.y * wcol[2 * i + 1]) * wr)}
+                                       : OCp<T>{(T)((double)v.x * (wcol[2 * i] * wr)), (T)((double)v.y * (wcol[2 * i + 1] * wr))};
             }
         } else {
             for (int i = tid; i < M; i += nth) s[own_pad(i)] = X[i];
@@ -256,7 +258,7 @@ struct OwnTwiddles {
 // respective side (complex for complex rows, real for real rows)
 template <typename T>
 static int own_fft_launch(int mode, int n, size_t batch, const void *in, void *out, size_t in_dist, size_t out_dist, double scale,
-                          const OwnTwiddles &tw, hipStream_t st, const double *wcol = nullptr, const double *wrow = nullptr)
+                          const OwnTwiddles &tw, hipStream_t st, const double *wcol = nullptr, const double *wrow = nullptr, int wfirst = 0)
 {
     const int M = (mode == OWN_R2C || mode == OWN_C2R) ? n / 2 : n;
     int logm = 0;
@@ -278,7 +280,7 @@ static int own_fft_launch(int mode, int n, size_t batch, const void *in, void *o
     do {                                                                                                                          \
         auto k = own_fft_rows<T, MODE>;                                                                                           \
         IMPDAR_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
-        hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(threads), lds, st, in, out, M, logm, in_dist, out_dist, (T)scale, t, wcol, wrow); \
+        hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(threads), lds, st, in, out, M, logm, in_dist, out_dist, (T)scale, t, wcol, wrow, wfirst); \
     } while (0)
     switch (mode) {
     case OWN_C2C_FWD: OWN_LAUNCH(OWN_C2C_FWD); break;

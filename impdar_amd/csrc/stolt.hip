@@ -220,6 +220,61 @@ __global__ __launch_bounds__(256) void stolt_stretch_t(const Cx<T> *__restrict__
     K[(size_t)zj * tnum + xi] = o;
 }
 
+// The same on the spectrum as [kx >= 0][all frequencies] (round 6: the transform over the traces taken first, on the radargram's own
+// rows; rows k = 0 .. tnum/2 of snum complex numbers in FFT order).  irfft2 (:202) extends KK Hermitian-wise, KK[-w][kx] =
+// conj KK[w][-kx], and conj FK[i][-kx] = FK[-i][kx] for a real radargram: the negative-frequency half of row kx is the same
+// interpolation, with the same weights (they depend on |kx| only), between the mirrored knots of the SAME row.  One thread per
+// (kx, zj), zj the fast index; the zero-frequency and Nyquist rows of KK are zero (kz = 0 scales the first to zero, :196; KK[:nz]
+// alone is filled, :190), so numpy's dropping of their imaginary parts has nothing to drop.
+template <typename T>
+__global__ __launch_bounds__(256) void stolt_stretch_rows(const Cx<T> *__restrict__ B, Cx<T> *__restrict__ K,
+                                                          const double *__restrict__ kx, const double *__restrict__ ws,
+                                                          int m, int nz, int snum, double vel)
+{
+    const int zj = blockIdx.x * 256 + threadIdx.x;
+    const int xi = blockIdx.y;
+    if (zj > nz) return;
+    const Cx<T> *row = B + (size_t)xi * snum;
+    Cx<T> *orow = K + (size_t)xi * snum;
+    Cx<T> o, om;
+    o.x = o.y = om.x = om.y = 0;
+    if (zj < nz) {
+        const double kxi = kx[xi];
+        const double kz = ws[zj] * 2.0 / vel;                       // :180
+        const double kk = sqrt(kz * kz + kxi * kxi);                // :188 and :196
+        double wq = vel / 2.0 * kk;
+        const double wlast = ws[m - 1];
+        if (wq > wlast) wq = wlast;                                 // FITPACK clamps to the last knot
+        const double dw = ws[1] - ws[0];
+        int i0 = (int)floor(wq / dw);
+        i0 = min(max(i0, 0), m - 2);
+        while (i0 > 0 && ws[i0] > wq) --i0;
+        while (i0 < m - 2 && ws[i0 + 1] <= wq) ++i0;
+        const double w = (wq - ws[i0]) / (ws[i0 + 1] - ws[i0]);
+        const double sc = kz / kk;                                  // :196
+        {
+            const Cx<T> a = row[i0], b = row[i0 + 1];
+            const T re = (T)((1.0 - w) * (double)a.x + w * (double)b.x);    // (:190, :198: stored, then scaled in double and rounded again)
+            const T im = (T)((1.0 - w) * (double)a.y + w * (double)b.y);
+            o.x = (T)((double)re * sc);
+            o.y = (T)((double)im * sc);
+        }
+        if (zj > 0) {
+            const Cx<T> a = row[i0 == 0 ? 0 : snum - i0], b = row[snum - i0 - 1];
+            const T re = (T)((1.0 - w) * (double)a.x + w * (double)b.x);
+            const T im = (T)((1.0 - w) * (double)a.y + w * (double)b.y);
+            om.x = (T)((double)re * sc);
+            om.y = (T)((double)im * sc);
+        }
+        if (zj == 0 && xi == 0) {                                   // :200
+            o.x = 0;
+            o.y = 0;
+        }
+    }
+    orow[zj] = o;                                                   // (zj = nz: the Nyquist row, zero)
+    if (zj > 0 && zj < nz) orow[snum - zj] = om;
+}
+
 // C2R ignores the imaginary part of the DC and Nyquist bins (numpy irfft):
 // clear them so any Hermitian-assuming backend agrees.
 template <typename T>
@@ -242,6 +297,9 @@ struct StoltPlan {
     FftPlan fwd2d, inv2d;               // the same two pairs as 2-D real transforms (default)
     bool use2d = true, no_own = false;
     DevBuf X, F, K, Y, d_kx, d_ws;
+    DevBuf d_taper;                     // [tnum + snum] float64 taper weights (the transform over the traces taken first)
+    std::vector<double> h_taper;        // ... on the host (alive until the next call: async copy), and what they were made from
+    double taper_h = -1.0, taper_v = -1.0;
 };
 
 static std::mutex g_stolt_mu;
@@ -292,8 +350,9 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
         pl.own_calls = 0;
         pl.plans_ready = false;
         pl.dtype = -1;
+        pl.h_taper.clear();
         if (pl.owner != ctx) {               // another device / stream: drop everything bound to the old one
-            pl.X.release(); pl.F.release(); pl.K.release(); pl.Y.release(); pl.d_kx.release(); pl.d_ws.release();
+            pl.X.release(); pl.F.release(); pl.K.release(); pl.Y.release(); pl.d_kx.release(); pl.d_ws.release(); pl.d_taper.release();
             pl.owner = ctx;
         }
         int rc;
@@ -333,8 +392,10 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
                 return rc;
         }
         IMPDAR_HIP_CHECK(pl.X.ensure((size_t)tnum * snum * sizeof(T)));
-        IMPDAR_HIP_CHECK(pl.F.ensure((size_t)tnum * m * 2 * sizeof(T)));
-        IMPDAR_HIP_CHECK(pl.K.ensure((size_t)tnum * m * 2 * sizeof(T)));
+        // (the rows layout, below: [snum][tnum/2 + 1] and [tnum/2 + 1][snum] complex)
+        const size_t spec = std::max((size_t)tnum * m, (size_t)snum * (tnum / 2 + 1));
+        IMPDAR_HIP_CHECK(pl.F.ensure(spec * 2 * sizeof(T)));
+        IMPDAR_HIP_CHECK(pl.K.ensure(spec * 2 * sizeof(T)));
         IMPDAR_HIP_CHECK(pl.Y.ensure((size_t)tnum * nout * sizeof(T)));
         IMPDAR_HIP_CHECK(pl.d_kx.ensure((size_t)tnum * 8));
         IMPDAR_HIP_CHECK(pl.d_ws.ensure((size_t)m * 8));
@@ -356,10 +417,46 @@ static int stolt_run(impdar_ctx *ctx, StoltPlan &pl, const void *d_data, int snu
         if (trc) return trc;
     }
     const int do_taper = !(htaper != htaper);     // NaN = caller already tapered (integer dtypes)
+    // Round 6, power-of-two sizes: the transform over the TRACES first, on the radargram's own rows with the taper applied on load,
+    // wavenumbers k = 0 .. tnum/2 only -- R2C over x -> [snum][hs]; transpose -> [hs][snum]; C2C over time; the stretch along the rows
+    // (both signs of the frequency: stolt_stretch_rows); C2C back over time; transpose -> [snum][hs]; C2R over x straight into the
+    // output: seven passes instead of ten (no transposes of the real arrays at either end, two half-size transposes instead of two
+    // whole ones)
+    const bool use_rows = use_own && own_fft_len_ok(snum) && tnum >= 64 && nout == snum;
+    if (use_rows && do_taper && !(pl.h_taper.size() == (size_t)tnum + snum && pl.taper_h == htaper && pl.taper_v == vtaper && pl.d_taper.p)) {
+        std::vector<double> &taps = pl.h_taper;
+        taps.resize((size_t)tnum + snum);
+        for (int j = 0; j < tnum; ++j) taps[j] = impdar_taper_w(j, tnum, htaper);
+        for (int i = 0; i < snum; ++i) taps[(size_t)tnum + i] = impdar_taper_w(i, snum, vtaper);
+        IMPDAR_HIP_CHECK(pl.d_taper.ensure(taps.size() * 8));
+        IMPDAR_HIP_CHECK(hipMemcpyAsync(pl.d_taper.p, taps.data(), taps.size() * 8, hipMemcpyHostToDevice, st));
+        pl.taper_h = htaper;
+        pl.taper_v = vtaper;
+    }
+    int rc;
+    if (use_rows) {
+        const int hs = tnum / 2 + 1;
+        const double *th = do_taper ? pl.d_taper.as<double>() : nullptr, *tv = do_taper ? th + tnum : nullptr;
+        if ((rc = own_fft_launch<T>(OWN_R2C, tnum, (size_t)snum, d_data, pl.F.p, (size_t)tnum, (size_t)hs, 1.0, pl.tw_trace, st, th, tv, 1))) return rc;
+        own_launch_transpose<T>(pl.F.p, pl.K.p, snum, hs, st);
+        if ((rc = own_fft_launch<T>(OWN_C2C_FWD, snum, (size_t)hs, pl.K.p, pl.K.p, (size_t)snum, (size_t)snum, 1.0, pl.tw_time, st))) return rc;
+        hipLaunchKernelGGL((stolt_stretch_rows<T>), dim3((nz + 1 + 255) / 256, hs), dim3(256), 0, st, pl.K.as<Cx<T>>(), pl.F.as<Cx<T>>(),
+                           pl.d_kx.as<double>(), pl.d_ws.as<double>(), m, nz, snum, vel);
+        if ((rc = own_fft_launch<T>(OWN_C2C_INV, snum, (size_t)hs, pl.F.p, pl.F.p, (size_t)snum, (size_t)snum, 1.0 / snum, pl.tw_time, st))) return rc;
+        own_launch_transpose<T>(pl.F.p, pl.K.p, hs, snum, st);
+        if ((rc = own_fft_launch<T>(OWN_C2R, tnum, (size_t)snum, pl.K.p, d_out, (size_t)hs, (size_t)tnum, 1.0 / tnum, pl.tw_trace, st))) return rc;
+        IMPDAR_HIP_CHECK(hipGetLastError());
+        impdar_trace("stolt: all kernels enqueued (traces first)");
+        ctx->m_entry = "impdar_stolt";
+        ctx->m_kernel = "stolt_stretch_rows (+ the library's own row transforms, traces first)";
+        ctx->m_kernel_ms = -1.f;
+        ctx->ktimed = false;
+        ctx->m_extra[0] = 0;
+        return impdar_ctx_toc(ctx);
+    }
     dim3 tgrid((tnum + 63) / 64, (snum + 63) / 64);
     hipLaunchKernelGGL((stolt_taper_transpose<T>), tgrid, dim3(256), 0, st, (const T *)d_data, pl.X.as<T>(), snum, tnum,
                        htaper, vtaper, do_taper);
-    int rc;
     if (use_own) {
         // the four 1-D passes of the "1d" form on the library's own row kernels: real-to-complex over time (rows of X), over
         // the traces on contiguous rows of the transposed spectrum (K is free until the stretch writes it)

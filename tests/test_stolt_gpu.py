@@ -69,6 +69,37 @@ def test_vs_oracle_sizes(hip, snum, tnum, dtype):
         assert rel_max(d.data, want) < F64_TOL
 
 
+@pytest.mark.parametrize('snum,tnum,dtype', [(256, 64, np.float64), (128, 512, np.float64), (1024, 256, np.float32), (64, 2048, np.float32),
+                                             (512, 128, np.int16)])
+def test_traces_first_on_power_of_two_sizes(hip, snum, tnum, dtype):
+    """Power-of-two sizes (64 traces or more) run the transform over the TRACES first, on the radargram's own rows with the taper
+    applied on load, keep the wavenumbers k >= 0 with all frequencies and stretch along contiguous rows -- both signs of the
+    frequency, the negative half through the mirrored knots of the same row (stolt_stretch_rows; rfft2 / irfft2 at
+    mig_python.py:159, 202 keep the frequencies w >= 0 of all wavenumbers instead).  Against the oracle at the stated bars, records
+    longer and shorter than they are wide, and int16 data (tapered on the host: the kernel gets no weights)."""
+    import ctypes as C
+    import json
+    from impdar_amd import _hip, synth
+    from impdar_amd.lib.RadarData import RadarData
+    from oracle import mig_oracle
+    geo = synth.geometry(snum, tnum)
+    data = synth.noise_radargram(snum, tnum, seed=snum + tnum)
+    data = (data * 3000).astype(dtype) if dtype == np.int16 else data.astype(dtype)
+    want = mig_oracle.stolt(data, geo['dt'], geo['trace_int'], geo['dist'], 1.68e8, 7, 11)
+    d = RadarData(None)
+    d.data, d.snum, d.tnum = data.copy(), snum, tnum
+    d.travel_time, d.dist, d.trace_int, d.dt = geo['travel_time'], geo['dist'], geo['trace_int'], geo['dt']
+    d.migrate('stolt', htaper=7, vtaper=11)
+    buf = C.create_string_buffer(1024)
+    _hip.check(_hip.load().impdar_ctx_last_metrics(_hip.context(), buf, len(buf)), 'metrics')
+    assert 'stolt_stretch_rows' in json.loads(buf.value.decode())['kernel'], buf.value
+    assert d.data.dtype == want.dtype
+    if dtype == np.float32:
+        assert rel_l2(d.data, want) < F32_L2
+    else:
+        assert rel_max(d.data, want) < F64_TOL
+
+
 def test_config2_size_vs_oracle(hip):
     """BASELINE config 2 (4096 x 4096 float32) against the NumPy oracle on the same input."""
     from impdar_amd import synth
