@@ -366,7 +366,7 @@ def valu_roofline(kind, kernel, kms, n, flop, no_pmc):
     nf, nk = n // 2, n
     esz = 16 if kind.endswith('_f64') else 8
     floor_ms = (esz * nf * nk + esz * n * nk) / (HBM_PEAK_GBS * 1e9) * 1e3       # spectrum read once + TK written once
-    r = {"bound": "valu issue", "unit": "share of vector issue slots busy", "peak": 1.0, "achieved": None, "frac": None,
+    r = {"bound": "valu issue", "unit": VALU_UNIT, "peak": 1.0, "achieved": None, "frac": None,
          "hbm_floor_ms": floor_ms, "kernel_ms_over_hbm_floor": kms / floor_ms,
          "x_direct_sum": {"TFLOPs_equivalent": flop / (kms * 1e-3) / 1e12, "x_fp32_vector_peak": flop / (kms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TF}}
     if not no_pmc:
@@ -805,10 +805,11 @@ def first_call_records():
 
 # keys whose values are prose: explained once in profiles/bench_record_keys.md, not printed with every run (the driver keeps the
 # last 8 KB of stdout: round 5's 14.7 KB line lost config 2, the one-shot calls and the first calls)
+VALU_UNIT = "share of vector issue slots busy"
 PROSE_KEYS = ('note', 'traffic_source', 'parity_vs', 'source', 'what', 'method')
 SUBRECORD_DROPS = ('workload', 'parity_wavenumbers', 'steps_executed', 'rotate_accumulate_steps', 'algorithmic_flop', 'kernel_cache', 'import_ms',
                    'kind', 'finite', 'fused_floor_bytes', 'algorithmic_bytes', 'fetch_bytes_if_all_16B_per_lane', 'fetch_raw_over_write',
-                   'valu_instructions', 'kernel_cycles', 'parity_cols')
+                   'valu_instructions', 'kernel_cycles', 'parity_cols', 'kernel_ms_over_hbm_floor', 'x_fp32_vector_peak')
 
 
 SUBRECORD_DROPS_EXTRA = []
@@ -822,6 +823,8 @@ def compact_record(o, depth=0):
             if k in PROSE_KEYS:
                 continue
             if (depth > 1 and k in SUBRECORD_DROPS) or (depth > 0 and k in SUBRECORD_DROPS_EXTRA):     # sub-records: constants of the workload (profiles/bench_record_keys.md)
+                continue
+            if depth > 1 and k == 'unit' and v == VALU_UNIT:          # (the unit of every "valu issue" roofline: profiles/bench_record_keys.md)
                 continue
             if k == 'sample' and isinstance(v, str) and len(v) > (90 if depth < 2 else 44):
                 v = v[:(87 if depth < 2 else 41)] + '...'
