@@ -21,14 +21,17 @@
 // float64 direct sum on config-5 geometries before any of this was written) -- the matrix-core paths, with their float16
 // hi/lo operands, are at 1.1e-6.
 //
-// Work split: one workgroup of 1024 threads per wavenumber; a thread owns 4 frequencies with their phase in a float64
-// register and walks the pieces in depth order -- runs cut to <= 4096 steps (G <= 8192 grid points: the coefficients and the
-// spreading cost per PIECE, frequencies x 8 window values, the FFT per grid point: long pieces are the cheap ones; LDS by the
-// call's longest piece, <= 126 KB).  The few single steps a layer boundary is smeared over are summed directly (a sincos per
-// frequency and step, block reduction in a fixed order): a tenth of a piece each, which is what hands tables of more than
-// ~10 layers to ps_runs_kernel.  Frequencies on the evanescent boundary of some run take no part and are listed for
-// ps_edge_kernel, as in ps_mfma.h / ps_runs.h; for a constant velocity the reference's own test decides them (:411-412).
-// Measured (profiles/r05_ps_nufft.txt): config 5 at 8192^2 3.7 ms (ps_mfma_kernel 9.1), constant velocity 1.6 ms (5.3).
+// Work split: one workgroup of 1024 threads per wavenumber -- per PAIR of wavenumbers (k, tnum - k) when the whole antisymmetric axis
+// is summed and the sums go on into the inverse transform (template parameter PAIR, below: every migrate call on one GPU); a thread
+// owns 4 frequencies with their phase in a float64 register and walks the pieces in depth order -- runs cut to <= 4096 steps (G <= 8192
+// grid points: the coefficients and the spreading cost per PIECE, frequencies x 8 window values, the FFT per grid point: long
+// pieces are the cheap ones; LDS by the call's longest piece, <= 126 KB, 159 KB for a pair).  The few single steps a layer boundary
+// is smeared over are summed directly (a sincos per frequency and step, block reduction in a fixed order): a seventh of a piece
+// each.  Which tables come here and which go to ps_runs_kernel: an estimate of both (ps_run, phaseshift.hip).  Frequencies on the
+// evanescent boundary of some run take no part and are listed for ps_edge_kernel, as in ps_mfma.h / ps_runs.h; for a constant
+// velocity the reference's own test decides them (:411-412).
+// Measured at 8192^2: round 5 (profiles/r05_ps_nufft.txt) config 5 3.7 ms (ps_mfma_kernel 9.1), constant velocity 1.6 ms (5.3);
+// round 6 with pairs (profiles/r06_transforms.txt) 1.64 and 0.90 ms; float64 data 6.7 and 4.0 ms.
 #pragma once
 
 constexpr int PN_NFMAX = 4096;              // frequencies per wavenumber this kernel takes (one workgroup holds them all)
