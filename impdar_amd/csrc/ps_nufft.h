@@ -413,8 +413,11 @@ __global__ __launch_bounds__(PnCfg<T>::NTH, PnCfg<T>::OCC) void ps_nufft_kernel(
                     float hx = 0.f, hy = 0.f, b2x = 0.f, b2y = 0.f;
                     const float uhi = mm + 0.5f * PN_W, ulo = fmaxf(mm - 0.5f * PN_W, 0.f);
                     if (uhi > 0.f) {
-                        int ilo = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * ulo, ulo, c2)) * inv_dw) - 3;
-                        int ihi = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * uhi, uhi, c2)) * inv_dw) + 2;
+                        // (w(u) / dw = i + 1: the frequencies with ulo <= u_i <= uhi are i = (int)(w(ulo)/dw) - 1 ... (int)(w(uhi)/dw) - 1 at the
+                        // widest; one more on either side for the float32 estimate's rounding (1e-7 of up to 4096).  The one-row kernel below
+                        // keeps round 5's two and three: every index beyond the support costs a window value and adds e^{-beta})
+                        int ilo = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * ulo, ulo, c2)) * inv_dw) - 2;
+                        int ihi = (int)(__builtin_amdgcn_sqrtf(fmaf(a2 * uhi, uhi, c2)) * inv_dw);
                         ilo = max(ilo, i0);
                         ihi = min(ihi, i1);
                         for (int i = ilo - i0; i <= ihi - i0; ++i) {
