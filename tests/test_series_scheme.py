@@ -65,3 +65,34 @@ def test_series_through_the_window_and_fft(lib, dbl):
         got = S.series_sum(pieces, F, w, v, kx[k], dt, kxh_max, np.float64 if dbl else np.float32)
         err = np.abs(got - want).max() / np.abs(want).max()
         assert err < (5e-12 if dbl else 3e-6), err
+
+
+def test_a_pair_of_wavenumbers_shares_the_series_because_its_coefficients_alternate_between_real_and_imaginary():
+    """ps_series_kernel<float, true> (round 6): rows k and tnum - k as G = (TK[k] + conj TK[tnum - k]) / 2.  The series' coefficients
+    y_p(n) of exp(i sum_m r_m z^(2m-1)) are real for even p and imaginary for odd p (the exponent is imaginary and odd in z), so
+    conj(sum_p y_p z^p S_p) = sum_p y_p (-z)^p conj(S_p): the partner's coefficients enter grid p mirrored (node -phi) with (-z)^p and the
+    SAME y_p multiply the J transforms of the pair."""
+    rng = np.random.default_rng(11)
+    L, J, mj, nw = 40, 12, 6, 25
+    r = 0.3 * rng.standard_normal((L, mj))                        # (L, mj): coefficient of z^(2m-1) at step n, real
+    y = np.zeros((J, L), dtype=complex)
+    y[0] = 1
+    for p in range(1, J):
+        acc = 0
+        for m in range(mj):
+            k = 2 * m + 1
+            if k <= p:
+                acc = acc + k * 1j * r[:, m] * y[p - k]
+        y[p] = acc / p
+    assert np.abs(y[0::2].imag).max() == 0.0 and np.abs(y[1::2].real).max() == 0.0
+    phi = rng.uniform(0.1, 3.0, nw)
+    z = rng.uniform(0.2, 1.0, nw)
+    a = rng.standard_normal(nw) + 1j * rng.standard_normal(nw)     # row k
+    b = rng.standard_normal(nw) + 1j * rng.standard_normal(nw)     # row tnum - k
+    n1 = np.arange(1, L + 1)
+    Ep = np.exp(1j * np.outer(n1, phi))
+    row_k = sum(y[p] * (Ep @ (a * z ** p)) for p in range(J))
+    row_m = sum(y[p] * (Ep @ (b * z ** p)) for p in range(J))
+    want = 0.5 * (row_k + np.conj(row_m))
+    got = 0.5 * sum(y[p] * (Ep @ (a * z ** p) + np.conj(Ep) @ (np.conj(b) * (-z) ** p)) for p in range(J))
+    assert np.max(np.abs(got - want)) < 1e-12 * np.max(np.abs(want))
